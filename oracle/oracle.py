@@ -1,0 +1,268 @@
+"""ctypes binding of the CPU oracle (oracle/adder_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product path never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libadder_oracle.so")
+
+FRAME_PERFECT, CONTINUOUS = 0, 1
+NORMAL, COLLAPSE = 0, 1
+DELTA_T, ABSOLUTE_T, MIXED = 0, 1, 2
+CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE = 0, 1, 2
+SEED = 0xADDE5EED
+
+# same 12-byte host-order record as include/adder_hip.h::AdderEvent
+EVENT_DTYPE = np.dtype(
+    [("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("d", "u1"), ("pad", "<u2"), ("t", "<u4")]
+)
+assert EVENT_DTYPE.itemsize == 12
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "adder_oracle.c")
+    if (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libadder_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    vp, u8, u16, u32, f32, i32, sz = (
+        C.c_void_p, C.c_uint8, C.c_uint16, C.c_uint32, C.c_float, C.c_int, C.c_size_t,
+    )
+    L.oracle_px_new.restype = vp
+    L.oracle_px_new.argtypes = [f32, u16, u16, u8]
+    L.oracle_px_free.argtypes = [vp]
+    L.oracle_px_time_mode.argtypes = [vp, i32]
+    L.oracle_px_integrate.argtypes = [vp, f32, f32, i32, u32, u32, u8, u8, i32]
+    L.oracle_px_pop_best_events.restype = sz
+    L.oracle_px_pop_best_events.argtypes = [vp, i32, i32, u32, f32]
+    L.oracle_px_pop_top_event.argtypes = [vp, f32, i32, u32]
+    L.oracle_px_set_d_for_continuous.restype = i32
+    L.oracle_px_set_d_for_continuous.argtypes = [vp, f32, u32]
+    L.oracle_px_step.restype = i32
+    L.oracle_px_step.argtypes = [vp, u8, f32, f32, i32, i32, u32, u32, u8, u8]
+    L.oracle_px_num_events.restype = sz
+    L.oracle_px_num_events.argtypes = [vp]
+    L.oracle_px_events.restype = vp
+    L.oracle_px_events.argtypes = [vp]
+    L.oracle_px_clear_events.argtypes = [vp]
+    L.oracle_px_length.restype = sz
+    L.oracle_px_length.argtypes = [vp]
+    L.oracle_px_need_to_pop_top.restype = i32
+    L.oracle_px_need_to_pop_top.argtypes = [vp]
+    L.oracle_px_popped_dtm.restype = i32
+    L.oracle_px_popped_dtm.argtypes = [vp]
+    L.oracle_px_c_thresh.restype = u8
+    L.oracle_px_c_thresh.argtypes = [vp]
+    L.oracle_px_set_c_thresh.argtypes = [vp, u8, u8]
+    L.oracle_px_node.argtypes = [vp, sz, C.POINTER(f32)]
+
+    L.oracle_video_new.restype = vp
+    L.oracle_video_new.argtypes = [u16, u16, u8, u32, i32, i32, u32, u32, u32, i32]
+    L.oracle_video_free.argtypes = [vp]
+    L.oracle_video_set_crf_parameters.argtypes = [vp, u8, u8]
+    L.oracle_video_reset_c_thresh.argtypes = [vp, u8]
+    L.oracle_video_set_delta_t_max.argtypes = [vp, u32]
+    L.oracle_video_set_time_mode.argtypes = [vp, i32]
+    L.oracle_video_set_threads.argtypes = [vp, i32]
+    L.oracle_video_running_intensities.restype = vp
+    L.oracle_video_running_intensities.argtypes = [vp]
+    L.oracle_video_integrate_matrix.restype = sz
+    L.oracle_video_integrate_matrix.argtypes = [vp, vp, sz, f32, vp, sz, C.POINTER(sz), vp]
+
+    L.oracle_raw_header.restype = sz
+    L.oracle_raw_header.argtypes = [vp, u8, u16, u16, u8, u32, u32, u32, u32, u32, u32]
+    L.oracle_raw_events.restype = sz
+    L.oracle_raw_events.argtypes = [vp, vp, sz, u8]
+    L.oracle_raw_eof.restype = sz
+    L.oracle_raw_eof.argtypes = [vp]
+
+    L.oracle_synth_clip.argtypes = [vp, i32, C.c_uint64, u32, u32, u32, u32, u32, u32, u32]
+    L.oracle_max_threads.restype = i32
+    _lib = L
+    return L
+
+
+class Pixel:
+    """One PixelArena (event_pixel_tree.rs:53-87) for the unit-test known answers."""
+
+    def __init__(self, start_intensity, x=0, y=0, c=0xFF):
+        self.L = lib()
+        self.h = self.L.oracle_px_new(start_intensity, x, y, c)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_px_free(self.h)
+            self.h = None
+
+    def time_mode(self, tm):
+        self.L.oracle_px_time_mode(self.h, tm)
+
+    def integrate(self, intensity, time, mode, dtm, ref_time, c_max, velocity, multi_mode):
+        self.L.oracle_px_integrate(self.h, intensity, time, mode, dtm, ref_time, c_max, velocity, multi_mode)
+
+    def pop_best_events(self, mode, multi_mode, ref_time, intensity):
+        n0 = self.L.oracle_px_num_events(self.h)
+        n = self.L.oracle_px_pop_best_events(self.h, mode, multi_mode, ref_time, intensity)
+        return self.events()[n0 : n0 + n]
+
+    def pop_top_event(self, next_intensity, mode, ref_time):
+        self.L.oracle_px_pop_top_event(self.h, next_intensity, mode, ref_time)
+        return self.events()[-1]
+
+    def set_d_for_continuous(self, next_intensity, ref_time):
+        if self.L.oracle_px_set_d_for_continuous(self.h, next_intensity, ref_time):
+            return self.events()[-1]
+        return None
+
+    def step(self, frame_val, time_spanned, mode, multi_mode, dtm, ref_time, c_max, velocity):
+        return self.L.oracle_px_step(
+            self.h, frame_val, float(frame_val), time_spanned, mode, multi_mode, dtm, ref_time, c_max, velocity
+        )
+
+    def set_c_thresh(self, c, counter):
+        self.L.oracle_px_set_c_thresh(self.h, c, counter)
+
+    def events(self):
+        n = self.L.oracle_px_num_events(self.h)
+        if n == 0:
+            return np.zeros(0, EVENT_DTYPE)
+        p = self.L.oracle_px_events(self.h)
+        buf = (C.c_uint8 * (n * 12)).from_address(p)
+        return np.frombuffer(buf, dtype=EVENT_DTYPE).copy()
+
+    @property
+    def length(self):
+        return self.L.oracle_px_length(self.h)
+
+    @property
+    def need_to_pop_top(self):
+        return bool(self.L.oracle_px_need_to_pop_top(self.h))
+
+    def node(self, idx):
+        out = (C.c_float * 7)()
+        self.L.oracle_px_node(self.h, idx, out)
+        return dict(
+            d=int(out[0]), integration=np.float32(out[1]), delta_t=np.float32(out[2]),
+            has_best=bool(out[3]), best_d=int(out[4]), best_delta_t=np.float32(out[5]), alt=bool(out[6]),
+        )
+
+
+class Video:
+    """Video<W> driver state + integrate_matrix (video.rs:350-438, 651-778)."""
+
+    def __init__(self, width, height, channels=1, *, row_begin=0, time_mode=ABSOLUTE_T,
+                 multi_mode=COLLAPSE, ref_time=255, delta_t_max=7650, chunk_rows=1, threads=1):
+        self.L = lib()
+        self.width, self.height, self.channels = width, height, channels
+        self.chunk_rows = chunk_rows
+        self.num_chunks = (height + chunk_rows - 1) // chunk_rows
+        self.h = self.L.oracle_video_new(
+            width, height, channels, row_begin, time_mode, multi_mode, ref_time, delta_t_max, chunk_rows, threads
+        )
+        if not self.h:
+            raise ValueError("bad oracle video parameters")
+        self._cap = max(1024, width * height * channels * 2)
+        self._out = np.zeros(self._cap, EVENT_DTYPE)
+        self._chunks = np.zeros(self.num_chunks + 1, np.uint32)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_video_free(self.h)
+            self.h = None
+
+    def set_crf_parameters(self, c_thresh_max, c_increase_velocity):
+        self.L.oracle_video_set_crf_parameters(self.h, c_thresh_max, c_increase_velocity)
+
+    def reset_c_thresh(self, baseline):
+        self.L.oracle_video_reset_c_thresh(self.h, baseline)
+
+    def set_delta_t_max(self, dtm):
+        self.L.oracle_video_set_delta_t_max(self.h, dtm)
+
+    def set_time_mode(self, tm):
+        self.L.oracle_video_set_time_mode(self.h, tm)
+
+    def set_threads(self, n):
+        self.L.oracle_video_set_threads(self.h, n)
+
+    def running_intensities(self):
+        p = self.L.oracle_video_running_intensities(self.h)
+        n = self.width * self.height * self.channels
+        buf = (C.c_uint8 * n).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, self.channels).copy()
+
+    def integrate_matrix(self, frame, time_spanned=None, ref_time=255, want_chunks=False):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(self.height, self.width * self.channels)
+        if time_spanned is None:
+            time_spanned = float(ref_time)
+        n = C.c_size_t(0)
+        while True:
+            r = self.L.oracle_video_integrate_matrix(
+                self.h, frame.ctypes.data, frame.strides[0], time_spanned,
+                self._out.ctypes.data, self._cap, C.byref(n), self._chunks.ctypes.data,
+            )
+            if r != C.c_size_t(-1).value:
+                break
+            raise RuntimeError("oracle event buffer too small (state already advanced)")
+        ev = self._out[: n.value].copy()
+        if want_chunks:
+            return ev, self._chunks.copy()
+        return ev
+
+    def ensure_capacity(self, events_per_unit):
+        cap = int(self.width * self.height * self.channels * events_per_unit) + 1024
+        if cap > self._cap:
+            self._cap = cap
+            self._out = np.zeros(cap, EVENT_DTYPE)
+
+
+def raw_header(codec_version, width, height, channels, tps, ref_interval, delta_t_max,
+               source_camera=0, time_mode=ABSOLUTE_T, adu_interval=0):
+    buf = np.zeros(64, np.uint8)
+    n = lib().oracle_raw_header(buf.ctypes.data, codec_version, width, height, channels, tps,
+                                ref_interval, delta_t_max, source_camera, time_mode, adu_interval)
+    return buf[:n].tobytes()
+
+
+def raw_events(events, channels):
+    events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+    buf = np.zeros(len(events) * 11 + 16, np.uint8)
+    n = lib().oracle_raw_events(buf.ctypes.data, events.ctypes.data, len(events), channels)
+    return buf[:n].tobytes()
+
+
+def raw_eof():
+    buf = np.zeros(16, np.uint8)
+    n = lib().oracle_raw_eof(buf.ctypes.data)
+    return buf[:n].tobytes()
+
+
+def synth_clip(content, W, H, C_, frames, *, y0=0, rows=None, k0=0, seed=SEED):
+    rows = H - y0 if rows is None else rows
+    out = np.zeros((frames, rows, W, C_), np.uint8)
+    lib().oracle_synth_clip(out.ctypes.data, content, seed, W, H, C_, y0, rows, k0, frames)
+    return out
+
+
+def max_threads():
+    return lib().oracle_max_threads()
