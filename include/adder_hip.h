@@ -1,0 +1,176 @@
+/*
+ * adder_hip.h -- C-ABI of the MI355X-native framed->ADDER integration path.
+ *
+ * This is the drop-in boundary for ONE region of the reference
+ * (ac-freeman/adder-codec-rs): the rayon per-pixel loop of
+ * Video::integrate_matrix, adder-codec-rs/src/transcoder/source/video.rs:677-734
+ * (per pixel: integrate_for_px, video.rs:1318-1380, which drives
+ * PixelArena::{integrate,pop_best_events,pop_top_event},
+ * adder-codec-rs/src/transcoder/event_pixel_tree.rs:139-413).  Everything a
+ * Rust `extern "C"` shim inside Video<W> would need is here: plain pointers and
+ * sizes, no C++ or torch types.  See INTEGRATION.md for the Rust-side binding.
+ *
+ * Threading: a context is NOT thread-safe (mirrors `consume(&mut self)`); use one
+ * context per device / row band; different contexts may be driven concurrently.
+ * No C++ exception or abort crosses this boundary: every entry point returns an
+ * int status (0 = ok, negative = AdderStatus) and adder_hip_last_error() gives
+ * the message.
+ */
+#ifndef ADDER_HIP_H
+#define ADDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADDER_HIP_ABI_VERSION 1
+
+/* adder-codec-core/src/lib.rs:72-83 (TimeMode), :196-213 (Mode, PixelMultiMode) */
+enum { ADDER_TIME_DELTA_T = 0, ADDER_TIME_ABSOLUTE_T = 1, ADDER_TIME_MIXED = 2 };
+enum { ADDER_MULTI_NORMAL = 0, ADDER_MULTI_COLLAPSE = 1 };
+enum { ADDER_MODE_FRAME_PERFECT = 0 }; /* framed sources always use FramePerfect: framed.rs:67 */
+
+/* adder-codec-core/src/lib.rs:181-193 */
+#define ADDER_D_MAX 127
+#define ADDER_D_ZERO_INTEGRATION 128
+#define ADDER_D_EMPTY 255
+#define ADDER_C_NONE 0xFF /* Coord::c == None (single-channel plane) */
+
+typedef enum AdderStatus {
+    ADDER_OK = 0,
+    ADDER_E_BAD_PARAMS = -1,   /* SourceError::BadParams analogue (video.rs:55-122) */
+    ADDER_E_HIP = -2,          /* a HIP runtime call failed */
+    ADDER_E_NO_DEVICE = -3,    /* no usable gfx950 device: there is NO CPU fallback */
+    ADDER_E_OUT_CAPACITY = -4, /* event buffer too small; *n_out holds the required count.
+                                  Pixel state HAS advanced: the context is poisoned. */
+    ADDER_E_ARENA_DEPTH = -5,  /* a pixel needed more stored nodes than max_depth; poisoned */
+    ADDER_E_TIMEOUT = -6,      /* in-kernel bounded wait expired (should never happen); poisoned */
+    ADDER_E_POISONED = -7      /* a previous call failed after state had advanced */
+} AdderStatus;
+
+/* One ADDER event in host byte order: lib.rs:371-377 `Event{coord{x,y,c},d,t}`.
+ * Serialisation to the 9/11-byte big-endian wire form (raw/stream.rs:101-120)
+ * is the sink's job (adder_raw_* below), not the kernel's. */
+typedef struct AdderEvent {
+    uint16_t x;
+    uint16_t y;
+    uint8_t c; /* ADDER_C_NONE for 1-channel planes */
+    uint8_t d;
+    uint16_t pad; /* always 0 */
+    uint32_t t;
+} AdderEvent;
+
+/* What Video::new (video.rs:350-438) + time_parameters (:493-537) + write_out
+ * (:546-636) + chunk_rows (:471-479) + update_crf/update_quality_manual
+ * (:1241-1287) establish before the first consume(). */
+typedef struct AdderHipParams {
+    uint32_t abi_version;  /* = ADDER_HIP_ABI_VERSION */
+    uint16_t width;        /* full plane width  (PlaneSize, lib.rs:86-118) */
+    uint16_t height;       /* full plane height */
+    uint8_t channels;      /* 1 (c = None) or 3 */
+    uint8_t time_mode;     /* ADDER_TIME_* ; pixels default to AbsoluteT (event_pixel_tree.rs:76) */
+    uint8_t multi_mode;    /* ADDER_MULTI_* ; write_out defaults to Collapse (video.rs:598) */
+    uint8_t pixel_mode;    /* ADDER_MODE_FRAME_PERFECT only */
+    uint32_t row_begin;    /* this context integrates rows [row_begin,row_end) of the plane */
+    uint32_t row_end;      /*   (0,0 => the whole plane); events carry absolute y          */
+    uint32_t ref_time;     /* ticks per input frame (VideoStateParams::ref_time)            */
+    uint32_t delta_t_max;  /* >= ref_time (video.rs:527-533)                               */
+    uint8_t c_thresh_max;         /* CrfParameters (rate_controller.rs:40-53); EncoderOptions */
+    uint8_t c_increase_velocity;  /*   ::default => quality 3 => (7, 7); must be >= 1         */
+    uint8_t c_thresh_start;       /* per-pixel c_thresh at construction: 10 (event_pixel_tree.rs:82) */
+    uint8_t c_counter_start;      /* per-pixel c_increase_counter at construction: 1 (:83)      */
+    uint32_t chunk_rows;   /* rows per output chunk (video.rs:230); 0 => 1                  */
+    uint32_t max_depth;    /* stored arena nodes per pixel, 1..31; 0 => 16                  */
+    int32_t device_id;     /* HIP device ordinal; -1 => current device                     */
+} AdderHipParams;
+
+typedef struct AdderHipCtx AdderHipCtx;
+
+/* Fills *p with the reference's construction defaults for a w x h x c plane
+ * (Video::new + VideoStateParams::default: Collapse, AbsoluteT, ref 255, dtm 7650,
+ * c_thresh 10 / counter 1, crf parameters of quality 3). */
+void adder_hip_default_params(AdderHipParams *p, uint16_t width, uint16_t height, uint8_t channels);
+
+int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out);
+void adder_hip_destroy(AdderHipCtx *ctx);
+const char *adder_hip_last_error(const AdderHipCtx *ctx); /* ctx may be NULL: last create() error */
+
+/* Encoder-side Crf replacement done by write_out (video.rs:629): c_thresh_max and
+ * c_increase_velocity change, per-pixel c_thresh does NOT. */
+int adder_hip_set_crf_parameters(AdderHipCtx *ctx, uint8_t c_thresh_max, uint8_t c_increase_velocity);
+/* Per-pixel reset performed by update_crf / update_quality_manual (video.rs:1247-1250,
+ * :1283-1286): every pixel's c_thresh = baseline, c_increase_counter = 0. */
+int adder_hip_reset_c_thresh(AdderHipCtx *ctx, uint8_t c_thresh_baseline);
+/* update_quality_manual's delta_t_max = multiplier * ref_time (video.rs:1280). */
+int adder_hip_set_delta_t_max(AdderHipCtx *ctx, uint32_t delta_t_max);
+/* time_parameters / write_out `px.time_mode(..)` (video.rs:499-503,632-634); only
+ * legal before the first frame has been integrated. */
+int adder_hip_set_time_mode(AdderHipCtx *ctx, uint8_t time_mode);
+
+/* Number of row chunks of this context's band: ceil(rows / chunk_rows) (video.rs:473-477). */
+uint32_t adder_hip_num_chunks(const AdderHipCtx *ctx);
+/* Upper bound on events one frame can emit for this context (units * (max_depth + 2)). */
+size_t adder_hip_max_events_per_frame(const AdderHipCtx *ctx);
+
+/* --- one frame: the region video.rs:677-734 -------------------------------------
+ * frame_hwc: host pointer to this band's rows, [rows][width][channels] u8 with
+ * row_stride_bytes between rows.  Events come back in the reference's order
+ * (y, x, c, per-pixel emission order); chunk_offsets (may be NULL) receives
+ * num_chunks+1 prefix offsets so the caller can rebuild Vec<Vec<Event>>. */
+int adder_hip_integrate(AdderHipCtx *ctx, const uint8_t *frame_hwc, size_t row_stride_bytes,
+                        float time_spanned, AdderEvent *out, size_t out_cap, size_t *n_out,
+                        uint32_t *chunk_offsets);
+
+/* --- T frames, host buffers: same stream, frame-major; frame_offsets gets T+1 entries. */
+int adder_hip_integrate_batch(AdderHipCtx *ctx, const uint8_t *frames_hwc, uint32_t num_frames,
+                              size_t frame_stride_bytes, size_t row_stride_bytes,
+                              float time_spanned, AdderEvent *out, size_t out_cap, size_t *n_out,
+                              uint64_t *frame_offsets);
+
+/* --- T frames resident in HBM (clip and event buffer are DEVICE pointers) -----------
+ * d_frames: packed [T][rows][width][channels] u8.  d_out: device AdderEvent[out_cap].
+ * d_frame_offsets: device uint64[T+1] (prefix offsets into d_out; [0] = 0).
+ * stream: hipStream_t (NULL = the context's own stream).  Asynchronous: call
+ * adder_hip_finish() (or synchronise the stream and call it) to collect status. */
+int adder_hip_integrate_device(AdderHipCtx *ctx, const uint8_t *d_frames, uint32_t num_frames,
+                               float time_spanned, AdderEvent *d_out, size_t out_cap,
+                               uint64_t *d_frame_offsets, void *stream);
+/* Waits for the work queued by adder_hip_integrate_device and reports its status;
+ * *n_out (may be NULL) = total events of the last device batch. */
+int adder_hip_finish(AdderHipCtx *ctx, size_t *n_out);
+
+/* Per-chunk offsets of one frame's events on the device (binary search on y);
+ * d_chunk_offsets: device uint32[num_chunks+1], relative to d_events. */
+int adder_hip_chunk_offsets_device(AdderHipCtx *ctx, const AdderEvent *d_events, size_t n_events,
+                                   uint32_t *d_chunk_offsets, void *stream);
+
+/* Optional side plane Video::running_intensities (video.rs:713-730): copies the
+ * band's [rows][width][channels] u8 plane to a host buffer. */
+int adder_hip_running_intensities(AdderHipCtx *ctx, uint8_t *dst_host);
+int adder_hip_enable_running_intensities(AdderHipCtx *ctx, int enable);
+
+/* Duration in milliseconds of the kernels of the last adder_hip_integrate_device
+ * batch, measured with HIP events on the launch stream (0 if none). */
+float adder_hip_last_batch_ms(AdderHipCtx *ctx);
+
+/* --- deterministic synthetic clips generated directly in HBM ------ */
+enum { ADDER_CONTENT_STATIC = 0, ADDER_CONTENT_NOISE = 1, ADDER_CONTENT_SCENE = 2 };
+int adder_hip_synth_clip_device(uint8_t *d_dst, int content, uint64_t seed, uint32_t width,
+                                uint32_t height, uint32_t channels, uint32_t row_begin,
+                                uint32_t rows, uint32_t frame_begin, uint32_t num_frames,
+                                void *stream);
+
+/* --- raw `.adder` sink (encoder.rs:170-229, raw/stream.rs:79-120), host side -------- */
+size_t adder_raw_header(uint8_t *dst, uint8_t codec_version, uint16_t width, uint16_t height,
+                        uint8_t channels, uint32_t tps, uint32_t ref_interval, uint32_t delta_t_max,
+                        uint32_t source_camera, uint32_t time_mode, uint32_t adu_interval);
+size_t adder_raw_events(uint8_t *dst, const AdderEvent *events, size_t n, uint8_t channels);
+size_t adder_raw_eof(uint8_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADDER_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes wrapper of tests/cpu_sim (g++ build of the device header) -- test helper."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SRC = os.path.join(_HERE, "cpu_sim", "sim.cpp")
+_HDR = os.path.join(_ROOT, "adder-codec-rs_amd", "csrc", "adder_pixel.hpp")
+_LIB = os.path.join(_HERE, "cpu_sim", "libadder_sim.so")
+
+EVENT_DTYPE = np.dtype(
+    [("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("d", "u1"), ("pad", "<u2"), ("t", "<u4")]
+)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_HDR))
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
+        subprocess.check_call([
+            "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra",
+            "-I", os.path.dirname(_HDR), _SRC, "-o", _LIB])
+    L = C.CDLL(_LIB)
+    vp, u8, u32, f32, i32, sz = C.c_void_p, C.c_uint8, C.c_uint32, C.c_float, C.c_int, C.c_size_t
+    L.sim_new.restype = vp
+    L.sim_new.argtypes = [u32, u32, u32, u32, i32, i32, u32, u32, u32]
+    L.sim_free.argtypes = [vp]
+    L.sim_set_crf_parameters.argtypes = [vp, u8, u8]
+    L.sim_reset_c_thresh.argtypes = [vp, u8]
+    L.sim_set_delta_t_max.argtypes = [vp, u32]
+    L.sim_plan_mismatches.restype = C.c_uint64
+    L.sim_plan_mismatches.argtypes = [vp]
+    L.sim_max_m.restype = u32
+    L.sim_max_m.argtypes = [vp]
+    L.sim_integrate.restype = i32
+    L.sim_integrate.argtypes = [vp, vp, f32, vp, sz, C.POINTER(sz)]
+    _lib = L
+    return L
+
+
+class Sim:
+    def __init__(self, width, height, channels=1, *, row_begin=0, time_mode=1, multi_mode=1,
+                 ref_time=255, delta_t_max=7650, max_depth=16):
+        self.L = lib()
+        self.n = width * height * channels
+        self.h = self.L.sim_new(width, height, channels, row_begin, time_mode, multi_mode, ref_time,
+                                delta_t_max, max_depth)
+        self._cap = self.n * (max_depth + 2)
+        self._out = np.zeros(self._cap, EVENT_DTYPE)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.sim_free(self.h)
+            self.h = None
+
+    def set_crf_parameters(self, c_max, velocity):
+        self.L.sim_set_crf_parameters(self.h, c_max, velocity)
+
+    def reset_c_thresh(self, baseline):
+        self.L.sim_reset_c_thresh(self.h, baseline)
+
+    def set_delta_t_max(self, dtm):
+        self.L.sim_set_delta_t_max(self.h, dtm)
+
+    @property
+    def plan_mismatches(self):
+        return self.L.sim_plan_mismatches(self.h)
+
+    @property
+    def max_m(self):
+        return self.L.sim_max_m(self.h)
+
+    def integrate(self, frame, time_spanned):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)
+        assert frame.size == self.n
+        n = C.c_size_t(0)
+        rc = self.L.sim_integrate(self.h, frame.ctypes.data, time_spanned, self._out.ctypes.data,
+                                  self._cap, C.byref(n))
+        return rc, self._out[: n.value].copy()

@@ -1,0 +1,116 @@
+"""The device header (adder_pixel.hpp), compiled for the host by tests/cpu_sim, must
+reproduce the oracle event-for-event in every mode -- this validates the compact
+[fired levels | tail] state representation and the count-then-emit split on CPU,
+before any GPU time is spent.  (The HIP path itself is tested in test_gpu_parity.py.)
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import clips
+from sim_py import Sim
+
+
+def run_pair(clip, *, time_mode, multi_mode, dtm, ref_time=255, crf=None, default_pixels=False,
+             time_spanned=None, max_depth=20):
+    frames, H, W, Cn = clip.shape
+    ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=ref_time, delta_t_max=dtm)
+    sv = Sim(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=ref_time, delta_t_max=dtm,
+             max_depth=max_depth)
+    ov.ensure_capacity(max_depth + 2)
+    if crf is not None:
+        base, cmax, vel = crf
+        ov.set_crf_parameters(cmax, vel)
+        sv.set_crf_parameters(cmax, vel)
+        if not default_pixels:
+            ov.reset_c_thresh(base)
+            sv.reset_c_thresh(base)
+    ts = float(ref_time) if time_spanned is None else time_spanned
+    total = 0
+    for k in range(frames):
+        a = ov.integrate_matrix(clip[k], time_spanned=ts)
+        rc, b = sv.integrate(clip[k], ts)
+        assert rc == 0, (k, rc)
+        assert len(a) == len(b), (k, len(a), len(b))
+        assert np.array_equal(a, b), k
+        total += len(a)
+    assert sv.plan_mismatches == 0
+    return total, sv.max_m
+
+
+CRFS = {0: (0, 0, 10), 3: (2, 7, 7), 6: (7, 13, 4), 9: (15, 25, 1)}
+
+
+@pytest.mark.parametrize("kind", ["noise", "static", "dark", "jitter", "runs", "steps"])
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_modes_crf0(kind, multi_mode, time_mode):
+    clip = clips.make_clip(kind, 70, 6, 9, 1, seed=zlib.crc32(f"{kind}-{multi_mode}-{time_mode}".encode()) & 0xFFFF)
+    for dtm in (255, 1020, 7650):
+        n, _ = run_pair(clip, time_mode=time_mode, multi_mode=multi_mode, dtm=dtm, crf=CRFS[0])
+        if kind not in ("static",):
+            assert n > 0
+
+
+@pytest.mark.parametrize("crf", [3, 6, 9])
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+def test_lossy_crf(crf, multi_mode):
+    for kind in ("jitter", "runs", "dark", "steps"):
+        clip = clips.make_clip(kind, 90, 5, 8, 1, seed=crf * 100 + multi_mode)
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            run_pair(clip, time_mode=tm, multi_mode=multi_mode, dtm=7650, crf=CRFS[crf])
+            run_pair(clip, time_mode=tm, multi_mode=multi_mode, dtm=255, crf=CRFS[crf])
+
+
+def test_construction_default_pixels():
+    # pixels keep c_thresh 10 / counter 1 when crf() was never called (SURVEY 8(a) note 6)
+    clip = clips.make_clip("jitter", 80, 6, 6, 1, seed=5)
+    for mm in (O.NORMAL, O.COLLAPSE):
+        run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=mm, dtm=7650, crf=(2, 7, 7), default_pixels=True)
+        run_pair(clip, time_mode=O.DELTA_T, multi_mode=mm, dtm=510, crf=None)
+
+
+def test_rgb_interleaved():
+    clip = clips.make_clip("runs", 60, 4, 5, 3, seed=11)
+    for mm in (O.NORMAL, O.COLLAPSE):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            run_pair(clip, time_mode=tm, multi_mode=mm, dtm=1020, crf=CRFS[0])
+
+
+@pytest.mark.parametrize("ref_time,dtm", [(5000, 240000), (1000, 2000), (20, 10000), (255, 6120)])
+def test_other_tick_rates(ref_time, dtm):
+    clip = clips.make_clip("runs", 80, 4, 6, 1, seed=ref_time)
+    for mm in (O.NORMAL, O.COLLAPSE):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            run_pair(clip, time_mode=tm, multi_mode=mm, dtm=dtm, ref_time=ref_time, crf=CRFS[0])
+            run_pair(clip, time_mode=tm, multi_mode=mm, dtm=dtm, ref_time=ref_time, crf=CRFS[3])
+
+
+def test_long_static_deep_arena():
+    clip = clips.make_clip("static", 600, 3, 4, 1, seed=2)
+    n, max_m = run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.NORMAL, dtm=255, crf=CRFS[0])
+    assert max_m >= 8  # the arena really does get deep in Normal mode
+    # a flush at the very end drains the deep arena
+    clip2 = clip.copy()
+    clip2[-1] = 255 - clip2[-1]
+    run_pair(clip2, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=255, crf=CRFS[0])
+    run_pair(clip2, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=CRFS[0])
+
+
+def test_lake_fixture(golden_dir):
+    frames = np.load(os.path.join(golden_dir, "lake_scaled_hd_frames_reconstructed.npz"))["frames"]
+    clip = frames[:, :, :, None]
+    n, _ = run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.NORMAL, dtm=6120, crf=CRFS[0])
+    assert n == 201_620
+
+
+def test_depth_overflow_is_reported():
+    clip = clips.make_clip("static", 200, 2, 2, 1, seed=3)
+    sv = Sim(2, 2, 1, time_mode=O.DELTA_T, multi_mode=O.NORMAL, delta_t_max=255, max_depth=3)
+    sv.set_crf_parameters(0, 10)
+    sv.reset_c_thresh(0)
+    rcs = [sv.integrate(clip[k], 255.0)[0] for k in range(200)]
+    assert -5 in rcs
