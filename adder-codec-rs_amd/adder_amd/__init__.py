@@ -1,0 +1,13 @@
+"""adder_amd -- Python plumbing over the MI355X framed->ADDER C-ABI (libadder_hip.so).
+
+The compute path is the HIP library; this package only moves pointers around
+(ctypes, torch device memory, torch.distributed) so that tests and bench.py can
+drive it.  The C++ mirror of the reference's Source/Video/Encoder surface lives in
+../host/.
+"""
+from ._native import (  # noqa: F401
+    AdderHipError, AdderHipParams, EVENT_DTYPE, LIB_PATH, load,
+    TIME_DELTA_T, TIME_ABSOLUTE_T, TIME_MIXED, MULTI_NORMAL, MULTI_COLLAPSE,
+    CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE, D_EMPTY, D_ZERO_INTEGRATION, D_MAX, C_NONE,
+)
+from .video import CRF, HipVideo, raw_header, raw_events, raw_eof, synth_clip_device  # noqa: F401

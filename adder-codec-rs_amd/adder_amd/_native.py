@@ -1,0 +1,111 @@
+"""ctypes loader of libadder_hip.so -- the C-ABI declared in include/adder_hip.h.
+
+The library is built in-tree by `make -C adder-codec-rs_amd` (or __graft_entry__.build()).
+There is no fallback of any kind: if the shared object is missing, or no gfx950 device
+is visible when a context is created, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "libadder_hip.so")
+
+ABI_VERSION = 1
+TIME_DELTA_T, TIME_ABSOLUTE_T, TIME_MIXED = 0, 1, 2
+MULTI_NORMAL, MULTI_COLLAPSE = 0, 1
+CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE = 0, 1, 2
+D_MAX, D_ZERO_INTEGRATION, D_EMPTY, C_NONE = 127, 128, 255, 0xFF
+
+OK = 0
+E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED = -1, -2, -3, -4, -5, -6, -7
+
+EVENT_DTYPE = np.dtype(
+    [("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("d", "u1"), ("pad", "<u2"), ("t", "<u4")]
+)
+assert EVENT_DTYPE.itemsize == 12
+
+
+class AdderHipParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("width", C.c_uint16),
+        ("height", C.c_uint16),
+        ("channels", C.c_uint8),
+        ("time_mode", C.c_uint8),
+        ("multi_mode", C.c_uint8),
+        ("pixel_mode", C.c_uint8),
+        ("row_begin", C.c_uint32),
+        ("row_end", C.c_uint32),
+        ("ref_time", C.c_uint32),
+        ("delta_t_max", C.c_uint32),
+        ("c_thresh_max", C.c_uint8),
+        ("c_increase_velocity", C.c_uint8),
+        ("c_thresh_start", C.c_uint8),
+        ("c_counter_start", C.c_uint8),
+        ("chunk_rows", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("device_id", C.c_int32),
+    ]
+
+
+# every symbol include/adder_hip.h declares: name -> (restype, argtypes)
+_vp, _u8, _u16, _u32, _u64, _f32, _i32, _sz = (
+    C.c_void_p, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_size_t)
+SYMBOLS = {
+    "adder_hip_default_params": (None, [C.POINTER(AdderHipParams), _u16, _u16, _u8]),
+    "adder_hip_create": (_i32, [C.POINTER(AdderHipParams), C.POINTER(_vp)]),
+    "adder_hip_destroy": (None, [_vp]),
+    "adder_hip_last_error": (C.c_char_p, [_vp]),
+    "adder_hip_set_crf_parameters": (_i32, [_vp, _u8, _u8]),
+    "adder_hip_reset_c_thresh": (_i32, [_vp, _u8]),
+    "adder_hip_set_delta_t_max": (_i32, [_vp, _u32]),
+    "adder_hip_set_time_mode": (_i32, [_vp, _u8]),
+    "adder_hip_num_chunks": (_u32, [_vp]),
+    "adder_hip_max_events_per_frame": (_sz, [_vp]),
+    "adder_hip_integrate": (_i32, [_vp, _vp, _sz, _f32, _vp, _sz, C.POINTER(_sz), _vp]),
+    "adder_hip_integrate_batch": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _vp, _sz, C.POINTER(_sz), _vp]),
+    "adder_hip_integrate_device": (_i32, [_vp, _vp, _u32, _f32, _vp, _sz, _vp, _vp]),
+    "adder_hip_finish": (_i32, [_vp, C.POINTER(_sz)]),
+    "adder_hip_chunk_offsets_device": (_i32, [_vp, _vp, _sz, _vp, _vp]),
+    "adder_hip_running_intensities": (_i32, [_vp, _vp]),
+    "adder_hip_enable_running_intensities": (_i32, [_vp, _i32]),
+    "adder_hip_last_batch_ms": (_f32, [_vp]),
+    "adder_hip_synth_clip_device": (_i32, [_vp, _i32, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),
+    "adder_raw_eof": (_sz, [_vp]),
+}
+
+_lib = None
+
+
+class AdderHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"adder_hip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Loads libadder_hip.so and binds every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: build it with `make -C adder-codec-rs_amd` "
+            "(hipcc, gfx950).  This path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc != OK:
+        msg = load().adder_hip_last_error(ctx)
+        raise AdderHipError(rc, msg.decode() if msg else "")

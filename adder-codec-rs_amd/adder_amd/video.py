@@ -1,0 +1,190 @@
+"""HipVideo: the `Video<W>` surface of the reference for the framed->ADDER path,
+bound to the C-ABI (include/adder_hip.h).
+
+Mirrors adder-codec-rs/src/transcoder/source/video.rs: construction (Video::new
+:350-438), time_parameters (:493-537), write_out's mode arguments (:546-636),
+chunk_rows (:471-479), update_crf / update_quality_manual (:1241-1287) and
+integrate_matrix (:651-778).  Every call goes through libadder_hip.so; nothing here
+computes events.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+# adder-codec-core/src/codec/rate_controller.rs:5-18 : baseline C, max C, C increase velocity
+CRF = [
+    (0, 0, 10), (0, 1, 9), (1, 3, 8), (2, 7, 7), (5, 9, 6),
+    (6, 10, 5), (7, 13, 4), (8, 16, 3), (10, 20, 2), (15, 25, 1),
+]
+DEFAULT_CRF_QUALITY = 3
+
+
+class HipVideo:
+    def __init__(self, width, height, channels=1, *, row_begin=0, row_end=None,
+                 time_mode=N.TIME_ABSOLUTE_T, multi_mode=N.MULTI_COLLAPSE, ref_time=255,
+                 delta_t_max=7650, chunk_rows=1, max_depth=16, device_id=-1):
+        self.L = N.load()
+        p = N.AdderHipParams()
+        self.L.adder_hip_default_params(C.byref(p), width, height, channels)
+        p.row_begin = row_begin
+        p.row_end = height if row_end is None else row_end
+        p.time_mode, p.multi_mode = time_mode, multi_mode
+        p.ref_time, p.delta_t_max = ref_time, delta_t_max
+        p.chunk_rows, p.max_depth, p.device_id = chunk_rows, max_depth, device_id
+        self.params = p
+        self.width, self.height, self.channels = width, height, channels
+        self.rows = p.row_end - p.row_begin
+        self.n_units = self.rows * width * channels
+        self.ref_time = ref_time
+        h = C.c_void_p()
+        rc = self.L.adder_hip_create(C.byref(p), C.byref(h))
+        if rc != N.OK:
+            msg = self.L.adder_hip_last_error(None)
+            raise N.AdderHipError(rc, msg.decode() if msg else "")
+        self.h = h
+        self.num_chunks = self.L.adder_hip_num_chunks(self.h)
+        self.max_events_per_frame = self.L.adder_hip_max_events_per_frame(self.h)
+        self._out = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.adder_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- quality controls -------------------------------------------------------------
+    def set_crf_parameters(self, c_thresh_max, c_increase_velocity):
+        N.check(self.h, self.L.adder_hip_set_crf_parameters(self.h, c_thresh_max, c_increase_velocity))
+
+    def reset_c_thresh(self, baseline):
+        N.check(self.h, self.L.adder_hip_reset_c_thresh(self.h, baseline))
+
+    def update_crf(self, crf):
+        """Video::update_crf (video.rs:1241-1251)."""
+        base, cmax, vel = CRF[crf]
+        self.set_crf_parameters(cmax, vel)
+        self.reset_c_thresh(base)
+
+    def update_quality_manual(self, c_thresh_baseline, c_thresh_max, delta_t_max_multiplier, c_increase_velocity):
+        """Video::update_quality_manual (video.rs:1264-1287)."""
+        self.set_crf_parameters(c_thresh_max, c_increase_velocity)
+        N.check(self.h, self.L.adder_hip_set_delta_t_max(self.h, delta_t_max_multiplier * self.ref_time))
+        self.reset_c_thresh(c_thresh_baseline)
+
+    def set_delta_t_max(self, dtm):
+        N.check(self.h, self.L.adder_hip_set_delta_t_max(self.h, dtm))
+
+    def set_time_mode(self, tm):
+        N.check(self.h, self.L.adder_hip_set_time_mode(self.h, tm))
+
+    def enable_running_intensities(self, on=True):
+        N.check(self.h, self.L.adder_hip_enable_running_intensities(self.h, int(on)))
+
+    def running_intensities(self):
+        out = np.zeros(self.n_units, np.uint8)
+        N.check(self.h, self.L.adder_hip_running_intensities(self.h, out.ctypes.data))
+        return out.reshape(self.rows, self.width, self.channels)
+
+    # ---- host-buffer entry points --------------------------------------------------------
+    def _host_out(self, cap):
+        if self._out is None or len(self._out) < cap:
+            self._out = np.zeros(cap, N.EVENT_DTYPE)
+        return self._out
+
+    def integrate_matrix(self, frame, time_spanned=None, want_chunks=False, out_cap=None):
+        """One frame in, events out in the reference's order (video.rs:651-740)."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(self.rows, self.width * self.channels)
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        cap = self.max_events_per_frame if out_cap is None else out_cap
+        out = self._host_out(cap)
+        n = C.c_size_t(0)
+        chunks = np.zeros(self.num_chunks + 1, np.uint32)
+        rc = self.L.adder_hip_integrate(self.h, frame.ctypes.data, frame.strides[0], ts, out.ctypes.data, cap,
+                                        C.byref(n), chunks.ctypes.data)
+        self.last_required = n.value
+        N.check(self.h, rc)
+        ev = out[: n.value].copy()
+        return (ev, chunks) if want_chunks else ev
+
+    def integrate_batch(self, frames, time_spanned=None, out_cap=None):
+        """T frames (host array [T, rows, W, C]) -> (events, frame_offsets[T+1])."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), self.n_units)
+        T = frames.shape[0]
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        cap = min(self.max_events_per_frame, 4 * self.n_units) * T if out_cap is None else out_cap
+        out = self._host_out(cap)
+        n = C.c_size_t(0)
+        offs = np.zeros(T + 1, np.uint64)
+        rc = self.L.adder_hip_integrate_batch(self.h, frames.ctypes.data, T, self.n_units,
+                                              self.width * self.channels, ts, out.ctypes.data, cap,
+                                              C.byref(n), offs.ctypes.data)
+        self.last_required = n.value
+        N.check(self.h, rc)
+        return out[: n.value].copy(), offs
+
+    # ---- device-resident entry points (torch tensors provide the HBM buffers) ------------------
+    def integrate_device(self, d_frames, d_events, d_offsets, time_spanned=None, stream=None):
+        """Queues T frames resident in HBM.  d_frames: uint8 CUDA tensor [T, n_units];
+        d_events: uint8 CUDA tensor of 12*cap bytes; d_offsets: int64 CUDA tensor [T+1]."""
+        T = d_frames.shape[0]
+        assert d_frames.is_contiguous() and d_frames.numel() == T * self.n_units
+        assert d_offsets.numel() >= T + 1 and d_offsets.element_size() == 8
+        cap = d_events.numel() * d_events.element_size() // 12
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        N.check(self.h, self.L.adder_hip_integrate_device(
+            self.h, d_frames.data_ptr(), T, ts, d_events.data_ptr(), cap, d_offsets.data_ptr(),
+            C.c_void_p(stream) if stream else None))
+
+    def finish(self):
+        n = C.c_size_t(0)
+        rc = self.L.adder_hip_finish(self.h, C.byref(n))
+        self.last_required = n.value
+        N.check(self.h, rc)
+        return n.value
+
+    def last_batch_ms(self):
+        return float(self.L.adder_hip_last_batch_ms(self.h))
+
+    def chunk_offsets_device(self, d_events_ptr, n_events, d_chunk_offsets, stream=None):
+        N.check(self.h, self.L.adder_hip_chunk_offsets_device(
+            self.h, d_events_ptr, n_events, d_chunk_offsets.data_ptr(), C.c_void_p(stream) if stream else None))
+
+
+def synth_clip_device(d_dst, content, width, height, channels, *, row_begin=0, rows=None, frame_begin=0,
+                      num_frames=1, seed=0xADDE5EED, stream=None):
+    """Fills a uint8 CUDA tensor [num_frames, rows, width, channels] with SURVEY 8(d) content."""
+    rows = height - row_begin if rows is None else rows
+    assert d_dst.numel() == num_frames * rows * width * channels
+    rc = N.load().adder_hip_synth_clip_device(d_dst.data_ptr(), content, seed, width, height, channels,
+                                              row_begin, rows, frame_begin, num_frames,
+                                              C.c_void_p(stream) if stream else None)
+    N.check(None, rc)
+
+
+# ---- raw `.adder` sink through the C-ABI ------------------------------------------------------
+def raw_header(codec_version, width, height, channels, tps, ref_interval, delta_t_max,
+               source_camera=0, time_mode=N.TIME_ABSOLUTE_T, adu_interval=0):
+    buf = np.zeros(64, np.uint8)
+    n = N.load().adder_raw_header(buf.ctypes.data, codec_version, width, height, channels, tps,
+                                  ref_interval, delta_t_max, source_camera, time_mode, adu_interval)
+    return buf[:n].tobytes()
+
+
+def raw_events(events, channels):
+    events = np.ascontiguousarray(events, dtype=N.EVENT_DTYPE)
+    buf = np.zeros(len(events) * 11 + 16, np.uint8)
+    n = N.load().adder_raw_events(buf.ctypes.data, events.ctypes.data, len(events), channels)
+    return buf[:n].tobytes()
+
+
+def raw_eof():
+    buf = np.zeros(16, np.uint8)
+    n = N.load().adder_raw_eof(buf.ctypes.data)
+    return buf[:n].tobytes()

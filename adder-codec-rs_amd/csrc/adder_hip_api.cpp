@@ -1,0 +1,551 @@
+// adder_hip_api.cpp -- C-ABI of the MI355X framed->ADDER integration path (include/adder_hip.h).
+//
+// Owns what Video<W> owns for this path in the reference (video.rs:322-346): the pixel
+// state (here: structure-of-arrays planes in HBM) and the step parameters; the caller
+// owns frames and event buffers.  There is NO CPU fallback: without a gfx950 device
+// adder_hip_create fails with ADDER_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adder_hip.h"
+#include "adder_kernels.h"
+
+using namespace adder;
+
+static_assert(sizeof(AdderEvent) == 12, "AdderEvent must be 12 bytes");
+static_assert(sizeof(AdderEventPod) == sizeof(AdderEvent), "layout mismatch");
+
+static thread_local std::string g_create_error;
+
+struct AdderHipCtx {
+    AdderHipParams p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t rows = 0, n_units = 0, num_tiles = 0, num_chunks = 0, grid = 0, num_cus = 0;
+    size_t n_pad = 0;
+    uint32_t max_depth = 0;
+    // state planes
+    uint32_t *hdr = nullptr;
+    float *tinteg = nullptr, *tdt = nullptr, *lastf = nullptr;
+    uint8_t *td = nullptr;
+    float *lv_integ = nullptr, *lv_dt = nullptr, *lv_bdt = nullptr;
+    uint16_t *lv_dbd = nullptr;
+    uint8_t *running = nullptr;
+    bool running_enabled = false;
+    // compaction scratch
+    uint64_t *desc[2] = {nullptr, nullptr};
+    uint32_t *status = nullptr;   // device status word
+    uint32_t *census = nullptr;   // device census counter
+    uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
+    size_t d_offsets_cap = 0;       // all *_cap below are in BYTES
+    // staging for the host-buffer API
+    uint8_t *d_frames = nullptr;
+    size_t d_frames_cap = 0;
+    AdderEvent *d_events = nullptr;
+    size_t d_events_cap = 0;
+    uint32_t *d_chunks = nullptr;
+    // running state
+    float running_t = 0.0f;  // PixelArena::running_t (identical for all pixels)
+    uint64_t frames_done = 0;
+    bool poisoned = false;
+    std::string err;
+    // pending device batch
+    bool pending = false;
+    hipStream_t pending_stream = nullptr;
+    uint64_t *pending_offsets = nullptr;
+    uint32_t pending_frames = 0;
+    size_t pending_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float last_ms = 0.0f;
+};
+
+static int fail(AdderHipCtx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, ADDER_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T **p, size_t count) {
+    return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+static void free_ctx(AdderHipCtx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->hdr,     c->tinteg,  c->tdt,     c->lastf,  c->td,       c->lv_integ, c->lv_dt,
+                    c->lv_bdt,  c->lv_dbd,  c->running, c->desc[0], c->desc[1], c->status,   c->census,
+                    c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void adder_hip_default_params(AdderHipParams *p, uint16_t width, uint16_t height, uint8_t channels) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->abi_version = ADDER_HIP_ABI_VERSION;
+    p->width = width;
+    p->height = height;
+    p->channels = channels;
+    p->time_mode = ADDER_TIME_ABSOLUTE_T;   // TimeMode::default (lib.rs:77-79)
+    p->multi_mode = ADDER_MULTI_COLLAPSE;   // PixelMultiMode::default (lib.rs:211-212)
+    p->pixel_mode = ADDER_MODE_FRAME_PERFECT;
+    p->row_begin = 0;
+    p->row_end = height;
+    p->ref_time = 255;      // VideoStateParams::default (video.rs:173-182)
+    p->delta_t_max = 7650;
+    p->c_thresh_max = 7;    // Crf::new(None) -> quality 3 (rate_controller.rs:21,55-70)
+    p->c_increase_velocity = 7;
+    p->c_thresh_start = 10; // PixelArena::new (event_pixel_tree.rs:82-83)
+    p->c_counter_start = 1;
+    p->chunk_rows = 1;      // VideoState::default (video.rs:230)
+    p->max_depth = 16;
+    p->device_id = -1;
+}
+
+static StepConsts make_consts(const AdderHipCtx *c, float time_spanned, float running_t) {
+    StepConsts sc;
+    sc.time_spanned = time_spanned;
+    sc.running_t = running_t;
+    sc.dtm_f = (float)c->p.delta_t_max;
+    sc.ref_time = c->p.ref_time;
+    sc.c_thresh_max = c->p.c_thresh_max;
+    sc.velocity_m1 = (uint8_t)(c->p.c_increase_velocity - 1);
+    sc.c_inc = (uint8_t)(f32_as_u32(time_spanned) / c->p.ref_time);
+    sc.collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE ? 1u : 0u;
+    sc.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
+    sc.max_depth = c->max_depth;
+    return sc;
+}
+
+static void base_args(const AdderHipCtx *c, FrameArgs *a) {
+    memset(a, 0, sizeof *a);
+    a->hdr = c->hdr;
+    a->tinteg = c->tinteg;
+    a->tdt = c->tdt;
+    a->td = c->td;
+    a->lastf = c->lastf;
+    a->lv_integ = c->lv_integ;
+    a->lv_dt = c->lv_dt;
+    a->lv_bdt = c->lv_bdt;
+    a->lv_dbd = c->lv_dbd;
+    a->running = c->running_enabled ? c->running : nullptr;
+    a->plane_stride = c->n_pad;
+    a->status = c->status;
+    a->census = nullptr;
+    a->n_units = c->n_units;
+    a->num_tiles = c->num_tiles;
+    a->width = c->p.width;
+    a->channels = c->p.channels;
+    a->rowlen = (uint32_t)c->p.width * c->p.channels;
+    a->row_begin = c->p.row_begin;
+    a->spin_limit = 1u << 22;
+}
+
+// Finds the largest persistent grid whose blocks are all resident at once.
+static int choose_grid(AdderHipCtx *c) {
+    int occ = 0;
+    HIPCHK(c, adder_frame_kernel_occupancy(&occ));
+    if (occ < 1) return fail(c, ADDER_E_HIP, "frame kernel does not fit on a CU");
+    occ = std::min(occ, 8);
+    FrameArgs a;
+    base_args(c, &a);
+    a.census = c->census;
+    a.spin_limit = 1u << 16;
+    for (int k = occ; k >= 1; --k) {
+        const uint32_t grid = c->num_cus * (uint32_t)k;
+        HIPCHK(c, hipMemsetAsync(c->census, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, adder_launch_frame(&a, grid, c->stream));
+        uint32_t st = 0;
+        HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (st == 0) {
+            c->grid = std::min<uint32_t>(c->num_tiles, grid);
+            HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+            return ADDER_OK;
+        }
+    }
+    return fail(c, ADDER_E_HIP, "no resident grid size found for the frame kernel");
+}
+
+extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
+    if (!out) return fail(nullptr, ADDER_E_BAD_PARAMS, "out is null");
+    *out = nullptr;
+    if (!params) return fail(nullptr, ADDER_E_BAD_PARAMS, "params is null");
+    AdderHipParams p = *params;
+    if (p.abi_version != ADDER_HIP_ABI_VERSION)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "abi_version %u != %u", p.abi_version, ADDER_HIP_ABI_VERSION);
+    if (p.width == 0 || p.height == 0)  // PlaneSize::new (lib.rs:103-118)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "invalid plane %ux%ux%u", p.width, p.height, p.channels);
+    if (p.channels != 1 && p.channels != 3)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "channels must be 1 or 3 (got %u)", p.channels);
+    if (p.pixel_mode != ADDER_MODE_FRAME_PERFECT)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "only Mode::FramePerfect is implemented on this path");
+    if (p.time_mode > ADDER_TIME_MIXED || p.multi_mode > ADDER_MULTI_COLLAPSE)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "bad time_mode / multi_mode");
+    if (p.row_begin == 0 && p.row_end == 0) p.row_end = p.height;
+    if (p.row_begin >= p.row_end || p.row_end > p.height)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "bad row band [%u,%u) of %u", p.row_begin, p.row_end, p.height);
+    if (p.ref_time == 0) return fail(nullptr, ADDER_E_BAD_PARAMS, "ref_time must be > 0");
+    if (p.delta_t_max < p.ref_time)  // video.rs:527-533
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "delta_t_max %u is smaller than ref_time %u", p.delta_t_max,
+                    p.ref_time);
+    if (p.delta_t_max % p.ref_time != 0)  // framed.rs:100-109
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "delta_t_max must be a multiple of ref_time");
+    if (p.c_increase_velocity == 0) return fail(nullptr, ADDER_E_BAD_PARAMS, "c_increase_velocity must be >= 1");
+    if (p.chunk_rows == 0) p.chunk_rows = 1;
+    if (p.max_depth == 0) p.max_depth = 16;
+    if (p.max_depth > kMaxDepthLimit)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "max_depth must be <= %u", kMaxDepthLimit);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, ADDER_E_NO_DEVICE, "no HIP device visible; this path has no CPU fallback");
+    int dev = p.device_id;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) return fail(nullptr, ADDER_E_BAD_PARAMS, "device_id %d out of range (%d devices)", dev, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(nullptr, ADDER_E_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, ADDER_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev,
+                    prop.gcnArchName);
+
+    AdderHipCtx *c = new (std::nothrow) AdderHipCtx();
+    if (!c) return fail(nullptr, ADDER_E_HIP, "out of host memory");
+    c->p = p;
+    c->device = dev;
+    c->num_cus = (uint32_t)prop.multiProcessorCount;
+    c->rows = p.row_end - p.row_begin;
+    const uint64_t units = (uint64_t)c->rows * p.width * p.channels;
+    if (units > 0x7ffffc00ull) {
+        delete c;
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "row band too large (%llu pixel-channels)", (unsigned long long)units);
+    }
+    c->n_units = (uint32_t)units;
+    c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;
+    c->n_pad = (size_t)c->num_tiles * kTileUnits;
+    c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
+    c->max_depth = p.max_depth;
+
+    int rc = ADDER_OK;
+    auto setup = [&]() -> int {
+        HIPCHK(c, hipSetDevice(dev));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreate(&c->ev_start));
+        HIPCHK(c, hipEventCreate(&c->ev_stop));
+        HIPCHK(c, dalloc(&c->hdr, c->n_pad));
+        HIPCHK(c, dalloc(&c->tinteg, c->n_pad));
+        HIPCHK(c, dalloc(&c->tdt, c->n_pad));
+        HIPCHK(c, dalloc(&c->lastf, c->n_pad));
+        HIPCHK(c, dalloc(&c->td, c->n_pad));
+        HIPCHK(c, dalloc(&c->lv_integ, c->n_pad * c->max_depth));
+        HIPCHK(c, dalloc(&c->lv_dt, c->n_pad * c->max_depth));
+        HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
+        HIPCHK(c, dalloc(&c->lv_dbd, c->n_pad * c->max_depth));
+        HIPCHK(c, dalloc(&c->running, c->n_pad));
+        HIPCHK(c, dalloc(&c->desc[0], c->num_tiles));
+        HIPCHK(c, dalloc(&c->desc[1], c->num_tiles));
+        HIPCHK(c, dalloc(&c->status, 1));
+        HIPCHK(c, dalloc(&c->census, 1));
+        HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
+        // PixelArena::new(1.0, coord): base_val 0, c_thresh 10, counter 1, one pristine node
+        const uint32_t hdr0 = 0u | ((uint32_t)p.c_thresh_start << 8) | ((uint32_t)p.c_counter_start << 16);
+        HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, hdr0, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tinteg, 0, c->n_pad * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tdt, 0, c->n_pad * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->td, 0, c->n_pad, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lv_integ, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lv_dt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lv_bdt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lv_dbd, 0, c->n_pad * c->max_depth * sizeof(uint16_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->desc[1], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return choose_grid(c);
+    };
+    rc = setup();
+    if (rc != ADDER_OK) {
+        g_create_error = c->err;
+        free_ctx(c);
+        return rc;
+    }
+    *out = c;
+    return ADDER_OK;
+}
+
+extern "C" void adder_hip_destroy(AdderHipCtx *ctx) { free_ctx(ctx); }
+
+extern "C" const char *adder_hip_last_error(const AdderHipCtx *ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int adder_hip_set_crf_parameters(AdderHipCtx *c, uint8_t c_thresh_max, uint8_t c_increase_velocity) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c_increase_velocity == 0) return fail(c, ADDER_E_BAD_PARAMS, "c_increase_velocity must be >= 1");
+    c->p.c_thresh_max = c_thresh_max;
+    c->p.c_increase_velocity = c_increase_velocity;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_reset_c_thresh(AdderHipCtx *c, uint8_t baseline) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, adder_launch_reset_c_thresh(c->hdr, c->n_pad, baseline, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_set_delta_t_max(AdderHipCtx *c, uint32_t dtm) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (dtm < c->p.ref_time || dtm % c->p.ref_time != 0)
+        return fail(c, ADDER_E_BAD_PARAMS, "delta_t_max must be a multiple of ref_time and >= ref_time");
+    c->p.delta_t_max = dtm;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_set_time_mode(AdderHipCtx *c, uint8_t time_mode) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (time_mode > ADDER_TIME_MIXED) return fail(c, ADDER_E_BAD_PARAMS, "bad time_mode");
+    if (c->frames_done != 0)
+        return fail(c, ADDER_E_BAD_PARAMS, "time mode can only be set before the first frame is integrated");
+    c->p.time_mode = time_mode;
+    return ADDER_OK;
+}
+
+extern "C" uint32_t adder_hip_num_chunks(const AdderHipCtx *c) { return c ? c->num_chunks : 0; }
+
+extern "C" size_t adder_hip_max_events_per_frame(const AdderHipCtx *c) {
+    return c ? (size_t)c->n_units * (c->max_depth + 2) : 0;
+}
+
+static int status_to_code(AdderHipCtx *c, uint32_t st) {
+    if (st == 0) return ADDER_OK;
+    c->poisoned = true;
+    if (st & kStatusTimeout) return fail(c, ADDER_E_TIMEOUT, "a bounded in-kernel wait expired");
+    if (st & kStatusDepth)
+        return fail(c, ADDER_E_ARENA_DEPTH, "a pixel needed more than max_depth=%u stored nodes", c->max_depth);
+    return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
+}
+
+// Queues `num_frames` frame launches on `stream`.
+static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
+                          AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
+    FrameArgs a;
+    base_args(c, &a);
+    a.out = reinterpret_cast<AdderEventPod *>(d_out);
+    a.out_cap = out_cap;
+    a.frame_offsets = d_offsets;
+    HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+    HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), stream));
+    HIPCHK(c, hipEventRecord(c->ev_start, stream));
+    float rt = c->running_t;
+    for (uint32_t f = 0; f < num_frames; ++f) {
+        a.frame = d_frames + (size_t)f * c->n_units;
+        a.frame_idx = f;
+        a.desc_cur = c->desc[f & 1u];
+        a.desc_next = c->desc[(f + 1u) & 1u];
+        a.sc = make_consts(c, time_spanned, rt);
+        HIPCHK(c, adder_launch_frame(&a, c->grid, stream));
+        rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
+    }
+    HIPCHK(c, hipEventRecord(c->ev_stop, stream));
+    c->running_t = rt;
+    c->frames_done += num_frames;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames,
+                                          float time_spanned, AdderEvent *d_out, size_t out_cap,
+                                          uint64_t *d_frame_offsets, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "previous device batch not finished (call adder_hip_finish)");
+    if (!d_frames || !d_frame_offsets || (!d_out && out_cap)) return fail(c, ADDER_E_BAD_PARAMS, "null pointer");
+    if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (num_frames == 0) {
+        HIPCHK(c, hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), s));
+    } else {
+        int rc = enqueue_frames(c, d_frames, num_frames, time_spanned, d_out, out_cap, d_frame_offsets, s);
+        if (rc != ADDER_OK) {
+            c->poisoned = true;
+            return rc;
+        }
+    }
+    c->pending = true;
+    c->pending_stream = s;
+    c->pending_offsets = d_frame_offsets;
+    c->pending_frames = num_frames;
+    c->pending_cap = out_cap;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (!c->pending) return fail(c, ADDER_E_BAD_PARAMS, "no device batch pending");
+    c->pending = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t st = 0;
+    uint64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));
+    HIPCHK(c, hipMemcpyAsync(&total, c->pending_offsets + c->pending_frames, sizeof total, hipMemcpyDeviceToHost,
+                             c->pending_stream));
+    HIPCHK(c, hipStreamSynchronize(c->pending_stream));
+    if (c->pending_frames)
+        HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev_start, c->ev_stop));
+    else
+        c->last_ms = 0.0f;
+    if (n_out) *n_out = (size_t)total;
+    return status_to_code(c, st);
+}
+
+extern "C" float adder_hip_last_batch_ms(AdderHipCtx *c) { return c ? c->last_ms : 0.0f; }
+
+extern "C" int adder_hip_chunk_offsets_device(AdderHipCtx *c, const AdderEvent *d_events, size_t n_events,
+                                              uint32_t *d_chunk_offsets, void *stream) {
+    if (!c || !d_chunk_offsets) return ADDER_E_BAD_PARAMS;
+    if (n_events > 0xffffffffull) return fail(c, ADDER_E_BAD_PARAMS, "too many events for one frame");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    HIPCHK(c, adder_launch_chunk_offsets(reinterpret_cast<const AdderEventPod *>(d_events), (uint32_t)n_events,
+                                         c->p.row_begin, c->p.chunk_rows, c->num_chunks, d_chunk_offsets, s));
+    return ADDER_OK;
+}
+
+static int ensure(AdderHipCtx *c, void **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return ADDER_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipMalloc(p, std::max<size_t>(need, 16)));
+    *cap = need;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_integrate_batch(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
+                                         size_t frame_stride, size_t row_stride, float time_spanned,
+                                         AdderEvent *out, size_t out_cap, size_t *n_out,
+                                         uint64_t *frame_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_out) *n_out = 0;
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
+    if (!frames && num_frames) return fail(c, ADDER_E_BAD_PARAMS, "frames is null");
+    if (!out && out_cap) return fail(c, ADDER_E_BAD_PARAMS, "out is null");
+    const size_t rowlen = (size_t)c->p.width * c->p.channels;
+    if (row_stride == 0) row_stride = rowlen;
+    if (row_stride < rowlen) return fail(c, ADDER_E_BAD_PARAMS, "row_stride_bytes smaller than a row");
+    if (frame_stride == 0) frame_stride = row_stride * c->rows;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    void *vp = c->d_frames;
+    if ((rc = ensure(c, &vp, &c->d_frames_cap, (size_t)num_frames * c->n_units + 16)) != ADDER_OK) return rc;
+    c->d_frames = (uint8_t *)vp;
+    vp = c->d_events;
+    if ((rc = ensure(c, &vp, &c->d_events_cap, out_cap * sizeof(AdderEvent))) != ADDER_OK) return rc;
+    c->d_events = (AdderEvent *)vp;
+    vp = c->d_offsets;
+    if ((rc = ensure(c, &vp, &c->d_offsets_cap, ((size_t)num_frames + 1) * sizeof(uint64_t))) != ADDER_OK) return rc;
+    c->d_offsets = (uint64_t *)vp;
+
+    for (uint32_t f = 0; f < num_frames; ++f)
+        HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * c->n_units, rowlen, frames + (size_t)f * frame_stride,
+                                   row_stride, rowlen, c->rows, hipMemcpyHostToDevice, c->stream));
+    rc = adder_hip_integrate_device(c, c->d_frames, num_frames, time_spanned, c->d_events, out_cap, c->d_offsets,
+                                    c->stream);
+    if (rc != ADDER_OK) return rc;
+    size_t total = 0;
+    rc = adder_hip_finish(c, &total);
+    if (n_out) *n_out = total;
+    if (rc != ADDER_OK) return rc;
+    if (total > out_cap) {  // defensive; the kernel reports this through the status word
+        c->poisoned = true;
+        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: need %zu", total);
+    }
+    if (total) HIPCHK(c, hipMemcpy(out, c->d_events, total * sizeof(AdderEvent), hipMemcpyDeviceToHost));
+    if (frame_offsets)
+        HIPCHK(c, hipMemcpy(frame_offsets, c->d_offsets, ((size_t)num_frames + 1) * sizeof(uint64_t),
+                            hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
+                                   AdderEvent *out, size_t out_cap, size_t *n_out, uint32_t *chunk_offsets) {
+    size_t n = 0;
+    int rc = adder_hip_integrate_batch(c, frame, 1, 0, row_stride, time_spanned, out, out_cap, &n, nullptr);
+    if (n_out) *n_out = n;
+    if (rc != ADDER_OK) return rc;
+    if (chunk_offsets) {
+        // events are in raster order, so chunk boundaries are boundaries in y
+        size_t i = 0;
+        for (uint32_t ch = 0; ch < c->num_chunks; ++ch) {
+            const uint32_t y0 = c->p.row_begin + ch * c->p.chunk_rows;
+            while (i < n && out[i].y < y0) ++i;
+            chunk_offsets[ch] = (uint32_t)i;
+        }
+        chunk_offsets[c->num_chunks] = (uint32_t)n;
+    }
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_enable_running_intensities(AdderHipCtx *c, int enable) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    c->running_enabled = enable != 0;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_running_intensities(AdderHipCtx *c, uint8_t *dst) {
+    if (!c || !dst) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, c->running, c->n_units, hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_synth_clip_device(uint8_t *d_dst, int content, uint64_t seed, uint32_t width,
+                                           uint32_t height, uint32_t channels, uint32_t row_begin, uint32_t rows,
+                                           uint32_t frame_begin, uint32_t num_frames, void *stream) {
+    if (!d_dst || content < 0 || content > 2 || !width || !height || !channels) return ADDER_E_BAD_PARAMS;
+    hipError_t e = adder_launch_synth(d_dst, content, seed, width, height, channels, row_begin, rows, frame_begin,
+                                      num_frames, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        g_create_error = std::string("synth launch failed: ") + hipGetErrorString(e);
+        return ADDER_E_HIP;
+    }
+    return ADDER_OK;
+}

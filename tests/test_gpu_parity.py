@@ -1,0 +1,218 @@
+"""GPU parity proper: the HIP path (through the C-ABI, libadder_hip.so) against the CPU
+oracle on the same seeded inputs -- bit-exact on every field of every event, in order.
+"""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+import clips
+
+CRFS = {0: (0, 0, 10), 3: (2, 7, 7), 6: (7, 13, 4), 9: (15, 25, 1)}
+
+
+def _hip():
+    import adder_amd
+    return adder_amd
+
+
+def run_pair(clip, *, time_mode, multi_mode, dtm, ref_time=255, crf=None, default_pixels=False,
+             max_depth=20, batch=False, row_band=None, chunk_rows=1):
+    A = _hip()
+    frames, H, W, Cn = clip.shape
+    y0, y1 = (0, H) if row_band is None else row_band
+    sub = clip[:, y0:y1]
+    ov = O.Video(W, y1 - y0, Cn, row_begin=y0, time_mode=time_mode, multi_mode=multi_mode, ref_time=ref_time,
+                 delta_t_max=dtm, chunk_rows=chunk_rows)
+    hv = A.HipVideo(W, H, Cn, row_begin=y0, row_end=y1, time_mode=time_mode, multi_mode=multi_mode,
+                    ref_time=ref_time, delta_t_max=dtm, max_depth=max_depth, chunk_rows=chunk_rows)
+    ov.ensure_capacity(max_depth + 2)
+    if crf is not None:
+        base, cmax, vel = crf
+        ov.set_crf_parameters(cmax, vel)
+        hv.set_crf_parameters(cmax, vel)
+        if not default_pixels:
+            ov.reset_c_thresh(base)
+            hv.reset_c_thresh(base)
+    total = 0
+    if batch:
+        want = [ov.integrate_matrix(sub[k], time_spanned=float(ref_time)) for k in range(frames)]
+        got, offs = hv.integrate_batch(sub)
+        assert [int(offs[k + 1] - offs[k]) for k in range(frames)] == [len(w) for w in want]
+        want = np.concatenate(want)
+        assert np.array_equal(got, want)
+        total = len(want)
+    else:
+        for k in range(frames):
+            a, ca = ov.integrate_matrix(sub[k], time_spanned=float(ref_time), want_chunks=True)
+            b, cb = hv.integrate_matrix(sub[k], want_chunks=True)
+            assert len(a) == len(b), (k, len(a), len(b))
+            assert np.array_equal(a, b), k
+            assert np.array_equal(ca, cb), k
+            total += len(a)
+    hv.close()
+    return total
+
+
+@pytest.mark.parametrize("kind", ["noise", "static", "dark", "jitter", "runs", "steps"])
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_modes_crf0(kind, multi_mode, time_mode):
+    clip = clips.make_clip(kind, 40, 37, 53, 1, seed=17 + multi_mode * 2 + time_mode)
+    for dtm in (255, 7650):
+        run_pair(clip, time_mode=time_mode, multi_mode=multi_mode, dtm=dtm, crf=CRFS[0])
+
+
+@pytest.mark.parametrize("crf", [3, 9])
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+def test_lossy_crf(crf, multi_mode):
+    for kind in ("jitter", "runs", "dark"):
+        clip = clips.make_clip(kind, 60, 33, 41, 1, seed=crf * 100 + multi_mode)
+        run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=multi_mode, dtm=7650, crf=CRFS[crf], batch=True)
+        run_pair(clip, time_mode=O.DELTA_T, multi_mode=multi_mode, dtm=255, crf=CRFS[crf], batch=True)
+
+
+def test_construction_default_pixels():
+    clip = clips.make_clip("jitter", 50, 20, 30, 1, seed=5)
+    run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=(2, 7, 7), default_pixels=True)
+    run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.NORMAL, dtm=510, crf=None)
+
+
+def test_rgb_interleaved():
+    clip = clips.make_clip("runs", 40, 19, 23, 3, seed=11)
+    for mm in (O.NORMAL, O.COLLAPSE):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            run_pair(clip, time_mode=tm, multi_mode=mm, dtm=1020, crf=CRFS[0], batch=True)
+
+
+@pytest.mark.parametrize("ref_time,dtm", [(5000, 240000), (1000, 2000), (20, 10000)])
+def test_other_tick_rates(ref_time, dtm):
+    clip = clips.make_clip("runs", 50, 16, 24, 1, seed=ref_time)
+    for mm in (O.NORMAL, O.COLLAPSE):
+        run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=mm, dtm=dtm, ref_time=ref_time, crf=CRFS[0], batch=True)
+        run_pair(clip, time_mode=O.DELTA_T, multi_mode=mm, dtm=dtm, ref_time=ref_time, crf=CRFS[3], batch=True)
+
+
+def test_ragged_tiny_and_odd_planes():
+    # 1x1, single row, widths that are not multiples of the lane/tile size
+    for (H, W, Cn) in [(1, 1, 1), (1, 1, 3), (1, 7, 1), (3, 5, 3), (2, 1025, 1), (5, 341, 3), (1, 4097, 1)]:
+        clip = clips.make_clip("runs", 24, H, W, Cn, seed=H * 1000 + W)
+        run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0])
+        run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=510, crf=CRFS[0], batch=True)
+
+
+def test_many_tiles_lookback_chain():
+    # > 2 x resident grid worth of tiles so the persistent blocks loop and the look-back
+    # crosses many tiles; noise makes every tile emit
+    clip = clips.make_clip("noise", 6, 1080, 1920, 1, seed=3)
+    run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
+    clip = clips.make_clip("runs", 12, 540, 960, 3, seed=4)
+    run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=1020, crf=CRFS[0], batch=True)
+
+
+def test_row_band_and_chunks():
+    clip = clips.make_clip("runs", 30, 64, 48, 1, seed=8)
+    run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], row_band=(16, 40), chunk_rows=5)
+    run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=510, crf=CRFS[0], row_band=(40, 64), chunk_rows=64)
+
+
+def test_long_static_deep_arena():
+    clip = clips.make_clip("static", 400, 8, 16, 1, seed=2)
+    clip[-1] = 255 - clip[-1]
+    run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=255, crf=CRFS[0], batch=True)
+    run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=7650, crf=CRFS[0], batch=True)
+
+
+def test_lake_golden_bytes(golden_dir):
+    """Reference golden: frames -> HIP path -> raw sink == lake_scaled_hd_out.adder byte for byte."""
+    A = _hip()
+    raw = gzip.open(os.path.join(golden_dir, "lake_scaled_hd_out.adder.gz")).read()
+    frames = np.load(os.path.join(golden_dir, "lake_scaled_hd_frames_reconstructed.npz"))["frames"]
+    hv = A.HipVideo(200, 50, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, ref_time=255, delta_t_max=6120)
+    hv.update_crf(0)
+    ev, offs = hv.integrate_batch(frames[:, :, :, None])
+    assert len(ev) == 201_620 and offs[1] == 0
+    blob = A.raw_header(3, 200, 50, 1, 6113, 255, 6120, 0, A.TIME_DELTA_T, 0) + A.raw_events(ev, 1) + A.raw_eof()
+    assert hashlib.sha256(blob).hexdigest() == "b3ceb84fbef8c6f0f054c521b3d66fdda397219befc8201d6e3e1dd64cb80967"
+    assert blob == raw
+
+
+def test_second_opinion_vectors(golden_dir):
+    A = _hip()
+    d = json.load(open(os.path.join(golden_dir, "model_second_opinion_vectors.json")))
+    for case in d["cases"]:
+        W, H, Cn = case["width"], case["height"], case["channels"]
+        hv = A.HipVideo(W, H, Cn, time_mode=case["time_mode"], multi_mode=case["multi_mode"],
+                        ref_time=case["ref_time"], delta_t_max=case["delta_t_max"])
+        hv.set_crf_parameters(case["c_thresh_max"], case["c_increase_velocity"])
+        if case["c_start"] is not None:
+            hv.reset_c_thresh(case["c_start"])
+        frames = np.array(case["input_hwc_u8"], dtype=np.uint8).reshape(case["frames"], H, W, Cn)
+        got, offs = hv.integrate_batch(frames)
+        assert [int(offs[k + 1] - offs[k]) for k in range(case["frames"])] == case["events_per_frame"]
+        want = np.array(case["events"], dtype=np.int64).reshape(-1, 5)
+        gc = got["c"].astype(np.int64)
+        gc[gc == 0xFF] = -1
+        have = np.stack([got["x"].astype(np.int64), got["y"].astype(np.int64), gc,
+                         got["d"].astype(np.int64), got["t"].astype(np.int64)], axis=1)
+        assert np.array_equal(have, want), case["name"]
+
+
+def test_running_intensities_side_plane():
+    A = _hip()
+    clip = clips.make_clip("runs", 30, 12, 20, 1, seed=21)
+    ov = O.Video(20, 12, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+    hv = A.HipVideo(20, 12, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=7650)
+    hv.enable_running_intensities(True)
+    for v in (ov, hv):
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+    for k in range(30):
+        ov.integrate_matrix(clip[k])
+        hv.integrate_matrix(clip[k])
+        assert np.array_equal(ov.running_intensities(), hv.running_intensities()), k
+
+
+def test_errors_are_loud():
+    A = _hip()
+    with pytest.raises(A.AdderHipError):
+        A.HipVideo(16, 16, 2)  # channels must be 1 or 3
+    with pytest.raises(A.AdderHipError):
+        A.HipVideo(16, 16, 1, delta_t_max=100)  # dtm < ref_time
+    # capacity overflow is reported with the required size, and poisons the context
+    clip = clips.make_clip("noise", 3, 16, 16, 1, seed=1)
+    hv = A.HipVideo(16, 16, 1, time_mode=A.TIME_DELTA_T, delta_t_max=255)
+    hv.update_crf(0)
+    hv.integrate_matrix(clip[0])
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.integrate_matrix(clip[1], out_cap=10)
+    assert ei.value.code == -4 and hv.last_required > 10
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.integrate_matrix(clip[2])
+    assert ei.value.code == -7
+    # arena depth overflow
+    clip = clips.make_clip("static", 100, 4, 4, 1, seed=1)
+    hv = A.HipVideo(4, 4, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, delta_t_max=255, max_depth=3)
+    hv.update_crf(0)
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.integrate_batch(clip)
+    assert ei.value.code == -5
+
+
+def test_synth_clip_matches_oracle_generator():
+    import torch
+    A = _hip()
+    for content in (0, 1, 2):
+        for (W, H, Cn) in [(64, 48, 1), (31, 17, 3)]:
+            want = O.synth_clip(content, W, H, Cn, 5, y0=3, rows=H - 5, k0=2)
+            d = torch.empty(want.shape, dtype=torch.uint8, device="cuda")
+            A.synth_clip_device(d, content, W, H, Cn, row_begin=3, rows=H - 5, frame_begin=2, num_frames=5,
+                                stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy(), want), (content, W, H, Cn)
