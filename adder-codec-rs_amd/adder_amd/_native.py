@@ -92,6 +92,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME
+    # as /opt/rocm's).  If torch is going to be used in this process it must be loaded
+    # FIRST so that the dynamic loader binds libadder_hip.so to that same copy -- two
+    # copies cannot both open the device (the second one reports "no devices").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} not found: build it with `make -C adder-codec-rs_amd` "
