@@ -1,0 +1,83 @@
+"""Row-band sharding of a plane across ranks and the ordered gather of the event stream.
+
+The reference already splits a frame by rows (rayon row chunks, video.rs:677-691) and,
+with feature detection off, pixels never interact (integrate_for_px touches only `px`,
+video.rs:1318-1380).  So each rank owns a contiguous band of rows for the whole clip
+and NO collective is needed while integrating.  The only exchange is the one that
+concatenates the emitted events before the (unchanged, serial) sink: per frame the
+segments must appear in rank order, which is raster order.
+
+Works on CUDA tensors over RCCL (backend "nccl") and on CPU tensors over gloo (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def row_bands(height, world, chunk_rows=1):
+    """Contiguous bands [y0, y1) per rank, each a multiple of chunk_rows (except the last)."""
+    chunks = (height + chunk_rows - 1) // chunk_rows
+    base, extra = divmod(chunks, world)
+    bands, c0 = [], 0
+    for r in range(world):
+        c1 = c0 + base + (1 if r < extra else 0)
+        bands.append((min(c0 * chunk_rows, height), min(c1 * chunk_rows, height)))
+        c0 = c1
+    return bands
+
+
+def merge_frame_major(segments):
+    """segments[r] = (events int32 [n_r, 3], offsets int64 [T+1]) of rank r, each frame-major.
+    Returns (events [sum n_r, 3], offsets [T+1]) with, per frame, rank 0's events first, then
+    rank 1's, ... -- the stream a single context over the whole plane would have produced."""
+    dev = segments[0][0].device
+    T = segments[0][1].numel() - 1
+    counts = torch.stack([s[1][1:] - s[1][:-1] for s in segments]).to(dev)  # [R, T]
+    frame_tot = counts.sum(0)
+    frame_base = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+    frame_base[1:] = torch.cumsum(frame_tot, 0)
+    before = torch.cumsum(counts, 0) - counts  # events of lower ranks in the same frame
+    total = int(frame_base[-1])
+    out = torch.empty((total, 3), dtype=torch.int32, device=dev)
+    for r, (ev, offs) in enumerate(segments):
+        n = ev.shape[0]
+        if n == 0:
+            continue
+        offs = offs.to(dev)
+        frame_id = torch.repeat_interleave(torch.arange(T, device=dev), counts[r])
+        shift = frame_base[:-1] + before[r] - offs[:-1]
+        dest = torch.arange(n, device=dev) + shift[frame_id]
+        out[dest] = ev
+    return out, frame_base
+
+
+def gather_event_stream(events, offsets, dst=0, group=None):
+    """Ordered variable-length gather of every rank's frame-major event segment to `dst`.
+    events: int32 [n, 3] (the 12-byte records), offsets: int64 [T+1].  Returns the merged
+    (events, offsets) on dst and None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return events, offsets
+    offsets = offsets.contiguous()
+    all_offs = [torch.empty_like(offsets) for _ in range(world)]
+    dist.all_gather(all_offs, offsets, group=group)
+    ops, segs = [], None
+    if rank == dst:
+        segs = []
+        for r in range(world):
+            if r == dst:
+                segs.append((events, offsets))
+                continue
+            n_r = int(all_offs[r][-1])
+            buf = torch.empty((n_r, 3), dtype=torch.int32, device=events.device)
+            segs.append((buf, all_offs[r]))
+            if n_r:
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+    elif events.shape[0]:
+        ops.append(dist.P2POp(dist.isend, events.contiguous(), dst, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank != dst:
+        return None
+    return merge_frame_major(segs)

@@ -24,7 +24,8 @@ DEFAULT_CRF_QUALITY = 3
 class HipVideo:
     def __init__(self, width, height, channels=1, *, row_begin=0, row_end=None,
                  time_mode=N.TIME_ABSOLUTE_T, multi_mode=N.MULTI_COLLAPSE, ref_time=255,
-                 delta_t_max=7650, chunk_rows=1, max_depth=16, device_id=-1):
+                 delta_t_max=7650, chunk_rows=1, max_depth=16, device_id=-1,
+                 c_thresh_start=None, c_counter_start=None):
         self.L = N.load()
         p = N.AdderHipParams()
         self.L.adder_hip_default_params(C.byref(p), width, height, channels)
@@ -33,6 +34,10 @@ class HipVideo:
         p.time_mode, p.multi_mode = time_mode, multi_mode
         p.ref_time, p.delta_t_max = ref_time, delta_t_max
         p.chunk_rows, p.max_depth, p.device_id = chunk_rows, max_depth, device_id
+        if c_thresh_start is not None:
+            p.c_thresh_start = c_thresh_start
+        if c_counter_start is not None:
+            p.c_counter_start = c_counter_start
         self.params = p
         self.width, self.height, self.channels = width, height, channels
         self.rows = p.row_end - p.row_begin
@@ -151,6 +156,16 @@ class HipVideo:
 
     def last_batch_ms(self):
         return float(self.L.adder_hip_last_batch_ms(self.h))
+
+    def set_launch_timing(self, on=True):
+        N.check(self.h, self.L.adder_hip_set_launch_timing(self.h, int(on)))
+
+    def last_launch_avg_us(self):
+        return float(self.L.adder_hip_last_launch_avg_us(self.h))
+
+    def reset(self):
+        """Back to the freshly constructed state (Video::new); parameters are kept."""
+        N.check(self.h, self.L.adder_hip_reset(self.h))
 
     def chunk_offsets_device(self, d_events_ptr, n_events, d_chunk_offsets, stream=None):
         N.check(self.h, self.L.adder_hip_chunk_offsets_device(

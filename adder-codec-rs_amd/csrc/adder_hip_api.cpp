@@ -64,6 +64,11 @@ struct AdderHipCtx {
     size_t pending_cap = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float last_ms = 0.0f;
+    // optional per-launch timing (one HIP event pair around every frame launch)
+    bool launch_timing = false;
+    std::vector<hipEvent_t> launch_events;
+    uint32_t timed_launches = 0;
+    float last_launch_avg_us = 0.0f;
 };
 
 static int fail(AdderHipCtx *ctx, int code, const char *fmt, ...) {
@@ -101,6 +106,7 @@ static void free_ctx(AdderHipCtx *c) {
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -167,6 +173,35 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->rowlen = (uint32_t)c->p.width * c->p.channels;
     a->row_begin = c->p.row_begin;
     a->spin_limit = 1u << 22;
+}
+
+// Video::new (video.rs:350-438): every pixel = PixelArena::new(1.0, coord): base_val 0,
+// c_thresh 10, counter 1, one pristine node, last_fired_t 0, running_t 0.
+static int init_state(AdderHipCtx *c, bool full) {
+    const AdderHipParams &p = c->p;
+    // PixelArena::new(1.0, coord): base_val 0, c_thresh 10, counter 1, one pristine node
+    const uint32_t hdr0 = 0u | ((uint32_t)p.c_thresh_start << 8) | ((uint32_t)p.c_counter_start << 16);
+    HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, hdr0, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
+    // tail and level planes are only read where the header says they are live (m > 0 /
+    // tail_live), so a reset does not need to clear them
+    if (full) {
+    HIPCHK(c, hipMemsetAsync(c->tinteg, 0, c->n_pad * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tdt, 0, c->n_pad * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->td, 0, c->n_pad, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lv_integ, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lv_dt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lv_bdt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lv_dbd, 0, c->n_pad * c->max_depth * sizeof(uint16_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->desc[1], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+    c->running_t = 0.0f;
+    c->frames_done = 0;
+    c->poisoned = false;
+    return ADDER_OK;
 }
 
 // Finds the largest persistent grid whose blocks are all resident at once.
@@ -279,21 +314,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->census, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
-        // PixelArena::new(1.0, coord): base_val 0, c_thresh 10, counter 1, one pristine node
-        const uint32_t hdr0 = 0u | ((uint32_t)p.c_thresh_start << 8) | ((uint32_t)p.c_counter_start << 16);
-        HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, hdr0, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tinteg, 0, c->n_pad * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tdt, 0, c->n_pad * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->td, 0, c->n_pad, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->lv_integ, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->lv_dt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->lv_bdt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->lv_dbd, 0, c->n_pad * c->max_depth * sizeof(uint16_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->desc[1], 0, c->num_tiles * sizeof(uint64_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+        { int rc_ = init_state(c, true); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return choose_grid(c);
     };
@@ -373,13 +394,26 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), stream));
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     float rt = c->running_t;
+    c->timed_launches = 0;
+    if (c->launch_timing) {
+        while (c->launch_events.size() < 2 * (size_t)num_frames) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->launch_events.push_back(e);
+        }
+    }
     for (uint32_t f = 0; f < num_frames; ++f) {
         a.frame = d_frames + (size_t)f * c->n_units;
         a.frame_idx = f;
         a.desc_cur = c->desc[f & 1u];
         a.desc_next = c->desc[(f + 1u) & 1u];
         a.sc = make_consts(c, time_spanned, rt);
+        if (c->launch_timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], stream));
         HIPCHK(c, adder_launch_frame(&a, c->grid, stream));
+        if (c->launch_timing) {
+            HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], stream));
+            c->timed_launches = f + 1;
+        }
         rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
     }
     HIPCHK(c, hipEventRecord(c->ev_stop, stream));
@@ -430,11 +464,40 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
         HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev_start, c->ev_stop));
     else
         c->last_ms = 0.0f;
+    c->last_launch_avg_us = 0.0f;
+    if (c->timed_launches) {
+        double sum = 0.0;
+        for (uint32_t f = 0; f < c->timed_launches; ++f) {
+            float ms = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->launch_events[2 * f], c->launch_events[2 * f + 1]));
+            sum += ms;
+        }
+        c->last_launch_avg_us = (float)(sum * 1000.0 / c->timed_launches);
+    }
     if (n_out) *n_out = (size_t)total;
     return status_to_code(c, st);
 }
 
 extern "C" float adder_hip_last_batch_ms(AdderHipCtx *c) { return c ? c->last_ms : 0.0f; }
+
+extern "C" int adder_hip_set_launch_timing(AdderHipCtx *c, int enable) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    c->launch_timing = enable != 0;
+    return ADDER_OK;
+}
+
+extern "C" float adder_hip_last_launch_avg_us(AdderHipCtx *c) { return c ? c->last_launch_avg_us : 0.0f; }
+
+extern "C" int adder_hip_reset(AdderHipCtx *c) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = init_state(c, false);
+    if (rc == ADDER_OK && c->running_enabled) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+    if (rc != ADDER_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ADDER_OK;
+}
 
 extern "C" int adder_hip_chunk_offsets_device(AdderHipCtx *c, const AdderEvent *d_events, size_t n_events,
                                               uint32_t *d_chunk_offsets, void *stream) {

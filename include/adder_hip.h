@@ -156,6 +156,18 @@ int adder_hip_enable_running_intensities(AdderHipCtx *ctx, int enable);
  * batch, measured with HIP events on the launch stream (0 if none). */
 float adder_hip_last_batch_ms(AdderHipCtx *ctx);
 
+/* Mean duration in microseconds of the frame-kernel launches of the last device batch,
+ * measured with one HIP event pair around EVERY launch on the launch stream; only
+ * collected while adder_hip_set_launch_timing(ctx, 1) is in effect (the extra event
+ * packets slow the batch down, so throughput runs leave it off). */
+int adder_hip_set_launch_timing(AdderHipCtx *ctx, int enable);
+float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
+
+/* Back to the state right after adder_hip_create (Video::new): every pixel pristine,
+ * c_thresh/counter = c_thresh_start/c_counter_start, running_t = 0, poison cleared.
+ * Parameters set since (crf parameters, delta_t_max, time mode) are kept. */
+int adder_hip_reset(AdderHipCtx *ctx);
+
 /* --- deterministic synthetic clips generated directly in HBM ------ */
 enum { ADDER_CONTENT_STATIC = 0, ADDER_CONTENT_NOISE = 1, ADDER_CONTENT_SCENE = 2 };
 int adder_hip_synth_clip_device(uint8_t *d_dst, int content, uint64_t seed, uint32_t width,

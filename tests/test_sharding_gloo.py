@@ -1,0 +1,97 @@
+"""N>1 path on CPU: world_size-2 gloo run of the row-band sharding + ordered event gather.
+Each rank integrates its band (the oracle stands in for the per-rank integrator here --
+the HIP integrator needs a GPU) and rank 0 must end up with exactly the stream a single
+context over the whole plane produces."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, chunk_rows, q):
+    for p in (ROOT, os.path.join(ROOT, "adder-codec-rs_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import oracle as O
+    import clips
+    from adder_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, T = 37, 29, 25
+        clip = clips.make_clip("runs", T, H, W, 1, seed=99)
+        y0, y1 = sharding.row_bands(H, world, chunk_rows)[rank]
+        v = O.Video(W, y1 - y0, 1, row_begin=y0, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE,
+                    ref_time=255, delta_t_max=510, chunk_rows=chunk_rows)
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+        per = [v.integrate_matrix(clip[k, y0:y1]) for k in range(T)]
+        offs = torch.tensor(np.concatenate([[0], np.cumsum([len(e) for e in per])]), dtype=torch.int64)
+        ev = np.concatenate(per)
+        ev_t = torch.from_numpy(np.frombuffer(ev.tobytes(), dtype=np.int32).reshape(-1, 3).copy())
+        merged = sharding.gather_event_stream(ev_t, offs, dst=0)
+        if rank == 0:
+            full = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=510)
+            full.set_crf_parameters(0, 10)
+            full.reset_c_thresh(0)
+            want_per = [full.integrate_matrix(clip[k]) for k in range(T)]
+            want = np.concatenate(want_per)
+            got = np.frombuffer(merged[0].numpy().tobytes(), dtype=O.EVENT_DTYPE)
+            ok = len(got) == len(want) and np.array_equal(got, want)
+            ok = ok and merged[1].tolist() == np.concatenate([[0], np.cumsum([len(e) for e in want_per])]).tolist()
+            q.put(bool(ok))
+        else:
+            assert merged is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunk_rows", [1, 4])
+def test_two_rank_band_sharding_matches_single_stream(chunk_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunk_rows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_row_bands_cover_plane():
+    from adder_amd import sharding
+    for H in (1, 7, 1080, 2160):
+        for world in (1, 2, 4, 8):
+            for cr in (1, 4, 64):
+                b = sharding.row_bands(H, world, cr)
+                assert b[0][0] == 0 and b[-1][1] == H
+                assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+                assert all(y0 % cr == 0 for y0, _ in b if y0 < H)
+    assert sharding.row_bands(2160, 8) == [(i * 270, (i + 1) * 270) for i in range(8)]
+
+
+def test_merge_frame_major_orders_by_frame_then_rank():
+    from adder_amd import sharding
+    a = (torch.tensor([[1, 0, 0], [2, 0, 0], [3, 0, 0]], dtype=torch.int32), torch.tensor([0, 1, 1, 3]))
+    b = (torch.tensor([[10, 0, 0], [20, 0, 0]], dtype=torch.int32), torch.tensor([0, 0, 2, 2]))
+    ev, offs = sharding.merge_frame_major([a, b])
+    assert ev[:, 0].tolist() == [1, 10, 20, 2, 3] and offs.tolist() == [0, 1, 3, 5]
