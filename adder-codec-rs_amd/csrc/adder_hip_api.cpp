@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -33,14 +34,18 @@ struct AdderHipCtx {
     uint32_t max_depth = 0;
     // state planes
     uint32_t *hdr = nullptr;
-    float *tinteg = nullptr, *tdt = nullptr, *lastf = nullptr;
-    uint8_t *td = nullptr;
+    float *lastf = nullptr;
     float *lv_integ = nullptr, *lv_dt = nullptr, *lv_bdt = nullptr;
-    uint16_t *lv_dbd = nullptr;
+    uint8_t *lv_bd = nullptr;
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // compaction scratch
-    uint64_t *desc[2] = {nullptr, nullptr};
+    uint64_t *agg[2] = {nullptr, nullptr};   // per-tile event counts (double-buffered by frame parity)
+    uint64_t *gsum[2] = {nullptr, nullptr};  // per-group sums
+    uint2 *worklist = nullptr;               // pixels for the generic kernel
+    uint32_t *wl_count = nullptr;            // [2]
+    uint32_t num_groups = 0;
+    uint32_t blocks_per_cu = 0;
     uint32_t *status = nullptr;   // device status word
     uint32_t *census = nullptr;   // device census counter
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
@@ -101,8 +106,8 @@ static void free_ctx(AdderHipCtx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->hdr,     c->tinteg,  c->tdt,     c->lastf,  c->td,       c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_dbd,  c->running, c->desc[0], c->desc[1], c->status,   c->census,
+    void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
+                    c->lv_bdt,  c->lv_bd,   c->running, c->agg[0], c->agg[1], c->gsum[0], c->gsum[1], c->worklist, c->wl_count, c->status,   c->census,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -148,20 +153,19 @@ static StepConsts make_consts(const AdderHipCtx *c, float time_spanned, float ru
     sc.collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE ? 1u : 0u;
     sc.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
     sc.max_depth = c->max_depth;
+    sc.ref_magic = c->p.ref_time >= 2 ? (uint32_t)(0x100000000ull / c->p.ref_time) : 0u;
     return sc;
 }
 
 static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     memset(a, 0, sizeof *a);
     a->hdr = c->hdr;
-    a->tinteg = c->tinteg;
-    a->tdt = c->tdt;
-    a->td = c->td;
     a->lastf = c->lastf;
     a->lv_integ = c->lv_integ;
     a->lv_dt = c->lv_dt;
     a->lv_bdt = c->lv_bdt;
-    a->lv_dbd = c->lv_dbd;
+    a->lv_bd = c->lv_bd;
+    a->worklist = c->worklist;
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
@@ -173,6 +177,7 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->rowlen = (uint32_t)c->p.width * c->p.channels;
     a->row_begin = c->p.row_begin;
     a->spin_limit = 1u << 22;
+    if (const char *ab = getenv("ADDER_HIP_ABLATE")) a->ablate = (uint32_t)atoi(ab);  // timing experiments only
 }
 
 // Video::new (video.rs:350-438): every pixel = PixelArena::new(1.0, coord): base_val 0,
@@ -183,20 +188,20 @@ static int init_state(AdderHipCtx *c, bool full) {
     const uint32_t hdr0 = 0u | ((uint32_t)p.c_thresh_start << 8) | ((uint32_t)p.c_counter_start << 16);
     HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, hdr0, c->stream));
     HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
-    // tail and level planes are only read where the header says they are live (m > 0 /
-    // tail_live), so a reset does not need to clear them
+    // level planes are only read where the header says they are live (m > k), so a reset
+    // does not need to clear them
     if (full) {
-    HIPCHK(c, hipMemsetAsync(c->tinteg, 0, c->n_pad * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tdt, 0, c->n_pad * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->td, 0, c->n_pad, c->stream));
     HIPCHK(c, hipMemsetAsync(c->lv_integ, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->lv_dt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->lv_bdt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->lv_dbd, 0, c->n_pad * c->max_depth * sizeof(uint16_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lv_bd, 0, c->n_pad * c->max_depth, c->stream));
     HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->desc[1], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(c, hipMemsetAsync(c->agg[b], 0, c->num_tiles * sizeof(uint64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->gsum[b], 0, c->num_groups * sizeof(uint64_t), c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, 2 * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
     c->running_t = 0.0f;
     c->frames_done = 0;
@@ -204,27 +209,41 @@ static int init_state(AdderHipCtx *c, bool full) {
     return ADDER_OK;
 }
 
-// Finds the largest persistent grid whose blocks are all resident at once.
+// Finds the largest persistent grid whose blocks are all resident at once, for every
+// instantiation of the frame kernel (the time mode can still change after creation).
 static int choose_grid(AdderHipCtx *c) {
-    int occ = 0;
-    HIPCHK(c, adder_frame_kernel_occupancy(&occ));
-    if (occ < 1) return fail(c, ADDER_E_HIP, "frame kernel does not fit on a CU");
-    occ = std::min(occ, 8);
     FrameArgs a;
     base_args(c, &a);
+    a.sc = make_consts(c, (float)c->p.ref_time, 0.0f);
+    int occ = 8;
+    for (uint32_t v = 0; v < 8; ++v) {
+        a.sc.collapse = v & 1u;
+        a.sc.abs_t = (v >> 1) & 1u;
+        a.generic = (v >> 2) | (a.sc.collapse ? 0u : 1u);
+        int o = 0;
+        HIPCHK(c, adder_frame_kernel_occupancy(&a, &o));
+        occ = std::min(occ, o);
+    }
+    if (occ < 1) return fail(c, ADDER_E_HIP, "frame kernel does not fit on a CU");
     a.census = c->census;
     a.spin_limit = 1u << 16;
     for (int k = occ; k >= 1; --k) {
         const uint32_t grid = c->num_cus * (uint32_t)k;
-        HIPCHK(c, hipMemsetAsync(c->census, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(c, adder_launch_frame(&a, grid, c->stream));
         uint32_t st = 0;
-        HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (st == 0) {
-            c->grid = std::min<uint32_t>(c->num_tiles, grid);
+        for (uint32_t v = 0; v < 8 && st == 0; ++v) {
+            a.sc.collapse = v & 1u;
+            a.sc.abs_t = (v >> 1) & 1u;
+            a.generic = (v >> 2) | (a.sc.collapse ? 0u : 1u);
+            HIPCHK(c, hipMemsetAsync(c->census, 0, sizeof(uint32_t), c->stream));
             HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, adder_launch_frame(&a, grid, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+        if (st == 0) {
+            c->blocks_per_cu = (uint32_t)k;
+            c->grid = std::min<uint32_t>(c->num_tiles, grid);
             return ADDER_OK;
         }
     }
@@ -290,6 +309,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
     c->n_units = (uint32_t)units;
     c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;
     c->n_pad = (size_t)c->num_tiles * kTileUnits;
+    c->num_groups = (c->num_tiles + kGroupTiles - 1) / kGroupTiles;
     c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
     c->max_depth = p.max_depth;
 
@@ -300,17 +320,18 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipEventCreate(&c->ev_start));
         HIPCHK(c, hipEventCreate(&c->ev_stop));
         HIPCHK(c, dalloc(&c->hdr, c->n_pad));
-        HIPCHK(c, dalloc(&c->tinteg, c->n_pad));
-        HIPCHK(c, dalloc(&c->tdt, c->n_pad));
         HIPCHK(c, dalloc(&c->lastf, c->n_pad));
-        HIPCHK(c, dalloc(&c->td, c->n_pad));
         HIPCHK(c, dalloc(&c->lv_integ, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->lv_dt, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
-        HIPCHK(c, dalloc(&c->lv_dbd, c->n_pad * c->max_depth));
+        HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->running, c->n_pad));
-        HIPCHK(c, dalloc(&c->desc[0], c->num_tiles));
-        HIPCHK(c, dalloc(&c->desc[1], c->num_tiles));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(c, dalloc(&c->agg[b], c->num_tiles));
+            HIPCHK(c, dalloc(&c->gsum[b], c->num_groups));
+        }
+        HIPCHK(c, dalloc(&c->worklist, c->n_pad));
+        HIPCHK(c, dalloc(&c->wl_count, 2));
         HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->census, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
@@ -391,7 +412,17 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     a.out_cap = out_cap;
     a.frame_offsets = d_offsets;
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
-    HIPCHK(c, hipMemsetAsync(c->desc[0], 0, c->num_tiles * sizeof(uint64_t), stream));
+    // frame f uses descriptor set f&1 and zeroes the other one for frame f+1
+    HIPCHK(c, hipMemsetAsync(c->agg[0], 0, c->num_tiles * sizeof(uint64_t), stream));
+    HIPCHK(c, hipMemsetAsync(c->gsum[0], 0, c->num_groups * sizeof(uint64_t), stream));
+    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t), stream));
+    // Pixels deeper than one fired level cannot occur when Collapse pops the root as soon as
+    // it has accumulated once (delta_t_max <= time_spanned): then the generic kernel is
+    // never needed (see fast_eligible in adder_pixel.hpp).
+    const bool generic_possible =
+        !(c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned);
+    const uint32_t generic_grid = std::min<uint32_t>(c->num_tiles * 4u, c->num_cus * 8u);
+    a.generic = generic_possible ? 1u : 0u;
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     float rt = c->running_t;
     c->timed_launches = 0;
@@ -405,11 +436,16 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     for (uint32_t f = 0; f < num_frames; ++f) {
         a.frame = d_frames + (size_t)f * c->n_units;
         a.frame_idx = f;
-        a.desc_cur = c->desc[f & 1u];
-        a.desc_next = c->desc[(f + 1u) & 1u];
+        a.agg_cur = c->agg[f & 1u];
+        a.agg_next = c->agg[(f + 1u) & 1u];
+        a.gsum_cur = c->gsum[f & 1u];
+        a.gsum_next = c->gsum[(f + 1u) & 1u];
+        a.wl_count_cur = c->wl_count + (f & 1u);
+        a.wl_count_next = c->wl_count + ((f + 1u) & 1u);
         a.sc = make_consts(c, time_spanned, rt);
         if (c->launch_timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], stream));
         HIPCHK(c, adder_launch_frame(&a, c->grid, stream));
+        if (generic_possible) HIPCHK(c, adder_launch_generic(&a, generic_grid, stream));
         if (c->launch_timing) {
             HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], stream));
             c->timed_launches = f + 1;

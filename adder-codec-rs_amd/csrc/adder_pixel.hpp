@@ -2,8 +2,8 @@
 //
 // Device code of the MI355X path (included by adder_kernels.hip).  It is written as
 // __host__ __device__ so that tests/cpu_sim can compile the *same* functions with g++
-// and diff them against the oracle without a GPU; nothing in the product calls the
-// host instantiation.
+// and diff them against the CPU reference restatement without a GPU; nothing in the
+// product calls the host instantiation.
 //
 // What it computes is what the reference's integrate_for_px does for one pixel and
 // one frame (adder-codec-rs/src/transcoder/source/video.rs:1318-1380, driving
@@ -15,20 +15,26 @@
 // STATE REPRESENTATION.  The reference keeps a SmallVec arena of `length` nodes.  In
 // FramePerfect mode the arena always has the shape
 //        [ fired_0, fired_1, ..., fired_{m-1}, tail ]        (length = m + 1)
-// where every fired_k carries a best_event and the tail carries none (a node gets
-// a best_event exactly when it fires, and firing creates a new tail behind it:
-// event_pixel_tree.rs:342-356; pop_top shifts left :199-207; pop_best leaves only
-// the old tail or a fresh node :249-273).  A tail with integration == 0 and
-// delta_t == 0 is "pristine": its d is rewritten from the next intensity before
-// it is used (:332-335), so nothing about it needs storing.  We therefore keep
+// where every fired_k carries a best_event and the tail carries none: a node gets a
+// best_event exactly when it fires, and firing creates a fresh tail behind it
+// (event_pixel_tree.rs:342-356); pop_top shifts left (:199-207); pop_best leaves only
+// the old tail or a fresh node (:249-273).  Moreover the tail is ALWAYS pristine
+// (integration 0, delta_t 0): a pristine tail gets d = floor(log2 I) (128 for I < 1)
+// right before it is visited (:332-335), so `0 + I >= 2^d` holds and it fires the first
+// time the walk reaches it (:427) -- it never accumulates, and FramePerfect hands the
+// child nothing (:468-469).  Consequently the zero-event and synthesised-event branches
+// of pop_top (:156-197) and the tail's zero event in pop_best (:225-230) are
+// unreachable here, and a pixel is fully described by
 //   hdr    : base_val | c_thresh<<8 | c_increase_counter<<16 | flags<<24
-//            flags = m (5 bits) | popped_dtm<<5 | tail_live<<6
-//   tail   : (d, integration, delta_t), meaningful iff tail_live
-//   level k: (d, integration, delta_t, best_d, best_delta_t) for k < m
+//            flags = m (5 bits) | popped_dtm<<5
+//   level k: (integration, delta_t, best_d, best_delta_t) for k < m; the node's d is a
+//            function of best_d (fired_d below)
 //   last_fired_t (AbsoluteT only);  running_t is identical for every pixel and is
 //   passed in.
 // need_to_pop_top is never set between frames (integrate_for_px pops at its end),
 // dtm_reached is recomputed by every integrate, `alt` is only asserted on.
+// tests/cpu_sim + tests/test_device_logic_cpu.py check all of this against the literal
+// restatement on randomised clips in every mode.
 #pragma once
 #include <stdint.h>
 
@@ -46,7 +52,6 @@ constexpr uint32_t kDEmpty = 255;
 
 constexpr uint32_t kFlagMMask = 0x1f;
 constexpr uint32_t kFlagPopped = 0x20;
-constexpr uint32_t kFlagTailLive = 0x40;
 
 constexpr uint32_t kMaxDepthLimit = 31;
 
@@ -62,13 +67,14 @@ struct StepConsts {
     uint32_t collapse;     // PixelMultiMode::Collapse
     uint32_t abs_t;        // TimeMode::AbsoluteT
     uint32_t max_depth;    // stored levels available
+    uint32_t ref_magic;    // floor(2^32 / ref_time) (ref_time >= 2), see ceil_to_ref()
 };
 
+// One fired node.
 struct Node {
     float integ;
     float dt;
     float bdt;    // best_event.delta_t
-    uint32_t d;
     uint32_t bd;  // best_event.d
 };
 
@@ -76,8 +82,6 @@ struct Node {
 struct PxState {
     uint32_t hdr;
     Node n0;  // level 0, valid iff m > 0
-    float tinteg, tdt;
-    uint32_t td;
     float lastf;
 };
 
@@ -90,10 +94,14 @@ ADDER_HD float pow2_d(uint32_t d) { return d >= 128u ? 0.0f : bits_to_f32((d + 1
 // get_d_from_intensity (event_pixel_tree.rs:482-499): floor(log2(trunc(x))) clamped to
 // D_MAX, 128 if x < 1.  For x >= 1 that is the unbiased binary32 exponent.
 ADDER_HD uint32_t get_d(float x) {
-    if (x < 1.0f) return kDZero;
-    uint32_t e = ((f32_to_bits(x) >> 23) & 0xffu) - 127u;
-    return e > kDMax ? kDMax : e;
+    const uint32_t e = ((f32_to_bits(x) >> 23) & 0xffu) - 127u;
+    return x < 1.0f ? kDZero : (e > kDMax ? kDMax : e);
 }
+
+// d of a FIRED node as a function of its best_event.d: firing sets best_d = nd and
+// d = nd + 1 (nd < D_MAX) or d = nd (nd = 127 / 128), and nothing but the next firing
+// changes either (event_pixel_tree.rs:438-461).  So stored levels keep only best_d.
+ADDER_HD uint32_t fired_d(uint32_t bd) { return bd < kDMax ? bd + 1u : bd; }
 
 // rustc `f32 as u32`: truncate toward zero, saturate, NaN -> 0
 ADDER_HD uint32_t f32_as_u32(float f) {
@@ -117,24 +125,26 @@ ADDER_HD float fsub(float a, float b) { return a - b; }
 ADDER_HD float fdiv(float a, float b) { return a / b; }
 #endif
 
-// integrate_main (event_pixel_tree.rs:418-479), FramePerfect.  Returns true if the
-// node fired (the caller then creates the fresh child / truncates the arena).
+// The firing arm of integrate_main (event_pixel_tree.rs:427-473), FramePerfect: node with
+// (integ, dt) and current d fires on intensity I over `time`; s = integ + I >= 2^d.
+ADDER_HD void node_fire(Node &n, uint32_t d, float s, float intensity, float time) {
+    const uint32_t nd = get_d(s);
+    float prop = fdiv(fsub(pow2_d(nd), n.integ), intensity);
+    if (nd == kDZero || d == kDZero || intensity < 1.1920929e-7f) prop = 1.0f;
+    n.bd = nd;
+    n.bdt = fadd(n.dt, fmul(time, prop));
+    if (nd < kDMax) {  // otherwise the node keeps (integ, dt) and d = nd
+        n.integ = s;
+        n.dt = fadd(n.dt, time);
+    }
+}
+
+// integrate_main for a stored level.  Returns true if it fired.
 ADDER_HD bool node_integrate(Node &n, float intensity, float time) {
+    const uint32_t d = fired_d(n.bd);
     const float s = fadd(n.integ, intensity);
-    if (s >= pow2_d(n.d)) {
-        const uint32_t nd = get_d(s);
-        float prop = fdiv(fsub(pow2_d(nd), n.integ), intensity);
-        if (nd == kDZero || n.d == kDZero || intensity < 1.1920929e-7f) prop = 1.0f;
-        n.bd = nd;
-        n.bdt = fadd(n.dt, fmul(time, prop));
-        if (nd < kDMax) {
-            n.integ = s;
-            n.dt = fadd(n.dt, time);
-            // smallest k > nd with 2^k > trunc(integration): nd = floor(log2(s)) so k = nd+1
-            n.d = nd + 1u;
-        } else {
-            n.d = nd;
-        }
+    if (s >= pow2_d(d)) {
+        node_fire(n, d, s, intensity, time);
         return true;
     }
     n.integ = s;
@@ -142,157 +152,216 @@ ADDER_HD bool node_integrate(Node &n, float intensity, float time) {
     return false;
 }
 
+// The (always pristine) tail being visited: it fires and becomes a stored level.
+ADDER_HD Node tail_fire(float intensity, float time) {
+    Node n;
+    n.integ = 0.0f;
+    n.dt = 0.0f;
+    n.bdt = 0.0f;
+    n.bd = 0u;
+    node_fire(n, get_d(intensity), intensity, intensity, time);
+    return n;
+}
+
+// floor-to-multiple helper for the FramePerfect last_fired_t rounding without a hardware
+// divide: magic = floor(2^32 / ref_time) (ref_time >= 2) gives q or q-1.
+ADDER_HD uint32_t ceil_to_ref(uint32_t lf, uint32_t ref_time, uint32_t magic) {
+    if (ref_time == 1u) return lf;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t q = __umulhi(lf, magic);
+#else
+    uint32_t q = (uint32_t)(((uint64_t)lf * magic) >> 32);
+#endif
+    uint32_t r = lf - q * ref_time;
+    if (r >= ref_time) {
+        r -= ref_time;
+        q += 1u;
+    }
+    return r == 0u ? lf : (q + 1u) * ref_time;
+}
+
 // delta_t_to_absolute_t (event_pixel_tree.rs:113-137), FramePerfect.  Returns the
 // event's `t` and updates last_fired_t.
+template <bool ABS_T>
 ADDER_HD uint32_t event_time(float ev_dt, float &lastf, const StepConsts &sc) {
-    if (sc.abs_t) {
+    if (ABS_T) {
         ev_dt = fadd(ev_dt, lastf);
-        lastf = ev_dt;
-        const uint32_t lf = f32_as_u32(lastf);
-        const uint32_t q = lf / sc.ref_time;
-        const uint32_t r = lf - q * sc.ref_time;
-        lastf = (r == 0u) ? (float)lf : (float)((q + 1u) * sc.ref_time);
+        lastf = (float)ceil_to_ref(f32_as_u32(ev_dt), sc.ref_time, sc.ref_magic);
     }
     return f32_as_u32(ev_dt);
 }
 
+// video.rs:1338-1340: frame_val outside [base (-sat) c_thresh, base (+sat) c_thresh].
+// v, base, c_thresh are u8, so the saturating bounds reduce to |v - base| > c_thresh.
 ADDER_HD bool contrast_exceeded(uint32_t v, uint32_t hdr) {
     const uint32_t base = hdr & 0xffu;
     const uint32_t cth = (hdr >> 8) & 0xffu;
-    const uint32_t lo = base > cth ? base - cth : 0u;  // saturating_sub
-    uint32_t hi = base + cth;                          // saturating_add
-    hi = hi > 255u ? 255u : hi;
-    return v < lo || v > hi;  // video.rs:1338-1340
+    const uint32_t diff = v > base ? v - base : base - v;
+    return diff > cth;
 }
 
-// Phase A: how many events will this pixel emit this frame?  Needs only the resident
-// part of the state (hdr, level 0, tail), so every lane can run it before the block's
-// ordered compaction assigns output positions.
+// need_to_pop_top after an integrate (event_pixel_tree.rs:394-396); the root is level 0.
+ADDER_HD bool root_needs_pop(const Node &root, bool popped, const StepConsts &sc) {
+    return fired_d(root.bd) == kDMax || (root.dt >= sc.dtm_f && !popped);
+}
+
+// ---------------------------------------------------------------------------------------
+// FAST PATH: pixels whose arena has at most ONE fired level before the step and at most
+// one after it.  That is every pixel, always, when PixelMultiMode::Collapse is combined
+// with delta_t_max <= time_spanned (the headline configuration: the root pops as soon as
+// it has accumulated once), and the common case otherwise.
+// ---------------------------------------------------------------------------------------
+
+// Events of one fast step, in emission order: A (pop_best's first event), B (the D_EMPTY
+// filler of a collapsed pop_best), C (pop_top's event).
+struct FastEvents {
+    uint32_t mask;  // bit0 A, bit1 B, bit2 C
+    uint32_t da, ta, db, tb, dc, tc;
+};
+
+template <bool COLLAPSE>
+ADDER_HD bool fast_eligible(const PxState &s, uint32_t v) {
+    const uint32_t flags = s.hdr >> 24;
+    const uint32_t m = flags & kFlagMMask;
+    if (m >= 2u) return false;
+    if (m == 0u) return true;
+    // m == 1: the walk must stop at level 0 (else the tail fires and creates level 1)
+    if (contrast_exceeded(v, s.hdr)) return true;        // arena restarts from the tail
+    if (COLLAPSE && (flags & kFlagPopped)) return true;  // only the root integrates
+    return fadd(s.n0.integ, (float)v) >= pow2_d(fired_d(s.n0.bd));
+}
+
+template <bool COLLAPSE, bool ABS_T>
+ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents &ev) {
+    const float I = (float)v;
+    const float T = sc.time_spanned;
+    const uint32_t hdr = s.hdr;
+    uint32_t base = hdr & 0xffu;
+    uint32_t cth = (hdr >> 8) & 0xffu;
+    uint32_t cctr = (hdr >> 16) & 0xffu;
+    bool has0 = ((hdr >> 24) & kFlagMMask) != 0u;  // m == 1
+    bool popped = (hdr & (kFlagPopped << 24)) != 0u;
+    Node n0 = s.n0;
+    ev.mask = 0u;
+
+    // ---- pop_best_events (event_pixel_tree.rs:213-287) ----
+    const uint32_t diff = v > base ? v - base : base - v;
+    if (diff > cth) {
+        if (has0) {
+            ev.da = n0.bd;
+            if (COLLAPSE && popped) {
+                ev.ta = f32_as_u32(ABS_T ? fadd(n0.bdt, s.lastf) : n0.bdt);
+                ev.db = kDEmpty;  // :259-263, carries running_t in every time mode
+                ev.tb = f32_as_u32(sc.running_t);
+                ev.mask = 3u;
+                s.lastf = sc.running_t;  // :257
+            } else {
+                ev.ta = event_time<ABS_T>(n0.bdt, s.lastf, sc);
+                ev.mask = 1u;
+            }
+        }
+        has0 = false;
+        popped = false;
+        base = v;
+    }
+
+    // ---- integrate (:317-413): arena index 0 is level 0 if present, else the tail ----
+    if (has0) {
+        node_integrate(n0, I, T);  // no fire => the walk stops here (fast_eligible)
+    } else {
+        n0 = tail_fire(I, T);
+        has0 = true;
+    }
+    const bool need_pop = root_needs_pop(n0, popped, sc);
+
+    if (sc.c_thresh_max != 0u && cth < sc.c_thresh_max) {  // :402-412, u8 saturating
+        if (cctr >= sc.velocity_m1) {
+            cth = cth >= 255u ? 255u : cth + 1u;
+            cctr = 0u;
+        } else {
+            cctr += sc.c_inc;
+            cctr = cctr > 255u ? 255u : cctr;
+        }
+    }
+
+    // ---- pop_top_event (:139-210): the root has a best event, shift the arena ----
+    if (need_pop) {
+        ev.dc = n0.bd;
+        ev.tc = event_time<ABS_T>(n0.bdt, s.lastf, sc);
+        ev.mask |= 4u;
+        has0 = false;
+        popped = true;
+    }
+
+    s.n0 = n0;
+    s.hdr = base | (cth << 8) | (cctr << 16) | ((has0 ? 1u : 0u) | (popped ? kFlagPopped : 0u)) << 24;
+}
+
+// ---------------------------------------------------------------------------------------
+// GENERIC PATH: any arena depth.  plan_count tells how many events the step will emit
+// (so the ordered compaction can reserve the slots before the step runs), exec_step runs it.
+// ---------------------------------------------------------------------------------------
 ADDER_HD uint32_t plan_count(const PxState &s, uint32_t v, const StepConsts &sc) {
     const float I = (float)v;
     const uint32_t flags = s.hdr >> 24;
     const uint32_t m = flags & kFlagMMask;
     bool popped = (flags & kFlagPopped) != 0u;
-    const bool live = (flags & kFlagTailLive) != 0u;
-    float tinteg = live ? s.tinteg : 0.0f;
-    float tdt = live ? s.tdt : 0.0f;
-
     uint32_t count = 0;
-    float r_integ, r_dt;
-    uint32_t r_d;
-    bool r_from_tail;
+    bool from_tail = (m == 0u);
     if (contrast_exceeded(v, s.hdr)) {
-        const uint32_t tz = (tinteg == 0.0f && tdt > 0.0f) ? 1u : 0u;
-        const uint32_t nloc = m + tz;
-        if (popped && sc.collapse && nloc > 0u) {
-            count = 2u;
-            tinteg = 0.0f;
-            tdt = 0.0f;
-        } else {
-            count = nloc;
-            if (tz) tdt = 0.0f;
-        }
+        count = (popped && sc.collapse && m > 0u) ? 2u : m;
         popped = false;
-        r_from_tail = true;
-    } else {
-        r_from_tail = (m == 0u);
+        from_tail = true;
     }
-    if (r_from_tail) {
-        r_integ = tinteg;
-        r_dt = tdt;
-        r_d = (tinteg == 0.0f && tdt == 0.0f) ? get_d(I) : s.td;
-    } else {
-        r_integ = s.n0.integ;
-        r_dt = s.n0.dt;
-        r_d = s.n0.d;
-    }
-    // root's integrate_main outcome -> need_to_pop_top (event_pixel_tree.rs:394-396)
-    const float sum = fadd(r_integ, I);
-    uint32_t d_after;
-    float dt_after;
-    if (sum >= pow2_d(r_d)) {
-        const uint32_t nd = get_d(sum);
-        if (nd < kDMax) {
-            d_after = nd + 1u;
-            dt_after = fadd(r_dt, sc.time_spanned);
-        } else {
-            d_after = nd;
-            dt_after = r_dt;
-        }
-    } else {
-        d_after = r_d;
-        dt_after = fadd(r_dt, sc.time_spanned);
-    }
-    if (d_after == kDMax || (dt_after >= sc.dtm_f && !popped)) count += 1u;
+    Node r = s.n0;
+    if (from_tail)
+        r = tail_fire(I, sc.time_spanned);
+    else
+        node_integrate(r, I, sc.time_spanned);
+    if (root_needs_pop(r, popped, sc)) count += 1u;
     return count;
 }
 
-// Phase B: the full step.  `deep` gives access to levels k >= 1 of this pixel
-// (load(k, Node&), store(k, const Node&)); `emit(d, t)` appends one event of this
-// pixel (in order).  Returns false if the pixel needed more than sc.max_depth levels.
-template <class Deep, class Emit>
-ADDER_HD bool exec_step(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
+// `deep` gives access to levels k >= 1 of this pixel (load(k, Node&), store(k, const
+// Node&)); `emit(d, t)` appends one event of this pixel (in order).  Returns false if the
+// pixel needed more than sc.max_depth levels.
+template <bool ABS_T, class Deep, class Emit>
+ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
     const float I = (float)v;
     const float T = sc.time_spanned;
     uint32_t flags = s.hdr >> 24;
     uint32_t m = flags & kFlagMMask;
     bool popped = (flags & kFlagPopped) != 0u;
-    if (!(flags & kFlagTailLive)) {
-        s.tinteg = 0.0f;
-        s.tdt = 0.0f;
-    }
     uint32_t base = s.hdr & 0xffu;
     uint32_t cth = (s.hdr >> 8) & 0xffu;
     uint32_t cctr = (s.hdr >> 16) & 0xffu;
     bool ok = true;
 
-    // ---- pop_best_events (event_pixel_tree.rs:213-287) when the contrast test trips ----
+    // ---- pop_best_events ----
     if (contrast_exceeded(v, s.hdr)) {
-        const bool tz = (s.tinteg == 0.0f && s.tdt > 0.0f);  // zero event of the tail (:225-230)
-        const uint32_t nloc = m + (tz ? 1u : 0u);
-        if (popped && sc.collapse && nloc > 0u) {
-            // :249-265  keep the first local event, then the D_EMPTY filler at running_t
-            uint32_t fd;
-            float fdt;
-            if (m > 0u) {
-                fd = s.n0.bd;
-                fdt = s.n0.bdt;
-            } else {
-                fd = kDZero;
-                fdt = s.tdt;
-            }
-            if (sc.abs_t) fdt = fadd(fdt, s.lastf);
-            emit(fd, f32_as_u32(fdt));
-            s.lastf = sc.running_t;  // :257 (overrides the chain's last_fired_t updates)
+        if (popped && sc.collapse && m > 0u) {
+            emit(s.n0.bd, f32_as_u32(ABS_T ? fadd(s.n0.bdt, s.lastf) : s.n0.bdt));
+            s.lastf = sc.running_t;
             emit(kDEmpty, f32_as_u32(sc.running_t));
-            s.tinteg = 0.0f;  // arena[0] = PixelNode::new(intensity)
-            s.tdt = 0.0f;
         } else {
-            if (m > 0u) emit(s.n0.bd, event_time(s.n0.bdt, s.lastf, sc));
+            if (m > 0u) emit(s.n0.bd, event_time<ABS_T>(s.n0.bdt, s.lastf, sc));
             for (uint32_t k = 1; k < m; ++k) {
                 Node nk;
                 deep.load(k, nk);
-                emit(nk.bd, event_time(nk.bdt, s.lastf, sc));
+                emit(nk.bd, event_time<ABS_T>(nk.bdt, s.lastf, sc));
             }
-            if (tz) {
-                emit(kDZero, event_time(s.tdt, s.lastf, sc));
-                s.tdt = 0.0f;  // get_zero_event (:103)
-            }
-            // arena.swap(0, length-1): the old tail becomes the root (:269)
         }
         m = 0u;
         popped = false;
-        base = v;  // video.rs:1350
+        base = v;
     }
 
-    // ---- integrate (event_pixel_tree.rs:317-413) ----
-    if (s.tinteg == 0.0f && s.tdt == 0.0f) s.td = get_d(I);  // pristine tail (:332-335)
+    // ---- integrate: walk the fired levels from the root; the first one that fires
+    // truncates the arena behind it; if none does, the tail fires and becomes level m ----
     bool stop = false;
     if (m > 0u) {
         if (node_integrate(s.n0, I, T)) {
-            m = 1u;  // length = idx + 2, fresh child
-            s.tinteg = 0.0f;
-            s.tdt = 0.0f;
+            m = 1u;
             stop = true;
         } else if (popped && sc.collapse) {
             stop = true;  // :360-362 only the root keeps integrating
@@ -304,42 +373,25 @@ ADDER_HD bool exec_step(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep
             deep.store(k, nk);
             if (fired) {
                 m = k + 1u;
-                s.tinteg = 0.0f;
-                s.tdt = 0.0f;
                 stop = true;
             }
         }
     }
     if (!stop) {
-        Node t;
-        t.integ = s.tinteg;
-        t.dt = s.tdt;
-        t.d = s.td;
-        t.bd = 0u;
-        t.bdt = 0.0f;
-        if (node_integrate(t, I, T)) {
-            if (m >= sc.max_depth) {
-                ok = false;  // would need another stored level
-            } else {
-                if (m == 0u)
-                    s.n0 = t;
-                else
-                    deep.store(m, t);
-                m += 1u;
-            }
-            s.tinteg = 0.0f;
-            s.tdt = 0.0f;
+        const Node t = tail_fire(I, T);
+        if (m >= sc.max_depth) {
+            ok = false;  // would need another stored level
         } else {
-            s.tinteg = t.integ;
-            s.tdt = t.dt;
+            if (m == 0u)
+                s.n0 = t;
+            else
+                deep.store(m, t);
+            m += 1u;
         }
     }
-    const float root_dt = m > 0u ? s.n0.dt : s.tdt;
-    const uint32_t root_d = m > 0u ? s.n0.d : s.td;
-    const bool need_pop = root_d == kDMax || (root_dt >= sc.dtm_f && !popped);  // :394-396
+    const bool need_pop = m > 0u && root_needs_pop(s.n0, popped, sc);
 
-    // contrast-threshold adaptation (:402-412), u8 saturating arithmetic
-    if (cth < sc.c_thresh_max) {
+    if (sc.c_thresh_max != 0u && cth < sc.c_thresh_max) {
         if (cctr >= sc.velocity_m1) {
             cth = cth >= 255u ? 255u : cth + 1u;
             cctr = 0u;
@@ -349,41 +401,31 @@ ADDER_HD bool exec_step(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep
         }
     }
 
-    // ---- pop_top_event (event_pixel_tree.rs:139-210) ----
+    // ---- pop_top_event ----
     if (need_pop) {
-        uint32_t ed;
-        float edt;
-        if (m > 0u) {
-            ed = s.n0.bd;
-            edt = s.n0.bdt;
-            for (uint32_t k = 1; k < m; ++k) {  // shift the arena left by one
-                Node nk;
-                deep.load(k, nk);
-                if (k == 1u)
-                    s.n0 = nk;
-                else
-                    deep.store(k - 1u, nk);
-            }
-            m -= 1u;
-        } else if (s.tinteg == 0.0f && s.tdt > 0.0f) {
-            ed = kDZero;  // get_zero_event(0, Some(next_intensity))
-            edt = s.tdt;
-            s.tdt = 0.0f;
-            s.td = get_d(I);
-        } else {
-            ed = s.tinteg < 1.0f ? kDZero : get_d(s.tinteg);  // synthesised best (:164-185)
-            edt = s.tdt;
-            s.tinteg = 0.0f;  // root <- fresh child
-            s.tdt = 0.0f;
+        const uint32_t ed = s.n0.bd;
+        const float edt = s.n0.bdt;
+        for (uint32_t k = 1; k < m; ++k) {  // shift the arena left by one
+            Node nk;
+            deep.load(k, nk);
+            if (k == 1u)
+                s.n0 = nk;
+            else
+                deep.store(k - 1u, nk);
         }
+        m -= 1u;
         popped = true;
-        emit(ed, event_time(edt, s.lastf, sc));
+        emit(ed, event_time<ABS_T>(edt, s.lastf, sc));
     }
 
-    const bool live = !(s.tinteg == 0.0f && s.tdt == 0.0f);
-    flags = m | (popped ? kFlagPopped : 0u) | (live ? kFlagTailLive : 0u);
+    flags = m | (popped ? kFlagPopped : 0u);
     s.hdr = base | (cth << 8) | (cctr << 16) | (flags << 24);
     return ok;
+}
+
+template <class Deep, class Emit>
+ADDER_HD bool exec_step(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
+    return sc.abs_t ? exec_step_t<true>(s, v, sc, deep, emit) : exec_step_t<false>(s, v, sc, deep, emit);
 }
 
 // u8::get_frame_value for the running_intensities side plane (video.rs:713-730,

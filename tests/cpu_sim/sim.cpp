@@ -31,12 +31,13 @@ struct Sim {
     uint32_t collapse, abs_t;
     float running_t;
     std::vector<uint32_t> hdr;
-    std::vector<float> tinteg, tdt, lastf;
-    std::vector<uint8_t> td;
+    std::vector<float> lastf;
     std::vector<float> lv_integ, lv_dt, lv_bdt;  // [level][unit]
-    std::vector<uint16_t> lv_dbd;
+    std::vector<uint8_t> lv_bd;
     uint64_t plan_mismatch;
     uint32_t max_m;
+    int use_fast;
+    uint64_t fast_steps, generic_steps, live_seen;
 };
 
 struct DeepAcc {
@@ -47,15 +48,14 @@ struct DeepAcc {
         n.integ = s->lv_integ[i];
         n.dt = s->lv_dt[i];
         n.bdt = s->lv_bdt[i];
-        n.d = s->lv_dbd[i] & 0xff;
-        n.bd = s->lv_dbd[i] >> 8;
+        n.bd = s->lv_bd[i];
     }
     void store(uint32_t k, const Node &n) {
         size_t i = (size_t)k * s->N + u;
         s->lv_integ[i] = n.integ;
         s->lv_dt[i] = n.dt;
         s->lv_bdt[i] = n.bdt;
-        s->lv_dbd[i] = (uint16_t)(n.d | (n.bd << 8));
+        s->lv_bd[i] = (uint8_t)n.bd;
     }
 };
 
@@ -87,16 +87,15 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->collapse = multi_mode == 1; s->abs_t = time_mode == 1;
     s->running_t = 0.0f;
     s->hdr.assign(s->N, 0u | (10u << 8) | (1u << 16));  // base 0, c_thresh 10, counter 1
-    s->tinteg.assign(s->N, 0.0f);
-    s->tdt.assign(s->N, 0.0f);
     s->lastf.assign(s->N, 0.0f);
-    s->td.assign(s->N, 0);
     s->lv_integ.assign(s->N * max_depth, 0.0f);
     s->lv_dt.assign(s->N * max_depth, 0.0f);
     s->lv_bdt.assign(s->N * max_depth, 0.0f);
-    s->lv_dbd.assign(s->N * max_depth, 0);
+    s->lv_bd.assign(s->N * max_depth, 0);
     s->plan_mismatch = 0;
     s->max_m = 0;
+    s->use_fast = 1;
+    s->fast_steps = s->generic_steps = s->live_seen = 0;
     return s;
 }
 void sim_free(Sim *s) { delete s; }
@@ -107,6 +106,10 @@ void sim_reset_c_thresh(Sim *s, uint8_t baseline) {
 void sim_set_delta_t_max(Sim *s, uint32_t dtm) { s->dtm = dtm; }
 uint64_t sim_plan_mismatches(const Sim *s) { return s->plan_mismatch; }
 uint32_t sim_max_m(const Sim *s) { return s->max_m; }
+void sim_set_use_fast(Sim *s, int on) { s->use_fast = on; }
+uint64_t sim_fast_steps(const Sim *s) { return s->fast_steps; }
+uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
+uint64_t sim_live_seen(const Sim *s) { return s->live_seen; }
 
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
@@ -121,6 +124,7 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     sc.collapse = s->collapse;
     sc.abs_t = s->abs_t;
     sc.max_depth = s->max_depth;
+    sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
     int rc = 0;
     Emitter em;
     em.out = out; em.cap = cap; em.pos = 0;
@@ -133,33 +137,41 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                 uint32_t m = (p.hdr >> 24) & kFlagMMask;
                 if (m > 0) {
                     p.n0.integ = s->lv_integ[u]; p.n0.dt = s->lv_dt[u]; p.n0.bdt = s->lv_bdt[u];
-                    p.n0.d = s->lv_dbd[u] & 0xff; p.n0.bd = s->lv_dbd[u] >> 8;
+                    p.n0.bd = s->lv_bd[u];
                 } else {
                     // garbage on purpose: level 0 must not be read when m == 0
-                    p.n0.integ = -12345.0f; p.n0.dt = -777.0f; p.n0.bdt = -999.0f; p.n0.d = 99; p.n0.bd = 77;
-                }
-                if ((p.hdr >> 24) & kFlagTailLive) {
-                    p.tinteg = s->tinteg[u]; p.tdt = s->tdt[u]; p.td = s->td[u];
-                } else {
-                    p.tinteg = -5.0f; p.tdt = -6.0f; p.td = 55;
+                    p.n0.integ = -12345.0f; p.n0.dt = -777.0f; p.n0.bdt = -999.0f; p.n0.bd = 77;
                 }
                 p.lastf = s->abs_t ? s->lastf[u] : -1.0f;
                 uint32_t v = frame[u];
                 uint32_t planned = plan_count(p, v, sc);
                 size_t before = em.pos;
                 em.x = (uint16_t)x; em.y = (uint16_t)(y + s->row_begin); em.c = s->C == 1 ? 0xFF : (uint8_t)c;
-                DeepAcc deep{s, u};
-                if (!exec_step(p, v, sc, deep, em)) rc = -5;
+                bool fast = false;
+                if (s->use_fast)
+                    fast = s->collapse ? fast_eligible<true>(p, v) : fast_eligible<false>(p, v);
+                if (fast) {
+                    FastEvents fe;
+                    if (s->collapse && s->abs_t) step_fast<true, true>(p, v, sc, fe);
+                    else if (s->collapse) step_fast<true, false>(p, v, sc, fe);
+                    else if (s->abs_t) step_fast<false, true>(p, v, sc, fe);
+                    else step_fast<false, false>(p, v, sc, fe);
+                    if (fe.mask & 1u) em(fe.da, fe.ta);
+                    if (fe.mask & 2u) em(fe.db, fe.tb);
+                    if (fe.mask & 4u) em(fe.dc, fe.tc);
+                    s->fast_steps++;
+                } else {
+                    DeepAcc deep{s, u};
+                    if (!exec_step(p, v, sc, deep, em)) rc = -5;
+                    s->generic_steps++;
+                }
                 if (em.pos - before != planned) s->plan_mismatch++;
                 s->hdr[u] = p.hdr;
                 m = (p.hdr >> 24) & kFlagMMask;
                 if (m > s->max_m) s->max_m = m;
                 if (m > 0) {
                     s->lv_integ[u] = p.n0.integ; s->lv_dt[u] = p.n0.dt; s->lv_bdt[u] = p.n0.bdt;
-                    s->lv_dbd[u] = (uint16_t)(p.n0.d | (p.n0.bd << 8));
-                }
-                if ((p.hdr >> 24) & kFlagTailLive) {
-                    s->tinteg[u] = p.tinteg; s->tdt[u] = p.tdt; s->td[u] = (uint8_t)p.td;
+                    s->lv_bd[u] = (uint8_t)p.n0.bd;
                 }
                 if (s->abs_t) s->lastf[u] = p.lastf;
             }

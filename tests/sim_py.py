@@ -39,6 +39,11 @@ def lib():
     L.sim_plan_mismatches.argtypes = [vp]
     L.sim_max_m.restype = u32
     L.sim_max_m.argtypes = [vp]
+    L.sim_set_use_fast.argtypes = [vp, i32]
+    L.sim_fast_steps.restype = C.c_uint64
+    L.sim_fast_steps.argtypes = [vp]
+    L.sim_generic_steps.restype = C.c_uint64
+    L.sim_generic_steps.argtypes = [vp]
     L.sim_integrate.restype = i32
     L.sim_integrate.argtypes = [vp, vp, f32, vp, sz, C.POINTER(sz)]
     _lib = L
@@ -68,6 +73,17 @@ class Sim:
 
     def set_delta_t_max(self, dtm):
         self.L.sim_set_delta_t_max(self.h, dtm)
+
+    def set_use_fast(self, on):
+        self.L.sim_set_use_fast(self.h, int(on))
+
+    @property
+    def fast_steps(self):
+        return self.L.sim_fast_steps(self.h)
+
+    @property
+    def generic_steps(self):
+        return self.L.sim_generic_steps(self.h)
 
     @property
     def plan_mismatches(self):
