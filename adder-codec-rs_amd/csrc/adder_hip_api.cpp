@@ -40,14 +40,15 @@ struct AdderHipCtx {
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // compaction scratch
-    uint64_t *agg[2] = {nullptr, nullptr};   // per-tile event counts (double-buffered by frame parity)
-    uint64_t *gsum[2] = {nullptr, nullptr};  // per-group sums
-    uint2 *worklist = nullptr;               // pixels for the generic kernel
-    uint32_t *wl_count = nullptr;            // [2]
-    uint32_t num_groups = 0;
-    uint32_t blocks_per_cu = 0;
+    // ordered compaction scratch, double-buffered by frame parity so that the expand kernel
+    // of frame f can overlap the frame kernel of frame f+1
+    uint2 *park[2] = {nullptr, nullptr};       // [num_waves][kParkPerWave]
+    uint32_t *wtot[2] = {nullptr, nullptr};    // [num_waves]
+    uint32_t *wpref[2] = {nullptr, nullptr};   // [num_waves]
+    uint2 *worklist = nullptr;                 // pixels for the generic kernel
+    uint32_t *wl_count = nullptr;
+    uint32_t num_waves = 0;
     uint32_t *status = nullptr;   // device status word
-    uint32_t *census = nullptr;   // device census counter
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
     size_t d_offsets_cap = 0;       // all *_cap below are in BYTES
     // staging for the host-buffer API
@@ -107,7 +108,7 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_bd,   c->running, c->agg[0], c->agg[1], c->gsum[0], c->gsum[1], c->worklist, c->wl_count, c->status,   c->census,
+                    c->lv_bdt,  c->lv_bd,   c->running, c->park[0], c->park[1], c->wtot[0], c->wtot[1], c->wpref[0], c->wpref[1], c->worklist, c->wl_count, c->status,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -169,14 +170,13 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
-    a->census = nullptr;
+    a->wl_count = c->wl_count;
     a->n_units = c->n_units;
-    a->num_tiles = c->num_tiles;
+    a->num_waves = c->num_waves;
     a->width = c->p.width;
     a->channels = c->p.channels;
     a->rowlen = (uint32_t)c->p.width * c->p.channels;
     a->row_begin = c->p.row_begin;
-    a->spin_limit = 1u << 22;
     if (const char *ab = getenv("ADDER_HIP_ABLATE")) a->ablate = (uint32_t)atoi(ab);  // timing experiments only
 }
 
@@ -197,57 +197,12 @@ static int init_state(AdderHipCtx *c, bool full) {
     HIPCHK(c, hipMemsetAsync(c->lv_bd, 0, c->n_pad * c->max_depth, c->stream));
     HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
     }
-    for (int b = 0; b < 2; ++b) {
-        HIPCHK(c, hipMemsetAsync(c->agg[b], 0, c->num_tiles * sizeof(uint64_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->gsum[b], 0, c->num_groups * sizeof(uint64_t), c->stream));
-    }
-    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
     c->running_t = 0.0f;
     c->frames_done = 0;
     c->poisoned = false;
     return ADDER_OK;
-}
-
-// Finds the largest persistent grid whose blocks are all resident at once, for every
-// instantiation of the frame kernel (the time mode can still change after creation).
-static int choose_grid(AdderHipCtx *c) {
-    FrameArgs a;
-    base_args(c, &a);
-    a.sc = make_consts(c, (float)c->p.ref_time, 0.0f);
-    int occ = 8;
-    for (uint32_t v = 0; v < 8; ++v) {
-        a.sc.collapse = v & 1u;
-        a.sc.abs_t = (v >> 1) & 1u;
-        a.generic = (v >> 2) | (a.sc.collapse ? 0u : 1u);
-        int o = 0;
-        HIPCHK(c, adder_frame_kernel_occupancy(&a, &o));
-        occ = std::min(occ, o);
-    }
-    if (occ < 1) return fail(c, ADDER_E_HIP, "frame kernel does not fit on a CU");
-    a.census = c->census;
-    a.spin_limit = 1u << 16;
-    for (int k = occ; k >= 1; --k) {
-        const uint32_t grid = c->num_cus * (uint32_t)k;
-        uint32_t st = 0;
-        for (uint32_t v = 0; v < 8 && st == 0; ++v) {
-            a.sc.collapse = v & 1u;
-            a.sc.abs_t = (v >> 1) & 1u;
-            a.generic = (v >> 2) | (a.sc.collapse ? 0u : 1u);
-            HIPCHK(c, hipMemsetAsync(c->census, 0, sizeof(uint32_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
-            HIPCHK(c, adder_launch_frame(&a, grid, c->stream));
-            HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
-        if (st == 0) {
-            c->blocks_per_cu = (uint32_t)k;
-            c->grid = std::min<uint32_t>(c->num_tiles, grid);
-            return ADDER_OK;
-        }
-    }
-    return fail(c, ADDER_E_HIP, "no resident grid size found for the frame kernel");
 }
 
 extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
@@ -309,7 +264,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
     c->n_units = (uint32_t)units;
     c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;
     c->n_pad = (size_t)c->num_tiles * kTileUnits;
-    c->num_groups = (c->num_tiles + kGroupTiles - 1) / kGroupTiles;
+    c->num_waves = (uint32_t)(c->n_pad / kWaveUnits);
     c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
     c->max_depth = p.max_depth;
 
@@ -327,17 +282,17 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->running, c->n_pad));
         for (int b = 0; b < 2; ++b) {
-            HIPCHK(c, dalloc(&c->agg[b], c->num_tiles));
-            HIPCHK(c, dalloc(&c->gsum[b], c->num_groups));
+            HIPCHK(c, dalloc(&c->park[b], (size_t)c->num_waves * kParkPerWave));
+            HIPCHK(c, dalloc(&c->wtot[b], c->num_waves));
+            HIPCHK(c, dalloc(&c->wpref[b], c->num_waves));
         }
         HIPCHK(c, dalloc(&c->worklist, c->n_pad));
-        HIPCHK(c, dalloc(&c->wl_count, 2));
+        HIPCHK(c, dalloc(&c->wl_count, 1));
         HIPCHK(c, dalloc(&c->status, 1));
-        HIPCHK(c, dalloc(&c->census, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c, true); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        return choose_grid(c);
+        return ADDER_OK;
     };
     rc = setup();
     if (rc != ADDER_OK) {
@@ -397,7 +352,6 @@ extern "C" size_t adder_hip_max_events_per_frame(const AdderHipCtx *c) {
 static int status_to_code(AdderHipCtx *c, uint32_t st) {
     if (st == 0) return ADDER_OK;
     c->poisoned = true;
-    if (st & kStatusTimeout) return fail(c, ADDER_E_TIMEOUT, "a bounded in-kernel wait expired");
     if (st & kStatusDepth)
         return fail(c, ADDER_E_ARENA_DEPTH, "a pixel needed more than max_depth=%u stored nodes", c->max_depth);
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
@@ -412,10 +366,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     a.out_cap = out_cap;
     a.frame_offsets = d_offsets;
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
-    // frame f uses descriptor set f&1 and zeroes the other one for frame f+1
-    HIPCHK(c, hipMemsetAsync(c->agg[0], 0, c->num_tiles * sizeof(uint64_t), stream));
-    HIPCHK(c, hipMemsetAsync(c->gsum[0], 0, c->num_groups * sizeof(uint64_t), stream));
-    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t), stream));
     // Pixels deeper than one fired level cannot occur when Collapse pops the root as soon as
     // it has accumulated once (delta_t_max <= time_spanned): then the generic kernel is
     // never needed (see fast_eligible in adder_pixel.hpp).
@@ -436,20 +386,19 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     for (uint32_t f = 0; f < num_frames; ++f) {
         a.frame = d_frames + (size_t)f * c->n_units;
         a.frame_idx = f;
-        a.agg_cur = c->agg[f & 1u];
-        a.agg_next = c->agg[(f + 1u) & 1u];
-        a.gsum_cur = c->gsum[f & 1u];
-        a.gsum_next = c->gsum[(f + 1u) & 1u];
-        a.wl_count_cur = c->wl_count + (f & 1u);
-        a.wl_count_next = c->wl_count + ((f + 1u) & 1u);
+        a.park = c->park[f & 1u];
+        a.wtot = c->wtot[f & 1u];
+        a.wpref = c->wpref[f & 1u];
         a.sc = make_consts(c, time_spanned, rt);
         if (c->launch_timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], stream));
-        HIPCHK(c, adder_launch_frame(&a, c->grid, stream));
-        if (generic_possible) HIPCHK(c, adder_launch_generic(&a, generic_grid, stream));
-        if (c->launch_timing) {
+        HIPCHK(c, adder_launch_frame(&a, stream));
+        if (c->launch_timing) {  // the pair brackets the frame kernel (K1) only
             HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], stream));
             c->timed_launches = f + 1;
         }
+        HIPCHK(c, adder_launch_scan(&a, stream));
+        HIPCHK(c, adder_launch_expand(&a, stream));
+        if (generic_possible) HIPCHK(c, adder_launch_generic(&a, generic_grid, stream));
         rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
     }
     HIPCHK(c, hipEventRecord(c->ev_stop, stream));

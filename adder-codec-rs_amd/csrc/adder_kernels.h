@@ -11,14 +11,14 @@ namespace adder {
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kUnitsPerLane = 4;                              // pixel-channels per lane
-constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // 1024 units per tile
-constexpr uint32_t kGroupTiles = 32;                               // tiles per prefix group
+constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // 1024 units per block
+constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // 256 units per wave segment
 constexpr uint32_t kSlotsPerLane = 12;                             // 4 px x 3 fast-path events
+constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
 constexpr uint32_t kStatusDepth = 2u;     // a pixel needed more than max_depth stored levels
-constexpr uint32_t kStatusTimeout = 4u;   // a bounded wait expired
 
 struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint16_t x, y;
@@ -27,6 +27,7 @@ struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint32_t t;
 };
 
+// Everything the per-frame kernels need.  `f` = frame index inside the batch.
 struct FrameArgs {
     // structure-of-arrays pixel state, resident in HBM across frames
     uint32_t *hdr;      // [n_pad]
@@ -41,23 +42,20 @@ struct FrameArgs {
     const uint8_t *frame;  // n_units bytes, packed [rows][width][channels]
     AdderEventPod *out;
     uint64_t out_cap;
-    uint64_t *frame_offsets;  // [frame_idx] is read, [frame_idx+1] is written
+    uint64_t *frame_offsets;  // [frame_idx] is read, [frame_idx+1] is written (by the scan kernel)
     uint32_t frame_idx;
-    // ordered compaction: per-tile and per-group event counts of this frame
-    uint64_t *agg_cur;    // [num_tiles]  {1<<32 | count}, zeroed beforehand
-    uint64_t *agg_next;   // zeroed by this launch for the next frame
-    uint64_t *gsum_cur;   // [num_groups] {1<<32 | sum over the group's tiles}
-    uint64_t *gsum_next;
-    // pixels that need the generic step this frame: {unit, frame-relative output position}
+    // ordered compaction, stage 1 (frame kernel): per wave segment of 256 units
+    uint2 *park;          // [num_waves][kParkPerWave] {t, d | unit_in_wave<<8 | final_offset_in_wave<<16}
+    uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked events (high 16)
+    // stage 2 (scan kernel): exclusive prefix of the low halves of wtot
+    uint32_t *wpref;      // [num_waves]
+    // pixels that need the generic step this frame: {unit, final offset inside its wave segment}
     uint2 *worklist;
-    uint32_t *wl_count_cur;
-    uint32_t *wl_count_next;
+    uint32_t *wl_count;   // zeroed by the scan kernel of the previous frame / by the host
     uint32_t *status;
-    uint32_t *census;     // non-null: residency census only
     uint32_t n_units;
-    uint32_t num_tiles;
+    uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t spin_limit;
     uint32_t ablate;      // experiments only (ADDER_HIP_ABLATE)
     uint32_t generic;     // 1: pixels deeper than one fired level are possible (worklist + generic kernel)
     StepConsts sc;
@@ -66,9 +64,10 @@ struct FrameArgs {
 }  // namespace adder
 
 extern "C" {
-hipError_t adder_launch_frame(const adder::FrameArgs *args, uint32_t grid, hipStream_t stream);
+hipError_t adder_launch_frame(const adder::FrameArgs *args, hipStream_t stream);    // K1
+hipError_t adder_launch_scan(const adder::FrameArgs *args, hipStream_t stream);     // Ks
+hipError_t adder_launch_expand(const adder::FrameArgs *args, hipStream_t stream);   // K2
 hipError_t adder_launch_generic(const adder::FrameArgs *args, uint32_t grid, hipStream_t stream);
-hipError_t adder_frame_kernel_occupancy(const adder::FrameArgs *args, int *blocks_per_cu);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

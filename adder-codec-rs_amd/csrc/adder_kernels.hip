@@ -1,31 +1,28 @@
 // adder_kernels.hip -- CDNA4 (gfx950) kernels of the framed->ADDER integration path.
 //
-// One launch of adder_frame_kernel does for one input frame what the reference's
-// rayon loop does (adder-codec-rs/src/transcoder/source/video.rs:677-734): every
-// pixel-channel runs integrate_for_px (video.rs:1318-1380) and the emitted events
+// One input frame goes through a wait-free three-kernel pipeline that does what the
+// reference's rayon loop does (adder-codec-rs/src/transcoder/source/video.rs:677-734):
+// every pixel-channel runs integrate_for_px (video.rs:1318-1380) and the emitted events
 // are gathered in raster order (y, x, c, per-pixel emission order).
 //
-// Mapping to the hardware (memory-bound, no MFMA):
-//   * structure-of-arrays pixel state resident in HBM across frames (fields: see
-//     adder_pixel.hpp).  A lane owns 4 consecutive pixel-channels, so every state access
-//     is a 16-byte-per-lane coalesced vector load/store and the frame row is read as one
-//     dword per lane.  Level-planar arena storage: plane k holds every pixel's k-th fired
-//     node, so only the planes a wave actually needs are touched (the headline mode never
-//     goes past plane 0).
-//   * the lean step (step_fast) runs once per pixel, its <= 3 events are parked in a
-//     lane-private LDS stack (conflict-free [slot][thread] layout);
-//   * ordered stream compaction in the same pass: per-lane counts -> wave prefix
-//     (cross-lane shuffles) -> block prefix in LDS -> tile prefix from a TWO-LEVEL scan over
-//     8-byte {valid,count} descriptors (per tile, and per group of 32 tiles) that are
-//     read/written with relaxed agent-scope atomics -- the data is the flag, so no fences,
-//     and every tile needs exactly two dependent hops instead of a serial look-back walk;
-//     then each lane copies its parked events to their final slots;
-//   * a persistent grid (<= resident capacity, verified by a census launch) strides over
-//     the 1024-unit tiles, so a wait can never be on a block that is not running; every
-//     wait is bounded and reports ADDER_E_TIMEOUT instead of hanging.
-//   * pixels whose arena is deeper than one fired level (Normal mode, delta_t_max >
-//     time_spanned) are listed in a worklist with their reserved output range and stepped
-//     by adder_generic_kernel right after (exec_step: the full arena walk).
+//   K1 adder_frame_kernel   one lane = 4 consecutive pixel-channels.  Loads the header
+//        word, the frame bytes and level 0 of the arena as 16-byte-per-lane vectors
+//        (structure-of-arrays state resident in HBM across frames, level-planar: plane
+//        k holds every pixel's k-th fired node, so the headline mode never goes past
+//        plane 0), runs the lean step (step_fast) once per pixel, parks its <= 3 events
+//        in a lane-private LDS stack, stores the state, then compacts the events of the
+//        WAVE (ballot-free prefix over cross-lane shuffles, no barrier, no atomics) into
+//        the wave's scratch segment and writes the segment's event count.
+//   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block).
+//   K2 adder_expand_kernel  reads the parked events linearly and writes each 12-byte
+//        event to its final slot of the ordered stream (coordinates from the unit index).
+//
+// No kernel waits on another workgroup, so there is no residency requirement, no spin
+// loop and nothing that can hang; K2 of frame f overlaps K1 of frame f+1 on a second
+// stream.  Pixels whose arena is deeper than one fired level (Normal mode, or
+// delta_t_max > time_spanned) get their output range reserved by K1 (plan_count) and
+// are stepped by adder_generic_kernel (exec_step: the full arena walk) after the scan.
+// Memory-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,14 +33,7 @@ namespace adder {
 
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
-constexpr uint64_t kValid = 1ull << 32;
 
-__device__ __forceinline__ uint64_t desc_load(uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void desc_store(uint64_t *p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
     __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -55,55 +45,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, uint32_t lan
         if (lane >= o) x += y;
     }
     return x;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
-#pragma unroll
-    for (uint32_t o = kWave / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, kWave);
-    return x;
-}
-
-// Waits until every lane's descriptor is valid and returns the wave-wide sum of the
-// counts; lanes with use == false contribute 0 and do not load.  false on time-out.
-__device__ __forceinline__ bool poll_sum(uint64_t *p, bool use, uint32_t spin_limit, uint32_t *sum) {
-    uint32_t spins = 0;
-    for (;;) {
-        const uint64_t d = use ? desc_load(p) : kValid;
-        if (__ballot((uint32_t)(d >> 32) == 0u) == 0ull) {
-            *sum = wave_sum(use ? (uint32_t)d : 0u);
-            return true;
-        }
-        if (++spins > spin_limit) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// Exclusive prefix of `tile` (events of all earlier tiles of this frame).  One full wave.
-// Level 1: the tile's predecessors inside its group of kGroupTiles.  Level 2: the sums of
-// all earlier groups (published by whichever block handles a group's last tile).  The
-// caller keeps (known_groups, known_sum) across its tiles so later rounds only read the
-// groups completed since.
-__device__ __forceinline__ uint32_t resolve_prefix(const FrameArgs &a, uint32_t tile, uint32_t block_total,
-                                                   uint32_t lane, uint32_t &known_groups,
-                                                   uint32_t &known_sum) {
-    const uint32_t g = tile / kGroupTiles;
-    const uint32_t r = tile - g * kGroupTiles;
-    const uint32_t gfirst = g * kGroupTiles;
-    const uint32_t in_group_tiles = min(kGroupTiles, a.num_tiles - gfirst);
-    bool ok = true;
-    uint32_t in_group = 0;
-    ok &= poll_sum(a.agg_cur + gfirst + lane, lane < r, a.spin_limit, &in_group);
-    if (r == in_group_tiles - 1u && lane == 0)
-        desc_store(a.gsum_cur + g, kValid | (uint64_t)(in_group + block_total));
-    uint32_t gs = known_sum;
-    for (uint32_t g0 = known_groups; g0 < g; g0 += kWave) {
-        uint32_t part = 0;
-        ok &= poll_sum(a.gsum_cur + g0 + lane, g0 + lane < g, a.spin_limit, &part);
-        gs += part;
-    }
-    if (!ok && lane == 0) raise(a.status, kStatusTimeout);
-    known_groups = g;
-    known_sum = gs;
-    return gs + in_group;
 }
 
 struct DeepGlobal {
@@ -150,240 +91,242 @@ struct EmitGlobal {
     }
 };
 
-// GENERIC = false is used when no pixel can ever be deeper than one fired level
+// ------------------------------------------------------------------------------------------
+// K1.  GENERIC = false is used when no pixel can ever be deeper than one fired level
 // (Collapse with delta_t_max <= time_spanned): the eligibility test, the slot reservation
 // for generic pixels and the worklist are compiled out.
+// ------------------------------------------------------------------------------------------
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(FrameArgs a) {
-    __shared__ uint2 s_slots[kSlotsPerLane * kBlockThreads];  // [slot][thread] {t, d | px << 8}
-    __shared__ uint32_t s_wave_tot[kWavesPerBlock];
-    __shared__ uint32_t s_tile_base;
+    __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t wid = tid / kWave;
-
-    if (a.census) {
-        // residency census: every block of the grid must be running at the same time
-        if (tid == 0) {
-            __hip_atomic_fetch_add(a.census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t spins = 0;
-            while (__hip_atomic_load(a.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                if (++spins > a.spin_limit) {
-                    raise(a.status, kStatusTimeout);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        return;
-    }
-
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // global wave segment
+    const uint32_t u0 = blockIdx.x * kTileUnits + tid * kUnitsPerLane;
     const StepConsts sc = a.sc;
-    const uint64_t frame_base = a.frame_offsets[a.frame_idx];
-    uint32_t known_groups = 0, known_sum = 0;
 
-    for (uint32_t tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
-        const uint32_t u0 = tile * kTileUnits + tid * kUnitsPerLane;
-
-        // ---------------- loads: header, input, level 0 ----------------
-        const uint4 hdr4 = *reinterpret_cast<const uint4 *>(a.hdr + u0);
-        const uint32_t hdrv[4] = {hdr4.x, hdr4.y, hdr4.z, hdr4.w};
-        uint32_t vin[4];
-        if (u0 + kUnitsPerLane <= a.n_units) {
-            uint32_t w;
-            __builtin_memcpy(&w, a.frame + u0, 4);
-            vin[0] = w & 0xffu;
-            vin[1] = (w >> 8) & 0xffu;
-            vin[2] = (w >> 16) & 0xffu;
-            vin[3] = w >> 24;
-        } else {
+    // ---------------- loads: header, input, level 0 ----------------
+    const uint4 hdr4 = *reinterpret_cast<const uint4 *>(a.hdr + u0);
+    const uint32_t hdrv[4] = {hdr4.x, hdr4.y, hdr4.z, hdr4.w};
+    uint32_t vin[4];
+    if (u0 + kUnitsPerLane <= a.n_units) {
+        uint32_t w;
+        __builtin_memcpy(&w, a.frame + u0, 4);
+        vin[0] = w & 0xffu;
+        vin[1] = (w >> 8) & 0xffu;
+        vin[2] = (w >> 16) & 0xffu;
+        vin[3] = w >> 24;
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vin[j] = (u0 + j < a.n_units) ? a.frame[u0 + j] : 0u;
-        }
-        const bool any_m = (((hdrv[0] | hdrv[1] | hdrv[2] | hdrv[3]) >> 24) & kFlagMMask) != 0u;
+        for (int j = 0; j < 4; ++j) vin[j] = (u0 + j < a.n_units) ? a.frame[u0 + j] : 0u;
+    }
+    const bool any_m = (((hdrv[0] | hdrv[1] | hdrv[2] | hdrv[3]) >> 24) & kFlagMMask) != 0u;
 
-        PxState px[4];
-        {
-            float4 li = make_float4(0.f, 0.f, 0.f, 0.f), ld = li, lb = li, lf = li;
-            uint32_t lbd = 0u;
-            if (any_m) {
-                li = *reinterpret_cast<const float4 *>(a.lv_integ + u0);
-                ld = *reinterpret_cast<const float4 *>(a.lv_dt + u0);
-                lb = *reinterpret_cast<const float4 *>(a.lv_bdt + u0);
-                lbd = *reinterpret_cast<const uint32_t *>(a.lv_bd + u0);
-            }
-            if (ABS_T) lf = *reinterpret_cast<const float4 *>(a.lastf + u0);
-            const float liv[4] = {li.x, li.y, li.z, li.w}, ldv[4] = {ld.x, ld.y, ld.z, ld.w};
-            const float lbv[4] = {lb.x, lb.y, lb.z, lb.w}, lfv[4] = {lf.x, lf.y, lf.z, lf.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                px[j].hdr = hdrv[j];
-                px[j].n0.integ = liv[j];
-                px[j].n0.dt = ldv[j];
-                px[j].n0.bdt = lbv[j];
-                px[j].n0.bd = (lbd >> (8 * j)) & 0xffu;
-                px[j].lastf = lfv[j];
-            }
+    PxState px[4];
+    {
+        float4 li = make_float4(0.f, 0.f, 0.f, 0.f), ld = li, lb = li, lf = li;
+        uint32_t lbd = 0u;
+        if (any_m) {
+            li = *reinterpret_cast<const float4 *>(a.lv_integ + u0);
+            ld = *reinterpret_cast<const float4 *>(a.lv_dt + u0);
+            lb = *reinterpret_cast<const float4 *>(a.lv_bdt + u0);
+            lbd = *reinterpret_cast<const uint32_t *>(a.lv_bd + u0);
         }
-
-        // ---------------- the step; events parked in the lane's LDS stack ----------------
-        uint32_t nl = 0;     // events parked by this lane
-        uint32_t cnts = 0;   // per-pixel event counts, 8 bits each
-        uint32_t gmask = 0;  // pixels left to the generic kernel
-        uint2 *my_slots = s_slots + tid;
+        if (ABS_T) lf = *reinterpret_cast<const float4 *>(a.lastf + u0);
+        const float liv[4] = {li.x, li.y, li.z, li.w}, ldv[4] = {ld.x, ld.y, ld.z, ld.w};
+        const float lbv[4] = {lb.x, lb.y, lb.z, lb.w}, lfv[4] = {lf.x, lf.y, lf.z, lf.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (u0 + j < a.n_units && !(a.ablate & 2u)) {
-                if (!GENERIC || fast_eligible<COLLAPSE>(px[j], vin[j])) {
-                    FastEvents fe;
-                    step_fast<COLLAPSE, ABS_T>(px[j], vin[j], sc, fe);
-                    const uint32_t tag = (uint32_t)j << 8;
-                    if (fe.mask & 1u) {
-                        my_slots[nl * kBlockThreads] = make_uint2(fe.ta, fe.da | tag);
-                        ++nl;
-                    }
-                    if (fe.mask & 2u) {
-                        my_slots[nl * kBlockThreads] = make_uint2(fe.tb, fe.db | tag);
-                        ++nl;
-                    }
-                    if (fe.mask & 4u) {
-                        my_slots[nl * kBlockThreads] = make_uint2(fe.tc, fe.dc | tag);
-                        ++nl;
-                    }
-                    cnts |= (uint32_t)__popc(fe.mask) << (8 * j);
-                } else {
-                    cnts |= plan_count(px[j], vin[j], sc) << (8 * j);
-                    gmask |= 1u << j;
-                }
-            }
+            px[j].hdr = hdrv[j];
+            px[j].n0.integ = liv[j];
+            px[j].n0.dt = ldv[j];
+            px[j].n0.bdt = lbv[j];
+            px[j].n0.bd = (lbd >> (8 * j)) & 0xffu;
+            px[j].lastf = lfv[j];
         }
-        const uint32_t lane_cnt = (cnts & 0xffu) + ((cnts >> 8) & 0xffu) + ((cnts >> 16) & 0xffu) + (cnts >> 24);
+    }
 
-        // ---------------- state back to HBM (generic pixels keep their old state) ----------------
-        {
-            uint4 h;
-            h.x = px[0].hdr;
-            h.y = px[1].hdr;
-            h.z = px[2].hdr;
-            h.w = px[3].hdr;
-            *reinterpret_cast<uint4 *>(a.hdr + u0) = h;
-            if (((h.x | h.y | h.z | h.w) >> 24) & kFlagMMask) {
-                *reinterpret_cast<float4 *>(a.lv_integ + u0) =
-                    make_float4(px[0].n0.integ, px[1].n0.integ, px[2].n0.integ, px[3].n0.integ);
-                *reinterpret_cast<float4 *>(a.lv_dt + u0) =
-                    make_float4(px[0].n0.dt, px[1].n0.dt, px[2].n0.dt, px[3].n0.dt);
-                *reinterpret_cast<float4 *>(a.lv_bdt + u0) =
-                    make_float4(px[0].n0.bdt, px[1].n0.bdt, px[2].n0.bdt, px[3].n0.bdt);
-                *reinterpret_cast<uint32_t *>(a.lv_bd + u0) = (px[0].n0.bd & 0xffu) | ((px[1].n0.bd & 0xffu) << 8) |
-                                                              ((px[2].n0.bd & 0xffu) << 16) | (px[3].n0.bd << 24);
-            }
-            if (ABS_T)
-                *reinterpret_cast<float4 *>(a.lastf + u0) =
-                    make_float4(px[0].lastf, px[1].lastf, px[2].lastf, px[3].lastf);
-            if (a.running) {
+    // ---------------- the step; events parked in the lane's LDS stack ----------------
+    // Branch-free parking: all three candidate events are written, the stack pointer only
+    // advances past the valid ones (hence kSlotsPerLane + 1 rows).
+    uint32_t nl = 0;     // events parked by this lane
+    uint32_t cnts = 0;   // per-pixel event counts, 8 bits each
+    uint32_t gmask = 0;  // pixels left to the generic kernel
+    uint2 *my_slots = s_slots + tid;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((px[j].hdr >> 24) & kFlagMMask))
-                        a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
-                                                                    (double)sc.ref_time);
-            }
+    for (int j = 0; j < 4; ++j) {
+        const bool active = u0 + j < a.n_units && !(a.ablate & 2u);
+        if (!GENERIC || fast_eligible<COLLAPSE>(px[j], vin[j])) {
+            FastEvents fe;
+            PxState nx = px[j];
+            step_fast<COLLAPSE, ABS_T>(nx, vin[j], sc, fe);
+            if (active) px[j] = nx;
+            const uint32_t mask = active ? fe.mask : 0u;
+            const uint32_t tag = (uint32_t)j << 8;
+            my_slots[nl * kBlockThreads] = make_uint2(fe.ta, fe.da | tag);
+            nl += mask & 1u;
+            my_slots[nl * kBlockThreads] = make_uint2(fe.tb, fe.db | tag | (1u << 10));
+            nl += (mask >> 1) & 1u;
+            // index of the event inside its pixel: after A and B if present
+            const uint32_t kc = (mask & 1u) + ((mask >> 1) & 1u);
+            my_slots[nl * kBlockThreads] = make_uint2(fe.tc, fe.dc | tag | (kc << 10));
+            nl += mask >> 2;
+            cnts |= (uint32_t)__popc(mask) << (8 * j);
+        } else if (active) {
+            cnts |= plan_count(px[j], vin[j], sc) << (8 * j);
+            gmask |= 1u << j;
         }
+    }
+    const uint32_t lane_cnt = (cnts & 0xffu) + ((cnts >> 8) & 0xffu) + ((cnts >> 16) & 0xffu) + (cnts >> 24);
 
-        // ---------------- ordered prefix: lane -> wave -> block -> tile ----------------
-        const uint32_t incl = wave_inclusive_scan(lane_cnt, lane);
-        if (lane == kWave - 1) s_wave_tot[wid] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, block_total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-            const uint32_t t = s_wave_tot[w];
-            if (w < wid) wave_off += t;
-            block_total += t;
+    // ---------------- state back to HBM (generic pixels keep their old state) ----------------
+    {
+        uint4 h;
+        h.x = px[0].hdr;
+        h.y = px[1].hdr;
+        h.z = px[2].hdr;
+        h.w = px[3].hdr;
+        *reinterpret_cast<uint4 *>(a.hdr + u0) = h;
+        if (((h.x | h.y | h.z | h.w) >> 24) & kFlagMMask) {
+            *reinterpret_cast<float4 *>(a.lv_integ + u0) =
+                make_float4(px[0].n0.integ, px[1].n0.integ, px[2].n0.integ, px[3].n0.integ);
+            *reinterpret_cast<float4 *>(a.lv_dt + u0) =
+                make_float4(px[0].n0.dt, px[1].n0.dt, px[2].n0.dt, px[3].n0.dt);
+            *reinterpret_cast<float4 *>(a.lv_bdt + u0) =
+                make_float4(px[0].n0.bdt, px[1].n0.bdt, px[2].n0.bdt, px[3].n0.bdt);
+            *reinterpret_cast<uint32_t *>(a.lv_bd + u0) = (px[0].n0.bd & 0xffu) | ((px[1].n0.bd & 0xffu) << 8) |
+                                                          ((px[2].n0.bd & 0xffu) << 16) | (px[3].n0.bd << 24);
         }
-        const uint32_t lane_off = wave_off + incl - lane_cnt;
+        if (ABS_T)
+            *reinterpret_cast<float4 *>(a.lastf + u0) =
+                make_float4(px[0].lastf, px[1].lastf, px[2].lastf, px[3].lastf);
+        if (a.running) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((px[j].hdr >> 24) & kFlagMMask))
+                    a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
+                                                                (double)sc.ref_time);
+        }
+    }
 
-        if (wid == 0) {
-            if (lane == 0) {
-                desc_store(a.agg_cur + tile, kValid | block_total);
-                a.agg_next[tile] = 0ull;  // ready for the next frame's launch
-                if (tile % kGroupTiles == 0u) a.gsum_next[tile / kGroupTiles] = 0ull;
-                if (GENERIC && tile == 0u) *a.wl_count_next = 0u;
-            }
-            uint32_t excl = 0;
-            if (!(a.ablate & 1u)) excl = resolve_prefix(a, tile, block_total, lane, known_groups, known_sum);
-            if (lane == 0) {
-                s_tile_base = excl;
-                if (tile == a.num_tiles - 1)
-                    a.frame_offsets[a.frame_idx + 1] = frame_base + excl + block_total;
+    // ---------------- wave-level ordered compaction into the segment ----------------
+    // low half: events of the lane in the final stream; high half: events it parked
+    const uint32_t packed = lane_cnt | (nl << 16);
+    const uint32_t incl = wave_inclusive_scan(packed, lane);
+    if (lane == kWave - 1) a.wtot[gw] = incl;
+    const uint32_t excl = incl - packed;
+    const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
+    // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
+    const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
+    uint2 *dst = a.park + (size_t)gw * kParkPerWave + (excl >> 16);
+    for (uint32_t i = 0; i < nl; ++i) {
+        uint2 sl = my_slots[i * kBlockThreads];
+        const uint32_t j = (sl.y >> 8) & 3u;
+        const uint32_t off = GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) + ((sl.y >> 10) & 3u) : lane_off + i;
+        sl.y = (sl.y & 0xffu) | ((lane * kUnitsPerLane + j) << 8) | (off << 16);
+        dst[i] = sl;
+    }
+    if (GENERIC && gmask) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((gmask >> j) & 1u) {
+                const uint32_t slot = atomicAdd(a.wl_count, 1u);
+                a.worklist[slot] = make_uint2(u0 + j, lane_off + ((pre >> (8 * j)) & 0xffu));
             }
         }
-        __syncthreads();
-
-        // ---------------- parked events -> their final slots ----------------
-        if (lane_cnt | gmask) {
-            const uint32_t rel0 = s_tile_base + lane_off;
-            uint64_t pos = frame_base + rel0;
-            uint32_t rel = rel0;
-            EventWords *out = reinterpret_cast<EventWords *>(a.out);
-            bool dropped = false;
-            // coordinates of the lane's first unit; later units advance with carry
-            uint32_t y = u0 / a.rowlen;
-            uint32_t rem = u0 - y * a.rowlen;
-            uint32_t x, c;
-            if (a.channels == 1u) {
-                x = rem;
-                c = 0u;
-            } else {
-                x = rem / a.channels;
-                c = rem - x * a.channels;
-            }
-            uint32_t si = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t cj = (cnts >> (8 * j)) & 0xffu;
-                if (GENERIC && ((gmask >> j) & 1u)) {
-                    const uint32_t slot = atomicAdd(a.wl_count_cur, 1u);
-                    a.worklist[slot] = make_uint2(u0 + j, rel);
-                } else {
-                    const uint32_t xy = x | ((y + a.row_begin) << 16);
-                    const uint32_t cc = a.channels == 1u ? 0xffu : c;
-#pragma unroll
-                    for (uint32_t k = 0; k < 3; ++k) {
-                        if (k < cj) {
-                            const uint2 sl = my_slots[(si + k) * kBlockThreads];
-                            if (pos + k < a.out_cap) {
-                                EventWords w;
-                                w.xy = xy;
-                                w.cd = cc | ((sl.y & 0xffu) << 8);
-                                w.t = sl.x;
-                                out[pos + k] = w;
-                            } else {
-                                dropped = true;
-                            }
-                        }
-                    }
-                    si += cj;
-                }
-                pos += cj;
-                rel += cj;
-                if (++c >= a.channels) {
-                    c = 0u;
-                    if (++x >= a.width) {
-                        x = 0u;
-                        ++y;
-                    }
-                }
-            }
-            if (dropped) raise(a.status, kStatusCapacity);
-        }
-        __syncthreads();  // s_slots / s_wave_tot / s_tile_base are reused by the next tile
     }
 }
 
-// The full arena walk for the pixels the frame kernel listed (deeper than one fired level).
+// ------------------------------------------------------------------------------------------
+// Ks: exclusive prefix of the per-segment event counts; also closes the frame's range in
+// frame_offsets and clears the worklist counter for the next frame.  One block.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(FrameArgs a) {
+    __shared__ uint32_t s_part[kScanThreads / kWave];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wid = tid / kWave;
+    // num_waves is a multiple of 4: each thread owns `per` consecutive uint4 groups
+    const uint32_t groups = a.num_waves / 4u;
+    const uint32_t per = (groups + kScanThreads - 1) / kScanThreads;
+    const uint32_t g0 = tid * per;
+    const uint32_t g1 = min(g0 + per, groups);
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.wtot);
+    uint4 *dst = reinterpret_cast<uint4 *>(a.wpref);
+    uint32_t sum = 0;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint4 v = src[g];
+        sum += (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+    }
+    const uint32_t incl = wave_inclusive_scan(sum, lane);
+    if (lane == kWave - 1) s_part[wid] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kScanThreads / kWave; ++w) {
+        const uint32_t t = s_part[w];
+        if (w < wid) base += t;
+        total += t;
+    }
+    uint32_t run = base + incl - sum;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint4 v = src[g];
+        uint4 o;
+        o.x = run;
+        o.y = o.x + (v.x & 0xffffu);
+        o.z = o.y + (v.y & 0xffffu);
+        o.w = o.z + (v.z & 0xffffu);
+        run = o.w + (v.w & 0xffffu);
+        dst[g] = o;
+    }
+    if (tid == 0) a.frame_offsets[a.frame_idx + 1] = a.frame_offsets[a.frame_idx] + total;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: parked events -> final 12-byte events of the ordered stream.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(FrameArgs a) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    if (gw >= a.num_waves) return;
+    const uint32_t parked = a.wtot[gw] >> 16;
+    if (parked == 0u) return;
+    const uint64_t base = a.frame_offsets[a.frame_idx] + a.wpref[gw];
+    const uint2 *src = a.park + (size_t)gw * kParkPerWave;
+    EventWords *out = reinterpret_cast<EventWords *>(a.out);
+    bool dropped = false;
+    for (uint32_t i = lane; i < parked; i += kWave) {
+        const uint2 sl = src[i];
+        const uint32_t u = gw * kWaveUnits + ((sl.y >> 8) & 0xffu);
+        const uint32_t y = u / a.rowlen;
+        const uint32_t rem = u - y * a.rowlen;
+        uint32_t x = rem, c = 0xffu;
+        if (a.channels != 1u) {
+            x = rem / a.channels;
+            c = rem - x * a.channels;
+        }
+        const uint64_t pos = base + (sl.y >> 16);
+        if (pos < a.out_cap) {
+            EventWords w;
+            w.xy = x | ((y + a.row_begin) << 16);
+            w.cd = c | ((sl.y & 0xffu) << 8);
+            w.t = sl.x;
+            out[pos] = w;
+        } else {
+            dropped = true;
+        }
+    }
+    if (dropped) raise(a.status, kStatusCapacity);
+}
+
+// ------------------------------------------------------------------------------------------
+// The full arena walk for the pixels K1 listed (deeper than one fired level).  Runs after
+// the scan kernel (needs wpref) and clears the worklist counter when done.
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(FrameArgs a) {
-    const uint32_t n = *a.wl_count_cur;
+    const uint32_t n = *a.wl_count;
     const StepConsts sc = a.sc;
     const uint64_t frame_base = a.frame_offsets[a.frame_idx];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -408,7 +351,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(FrameArgs 
         const uint32_t c = rem - x * a.channels;
         EmitGlobal em;
         em.out = reinterpret_cast<EventWords *>(a.out);
-        em.pos = frame_base + e.y;
+        em.pos = frame_base + a.wpref[u / kWaveUnits] + e.y;
         em.cap = a.out_cap;
         em.dropped = false;
         em.xy = x | ((y + a.row_begin) << 16);
@@ -430,6 +373,8 @@ __global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(FrameArgs 
         if (sc.abs_t) a.lastf[u] = px.lastf;
     }
 }
+
+__global__ void adder_clear_u32_kernel(uint32_t *p) { *p = 0u; }
 
 // update_crf / update_quality_manual per-pixel reset (video.rs:1247-1250,1283-1286)
 __global__ void adder_reset_c_thresh_kernel(uint32_t *hdr, size_t n, uint32_t baseline) {
@@ -519,18 +464,29 @@ static FrameKernelFn pick_frame_kernel(const FrameArgs *a) {
     return a->sc.abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
 }
 
-extern "C" hipError_t adder_launch_frame(const FrameArgs *args, uint32_t grid, hipStream_t stream) {
+extern "C" hipError_t adder_launch_frame(const FrameArgs *args, hipStream_t stream) {
+    const uint32_t grid = (args->num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(pick_frame_kernel(args), dim3(grid), dim3(kBlockThreads), 0, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_scan(const FrameArgs *args, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, *args);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_expand(const FrameArgs *args, hipStream_t stream) {
+    const uint32_t grid = (args->num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, *args);
     return hipGetLastError();
 }
 
 extern "C" hipError_t adder_launch_generic(const FrameArgs *args, uint32_t grid, hipStream_t stream) {
     hipLaunchKernelGGL(adder_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, *args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(adder_clear_u32_kernel, dim3(1), dim3(1), 0, stream, args->wl_count);
     return hipGetLastError();
-}
-
-extern "C" hipError_t adder_frame_kernel_occupancy(const FrameArgs *args, int *blocks_per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, pick_frame_kernel(args), kBlockThreads, 0);
 }
 
 extern "C" hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream) {

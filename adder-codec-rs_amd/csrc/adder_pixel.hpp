@@ -103,11 +103,19 @@ ADDER_HD uint32_t get_d(float x) {
 // changes either (event_pixel_tree.rs:438-461).  So stored levels keep only best_d.
 ADDER_HD uint32_t fired_d(uint32_t bd) { return bd < kDMax ? bd + 1u : bd; }
 
-// rustc `f32 as u32`: truncate toward zero, saturate, NaN -> 0
+// rustc `f32 as u32`: truncate toward zero, saturate, NaN -> 0.  On gfx950 that is exactly
+// v_cvt_u32_f32 (round toward zero, out-of-range clamped, NaN -> 0); C++'s cast is undefined
+// out of range, so the instruction is requested explicitly.
 ADDER_HD uint32_t f32_as_u32(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#else
     if (!(f > 0.0f)) return 0u;
     if (f >= 4294967296.0f) return 0xffffffffu;
     return (uint32_t)f;
+#endif
 }
 
 // Unfused multiply / add / correctly rounded divide.  The reference is compiled by
@@ -231,6 +239,9 @@ ADDER_HD bool fast_eligible(const PxState &s, uint32_t v) {
     return fadd(s.n0.integ, (float)v) >= pow2_d(fired_d(s.n0.bd));
 }
 
+// Written branch-free on purpose: on CDNA a divergent `if` costs scalar exec-mask
+// bookkeeping per region, and with 4 pixels per lane and ~10% of the pixels flushing every
+// wave takes every path anyway.  Everything is computed unconditionally and selected.
 template <bool COLLAPSE, bool ABS_T>
 ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents &ev) {
     const float I = (float)v;
@@ -241,60 +252,76 @@ ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents
     uint32_t cctr = (hdr >> 16) & 0xffu;
     bool has0 = ((hdr >> 24) & kFlagMMask) != 0u;  // m == 1
     bool popped = (hdr & (kFlagPopped << 24)) != 0u;
-    Node n0 = s.n0;
-    ev.mask = 0u;
+    float lastf = s.lastf;
 
-    // ---- pop_best_events (event_pixel_tree.rs:213-287) ----
+    // ---- pop_best_events (event_pixel_tree.rs:213-287): A = level 0's best event; with
+    // Collapse after a delta_t_max pop it is followed by the D_EMPTY filler B (:249-265) ----
     const uint32_t diff = v > base ? v - base : base - v;
-    if (diff > cth) {
-        if (has0) {
-            ev.da = n0.bd;
-            if (COLLAPSE && popped) {
-                ev.ta = f32_as_u32(ABS_T ? fadd(n0.bdt, s.lastf) : n0.bdt);
-                ev.db = kDEmpty;  // :259-263, carries running_t in every time mode
-                ev.tb = f32_as_u32(sc.running_t);
-                ev.mask = 3u;
-                s.lastf = sc.running_t;  // :257
-            } else {
-                ev.ta = event_time<ABS_T>(n0.bdt, s.lastf, sc);
-                ev.mask = 1u;
-            }
+    const bool flush = diff > cth;
+    const bool a_valid = flush && has0;
+    const bool b_valid = COLLAPSE && a_valid && popped;
+    {
+        float evdt = s.n0.bdt;
+        if (ABS_T) {
+            evdt = fadd(evdt, lastf);
+            const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
+            lastf = a_valid ? (b_valid ? sc.running_t : chained) : lastf;  // :122-129 / :257
         }
-        has0 = false;
-        popped = false;
-        base = v;
+        ev.da = s.n0.bd;
+        ev.ta = f32_as_u32(evdt);
+        ev.db = kDEmpty;
+        ev.tb = f32_as_u32(sc.running_t);
+    }
+    has0 = has0 && !flush;
+    popped = popped && !flush;
+    base = flush ? v : base;
+
+    // ---- integrate (:317-413): arena index 0 is level 0 if present, else the pristine
+    // tail, which always fires; the walk stops there (fast_eligible) ----
+    const float integ = has0 ? s.n0.integ : 0.0f;
+    const float dt = has0 ? s.n0.dt : 0.0f;
+    const uint32_t d = has0 ? fired_d(s.n0.bd) : get_d(I);
+    const float sum = fadd(integ, I);
+    const bool fire = sum >= pow2_d(d);
+    const uint32_t nd = get_d(sum);
+    float prop = fdiv(fsub(pow2_d(nd), integ), I);
+    prop = (nd == kDZero || d == kDZero || I < 1.1920929e-7f) ? 1.0f : prop;
+    const float bdt_fire = fadd(dt, fmul(T, prop));
+    const bool acc = !fire || nd < kDMax;  // a node that fires at nd >= D_MAX keeps (integ, dt)
+    Node n;
+    n.integ = acc ? sum : integ;
+    n.dt = acc ? fadd(dt, T) : dt;
+    n.bd = fire ? nd : s.n0.bd;
+    n.bdt = fire ? bdt_fire : s.n0.bdt;
+    const bool need_pop = fired_d(n.bd) == kDMax || (n.dt >= sc.dtm_f && !popped);  // :394-396
+
+    if (sc.c_thresh_max != 0u) {  // :402-412, u8 saturating; uniform branch
+        const bool adapt = cth < sc.c_thresh_max;
+        const bool bump = cctr >= sc.velocity_m1;
+        uint32_t cinc = cctr + sc.c_inc;
+        cinc = cinc > 255u ? 255u : cinc;
+        const uint32_t cth1 = cth >= 255u ? 255u : cth + 1u;
+        cth = (adapt && bump) ? cth1 : cth;
+        cctr = adapt ? (bump ? 0u : cinc) : cctr;
     }
 
-    // ---- integrate (:317-413): arena index 0 is level 0 if present, else the tail ----
-    if (has0) {
-        node_integrate(n0, I, T);  // no fire => the walk stops here (fast_eligible)
-    } else {
-        n0 = tail_fire(I, T);
-        has0 = true;
-    }
-    const bool need_pop = root_needs_pop(n0, popped, sc);
-
-    if (sc.c_thresh_max != 0u && cth < sc.c_thresh_max) {  // :402-412, u8 saturating
-        if (cctr >= sc.velocity_m1) {
-            cth = cth >= 255u ? 255u : cth + 1u;
-            cctr = 0u;
-        } else {
-            cctr += sc.c_inc;
-            cctr = cctr > 255u ? 255u : cctr;
+    // ---- pop_top_event (:139-210): C = the root's best event; the arena shifts left ----
+    {
+        float evdt = n.bdt;
+        if (ABS_T) {
+            evdt = fadd(evdt, lastf);
+            const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
+            lastf = need_pop ? chained : lastf;
         }
+        ev.dc = n.bd;
+        ev.tc = f32_as_u32(evdt);
     }
+    ev.mask = (a_valid ? 1u : 0u) | (b_valid ? 2u : 0u) | (need_pop ? 4u : 0u);
+    popped = popped || need_pop;
 
-    // ---- pop_top_event (:139-210): the root has a best event, shift the arena ----
-    if (need_pop) {
-        ev.dc = n0.bd;
-        ev.tc = event_time<ABS_T>(n0.bdt, s.lastf, sc);
-        ev.mask |= 4u;
-        has0 = false;
-        popped = true;
-    }
-
-    s.n0 = n0;
-    s.hdr = base | (cth << 8) | (cctr << 16) | ((has0 ? 1u : 0u) | (popped ? kFlagPopped : 0u)) << 24;
+    s.n0 = n;
+    s.lastf = lastf;
+    s.hdr = base | (cth << 8) | (cctr << 16) | ((need_pop ? 0u : 1u) | (popped ? kFlagPopped : 0u)) << 24;
 }
 
 // ---------------------------------------------------------------------------------------
