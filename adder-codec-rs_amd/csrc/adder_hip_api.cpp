@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -42,12 +43,23 @@ struct AdderHipCtx {
     // compaction scratch
     // ordered compaction scratch, double-buffered by frame parity so that the expand kernel
     // of frame f can overlap the frame kernel of frame f+1
-    uint2 *park[2] = {nullptr, nullptr};       // [num_waves][kParkPerWave]
-    uint32_t *wtot[2] = {nullptr, nullptr};    // [num_waves]
-    uint32_t *wpref[2] = {nullptr, nullptr};   // [num_waves]
+    uint2 *park[kScratchBuffers] = {};       // [num_waves][kParkPerWave]
+    uint32_t *wtot[kScratchBuffers] = {};    // [num_waves]
+    uint32_t *wpref[kScratchBuffers] = {};   // [num_waves]
     uint2 *worklist = nullptr;                 // pixels for the generic kernel
     uint32_t *wl_count = nullptr;
     uint32_t num_waves = 0;
+    // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
+    BatchArgs *d_batch = nullptr;
+    BatchArgs *h_batch = nullptr;   // pinned
+    float *d_rt = nullptr;          // running_t table
+    float *h_rt = nullptr;          // pinned
+    size_t rt_cap = 0;              // entries
+    // capture streams/events and the cache of instantiated frame-loop graphs
+    hipStream_t cap_s = nullptr, cap_s2 = nullptr;
+    hipEvent_t cap_e1 = nullptr, cap_e2[kScratchBuffers] = {}, cap_eg = nullptr;
+    std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
+    bool use_graph = true;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
     size_t d_offsets_cap = 0;       // all *_cap below are in BYTES
@@ -108,11 +120,27 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_bd,   c->running, c->park[0], c->park[1], c->wtot[0], c->wtot[1], c->wpref[0], c->wpref[1], c->worklist, c->wl_count, c->status,
+                    c->lv_bdt,  c->lv_bd,   c->running, c->worklist, c->wl_count, c->status,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (uint32_t i = 0; i < kScratchBuffers; ++i) {
+        if (c->park[i]) (void)hipFree(c->park[i]);
+        if (c->wtot[i]) (void)hipFree(c->wtot[i]);
+        if (c->wpref[i]) (void)hipFree(c->wpref[i]);
+    }
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
+    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (c->d_batch) (void)hipFree(c->d_batch);
+    if (c->h_batch) (void)hipHostFree(c->h_batch);
+    if (c->d_rt) (void)hipFree(c->d_rt);
+    if (c->h_rt) (void)hipHostFree(c->h_rt);
+    for (hipEvent_t e : {c->cap_e1, c->cap_eg})
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->cap_e2)
+        if (e) (void)hipEventDestroy(e);
+    if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
+    if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -281,11 +309,20 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->running, c->n_pad));
-        for (int b = 0; b < 2; ++b) {
+        for (uint32_t b = 0; b < kScratchBuffers; ++b) {
             HIPCHK(c, dalloc(&c->park[b], (size_t)c->num_waves * kParkPerWave));
             HIPCHK(c, dalloc(&c->wtot[b], c->num_waves));
             HIPCHK(c, dalloc(&c->wpref[b], c->num_waves));
         }
+        HIPCHK(c, dalloc(&c->d_batch, 1));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s2, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e1, hipEventDisableTiming));
+        for (uint32_t i = 0; i < kScratchBuffers; ++i)
+            HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->cap_eg, hipEventDisableTiming));
+        if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
         HIPCHK(c, dalloc(&c->worklist, c->n_pad));
         HIPCHK(c, dalloc(&c->wl_count, 1));
         HIPCHK(c, dalloc(&c->status, 1));
@@ -357,50 +394,142 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
-// Queues `num_frames` frame launches on `stream`.
+// The per-frame launch sequence.  Eager single-stream form (s2 == nullptr): K1, Ks, K2, [Kg]
+// in order.  Two-stream form (used under stream capture to build the graph): the scan and
+// expand kernels of frame f run on s2 behind K1(f) and overlap K1(f+1); K1(f+2) waits for
+// K2(f - kScratchBuffers) because the scratch is a ring of kScratchBuffers frames; in generic mode K1(f+1)
+// also waits for Kg(f), which updates pixel state.
+static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
+                             bool timing) {
+    const bool generic = (variant & 4u) != 0u;
+    const uint32_t generic_grid = std::min<uint32_t>(c->num_tiles * 4u, c->num_cus * 8u);
+    for (uint32_t f = 0; f < num_frames; ++f) {
+        if (s2) {
+            if (f >= kScratchBuffers) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[f % kScratchBuffers], 0));
+            if (generic && f >= 1) HIPCHK(c, hipStreamWaitEvent(s, c->cap_eg, 0));
+        }
+        if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], s));
+        HIPCHK(c, adder_launch_frame(c->d_batch, f, variant, c->num_waves, s));
+        if (timing) {  // the pair brackets the frame kernel (K1) only
+            HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], s));
+            c->timed_launches = f + 1;
+        }
+        hipStream_t t = s;
+        if (s2) {
+            HIPCHK(c, hipEventRecord(c->cap_e1, s));
+            HIPCHK(c, hipStreamWaitEvent(s2, c->cap_e1, 0));
+            t = s2;
+        }
+        HIPCHK(c, adder_launch_scan(c->d_batch, f, t));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f, c->num_waves, t));
+        if (generic) {
+            HIPCHK(c, adder_launch_generic(c->d_batch, f, generic_grid, t));
+            HIPCHK(c, adder_launch_clear_u32(c->wl_count, t));
+            if (s2) HIPCHK(c, hipEventRecord(c->cap_eg, s2));
+        }
+        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[f % kScratchBuffers], s2));
+    }
+    if (s2 && num_frames) {  // join
+        // s2 is in-order, so its last record covers everything queued on it
+        HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(num_frames - 1) % kScratchBuffers], 0));
+    }
+    return ADDER_OK;
+}
+
+static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
+    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32);
+    auto it = c->graphs.find(key);
+    if (it != c->graphs.end()) {
+        *out = it->second;
+        return ADDER_OK;
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
+    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
+    hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
+    if (rc != ADDER_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    HIPCHK(c, e);
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIPCHK(c, e);
+    if (c->graphs.size() >= 8) {  // keep the cache small
+        (void)hipGraphExecDestroy(c->graphs.begin()->second);
+        c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs[key] = exec;
+    *out = exec;
+    return ADDER_OK;
+}
+
+// Queues `num_frames` frames on `stream`.
 static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
                           AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
-    FrameArgs a;
-    base_args(c, &a);
-    a.out = reinterpret_cast<AdderEventPod *>(d_out);
-    a.out_cap = out_cap;
-    a.frame_offsets = d_offsets;
-    HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
     // Pixels deeper than one fired level cannot occur when Collapse pops the root as soon as
     // it has accumulated once (delta_t_max <= time_spanned): then the generic kernel is
     // never needed (see fast_eligible in adder_pixel.hpp).
-    const bool generic_possible =
-        !(c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned);
-    const uint32_t generic_grid = std::min<uint32_t>(c->num_tiles * 4u, c->num_cus * 8u);
-    a.generic = generic_possible ? 1u : 0u;
-    HIPCHK(c, hipEventRecord(c->ev_start, stream));
+    const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
+    const bool generic_possible = !(collapse && (float)c->p.delta_t_max <= time_spanned);
+    const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
+                             (generic_possible ? 4u : 0u);
+
+    // ---- batch description -> device ----
+    if (c->rt_cap < num_frames) {
+        if (c->d_rt) HIPCHK(c, hipFree(c->d_rt));
+        if (c->h_rt) HIPCHK(c, hipHostFree(c->h_rt));
+        c->d_rt = nullptr;
+        c->h_rt = nullptr;
+        c->rt_cap = 0;
+        const size_t cap = std::max<size_t>(num_frames, 64);
+        HIPCHK(c, dalloc(&c->d_rt, cap));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_rt), cap * sizeof(float), hipHostMallocDefault));
+        c->rt_cap = cap;
+    }
     float rt = c->running_t;
+    for (uint32_t f = 0; f < num_frames; ++f) {
+        c->h_rt[f] = rt;
+        rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
+    }
+    BatchArgs &b = *c->h_batch;
+    base_args(c, &b.base);
+    b.base.out = reinterpret_cast<AdderEventPod *>(d_out);
+    b.base.out_cap = out_cap;
+    b.base.frame_offsets = d_offsets;
+    b.base.generic = generic_possible ? 1u : 0u;
+    b.base.sc = make_consts(c, time_spanned, 0.0f);
+    b.frames = d_frames;
+    b.running_t = c->d_rt;
+    for (uint32_t i = 0; i < kScratchBuffers; ++i) {
+        b.park2[i] = c->park[i];
+        b.wtot2[i] = c->wtot[i];
+        b.wpref2[i] = c->wpref[i];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_rt, c->h_rt, num_frames * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+
     c->timed_launches = 0;
-    if (c->launch_timing) {
+    const bool timing = c->launch_timing;
+    if (timing) {
         while (c->launch_events.size() < 2 * (size_t)num_frames) {
             hipEvent_t e;
             HIPCHK(c, hipEventCreate(&e));
             c->launch_events.push_back(e);
         }
     }
-    for (uint32_t f = 0; f < num_frames; ++f) {
-        a.frame = d_frames + (size_t)f * c->n_units;
-        a.frame_idx = f;
-        a.park = c->park[f & 1u];
-        a.wtot = c->wtot[f & 1u];
-        a.wpref = c->wpref[f & 1u];
-        a.sc = make_consts(c, time_spanned, rt);
-        if (c->launch_timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], stream));
-        HIPCHK(c, adder_launch_frame(&a, stream));
-        if (c->launch_timing) {  // the pair brackets the frame kernel (K1) only
-            HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], stream));
-            c->timed_launches = f + 1;
-        }
-        HIPCHK(c, adder_launch_scan(&a, stream));
-        HIPCHK(c, adder_launch_expand(&a, stream));
-        if (generic_possible) HIPCHK(c, adder_launch_generic(&a, generic_grid, stream));
-        rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
+    HIPCHK(c, hipEventRecord(c->ev_start, stream));
+    int rc = ADDER_OK;
+    if (c->use_graph && !timing) {
+        hipGraphExec_t exec = nullptr;
+        rc = get_graph(c, num_frames, variant, &exec);
+        if (rc == ADDER_OK) HIPCHK(c, hipGraphLaunch(exec, stream));
+    } else {
+        rc = launch_frame_loop(c, num_frames, variant, stream, nullptr, timing);
     }
+    if (rc != ADDER_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_stop, stream));
     c->running_t = rt;
     c->frames_done += num_frames;

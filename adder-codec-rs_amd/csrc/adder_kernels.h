@@ -15,6 +15,7 @@ constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // 1024 units
 constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // 256 units per wave segment
 constexpr uint32_t kSlotsPerLane = 12;                             // 4 px x 3 fast-path events
 constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
+constexpr uint32_t kScratchBuffers = 4;                            // frames of compaction scratch in flight
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
@@ -61,13 +62,39 @@ struct FrameArgs {
     StepConsts sc;
 };
 
+// Device-resident description of one batch of frames.  The kernels take (BatchArgs*, f), so
+// a captured hipGraph of T frames can be replayed for ANY batch of T frames: the host only
+// rewrites this struct (and the running_t table) before launching the graph.
+struct BatchArgs {
+    FrameArgs base;           // per-frame fields (frame, frame_idx, park, wtot, wpref, sc.running_t) are derived
+    const uint8_t *frames;    // packed [T][n_units]
+    const float *running_t;   // [T] PixelArena::running_t before each frame's integrate
+    uint2 *park2[kScratchBuffers];  // scratch ring, indexed by f % kScratchBuffers
+    uint32_t *wtot2[kScratchBuffers];
+    uint32_t *wpref2[kScratchBuffers];
+};
+
+__device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) {
+    FrameArgs a = b->base;
+    a.frame = b->frames + (size_t)f * a.n_units;
+    a.frame_idx = f;
+    a.sc.running_t = b->running_t[f];
+    a.park = b->park2[f % kScratchBuffers];
+    a.wtot = b->wtot2[f % kScratchBuffers];
+    a.wpref = b->wpref2[f % kScratchBuffers];
+    return a;
+}
+
 }  // namespace adder
 
 extern "C" {
-hipError_t adder_launch_frame(const adder::FrameArgs *args, hipStream_t stream);    // K1
-hipError_t adder_launch_scan(const adder::FrameArgs *args, hipStream_t stream);     // Ks
-hipError_t adder_launch_expand(const adder::FrameArgs *args, hipStream_t stream);   // K2
-hipError_t adder_launch_generic(const adder::FrameArgs *args, uint32_t grid, hipStream_t stream);
+// variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
+hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
+                              hipStream_t stream);                                                   // K1
+hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f, hipStream_t stream);             // Ks
+hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream);  // K2
+hipError_t adder_launch_generic(const adder::BatchArgs *b, uint32_t f, uint32_t grid, hipStream_t stream);
+hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

@@ -97,7 +97,8 @@ struct EmitGlobal {
 // for generic pixels and the worklist are compiled out.
 // ------------------------------------------------------------------------------------------
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(FrameArgs a) {
+__global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
     __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
 
     const uint32_t tid = threadIdx.x;
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(FrameArgs a)
 // frame_offsets and clears the worklist counter for the next frame.  One block.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(FrameArgs a) {
+__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
     __shared__ uint32_t s_part[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(FrameArgs a) {
 // ------------------------------------------------------------------------------------------
 // K2: parked events -> final 12-byte events of the ordered stream.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(FrameArgs a) {
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
     if (gw >= a.num_waves) return;
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(FrameArgs a
 // The full arena walk for the pixels K1 listed (deeper than one fired level).  Runs after
 // the scan kernel (needs wpref) and clears the worklist counter when done.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(FrameArgs a) {
+__global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
     const uint32_t n = *a.wl_count;
     const StepConsts sc = a.sc;
     const uint64_t frame_base = a.frame_offsets[a.frame_idx];
@@ -454,38 +458,41 @@ __global__ void adder_synth_kernel(uint8_t *dst, int content, uint64_t seed, uin
 // ------------------------- launch wrappers (called from adder_hip_api.cpp) -------------------------
 using namespace adder;
 
-typedef void (*FrameKernelFn)(FrameArgs);
-static FrameKernelFn pick_frame_kernel(const FrameArgs *a) {
-    if (a->sc.collapse) {
-        if (a->generic)
-            return a->sc.abs_t ? adder_frame_kernel<true, true, true> : adder_frame_kernel<true, false, true>;
-        return a->sc.abs_t ? adder_frame_kernel<true, true, false> : adder_frame_kernel<true, false, false>;
+typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t);
+static FrameKernelFn pick_frame_kernel(uint32_t variant) {
+    const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
+    if (collapse) {
+        if (generic) return abs_t ? adder_frame_kernel<true, true, true> : adder_frame_kernel<true, false, true>;
+        return abs_t ? adder_frame_kernel<true, true, false> : adder_frame_kernel<true, false, false>;
     }
-    return a->sc.abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
+    return abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
 }
 
-extern "C" hipError_t adder_launch_frame(const FrameArgs *args, hipStream_t stream) {
-    const uint32_t grid = (args->num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(pick_frame_kernel(args), dim3(grid), dim3(kBlockThreads), 0, stream, *args);
+extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
+                                         hipStream_t stream) {
+    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_scan(const FrameArgs *args, hipStream_t stream) {
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, *args);
+extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, b, f);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_expand(const FrameArgs *args, hipStream_t stream) {
-    const uint32_t grid = (args->num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, *args);
+extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream) {
+    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_generic(const FrameArgs *args, uint32_t grid, hipStream_t stream) {
-    hipLaunchKernelGGL(adder_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, *args);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(adder_clear_u32_kernel, dim3(1), dim3(1), 0, stream, args->wl_count);
+extern "C" hipError_t adder_launch_generic(const BatchArgs *b, uint32_t f, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_clear_u32_kernel, dim3(1), dim3(1), 0, stream, p);
     return hipGetLastError();
 }
 
