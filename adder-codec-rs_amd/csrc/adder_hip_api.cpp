@@ -43,9 +43,13 @@ struct AdderHipCtx {
     // compaction scratch
     // ordered compaction scratch, double-buffered by frame parity so that the expand kernel
     // of frame f can overlap the frame kernel of frame f+1
-    uint2 *park[kScratchBuffers] = {};       // [num_waves][kParkPerWave]
-    uint32_t *wtot[kScratchBuffers] = {};    // [num_waves]
-    uint32_t *wpref[kScratchBuffers] = {};   // [num_waves]
+    // compaction scratch: a ring of 2*chunk frames (the expand kernels of one chunk overlap the
+    // frame kernels of the next)
+    uint2 *park_ring = nullptr;      // [slots][num_waves][kParkPerWave]
+    uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
+    uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
+    uint32_t *ftot_ring = nullptr;   // [slots]
+    uint32_t chunk = 1, slots = 2;
     uint2 *worklist = nullptr;                 // pixels for the generic kernel
     uint32_t *wl_count = nullptr;
     uint32_t num_waves = 0;
@@ -57,7 +61,7 @@ struct AdderHipCtx {
     size_t rt_cap = 0;              // entries
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
-    hipEvent_t cap_e1 = nullptr, cap_e2[kScratchBuffers] = {}, cap_eg = nullptr;
+    hipEvent_t cap_e1 = nullptr, cap_e2[2] = {nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
     bool use_graph = true;
     uint32_t *status = nullptr;   // device status word
@@ -124,20 +128,15 @@ static void free_ctx(AdderHipCtx *c) {
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (uint32_t i = 0; i < kScratchBuffers; ++i) {
-        if (c->park[i]) (void)hipFree(c->park[i]);
-        if (c->wtot[i]) (void)hipFree(c->wtot[i]);
-        if (c->wpref[i]) (void)hipFree(c->wpref[i]);
-    }
+    for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
+        if (p) (void)hipFree(p);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->d_batch) (void)hipFree(c->d_batch);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->d_rt) (void)hipFree(c->d_rt);
     if (c->h_rt) (void)hipHostFree(c->h_rt);
-    for (hipEvent_t e : {c->cap_e1, c->cap_eg})
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->cap_e2)
+    for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1]})
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
     if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
@@ -290,7 +289,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "row band too large (%llu pixel-channels)", (unsigned long long)units);
     }
     c->n_units = (uint32_t)units;
-    c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;
+    c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;  // K1 blocks
     c->n_pad = (size_t)c->num_tiles * kTileUnits;
     c->num_waves = (uint32_t)(c->n_pad / kWaveUnits);
     c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
@@ -309,19 +308,25 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->running, c->n_pad));
-        for (uint32_t b = 0; b < kScratchBuffers; ++b) {
-            HIPCHK(c, dalloc(&c->park[b], (size_t)c->num_waves * kParkPerWave));
-            HIPCHK(c, dalloc(&c->wtot[b], c->num_waves));
-            HIPCHK(c, dalloc(&c->wpref[b], c->num_waves));
+        {
+            // frames per scan/expand launch: as many as ~4 GiB of scratch allow, at most kMaxChunk
+            const size_t per_frame = (size_t)c->num_waves * (kParkPerWave * sizeof(uint2) + 2 * sizeof(uint32_t));
+            size_t ch = ((size_t)4 << 30) / (2 * per_frame);
+            c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
+            if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
+            c->slots = 2 * c->chunk;
+            HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * kParkPerWave));
+            HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
+            HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
+            HIPCHK(c, dalloc(&c->ftot_ring, c->slots));
         }
         HIPCHK(c, dalloc(&c->d_batch, 1));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s2, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e1, hipEventDisableTiming));
-        for (uint32_t i = 0; i < kScratchBuffers; ++i)
-            HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[i], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->cap_eg, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[0], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[1], hipEventDisableTiming));
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
         HIPCHK(c, dalloc(&c->worklist, c->n_pad));
         HIPCHK(c, dalloc(&c->wl_count, 1));
@@ -394,25 +399,36 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
-// The per-frame launch sequence.  Eager single-stream form (s2 == nullptr): K1, Ks, K2, [Kg]
-// in order.  Two-stream form (used under stream capture to build the graph): the scan and
-// expand kernels of frame f run on s2 behind K1(f) and overlap K1(f+1); K1(f+2) waits for
-// K2(f - kScratchBuffers) because the scratch is a ring of kScratchBuffers frames; in generic mode K1(f+1)
-// also waits for Kg(f), which updates pixel state.
+// The launch sequence of a batch.  Frames are handled in chunks of c->chunk:
+//   stream s : K1 of every frame of the chunk, back to back (frame f+1 only needs frame f's
+//              pixel state);
+//   stream s2: behind the chunk's last K1 -- one scan launch (a block per frame), the
+//              frame_offsets chain, one expand launch for all the chunk's parked events.
+// The scratch ring holds two chunks, so the K1s of chunk k+2 wait for the expand of chunk k.
+// Eager form (s2 == nullptr): everything in order on s.  Generic mode (pixels deeper than one
+// fired level possible): the generic kernel of frame f needs that frame's prefix and updates
+// pixel state, so scan + offsets + generic run per frame on s; only the expand is chunked.
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
     const bool generic = (variant & 4u) != 0u;
-    const uint32_t generic_grid = std::min<uint32_t>(c->num_tiles * 4u, c->num_cus * 8u);
-    for (uint32_t f = 0; f < num_frames; ++f) {
-        if (s2) {
-            if (f >= kScratchBuffers) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[f % kScratchBuffers], 0));
-            if (generic && f >= 1) HIPCHK(c, hipStreamWaitEvent(s, c->cap_eg, 0));
-        }
-        if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], s));
-        HIPCHK(c, adder_launch_frame(c->d_batch, f, variant, c->num_waves, s));
-        if (timing) {  // the pair brackets the frame kernel (K1) only
-            HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], s));
-            c->timed_launches = f + 1;
+    const uint32_t generic_grid = std::min<uint32_t>(c->num_waves, c->num_cus * 8u);
+    uint32_t k = 0;
+    for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
+        const uint32_t nf = std::min(c->chunk, num_frames - f0);
+        if (s2 && k >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[k & 1u], 0));
+        for (uint32_t f = f0; f < f0 + nf; ++f) {
+            if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], s));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, variant, c->num_waves, s));
+            if (timing) {  // the pair brackets the frame kernel (K1) only
+                HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], s));
+                c->timed_launches = f + 1;
+            }
+            if (generic) {
+                HIPCHK(c, adder_launch_scan(c->d_batch, f, 1, s));
+                HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1, s));
+                HIPCHK(c, adder_launch_generic(c->d_batch, f, generic_grid, s));
+                HIPCHK(c, adder_launch_clear_u32(c->wl_count, s));
+            }
         }
         hipStream_t t = s;
         if (s2) {
@@ -420,19 +436,14 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             HIPCHK(c, hipStreamWaitEvent(s2, c->cap_e1, 0));
             t = s2;
         }
-        HIPCHK(c, adder_launch_scan(c->d_batch, f, t));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f, c->num_waves, t));
-        if (generic) {
-            HIPCHK(c, adder_launch_generic(c->d_batch, f, generic_grid, t));
-            HIPCHK(c, adder_launch_clear_u32(c->wl_count, t));
-            if (s2) HIPCHK(c, hipEventRecord(c->cap_eg, s2));
+        if (!generic) {
+            HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
+            HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
         }
-        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[f % kScratchBuffers], s2));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
+        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k & 1u], s2));
     }
-    if (s2 && num_frames) {  // join
-        // s2 is in-order, so its last record covers everything queued on it
-        HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(num_frames - 1) % kScratchBuffers], 0));
-    }
+    if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) & 1u], 0));  // join (s2 is in-order)
     return ADDER_OK;
 }
 
@@ -502,11 +513,11 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.sc = make_consts(c, time_spanned, 0.0f);
     b.frames = d_frames;
     b.running_t = c->d_rt;
-    for (uint32_t i = 0; i < kScratchBuffers; ++i) {
-        b.park2[i] = c->park[i];
-        b.wtot2[i] = c->wtot[i];
-        b.wpref2[i] = c->wpref[i];
-    }
+    b.park_ring = c->park_ring;
+    b.wtot_ring = c->wtot_ring;
+    b.wpref_ring = c->wpref_ring;
+    b.ftot_ring = c->ftot_ring;
+    b.slots = c->slots;
     HIPCHK(c, hipMemcpyAsync(c->d_rt, c->h_rt, num_frames * sizeof(float), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));

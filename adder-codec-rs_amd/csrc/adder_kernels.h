@@ -10,12 +10,13 @@
 namespace adder {
 
 constexpr uint32_t kBlockThreads = 256;
-constexpr uint32_t kUnitsPerLane = 4;                              // pixel-channels per lane
-constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // 1024 units per block
+constexpr uint32_t kUnitsPerLane = 4;                              // pixel-channels per lane and segment
 constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // 256 units per wave segment
+constexpr uint32_t kSegsPerWave = 2;                               // segments a K1 wave processes (prefetched)
+constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane * kSegsPerWave;  // 2048 units per K1 block
 constexpr uint32_t kSlotsPerLane = 12;                             // 4 px x 3 fast-path events
 constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
-constexpr uint32_t kScratchBuffers = 4;                            // frames of compaction scratch in flight
+constexpr uint32_t kMaxChunk = 16;                                 // frames per scan/expand launch
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
@@ -43,16 +44,17 @@ struct FrameArgs {
     const uint8_t *frame;  // n_units bytes, packed [rows][width][channels]
     AdderEventPod *out;
     uint64_t out_cap;
-    uint64_t *frame_offsets;  // [frame_idx] is read, [frame_idx+1] is written (by the scan kernel)
+    uint64_t *frame_offsets;  // [frame_idx] = first event of the frame, [frame_idx+1] = end
     uint32_t frame_idx;
     // ordered compaction, stage 1 (frame kernel): per wave segment of 256 units
     uint2 *park;          // [num_waves][kParkPerWave] {t, d | unit_in_wave<<8 | final_offset_in_wave<<16}
     uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked events (high 16)
-    // stage 2 (scan kernel): exclusive prefix of the low halves of wtot
+    // stage 2 (scan kernel): exclusive prefix of the low halves of wtot, frame total
     uint32_t *wpref;      // [num_waves]
+    uint32_t *ftot;       // [1] events of the frame
     // pixels that need the generic step this frame: {unit, final offset inside its wave segment}
     uint2 *worklist;
-    uint32_t *wl_count;   // zeroed by the scan kernel of the previous frame / by the host
+    uint32_t *wl_count;
     uint32_t *status;
     uint32_t n_units;
     uint32_t num_waves;
@@ -66,22 +68,27 @@ struct FrameArgs {
 // a captured hipGraph of T frames can be replayed for ANY batch of T frames: the host only
 // rewrites this struct (and the running_t table) before launching the graph.
 struct BatchArgs {
-    FrameArgs base;           // per-frame fields (frame, frame_idx, park, wtot, wpref, sc.running_t) are derived
+    FrameArgs base;           // per-frame fields (frame, frame_idx, park, wtot, wpref, ftot, sc.running_t) are derived
     const uint8_t *frames;    // packed [T][n_units]
     const float *running_t;   // [T] PixelArena::running_t before each frame's integrate
-    uint2 *park2[kScratchBuffers];  // scratch ring, indexed by f % kScratchBuffers
-    uint32_t *wtot2[kScratchBuffers];
-    uint32_t *wpref2[kScratchBuffers];
+    // compaction scratch: a ring of `slots` frames
+    uint2 *park_ring;         // [slots][num_waves][kParkPerWave]
+    uint32_t *wtot_ring;      // [slots][num_waves]
+    uint32_t *wpref_ring;     // [slots][num_waves]
+    uint32_t *ftot_ring;      // [slots]
+    uint32_t slots;
 };
 
 __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) {
     FrameArgs a = b->base;
+    const uint32_t slot = f % b->slots;
     a.frame = b->frames + (size_t)f * a.n_units;
     a.frame_idx = f;
     a.sc.running_t = b->running_t[f];
-    a.park = b->park2[f % kScratchBuffers];
-    a.wtot = b->wtot2[f % kScratchBuffers];
-    a.wpref = b->wpref2[f % kScratchBuffers];
+    a.park = b->park_ring + (size_t)slot * a.num_waves * kParkPerWave;
+    a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
+    a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
+    a.ftot = b->ftot_ring + slot;
     return a;
 }
 
@@ -91,8 +98,11 @@ extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
                               hipStream_t stream);                                                   // K1
-hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f, hipStream_t stream);             // Ks
-hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream);  // K2
+// frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked events
+hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
+hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
+hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
+                               hipStream_t stream);
 hipError_t adder_launch_generic(const adder::BatchArgs *b, uint32_t f, uint32_t grid, hipStream_t stream);
 hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);

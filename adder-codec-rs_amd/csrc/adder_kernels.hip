@@ -13,13 +13,14 @@
 //        in a lane-private LDS stack, stores the state, then compacts the events of the
 //        WAVE (ballot-free prefix over cross-lane shuffles, no barrier, no atomics) into
 //        the wave's scratch segment and writes the segment's event count.
-//   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block).
+//   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block per
+//        frame) + adder_offsets_kernel (the frame_offsets chain); run once per CHUNK of frames.
 //   K2 adder_expand_kernel  reads the parked events linearly and writes each 12-byte
 //        event to its final slot of the ordered stream (coordinates from the unit index).
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
-// loop and nothing that can hang; K2 of frame f overlaps K1 of frame f+1 on a second
-// stream.  Pixels whose arena is deeper than one fired level (Normal mode, or
+// loop and nothing that can hang; the scan/expand kernels of a chunk of frames overlap the
+// frame kernels of the next chunk on a second stream.  Pixels whose arena is deeper than one fired level (Normal mode, or
 // delta_t_max > time_spanned) get their output range reserved by K1 (plan_count) and
 // are stepped by adder_generic_kernel (exec_step: the full arena walk) after the scan.
 // Memory-bound integer/f32 work: no MFMA anywhere.
@@ -95,57 +96,58 @@ struct EmitGlobal {
 // K1.  GENERIC = false is used when no pixel can ever be deeper than one fired level
 // (Collapse with delta_t_max <= time_spanned): the eligibility test, the slot reservation
 // for generic pixels and the worklist are compiled out.
+//
+// A wave owns kSegsPerWave consecutive 256-unit segments.  The loads of ALL its segments are
+// issued before any of them is processed, so while one segment is being stepped the next
+// one's state is already streaming in (the step is ~140 VALU instructions per pixel; without
+// this the kernel alternates between a bandwidth phase and a compute phase).
 // ------------------------------------------------------------------------------------------
-template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
-    const FrameArgs a = frame_args(b, f);
-    __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
+struct RawSeg {
+    uint4 hdr;
+    uint32_t vin;
+    float4 li, ld, lb, lf;
+    uint32_t lbd;
+};
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // global wave segment
-    const uint32_t u0 = blockIdx.x * kTileUnits + tid * kUnitsPerLane;
-    const StepConsts sc = a.sc;
-
-    // ---------------- loads: header, input, level 0 ----------------
-    const uint4 hdr4 = *reinterpret_cast<const uint4 *>(a.hdr + u0);
-    const uint32_t hdrv[4] = {hdr4.x, hdr4.y, hdr4.z, hdr4.w};
-    uint32_t vin[4];
+template <bool ABS_T>
+__device__ __forceinline__ void load_segment(const FrameArgs &a, uint32_t u0, RawSeg &r) {
+    r.hdr = *reinterpret_cast<const uint4 *>(a.hdr + u0);
     if (u0 + kUnitsPerLane <= a.n_units) {
-        uint32_t w;
-        __builtin_memcpy(&w, a.frame + u0, 4);
-        vin[0] = w & 0xffu;
-        vin[1] = (w >> 8) & 0xffu;
-        vin[2] = (w >> 16) & 0xffu;
-        vin[3] = w >> 24;
+        __builtin_memcpy(&r.vin, a.frame + u0, 4);
     } else {
+        r.vin = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vin[j] = (u0 + j < a.n_units) ? a.frame[u0 + j] : 0u;
+        for (int j = 0; j < 4; ++j)
+            if (u0 + j < a.n_units) r.vin |= (uint32_t)a.frame[u0 + j] << (8 * j);
     }
-    const bool any_m = (((hdrv[0] | hdrv[1] | hdrv[2] | hdrv[3]) >> 24) & kFlagMMask) != 0u;
+    const bool any_m = (((r.hdr.x | r.hdr.y | r.hdr.z | r.hdr.w) >> 24) & kFlagMMask) != 0u;
+    r.li = r.ld = r.lb = r.lf = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.lbd = 0u;
+    if (any_m) {
+        r.li = *reinterpret_cast<const float4 *>(a.lv_integ + u0);
+        r.ld = *reinterpret_cast<const float4 *>(a.lv_dt + u0);
+        r.lb = *reinterpret_cast<const float4 *>(a.lv_bdt + u0);
+        r.lbd = *reinterpret_cast<const uint32_t *>(a.lv_bd + u0);
+    }
+    if (ABS_T) r.lf = *reinterpret_cast<const float4 *>(a.lastf + u0);
+}
 
+template <bool COLLAPSE, bool ABS_T, bool GENERIC>
+__device__ __forceinline__ void process_segment(const FrameArgs &a, const StepConsts &sc, uint32_t u0, uint32_t gw,
+                                                uint32_t lane, const RawSeg &r, uint2 *my_slots) {
+    const uint32_t hdrv[4] = {r.hdr.x, r.hdr.y, r.hdr.z, r.hdr.w};
+    const uint32_t vin[4] = {r.vin & 0xffu, (r.vin >> 8) & 0xffu, (r.vin >> 16) & 0xffu, r.vin >> 24};
+    const float liv[4] = {r.li.x, r.li.y, r.li.z, r.li.w}, ldv[4] = {r.ld.x, r.ld.y, r.ld.z, r.ld.w};
+    const float lbv[4] = {r.lb.x, r.lb.y, r.lb.z, r.lb.w}, lfv[4] = {r.lf.x, r.lf.y, r.lf.z, r.lf.w};
     PxState px[4];
-    {
-        float4 li = make_float4(0.f, 0.f, 0.f, 0.f), ld = li, lb = li, lf = li;
-        uint32_t lbd = 0u;
-        if (any_m) {
-            li = *reinterpret_cast<const float4 *>(a.lv_integ + u0);
-            ld = *reinterpret_cast<const float4 *>(a.lv_dt + u0);
-            lb = *reinterpret_cast<const float4 *>(a.lv_bdt + u0);
-            lbd = *reinterpret_cast<const uint32_t *>(a.lv_bd + u0);
-        }
-        if (ABS_T) lf = *reinterpret_cast<const float4 *>(a.lastf + u0);
-        const float liv[4] = {li.x, li.y, li.z, li.w}, ldv[4] = {ld.x, ld.y, ld.z, ld.w};
-        const float lbv[4] = {lb.x, lb.y, lb.z, lb.w}, lfv[4] = {lf.x, lf.y, lf.z, lf.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            px[j].hdr = hdrv[j];
-            px[j].n0.integ = liv[j];
-            px[j].n0.dt = ldv[j];
-            px[j].n0.bdt = lbv[j];
-            px[j].n0.bd = (lbd >> (8 * j)) & 0xffu;
-            px[j].lastf = lfv[j];
-        }
+    for (int j = 0; j < 4; ++j) {
+        px[j].hdr = hdrv[j];
+        px[j].n0.integ = liv[j];
+        px[j].n0.dt = ldv[j];
+        px[j].n0.bdt = lbv[j];
+        px[j].n0.bd = (r.lbd >> (8 * j)) & 0xffu;
+        px[j].lastf = lfv[j];
     }
 
     // ---------------- the step; events parked in the lane's LDS stack ----------------
@@ -154,7 +156,6 @@ __global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchA
     uint32_t nl = 0;     // events parked by this lane
     uint32_t cnts = 0;   // per-pixel event counts, 8 bits each
     uint32_t gmask = 0;  // pixels left to the generic kernel
-    uint2 *my_slots = s_slots + tid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool active = u0 + j < a.n_units && !(a.ablate & 2u);
@@ -239,13 +240,31 @@ __global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchA
     }
 }
 
+template <bool COLLAPSE, bool ABS_T, bool GENERIC>
+__global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * kSegsPerWave;  // first segment of the wave
+    const uint32_t u0 = gw0 * kWaveUnits + lane * kUnitsPerLane;
+    const StepConsts sc = a.sc;
+
+    RawSeg r[kSegsPerWave];
+#pragma unroll
+    for (uint32_t g = 0; g < kSegsPerWave; ++g) load_segment<ABS_T>(a, u0 + g * kWaveUnits, r[g]);
+#pragma unroll
+    for (uint32_t g = 0; g < kSegsPerWave; ++g)
+        process_segment<COLLAPSE, ABS_T, GENERIC>(a, sc, u0 + g * kWaveUnits, gw0 + g, lane, r[g], s_slots + tid);
+}
+
 // ------------------------------------------------------------------------------------------
-// Ks: exclusive prefix of the per-segment event counts; also closes the frame's range in
-// frame_offsets and clears the worklist counter for the next frame.  One block.
+// Scan: exclusive prefix of the per-segment event counts of one frame per block
+// (blockIdx.x = frame inside the chunk) and the frame's total.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
-    const FrameArgs a = frame_args(b, f);
+__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+    const FrameArgs a = frame_args(b, f0 + blockIdx.x);
     __shared__ uint32_t s_part[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
@@ -283,14 +302,26 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
         run = o.w + (v.w & 0xffffu);
         dst[g] = o;
     }
-    if (tid == 0) a.frame_offsets[a.frame_idx + 1] = a.frame_offsets[a.frame_idx] + total;
+    if (tid == 0) *a.ftot = total;
+}
+
+// frame_offsets[f+1] = frame_offsets[f] + events(f) for the frames of the chunk, in order.
+__global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t nf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t *offs = b->base.frame_offsets;
+    uint64_t run = offs[f0];
+    for (uint32_t i = 0; i < nf; ++i) {
+        run += b->ftot_ring[(f0 + i) % b->slots];
+        offs[f0 + i + 1] = run;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: parked events -> final 12-byte events of the ordered stream.
+// K2: parked events -> final 12-byte events of the ordered stream (blockIdx.y = frame
+// inside the chunk).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
-    const FrameArgs a = frame_args(b, f);
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+    const FrameArgs a = frame_args(b, f0 + blockIdx.y);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
     if (gw >= a.num_waves) return;
@@ -470,19 +501,26 @@ static FrameKernelFn pick_frame_kernel(uint32_t variant) {
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
                                          hipStream_t stream) {
-    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t per_block = kWavesPerBlock * kSegsPerWave;
+    const uint32_t grid = (num_waves + per_block - 1) / per_block;
     hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f, hipStream_t stream) {
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(1), dim3(kScanThreads), 0, stream, b, f);
+extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf), dim3(kScanThreads), 0, stream, b, f0);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream) {
+extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_offsets_kernel, dim3(1), dim3(64), 0, stream, b, f0, nf);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
+                                          hipStream_t stream) {
     const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid, nf), dim3(kBlockThreads), 0, stream, b, f0);
     return hipGetLastError();
 }
 
