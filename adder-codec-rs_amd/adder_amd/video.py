@@ -163,6 +163,12 @@ class HipVideo:
     def last_launch_avg_us(self):
         return float(self.L.adder_hip_last_launch_avg_us(self.h))
 
+    def last_launch_frames(self):
+        return float(self.L.adder_hip_last_launch_frames(self.h))
+
+    def set_frames_per_launch(self, frames):
+        N.check(self.h, self.L.adder_hip_set_frames_per_launch(self.h, frames))
+
     def reset(self):
         """Back to the freshly constructed state (Video::new); parameters are kept."""
         N.check(self.h, self.L.adder_hip_reset(self.h))

@@ -50,6 +50,7 @@ struct AdderHipCtx {
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2;
+    uint32_t frames_per_launch = 8;  // temporal blocking depth of the frame kernel (non-generic modes)
     uint2 *worklist = nullptr;                 // pixels for the generic kernel
     uint32_t *wl_count = nullptr;
     uint32_t num_waves = 0;
@@ -89,7 +90,7 @@ struct AdderHipCtx {
     // optional per-launch timing (one HIP event pair around every frame launch)
     bool launch_timing = false;
     std::vector<hipEvent_t> launch_events;
-    uint32_t timed_launches = 0;
+    uint32_t timed_launches = 0, timed_frames = 0;
     float last_launch_avg_us = 0.0f;
 };
 
@@ -173,6 +174,7 @@ static StepConsts make_consts(const AdderHipCtx *c, float time_spanned, float ru
     StepConsts sc;
     sc.time_spanned = time_spanned;
     sc.running_t = running_t;
+    sc.running_t_u32 = f32_as_u32(running_t);
     sc.dtm_f = (float)c->p.delta_t_max;
     sc.ref_time = c->p.ref_time;
     sc.c_thresh_max = c->p.c_thresh_max;
@@ -289,8 +291,12 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "row band too large (%llu pixel-channels)", (unsigned long long)units);
     }
     c->n_units = (uint32_t)units;
-    c->num_tiles = (c->n_units + kTileUnits - 1) / kTileUnits;  // K1 blocks
-    c->n_pad = (size_t)c->num_tiles * kTileUnits;
+    // pad to a whole number of K1 blocks and of 8-segment groups (the expand kernel's unit)
+    {
+        const uint32_t quantum = std::max<uint32_t>(kTileUnits, 8u * kWaveUnits);
+        c->n_pad = (size_t)((c->n_units + quantum - 1) / quantum) * quantum;
+        c->num_tiles = (uint32_t)(c->n_pad / kTileUnits);  // K1 blocks
+    }
     c->num_waves = (uint32_t)(c->n_pad / kWaveUnits);
     c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
     c->max_depth = p.max_depth;
@@ -328,6 +334,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[0], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[1], hipEventDisableTiming));
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
+        if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
+            c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->worklist, c->n_pad));
         HIPCHK(c, dalloc(&c->wl_count, 1));
         HIPCHK(c, dalloc(&c->status, 1));
@@ -416,12 +424,18 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
         if (s2 && k >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[k & 1u], 0));
-        for (uint32_t f = f0; f < f0 + nf; ++f) {
-            if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * f], s));
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, variant, c->num_waves, s));
+        // temporal blocking: one K1 launch steps `nb` consecutive frames with the pixel state
+        // in registers; not with generic pixels (their kernel runs between frames) nor with the
+        // running-intensities side plane (per-frame semantics)
+        const uint32_t depth = (generic || c->running_enabled) ? 1u : c->frames_per_launch;
+        for (uint32_t f = f0; f < f0 + nf; f += depth) {
+            const uint32_t nb = std::min(depth, f0 + nf - f);
+            if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
-                HIPCHK(c, hipEventRecord(c->launch_events[2 * f + 1], s));
-                c->timed_launches = f + 1;
+                HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
+                c->timed_launches += 1;
+                c->timed_frames += nb;
             }
             if (generic) {
                 HIPCHK(c, adder_launch_scan(c->d_batch, f, 1, s));
@@ -523,6 +537,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
 
     c->timed_launches = 0;
+    c->timed_frames = 0;
     const bool timing = c->launch_timing;
     if (timing) {
         while (c->launch_events.size() < 2 * (size_t)num_frames) {
@@ -612,6 +627,18 @@ extern "C" int adder_hip_set_launch_timing(AdderHipCtx *c, int enable) {
 }
 
 extern "C" float adder_hip_last_launch_avg_us(AdderHipCtx *c) { return c ? c->last_launch_avg_us : 0.0f; }
+
+extern "C" float adder_hip_last_launch_frames(AdderHipCtx *c) {
+    return (c && c->timed_launches) ? (float)c->timed_frames / (float)c->timed_launches : 0.0f;
+}
+
+extern "C" int adder_hip_set_frames_per_launch(AdderHipCtx *c, uint32_t frames) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (frames < 1 || frames > kMaxFramesPerLaunch)
+        return fail(c, ADDER_E_BAD_PARAMS, "frames_per_launch must be in 1..%u", kMaxFramesPerLaunch);
+    c->frames_per_launch = frames;
+    return ADDER_OK;
+}
 
 extern "C" int adder_hip_reset(AdderHipCtx *c) {
     if (!c) return ADDER_E_BAD_PARAMS;

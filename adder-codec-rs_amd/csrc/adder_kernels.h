@@ -10,13 +10,20 @@
 namespace adder {
 
 constexpr uint32_t kBlockThreads = 256;
-constexpr uint32_t kUnitsPerLane = 4;                              // pixel-channels per lane and segment
-constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // 256 units per wave segment
-constexpr uint32_t kSegsPerWave = 2;                               // segments a K1 wave processes (prefetched)
-constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane * kSegsPerWave;  // 2048 units per K1 block
-constexpr uint32_t kSlotsPerLane = 12;                             // 4 px x 3 fast-path events
+#ifndef ADDER_UNITS_PER_LANE
+#define ADDER_UNITS_PER_LANE 2
+#endif
+#ifndef ADDER_FRAME_WAVES_PER_SIMD
+#define ADDER_FRAME_WAVES_PER_SIMD 8
+#endif
+constexpr uint32_t kUnitsPerLane = ADDER_UNITS_PER_LANE;           // pixel-channels per lane (2 or 4)
+constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // units per wave segment
+constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // units per K1 block
+constexpr uint32_t kSlotsPerLane = 3 * kUnitsPerLane;              // <= 3 fast-path events per pixel
+constexpr uint32_t kFrameKernelWavesPerSimd = ADDER_FRAME_WAVES_PER_SIMD;  // register budget of K1
 constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
 constexpr uint32_t kMaxChunk = 16;                                 // frames per scan/expand launch
+constexpr uint32_t kMaxFramesPerLaunch = 8;                        // temporal blocking depth of K1
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
@@ -85,6 +92,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     a.frame = b->frames + (size_t)f * a.n_units;
     a.frame_idx = f;
     a.sc.running_t = b->running_t[f];
+    a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.park = b->park_ring + (size_t)slot * a.num_waves * kParkPerWave;
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
@@ -96,8 +104,9 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 
 extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
-hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
-                              hipStream_t stream);                                                   // K1
+// K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking, non-generic variants only)
+hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
+                              uint32_t num_waves, hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked events
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);

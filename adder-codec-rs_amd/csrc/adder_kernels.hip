@@ -102,160 +102,219 @@ struct EmitGlobal {
 // one's state is already streaming in (the step is ~140 VALU instructions per pixel; without
 // this the kernel alternates between a bandwidth phase and a compute phase).
 // ------------------------------------------------------------------------------------------
-struct RawSeg {
-    uint4 hdr;
-    uint32_t vin;
-    float4 li, ld, lb, lf;
-    uint32_t lbd;
-};
+// kUnitsPerLane consecutive values as one vector access
+template <class T, int N>
+struct VecOf;
+template <> struct VecOf<uint32_t, 4> { using type = uint4; };
+template <> struct VecOf<uint32_t, 2> { using type = uint2; };
+template <> struct VecOf<float, 4> { using type = float4; };
+template <> struct VecOf<float, 2> { using type = float2; };
+template <> struct VecOf<uint8_t, 4> { using type = uint32_t; };
+template <> struct VecOf<uint8_t, 2> { using type = uint16_t; };
 
-template <bool ABS_T>
-__device__ __forceinline__ void load_segment(const FrameArgs &a, uint32_t u0, RawSeg &r) {
-    r.hdr = *reinterpret_cast<const uint4 *>(a.hdr + u0);
-    if (u0 + kUnitsPerLane <= a.n_units) {
-        __builtin_memcpy(&r.vin, a.frame + u0, 4);
-    } else {
-        r.vin = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (u0 + j < a.n_units) r.vin |= (uint32_t)a.frame[u0 + j] << (8 * j);
-    }
-    const bool any_m = (((r.hdr.x | r.hdr.y | r.hdr.z | r.hdr.w) >> 24) & kFlagMMask) != 0u;
-    r.li = r.ld = r.lb = r.lf = make_float4(0.f, 0.f, 0.f, 0.f);
-    r.lbd = 0u;
-    if (any_m) {
-        r.li = *reinterpret_cast<const float4 *>(a.lv_integ + u0);
-        r.ld = *reinterpret_cast<const float4 *>(a.lv_dt + u0);
-        r.lb = *reinterpret_cast<const float4 *>(a.lv_bdt + u0);
-        r.lbd = *reinterpret_cast<const uint32_t *>(a.lv_bd + u0);
-    }
-    if (ABS_T) r.lf = *reinterpret_cast<const float4 *>(a.lastf + u0);
+template <class T>
+__device__ __forceinline__ void load_vec(const T *p, T (&v)[kUnitsPerLane]) {
+    using V = typename VecOf<T, kUnitsPerLane>::type;
+    const V x = *reinterpret_cast<const V *>(p);
+    __builtin_memcpy(v, &x, sizeof(V));
+}
+template <class T>
+__device__ __forceinline__ void store_vec(T *p, const T (&v)[kUnitsPerLane]) {
+    using V = typename VecOf<T, kUnitsPerLane>::type;
+    V x;
+    __builtin_memcpy(&x, v, sizeof(V));
+    *reinterpret_cast<V *>(p) = x;
 }
 
-template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__device__ __forceinline__ void process_segment(const FrameArgs &a, const StepConsts &sc, uint32_t u0, uint32_t gw,
-                                                uint32_t lane, const RawSeg &r, uint2 *my_slots) {
-    const uint32_t hdrv[4] = {r.hdr.x, r.hdr.y, r.hdr.z, r.hdr.w};
-    const uint32_t vin[4] = {r.vin & 0xffu, (r.vin >> 8) & 0xffu, (r.vin >> 16) & 0xffu, r.vin >> 24};
-    const float liv[4] = {r.li.x, r.li.y, r.li.z, r.li.w}, ldv[4] = {r.ld.x, r.ld.y, r.ld.z, r.ld.w};
-    const float lbv[4] = {r.lb.x, r.lb.y, r.lb.z, r.lb.w}, lfv[4] = {r.lf.x, r.lf.y, r.lf.z, r.lf.w};
-    PxState px[4];
+// the lane's kUnitsPerLane input bytes of one frame, packed little-endian
+__device__ __forceinline__ uint32_t load_input(const uint8_t *frame, uint32_t u0, uint32_t n_units) {
+    uint32_t w = 0u;
+    if (u0 + kUnitsPerLane <= n_units) {
+        typename VecOf<uint8_t, kUnitsPerLane>::type x;
+        __builtin_memcpy(&x, frame + u0, kUnitsPerLane);
+        w = x;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        px[j].hdr = hdrv[j];
-        px[j].n0.integ = liv[j];
-        px[j].n0.dt = ldv[j];
-        px[j].n0.bdt = lbv[j];
-        px[j].n0.bd = (r.lbd >> (8 * j)) & 0xffu;
-        px[j].lastf = lfv[j];
+        for (uint32_t j = 0; j < kUnitsPerLane; ++j)
+            if (u0 + j < n_units) w |= (uint32_t)frame[u0 + j] << (8 * j);
     }
+    return w;
+}
 
-    // ---------------- the step; events parked in the lane's LDS stack ----------------
-    // Branch-free parking: all three candidate events are written, the stack pointer only
-    // advances past the valid ones (hence kSlotsPerLane + 1 rows).
-    uint32_t nl = 0;     // events parked by this lane
-    uint32_t cnts = 0;   // per-pixel event counts, 8 bits each
-    uint32_t gmask = 0;  // pixels left to the generic kernel
+// inclusive prefix sum across the wave with DPP row shifts / broadcasts (no LDS traffic)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
+    // row_shr:1,2,4,8 within rows of 16, then row_bcast:15 and row_bcast:31
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+    return x;
+}
+
+// One segment (64 lanes x kUnitsPerLane units) through `nb` consecutive frames starting at
+// a.frame_idx.  The pixel state lives in registers for the whole run (temporal blocking): it
+// is read from HBM once and written back once; per frame only the input bytes are loaded
+// (one frame ahead) and the segment's events are compacted into that frame's scratch slot.
+// nb > 1 is only used when no pixel can need the generic kernel.
+template <bool COLLAPSE, bool ABS_T, bool GENERIC>
+__device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
+                                            uint32_t u0, uint32_t gw, uint32_t lane, uint2 *my_slots) {
+    constexpr uint32_t N = kUnitsPerLane;
+    PxState px[N];
+    uint32_t vin_w;
+    {
+        uint32_t hdrv[N];
+        load_vec(a.hdr + u0, hdrv);
+        vin_w = load_input(a.frame, u0, a.n_units);
+        uint32_t hor = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool active = u0 + j < a.n_units && !(a.ablate & 2u);
-        if (!GENERIC || fast_eligible<COLLAPSE>(px[j], vin[j])) {
-            FastEvents fe;
-            PxState nx = px[j];
-            step_fast<COLLAPSE, ABS_T>(nx, vin[j], sc, fe);
-            if (active) px[j] = nx;
-            const uint32_t mask = active ? fe.mask : 0u;
-            const uint32_t tag = (uint32_t)j << 8;
-            my_slots[nl * kBlockThreads] = make_uint2(fe.ta, fe.da | tag);
-            nl += mask & 1u;
-            my_slots[nl * kBlockThreads] = make_uint2(fe.tb, fe.db | tag | (1u << 10));
-            nl += (mask >> 1) & 1u;
-            // index of the event inside its pixel: after A and B if present
-            const uint32_t kc = (mask & 1u) + ((mask >> 1) & 1u);
-            my_slots[nl * kBlockThreads] = make_uint2(fe.tc, fe.dc | tag | (kc << 10));
-            nl += mask >> 2;
-            cnts |= (uint32_t)__popc(mask) << (8 * j);
-        } else if (active) {
-            cnts |= plan_count(px[j], vin[j], sc) << (8 * j);
-            gmask |= 1u << j;
+        for (uint32_t j = 0; j < N; ++j) hor |= hdrv[j];
+        float liv[N], ldv[N], lbv[N], lfv[N];
+        uint8_t bdv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            liv[j] = ldv[j] = lbv[j] = lfv[j] = 0.0f;
+            bdv[j] = 0;
+        }
+        if ((hor >> 24) & kFlagMMask) {
+            load_vec(a.lv_integ + u0, liv);
+            load_vec(a.lv_dt + u0, ldv);
+            load_vec(a.lv_bdt + u0, lbv);
+            load_vec(a.lv_bd + u0, bdv);
+        }
+        if (ABS_T) load_vec(a.lastf + u0, lfv);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            px[j].hdr = hdrv[j];
+            px[j].n0.integ = liv[j];
+            px[j].n0.dt = ldv[j];
+            px[j].n0.bdt = lbv[j];
+            px[j].n0.bd = bdv[j];
+            px[j].lastf = lfv[j];
         }
     }
-    const uint32_t lane_cnt = (cnts & 0xffu) + ((cnts >> 8) & 0xffu) + ((cnts >> 16) & 0xffu) + (cnts >> 24);
+    StepConsts sc = a.sc;
+    uint32_t gmask = 0;  // pixels left to the generic kernel (nb == 1 only)
+
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t f = a.frame_idx + i;
+        uint32_t next_w = 0u;
+        if (i + 1 < nb) next_w = load_input(b->frames + (size_t)(f + 1) * a.n_units, u0, a.n_units);
+        // wave-uniform per-frame values, pinned to SGPRs so they are fetched once per frame
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(f % b->slots);
+        sc.running_t = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->running_t[f])));
+        sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
+
+        // ---------------- the step; events parked in the lane's LDS stack ----------------
+        // Branch-free parking: all three candidate events are written, the stack pointer only
+        // advances past the valid ones (hence kSlotsPerLane + 1 rows).
+        uint32_t nl = 0;    // events parked by this lane
+        uint32_t cnts = 0;  // per-pixel event counts, 8 bits each
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            // units past the band's end are padding: their state may be stepped freely, only
+            // their events must be suppressed
+            const bool active = u0 + j < a.n_units;
+            if (!GENERIC || fast_eligible<COLLAPSE>(px[j], v)) {
+                FastEvents fe;
+                step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe);
+                const uint32_t mask = active ? fe.mask : 0u;
+                const uint32_t tag = j << 8;
+                my_slots[nl * kBlockThreads] = make_uint2(fe.ta, fe.da | tag);
+                nl += mask & 1u;
+                my_slots[nl * kBlockThreads] = make_uint2(fe.tb, fe.db | tag | (1u << 10));
+                nl += (mask >> 1) & 1u;
+                // index of the event inside its pixel: after A and B if present
+                const uint32_t kc = (mask & 1u) + ((mask >> 1) & 1u);
+                my_slots[nl * kBlockThreads] = make_uint2(fe.tc, fe.dc | tag | (kc << 10));
+                nl += mask >> 2;
+                cnts |= (uint32_t)__popc(mask) << (8 * j);
+            } else if (active) {
+                cnts |= plan_count(px[j], v, sc) << (8 * j);
+                gmask |= 1u << j;
+            }
+        }
+        uint32_t lane_cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) lane_cnt += (cnts >> (8 * j)) & 0xffu;
+
+        // ---------------- wave-level ordered compaction into the frame's segment ----------------
+        // low half: events of the lane in the final stream; high half: events it parked
+        const uint32_t packed = lane_cnt | (nl << 16);
+        const uint32_t incl = wave_inclusive_scan_dpp(packed);
+        if (lane == kWave - 1) b->wtot_ring[(size_t)slot * a.num_waves + gw] = incl;
+        const uint32_t excl = incl - packed;
+        const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
+        // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
+        const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
+        uint2 *dst = b->park_ring + ((size_t)slot * a.num_waves + gw) * kParkPerWave + (excl >> 16);
+        for (uint32_t e = 0; e < nl; ++e) {
+            uint2 sl = my_slots[e * kBlockThreads];
+            const uint32_t j = (sl.y >> 8) & 3u;
+            const uint32_t off =
+                GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) + ((sl.y >> 10) & 3u) : lane_off + e;
+            sl.y = (sl.y & 0xffu) | ((lane * N + j) << 8) | (off << 16);
+            dst[e] = sl;
+        }
+        if (GENERIC && gmask) {
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                if ((gmask >> j) & 1u) {
+                    const uint32_t wslot = atomicAdd(a.wl_count, 1u);
+                    a.worklist[wslot] = make_uint2(u0 + j, lane_off + ((pre >> (8 * j)) & 0xffu));
+                }
+            }
+        }
+        vin_w = next_w;
+    }
 
     // ---------------- state back to HBM (generic pixels keep their old state) ----------------
     {
-        uint4 h;
-        h.x = px[0].hdr;
-        h.y = px[1].hdr;
-        h.z = px[2].hdr;
-        h.w = px[3].hdr;
-        *reinterpret_cast<uint4 *>(a.hdr + u0) = h;
-        if (((h.x | h.y | h.z | h.w) >> 24) & kFlagMMask) {
-            *reinterpret_cast<float4 *>(a.lv_integ + u0) =
-                make_float4(px[0].n0.integ, px[1].n0.integ, px[2].n0.integ, px[3].n0.integ);
-            *reinterpret_cast<float4 *>(a.lv_dt + u0) =
-                make_float4(px[0].n0.dt, px[1].n0.dt, px[2].n0.dt, px[3].n0.dt);
-            *reinterpret_cast<float4 *>(a.lv_bdt + u0) =
-                make_float4(px[0].n0.bdt, px[1].n0.bdt, px[2].n0.bdt, px[3].n0.bdt);
-            *reinterpret_cast<uint32_t *>(a.lv_bd + u0) = (px[0].n0.bd & 0xffu) | ((px[1].n0.bd & 0xffu) << 8) |
-                                                          ((px[2].n0.bd & 0xffu) << 16) | (px[3].n0.bd << 24);
-        }
-        if (ABS_T)
-            *reinterpret_cast<float4 *>(a.lastf + u0) =
-                make_float4(px[0].lastf, px[1].lastf, px[2].lastf, px[3].lastf);
-        if (a.running) {
+        uint32_t hdrv[N];
+        float liv[N], ldv[N], lbv[N], lfv[N];
+        uint8_t bdv[N];
+        uint32_t hor = 0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (uint32_t j = 0; j < N; ++j) {
+            hdrv[j] = px[j].hdr;
+            hor |= px[j].hdr;
+            liv[j] = px[j].n0.integ;
+            ldv[j] = px[j].n0.dt;
+            lbv[j] = px[j].n0.bdt;
+            bdv[j] = (uint8_t)px[j].n0.bd;
+            lfv[j] = px[j].lastf;
+        }
+        store_vec(a.hdr + u0, hdrv);
+        if ((hor >> 24) & kFlagMMask) {
+            store_vec(a.lv_integ + u0, liv);
+            store_vec(a.lv_dt + u0, ldv);
+            store_vec(a.lv_bdt + u0, lbv);
+            store_vec(a.lv_bd + u0, bdv);
+        }
+        if (ABS_T) store_vec(a.lastf + u0, lfv);
+        if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j)
                 if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((px[j].hdr >> 24) & kFlagMMask))
                     a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
                                                                 (double)sc.ref_time);
         }
     }
-
-    // ---------------- wave-level ordered compaction into the segment ----------------
-    // low half: events of the lane in the final stream; high half: events it parked
-    const uint32_t packed = lane_cnt | (nl << 16);
-    const uint32_t incl = wave_inclusive_scan(packed, lane);
-    if (lane == kWave - 1) a.wtot[gw] = incl;
-    const uint32_t excl = incl - packed;
-    const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
-    // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
-    const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
-    uint2 *dst = a.park + (size_t)gw * kParkPerWave + (excl >> 16);
-    for (uint32_t i = 0; i < nl; ++i) {
-        uint2 sl = my_slots[i * kBlockThreads];
-        const uint32_t j = (sl.y >> 8) & 3u;
-        const uint32_t off = GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) + ((sl.y >> 10) & 3u) : lane_off + i;
-        sl.y = (sl.y & 0xffu) | ((lane * kUnitsPerLane + j) << 8) | (off << 16);
-        dst[i] = sl;
-    }
-    if (GENERIC && gmask) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if ((gmask >> j) & 1u) {
-                const uint32_t slot = atomicAdd(a.wl_count, 1u);
-                a.worklist[slot] = make_uint2(u0 + j, lane_off + ((pre >> (8 * j)) & 0xffu));
-            }
-        }
-    }
 }
 
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+__global__ __launch_bounds__(kBlockThreads, kFrameKernelWavesPerSimd) void adder_frame_kernel(
+    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
     __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * kSegsPerWave;  // first segment of the wave
-    const uint32_t u0 = gw0 * kWaveUnits + lane * kUnitsPerLane;
-    const StepConsts sc = a.sc;
-
-    RawSeg r[kSegsPerWave];
-#pragma unroll
-    for (uint32_t g = 0; g < kSegsPerWave; ++g) load_segment<ABS_T>(a, u0 + g * kWaveUnits, r[g]);
-#pragma unroll
-    for (uint32_t g = 0; g < kSegsPerWave; ++g)
-        process_segment<COLLAPSE, ABS_T, GENERIC>(a, sc, u0 + g * kWaveUnits, gw0 + g, lane, r[g], s_slots + tid);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
+    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane, s_slots + tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,41 +377,82 @@ __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f
 
 // ------------------------------------------------------------------------------------------
 // K2: parked events -> final 12-byte events of the ordered stream (blockIdx.y = frame
-// inside the chunk).
+// inside the chunk).  A segment parks only a few dozen events, so a wave per segment would
+// be nothing but start-up latency (kernel arguments -> metadata -> parked slots -> store).
+// Each wave therefore takes kExpandSegs consecutive segments and issues ALL their loads --
+// metadata and, speculatively, the first 64 parked slots of every segment -- before it
+// consumes any of them: one memory round trip per wave.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kExpandSegs = 8;
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
-    const FrameArgs a = frame_args(b, f0 + blockIdx.y);
+    // only the frame-independent part of the arguments is needed here (no running_t fetch)
+    const uint32_t f = f0 + blockIdx.y;
+    const uint32_t slot = f % b->slots;
+    const uint32_t num_waves = b->base.num_waves;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-    if (gw >= a.num_waves) return;
-    const uint32_t parked = a.wtot[gw] >> 16;
-    if (parked == 0u) return;
-    const uint64_t base = a.frame_offsets[a.frame_idx] + a.wpref[gw];
-    const uint2 *src = a.park + (size_t)gw * kParkPerWave;
-    EventWords *out = reinterpret_cast<EventWords *>(a.out);
+    const uint32_t seg0 = (blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs;
+    if (seg0 >= num_waves) return;
+    const uint2 *park = b->park_ring + (size_t)slot * num_waves * kParkPerWave;
+    const uint32_t *wtot = b->wtot_ring + (size_t)slot * num_waves;
+    const uint32_t *wpref = b->wpref_ring + (size_t)slot * num_waves;
+    const uint32_t rowlen = b->base.rowlen, channels = b->base.channels, row_begin = b->base.row_begin;
+    const uint64_t out_cap = b->base.out_cap;
+
+    // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly)
+    uint2 first[kExpandSegs];
+#pragma unroll
+    for (uint32_t q = 0; q < kExpandSegs; ++q) first[q] = park[(size_t)(seg0 + q) * kParkPerWave + lane];
+    uint32_t my_tot = 0u, my_pref = 0u;
+    if (lane < kExpandSegs) {
+        my_tot = wtot[seg0 + lane];
+        my_pref = wpref[seg0 + lane];
+    }
+    const uint64_t frame_base = b->base.frame_offsets[f];
+    EventWords *out = reinterpret_cast<EventWords *>(b->base.out);
     bool dropped = false;
-    for (uint32_t i = lane; i < parked; i += kWave) {
-        const uint2 sl = src[i];
-        const uint32_t u = gw * kWaveUnits + ((sl.y >> 8) & 0xffu);
-        const uint32_t y = u / a.rowlen;
-        const uint32_t rem = u - y * a.rowlen;
-        uint32_t x = rem, c = 0xffu;
-        if (a.channels != 1u) {
-            x = rem / a.channels;
-            c = rem - x * a.channels;
-        }
-        const uint64_t pos = base + (sl.y >> 16);
-        if (pos < a.out_cap) {
-            EventWords w;
-            w.xy = x | ((y + a.row_begin) << 16);
-            w.cd = c | ((sl.y & 0xffu) << 8);
-            w.t = sl.x;
-            out[pos] = w;
-        } else {
-            dropped = true;
+    const bool one_wrap = rowlen >= kWaveUnits;
+#pragma unroll
+    for (uint32_t q = 0; q < kExpandSegs; ++q) {
+        const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
+        if (parked == 0u) continue;
+        const uint32_t gw = seg0 + q;
+        const uint64_t base = frame_base + __builtin_amdgcn_readlane(my_pref, q);
+        // (row, offset in row) of the segment's first unit: one wave-uniform division instead
+        // of one per event; a segment spans at most one row boundary when rowlen >= kWaveUnits
+        const uint32_t ubase = gw * kWaveUnits;
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(ubase / rowlen);
+        const uint32_t rem0 = ubase - y0 * rowlen;
+        for (uint32_t i = lane; i < parked; i += kWave) {
+            const uint2 sl = (i == lane) ? first[q] : park[(size_t)gw * kParkPerWave + i];
+            uint32_t rem = rem0 + ((sl.y >> 8) & 0xffu);
+            uint32_t y = y0;
+            if (one_wrap) {
+                const bool wrap = rem >= rowlen;
+                rem -= wrap ? rowlen : 0u;
+                y += wrap ? 1u : 0u;
+            } else {
+                const uint32_t d = rem / rowlen;
+                rem -= d * rowlen;
+                y += d;
+            }
+            uint32_t x = rem, c = 0xffu;
+            if (channels == 3u) {
+                x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
+                c = rem - 3u * x;
+            }
+            const uint64_t pos = base + (sl.y >> 16);
+            if (pos < out_cap) {
+                EventWords w;
+                w.xy = x | ((y + row_begin) << 16);
+                w.cd = c | ((sl.y & 0xffu) << 8);
+                w.t = sl.x;
+                out[pos] = w;
+            } else {
+                dropped = true;
+            }
         }
     }
-    if (dropped) raise(a.status, kStatusCapacity);
+    if (dropped) raise(b->base.status, kStatusCapacity);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -489,7 +589,7 @@ __global__ void adder_synth_kernel(uint8_t *dst, int content, uint64_t seed, uin
 // ------------------------- launch wrappers (called from adder_hip_api.cpp) -------------------------
 using namespace adder;
 
-typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t);
+typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t);
 static FrameKernelFn pick_frame_kernel(uint32_t variant) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     if (collapse) {
@@ -499,11 +599,10 @@ static FrameKernelFn pick_frame_kernel(uint32_t variant) {
     return abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
 }
 
-extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t variant, uint32_t num_waves,
-                                         hipStream_t stream) {
-    const uint32_t per_block = kWavesPerBlock * kSegsPerWave;
-    const uint32_t grid = (num_waves + per_block - 1) / per_block;
-    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
+                                         uint32_t num_waves, hipStream_t stream) {
+    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(grid), dim3(kBlockThreads), 0, stream, b, f, nb);
     return hipGetLastError();
 }
 
@@ -519,7 +618,8 @@ extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint
 
 extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                           hipStream_t stream) {
-    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
+    const uint32_t grid = (num_waves + per_block - 1) / per_block;
     hipLaunchKernelGGL(adder_expand_kernel, dim3(grid, nf), dim3(kBlockThreads), 0, stream, b, f0);
     return hipGetLastError();
 }

@@ -59,6 +59,7 @@ constexpr uint32_t kMaxDepthLimit = 31;
 struct StepConsts {
     float time_spanned;  // `time` of PixelArena::integrate
     float running_t;     // PixelArena::running_t BEFORE this frame's integrate
+    uint32_t running_t_u32;  // running_t as u32 (the t of a D_EMPTY event)
     float dtm_f;         // delta_t_max as f32 (event_pixel_tree.rs:394)
     uint32_t ref_time;
     uint32_t c_thresh_max;
@@ -270,7 +271,7 @@ ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents
         ev.da = s.n0.bd;
         ev.ta = f32_as_u32(evdt);
         ev.db = kDEmpty;
-        ev.tb = f32_as_u32(sc.running_t);
+        ev.tb = sc.running_t_u32;
     }
     has0 = has0 && !flush;
     popped = popped && !flush;

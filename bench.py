@@ -132,6 +132,7 @@ def main():
     hv.set_launch_timing(True)
     step()
     launch_us = hv.last_launch_avg_us()
+    launch_frames = hv.last_launch_frames() or 1.0
     hv.set_launch_timing(False)
 
     if rank != 0:
@@ -144,12 +145,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = pixels_per_step / (elapsed / args.steps) / 1e6
     e = total_events / float(units * world * T)
-    # B = 1 + (S_in + S_out)/T_launch + 12 e ; S = 20 B (Collapse/DeltaT),
-    # +4 B with AbsoluteT; one frame per launch.
+    # B = 1 + (S_in + S_out)/T_launch + 12 e per pixel-channel-frame;
+    # S = 20 B (Collapse/DeltaT), +4 B with AbsoluteT; T_launch = frames one launch steps.
     S = 20 + (4 if tmode == A.TIME_ABSOLUTE_T else 0)
     e_rank0 = n_events / float(units * T)
-    bytes_per_unit = 1 + 2 * S + 12 * e_rank0
-    achieved = bytes_per_unit * units / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+    bytes_per_unit = 1 + 2 * S / launch_frames + 12 * e_rank0
+    units_per_launch = units * launch_frames
+    achieved = bytes_per_unit * units_per_launch / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -191,8 +193,9 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "bytes_per_unit": round(bytes_per_unit, 3),
-            "units_per_launch": units,
+            "bytes_per_unit_frame": round(bytes_per_unit, 3),
+            "frames_per_launch": launch_frames,
+            "units_per_launch": int(units_per_launch),
             "launch_avg_us": round(launch_us, 3),
         },
     }

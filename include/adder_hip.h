@@ -162,6 +162,14 @@ float adder_hip_last_batch_ms(AdderHipCtx *ctx);
  * packets slow the batch down, so throughput runs leave it off). */
 int adder_hip_set_launch_timing(AdderHipCtx *ctx, int enable);
 float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
+/* Mean number of frames one timed frame-kernel launch stepped (see frames_per_launch). */
+float adder_hip_last_launch_frames(AdderHipCtx *ctx);
+
+/* Temporal blocking depth of the frame kernel: how many consecutive frames of a batch one
+ * launch steps with the pixel state held in registers (1..8, default 8).  Results do not
+ * depend on it.  It only applies to batches in which no pixel can be deeper than one fired
+ * node (Collapse with delta_t_max <= time_spanned); other batches run one frame per launch. */
+int adder_hip_set_frames_per_launch(AdderHipCtx *ctx, uint32_t frames);
 
 /* Back to the state right after adder_hip_create (Video::new): every pixel pristine,
  * c_thresh/counter = c_thresh_start/c_counter_start, running_t = 0, poison cleared.

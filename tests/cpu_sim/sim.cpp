@@ -116,6 +116,7 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     StepConsts sc;
     sc.time_spanned = time_spanned;
     sc.running_t = s->running_t;
+    sc.running_t_u32 = f32_as_u32(s->running_t);
     sc.dtm_f = (float)s->dtm;
     sc.ref_time = s->ref_time;
     sc.c_thresh_max = s->c_max;
