@@ -1,0 +1,389 @@
+// adder_host.cpp -- see adder_host.hpp.  Reference file:line citations are in the header.
+#include "adder_host.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace adder_host {
+
+// ---------------------------------------------------------------- PlaneSize
+PlaneSize::PlaneSize(uint16_t width, uint16_t height, uint8_t channels)
+    : width_(width), height_(height), channels_(channels) {
+    if (width == 0 || height == 0 || channels == 0)  // PlaneError::InvalidPlane (lib.rs:103-110)
+        throw SourceError(SourceError::BadParams, "invalid plane " + std::to_string(width) + "x" +
+                                                      std::to_string(height) + "x" + std::to_string(channels));
+}
+
+// ---------------------------------------------------------------- Crf
+// baseline C, max C, C increase velocity, feature radius (x min resolution)
+const float CRF[10][4] = {
+    {0.0f, 0.0f, 10.0f, 1E-9f},         {0.0f, 1.0f, 9.0f, 1.0f / 12.0f},  {1.0f, 3.0f, 8.0f, 1.0f / 14.0f},
+    {2.0f, 7.0f, 7.0f, 1.0f / 15.0f},   {5.0f, 9.0f, 6.0f, 1.0f / 18.0f},  {6.0f, 10.0f, 5.0f, 1.0f / 20.0f},
+    {7.0f, 13.0f, 4.0f, 1.0f / 25.0f},  {8.0f, 16.0f, 3.0f, 1.0f / 30.0f}, {10.0f, 20.0f, 2.0f, 1.0f / 30.0f},
+    {15.0f, 25.0f, 1.0f, 1.0f / 30.0f},
+};
+
+static CrfParameters crf_row(uint8_t q, PlaneSize plane) {
+    if (q > 9) throw SourceError(SourceError::BadParams, "crf must be in 0..9");
+    CrfParameters p;
+    p.c_thresh_baseline = (uint8_t)CRF[q][0];
+    p.c_thresh_max = (uint8_t)CRF[q][1];
+    p.c_increase_velocity = (uint8_t)CRF[q][2];
+    p.feature_c_radius = (uint16_t)(CRF[q][3] * (float)plane.min_resolution());
+    return p;
+}
+
+Crf::Crf(std::optional<uint8_t> crf, PlaneSize plane_)
+    : plane(plane_), quality_(crf), parameters_(crf_row(crf.value_or(DEFAULT_CRF_QUALITY), plane_)) {}
+
+void Crf::update_quality(uint8_t crf) {
+    parameters_ = crf_row(crf, plane);
+    quality_ = crf;
+}
+
+// ---------------------------------------------------------------- Encoder
+Encoder::Encoder(CodecMetadata meta, std::ostream *w, EncoderOptions o, EncoderType t)
+    : options(o), meta_(meta), writer_(w), type_(t) {}
+
+Encoder Encoder::new_raw(CodecMetadata meta, std::ostream *writer, EncoderOptions options) {
+    if (!writer) throw CodecError(CodecError::Io, "raw encoder needs a writer");
+    meta.event_size = meta.plane.c() == 1 ? 9 : 11;  // RawOutput::new (raw/stream.rs:33-46)
+    Encoder e(meta, writer, options, EncoderType::Raw);
+    e.encode_header();
+    return e;
+}
+
+Encoder Encoder::new_empty(CodecMetadata meta, EncoderOptions options) {
+    Encoder e(meta, nullptr, options, EncoderType::Empty);
+    e.encode_header();
+    return e;
+}
+
+void Encoder::encode_header() {
+    uint8_t buf[64];
+    const size_t n = adder_raw_header(buf, meta_.codec_version, meta_.plane.w(), meta_.plane.h(), meta_.plane.c(),
+                                      meta_.tps, meta_.ref_interval, meta_.delta_t_max,
+                                      (uint32_t)meta_.source_camera, (uint32_t)meta_.time_mode,
+                                      (uint32_t)meta_.adu_interval);
+    if (meta_.codec_version > LATEST_CODEC_VERSION) throw CodecError(CodecError::BadFile, "bad codec version");
+    if (writer_) writer_->write(reinterpret_cast<const char *>(buf), (std::streamsize)n);
+    meta_.header_size = n;
+}
+
+void Encoder::ingest_events(const Event *events, size_t n) {
+    if (!writer_ || n == 0) return;  // EmptyOutput swallows events
+    scratch_.resize(n * 11);
+    const size_t bytes = adder_raw_events(scratch_.data(), events, n, meta_.plane.c());
+    writer_->write(reinterpret_cast<const char *>(scratch_.data()), (std::streamsize)bytes);
+    if (!*writer_) throw CodecError(CodecError::Io, "write failed");
+}
+
+void Encoder::ingest_event(const Event &e) { ingest_events(&e, 1); }
+
+void Encoder::ingest_events_events(const std::vector<std::vector<Event>> &v) {
+    for (const auto &chunk : v) ingest_events(chunk.data(), chunk.size());
+}
+
+std::ostream *Encoder::close_writer() {
+    if (!writer_) return nullptr;  // EmptyOutput::into_writer -> None
+    uint8_t eof[16];
+    const size_t n = adder_raw_eof(eof);
+    writer_->write(reinterpret_cast<const char *>(eof), (std::streamsize)n);
+    writer_->flush();
+    std::ostream *w = writer_;
+    writer_ = nullptr;
+    return w;
+}
+
+// ---------------------------------------------------------------- Decoder
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
+static uint32_t rd32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+Decoder::Decoder(const uint8_t *data, size_t size) : data_(data), size_(size) {
+    if (size < 25) throw CodecError(CodecError::Deserialize, "stream shorter than a header");
+    if (memcmp(data, "adder", 5) != 0) throw CodecError(CodecError::WrongMagic, "not a raw ADDER stream");
+    meta_.codec_version = data[5];
+    meta_.plane = PlaneSize(rd16(data + 7), rd16(data + 9), data[24]);
+    meta_.tps = rd32(data + 11);
+    meta_.ref_interval = rd32(data + 15);
+    meta_.delta_t_max = rd32(data + 19);
+    meta_.event_size = data[23] == 10 ? 11 : data[23];  // "manual fix for malformed files" (decoder.rs:132-135)
+    meta_.time_mode = TimeMode::AbsoluteT;
+    meta_.source_camera = SourceCamera::FramedU8;
+    meta_.adu_interval = 0;
+    pos_ = 25;
+    auto ext = [&]() -> uint32_t {
+        if (pos_ + 4 > size_) throw CodecError(CodecError::Deserialize, "truncated header extension");
+        const uint32_t v = rd32(data_ + pos_);
+        pos_ += 4;
+        return v;
+    };
+    if (meta_.codec_version >= 1) meta_.source_camera = (SourceCamera)ext();
+    if (meta_.codec_version >= 2) meta_.time_mode = (TimeMode)ext();
+    if (meta_.codec_version >= 3) meta_.adu_interval = ext();
+    if (meta_.codec_version > 3)
+        throw CodecError(CodecError::UnsupportedVersion, "codec version " + std::to_string(meta_.codec_version));
+    meta_.header_size = pos_;
+}
+
+bool Decoder::digest_event(Event *out) {
+    const size_t es = meta_.event_size;
+    if (pos_ + es > size_) return false;
+    const uint8_t *p = data_ + pos_;
+    Event e;
+    e.x = rd16(p);
+    e.y = rd16(p + 2);
+    e.pad = 0;
+    if (meta_.plane.c() == 1) {
+        e.c = ADDER_C_NONE;
+        e.d = p[4];
+        e.t = rd32(p + 5);
+    } else {
+        if (p[4] != 1) throw CodecError(CodecError::Deserialize, "event without a channel in a multi-channel stream");
+        e.c = p[5];
+        e.d = p[6];
+        e.t = rd32(p + 7);
+    }
+    if (e.x == 0xFFFF && e.y == 0xFFFF) return false;  // Coord::is_eof -> CodecError::Eof
+    pos_ += es;
+    *out = e;
+    return true;
+}
+
+// ---------------------------------------------------------------- Video
+static void hip_check(AdderHipCtx *ctx, int rc) {
+    if (rc == ADDER_OK) return;
+    const char *m = adder_hip_last_error(ctx);
+    throw SourceError(rc == ADDER_E_BAD_PARAMS ? SourceError::BadParams : SourceError::Hip,
+                      std::string("adder_hip: ") + (m ? m : "") + " (" + std::to_string(rc) + ")");
+}
+
+Video::Video(PlaneSize plane, std::ostream *writer, int device_id) : plane_(plane), device_id_(device_id) {
+    CodecMetadata meta;  // video.rs:391-402
+    meta.codec_version = LATEST_CODEC_VERSION;
+    meta.header_size = 0;
+    meta.time_mode = TimeMode::AbsoluteT;
+    meta.plane = plane;
+    meta.tps = tps_;
+    meta.ref_interval = ref_time_;
+    meta.delta_t_max = delta_t_max_;
+    meta.event_size = 0;
+    meta.source_camera = SourceCamera::FramedU8;
+    meta.adu_interval = 0;
+    EncoderOptions opts = EncoderOptions::default_(plane);
+    encoder_.reset(new Encoder(writer ? Encoder::new_raw(meta, writer, opts) : Encoder::new_empty(meta, opts)));
+}
+
+Video::~Video() {
+    if (ctx_) adder_hip_destroy(ctx_);
+}
+
+Video &Video::chunk_rows(size_t n) {
+    if (n == 0) throw SourceError(SourceError::BadParams, "chunk_rows must be > 0");
+    if (ctx_) throw SourceError(SourceError::BadParams, "chunk_rows must be set before the first frame");
+    chunk_rows_ = n;
+    return *this;
+}
+
+Video &Video::time_parameters(uint32_t tps, uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> tm) {
+    if (tm) px_time_mode_ = *tm;  // px.time_mode(time_mode) for every pixel (:499-503)
+    if (delta_t_max < ref_time) return *this;  // reference prints a warning and keeps the current values (:527-533)
+    if (ctx_) {
+        if (ref_time != ref_time_) throw SourceError(SourceError::BadParams, "ref_time cannot change mid-stream here");
+        hip_check(ctx_, adder_hip_set_delta_t_max(ctx_, delta_t_max));
+        if (tm) hip_check(ctx_, adder_hip_set_time_mode(ctx_, (uint8_t)*tm));
+    }
+    delta_t_max_ = delta_t_max;
+    ref_time_ = ref_time;
+    tps_ = tps;
+    return *this;
+}
+
+Video &Video::write_out(std::optional<SourceCamera> source_camera, std::optional<TimeMode> time_mode,
+                        std::optional<PixelMultiMode> pixel_multi_mode, std::optional<size_t> adu_interval,
+                        EncoderType encoder_type, EncoderOptions encoder_options, std::ostream *write) {
+    if (encoder_type == EncoderType::Compressed)  // video.rs:586-593 when the feature is off
+        throw SourceError(SourceError::BadParams,
+                          "Compressed representation is experimental and is not enabled by default!");
+    if (ctx_ && pixel_multi_mode.value_or(PixelMultiMode::Collapse) != multi_mode_)
+        throw SourceError(SourceError::BadParams, "pixel_multi_mode cannot change after the first frame");
+    multi_mode_ = pixel_multi_mode.value_or(PixelMultiMode::Collapse);
+    CodecMetadata meta;
+    meta.codec_version = LATEST_CODEC_VERSION;
+    meta.header_size = 0;
+    meta.time_mode = time_mode.value_or(TimeMode::AbsoluteT);
+    meta.plane = plane_;
+    meta.tps = tps_;
+    meta.ref_interval = ref_time_;
+    meta.delta_t_max = delta_t_max_;
+    meta.event_size = 0;
+    meta.source_camera = source_camera.value_or(SourceCamera::FramedU8);
+    meta.adu_interval = 0;  // Default::default() for Raw / Empty (:612, :630)
+    (void)adu_interval;
+    encoder_.reset(new Encoder(encoder_type == EncoderType::Raw ? Encoder::new_raw(meta, write, encoder_options)
+                                                               : Encoder::new_empty(meta, encoder_options)));
+    if (time_mode) {  // px.time_mode(time_mode) (:632-634)
+        px_time_mode_ = *time_mode;
+        if (ctx_) hip_check(ctx_, adder_hip_set_time_mode(ctx_, (uint8_t)*time_mode));
+    }
+    if (ctx_)  // the encoder's Crf is replaced, the pixels' c_thresh is not (:629)
+        hip_check(ctx_, adder_hip_set_crf_parameters(ctx_, encoder_options.crf.get_parameters().c_thresh_max,
+                                                     encoder_options.crf.get_parameters().c_increase_velocity));
+    return *this;
+}
+
+std::ostream *Video::end_write_stream() {
+    // pending per-pixel events are dropped, like the reference (only the writer is closed)
+    std::ostream *w = encoder_->close_writer();
+    CodecMetadata meta;
+    encoder_.reset(new Encoder(Encoder::new_empty(meta, encoder_->options)));
+    return w;
+}
+
+void Video::update_crf(uint8_t crf) {
+    encoder_->options.crf = Crf(crf, plane_);
+    const CrfParameters &p = encoder_->options.crf.get_parameters();
+    px_c_thresh_reset_ = p.c_thresh_baseline;
+    if (ctx_) {
+        hip_check(ctx_, adder_hip_set_crf_parameters(ctx_, p.c_thresh_max, p.c_increase_velocity));
+        hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, p.c_thresh_baseline));
+        px_c_thresh_reset_.reset();
+    }
+}
+
+void Video::update_quality_manual(uint8_t c_thresh_baseline, uint8_t c_thresh_max, uint32_t delta_t_max_multiplier,
+                                  uint8_t c_increase_velocity, float feature_c_radius) {
+    Crf &crf = encoder_->options.crf;
+    crf.override_c_thresh_baseline(c_thresh_baseline);
+    crf.override_c_thresh_max(c_thresh_max);
+    crf.override_c_increase_velocity(c_increase_velocity);
+    crf.override_feature_c_radius((uint16_t)feature_c_radius);
+    delta_t_max_ = delta_t_max_multiplier * ref_time_;
+    px_c_thresh_reset_ = c_thresh_baseline;
+    if (ctx_) {
+        hip_check(ctx_, adder_hip_set_crf_parameters(ctx_, c_thresh_max, c_increase_velocity));
+        hip_check(ctx_, adder_hip_set_delta_t_max(ctx_, delta_t_max_));
+        hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, c_thresh_baseline));
+        px_c_thresh_reset_.reset();
+    }
+}
+
+void Video::ensure_ctx() {
+    if (ctx_) return;
+    AdderHipParams p;
+    adder_hip_default_params(&p, plane_.w(), plane_.h(), plane_.c());
+    p.time_mode = (uint8_t)px_time_mode_;
+    p.multi_mode = (uint8_t)multi_mode_;
+    p.ref_time = ref_time_;
+    p.delta_t_max = delta_t_max_;
+    p.c_thresh_max = encoder_->options.crf.get_parameters().c_thresh_max;
+    p.c_increase_velocity = encoder_->options.crf.get_parameters().c_increase_velocity;
+    p.chunk_rows = (uint32_t)chunk_rows_;
+    p.device_id = device_id_;
+    const int rc = adder_hip_create(&p, &ctx_);
+    if (rc != ADDER_OK) {
+        ctx_ = nullptr;
+        hip_check(nullptr, rc);
+    }
+    if (px_c_thresh_reset_) {
+        hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, *px_c_thresh_reset_));
+        px_c_thresh_reset_.reset();
+    }
+}
+
+std::vector<std::vector<Event>> Video::integrate_matrix(const Frame &matrix, float time_spanned) {
+    if (matrix.size() != plane_.volume())
+        throw SourceError(SourceError::BadParams, "frame does not match the plane");
+    ensure_ctx();
+    // in_interval_count starts at 1 (video.rs:231), so set_initial_d (:656-658) is never taken here
+    in_interval_count_ += 1;
+    const uint32_t num_chunks = adder_hip_num_chunks(ctx_);
+    buf_.resize(std::max<size_t>(buf_.size(), std::min<size_t>(adder_hip_max_events_per_frame(ctx_), 4 * plane_.volume() + 64)));
+    std::vector<uint32_t> offs(num_chunks + 1);
+    size_t n = 0;
+    int rc = adder_hip_integrate(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned, buf_.data(),
+                                 buf_.size(), &n, offs.data());
+    hip_check(ctx_, rc);
+    std::vector<std::vector<Event>> big_buffer(num_chunks);
+    for (uint32_t ch = 0; ch < num_chunks; ++ch)
+        big_buffer[ch].assign(buf_.begin() + offs[ch], buf_.begin() + offs[ch + 1]);
+    encoder_->ingest_events(buf_.data(), n);  // for events in &big_buffer { encoder.ingest_event } (:736-740)
+    return big_buffer;
+}
+
+std::vector<Event> Video::integrate_frames(const uint8_t *frames, uint32_t num_frames, float time_spanned,
+                                           std::vector<uint64_t> *frame_offsets) {
+    ensure_ctx();
+    in_interval_count_ += num_frames;
+    std::vector<Event> out(std::min<size_t>(adder_hip_max_events_per_frame(ctx_), 2 * plane_.volume() + 64) * num_frames);
+    std::vector<uint64_t> offs(num_frames + 1);
+    size_t n = 0;
+    hip_check(ctx_, adder_hip_integrate_batch(ctx_, frames, num_frames, 0, 0, time_spanned, out.data(), out.size(), &n,
+                                              offs.data()));
+    out.resize(n);
+    encoder_->ingest_events(out.data(), n);
+    if (frame_offsets) *frame_offsets = offs;
+    return out;
+}
+
+// ---------------------------------------------------------------- Framed
+Frame handle_color(const Frame &input, uint32_t width, uint32_t height, uint32_t channels, bool color) {
+    if (color || channels == 1) return input;
+    Frame out((size_t)width * height);
+    for (size_t i = 0; i < out.size(); ++i) {
+        const double v = (double)input[3 * i] * 0.114 + (double)input[3 * i + 1] * 0.587 + (double)input[3 * i + 2] * 0.299;
+        out[i] = v >= 255.0 ? 255 : (v <= 0.0 ? 0 : (uint8_t)v);  // `as u8`
+    }
+    return out;
+}
+
+Framed::Framed(FrameProvider provider, bool color_input, int device_id)
+    : source_fps(provider.frame_rate), cap_(provider), color_input_(color_input),
+      video_(PlaneSize((uint16_t)provider.width, (uint16_t)provider.height, color_input ? 3 : 1), nullptr, device_id) {
+    if (color_input && provider.channels != 3)
+        throw SourceError(SourceError::BadParams, "color input needs a 3-channel frame provider");
+}
+
+Framed &Framed::frame_start(uint32_t idx) {
+    if (idx >= cap_.frame_count) throw SourceError(SourceError::StartOutOfBounds, "frame_start out of bounds");
+    frame_idx_start = idx;
+    next_frame_ = idx;
+    return *this;
+}
+
+Framed &Framed::auto_time_parameters(uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> time_mode) {
+    if (delta_t_max % ref_time != 0)
+        throw SourceError(SourceError::BadParams, "delta_t_max must be a multiple of ref_time");
+    const uint32_t tps = (uint32_t)((float)ref_time * source_fps);  // framed.rs:101
+    video_.time_parameters(tps, ref_time, delta_t_max, time_mode);
+    return *this;
+}
+
+Framed &Framed::time_parameters(uint32_t tps, uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> tm) {
+    if (delta_t_max % ref_time == 0) video_.time_parameters(tps, ref_time, delta_t_max, tm);
+    return *this;  // otherwise: "delta_t_max must be a multiple of ref_time" is only printed (framed.rs:229-232)
+}
+
+Framed &Framed::write_out(SourceCamera source_camera, TimeMode time_mode, PixelMultiMode pixel_multi_mode,
+                          std::optional<size_t> adu_interval, EncoderType encoder_type,
+                          EncoderOptions encoder_options, std::ostream *write) {
+    video_.write_out(source_camera, time_mode, pixel_multi_mode, adu_interval, encoder_type, encoder_options, write);
+    return *this;
+}
+
+std::vector<std::vector<Event>> Framed::consume() {
+    Frame raw;
+    if (!cap_.decode || !cap_.decode(next_frame_, raw)) throw SourceError(SourceError::NoData, "no more frames");
+    ++next_frame_;
+    input_frame_ = handle_color(raw, cap_.width, cap_.height, cap_.channels, color_input_);
+    return video_.integrate_matrix(input_frame_, (float)video_.get_ref_time());
+}
+
+double Framed::get_running_input_bitrate() const {
+    return (double)video_.get_tps() / (double)video_.get_ref_time() * (double)video_.plane().volume() * 8.0;
+}
+
+}  // namespace adder_host

@@ -1,0 +1,252 @@
+// adder_host.hpp -- host side of the framed->ADDER path, in C++ (the reference's host is Rust;
+// this image has no Rust toolchain, see INTEGRATION.md for the Rust binding of the same ABI).
+//
+// Mirrors, with the same names, argument meaning and error behaviour, the part of the
+// reference's operator surface this path lives behind:
+//   PlaneSize / Event / TimeMode / PixelMultiMode / SourceCamera   adder-codec-core/src/lib.rs
+//   Crf / CrfParameters / CRF table                                codec/rate_controller.rs
+//   EncoderOptions / EncoderType / CodecMetadata                   codec/mod.rs
+//   Encoder + RawOutput + EmptyOutput (sink)                       codec/encoder.rs, raw/stream.rs
+//   Decoder + RawInput (reader, used by tests/tools)               codec/decoder.rs, raw/stream.rs
+//   Video  (integrate_matrix & builders)                           transcoder/source/video.rs
+//   Source trait + Framed                                          transcoder/source/{video,framed}.rs
+// The per-pixel work of Video::integrate_matrix (video.rs:677-734) is NOT done here: it is
+// one call into the C-ABI of libadder_hip.so (include/adder_hip.h).  There is no CPU path.
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <memory>
+#include <optional>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/adder_hip.h"
+
+namespace adder_host {
+
+// ---------------------------------------------------------------- errors (video.rs:55-122, codec/mod.rs:209-256)
+struct SourceError : std::runtime_error {
+    enum Kind { BadParams, StartOutOfBounds, BufferEmpty, NoData, Hip, Codec } kind;
+    SourceError(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+};
+struct CodecError : std::runtime_error {
+    enum Kind { WrongMagic, Deserialize, Eof, BadFile, UnsupportedVersion, Io } kind;
+    CodecError(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+};
+
+// ---------------------------------------------------------------- core types (lib.rs)
+enum class TimeMode : uint32_t { DeltaT = 0, AbsoluteT = 1, Mixed = 2 };  // lib.rs:72-83 (default AbsoluteT)
+enum class PixelMultiMode : uint8_t { Normal = 0, Collapse = 1 };         // lib.rs:207-213 (default Collapse)
+enum class SourceCamera : uint32_t {                                      // lib.rs:35-47
+    FramedU8 = 0, FramedU16, FramedU32, FramedU64, FramedF32, FramedF64, Dvs, DavisU8, Atis, Asint
+};
+enum class EncoderType { Compressed, Raw, Empty };  // codec/mod.rs
+constexpr uint8_t LATEST_CODEC_VERSION = 3;         // codec/mod.rs:74
+
+struct PlaneSize {  // lib.rs:86-178
+    PlaneSize() = default;
+    PlaneSize(uint16_t width, uint16_t height, uint8_t channels);  // throws like PlaneSize::new
+    uint16_t w() const { return width_; }
+    uint16_t h() const { return height_; }
+    uint8_t c() const { return channels_; }
+    size_t volume() const { return (size_t)width_ * height_ * channels_; }
+    uint16_t min_resolution() const { return width_ < height_ ? width_ : height_; }
+
+  private:
+    uint16_t width_ = 1, height_ = 1;
+    uint8_t channels_ = 1;
+};
+
+using Event = AdderEvent;  // lib.rs:371-377; c == ADDER_C_NONE <=> Coord::c == None
+using Frame = std::vector<uint8_t>;  // [h][w][c] u8, row-major (ndarray::Array3<u8>)
+
+// ---------------------------------------------------------------- rate control (rate_controller.rs)
+extern const float CRF[10][4];                 // rate_controller.rs:5-18
+constexpr uint8_t DEFAULT_CRF_QUALITY = 3;     // :21
+struct CrfParameters {                         // :40-53
+    uint8_t c_thresh_baseline, c_thresh_max, c_increase_velocity;
+    uint16_t feature_c_radius;
+};
+class Crf {  // :24-37, :55-118
+  public:
+    Crf(std::optional<uint8_t> crf, PlaneSize plane);
+    void update_quality(uint8_t crf);
+    void override_c_thresh_baseline(uint8_t v) { parameters_.c_thresh_baseline = v; quality_.reset(); }
+    void override_c_thresh_max(uint8_t v) { parameters_.c_thresh_max = v; quality_.reset(); }
+    void override_c_increase_velocity(uint8_t v) { parameters_.c_increase_velocity = v; quality_.reset(); }
+    void override_feature_c_radius(uint16_t v) { parameters_.feature_c_radius = v; quality_.reset(); }
+    const CrfParameters &get_parameters() const { return parameters_; }
+    std::optional<uint8_t> get_quality() const { return quality_; }
+    PlaneSize plane;
+
+  private:
+    std::optional<uint8_t> quality_;
+    CrfParameters parameters_;
+};
+
+struct EncoderOptions {  // codec/mod.rs:264-283; only the defaults of event_drop / event_order exist here
+    Crf crf;
+    static EncoderOptions default_(PlaneSize plane) { return EncoderOptions{Crf(std::nullopt, plane)}; }
+};
+
+struct CodecMetadata {  // codec/mod.rs:76-107
+    uint8_t codec_version = LATEST_CODEC_VERSION;
+    size_t header_size = 24;
+    TimeMode time_mode = TimeMode::AbsoluteT;
+    PlaneSize plane;
+    uint32_t tps = 2550, ref_interval = 255, delta_t_max = 255;
+    uint8_t event_size = 9;
+    SourceCamera source_camera = SourceCamera::FramedU8;
+    size_t adu_interval = 1;
+};
+
+// ---------------------------------------------------------------- sink: Encoder over RawOutput / EmptyOutput
+// W of the reference (any std::io::Write) is a std::ostream here; the Encoder does not own it.
+class Encoder {  // encoder.rs:29-37
+  public:
+    static Encoder new_raw(CodecMetadata meta, std::ostream *writer, EncoderOptions options);  // :94-108
+    static Encoder new_empty(CodecMetadata meta, EncoderOptions options);                      // :57-72
+    const CodecMetadata &meta() const { return meta_; }
+    void ingest_event(const Event &e);                                   // :233-273 (EventDrop::None, Unchanged)
+    void ingest_events(const Event *events, size_t n);                   // :281-286
+    void ingest_events_events(const std::vector<std::vector<Event>> &v); // :289-294
+    std::ostream *close_writer();  // :154-168 -> RawOutput::into_writer writes the 11-byte EOF and flushes
+    EncoderOptions options;
+
+  private:
+    Encoder(CodecMetadata meta, std::ostream *w, EncoderOptions o, EncoderType t);
+    void encode_header();  // :170-229
+    CodecMetadata meta_;
+    std::ostream *writer_;
+    EncoderType type_;
+    std::vector<uint8_t> scratch_;
+};
+
+// ---------------------------------------------------------------- reader: Decoder over RawInput
+class Decoder {  // decoder.rs:22-29
+  public:
+    Decoder(const uint8_t *data, size_t size);  // Decoder::new_raw + decode_header (:102-203)
+    const CodecMetadata &meta() const { return meta_; }
+    bool digest_event(Event *out);  // raw/stream.rs:177-201 ; false at the EOF event / end of data
+    size_t position() const { return pos_; }
+
+  private:
+    const uint8_t *data_;
+    size_t size_, pos_ = 0;
+    CodecMetadata meta_;
+};
+
+// ---------------------------------------------------------------- Video (video.rs:322-346)
+class Video {
+  public:
+    Video(PlaneSize plane, std::ostream *writer /* may be null: EmptyOutput */, int device_id = -1);  // ::new :350-438
+    ~Video();
+    Video(const Video &) = delete;
+    Video &operator=(const Video &) = delete;
+
+    Video &chunk_rows(size_t chunk_rows);  // :471-479
+    // :493-537 -- like the reference, an invalid delta_t_max/ref_time keeps the current values
+    Video &time_parameters(uint32_t tps, uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> time_mode);
+    // :546-636
+    Video &write_out(std::optional<SourceCamera> source_camera, std::optional<TimeMode> time_mode,
+                     std::optional<PixelMultiMode> pixel_multi_mode, std::optional<size_t> adu_interval,
+                     EncoderType encoder_type, EncoderOptions encoder_options, std::ostream *write);
+    std::ostream *end_write_stream();  // :641-648
+    void update_crf(uint8_t crf);      // :1241-1251
+    void update_quality_manual(uint8_t c_thresh_baseline, uint8_t c_thresh_max, uint32_t delta_t_max_multiplier,
+                               uint8_t c_increase_velocity, float feature_c_radius);  // :1264-1287
+    EncoderOptions get_encoder_options() const { return encoder_->options; }
+    TimeMode get_time_mode() const { return encoder_->meta().time_mode; }
+    uint8_t get_event_size() const { return encoder_->meta().event_size; }
+    uint32_t get_tps() const { return tps_; }
+    uint32_t get_ref_time() const { return ref_time_; }
+    uint32_t get_delta_t_max() const { return delta_t_max_; }
+    PlaneSize plane() const { return plane_; }
+
+    // :651-778 -- one frame in; Vec<Vec<Event>> out (one vector per row chunk, raster order);
+    // the events are also pushed through the encoder, exactly like the reference.
+    std::vector<std::vector<Event>> integrate_matrix(const Frame &matrix, float time_spanned);
+    // the same for T packed frames in one boundary call (events of all frames, frame-major)
+    std::vector<Event> integrate_frames(const uint8_t *frames, uint32_t num_frames, float time_spanned,
+                                        std::vector<uint64_t> *frame_offsets);
+
+  private:
+    void ensure_ctx();  // (re)creates the device context once every builder call has been made
+    PlaneSize plane_;
+    int device_id_;
+    uint32_t tps_ = 7650, ref_time_ = 255, delta_t_max_ = 7650;  // VideoState/VideoStateParams::default
+    size_t chunk_rows_ = 1;
+    PixelMultiMode multi_mode_ = PixelMultiMode::Collapse;
+    TimeMode px_time_mode_ = TimeMode::AbsoluteT;  // PixelArena::time_mode default (event_pixel_tree.rs:76)
+    std::optional<uint8_t> px_c_thresh_reset_;     // pending per-pixel reset from update_crf / quality_manual
+    uint32_t in_interval_count_ = 1;
+    std::unique_ptr<Encoder> encoder_;
+    AdderHipCtx *ctx_ = nullptr;
+    std::vector<Event> buf_;
+};
+
+// ---------------------------------------------------------------- Source + Framed (video.rs:1419-1442, framed.rs)
+class Source {
+  public:
+    virtual ~Source() = default;
+    virtual std::vector<std::vector<Event>> consume() = 0;
+    virtual void crf(uint8_t crf) = 0;
+    virtual Video &get_video_mut() = 0;
+    virtual const Video &get_video_ref() const = 0;
+    virtual const Frame *get_input() const = 0;
+    virtual double get_running_input_bitrate() const = 0;
+};
+
+// Stands in for video_rs_adder_dep::Decoder (ffmpeg, un-vendored, out of scope): yields
+// decoded 8-bit frames [h][w][3] (or [h][w][1] for an already-gray provider).
+struct FrameProvider {
+    uint32_t width = 0, height = 0, channels = 3;
+    float frame_rate = 30.0f;
+    uint64_t frame_count = 0;
+    std::function<bool(uint64_t index, Frame &out)> decode;  // false = end of stream (-> SourceError::NoData)
+};
+
+class Framed : public Source {  // framed.rs:22-39
+  public:
+    Framed(FrameProvider provider, bool color_input, int device_id = -1);  // ::new :44-78 (scale handled upstream)
+    Framed &frame_start(uint32_t frame_idx_start);                          // :81-91
+    Framed &auto_time_parameters(uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> time_mode);  // :94-111
+    uint32_t get_ref_time() const { return video_.get_ref_time(); }
+    const Frame &get_last_input_frame() const { return input_frame_; }
+    // VideoBuilder (framed.rs:187-280)
+    Framed &crf_builder(uint8_t crf) { video_.update_crf(crf); return *this; }
+    Framed &quality_manual(uint8_t base, uint8_t max, uint32_t dtm_mult, uint8_t velocity, float radius) {
+        video_.update_quality_manual(base, max, dtm_mult, velocity, radius);
+        return *this;
+    }
+    Framed &chunk_rows(size_t n) { video_.chunk_rows(n); return *this; }
+    Framed &time_parameters(uint32_t tps, uint32_t ref_time, uint32_t delta_t_max, std::optional<TimeMode> tm);
+    Framed &write_out(SourceCamera source_camera, TimeMode time_mode, PixelMultiMode pixel_multi_mode,
+                      std::optional<size_t> adu_interval, EncoderType encoder_type, EncoderOptions encoder_options,
+                      std::ostream *write);
+    // Source
+    std::vector<std::vector<Event>> consume() override;  // :127-157
+    void crf(uint8_t crf) override { video_.update_crf(crf); }
+    Video &get_video_mut() override { return video_; }
+    const Video &get_video_ref() const override { return video_; }
+    const Frame *get_input() const override { return &input_frame_; }
+    double get_running_input_bitrate() const override;
+
+    uint32_t frame_idx_start = 0;
+    float source_fps;
+
+  private:
+    FrameProvider cap_;
+    uint64_t next_frame_ = 0;
+    Frame input_frame_;
+    bool color_input_;
+    Video video_;
+};
+
+// utils/cv.rs:215-232
+Frame handle_color(const Frame &input, uint32_t width, uint32_t height, uint32_t channels, bool color);
+
+}  // namespace adder_host

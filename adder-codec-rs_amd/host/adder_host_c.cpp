@@ -1,0 +1,142 @@
+// adder_host_c.cpp -- a small extern "C" facade over the C++ host mirror so that the pytest
+// suite can drive Framed -> Video -> Encoder exactly the way the reference's own transcode
+// test does (adder-codec-rs/src/bin/adder_simulproc.rs:170-268).  No exception crosses it.
+#include <string.h>
+
+#include <fstream>
+#include <sstream>
+#include <string>
+
+#include "adder_host.hpp"
+
+using namespace adder_host;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *adder_host_last_error() { return g_err.c_str(); }
+
+// Framed(gray) over `frames` ([T][h][w][channels_in] u8), builder calls in the order of the
+// reference's transcode test: crf -> (auto_)time_parameters -> write_out(raw, options) -> consume()
+// x T -> end_write_stream.  Returns the number of events, or -1.
+long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
+                                   uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
+                                   uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
+                                   uint32_t chunk_rows, int encoder_crf /* <0: EncoderOptions::default */,
+                                   const char *out_path, uint32_t *num_chunks_out) {
+    try {
+        FrameProvider cap;
+        cap.width = width;
+        cap.height = height;
+        cap.channels = channels_in;
+        cap.frame_rate = fps;
+        cap.frame_count = num_frames;
+        const size_t fsz = (size_t)width * height * channels_in;
+        cap.decode = [=](uint64_t idx, Frame &out) {
+            if (idx >= num_frames) return false;
+            out.assign(frames + idx * fsz, frames + (idx + 1) * fsz);
+            return true;
+        };
+        Framed source(cap, color_input != 0);
+        source.chunk_rows(chunk_rows ? chunk_rows : 1);
+        if (crf >= 0) source.crf_builder((uint8_t)crf);
+        source.auto_time_parameters(ref_time, delta_t_max, std::nullopt);
+        std::ofstream file(out_path, std::ios::binary);
+        if (!file) throw SourceError(SourceError::BadParams, "cannot open output file");
+        const PlaneSize plane = source.get_video_ref().plane();
+        EncoderOptions opts = EncoderOptions::default_(plane);
+        if (encoder_crf >= 0) opts.crf = Crf((uint8_t)encoder_crf, plane);
+        source.write_out(SourceCamera::FramedU8, (TimeMode)time_mode, (PixelMultiMode)multi_mode, std::nullopt,
+                         EncoderType::Raw, opts, &file);
+        long long total = 0;
+        uint32_t chunks = 0;
+        for (uint32_t k = 0; k < num_frames; ++k) {
+            auto events = source.consume();
+            chunks = (uint32_t)events.size();
+            for (auto &v : events) total += (long long)v.size();
+        }
+        source.get_video_mut().end_write_stream();
+        if (num_chunks_out) *num_chunks_out = chunks;
+        return total;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Decoder over a raw stream in memory: fills meta[10] = {version, width, height, channels, tps,
+// ref_interval, delta_t_max, event_size, source_camera|time_mode<<8, adu_interval} and up to cap
+// events; returns the number of events in the stream, or -1.
+long long adder_host_decode_raw(const uint8_t *data, size_t size, uint32_t *meta, AdderEvent *events, size_t cap) {
+    try {
+        Decoder dec(data, size);
+        const CodecMetadata &m = dec.meta();
+        meta[0] = m.codec_version;
+        meta[1] = m.plane.w();
+        meta[2] = m.plane.h();
+        meta[3] = m.plane.c();
+        meta[4] = m.tps;
+        meta[5] = m.ref_interval;
+        meta[6] = m.delta_t_max;
+        meta[7] = m.event_size;
+        meta[8] = (uint32_t)m.source_camera | ((uint32_t)m.time_mode << 8);
+        meta[9] = (uint32_t)m.adu_interval;
+        long long n = 0;
+        Event e;
+        while (dec.digest_event(&e)) {
+            if ((size_t)n < cap) events[n] = e;
+            ++n;
+        }
+        return n;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Crf table / EncoderOptions::default checks (no device needed): out[4] = baseline, max, velocity, radius
+int adder_host_crf_parameters(int crf /* <0: default */, uint16_t width, uint16_t height, uint32_t *out) {
+    try {
+        Crf c(crf < 0 ? std::nullopt : std::optional<uint8_t>((uint8_t)crf), PlaneSize(width, height, 1));
+        const CrfParameters &p = c.get_parameters();
+        out[0] = p.c_thresh_baseline;
+        out[1] = p.c_thresh_max;
+        out[2] = p.c_increase_velocity;
+        out[3] = p.feature_c_radius;
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+// Encoder over an in-memory writer: header + events + (optionally) EOF -> bytes.  Returns size or -1.
+long long adder_host_encode_raw(uint8_t codec_version, uint16_t width, uint16_t height, uint8_t channels,
+                                uint32_t tps, uint32_t ref_interval, uint32_t delta_t_max, uint32_t source_camera,
+                                uint32_t time_mode, const AdderEvent *events, size_t n, int close, uint8_t *dst,
+                                size_t cap) {
+    try {
+        std::ostringstream os;
+        CodecMetadata meta;
+        meta.codec_version = codec_version;
+        meta.plane = PlaneSize(width, height, channels);
+        meta.tps = tps;
+        meta.ref_interval = ref_interval;
+        meta.delta_t_max = delta_t_max;
+        meta.source_camera = (SourceCamera)source_camera;
+        meta.time_mode = (TimeMode)time_mode;
+        meta.adu_interval = 0;
+        Encoder enc = Encoder::new_raw(meta, &os, EncoderOptions::default_(meta.plane));
+        enc.ingest_events(events, n);
+        if (close) enc.close_writer();
+        const std::string s = os.str();
+        if (s.size() > cap) throw CodecError(CodecError::Io, "destination too small");
+        memcpy(dst, s.data(), s.size());
+        return (long long)s.size();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+}

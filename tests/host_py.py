@@ -1,0 +1,75 @@
+"""ctypes access to adder-codec-rs_amd/host/libadder_host.so (the C++ mirror's test facade)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import adder_amd
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(_ROOT, "adder-codec-rs_amd", "host", "libadder_host.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        adder_amd.load()  # libadder_hip.so (and torch's HIP runtime) first
+        L = C.CDLL(LIB)
+        L.adder_host_last_error.restype = C.c_char_p
+        L.adder_host_transcode_raw.restype = C.c_longlong
+        L.adder_host_transcode_raw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                               C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                               C.c_uint32, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
+        L.adder_host_decode_raw.restype = C.c_longlong
+        L.adder_host_decode_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.adder_host_crf_parameters.restype = C.c_int
+        L.adder_host_crf_parameters.argtypes = [C.c_int, C.c_uint16, C.c_uint16, C.c_void_p]
+        L.adder_host_encode_raw.restype = C.c_longlong
+        L.adder_host_encode_raw.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
+                                            C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def err():
+    return lib().adder_host_last_error().decode()
+
+
+def decode_raw(raw):
+    buf = np.frombuffer(raw, np.uint8)
+    meta = np.zeros(10, np.uint32)
+    n = lib().adder_host_decode_raw(buf.ctypes.data, len(buf), meta.ctypes.data, None, 0)
+    assert n >= 0, err()
+    ev = np.zeros(n, adder_amd.EVENT_DTYPE)
+    lib().adder_host_decode_raw(buf.ctypes.data, len(buf), meta.ctypes.data, ev.ctypes.data, n)
+    return meta, ev
+
+
+def encode_raw(version, w, h, c, tps, ref, dtm, cam, tm, events, close=True):
+    events = np.ascontiguousarray(events, adder_amd.EVENT_DTYPE)
+    dst = np.zeros(64 + 11 * len(events) + 16, np.uint8)
+    n = lib().adder_host_encode_raw(version, w, h, c, tps, ref, dtm, cam, tm, events.ctypes.data, len(events),
+                                    int(close), dst.ctypes.data, len(dst))
+    assert n >= 0, err()
+    return dst[:n].tobytes()
+
+
+def crf_parameters(crf, w, h):
+    out = np.zeros(4, np.uint32)
+    assert lib().adder_host_crf_parameters(crf, w, h, out.ctypes.data) == 0, err()
+    return tuple(int(x) for x in out)
+
+
+def transcode_raw(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, delta_t_max=7650, time_mode=1,
+                  multi_mode=1, chunk_rows=1, encoder_crf=-1, out_path=None):
+    frames = np.ascontiguousarray(frames, np.uint8)
+    T, H, W, Cin = frames.shape
+    chunks = C.c_uint32(0)
+    n = lib().adder_host_transcode_raw(frames.ctypes.data, T, W, H, Cin, int(color_input), fps, crf, ref_time,
+                                       delta_t_max, time_mode, multi_mode, chunk_rows, encoder_crf, out_path.encode(),
+                                       C.byref(chunks))
+    if n < 0:
+        raise RuntimeError(err())
+    return n, chunks.value
