@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle as O
 import clips
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 CRFS = {0: (0, 0, 10), 3: (2, 7, 7), 6: (7, 13, 4), 9: (15, 25, 1)}
 
 
@@ -216,3 +218,93 @@ def test_synth_clip_matches_oracle_generator():
                                 stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert np.array_equal(d.cpu().numpy(), want), (content, W, H, Cn)
+
+
+def _events_device(A, clip_np, *, time_mode, multi_mode, dtm, frames_per_launch=None, env=None, row_band=None,
+                   H_total=None):
+    """Runs a clip resident in HBM through the device-pointer entry point; returns (events, offsets)."""
+    import torch
+    T, H, W, Cn = clip_np.shape
+    y0, y1 = (0, H) if row_band is None else row_band
+    hv = A.HipVideo(W, H if H_total is None else H_total, Cn, row_begin=y0, row_end=y1, time_mode=time_mode,
+                    multi_mode=multi_mode, delta_t_max=dtm, c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    if frames_per_launch is not None:
+        hv.set_frames_per_launch(frames_per_launch)
+    d_frames = torch.from_numpy(np.ascontiguousarray(clip_np[:, y0:y1]).reshape(T, -1)).cuda()
+    d_ev = torch.empty((int(d_frames.numel() * 1.3) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
+    n = hv.finish()
+    ev = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE).copy()
+    offs = d_off.cpu().numpy().copy()
+    hv.close()
+    return ev, offs
+
+
+def test_full_size_properties_1080p():
+    """BASELINE config 2 size (1920x1080): size-independent properties of the full pipeline --
+    the result does not depend on how many frames one launch steps (temporal blocking), on
+    graph vs eager submission, or on row-band sharding; a prefix is checked against the oracle."""
+    import subprocess, sys
+    A = _hip()
+    T = 24
+    clip = O.synth_clip(O.CONTENT_SCENE, 1920, 1080, 1, T)
+    base, offs = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255)
+    assert offs[0] == 0 and offs[-1] == len(base) and np.all(np.diff(offs.astype(np.int64)) >= 0)
+    for fpl in (1, 3, 5):
+        ev, offs2 = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255,
+                                   frames_per_launch=fpl)
+        assert np.array_equal(offs, offs2) and np.array_equal(base, ev), fpl
+    # raster order inside every frame
+    for k in range(T):
+        seg = base[int(offs[k]):int(offs[k + 1])]
+        key = seg["y"].astype(np.int64) * 1920 + seg["x"]
+        assert np.all(np.diff(key) >= 0)
+    # row bands [0,400) + [400,1080) concatenated per frame == whole plane
+    top, ot = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255,
+                             row_band=(0, 400))
+    bot, ob = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255,
+                             row_band=(400, 1080))
+    merged = np.concatenate([np.concatenate([top[int(ot[k]):int(ot[k + 1])], bot[int(ob[k]):int(ob[k + 1])]])
+                             for k in range(T)])
+    assert np.array_equal(merged, base)
+    # oracle on the first frames
+    ov = O.Video(1920, 1080, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, threads=8)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    want = np.concatenate([ov.integrate_matrix(clip[k]) for k in range(6)])
+    assert np.array_equal(base[: int(offs[6])], want)
+
+
+def test_rgb_and_secondary_modes_at_size():
+    """1920x1080 RGB (config 3 shape) and the delta_t_max = 7650 / Normal / AbsoluteT points on a few frames."""
+    A = _hip()
+    clip = O.synth_clip(O.CONTENT_SCENE, 1920, 1080, 3, 5)
+    for (tm, mm, dtm) in [(O.DELTA_T, O.COLLAPSE, 255), (O.ABSOLUTE_T, O.COLLAPSE, 7650), (O.ABSOLUTE_T, O.NORMAL, 255)]:
+        got, offs = _events_device(A, clip, time_mode=tm, multi_mode=mm, dtm=dtm)
+        ov = O.Video(1920, 1080, 3, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, threads=8)
+        ov.set_crf_parameters(0, 10)
+        ov.reset_c_thresh(0)
+        want = np.concatenate([ov.integrate_matrix(f) for f in clip])
+        assert len(got) == len(want) and np.array_equal(got, want), (tm, mm, dtm)
+
+
+def test_eager_and_graph_submission_agree():
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/adder-codec-rs_amd"); sys.path.insert(0, "%s/tests")
+import adder_amd as A
+from oracle import oracle as O
+from test_gpu_parity import _events_device
+clip = O.synth_clip(O.CONTENT_NOISE, 640, 480, 1, 40)
+ev, offs = _events_device(A, clip, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, dtm=255)
+import hashlib; print(hashlib.sha256(ev.tobytes() + offs.tobytes()).hexdigest())
+''' % (ROOT, ROOT, ROOT)
+    outs = []
+    for env in ({}, {"ADDER_HIP_NO_GRAPH": "1"}, {"ADDER_HIP_CHUNK": "3", "ADDER_HIP_FRAMES_PER_LAUNCH": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2]
