@@ -162,12 +162,14 @@ template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                             uint32_t u0, uint32_t gw, uint32_t lane, uint2 *my_slots) {
     constexpr uint32_t N = kUnitsPerLane;
-    PxState px[N];
+    // whole wave inside the band: the common case takes the unguarded vector input load
+    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+    FastPx px[N];
     uint32_t vin_w;
     {
         uint32_t hdrv[N];
         load_vec(a.hdr + u0, hdrv);
-        vin_w = load_input(a.frame, u0, a.n_units);
+        vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
         uint32_t hor = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) hor |= hdrv[j];
@@ -187,24 +189,30 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         if (ABS_T) load_vec(a.lastf + u0, lfv);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            px[j].hdr = hdrv[j];
-            px[j].n0.integ = liv[j];
-            px[j].n0.dt = ldv[j];
-            px[j].n0.bdt = lbv[j];
-            px[j].n0.bd = bdv[j];
-            px[j].lastf = lfv[j];
+            PxState st;
+            st.hdr = hdrv[j];
+            st.n0.integ = liv[j];
+            st.n0.dt = ldv[j];
+            st.n0.bdt = lbv[j];
+            st.n0.bd = bdv[j];
+            st.lastf = lfv[j];
+            px[j] = unpack_px(st);
+            if (GENERIC) px[j].has0 = (hdrv[j] >> 24) & kFlagMMask;  // keep the full m for the generic test
         }
     }
     StepConsts sc = a.sc;
     uint32_t gmask = 0;  // pixels left to the generic kernel (nb == 1 only)
+    // running_t of the launch's frames (nb <= 8): one load, then a lane read per frame
+    const uint32_t rt_vec = (lane < kMaxFramesPerLaunch && lane < nb) ? __float_as_uint(b->running_t[a.frame_idx + lane]) : 0u;
 
     for (uint32_t i = 0; i < nb; ++i) {
         const uint32_t f = a.frame_idx + i;
         uint32_t next_w = 0u;
-        if (i + 1 < nb) next_w = load_input(b->frames + (size_t)(f + 1) * a.n_units, u0, a.n_units);
-        // wave-uniform per-frame values, pinned to SGPRs so they are fetched once per frame
+        if (i + 1 < nb)
+            next_w = load_input(b->frames + (size_t)(f + 1) * a.n_units, u0, full ? 0xffffffffu : a.n_units);
+        // wave-uniform per-frame values, kept in SGPRs
         const uint32_t slot = __builtin_amdgcn_readfirstlane(f % b->slots);
-        sc.running_t = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->running_t[f])));
+        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(rt_vec, i));
         sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
 
         // ---------------- the step; events parked in the lane's LDS stack ----------------
@@ -217,8 +225,16 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
             // units past the band's end are padding: their state may be stepped freely, only
             // their events must be suppressed
-            const bool active = u0 + j < a.n_units;
-            if (!GENERIC || fast_eligible<COLLAPSE>(px[j], v)) {
+            const bool active = full || u0 + j < a.n_units;
+            bool fast = true;
+            PxState st;
+            if (GENERIC) {
+                st.hdr = (pack_hdr(px[j]) & 0x00ffffffu) | ((px[j].has0 | (px[j].popped << 5)) << 24);
+                st.n0 = px[j].n0;
+                st.lastf = px[j].lastf;
+                fast = fast_eligible<COLLAPSE>(st, v);
+            }
+            if (fast) {
                 FastEvents fe;
                 step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe);
                 const uint32_t mask = active ? fe.mask : 0u;
@@ -233,7 +249,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 nl += mask >> 2;
                 cnts |= (uint32_t)__popc(mask) << (8 * j);
             } else if (active) {
-                cnts |= plan_count(px[j], v, sc) << (8 * j);
+                cnts |= plan_count(st, v, sc) << (8 * j);
                 gmask |= 1u << j;
             }
         }
@@ -279,8 +295,9 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         uint32_t hor = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            hdrv[j] = px[j].hdr;
-            hor |= px[j].hdr;
+            hdrv[j] = GENERIC ? ((pack_hdr(px[j]) & 0x00ffffffu) | ((px[j].has0 | (px[j].popped << 5)) << 24))
+                              : pack_hdr(px[j]);
+            hor |= hdrv[j];
             liv[j] = px[j].n0.integ;
             ldv[j] = px[j].n0.dt;
             lbv[j] = px[j].n0.bdt;
@@ -298,7 +315,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
-                if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((px[j].hdr >> 24) & kFlagMMask))
+                if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((hdrv[j] >> 24) & kFlagMMask))
                     a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
                                                                 (double)sc.ref_time);
         }

@@ -240,89 +240,119 @@ ADDER_HD bool fast_eligible(const PxState &s, uint32_t v) {
     return fadd(s.n0.integ, (float)v) >= pow2_d(fired_d(s.n0.bd));
 }
 
+// Unpacked form of PxState for the frame kernel: with temporal blocking the header word is
+// unpacked once per launch instead of once per frame.
+struct FastPx {
+    uint32_t base, cth, cctr;
+    uint32_t has0;    // m == 1 (0/1)
+    uint32_t popped;  // 0/1
+    Node n0;
+    float lastf;
+};
+
+ADDER_HD FastPx unpack_px(const PxState &s) {
+    FastPx p;
+    p.base = s.hdr & 0xffu;
+    p.cth = (s.hdr >> 8) & 0xffu;
+    p.cctr = (s.hdr >> 16) & 0xffu;
+    p.has0 = (s.hdr >> 24) & 1u;  // fast path: m is 0 or 1
+    p.popped = (s.hdr >> 29) & 1u;
+    p.n0 = s.n0;
+    p.lastf = s.lastf;
+    return p;
+}
+ADDER_HD uint32_t pack_hdr(const FastPx &p) {
+    return p.base | (p.cth << 8) | (p.cctr << 16) | ((p.has0 | (p.popped << 5)) << 24);
+}
+
 // Written branch-free on purpose: on CDNA a divergent `if` costs scalar exec-mask
-// bookkeeping per region, and with 4 pixels per lane and ~10% of the pixels flushing every
-// wave takes every path anyway.  Everything is computed unconditionally and selected.
+// bookkeeping per region, and with several pixels per lane and ~10% of the pixels flushing
+// every wave takes every path anyway.  Everything is computed unconditionally and selected.
 template <bool COLLAPSE, bool ABS_T>
-ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents &ev) {
+ADDER_HD void step_fast(FastPx &p, uint32_t v, const StepConsts &sc, FastEvents &ev) {
     const float I = (float)v;
     const float T = sc.time_spanned;
-    const uint32_t hdr = s.hdr;
-    uint32_t base = hdr & 0xffu;
-    uint32_t cth = (hdr >> 8) & 0xffu;
-    uint32_t cctr = (hdr >> 16) & 0xffu;
-    bool has0 = ((hdr >> 24) & kFlagMMask) != 0u;  // m == 1
-    bool popped = (hdr & (kFlagPopped << 24)) != 0u;
-    float lastf = s.lastf;
+    bool has0 = p.has0 != 0u;
+    bool popped = p.popped != 0u;
+    float lastf = p.lastf;
 
     // ---- pop_best_events (event_pixel_tree.rs:213-287): A = level 0's best event; with
     // Collapse after a delta_t_max pop it is followed by the D_EMPTY filler B (:249-265) ----
-    const uint32_t diff = v > base ? v - base : base - v;
-    const bool flush = diff > cth;
+    const uint32_t diff = v > p.base ? v - p.base : p.base - v;
+    const bool flush = diff > p.cth;  // == the saturating-bounds test of video.rs:1338-1340
     const bool a_valid = flush && has0;
     const bool b_valid = COLLAPSE && a_valid && popped;
     {
-        float evdt = s.n0.bdt;
+        float evdt = p.n0.bdt;
         if (ABS_T) {
             evdt = fadd(evdt, lastf);
             const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
             lastf = a_valid ? (b_valid ? sc.running_t : chained) : lastf;  // :122-129 / :257
         }
-        ev.da = s.n0.bd;
+        ev.da = p.n0.bd;
         ev.ta = f32_as_u32(evdt);
         ev.db = kDEmpty;
         ev.tb = sc.running_t_u32;
     }
     has0 = has0 && !flush;
     popped = popped && !flush;
-    base = flush ? v : base;
+    p.base = flush ? v : p.base;
 
     // ---- integrate (:317-413): arena index 0 is level 0 if present, else the pristine
     // tail, which always fires; the walk stops there (fast_eligible) ----
-    const float integ = has0 ? s.n0.integ : 0.0f;
-    const float dt = has0 ? s.n0.dt : 0.0f;
-    const uint32_t d = has0 ? fired_d(s.n0.bd) : get_d(I);
+    const float integ = has0 ? p.n0.integ : 0.0f;
+    const float dt = has0 ? p.n0.dt : 0.0f;
     const float sum = fadd(integ, I);
-    const bool fire = sum >= pow2_d(d);
+    // d of the node: fired_d(best_d) for level 0; for the tail floor(log2 I), which is get_d of
+    // the same `sum` (integ is 0 there)
     const uint32_t nd = get_d(sum);
+    const uint32_t d = has0 ? fired_d(p.n0.bd) : nd;
+    const bool fire = sum >= pow2_d(d);
     float prop = fdiv(fsub(pow2_d(nd), integ), I);
     prop = (nd == kDZero || d == kDZero || I < 1.1920929e-7f) ? 1.0f : prop;
     const float bdt_fire = fadd(dt, fmul(T, prop));
     const bool acc = !fire || nd < kDMax;  // a node that fires at nd >= D_MAX keeps (integ, dt)
-    Node n;
-    n.integ = acc ? sum : integ;
-    n.dt = acc ? fadd(dt, T) : dt;
-    n.bd = fire ? nd : s.n0.bd;
-    n.bdt = fire ? bdt_fire : s.n0.bdt;
-    const bool need_pop = fired_d(n.bd) == kDMax || (n.dt >= sc.dtm_f && !popped);  // :394-396
+    p.n0.integ = acc ? sum : integ;
+    p.n0.dt = acc ? fadd(dt, T) : dt;
+    p.n0.bd = fire ? nd : p.n0.bd;
+    p.n0.bdt = fire ? bdt_fire : p.n0.bdt;
+    const bool need_pop = fired_d(p.n0.bd) == kDMax || (p.n0.dt >= sc.dtm_f && !popped);  // :394-396
 
     if (sc.c_thresh_max != 0u) {  // :402-412, u8 saturating; uniform branch
-        const bool adapt = cth < sc.c_thresh_max;
-        const bool bump = cctr >= sc.velocity_m1;
-        uint32_t cinc = cctr + sc.c_inc;
+        const bool adapt = p.cth < sc.c_thresh_max;
+        const bool bump = p.cctr >= sc.velocity_m1;
+        uint32_t cinc = p.cctr + sc.c_inc;
         cinc = cinc > 255u ? 255u : cinc;
-        const uint32_t cth1 = cth >= 255u ? 255u : cth + 1u;
-        cth = (adapt && bump) ? cth1 : cth;
-        cctr = adapt ? (bump ? 0u : cinc) : cctr;
+        const uint32_t cth1 = p.cth >= 255u ? 255u : p.cth + 1u;
+        p.cth = (adapt && bump) ? cth1 : p.cth;
+        p.cctr = adapt ? (bump ? 0u : cinc) : p.cctr;
     }
 
     // ---- pop_top_event (:139-210): C = the root's best event; the arena shifts left ----
     {
-        float evdt = n.bdt;
+        float evdt = p.n0.bdt;
         if (ABS_T) {
             evdt = fadd(evdt, lastf);
             const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
             lastf = need_pop ? chained : lastf;
         }
-        ev.dc = n.bd;
+        ev.dc = p.n0.bd;
         ev.tc = f32_as_u32(evdt);
     }
     ev.mask = (a_valid ? 1u : 0u) | (b_valid ? 2u : 0u) | (need_pop ? 4u : 0u);
-    popped = popped || need_pop;
+    p.has0 = need_pop ? 0u : 1u;
+    p.popped = (popped || need_pop) ? 1u : 0u;
+    p.lastf = lastf;
+}
 
-    s.n0 = n;
-    s.lastf = lastf;
-    s.hdr = base | (cth << 8) | (cctr << 16) | ((need_pop ? 0u : 1u) | (popped ? kFlagPopped : 0u)) << 24;
+// PxState front end (generic-capable kernels, CPU harness)
+template <bool COLLAPSE, bool ABS_T>
+ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents &ev) {
+    FastPx p = unpack_px(s);
+    step_fast<COLLAPSE, ABS_T>(p, v, sc, ev);
+    s.n0 = p.n0;
+    s.lastf = p.lastf;
+    s.hdr = pack_hdr(p);
 }
 
 // ---------------------------------------------------------------------------------------
