@@ -51,8 +51,8 @@ struct AdderHipCtx {
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2;
     uint32_t frames_per_launch = 8;  // temporal blocking depth of the frame kernel (non-generic modes)
-    uint2 *worklist = nullptr;                 // pixels for the generic kernel
-    uint32_t *wl_count = nullptr;
+    uint64_t *gmask = nullptr;                 // units for the generic kernel (lane masks)
+    uint16_t *goff = nullptr;                  // their reserved output offsets
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
     BatchArgs *d_batch = nullptr;
@@ -125,7 +125,7 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_bd,   c->running, c->worklist, c->wl_count, c->status,
+                    c->lv_bdt,  c->lv_bd,   c->running, c->gmask, c->goff, c->status,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -195,18 +195,17 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->lv_dt = c->lv_dt;
     a->lv_bdt = c->lv_bdt;
     a->lv_bd = c->lv_bd;
-    a->worklist = c->worklist;
+    a->gmask = c->gmask;
+    a->goff = c->goff;
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
-    a->wl_count = c->wl_count;
     a->n_units = c->n_units;
     a->num_waves = c->num_waves;
     a->width = c->p.width;
     a->channels = c->p.channels;
     a->rowlen = (uint32_t)c->p.width * c->p.channels;
     a->row_begin = c->p.row_begin;
-    if (const char *ab = getenv("ADDER_HIP_ABLATE")) a->ablate = (uint32_t)atoi(ab);  // timing experiments only
 }
 
 // Video::new (video.rs:350-438): every pixel = PixelArena::new(1.0, coord): base_val 0,
@@ -226,7 +225,6 @@ static int init_state(AdderHipCtx *c, bool full) {
     HIPCHK(c, hipMemsetAsync(c->lv_bd, 0, c->n_pad * c->max_depth, c->stream));
     HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
     c->running_t = 0.0f;
     c->frames_done = 0;
@@ -336,8 +334,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
-        HIPCHK(c, dalloc(&c->worklist, c->n_pad));
-        HIPCHK(c, dalloc(&c->wl_count, 1));
+        HIPCHK(c, dalloc(&c->gmask, (size_t)c->num_waves * kUnitsPerLane));
+        HIPCHK(c, dalloc(&c->goff, c->n_pad));
         HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c, true); if (rc_ != ADDER_OK) return rc_; }
@@ -419,7 +417,6 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
     const bool generic = (variant & 4u) != 0u;
-    const uint32_t generic_grid = std::min<uint32_t>(c->num_waves, c->num_cus * 8u);
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
@@ -440,8 +437,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             if (generic) {
                 HIPCHK(c, adder_launch_scan(c->d_batch, f, 1, s));
                 HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1, s));
-                HIPCHK(c, adder_launch_generic(c->d_batch, f, generic_grid, s));
-                HIPCHK(c, adder_launch_clear_u32(c->wl_count, s));
+                HIPCHK(c, adder_launch_generic(c->d_batch, f, c->num_waves, s));
             }
         }
         hipStream_t t = s;

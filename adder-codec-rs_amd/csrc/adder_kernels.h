@@ -59,14 +59,14 @@ struct FrameArgs {
     // stage 2 (scan kernel): exclusive prefix of the low halves of wtot, frame total
     uint32_t *wpref;      // [num_waves]
     uint32_t *ftot;       // [1] events of the frame
-    // pixels that need the generic step this frame: {unit, final offset inside its wave segment}
-    uint2 *worklist;
-    uint32_t *wl_count;
+    // units that need the generic step this frame: a 64-bit lane mask per (segment, pixel slot)
+    // and the start of each such unit's reserved output range inside its segment
+    uint64_t *gmask;      // [num_waves][kUnitsPerLane]
+    uint16_t *goff;       // [num_waves][kWaveUnits]
     uint32_t *status;
     uint32_t n_units;
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t ablate;      // experiments only (ADDER_HIP_ABLATE)
     uint32_t generic;     // 1: pixels deeper than one fired level are possible (worklist + generic kernel)
     StepConsts sc;
 };
@@ -112,7 +112,7 @@ hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                hipStream_t stream);
-hipError_t adder_launch_generic(const adder::BatchArgs *b, uint32_t f, uint32_t grid, hipStream_t stream);
+hipError_t adder_launch_generic(const adder::BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream);
 hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);

@@ -275,13 +275,15 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             sl.y = (sl.y & 0xffu) | ((lane * N + j) << 8) | (off << 16);
             dst[e] = sl;
         }
-        if (GENERIC && gmask) {
+        if (GENERIC) {
+            // tell the generic kernel which units of the segment it has to step (one bit mask
+            // per pixel slot j, no atomics) and where their reserved output range starts
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
-                if ((gmask >> j) & 1u) {
-                    const uint32_t wslot = atomicAdd(a.wl_count, 1u);
-                    a.worklist[wslot] = make_uint2(u0 + j, lane_off + ((pre >> (8 * j)) & 0xffu));
-                }
+                const bool g = (gmask >> j) & 1u;
+                const uint64_t m = __ballot(g);
+                if (lane == 0) a.gmask[(size_t)gw * N + j] = m;
+                if (g) a.goff[(size_t)gw * kWaveUnits + lane * N + j] = (uint16_t)(lane_off + ((pre >> (8 * j)) & 0xffu));
             }
         }
         vin_w = next_w;
@@ -427,18 +429,16 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     const uint64_t frame_base = b->base.frame_offsets[f];
     EventWords *out = reinterpret_cast<EventWords *>(b->base.out);
     bool dropped = false;
+    // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
+    // following segments advance it with scalar add/compare instead of dividing again
+    uint32_t y0 = __builtin_amdgcn_readfirstlane((seg0 * kWaveUnits) / rowlen);
+    uint32_t rem0 = seg0 * kWaveUnits - y0 * rowlen;
     const bool one_wrap = rowlen >= kWaveUnits;
 #pragma unroll
     for (uint32_t q = 0; q < kExpandSegs; ++q) {
         const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
-        if (parked == 0u) continue;
         const uint32_t gw = seg0 + q;
         const uint64_t base = frame_base + __builtin_amdgcn_readlane(my_pref, q);
-        // (row, offset in row) of the segment's first unit: one wave-uniform division instead
-        // of one per event; a segment spans at most one row boundary when rowlen >= kWaveUnits
-        const uint32_t ubase = gw * kWaveUnits;
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane(ubase / rowlen);
-        const uint32_t rem0 = ubase - y0 * rowlen;
         for (uint32_t i = lane; i < parked; i += kWave) {
             const uint2 sl = (i == lane) ? first[q] : park[(size_t)gw * kParkPerWave + i];
             uint32_t rem = rem0 + ((sl.y >> 8) & 0xffu);
@@ -468,22 +468,35 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
                 dropped = true;
             }
         }
+        // next segment starts kWaveUnits units later (uniform, scalar)
+        rem0 += kWaveUnits;
+        while (rem0 >= rowlen) {
+            rem0 -= rowlen;
+            ++y0;
+        }
     }
     if (dropped) raise(b->base.status, kStatusCapacity);
 }
 
 // ------------------------------------------------------------------------------------------
-// The full arena walk for the pixels K1 listed (deeper than one fired level).  Runs after
-// the scan kernel (needs wpref) and clears the worklist counter when done.
+// The full arena walk for the units K1 marked (deeper than one fired level).  Same
+// lane <-> unit mapping as K1: one wave per segment, lane l owns units l*N .. l*N+N-1 and
+// steps the marked ones.  Runs after the frame's scan + offsets kernels (needs wpref and
+// frame_offsets) and before the next frame's K1 (it updates pixel state).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
     const FrameArgs a = frame_args(b, f);
-    const uint32_t n = *a.wl_count;
+    constexpr uint32_t N = kUnitsPerLane;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    if (gw >= a.num_waves) return;
     const StepConsts sc = a.sc;
-    const uint64_t frame_base = a.frame_offsets[a.frame_idx];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint2 e = a.worklist[i];
-        const uint32_t u = e.x;
+    const uint64_t seg_base = a.frame_offsets[a.frame_idx] + a.wpref[gw];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        const uint64_t m = a.gmask[(size_t)gw * N + j];
+        if (!((m >> lane) & 1ull)) continue;
+        const uint32_t u = gw * kWaveUnits + lane * N + j;
         PxState px;
         px.hdr = a.hdr[u];
         px.n0.integ = px.n0.dt = px.n0.bdt = 0.0f;
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(const Batc
         const uint32_t c = rem - x * a.channels;
         EmitGlobal em;
         em.out = reinterpret_cast<EventWords *>(a.out);
-        em.pos = frame_base + a.wpref[u / kWaveUnits] + e.y;
+        em.pos = seg_base + a.goff[(size_t)gw * kWaveUnits + lane * N + j];
         em.cap = a.out_cap;
         em.dropped = false;
         em.xy = x | ((y + a.row_begin) << 16);
@@ -641,7 +654,8 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_generic(const BatchArgs *b, uint32_t f, uint32_t grid, hipStream_t stream) {
+extern "C" hipError_t adder_launch_generic(const BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream) {
+    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(adder_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
     return hipGetLastError();
 }
