@@ -62,6 +62,8 @@ SYMBOLS = {
     "adder_hip_reset_c_thresh": (_i32, [_vp, _u8]),
     "adder_hip_set_delta_t_max": (_i32, [_vp, _u32]),
     "adder_hip_set_time_mode": (_i32, [_vp, _u8]),
+    "adder_hip_alloc_pinned": (_vp, [_sz]),
+    "adder_hip_free_pinned": (None, [_vp]),
     "adder_hip_num_chunks": (_u32, [_vp]),
     "adder_hip_max_events_per_frame": (_sz, [_vp]),
     "adder_hip_integrate": (_i32, [_vp, _vp, _sz, _f32, _vp, _sz, C.POINTER(_sz), _vp]),

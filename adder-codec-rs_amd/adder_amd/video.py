@@ -52,8 +52,10 @@ class HipVideo:
         self.num_chunks = self.L.adder_hip_num_chunks(self.h)
         self.max_events_per_frame = self.L.adder_hip_max_events_per_frame(self.h)
         self._out = None
+        self._pinned = None
 
     def close(self):
+        self._free_pinned()
         if getattr(self, "h", None):
             self.L.adder_hip_destroy(self.h)
             self.h = None
@@ -99,9 +101,22 @@ class HipVideo:
 
     # ---- host-buffer entry points --------------------------------------------------------
     def _host_out(self, cap):
+        """Event buffer in page-locked host memory (PCIe copies at link speed)."""
         if self._out is None or len(self._out) < cap:
-            self._out = np.zeros(cap, N.EVENT_DTYPE)
+            self._free_pinned()
+            ptr = self.L.adder_hip_alloc_pinned(cap * 12)
+            if not ptr:
+                raise MemoryError("adder_hip_alloc_pinned failed")
+            self._pinned = ptr
+            buf = (C.c_uint8 * (cap * 12)).from_address(ptr)
+            self._out = np.frombuffer(buf, dtype=N.EVENT_DTYPE)
         return self._out
+
+    def _free_pinned(self):
+        if getattr(self, "_pinned", None):
+            self._out = None
+            self.L.adder_hip_free_pinned(self._pinned)
+            self._pinned = None
 
     def integrate_matrix(self, frame, time_spanned=None, want_chunks=False, out_cap=None):
         """One frame in, events out in the reference's order (video.rs:651-740)."""
@@ -115,7 +130,7 @@ class HipVideo:
                                         C.byref(n), chunks.ctypes.data)
         self.last_required = n.value
         N.check(self.h, rc)
-        ev = out[: n.value].copy()
+        ev = _copy_events(out, n.value)
         return (ev, chunks) if want_chunks else ev
 
     def integrate_batch(self, frames, time_spanned=None, out_cap=None):
@@ -132,7 +147,7 @@ class HipVideo:
                                               C.byref(n), offs.ctypes.data)
         self.last_required = n.value
         N.check(self.h, rc)
-        return out[: n.value].copy(), offs
+        return _copy_events(out, n.value), offs
 
     # ---- device-resident entry points (torch tensors provide the HBM buffers) ------------------
     def integrate_device(self, d_frames, d_events, d_offsets, time_spanned=None, stream=None):
@@ -176,6 +191,11 @@ class HipVideo:
     def chunk_offsets_device(self, d_events_ptr, n_events, d_chunk_offsets, stream=None):
         N.check(self.h, self.L.adder_hip_chunk_offsets_device(
             self.h, d_events_ptr, n_events, d_chunk_offsets.data_ptr(), C.c_void_p(stream) if stream else None))
+
+
+def _copy_events(buf, n):
+    """Plain memcpy of the first n 12-byte records (a structured-dtype copy goes field by field)."""
+    return buf[:n].view(np.uint32).copy().view(N.EVENT_DTYPE)
 
 
 def synth_clip_device(d_dst, content, width, height, channels, *, row_begin=0, rows=None, frame_begin=0,

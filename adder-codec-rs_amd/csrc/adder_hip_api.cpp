@@ -734,6 +734,16 @@ extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t 
     return ADDER_OK;
 }
 
+extern "C" void *adder_hip_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void adder_hip_free_pinned(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" int adder_hip_enable_running_intensities(AdderHipCtx *c, int enable) {
     if (!c) return ADDER_E_BAD_PARAMS;
     c->running_enabled = enable != 0;

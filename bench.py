@@ -133,6 +133,12 @@ def main():
     step()
     launch_us = hv.last_launch_avg_us()
     launch_frames = hv.last_launch_frames() or 1.0
+    # the same kernel with one frame per launch (the per-frame `consume` contract, state
+    # streamed from HBM every frame): this is the HBM-bound regime of SURVEY 8(d)
+    hv.set_frames_per_launch(1)
+    step()
+    launch1_us = hv.last_launch_avg_us()
+    hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "8")))
     hv.set_launch_timing(False)
 
     if rank != 0:
@@ -152,6 +158,8 @@ def main():
     bytes_per_unit = 1 + 2 * S / launch_frames + 12 * e_rank0
     units_per_launch = units * launch_frames
     achieved = bytes_per_unit * units_per_launch / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+    bytes1 = 1 + 2 * S + 12 * e_rank0
+    achieved1 = bytes1 * units / (launch1_us * 1e-6) / 1e9 if launch1_us > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -197,6 +205,19 @@ def main():
             "frames_per_launch": launch_frames,
             "units_per_launch": int(units_per_launch),
             "launch_avg_us": round(launch_us, 3),
+            "note": "default batches step 8 frames per launch with the state in registers: the kernel is then "
+                    "VALU-bound, not HBM-bound (DESIGN.md 4); roofline_one_frame_per_launch is the HBM-bound regime",
+        },
+        "roofline_one_frame_per_launch": {
+            "bound": "hbm",
+            "kernel": "adder_frame_kernel",
+            "achieved": round(achieved1, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved1 / HBM_PEAK_GBS, 4),
+            "bytes_per_unit_frame": round(bytes1, 3),
+            "units_per_launch": units,
+            "launch_avg_us": round(launch1_us, 3),
         },
     }
 

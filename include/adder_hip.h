@@ -115,6 +115,12 @@ uint32_t adder_hip_num_chunks(const AdderHipCtx *ctx);
 /* Upper bound on events one frame can emit for this context (units * (max_depth + 2)). */
 size_t adder_hip_max_events_per_frame(const AdderHipCtx *ctx);
 
+/* Page-locked host memory for frame / event buffers handed to the host-buffer entry points
+ * below: with pinned buffers the PCIe copies run at link speed and asynchronously; pageable
+ * buffers work too but are staged by the runtime.  NULL on failure. */
+void *adder_hip_alloc_pinned(size_t bytes);
+void adder_hip_free_pinned(void *p);
+
 /* --- one frame: the region video.rs:677-734 -------------------------------------
  * frame_hwc: host pointer to this band's rows, [rows][width][channels] u8 with
  * row_stride_bytes between rows.  Events come back in the reference's order

@@ -224,7 +224,7 @@ class Video:
             if r != C.c_size_t(-1).value:
                 break
             raise RuntimeError("oracle event buffer too small (state already advanced)")
-        ev = self._out[: n.value].copy()
+        ev = self._out[: n.value].view(np.uint32).copy().view(EVENT_DTYPE)
         if want_chunks:
             return ev, self._chunks.copy()
         return ev
