@@ -45,14 +45,13 @@ struct AdderHipCtx {
     // of frame f can overlap the frame kernel of frame f+1
     // compaction scratch: a ring of 2*chunk frames (the expand kernels of one chunk overlap the
     // frame kernels of the next)
-    uint2 *park_ring = nullptr;      // [slots][num_waves][kParkPerWave]
+    uint2 *park_ring = nullptr;      // [slots][num_waves][park_stride]
+    uint32_t park_stride = 0;        // parked-event capacity of a segment
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2;
     uint32_t frames_per_launch = 8;  // temporal blocking depth of the frame kernel (non-generic modes)
-    uint64_t *gmask = nullptr;                 // units for the generic kernel (lane masks)
-    uint16_t *goff = nullptr;                  // their reserved output offsets
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
     BatchArgs *d_batch = nullptr;
@@ -125,7 +124,7 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_bd,   c->running, c->gmask, c->goff, c->status,
+                    c->lv_bdt,  c->lv_bd,   c->running, c->status,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -195,8 +194,6 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->lv_dt = c->lv_dt;
     a->lv_bdt = c->lv_bdt;
     a->lv_bd = c->lv_bd;
-    a->gmask = c->gmask;
-    a->goff = c->goff;
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
@@ -231,6 +228,8 @@ static int init_state(AdderHipCtx *c, bool full) {
     c->poisoned = false;
     return ADDER_OK;
 }
+
+static int alloc_scratch(AdderHipCtx *c, uint32_t stride);
 
 extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
     if (!out) return fail(nullptr, ADDER_E_BAD_PARAMS, "out is null");
@@ -312,18 +311,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
         HIPCHK(c, dalloc(&c->running, c->n_pad));
-        {
-            // frames per scan/expand launch: as many as ~4 GiB of scratch allow, at most kMaxChunk
-            const size_t per_frame = (size_t)c->num_waves * (kParkPerWave * sizeof(uint2) + 2 * sizeof(uint32_t));
-            size_t ch = ((size_t)4 << 30) / (2 * per_frame);
-            c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
-            if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
-            c->slots = 2 * c->chunk;
-            HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * kParkPerWave));
-            HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
-            HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
-            HIPCHK(c, dalloc(&c->ftot_ring, c->slots));
-        }
+        { int rc_ = alloc_scratch(c, kParkPerWave); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, dalloc(&c->d_batch, 1));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
@@ -334,8 +322,6 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
-        HIPCHK(c, dalloc(&c->gmask, (size_t)c->num_waves * kUnitsPerLane));
-        HIPCHK(c, dalloc(&c->goff, c->n_pad));
         HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c, true); if (rc_ != ADDER_OK) return rc_; }
@@ -405,26 +391,49 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
+// (Re)allocates the compaction scratch ring for `stride` parked events per segment.  The
+// fast path parks at most 3 events per unit (kParkPerWave per segment); a generic batch can
+// park up to max_depth + 2 per unit.  Chunk = frames per scan/expand launch: as many as
+// ~6 GiB of scratch allow (two chunks are in flight), at most kMaxChunk.
+static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
+    if (c->park_stride >= stride && c->park_ring) return ADDER_OK;
+    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);  // they bake the chunking
+    c->graphs.clear();
+    for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
+        if (p) HIPCHK(c, hipFree(p));
+    c->park_ring = nullptr;
+    c->wtot_ring = c->wpref_ring = c->ftot_ring = nullptr;
+    c->park_stride = 0;
+    const size_t per_frame = (size_t)c->num_waves * ((size_t)stride * sizeof(uint2) + 2 * sizeof(uint32_t));
+    size_t ch = ((size_t)6 << 30) / (2 * per_frame);
+    c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
+    if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
+    c->slots = 2 * c->chunk;
+    HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * stride));
+    HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
+    HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
+    HIPCHK(c, dalloc(&c->ftot_ring, c->slots));
+    c->park_stride = stride;
+    return ADDER_OK;
+}
+
 // The launch sequence of a batch.  Frames are handled in chunks of c->chunk:
-//   stream s : K1 of every frame of the chunk, back to back (frame f+1 only needs frame f's
-//              pixel state);
+//   stream s : the chunk's K1 launches back to back, each stepping up to frames_per_launch
+//              consecutive frames (frame f+1 only needs frame f's pixel state);
 //   stream s2: behind the chunk's last K1 -- one scan launch (a block per frame), the
 //              frame_offsets chain, one expand launch for all the chunk's parked events.
 // The scratch ring holds two chunks, so the K1s of chunk k+2 wait for the expand of chunk k.
-// Eager form (s2 == nullptr): everything in order on s.  Generic mode (pixels deeper than one
-// fired level possible): the generic kernel of frame f needs that frame's prefix and updates
-// pixel state, so scan + offsets + generic run per frame on s; only the expand is chunked.
+// Eager form (s2 == nullptr): everything in order on s.
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
-    const bool generic = (variant & 4u) != 0u;
+    // temporal blocking is off while the running-intensities side plane is wanted (per-frame
+    // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
+    // to their unit, so the lane's own program order keeps them consistent across frames.
+    const uint32_t depth = c->running_enabled ? 1u : c->frames_per_launch;
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
         if (s2 && k >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[k & 1u], 0));
-        // temporal blocking: one K1 launch steps `nb` consecutive frames with the pixel state
-        // in registers; not with generic pixels (their kernel runs between frames) nor with the
-        // running-intensities side plane (per-frame semantics)
-        const uint32_t depth = (generic || c->running_enabled) ? 1u : c->frames_per_launch;
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
@@ -434,11 +443,6 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
                 c->timed_launches += 1;
                 c->timed_frames += nb;
             }
-            if (generic) {
-                HIPCHK(c, adder_launch_scan(c->d_batch, f, 1, s));
-                HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1, s));
-                HIPCHK(c, adder_launch_generic(c->d_batch, f, c->num_waves, s));
-            }
         }
         hipStream_t t = s;
         if (s2) {
@@ -446,10 +450,8 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             HIPCHK(c, hipStreamWaitEvent(s2, c->cap_e1, 0));
             t = s2;
         }
-        if (!generic) {
-            HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
-            HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        }
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
+        HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
         if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k & 1u], s2));
     }
@@ -497,6 +499,12 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic_possible ? 4u : 0u);
 
+    // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
+    if (generic_possible) {
+        int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2));
+        if (rc_ != ADDER_OK) return rc_;
+    }
+
     // ---- batch description -> device ----
     if (c->rt_cap < num_frames) {
         if (c->d_rt) HIPCHK(c, hipFree(c->d_rt));
@@ -524,6 +532,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.frames = d_frames;
     b.running_t = c->d_rt;
     b.park_ring = c->park_ring;
+    b.park_stride = c->park_stride;
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;

@@ -54,20 +54,16 @@ struct FrameArgs {
     uint64_t *frame_offsets;  // [frame_idx] = first event of the frame, [frame_idx+1] = end
     uint32_t frame_idx;
     // ordered compaction, stage 1 (frame kernel): per wave segment of 256 units
-    uint2 *park;          // [num_waves][kParkPerWave] {t, d | unit_in_wave<<8 | final_offset_in_wave<<16}
+    uint2 *park;          // [num_waves][park_stride] {t, d | unit_in_wave<<8 | final_offset_in_wave<<16}
     uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked events (high 16)
     // stage 2 (scan kernel): exclusive prefix of the low halves of wtot, frame total
     uint32_t *wpref;      // [num_waves]
     uint32_t *ftot;       // [1] events of the frame
-    // units that need the generic step this frame: a 64-bit lane mask per (segment, pixel slot)
-    // and the start of each such unit's reserved output range inside its segment
-    uint64_t *gmask;      // [num_waves][kUnitsPerLane]
-    uint16_t *goff;       // [num_waves][kWaveUnits]
     uint32_t *status;
     uint32_t n_units;
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t generic;     // 1: pixels deeper than one fired level are possible (worklist + generic kernel)
+    uint32_t generic;     // 1: pixels deeper than one fired level are possible (GENERIC kernel variants)
     StepConsts sc;
 };
 
@@ -79,7 +75,8 @@ struct BatchArgs {
     const uint8_t *frames;    // packed [T][n_units]
     const float *running_t;   // [T] PixelArena::running_t before each frame's integrate
     // compaction scratch: a ring of `slots` frames
-    uint2 *park_ring;         // [slots][num_waves][kParkPerWave]
+    uint2 *park_ring;         // [slots][num_waves][park_stride]
+    uint32_t park_stride;     // parked-event capacity of one segment (kParkPerWave, or more for generic batches)
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [slots]
@@ -93,7 +90,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     a.frame_idx = f;
     a.sc.running_t = b->running_t[f];
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
-    a.park = b->park_ring + (size_t)slot * a.num_waves * kParkPerWave;
+    a.park = b->park_ring + (size_t)slot * a.num_waves * b->park_stride;
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
     a.ftot = b->ftot_ring + slot;
@@ -112,7 +109,6 @@ hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                hipStream_t stream);
-hipError_t adder_launch_generic(const adder::BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream);
 hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);

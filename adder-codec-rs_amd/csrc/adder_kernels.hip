@@ -20,9 +20,9 @@
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
 // loop and nothing that can hang; the scan/expand kernels of a chunk of frames overlap the
-// frame kernels of the next chunk on a second stream.  Pixels whose arena is deeper than one fired level (Normal mode, or
-// delta_t_max > time_spanned) get their output range reserved by K1 (plan_count) and
-// are stepped by adder_generic_kernel (exec_step: the full arena walk) after the scan.
+// frame kernels of the next chunk on a second stream.  Pixels whose arena is deeper than one
+// fired level (Normal mode, or delta_t_max > time_spanned) take the full arena walk
+// (exec_step) inside the GENERIC instantiations of K1.
 // Memory-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,6 +89,17 @@ struct EmitGlobal {
             dropped = true;
         }
         ++pos;
+    }
+};
+
+// exec_step's events of one generic unit, parked with their final in-segment offset
+struct EmitPark {
+    uint2 *dst;     // next free parked slot of this lane
+    uint32_t tag;   // unit_in_wave << 8
+    uint32_t off;   // final offset of the unit's next event inside the segment
+    __device__ __forceinline__ void operator()(uint32_t d, uint32_t t) {
+        *dst++ = make_uint2(t, d | tag | (off << 16));
+        ++off;
     }
 };
 
@@ -218,8 +229,10 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         // ---------------- the step; events parked in the lane's LDS stack ----------------
         // Branch-free parking: all three candidate events are written, the stack pointer only
         // advances past the valid ones (hence kSlotsPerLane + 1 rows).
-        uint32_t nl = 0;    // events parked by this lane
+        uint32_t nl = 0;    // events parked by this lane (fast path, via the LDS stack)
+        uint32_t ngen = 0;  // events its generic units will park
         uint32_t cnts = 0;  // per-pixel event counts, 8 bits each
+        gmask = 0;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
@@ -249,8 +262,10 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 nl += mask >> 2;
                 cnts |= (uint32_t)__popc(mask) << (8 * j);
             } else if (active) {
-                cnts |= plan_count(st, v, sc) << (8 * j);
+                const uint32_t planned = plan_count(st, v, sc);
+                cnts |= planned << (8 * j);
                 gmask |= 1u << j;
+                ngen += planned;
             }
         }
         uint32_t lane_cnt = 0;
@@ -258,15 +273,16 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         for (uint32_t j = 0; j < N; ++j) lane_cnt += (cnts >> (8 * j)) & 0xffu;
 
         // ---------------- wave-level ordered compaction into the frame's segment ----------------
-        // low half: events of the lane in the final stream; high half: events it parked
-        const uint32_t packed = lane_cnt | (nl << 16);
+        // low half: events of the lane in the final stream; high half: events it parks (the
+        // fast ones from the LDS stack, then those of its generic units)
+        const uint32_t packed = lane_cnt | ((nl + ngen) << 16);
         const uint32_t incl = wave_inclusive_scan_dpp(packed);
         if (lane == kWave - 1) b->wtot_ring[(size_t)slot * a.num_waves + gw] = incl;
         const uint32_t excl = incl - packed;
         const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
         // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
         const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
-        uint2 *dst = b->park_ring + ((size_t)slot * a.num_waves + gw) * kParkPerWave + (excl >> 16);
+        uint2 *dst = b->park_ring + ((size_t)slot * a.num_waves + gw) * b->park_stride + (excl >> 16);
         for (uint32_t e = 0; e < nl; ++e) {
             uint2 sl = my_slots[e * kBlockThreads];
             const uint32_t j = (sl.y >> 8) & 3u;
@@ -275,21 +291,31 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             sl.y = (sl.y & 0xffu) | ((lane * N + j) << 8) | (off << 16);
             dst[e] = sl;
         }
-        if (GENERIC) {
-            // tell the generic kernel which units of the segment it has to step (one bit mask
-            // per pixel slot j, no atomics) and where their reserved output range starts
+        if (GENERIC && gmask) {
+            // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
+            // straight from / to the level planes; their events are parked behind the lane's
+            // fast ones (every parked event carries its final offset, so the order is free)
+            uint2 *gdst = dst + nl;
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
-                const bool g = (gmask >> j) & 1u;
-                const uint64_t m = __ballot(g);
-                if (lane == 0) a.gmask[(size_t)gw * N + j] = m;
-                if (g) a.goff[(size_t)gw * kWaveUnits + lane * N + j] = (uint16_t)(lane_off + ((pre >> (8 * j)) & 0xffu));
+                if (!((gmask >> j) & 1u)) continue;
+                const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+                PxState st;
+                st.hdr = pack_hdr(px[j]);
+                st.n0 = px[j].n0;
+                st.lastf = px[j].lastf;
+                DeepGlobal deep{a.lv_integ, a.lv_dt, a.lv_bdt, a.lv_bd, a.plane_stride, (size_t)u0 + j};
+                EmitPark em{gdst, (lane * N + j) << 8, lane_off + ((pre >> (8 * j)) & 0xffu)};
+                if (!exec_step(st, v, sc, deep, em)) raise(a.status, kStatusDepth);
+                gdst = em.dst;
+                px[j] = unpack_px(st);
+                px[j].has0 = (st.hdr >> 24) & kFlagMMask;  // keep the full m
             }
         }
         vin_w = next_w;
     }
 
-    // ---------------- state back to HBM (generic pixels keep their old state) ----------------
+    // ---------------- state back to HBM ----------------
     {
         uint32_t hdrv[N];
         float liv[N], ldv[N], lbv[N], lfv[N];
@@ -317,7 +343,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
-                if (u0 + j < a.n_units && !((gmask >> j) & 1u) && ((hdrv[j] >> 24) & kFlagMMask))
+                if (u0 + j < a.n_units && ((hdrv[j] >> 24) & kFlagMMask))
                     a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
                                                                 (double)sc.ref_time);
         }
@@ -325,7 +351,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
 }
 
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads, kFrameKernelWavesPerSimd) void adder_frame_kernel(
+__global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
     __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
     const FrameArgs a = frame_args(b, f);
@@ -411,7 +437,8 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t seg0 = (blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs;
     if (seg0 >= num_waves) return;
-    const uint2 *park = b->park_ring + (size_t)slot * num_waves * kParkPerWave;
+    const uint32_t park_stride = b->park_stride;
+    const uint2 *park = b->park_ring + (size_t)slot * num_waves * park_stride;
     const uint32_t *wtot = b->wtot_ring + (size_t)slot * num_waves;
     const uint32_t *wpref = b->wpref_ring + (size_t)slot * num_waves;
     const uint32_t rowlen = b->base.rowlen, channels = b->base.channels, row_begin = b->base.row_begin;
@@ -420,7 +447,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly)
     uint2 first[kExpandSegs];
 #pragma unroll
-    for (uint32_t q = 0; q < kExpandSegs; ++q) first[q] = park[(size_t)(seg0 + q) * kParkPerWave + lane];
+    for (uint32_t q = 0; q < kExpandSegs; ++q) first[q] = park[(size_t)(seg0 + q) * park_stride + lane];
     uint32_t my_tot = 0u, my_pref = 0u;
     if (lane < kExpandSegs) {
         my_tot = wtot[seg0 + lane];
@@ -440,7 +467,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
         const uint32_t gw = seg0 + q;
         const uint64_t base = frame_base + __builtin_amdgcn_readlane(my_pref, q);
         for (uint32_t i = lane; i < parked; i += kWave) {
-            const uint2 sl = (i == lane) ? first[q] : park[(size_t)gw * kParkPerWave + i];
+            const uint2 sl = (i == lane) ? first[q] : park[(size_t)gw * park_stride + i];
             uint32_t rem = rem0 + ((sl.y >> 8) & 0xffu);
             uint32_t y = y0;
             if (one_wrap) {
@@ -476,67 +503,6 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
         }
     }
     if (dropped) raise(b->base.status, kStatusCapacity);
-}
-
-// ------------------------------------------------------------------------------------------
-// The full arena walk for the units K1 marked (deeper than one fired level).  Same
-// lane <-> unit mapping as K1: one wave per segment, lane l owns units l*N .. l*N+N-1 and
-// steps the marked ones.  Runs after the frame's scan + offsets kernels (needs wpref and
-// frame_offsets) and before the next frame's K1 (it updates pixel state).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void adder_generic_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
-    const FrameArgs a = frame_args(b, f);
-    constexpr uint32_t N = kUnitsPerLane;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-    if (gw >= a.num_waves) return;
-    const StepConsts sc = a.sc;
-    const uint64_t seg_base = a.frame_offsets[a.frame_idx] + a.wpref[gw];
-#pragma unroll
-    for (uint32_t j = 0; j < N; ++j) {
-        const uint64_t m = a.gmask[(size_t)gw * N + j];
-        if (!((m >> lane) & 1ull)) continue;
-        const uint32_t u = gw * kWaveUnits + lane * N + j;
-        PxState px;
-        px.hdr = a.hdr[u];
-        px.n0.integ = px.n0.dt = px.n0.bdt = 0.0f;
-        px.n0.bd = 0u;
-        if ((px.hdr >> 24) & kFlagMMask) {
-            px.n0.integ = a.lv_integ[u];
-            px.n0.dt = a.lv_dt[u];
-            px.n0.bdt = a.lv_bdt[u];
-            px.n0.bd = a.lv_bd[u];
-        }
-        px.lastf = sc.abs_t ? a.lastf[u] : 0.0f;
-        const uint32_t v = a.frame[u];
-
-        const uint32_t y = u / a.rowlen;
-        const uint32_t rem = u - y * a.rowlen;
-        const uint32_t x = rem / a.channels;
-        const uint32_t c = rem - x * a.channels;
-        EmitGlobal em;
-        em.out = reinterpret_cast<EventWords *>(a.out);
-        em.pos = seg_base + a.goff[(size_t)gw * kWaveUnits + lane * N + j];
-        em.cap = a.out_cap;
-        em.dropped = false;
-        em.xy = x | ((y + a.row_begin) << 16);
-        em.c = a.channels == 1u ? 0xffu : c;
-        DeepGlobal deep{a.lv_integ, a.lv_dt, a.lv_bdt, a.lv_bd, a.plane_stride, u};
-        const bool depth_ok = exec_step(px, v, sc, deep, em);
-        if (em.dropped) raise(a.status, kStatusCapacity);
-        if (!depth_ok) raise(a.status, kStatusDepth);
-
-        a.hdr[u] = px.hdr;
-        if ((px.hdr >> 24) & kFlagMMask) {
-            a.lv_integ[u] = px.n0.integ;
-            a.lv_dt[u] = px.n0.dt;
-            a.lv_bdt[u] = px.n0.bdt;
-            a.lv_bd[u] = (uint8_t)px.n0.bd;
-            if (a.running)
-                a.running[u] = (uint8_t)frame_value_u8(px.n0.bd, f32_as_u32(px.n0.bdt), (double)sc.ref_time);
-        }
-        if (sc.abs_t) a.lastf[u] = px.lastf;
-    }
 }
 
 __global__ void adder_clear_u32_kernel(uint32_t *p) { *p = 0u; }
@@ -651,12 +617,6 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t grid = (num_waves + per_block - 1) / per_block;
     hipLaunchKernelGGL(adder_expand_kernel, dim3(grid, nf), dim3(kBlockThreads), 0, stream, b, f0);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t adder_launch_generic(const BatchArgs *b, uint32_t f, uint32_t num_waves, hipStream_t stream) {
-    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(adder_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
     return hipGetLastError();
 }
 
