@@ -308,3 +308,71 @@ import hashlib; print(hashlib.sha256(ev.tobytes() + offs.tobytes()).hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2]
+
+
+def _oracle_events(clip, *, time_mode, multi_mode, dtm, crf=(0, 0, 10), threads=8):
+    T, H, W, Cn = clip.shape
+    ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm, threads=threads)
+    ov.ensure_capacity(8)
+    ov.set_crf_parameters(crf[1], crf[2])
+    ov.reset_c_thresh(crf[0])
+    per = [ov.integrate_matrix(f) for f in clip]
+    return np.concatenate(per), np.concatenate([[0], np.cumsum([len(p) for p in per])])
+
+
+def test_baseline_config_1_plumbing_640x480(tmp_path):
+    """BASELINE.json configs[0]: 640x480 gray, 30 frames, raw .adder out -- through the C++ host
+    mirror (Framed -> Video -> Encoder), file compared with the oracle's serialisation."""
+    import host_py as Hst
+    clip = O.synth_clip(O.CONTENT_SCENE, 640, 480, 1, 30)
+    out = str(tmp_path / "c1.adder")
+    n, chunks = Hst.transcode_raw(clip, fps=30.0, crf=0, ref_time=255, delta_t_max=255, time_mode=0, multi_mode=1,
+                                  encoder_crf=0, out_path=out)
+    want, _ = _oracle_events(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255)
+    assert n == len(want) and chunks == 480
+    blob = O.raw_header(3, 640, 480, 1, 7650, 255, 255, 0, O.DELTA_T, 0) + O.raw_events(want, 1) + O.raw_eof()
+    assert open(out, "rb").read() == blob
+
+
+def test_baseline_config_4_shape_row_bands_3840x2160():
+    """configs[3] shape: 3840x2160 gray split into 8 row bands of 270 rows (one context per band, as
+    one rank per GPU would hold), merged frame-major in band order == the single-context stream;
+    a prefix is checked against the oracle."""
+    import torch
+    A = _hip()
+    from adder_amd import sharding
+    T = 6
+    clip = O.synth_clip(O.CONTENT_SCENE, 3840, 2160, 1, T)
+    whole, offs = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255)
+    bands = sharding.row_bands(2160, 8)
+    assert bands == [(i * 270, (i + 1) * 270) for i in range(8)]
+    segs = []
+    for (y0, y1) in bands:
+        ev, o = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255,
+                               row_band=(y0, y1))
+        segs.append((torch.from_numpy(np.frombuffer(ev.tobytes(), dtype=np.int32).reshape(-1, 3).copy()),
+                     torch.from_numpy(o.astype(np.int64))))
+    merged, moffs = sharding.merge_frame_major(segs)
+    got = np.frombuffer(merged.numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    assert np.array_equal(moffs.numpy(), offs.astype(np.int64)) and np.array_equal(got, whole)
+    want, woffs = _oracle_events(clip[:2], time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255)
+    assert np.array_equal(whole[: int(offs[2])], want)
+
+
+def test_baseline_config_5_shape_4k_rgb_lossy():
+    """configs[4] shape: 3840x2160 RGB, crf-3 numbers (baseline 2, max 7, velocity 7), AbsoluteT,
+    Collapse, delta_t_max = 7650 (the generic kernel variants) -- a few frames against the oracle."""
+    import torch
+    A = _hip()
+    T = 3
+    clip = O.synth_clip(O.CONTENT_SCENE, 3840, 2160, 3, T)
+    hv = A.HipVideo(3840, 2160, 3, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=7650)
+    hv.update_crf(3)
+    d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_ev = torch.empty((int(d_frames.numel() * 0.5) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
+    n = hv.finish()
+    got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    want, _ = _oracle_events(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=(2, 7, 7))
+    assert n == len(want) and np.array_equal(got, want)
