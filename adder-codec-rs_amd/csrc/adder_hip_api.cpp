@@ -51,7 +51,7 @@ struct AdderHipCtx {
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2;
-    uint32_t frames_per_launch = 8;  // temporal blocking depth of the frame kernel (non-generic modes)
+    uint32_t frames_per_launch = 16;  // temporal blocking depth of the frame kernel (non-generic modes)
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
     BatchArgs *d_batch = nullptr;
@@ -288,9 +288,9 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "row band too large (%llu pixel-channels)", (unsigned long long)units);
     }
     c->n_units = (uint32_t)units;
-    // pad to a whole number of K1 blocks and of 8-segment groups (the expand kernel's unit)
+    // pad to a whole number of K1 blocks and of segment groups (the expand kernel's unit)
     {
-        const uint32_t quantum = std::max<uint32_t>(kTileUnits, 8u * kWaveUnits);
+        const uint32_t quantum = std::max<uint32_t>(kTileUnits, (uint32_t)ADDER_EXPAND_SEGS * kWaveUnits);
         c->n_pad = (size_t)((c->n_units + quantum - 1) / quantum) * quantum;
         c->num_tiles = (uint32_t)(c->n_pad / kTileUnits);  // K1 blocks
     }

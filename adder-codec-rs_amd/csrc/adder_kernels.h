@@ -13,6 +13,9 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef ADDER_UNITS_PER_LANE
 #define ADDER_UNITS_PER_LANE 2
 #endif
+#ifndef ADDER_EXPAND_SEGS
+#define ADDER_EXPAND_SEGS 8
+#endif
 #ifndef ADDER_FRAME_WAVES_PER_SIMD
 #define ADDER_FRAME_WAVES_PER_SIMD 8
 #endif
@@ -23,7 +26,7 @@ constexpr uint32_t kSlotsPerLane = 3 * kUnitsPerLane;              // <= 3 fast-
 constexpr uint32_t kFrameKernelWavesPerSimd = ADDER_FRAME_WAVES_PER_SIMD;  // register budget of K1
 constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
 constexpr uint32_t kMaxChunk = 16;                                 // frames per scan/expand launch
-constexpr uint32_t kMaxFramesPerLaunch = 8;                        // temporal blocking depth of K1
+constexpr uint32_t kMaxFramesPerLaunch = 16;                       // temporal blocking depth of K1
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer

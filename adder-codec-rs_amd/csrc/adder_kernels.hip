@@ -171,7 +171,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
 // nb > 1 is only used when no pixel can need the generic kernel.
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                            uint32_t u0, uint32_t gw, uint32_t lane, uint2 *my_slots) {
+                                            uint32_t u0, uint32_t gw, uint32_t lane) {
     constexpr uint32_t N = kUnitsPerLane;
     // whole wave inside the band: the common case takes the unguarded vector input load
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
@@ -226,13 +226,14 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(rt_vec, i));
         sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
 
-        // ---------------- the step; events parked in the lane's LDS stack ----------------
-        // Branch-free parking: all three candidate events are written, the stack pointer only
-        // advances past the valid ones (hence kSlotsPerLane + 1 rows).
-        uint32_t nl = 0;    // events parked by this lane (fast path, via the LDS stack)
+        // ---------------- the step ----------------
+        uint32_t nl = 0;    // events parked by this lane's fast units
         uint32_t ngen = 0;  // events its generic units will park
         uint32_t cnts = 0;  // per-pixel event counts, 8 bits each
         gmask = 0;
+        FastEvents fe[N];   // <= 3 events per fast unit, kept in registers until the scan is done
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) fe[j].mask = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
@@ -248,19 +249,11 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 fast = fast_eligible<COLLAPSE>(st, v);
             }
             if (fast) {
-                FastEvents fe;
-                step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe);
-                const uint32_t mask = active ? fe.mask : 0u;
-                const uint32_t tag = j << 8;
-                my_slots[nl * kBlockThreads] = make_uint2(fe.ta, fe.da | tag);
-                nl += mask & 1u;
-                my_slots[nl * kBlockThreads] = make_uint2(fe.tb, fe.db | tag | (1u << 10));
-                nl += (mask >> 1) & 1u;
-                // index of the event inside its pixel: after A and B if present
-                const uint32_t kc = (mask & 1u) + ((mask >> 1) & 1u);
-                my_slots[nl * kBlockThreads] = make_uint2(fe.tc, fe.dc | tag | (kc << 10));
-                nl += mask >> 2;
-                cnts |= (uint32_t)__popc(mask) << (8 * j);
+                step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe[j]);
+                fe[j].mask = active ? fe[j].mask : 0u;
+                const uint32_t c = (uint32_t)__popc(fe[j].mask);
+                cnts |= c << (8 * j);
+                nl += c;
             } else if (active) {
                 const uint32_t planned = plan_count(st, v, sc);
                 cnts |= planned << (8 * j);
@@ -283,13 +276,24 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
         const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
         uint2 *dst = b->park_ring + ((size_t)slot * a.num_waves + gw) * b->park_stride + (excl >> 16);
-        for (uint32_t e = 0; e < nl; ++e) {
-            uint2 sl = my_slots[e * kBlockThreads];
-            const uint32_t j = (sl.y >> 8) & 3u;
-            const uint32_t off =
-                GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) + ((sl.y >> 10) & 3u) : lane_off + e;
-            sl.y = (sl.y & 0xffu) | ((lane * N + j) << 8) | (off << 16);
-            dst[e] = sl;
+        // the lane's fast events -> its range of the segment, each with {t, d | unit << 8 |
+        // final in-segment offset << 16}
+        {
+            uint32_t e = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                const uint32_t m = fe[j].mask;
+                const uint32_t tag = (lane * N + j) << 8;
+                uint32_t off = GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) : lane_off + e;
+                if (m & 1u) dst[e] = make_uint2(fe[j].ta, fe[j].da | tag | (off << 16));
+                e += m & 1u;
+                off += m & 1u;
+                if (m & 2u) dst[e] = make_uint2(fe[j].tb, fe[j].db | tag | (off << 16));
+                e += (m >> 1) & 1u;
+                off += (m >> 1) & 1u;
+                if (m & 4u) dst[e] = make_uint2(fe[j].tc, fe[j].dc | tag | (off << 16));
+                e += m >> 2;
+            }
         }
         if (GENERIC && gmask) {
             // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
@@ -353,13 +357,12 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
-    __shared__ uint2 s_slots[(kSlotsPerLane + 1) * kBlockThreads];  // [slot][thread] {t, d | px<<8 | k<<10}
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
     const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane, s_slots + tid);
+    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -428,7 +431,7 @@ __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f
 // metadata and, speculatively, the first 64 parked slots of every segment -- before it
 // consumes any of them: one memory round trip per wave.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kExpandSegs = 8;
+constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
     // only the frame-independent part of the arguments is needed here (no running_t fetch)
     const uint32_t f = f0 + blockIdx.y;

@@ -138,7 +138,7 @@ def main():
     hv.set_frames_per_launch(1)
     step()
     launch1_us = hv.last_launch_avg_us()
-    hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "8")))
+    hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "16")))
     hv.set_launch_timing(False)
 
     if rank != 0:
@@ -205,7 +205,7 @@ def main():
             "frames_per_launch": launch_frames,
             "units_per_launch": int(units_per_launch),
             "launch_avg_us": round(launch_us, 3),
-            "note": "default batches step 8 frames per launch with the state in registers: the kernel is then "
+            "note": "default batches step 16 frames per launch with the state in registers: the kernel is then "
                     "VALU-bound, not HBM-bound (DESIGN.md 4); roofline_one_frame_per_launch is the HBM-bound regime",
         },
         "roofline_one_frame_per_launch": {

@@ -172,9 +172,9 @@ float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
 float adder_hip_last_launch_frames(AdderHipCtx *ctx);
 
 /* Temporal blocking depth of the frame kernel: how many consecutive frames of a batch one
- * launch steps with the pixel state held in registers (1..8, default 8).  Results do not
- * depend on it.  It only applies to batches in which no pixel can be deeper than one fired
- * node (Collapse with delta_t_max <= time_spanned); other batches run one frame per launch. */
+ * launch steps with the pixel state held in registers (1..16, default 16).  Results do not
+ * depend on it.  Scratch is handled in chunks of at most 16 frames and a launch never spans
+ * two chunks; batches that want the running-intensities side plane run one frame per launch. */
 int adder_hip_set_frames_per_launch(AdderHipCtx *ctx, uint32_t frames);
 
 /* Back to the state right after adder_hip_create (Video::new): every pixel pristine,
