@@ -64,6 +64,7 @@ struct AdderHipCtx {
     hipEvent_t cap_e1 = nullptr, cap_e2[2] = {nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
     bool use_graph = true;
+    bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
     size_t d_offsets_cap = 0;       // all *_cap below are in BYTES
@@ -319,7 +320,10 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e1, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[0], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[1], hipEventDisableTiming));
-        if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) c->use_graph = atoi(ng) == 0;
+        if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) {
+            c->use_graph = atoi(ng) == 0;
+            c->eager_two_streams = atoi(ng) == 2;
+        }
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->status, 1));
@@ -557,6 +561,15 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         hipGraphExec_t exec = nullptr;
         rc = get_graph(c, num_frames, variant, &exec);
         if (rc == ADDER_OK) HIPCHK(c, hipGraphLaunch(exec, stream));
+    } else if (c->eager_two_streams && !timing) {
+        // the graph's two-stream structure, submitted eagerly (diagnostics)
+        HIPCHK(c, hipEventRecord(c->cap_e1, stream));
+        HIPCHK(c, hipStreamWaitEvent(c->cap_s, c->cap_e1, 0));
+        rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
+        if (rc == ADDER_OK) {
+            HIPCHK(c, hipEventRecord(c->cap_e1, c->cap_s));
+            HIPCHK(c, hipStreamWaitEvent(stream, c->cap_e1, 0));
+        }
     } else {
         rc = launch_frame_loop(c, num_frames, variant, stream, nullptr, timing);
     }
