@@ -64,6 +64,7 @@ struct AdderHipCtx {
     hipEvent_t cap_e1 = nullptr, cap_e2[2] = {nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
     bool use_graph = true;
+    bool fuse_expand = true;   // K1 expands the previous chunk (single stream); false: two streams
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
@@ -324,6 +325,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
         }
+        if (const char *fe = getenv("ADDER_HIP_FUSE_EXPAND")) c->fuse_expand = atoi(fe) != 0;
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->status, 1));
@@ -421,19 +423,27 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
     return ADDER_OK;
 }
 
-// The launch sequence of a batch.  Frames are handled in chunks of c->chunk:
-//   stream s : the chunk's K1 launches back to back, each stepping up to frames_per_launch
-//              consecutive frames (frame f+1 only needs frame f's pixel state);
-//   stream s2: behind the chunk's last K1 -- one scan launch (a block per frame), the
-//              frame_offsets chain, one expand launch for all the chunk's parked events.
-// The scratch ring holds two chunks, so the K1s of chunk k+2 wait for the expand of chunk k.
-// Eager form (s2 == nullptr): everything in order on s.
+// The launch sequence of a batch.  Frames are handled in chunks of c->chunk; per chunk
+//   * K1 launches back to back, each stepping up to frames_per_launch consecutive frames
+//     (frame f+1 only needs frame f's pixel state),
+//   * one scan launch (a block per frame) + the frame_offsets chain,
+//   * the expansion of the chunk's parked events.
+// Fused form (default): everything on ONE stream; the expansion of chunk k is done by extra
+// workgroups inside the K1 launches of chunk k+1 (the memory-bound expansion shares the SIMDs
+// with K1's VALU-bound step), and a stand-alone expand launch only handles the batch's last chunk.  The scratch ring holds two
+// chunks.  Unfused two-stream form (s2 != nullptr): scan/offsets/expand of chunk k on s2 behind
+// the chunk's last K1; the K1s of chunk k+2 wait for it.
+// Generic batches keep the stand-alone expansion (their K1 runs at 3 waves per SIMD and would
+// drag the expansion workgroups down to the same occupancy).
+static bool fuse_for(const AdderHipCtx *c, uint32_t variant) { return c->fuse_expand && !(variant & 4u); }
+
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
     // temporal blocking is off while the running-intensities side plane is wanted (per-frame
     // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
     // to their unit, so the lane's own program order keeps them consistent across frames.
     const uint32_t depth = c->running_enabled ? 1u : c->frames_per_launch;
+    const bool fused = !s2 && fuse_for(c, variant);
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
@@ -441,7 +451,9 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, s));
+            // fused: this launch also expands the frames at the same positions of the previous chunk
+            const bool fx = fused && f0 >= c->chunk;
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, fx ? f - c->chunk : 0u, fx ? nb : 0u, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
                 c->timed_launches += 1;
@@ -456,7 +468,15 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         }
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
+        if (fused) {
+            // frames of this chunk that the next chunk's K1s will not reach (it is shorter, or
+            // there is none) are expanded here
+            const uint32_t next_nf = f0 + c->chunk < num_frames ? std::min(c->chunk, num_frames - f0 - c->chunk) : 0u;
+            if (next_nf < nf)
+                HIPCHK(c, adder_launch_expand(c->d_batch, f0 + next_nf, nf - next_nf, c->num_waves, t));
+        } else {
+            HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
+        }
         if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k & 1u], s2));
     }
     if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) & 1u], 0));  // join (s2 is in-order)
@@ -472,7 +492,7 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     }
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
-    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
+    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, fuse_for(c, variant) ? nullptr : c->cap_s2, false);
     hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
     if (rc != ADDER_OK) {
         if (graph) (void)hipGraphDestroy(graph);

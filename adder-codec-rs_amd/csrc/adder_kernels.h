@@ -104,9 +104,10 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 
 extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
-// K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking, non-generic variants only)
+// K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking); the same grid also
+// expands frames [exp_f0, exp_f0 + exp_nf) of the previous, already scanned chunk (exp_nf may be 0)
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                              uint32_t num_waves, hipStream_t stream);
+                              uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked events
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);

@@ -354,13 +354,42 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
     }
 }
 
+__device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock);
+
+// K1.  The grid holds `step_blocks` workgroups that step frames [f, f + nb) (a wave per
+// segment) and, interleaved with them in dispatch order (exp_q expansion workgroups after
+// every step workgroup, the remainder at the end), the workgroups that expand frames
+// [exp_f0, exp_f0 + exp_nf) of the PREVIOUS chunk (already scanned).  The expansion is
+// memory-bound and the step VALU-bound, so sharing the SIMDs overlaps them; nothing in one
+// role waits for the other.
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
-    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
+    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb, uint32_t step_blocks, uint32_t exp_f0,
+    uint32_t exp_blocks_per_frame, uint32_t exp_q) {
+    uint32_t bid = blockIdx.x;
+    if (exp_blocks_per_frame != 0u) {
+        const uint32_t span = exp_q + 1u;
+        const uint32_t inter = step_blocks * span;
+        uint32_t e;
+        bool is_step = false;
+        if (bid < inter) {
+            const uint32_t g = bid / span, k = bid - g * span;
+            is_step = k == 0u;
+            bid = g;
+            e = g * exp_q + (k - 1u);
+        } else {
+            e = step_blocks * exp_q + (bid - inter);
+        }
+        if (!is_step) {
+            const uint32_t ef = e / exp_blocks_per_frame;
+            expand_block(b, exp_f0 + ef, e - ef * exp_blocks_per_frame);
+            return;
+        }
+    }
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
+    const uint32_t gw = bid * kWavesPerBlock + tid / kWave;  // the wave's segment
     const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
     run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane);
 }
@@ -432,13 +461,13 @@ __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f
 // consumes any of them: one memory round trip per wave.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
-__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+// One workgroup's share of a frame's expansion: 4 waves x kExpandSegs segments.
+__device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
     // only the frame-independent part of the arguments is needed here (no running_t fetch)
-    const uint32_t f = f0 + blockIdx.y;
     const uint32_t slot = f % b->slots;
     const uint32_t num_waves = b->base.num_waves;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t seg0 = (blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs;
+    const uint32_t seg0 = (xblock * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs;
     if (seg0 >= num_waves) return;
     const uint32_t park_stride = b->park_stride;
     const uint2 *park = b->park_ring + (size_t)slot * num_waves * park_stride;
@@ -506,6 +535,10 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
         }
     }
     if (dropped) raise(b->base.status, kStatusCapacity);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+    expand_block(b, f0 + blockIdx.y, blockIdx.x);
 }
 
 __global__ void adder_clear_u32_kernel(uint32_t *p) { *p = 0u; }
@@ -588,7 +621,7 @@ __global__ void adder_synth_kernel(uint8_t *dst, int content, uint64_t seed, uin
 // ------------------------- launch wrappers (called from adder_hip_api.cpp) -------------------------
 using namespace adder;
 
-typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t);
+typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 static FrameKernelFn pick_frame_kernel(uint32_t variant) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     if (collapse) {
@@ -599,9 +632,13 @@ static FrameKernelFn pick_frame_kernel(uint32_t variant) {
 }
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                                         uint32_t num_waves, hipStream_t stream) {
-    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(grid), dim3(kBlockThreads), 0, stream, b, f, nb);
+                                         uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
+    const uint32_t step_blocks = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t per_block = kWavesPerBlock * kExpandSegs;
+    const uint32_t exp_bpf = exp_nf ? (num_waves + per_block - 1) / per_block : 0u;
+    const uint32_t exp_blocks = exp_bpf * exp_nf;
+    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(step_blocks + exp_blocks), dim3(kBlockThreads), 0, stream, b, f,
+                       nb, step_blocks, exp_f0, exp_bpf, exp_blocks / step_blocks);
     return hipGetLastError();
 }
 

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--channels", type=int, default=C)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-roofline", action="store_true",
+                    help="no per-launch timing passes (used under rocprofv3 --pmc so that only default-depth launches are counted)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,17 +131,19 @@ def main():
             assert merged is not None and merged[0].shape[0] == total_events
 
     # ---- roofline of the dominant kernel: one extra step with an event pair per launch ----
-    hv.set_launch_timing(True)
-    step()
-    launch_us = hv.last_launch_avg_us()
-    launch_frames = hv.last_launch_frames() or 1.0
-    # the same kernel with one frame per launch (the per-frame `consume` contract, state
-    # streamed from HBM every frame): this is the HBM-bound regime of SURVEY 8(d)
-    hv.set_frames_per_launch(1)
-    step()
-    launch1_us = hv.last_launch_avg_us()
-    hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "16")))
-    hv.set_launch_timing(False)
+    launch_us, launch_frames, launch1_us = 0.0, 1.0, 0.0
+    if not args.skip_roofline:
+        hv.set_launch_timing(True)
+        step()
+        launch_us = hv.last_launch_avg_us()
+        launch_frames = hv.last_launch_frames() or 1.0
+        # the same kernel with one frame per launch (the per-frame `consume` contract, state
+        # streamed from HBM every frame): this is the HBM-bound regime of SURVEY 8(d)
+        hv.set_frames_per_launch(1)
+        step()
+        launch1_us = hv.last_launch_avg_us()
+        hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "16")))
+        hv.set_launch_timing(False)
 
     if rank != 0:
         if world > 1:
