@@ -61,7 +61,7 @@ struct AdderHipCtx {
     size_t rt_cap = 0;              // entries
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
-    hipEvent_t cap_e1 = nullptr, cap_e2[2] = {nullptr, nullptr};
+    hipEvent_t cap_e1 = nullptr, cap_e2[3] = {nullptr, nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
     bool use_graph = true;
     bool fuse_expand = true;   // K1 expands the previous chunk (single stream); false: two streams
@@ -138,7 +138,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->d_rt) (void)hipFree(c->d_rt);
     if (c->h_rt) (void)hipHostFree(c->h_rt);
-    for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1]})
+    for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1], c->cap_e2[2]})
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
     if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
@@ -231,6 +231,11 @@ static int init_state(AdderHipCtx *c, bool full) {
     return ADDER_OK;
 }
 
+// Fused expansion runs two chunks behind the step, so that the scan of chunk k (second stream)
+// overlaps the frame kernels of chunk k+1 instead of sitting between them; the scratch ring
+// therefore holds three chunks.
+constexpr uint32_t kFuseLagChunks = 2;
+
 static int alloc_scratch(AdderHipCtx *c, uint32_t stride);
 
 extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
@@ -321,6 +326,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e1, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[0], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[1], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[2], hipEventDisableTiming));
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) {
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
@@ -399,8 +405,8 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 
 // (Re)allocates the compaction scratch ring for `stride` parked events per segment.  The
 // fast path parks at most 3 events per unit (kParkPerWave per segment); a generic batch can
-// park up to max_depth + 2 per unit.  Chunk = frames per scan/expand launch: as many as
-// ~6 GiB of scratch allow (two chunks are in flight), at most kMaxChunk.
+// park up to max_depth + 2 per unit.  Chunk = frames per scan launch: as many as ~12 GiB of
+// scratch allow (three chunks are in flight), at most kMaxChunk.
 static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
     if (c->park_stride >= stride && c->park_ring) return ADDER_OK;
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);  // they bake the chunking
@@ -411,10 +417,10 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
     c->wtot_ring = c->wpref_ring = c->ftot_ring = nullptr;
     c->park_stride = 0;
     const size_t per_frame = (size_t)c->num_waves * ((size_t)stride * sizeof(uint2) + 2 * sizeof(uint32_t));
-    size_t ch = ((size_t)6 << 30) / (2 * per_frame);
+    size_t ch = ((size_t)12 << 30) / ((kFuseLagChunks + 1u) * per_frame);
     c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
     if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
-    c->slots = 2 * c->chunk;
+    c->slots = (kFuseLagChunks + 1u) * c->chunk;
     HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * stride));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
@@ -443,17 +449,23 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
     // to their unit, so the lane's own program order keeps them consistent across frames.
     const uint32_t depth = c->running_enabled ? 1u : c->frames_per_launch;
-    const bool fused = !s2 && fuse_for(c, variant);
+    const bool fused = fuse_for(c, variant);
+    const uint32_t lag = kFuseLagChunks * c->chunk;  // frames between a step and its fused expansion
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
-        if (s2 && k >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[k & 1u], 0));
+        if (s2) {
+            if (fused && k >= kFuseLagChunks)  // the scan of the chunk this one expands
+                HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - kFuseLagChunks) % 3u], 0));
+            if (!fused && k >= 2)  // scratch reuse: the expansion of chunk k-2
+                HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 2u) % 3u], 0));
+        }
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
-            // fused: this launch also expands the frames at the same positions of the previous chunk
-            const bool fx = fused && f0 >= c->chunk;
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, fx ? f - c->chunk : 0u, fx ? nb : 0u, s));
+            // fused: this launch also expands the frames `lag` back (same positions of an earlier chunk)
+            const bool fx = fused && f0 >= lag;
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, fx ? f - lag : 0u, fx ? nb : 0u, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
                 c->timed_launches += 1;
@@ -468,18 +480,16 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         }
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        if (fused) {
-            // frames of this chunk that the next chunk's K1s will not reach (it is shorter, or
-            // there is none) are expanded here
-            const uint32_t next_nf = f0 + c->chunk < num_frames ? std::min(c->chunk, num_frames - f0 - c->chunk) : 0u;
-            if (next_nf < nf)
-                HIPCHK(c, adder_launch_expand(c->d_batch, f0 + next_nf, nf - next_nf, c->num_waves, t));
-        } else {
-            HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
-        }
-        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k & 1u], s2));
+        if (!fused) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
+        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 3u], s2));
     }
-    if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) & 1u], 0));  // join (s2 is in-order)
+    if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 3u], 0));  // join (s2 is in-order)
+    if (fused) {
+        // frame f is expanded by the launch that steps frame f + lag; the last `lag` frames of
+        // the batch have no such launch
+        const uint32_t t0 = num_frames > lag ? num_frames - lag : 0u;
+        HIPCHK(c, adder_launch_expand(c->d_batch, t0, num_frames - t0, c->num_waves, s));
+    }
     return ADDER_OK;
 }
 
@@ -492,7 +502,7 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     }
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
-    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, fuse_for(c, variant) ? nullptr : c->cap_s2, false);
+    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
     hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
     if (rc != ADDER_OK) {
         if (graph) (void)hipGraphDestroy(graph);

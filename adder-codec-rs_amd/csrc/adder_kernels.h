@@ -113,7 +113,6 @@ hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                hipStream_t stream);
-hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream);
 hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

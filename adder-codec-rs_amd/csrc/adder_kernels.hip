@@ -5,25 +5,28 @@
 // every pixel-channel runs integrate_for_px (video.rs:1318-1380) and the emitted events
 // are gathered in raster order (y, x, c, per-pixel emission order).
 //
-//   K1 adder_frame_kernel   one lane = 4 consecutive pixel-channels.  Loads the header
-//        word, the frame bytes and level 0 of the arena as 16-byte-per-lane vectors
-//        (structure-of-arrays state resident in HBM across frames, level-planar: plane
-//        k holds every pixel's k-th fired node, so the headline mode never goes past
-//        plane 0), runs the lean step (step_fast) once per pixel, parks its <= 3 events
-//        in a lane-private LDS stack, stores the state, then compacts the events of the
-//        WAVE (ballot-free prefix over cross-lane shuffles, no barrier, no atomics) into
-//        the wave's scratch segment and writes the segment's event count.
+//   K1 adder_frame_kernel   one lane = 2 consecutive pixel-channels, one wave = one
+//        128-unit segment.  Loads the header word, the frame bytes and level 0 of the arena
+//        as 8-byte-per-lane vectors (structure-of-arrays state resident in HBM across
+//        frames, level-planar: plane k holds every pixel's k-th fired node, so the headline
+//        mode never goes past plane 0) and steps up to 16 consecutive frames with the state
+//        in registers.  Per frame: the lean step (step_fast) once per pixel, its <= 3 events
+//        held in registers, a DPP prefix scan over the WAVE (no barrier, no atomics, no
+//        LDS), the events written compacted into the wave's scratch segment, the segment's
+//        event count to wtot.
 //   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block per
 //        frame) + adder_offsets_kernel (the frame_offsets chain); run once per CHUNK of frames.
-//   K2 adder_expand_kernel  reads the parked events linearly and writes each 12-byte
-//        event to its final slot of the ordered stream (coordinates from the unit index).
+//   K2 expand_block         reads the parked events linearly and writes each 12-byte event
+//        to its final slot of the ordered stream (coordinates from the unit index).  Runs
+//        as extra workgroups inside K1's grid (the previous chunk's frames: memory-bound
+//        work sharing the SIMDs with K1's VALU-bound step) and as adder_expand_kernel for
+//        the last chunk of a batch.
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
-// loop and nothing that can hang; the scan/expand kernels of a chunk of frames overlap the
-// frame kernels of the next chunk on a second stream.  Pixels whose arena is deeper than one
-// fired level (Normal mode, or delta_t_max > time_spanned) take the full arena walk
-// (exec_step) inside the GENERIC instantiations of K1.
-// Memory-bound integer/f32 work: no MFMA anywhere.
+// loop and nothing that can hang.  Pixels whose arena is deeper than one fired level
+// (Normal mode, or delta_t_max > time_spanned) take the full arena walk (exec_step)
+// inside the GENERIC instantiations of K1.
+// HBM/VALU-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -541,8 +544,6 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     expand_block(b, f0 + blockIdx.y, blockIdx.x);
 }
 
-__global__ void adder_clear_u32_kernel(uint32_t *p) { *p = 0u; }
-
 // update_crf / update_quality_manual per-pixel reset (video.rs:1247-1250,1283-1286)
 __global__ void adder_reset_c_thresh_kernel(uint32_t *hdr, size_t n, uint32_t baseline) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -657,11 +658,6 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t grid = (num_waves + per_block - 1) / per_block;
     hipLaunchKernelGGL(adder_expand_kernel, dim3(grid, nf), dim3(kBlockThreads), 0, stream, b, f0);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t adder_launch_clear_u32(uint32_t *p, hipStream_t stream) {
-    hipLaunchKernelGGL(adder_clear_u32_kernel, dim3(1), dim3(1), 0, stream, p);
     return hipGetLastError();
 }
 
