@@ -290,7 +290,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
     c->num_cus = (uint32_t)prop.multiProcessorCount;
     c->rows = p.row_end - p.row_begin;
     const uint64_t units = (uint64_t)c->rows * p.width * p.channels;
-    if (units > 0x7ffffc00ull) {
+    // the kernels address a state plane with 32-bit byte offsets: 4 bytes per unit below 4 GiB
+    if (units > 0x3ffffc00ull) {
         delete c;
         return fail(nullptr, ADDER_E_BAD_PARAMS, "row band too large (%llu pixel-channels)", (unsigned long long)units);
     }
@@ -807,6 +808,23 @@ extern "C" int adder_hip_running_intensities(AdderHipCtx *c, uint8_t *dst) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(dst, c->running, c->n_units, hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_selftest_division(uint64_t *mismatches) {
+    if (!mismatches) return ADDER_E_BAD_PARAMS;
+    unsigned long long *d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(*d));
+    if (e == hipSuccess) e = hipMemset(d, 0, sizeof(*d));
+    if (e == hipSuccess) e = adder_launch_divtest(d, nullptr);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    if (e != hipSuccess) {
+        g_create_error = std::string("division self-test failed to run: ") + hipGetErrorString(e);
+        return ADDER_E_HIP;
+    }
+    *mismatches = h;
     return ADDER_OK;
 }
 

@@ -126,31 +126,66 @@ template <> struct VecOf<float, 2> { using type = float2; };
 template <> struct VecOf<uint8_t, 4> { using type = uint32_t; };
 template <> struct VecOf<uint8_t, 2> { using type = uint16_t; };
 
+// Global-address-space accesses as (wave-uniform base, 32-bit byte offset of the lane): the
+// pointers of the argument block are generic in the IR, which would make every access a FLAT
+// instruction with a 64-bit VALU address; with these the base stays in SGPRs and the lane
+// supplies one 32-bit offset (global_load/store ... saddr).  Offsets stay below 4 GiB: one state
+// plane holds n_pad * 4 bytes (adder_hip_create bounds n_pad), a parked segment a few KiB.
+#define ADDER_GLOBAL __attribute__((address_space(1)))
+template <int BYTES> struct RawOf;
+template <> struct RawOf<1> { using type = uint8_t; };
+template <> struct RawOf<2> { using type = uint16_t; };
+template <> struct RawOf<4> { using type = uint32_t; };
+template <> struct RawOf<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct RawOf<12> { typedef uint32_t type __attribute__((ext_vector_type(3))); };
+template <> struct RawOf<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <class V>
+__device__ __forceinline__ V gload(const void *base, uint32_t byte_off) {
+    using R = typename RawOf<sizeof(V)>::type;
+    const R r = *reinterpret_cast<const ADDER_GLOBAL R *>((const ADDER_GLOBAL char *)base + byte_off);
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+}
+template <class V>
+__device__ __forceinline__ void gstore(void *base, uint32_t byte_off, V v) {
+    using R = typename RawOf<sizeof(V)>::type;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    *reinterpret_cast<ADDER_GLOBAL R *>((ADDER_GLOBAL char *)base + byte_off) = r;
+}
+// a pointer that is the same in every lane, forced into SGPRs
 template <class T>
-__device__ __forceinline__ void load_vec(const T *p, T (&v)[kUnitsPerLane]) {
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+    const uint64_t x = (uint64_t)p;
+    // (the builtin returns int: without the casts the low half would be sign-extended)
+    return (T *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) |
+                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x));
+}
+
+template <class T>
+__device__ __forceinline__ void load_vec(const T *plane, uint32_t u0, T (&v)[kUnitsPerLane]) {
     using V = typename VecOf<T, kUnitsPerLane>::type;
-    const V x = *reinterpret_cast<const V *>(p);
+    const V x = gload<V>(plane, u0 * (uint32_t)sizeof(T));
     __builtin_memcpy(v, &x, sizeof(V));
 }
 template <class T>
-__device__ __forceinline__ void store_vec(T *p, const T (&v)[kUnitsPerLane]) {
+__device__ __forceinline__ void store_vec(T *plane, uint32_t u0, const T (&v)[kUnitsPerLane]) {
     using V = typename VecOf<T, kUnitsPerLane>::type;
     V x;
     __builtin_memcpy(&x, v, sizeof(V));
-    *reinterpret_cast<V *>(p) = x;
+    gstore<V>(plane, u0 * (uint32_t)sizeof(T), x);
 }
 
 // the lane's kUnitsPerLane input bytes of one frame, packed little-endian
 __device__ __forceinline__ uint32_t load_input(const uint8_t *frame, uint32_t u0, uint32_t n_units) {
     uint32_t w = 0u;
     if (u0 + kUnitsPerLane <= n_units) {
-        typename VecOf<uint8_t, kUnitsPerLane>::type x;
-        __builtin_memcpy(&x, frame + u0, kUnitsPerLane);
-        w = x;
+        w = gload<typename VecOf<uint8_t, kUnitsPerLane>::type>(frame, u0);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < kUnitsPerLane; ++j)
-            if (u0 + j < n_units) w |= (uint32_t)frame[u0 + j] << (8 * j);
+            if (u0 + j < n_units) w |= (uint32_t)gload<uint8_t>(frame, u0 + j) << (8 * j);
     }
     return w;
 }
@@ -182,7 +217,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
     uint32_t vin_w;
     {
         uint32_t hdrv[N];
-        load_vec(a.hdr + u0, hdrv);
+        load_vec(a.hdr, u0, hdrv);
         vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
         uint32_t hor = 0u;
 #pragma unroll
@@ -195,12 +230,12 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             bdv[j] = 0;
         }
         if ((hor >> 24) & kFlagMMask) {
-            load_vec(a.lv_integ + u0, liv);
-            load_vec(a.lv_dt + u0, ldv);
-            load_vec(a.lv_bdt + u0, lbv);
-            load_vec(a.lv_bd + u0, bdv);
+            load_vec(a.lv_integ, u0, liv);
+            load_vec(a.lv_dt, u0, ldv);
+            load_vec(a.lv_bdt, u0, lbv);
+            load_vec(a.lv_bd, u0, bdv);
         }
-        if (ABS_T) load_vec(a.lastf + u0, lfv);
+        if (ABS_T) load_vec(a.lastf, u0, lfv);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             PxState st;
@@ -219,13 +254,22 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
     // running_t of the launch's frames (nb <= 8): one load, then a lane read per frame
     const uint32_t rt_vec = (lane < kMaxFramesPerLaunch && lane < nb) ? __float_as_uint(b->running_t[a.frame_idx + lane]) : 0u;
 
-    for (uint32_t i = 0; i < nb; ++i) {
+    // wave-uniform bases of the per-frame accesses, in SGPRs
+    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
+    const uint8_t *const frames_u = uniform_ptr(b->frames);
+    uint2 *const park_ring_u = uniform_ptr(b->park_ring);
+    uint32_t *const wtot_ring_u = uniform_ptr(b->wtot_ring);
+    const uint32_t park_stride_u = __builtin_amdgcn_readfirstlane(b->park_stride);
+    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % slots_u);
+
+    for (uint32_t i = 0; i < nb; ++i, slot = (slot + 1u == slots_u) ? 0u : slot + 1u) {
         const uint32_t f = a.frame_idx + i;
         uint32_t next_w = 0u;
         if (i + 1 < nb)
-            next_w = load_input(b->frames + (size_t)(f + 1) * a.n_units, u0, full ? 0xffffffffu : a.n_units);
-        // wave-uniform per-frame values, kept in SGPRs
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(f % b->slots);
+            next_w = load_input(frames_u + (size_t)(f + 1) * n_units_u, u0, full ? 0xffffffffu : n_units_u);
         sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(rt_vec, i));
         sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
 
@@ -273,12 +317,14 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         // fast ones from the LDS stack, then those of its generic units)
         const uint32_t packed = lane_cnt | ((nl + ngen) << 16);
         const uint32_t incl = wave_inclusive_scan_dpp(packed);
-        if (lane == kWave - 1) b->wtot_ring[(size_t)slot * a.num_waves + gw] = incl;
+        const size_t seg_idx = (size_t)slot * num_waves_u + sgw;  // uniform
+        if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl);
         const uint32_t excl = incl - packed;
         const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
         // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
         const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
-        uint2 *dst = b->park_ring + ((size_t)slot * a.num_waves + gw) * b->park_stride + (excl >> 16);
+        uint2 *const seg = park_ring_u + seg_idx * park_stride_u;  // uniform
+        const uint32_t poff = (excl >> 16) * (uint32_t)sizeof(uint2);  // the lane's first parked slot
         // the lane's fast events -> its range of the segment, each with {t, d | unit << 8 |
         // final in-segment offset << 16}
         {
@@ -288,13 +334,13 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 const uint32_t m = fe[j].mask;
                 const uint32_t tag = (lane * N + j) << 8;
                 uint32_t off = GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) : lane_off + e;
-                if (m & 1u) dst[e] = make_uint2(fe[j].ta, fe[j].da | tag | (off << 16));
+                if (m & 1u) gstore(seg, poff + 8u * e, make_uint2(fe[j].ta, fe[j].da | tag | (off << 16)));
                 e += m & 1u;
                 off += m & 1u;
-                if (m & 2u) dst[e] = make_uint2(fe[j].tb, fe[j].db | tag | (off << 16));
+                if (m & 2u) gstore(seg, poff + 8u * e, make_uint2(fe[j].tb, fe[j].db | tag | (off << 16)));
                 e += (m >> 1) & 1u;
                 off += (m >> 1) & 1u;
-                if (m & 4u) dst[e] = make_uint2(fe[j].tc, fe[j].dc | tag | (off << 16));
+                if (m & 4u) gstore(seg, poff + 8u * e, make_uint2(fe[j].tc, fe[j].dc | tag | (off << 16)));
                 e += m >> 2;
             }
         }
@@ -302,7 +348,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
             // straight from / to the level planes; their events are parked behind the lane's
             // fast ones (every parked event carries its final offset, so the order is free)
-            uint2 *gdst = dst + nl;
+            uint2 *gdst = seg + (excl >> 16) + nl;
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
                 if (!((gmask >> j) & 1u)) continue;
@@ -339,14 +385,14 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             bdv[j] = (uint8_t)px[j].n0.bd;
             lfv[j] = px[j].lastf;
         }
-        store_vec(a.hdr + u0, hdrv);
+        store_vec(a.hdr, u0, hdrv);
         if ((hor >> 24) & kFlagMMask) {
-            store_vec(a.lv_integ + u0, liv);
-            store_vec(a.lv_dt + u0, ldv);
-            store_vec(a.lv_bdt + u0, lbv);
-            store_vec(a.lv_bd + u0, bdv);
+            store_vec(a.lv_integ, u0, liv);
+            store_vec(a.lv_dt, u0, ldv);
+            store_vec(a.lv_bdt, u0, lbv);
+            store_vec(a.lv_bd, u0, bdv);
         }
-        if (ABS_T) store_vec(a.lastf + u0, lfv);
+        if (ABS_T) store_vec(a.lastf, u0, lfv);
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
@@ -467,29 +513,34 @@ constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 // One workgroup's share of a frame's expansion: 4 waves x kExpandSegs segments.
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
     // only the frame-independent part of the arguments is needed here (no running_t fetch)
-    const uint32_t slot = f % b->slots;
-    const uint32_t num_waves = b->base.num_waves;
+    const uint32_t slots = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(f % slots);
+    const uint32_t num_waves = __builtin_amdgcn_readfirstlane(b->base.num_waves);
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t seg0 = (xblock * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs;
+    const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs);
     if (seg0 >= num_waves) return;
-    const uint32_t park_stride = b->park_stride;
-    const uint2 *park = b->park_ring + (size_t)slot * num_waves * park_stride;
-    const uint32_t *wtot = b->wtot_ring + (size_t)slot * num_waves;
-    const uint32_t *wpref = b->wpref_ring + (size_t)slot * num_waves;
-    const uint32_t rowlen = b->base.rowlen, channels = b->base.channels, row_begin = b->base.row_begin;
+    const uint32_t park_stride = __builtin_amdgcn_readfirstlane(b->park_stride);
+    // wave-uniform bases (SGPRs); the lanes add 32-bit byte offsets
+    const uint2 *park = uniform_ptr(b->park_ring) + ((size_t)slot * num_waves + seg0) * park_stride;
+    const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
+    const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
+    const uint32_t rowlen = __builtin_amdgcn_readfirstlane(b->base.rowlen);
+    const uint32_t channels = __builtin_amdgcn_readfirstlane(b->base.channels);
+    const uint32_t row_begin = __builtin_amdgcn_readfirstlane(b->base.row_begin);
     const uint64_t out_cap = b->base.out_cap;
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly)
     uint2 first[kExpandSegs];
 #pragma unroll
-    for (uint32_t q = 0; q < kExpandSegs; ++q) first[q] = park[(size_t)(seg0 + q) * park_stride + lane];
+    for (uint32_t q = 0; q < kExpandSegs; ++q)
+        first[q] = gload<uint2>(park + (size_t)q * park_stride, lane * (uint32_t)sizeof(uint2));
     uint32_t my_tot = 0u, my_pref = 0u;
     if (lane < kExpandSegs) {
-        my_tot = wtot[seg0 + lane];
-        my_pref = wpref[seg0 + lane];
+        my_tot = gload<uint32_t>(wtot, lane * 4u);
+        my_pref = gload<uint32_t>(wpref, lane * 4u);
     }
     const uint64_t frame_base = b->base.frame_offsets[f];
-    EventWords *out = reinterpret_cast<EventWords *>(b->base.out);
+    AdderEventPod *const out = uniform_ptr(b->base.out);
     bool dropped = false;
     // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
     // following segments advance it with scalar add/compare instead of dividing again
@@ -499,10 +550,14 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
 #pragma unroll
     for (uint32_t q = 0; q < kExpandSegs; ++q) {
         const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
-        const uint32_t gw = seg0 + q;
+        // the segment's first event in the stream (uniform); the lanes address relative to it
         const uint64_t base = frame_base + __builtin_amdgcn_readlane(my_pref, q);
+        const uint64_t room64 = base < out_cap ? out_cap - base : 0ull;
+        const uint32_t room = room64 > 0xffffffffull ? 0xffffffffu : (uint32_t)room64;  // events that still fit
+        EventWords *const seg_out = reinterpret_cast<EventWords *>(out) + base;
+        const uint2 *const seg_park = park + (size_t)q * park_stride;
         for (uint32_t i = lane; i < parked; i += kWave) {
-            const uint2 sl = (i == lane) ? first[q] : park[(size_t)gw * park_stride + i];
+            const uint2 sl = (i == lane) ? first[q] : gload<uint2>(seg_park, i * (uint32_t)sizeof(uint2));
             uint32_t rem = rem0 + ((sl.y >> 8) & 0xffu);
             uint32_t y = y0;
             if (one_wrap) {
@@ -519,13 +574,13 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
                 c = rem - 3u * x;
             }
-            const uint64_t pos = base + (sl.y >> 16);
-            if (pos < out_cap) {
+            const uint32_t pos = sl.y >> 16;  // final offset inside the segment
+            if (pos < room) {
                 EventWords w;
                 w.xy = x | ((y + row_begin) << 16);
                 w.cd = c | ((sl.y & 0xffu) << 8);
                 w.t = sl.x;
-                out[pos] = w;
+                gstore(seg_out, pos * (uint32_t)sizeof(EventWords), w);
             } else {
                 dropped = true;
             }
@@ -622,6 +677,13 @@ __global__ void adder_synth_kernel(uint8_t *dst, int content, uint64_t seed, uin
 // ------------------------- launch wrappers (called from adder_hip_api.cpp) -------------------------
 using namespace adder;
 
+// Exhaustive check of fdiv_small against the IEEE division on its whole domain
+// (a = blockIdx.x * 256 + threadIdx.x + 1 in [1, 2^24], b = blockIdx.y + 1 in [1, 255]).
+__global__ __launch_bounds__(256) void adder_divtest_kernel(unsigned long long *bad) {
+    const float a = (float)(blockIdx.x * 256u + threadIdx.x + 1u), b = (float)(blockIdx.y + 1u);
+    if (f32_as_u32(fdiv_small(a, b)) != f32_as_u32(fdiv(a, b))) atomicAdd(bad, 1ull);
+}
+
 typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 static FrameKernelFn pick_frame_kernel(uint32_t variant) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
@@ -630,6 +692,11 @@ static FrameKernelFn pick_frame_kernel(uint32_t variant) {
         return abs_t ? adder_frame_kernel<true, true, false> : adder_frame_kernel<true, false, false>;
     }
     return abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
+}
+
+extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_divtest_kernel, dim3((1u << 24) / 256u, 255), dim3(256), 0, stream, d_bad);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,

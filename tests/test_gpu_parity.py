@@ -376,3 +376,15 @@ def test_baseline_config_5_shape_4k_rgb_lossy():
     got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
     want, _ = _oracle_events(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=(2, 7, 7))
     assert n == len(want) and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_fast_division_is_exact_on_its_domain():
+    """step_fast's 4-instruction division == IEEE f32 division for every integer numerator in
+    [1, 2^24] and every u8 intensity in [1, 255] (adder_pixel.hpp fdiv_small)."""
+    import ctypes
+    import adder_amd
+    lib = adder_amd.load()
+    bad = ctypes.c_uint64(123)
+    assert lib.adder_hip_selftest_division(ctypes.byref(bad)) == 0
+    assert bad.value == 0
