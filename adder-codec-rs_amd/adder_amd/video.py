@@ -149,6 +149,32 @@ class HipVideo:
         N.check(self.h, rc)
         return _copy_events(out, n.value), offs
 
+    def integrate_batch_raw(self, frames, time_spanned=None, out_cap_bytes=None):
+        """T frames (host array) -> (wire bytes of the events as the raw `.adder` sink writes them,
+        number of events, frame_offsets[T+1] in events).  Serialisation happens on the device."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), self.n_units)
+        T = frames.shape[0]
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        rec = 9 if self.channels == 1 else 11
+        cap = (min(self.max_events_per_frame, 4 * self.n_units) * T * rec) if out_cap_bytes is None else out_cap_bytes
+        out = self._host_out((cap + 11) // 12).view(np.uint8)
+        nb, ne = C.c_size_t(0), C.c_size_t(0)
+        offs = np.zeros(T + 1, np.uint64)
+        rc = self.L.adder_hip_integrate_batch_raw(self.h, frames.ctypes.data, T, self.n_units,
+                                                  self.width * self.channels, ts, out.ctypes.data, cap,
+                                                  C.byref(nb), C.byref(ne), offs.ctypes.data)
+        self.last_required = ne.value
+        N.check(self.h, rc)
+        return out[: nb.value].tobytes(), ne.value, offs
+
+    def wire_events_device(self, d_events, n_events, d_out, stream=None):
+        """n_events events in HBM -> wire bytes in HBM (uint8 CUDA tensor); returns the byte count."""
+        nb = C.c_size_t(0)
+        N.check(self.h, self.L.adder_hip_wire_events_device(
+            self.h, d_events.data_ptr(), n_events, d_out.data_ptr(), d_out.numel() * d_out.element_size(),
+            C.byref(nb), C.c_void_p(stream) if stream else None))
+        return nb.value
+
     # ---- device-resident entry points (torch tensors provide the HBM buffers) ------------------
     def integrate_device(self, d_frames, d_events, d_offsets, time_spanned=None, stream=None):
         """Queues T frames resident in HBM.  d_frames: uint8 CUDA tensor [T, n_units];

@@ -74,6 +74,8 @@ struct AdderHipCtx {
     size_t d_frames_cap = 0;
     AdderEvent *d_events = nullptr;
     size_t d_events_cap = 0;
+    uint8_t *d_wire = nullptr;      // wire-format bytes of the last raw batch
+    size_t d_wire_cap = 0;
     uint32_t *d_chunks = nullptr;
     // running state
     float running_t = 0.0f;  // PixelArena::running_t (identical for all pixels)
@@ -127,7 +129,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
                     c->lv_bdt,  c->lv_bd,   c->running, c->status,
-                    c->d_offsets, c->d_frames, c->d_events, c->d_chunks};
+                    c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
@@ -401,6 +403,8 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     c->poisoned = true;
     if (st & kStatusDepth)
         return fail(c, ADDER_E_ARENA_DEPTH, "a pixel needed more than max_depth=%u stored nodes", c->max_depth);
+    if (st & kStatusWire)
+        return fail(c, ADDER_E_BAD_PARAMS, "wire serialisation: an event without a channel on a multi-channel plane");
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
@@ -721,16 +725,14 @@ static int ensure(AdderHipCtx *c, void **p, size_t *cap, size_t need) {
     return ADDER_OK;
 }
 
-extern "C" int adder_hip_integrate_batch(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
-                                         size_t frame_stride, size_t row_stride, float time_spanned,
-                                         AdderEvent *out, size_t out_cap, size_t *n_out,
-                                         uint64_t *frame_offsets) {
-    if (!c) return ADDER_E_BAD_PARAMS;
-    if (n_out) *n_out = 0;
+// Host frames -> device, integrate, finish: the events of the batch end up in c->d_events
+// (capacity out_cap events), the frame offsets in c->d_offsets; *total = number of events.
+static int batch_to_device(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames, size_t frame_stride,
+                           size_t row_stride, float time_spanned, size_t out_cap, size_t *total) {
+    *total = 0;
     if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
     if (!frames && num_frames) return fail(c, ADDER_E_BAD_PARAMS, "frames is null");
-    if (!out && out_cap) return fail(c, ADDER_E_BAD_PARAMS, "out is null");
     const size_t rowlen = (size_t)c->p.width * c->p.channels;
     if (row_stride == 0) row_stride = rowlen;
     if (row_stride < rowlen) return fail(c, ADDER_E_BAD_PARAMS, "row_stride_bytes smaller than a row");
@@ -753,19 +755,77 @@ extern "C" int adder_hip_integrate_batch(AdderHipCtx *c, const uint8_t *frames, 
     rc = adder_hip_integrate_device(c, c->d_frames, num_frames, time_spanned, c->d_events, out_cap, c->d_offsets,
                                     c->stream);
     if (rc != ADDER_OK) return rc;
+    rc = adder_hip_finish(c, total);
+    if (rc != ADDER_OK) return rc;
+    if (*total > out_cap) {  // defensive; the kernel reports this through the status word
+        c->poisoned = true;
+        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: need %zu", *total);
+    }
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_integrate_batch(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
+                                         size_t frame_stride, size_t row_stride, float time_spanned,
+                                         AdderEvent *out, size_t out_cap, size_t *n_out,
+                                         uint64_t *frame_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_out) *n_out = 0;
+    if (!out && out_cap) return fail(c, ADDER_E_BAD_PARAMS, "out is null");
     size_t total = 0;
-    rc = adder_hip_finish(c, &total);
+    int rc = batch_to_device(c, frames, num_frames, frame_stride, row_stride, time_spanned, out_cap, &total);
     if (n_out) *n_out = total;
     if (rc != ADDER_OK) return rc;
-    if (total > out_cap) {  // defensive; the kernel reports this through the status word
-        c->poisoned = true;
-        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: need %zu", total);
-    }
     if (total) HIPCHK(c, hipMemcpy(out, c->d_events, total * sizeof(AdderEvent), hipMemcpyDeviceToHost));
     if (frame_offsets)
         HIPCHK(c, hipMemcpy(frame_offsets, c->d_offsets, ((size_t)num_frames + 1) * sizeof(uint64_t),
                             hipMemcpyDeviceToHost));
     return ADDER_OK;
+}
+
+static uint32_t wire_record_bytes(const AdderHipCtx *c) { return c->p.channels == 1 ? 9u : 11u; }
+
+extern "C" int adder_hip_wire_events_device(AdderHipCtx *c, const AdderEvent *d_events, size_t n_events,
+                                            uint8_t *d_out, size_t out_cap_bytes, size_t *n_bytes, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_bytes) *n_bytes = 0;
+    if ((!d_events || !d_out) && n_events) return fail(c, ADDER_E_BAD_PARAMS, "null device buffer");
+    const size_t need = n_events * wire_record_bytes(c);
+    if (n_bytes) *n_bytes = need;
+    if (need > out_cap_bytes) return fail(c, ADDER_E_OUT_CAPACITY, "wire buffer too small: need %zu bytes", need);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, adder_launch_wire(reinterpret_cast<const AdderEventPod *>(d_events), n_events, wire_record_bytes(c), d_out,
+                                c->status, (hipStream_t)stream));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_integrate_batch_raw(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
+                                             size_t frame_stride, size_t row_stride, float time_spanned,
+                                             uint8_t *out_bytes, size_t out_cap_bytes, size_t *n_bytes,
+                                             size_t *n_events, uint64_t *frame_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_bytes) *n_bytes = 0;
+    if (n_events) *n_events = 0;
+    if (!out_bytes && out_cap_bytes) return fail(c, ADDER_E_BAD_PARAMS, "out_bytes is null");
+    const uint32_t rec = wire_record_bytes(c);
+    const size_t out_cap = out_cap_bytes / rec;
+    size_t total = 0;
+    int rc = batch_to_device(c, frames, num_frames, frame_stride, row_stride, time_spanned, out_cap, &total);
+    if (n_events) *n_events = total;
+    if (n_bytes) *n_bytes = total * rec;
+    if (rc != ADDER_OK) return rc;
+    void *vp = c->d_wire;
+    if ((rc = ensure(c, &vp, &c->d_wire_cap, std::max<size_t>(total * rec, 16))) != ADDER_OK) return rc;
+    c->d_wire = (uint8_t *)vp;
+    HIPCHK(c, adder_launch_wire(reinterpret_cast<const AdderEventPod *>(c->d_events), total, rec, c->d_wire, c->status,
+                                c->stream));
+    if (total) HIPCHK(c, hipMemcpyAsync(out_bytes, c->d_wire, total * rec, hipMemcpyDeviceToHost, c->stream));
+    if (frame_offsets)
+        HIPCHK(c, hipMemcpyAsync(frame_offsets, c->d_offsets, ((size_t)num_frames + 1) * sizeof(uint64_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return status_to_code(c, st);
 }
 
 extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,

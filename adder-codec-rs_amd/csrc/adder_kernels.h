@@ -30,6 +30,7 @@ constexpr uint32_t kMaxFramesPerLaunch = 16;                       // temporal b
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
+constexpr uint32_t kStatusWire = 4u;      // wire serialisation met c = None on a multi-channel plane
 constexpr uint32_t kStatusDepth = 2u;     // a pixel needed more than max_depth stored levels
 
 struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
@@ -110,6 +111,8 @@ hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb
                               uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked events
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
+hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
+                             hipStream_t stream);
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,

@@ -599,6 +599,68 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     expand_block(b, f0 + blockIdx.y, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------
+// K3: the raw sink's event serialisation (RawOutput::ingest_event, raw/stream.rs:101-120 =
+// bincode fixint big-endian) on the device: 12-byte AdderEvents -> 9-byte `EventSingle`
+// {x u16, y u16, d u8, t u32} records on a 1-channel plane, 11-byte `Event` {x, y, 0x01, c, d, t}
+// records otherwise.  The host then writes the bytes as they are (and D2H moves 9 instead of
+// 12 bytes per event).  A workgroup converts kWireEvents events: coalesced dword loads into
+// LDS, per-event repack in LDS, coalesced dword stores of the record bytes (kWireEvents is a
+// multiple of 4, so every workgroup's output starts dword-aligned).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kWireEvents = 1024;
+__global__ __launch_bounds__(256) void adder_wire_kernel(const uint32_t *__restrict__ ev, uint64_t n, uint32_t rec,
+                                                         uint8_t *__restrict__ out, uint32_t *status) {
+    __shared__ uint32_t s_w[kWireEvents * 3];
+    const uint64_t e0 = (uint64_t)blockIdx.x * kWireEvents;
+    const uint32_t cnt = (uint32_t)min((uint64_t)kWireEvents, n - e0);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t *src = ev + e0 * 3u;
+    for (uint32_t i = tid; i < cnt * 3u; i += 256u) s_w[i] = src[i];
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t e = tid; e < cnt; e += 256u) {
+        const uint32_t xy = s_w[3 * e], cd = s_w[3 * e + 1], t = s_w[3 * e + 2];
+        const uint32_t x = xy & 0xffffu, y = xy >> 16, c = cd & 0xffu, d = (cd >> 8) & 0xffu;
+        // record bytes, little-endian packed into dwords: byte k of the record = bits 8k.. of (w0,w1,w2)
+        const uint32_t w0 = (x >> 8) | ((x & 0xffu) << 8) | ((y >> 8) << 16) | ((y & 0xffu) << 24);
+        uint32_t w1, w2;
+        if (rec == 9u) {  // d, t3, t2, t1 | t0
+            w1 = d | ((t >> 24) << 8) | (((t >> 16) & 0xffu) << 16) | (((t >> 8) & 0xffu) << 24);
+            w2 = t & 0xffu;
+        } else {  // 0x01, c, d, t3 | t2, t1, t0
+            bad |= c == 0xffu;  // Option::None inside a multi-channel plane is a 10-byte record: not produced by the integrator
+            w1 = 1u | (c << 8) | (d << 16) | ((t >> 24) << 24);
+            w2 = ((t >> 16) & 0xffu) | (((t >> 8) & 0xffu) << 8) | ((t & 0xffu) << 16);
+        }
+        s_w[3 * e] = w0;
+        s_w[3 * e + 1] = w1;
+        s_w[3 * e + 2] = w2;
+    }
+    __syncthreads();
+    const uint32_t bytes = cnt * rec;
+    uint8_t *dst = out + e0 * rec;
+    const uint32_t magic = rec == 9u ? 0x38e38e39u : 0xba2e8ba3u;  // floor(B / rec) = mulhi(B, magic) >> (1 | 3)
+    const uint32_t sh = rec == 9u ? 1u : 3u;
+    for (uint32_t k = tid; k * 4u < bytes; k += 256u) {
+        uint32_t o = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t B = 4u * k + j;
+            const uint32_t e = __umulhi(B, magic) >> sh;
+            const uint32_t r = B - e * rec;
+            const uint32_t byte = B < bytes ? (s_w[3u * e + (r >> 2)] >> (8u * (r & 3u))) & 0xffu : 0u;
+            o |= byte << (8u * j);
+        }
+        if (4u * k + 4u <= bytes) {
+            reinterpret_cast<uint32_t *>(dst)[k] = o;
+        } else {  // the stream's last, partial dword
+            for (uint32_t j = 0; 4u * k + j < bytes; ++j) dst[4u * k + j] = (uint8_t)(o >> (8u * j));
+        }
+    }
+    if (bad) raise(status, kStatusWire);
+}
+
 // update_crf / update_quality_manual per-pixel reset (video.rs:1247-1250,1283-1286)
 __global__ void adder_reset_c_thresh_kernel(uint32_t *hdr, size_t n, uint32_t baseline) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,6 +769,15 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     const uint32_t exp_blocks = exp_bpf * exp_nf;
     hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(step_blocks + exp_blocks), dim3(kBlockThreads), 0, stream, b, f,
                        nb, step_blocks, exp_f0, exp_bpf, exp_blocks / step_blocks);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_wire(const AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
+                                        hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t grid = (n + kWireEvents - 1) / kWireEvents;
+    hipLaunchKernelGGL(adder_wire_kernel, dim3((uint32_t)grid), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(ev), n, rec, out, status);
     return hipGetLastError();
 }
 

@@ -182,6 +182,25 @@ int adder_hip_set_frames_per_launch(AdderHipCtx *ctx, uint32_t frames);
  * Parameters set since (crf parameters, delta_t_max, time mode) are kept. */
 int adder_hip_reset(AdderHipCtx *ctx);
 
+/* --- raw sink on the device ---------------------------------------------------------
+ * Replaces the per-event `RawOutput::ingest_event` loop (adder-codec-core/src/codec/raw/stream.rs:101-120,
+ * reached from video.rs:736-740 through encoder.rs:233-273): the events are serialised to the
+ * `.adder` wire form (bincode fixint big-endian: 9-byte EventSingle on a 1-channel plane, 11-byte
+ * Event {x, y, Some(c), d, t} otherwise) by a kernel, so the host writes the bytes as they are.
+ * Header and EOF stay on the host (adder_raw_header / adder_raw_eof).
+ *
+ * adder_hip_wire_events_device: `n_events` events of this context at d_events -> d_out (device
+ * memory), asynchronously on `stream`; *n_bytes = n_events * 9 (or 11).
+ * adder_hip_integrate_batch_raw: adder_hip_integrate_batch with the serialisation appended; out_bytes
+ * (host memory, pinned for full speed) receives the records of all T frames in stream order;
+ * frame_offsets (optional, T+1) are EVENT indices as in adder_hip_integrate_batch. */
+int adder_hip_wire_events_device(AdderHipCtx *ctx, const AdderEvent *d_events, size_t n_events,
+                                 uint8_t *d_out, size_t out_cap_bytes, size_t *n_bytes, void *stream);
+int adder_hip_integrate_batch_raw(AdderHipCtx *ctx, const uint8_t *frames, uint32_t num_frames,
+                                  size_t frame_stride_bytes, size_t row_stride_bytes, float time_spanned,
+                                  uint8_t *out_bytes, size_t out_cap_bytes, size_t *n_bytes,
+                                  size_t *n_events, uint64_t *frame_offsets);
+
 /* --- self-test ----------------------------------------------------------------------
  * The lean step replaces the one f32 division of integrate_main (event_pixel_tree.rs:431,445)
  * by a 4-instruction sequence that is correctly rounded on the domain it is used on

@@ -388,3 +388,51 @@ def test_fast_division_is_exact_on_its_domain():
     bad = ctypes.c_uint64(123)
     assert lib.adder_hip_selftest_division(ctypes.byref(bad)) == 0
     assert bad.value == 0
+
+
+@pytest.mark.gpu
+def test_lake_golden_bytes_device_sink(golden_dir):
+    """Same golden, but the events are serialised by the device-side raw sink (K3)."""
+    A = _hip()
+    raw = gzip.open(os.path.join(golden_dir, "lake_scaled_hd_out.adder.gz")).read()
+    frames = np.load(os.path.join(golden_dir, "lake_scaled_hd_frames_reconstructed.npz"))["frames"]
+    T, H, W = frames.shape[:3]
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, ref_time=255, delta_t_max=6120)
+    hv.update_crf(0)
+    body = b""
+    n_total = 0
+    for k0 in range(0, T, 32):  # several batches: state carries over, bytes concatenate
+        b, n, offs = hv.integrate_batch_raw(frames[k0:k0 + 32])
+        assert len(b) == 9 * n and int(offs[-1]) == n
+        body += b
+        n_total += n
+    assert n_total == 201620
+    assert raw[37:-11] == body
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3])
+def test_device_sink_equals_host_sink(channels):
+    """adder_hip_wire_events_device == adder_raw_events == oracle raw sink, incl. ragged sizes
+    (partial last workgroup, partial last dword)."""
+    import torch
+    A = _hip()
+    clip = clips.make_clip("noise", 5, 37, 53, channels, seed=11)
+    hv = A.HipVideo(53, 37, channels, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
+                    c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    ev, _ = hv.integrate_batch(clip)
+    assert len(ev) > 3000
+    rec = 9 if channels == 1 else 11
+    for n in (0, 1, 2, 3, 5, 1023, 1024, 1025, 2049, len(ev)):
+        sub = np.ascontiguousarray(ev[:n])
+        want = O.raw_events(sub, channels)
+        assert A.raw_events(sub, channels) == want
+        d_ev = torch.from_numpy(sub.view(np.uint8).copy()).cuda() if n else torch.zeros(12, dtype=torch.uint8, device="cuda")
+        d_out = torch.full((n * rec + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+        nb = hv.wire_events_device(d_ev, n, d_out, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert nb == n * rec
+        got = d_out.cpu().numpy()
+        assert got[:nb].tobytes() == want
+        assert (got[nb:] == 0xAB).all()  # nothing written past the stream's end
