@@ -81,6 +81,8 @@ SYMBOLS = {
     "adder_hip_reset": (_i32, [_vp]),
     "adder_hip_wire_events_device": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "adder_hip_integrate_batch_raw": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp]),
+    "adder_hip_stream_submit": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _sz]),
+    "adder_hip_stream_collect": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_vp)]),
     "adder_hip_selftest_division": (_i32, [_vp]),
     "adder_hip_synth_clip_device": (_i32, [_vp, _i32, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),

@@ -167,6 +167,24 @@ class HipVideo:
         N.check(self.h, rc)
         return out[: nb.value].tobytes(), ne.value, offs
 
+    def stream_submit(self, frames, time_spanned=None, out_cap_events=None):
+        """Pipelined raw transcode: upload + integrate this batch, queue its serialisation + download."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), self.n_units)
+        T = frames.shape[0]
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        cap = min(self.max_events_per_frame, 4 * self.n_units) * T if out_cap_events is None else out_cap_events
+        N.check(self.h, self.L.adder_hip_stream_submit(self.h, frames.ctypes.data, T, self.n_units,
+                                                       self.width * self.channels, ts, cap))
+
+    def stream_collect(self, copy=True):
+        """Oldest batch in flight -> (wire bytes, number of events, frame_offsets[T+1])."""
+        p, po = C.c_void_p(), C.c_void_p()
+        nb, ne = C.c_size_t(0), C.c_size_t(0)
+        rc = self.L.adder_hip_stream_collect(self.h, C.byref(p), C.byref(nb), C.byref(ne), C.byref(po))
+        N.check(self.h, rc)
+        buf = (C.c_uint8 * nb.value).from_address(p.value) if nb.value else b""
+        return (bytes(buf) if copy else buf), ne.value, po.value
+
     def wire_events_device(self, d_events, n_events, d_out, stream=None):
         """n_events events in HBM -> wire bytes in HBM (uint8 CUDA tensor); returns the byte count."""
         nb = C.c_size_t(0)

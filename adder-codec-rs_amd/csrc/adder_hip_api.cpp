@@ -76,6 +76,22 @@ struct AdderHipCtx {
     size_t d_events_cap = 0;
     uint8_t *d_wire = nullptr;      // wire-format bytes of the last raw batch
     size_t d_wire_cap = 0;
+    // pipelined raw transcode (adder_hip_stream_*): two slots, each one batch in flight
+    struct StreamSlot {
+        uint8_t *d_wire = nullptr;
+        size_t d_wire_cap = 0;
+        uint8_t *h_wire = nullptr;   // pinned
+        size_t h_wire_cap = 0;
+        uint64_t *h_offsets = nullptr;  // pinned, [T+1]
+        size_t h_offsets_cap = 0;
+        hipEvent_t done = nullptr;   // wire kernel + D2H of this slot
+        hipEvent_t wired = nullptr;  // wire kernel only (d_events may be overwritten after it)
+        size_t n_events = 0, n_bytes = 0;
+        uint32_t status = 0;
+        bool busy = false;
+    } slot[2];
+    hipStream_t out_s = nullptr;     // wire + D2H stream of the pipeline
+    uint64_t submitted = 0, collected = 0;
     uint32_t *d_chunks = nullptr;
     // running state
     float running_t = 0.0f;  // PixelArena::running_t (identical for all pixels)
@@ -134,6 +150,14 @@ static void free_ctx(AdderHipCtx *c) {
         if (p) (void)hipFree(p);
     for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
         if (p) (void)hipFree(p);
+    for (auto &sl : c->slot) {
+        if (sl.d_wire) (void)hipFree(sl.d_wire);
+        if (sl.h_wire) (void)hipHostFree(sl.h_wire);
+        if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.wired) (void)hipEventDestroy(sl.wired);
+    }
+    if (c->out_s) (void)hipStreamDestroy(c->out_s);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->d_batch) (void)hipFree(c->d_batch);
@@ -826,6 +850,80 @@ extern "C" int adder_hip_integrate_batch_raw(AdderHipCtx *c, const uint8_t *fram
     HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return status_to_code(c, st);
+}
+
+static int ensure_pinned(AdderHipCtx *c, void **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return ADDER_OK;
+    if (*p) HIPCHK(c, hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIPCHK(c, hipHostMalloc(p, std::max<size_t>(need, 16), hipHostMallocDefault));
+    *cap = need;
+    return ADDER_OK;
+}
+
+// Pipelined raw transcode.  submit(k) uploads and integrates batch k (blocking for exactly
+// that), then queues its serialisation and download on a second stream and returns; the
+// download of batch k therefore overlaps the upload + integration of batch k+1 when the
+// caller submits k+1 before collecting k.  At most two batches are in flight.
+extern "C" int adder_hip_stream_submit(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
+                                       size_t frame_stride, size_t row_stride, float time_spanned,
+                                       size_t out_cap_events) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->submitted - c->collected >= 2)
+        return fail(c, ADDER_E_BAD_PARAMS, "two batches are in flight: call adder_hip_stream_collect first");
+    HIPCHK(c, hipSetDevice(c->device));
+    AdderHipCtx::StreamSlot &sl = c->slot[c->submitted & 1u];
+    AdderHipCtx::StreamSlot &prev = c->slot[(c->submitted & 1u) ^ 1u];
+    if (!c->out_s) HIPCHK(c, hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
+    if (!sl.done) {
+        HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.wired, hipEventDisableTiming));
+    }
+    // the previous batch's serialisation still reads c->d_events
+    if (prev.busy && prev.wired) HIPCHK(c, hipStreamWaitEvent(c->stream, prev.wired, 0));
+    size_t total = 0;
+    int rc = batch_to_device(c, frames, num_frames, frame_stride, row_stride, time_spanned, out_cap_events, &total);
+    if (rc != ADDER_OK) return rc;
+    const uint32_t rec = wire_record_bytes(c);
+    void *vp = sl.d_wire;
+    if ((rc = ensure(c, &vp, &sl.d_wire_cap, total * rec)) != ADDER_OK) return rc;
+    sl.d_wire = (uint8_t *)vp;
+    vp = sl.h_wire;
+    if ((rc = ensure_pinned(c, &vp, &sl.h_wire_cap, total * rec)) != ADDER_OK) return rc;
+    sl.h_wire = (uint8_t *)vp;
+    vp = sl.h_offsets;
+    if ((rc = ensure_pinned(c, &vp, &sl.h_offsets_cap, ((size_t)num_frames + 1) * sizeof(uint64_t))) != ADDER_OK) return rc;
+    sl.h_offsets = (uint64_t *)vp;
+    sl.n_events = total;
+    sl.n_bytes = total * rec;
+    // batch_to_device has synchronised c->stream: the events are complete
+    HIPCHK(c, adder_launch_wire(reinterpret_cast<const AdderEventPod *>(c->d_events), total, rec, sl.d_wire, c->status,
+                                c->out_s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_offsets, c->d_offsets, ((size_t)num_frames + 1) * sizeof(uint64_t),
+                             hipMemcpyDeviceToHost, c->out_s));
+    HIPCHK(c, hipEventRecord(sl.wired, c->out_s));
+    if (total) HIPCHK(c, hipMemcpyAsync(sl.h_wire, sl.d_wire, total * rec, hipMemcpyDeviceToHost, c->out_s));
+    HIPCHK(c, hipMemcpyAsync(&sl.status, c->status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->out_s));
+    HIPCHK(c, hipEventRecord(sl.done, c->out_s));
+    sl.busy = true;
+    c->submitted += 1;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_stream_collect(AdderHipCtx *c, const uint8_t **bytes, size_t *n_bytes, size_t *n_events,
+                                        const uint64_t **frame_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->collected == c->submitted) return fail(c, ADDER_E_BAD_PARAMS, "no batch in flight");
+    AdderHipCtx::StreamSlot &sl = c->slot[c->collected & 1u];
+    HIPCHK(c, hipEventSynchronize(sl.done));
+    sl.busy = false;
+    c->collected += 1;
+    if (bytes) *bytes = sl.h_wire;
+    if (n_bytes) *n_bytes = sl.n_bytes;
+    if (n_events) *n_events = sl.n_events;
+    if (frame_offsets) *frame_offsets = sl.h_offsets;
+    return status_to_code(c, sl.status);
 }
 
 extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,

@@ -201,6 +201,19 @@ int adder_hip_integrate_batch_raw(AdderHipCtx *ctx, const uint8_t *frames, uint3
                                   uint8_t *out_bytes, size_t out_cap_bytes, size_t *n_bytes,
                                   size_t *n_events, uint64_t *frame_offsets);
 
+/* Pipelined form for whole clips (what the reference's SimulProcessor / Framed::consume loop does frame
+ * by frame, utils/simulproc.rs:233): submit(k) uploads and integrates batch k, then queues its
+ * serialisation and download on a second stream and returns; collect() waits for the oldest batch in
+ * flight and hands out its wire bytes (a pinned host buffer owned by the context, valid until the batch
+ * after next is submitted).  With submit(k+1) called before collect(k) the download of batch k overlaps
+ * the upload + integration of batch k+1.  At most two batches are in flight.  frames should be pinned
+ * (adder_hip_alloc_pinned) for the upload to run at link speed. */
+int adder_hip_stream_submit(AdderHipCtx *ctx, const uint8_t *frames, uint32_t num_frames,
+                            size_t frame_stride_bytes, size_t row_stride_bytes, float time_spanned,
+                            size_t out_cap_events);
+int adder_hip_stream_collect(AdderHipCtx *ctx, const uint8_t **bytes, size_t *n_bytes, size_t *n_events,
+                             const uint64_t **frame_offsets);
+
 /* --- self-test ----------------------------------------------------------------------
  * The lean step replaces the one f32 division of integrate_main (event_pixel_tree.rs:431,445)
  * by a 4-instruction sequence that is correctly rounded on the domain it is used on

@@ -436,3 +436,25 @@ def test_device_sink_equals_host_sink(channels):
         got = d_out.cpu().numpy()
         assert got[:nb].tobytes() == want
         assert (got[nb:] == 0xAB).all()  # nothing written past the stream's end
+
+
+def test_lake_golden_bytes_pipelined_stream(golden_dir):
+    """Same golden through the pipelined submit/collect form (two batches in flight)."""
+    A = _hip()
+    raw = gzip.open(os.path.join(golden_dir, "lake_scaled_hd_out.adder.gz")).read()
+    frames = np.load(os.path.join(golden_dir, "lake_scaled_hd_frames_reconstructed.npz"))["frames"]
+    hv = A.HipVideo(200, 50, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, ref_time=255, delta_t_max=6120)
+    hv.update_crf(0)
+    batches = [frames[k:k + 24] for k in range(0, len(frames), 24)]
+    body, n_total = b"", 0
+    hv.stream_submit(batches[0])
+    for k in range(len(batches)):
+        if k + 1 < len(batches):
+            hv.stream_submit(batches[k + 1])
+        b, n, _ = hv.stream_collect()
+        assert len(b) == 9 * n
+        body += b
+        n_total += n
+    assert n_total == 201620 and raw[37:-11] == body
+    with pytest.raises(Exception):
+        hv.stream_collect()  # nothing in flight

@@ -33,3 +33,30 @@ for it in range(3):
     rc = hv.L.adder_hip_integrate_batch(hv.h, frames.ctypes.data, T, W * H, W, 255.0, out.ctypes.data, cap, C.byref(n), offs.ctypes.data)
     dt = time.perf_counter() - t0
     print("C call only:", rc, round(dt, 4), "s ->", round(W * H * T / dt / 1e6, 1), "Mpx/s; kernel ms", hv.last_batch_ms())
+
+# ---- device-side raw sink (9-byte records), unpipelined: one C call
+nb, ne = C.c_size_t(0), C.c_size_t(0)
+cap_b = cap * 9
+for it in range(3):
+    hv.reset(); t0 = time.perf_counter()
+    rc = hv.L.adder_hip_integrate_batch_raw(hv.h, frames.ctypes.data, T, W * H, W, 255.0, out.ctypes.data, cap_b,
+                                            C.byref(nb), C.byref(ne), offs.ctypes.data)
+    dt = time.perf_counter() - t0
+    print("batch_raw C call:", rc, round(dt, 4), "s ->", round(W * H * T / dt / 1e6, 1), "Mpx/s;", nb.value, "bytes")
+
+# ---- pipelined submit/collect, 4 clips of T frames back to back (state carries over)
+K = 6
+p, po = C.c_void_p(), C.c_void_p()
+for it in range(3):
+    hv.reset(); t0 = time.perf_counter(); tot = 0
+    hv.L.adder_hip_stream_submit(hv.h, frames.ctypes.data, T, W * H, W, 255.0, cap)
+    for k in range(K):
+        if k + 1 < K:
+            rc = hv.L.adder_hip_stream_submit(hv.h, frames.ctypes.data, T, W * H, W, 255.0, cap)
+            assert rc == 0, rc
+        rc = hv.L.adder_hip_stream_collect(hv.h, C.byref(p), C.byref(nb), C.byref(ne), C.byref(po))
+        assert rc == 0, rc
+        tot += nb.value
+    dt = time.perf_counter() - t0
+    print("pipelined stream:", round(dt, 4), "s for", K * T, "frames ->", round(W * H * T * K / dt / 1e6, 1), "Mpx/s;",
+          tot, "bytes,", round(tot / dt / 1e9, 1), "GB/s down")
