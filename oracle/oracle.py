@@ -26,11 +26,11 @@ assert EVENT_DTYPE.itemsize == 12
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "adder_oracle.c")
+    srcs = [os.path.join(_HERE, n) for n in ("adder_oracle.c", "adder_framer_oracle.c")]
     if (
         force
         or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libadder_oracle.so"])
     return _LIB_PATH
@@ -95,6 +95,31 @@ def lib():
     L.oracle_raw_events.argtypes = [vp, vp, sz, u8]
     L.oracle_raw_eof.restype = sz
     L.oracle_raw_eof.argtypes = [vp]
+
+    L.oracle_framer_new.restype = vp
+    L.oracle_framer_new.argtypes = [u16, u16, u8, u32, u32, u32, u32, f32, u8, i32, u32]
+    L.oracle_framer_free.argtypes = [vp]
+    L.oracle_framer_buffer_limit.argtypes = [vp, i32, u32]
+    L.oracle_framer_tpf.restype = u32
+    L.oracle_framer_tpf.argtypes = [vp]
+    L.oracle_framer_frames_written.restype = C.c_int64
+    L.oracle_framer_frames_written.argtypes = [vp]
+    L.oracle_framer_num_chunks.restype = sz
+    L.oracle_framer_num_chunks.argtypes = [vp]
+    L.oracle_framer_is_frame_0_filled.restype = i32
+    L.oracle_framer_is_frame_0_filled.argtypes = [vp]
+    L.oracle_framer_ingest_event.restype = i32
+    L.oracle_framer_ingest_event.argtypes = [vp, vp]
+    L.oracle_framer_ingest_events_events.restype = i32
+    L.oracle_framer_ingest_events_events.argtypes = [vp, vp, vp]
+    L.oracle_framer_flush_frame_buffer.restype = i32
+    L.oracle_framer_flush_frame_buffer.argtypes = [vp]
+    L.oracle_framer_is_frame_filled.restype = i32
+    L.oracle_framer_is_frame_filled.argtypes = [vp, sz]
+    L.oracle_framer_write_frame_bytes.restype = sz
+    L.oracle_framer_write_frame_bytes.argtypes = [vp, vp]
+    L.oracle_framer_write_multi_frame_bytes.restype = i32
+    L.oracle_framer_write_multi_frame_bytes.argtypes = [vp, vp, sz, C.POINTER(sz)]
 
     L.oracle_synth_clip.argtypes = [vp, i32, C.c_uint64, u32, u32, u32, u32, u32, u32, u32]
     L.oracle_max_threads.restype = i32
@@ -234,6 +259,83 @@ class Video:
         if cap > self._cap:
             self._cap = cap
             self._out = np.zeros(cap, EVENT_DTYPE)
+
+
+FRAMED_U8, DVS = 0, 6  # SourceCamera (adder-codec-core/src/lib.rs:35-47)
+
+
+class Framer:
+    """FrameSequence<u8>, INSTANTANEOUS / Intensity (framer/driver.rs:261-981)."""
+
+    def __init__(self, width, height, channels=1, *, chunk_rows=64, tps, ref_interval, delta_t_max,
+                 output_fps=None, codec_version=1, time_mode=DELTA_T, source_camera=FRAMED_U8):
+        self.L = lib()
+        self.width, self.height, self.channels = width, height, channels
+        self.frame_bytes = width * height * channels
+        self.h = self.L.oracle_framer_new(width, height, channels, chunk_rows, tps, ref_interval, delta_t_max,
+                                          -1.0 if output_fps is None else float(output_fps), codec_version,
+                                          time_mode, source_camera)
+        if not self.h:
+            raise ValueError("bad oracle framer parameters")
+        self.chunk_rows = chunk_rows
+        self.num_chunks = self.L.oracle_framer_num_chunks(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_framer_free(self.h)
+            self.h = None
+
+    @property
+    def tpf(self):
+        return self.L.oracle_framer_tpf(self.h)
+
+    @property
+    def frames_written(self):
+        return self.L.oracle_framer_frames_written(self.h)
+
+    def ingest_event(self, x, y, c, d, t):
+        ev = np.zeros(1, EVENT_DTYPE)
+        ev[0] = (x, y, 0xFF if c is None else c, d, 0, t)
+        return bool(self.L.oracle_framer_ingest_event(self.h, ev.ctypes.data))
+
+    def ingest_events(self, events):
+        """Event by event (Framer::ingest_event); returns the frames that became ready, in order,
+        popped exactly where the reference's read loop pops them (tests/integration_tests.rs:86-101)."""
+        events = np.ascontiguousarray(events, dtype=EVENT_DTYPE).copy()
+        out = []
+        p = events.ctypes.data
+        for i in range(len(events)):
+            if self.L.oracle_framer_ingest_event(self.h, p + 12 * i):
+                out.append(self.write_multi_frame_bytes())
+        return b"".join(out)
+
+    def ingest_events_events(self, events, chunk_offsets):
+        events = np.ascontiguousarray(events, dtype=EVENT_DTYPE).copy()
+        offs = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
+        assert len(offs) == self.num_chunks + 1
+        return bool(self.L.oracle_framer_ingest_events_events(self.h, events.ctypes.data, offs.ctypes.data))
+
+    def flush_frame_buffer(self):
+        return bool(self.L.oracle_framer_flush_frame_buffer(self.h))
+
+    def is_frame_filled(self, idx):
+        r = self.L.oracle_framer_is_frame_filled(self.h, idx)
+        if r < 0:
+            raise IndexError("InvalidIndex" if r == -1 else "BadFillCount")
+        return bool(r)
+
+    def write_frame_bytes(self):
+        buf = np.zeros(self.frame_bytes, np.uint8)
+        n = self.L.oracle_framer_write_frame_bytes(self.h, buf.ctypes.data)
+        return buf[:n].tobytes()
+
+    def write_multi_frame_bytes(self, max_frames=4096):
+        buf = np.zeros(self.frame_bytes * max_frames, np.uint8)
+        n = C.c_size_t(0)
+        frames = self.L.oracle_framer_write_multi_frame_bytes(self.h, buf.ctypes.data, buf.nbytes, C.byref(n))
+        if frames < 0:
+            raise RuntimeError("write_multi_frame_bytes failed")
+        return buf[: n.value].tobytes()
 
 
 def raw_header(codec_version, width, height, channels, tps, ref_interval, delta_t_max,

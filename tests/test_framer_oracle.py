@@ -1,0 +1,85 @@
+"""Pins the framer oracle (oracle/adder_framer_oracle.c) to what the reference's own tests hold:
+  * get_frame_bytes_u8 / test_get_empty_frame   (adder-codec-rs/tests/integration_tests.rs:555-611, 782-820)
+  * sample_3_{ordered,unordered}.adder -> sample_3.gray, 405 frames (:822-975)
+  * the `dark` test: lake_scaled_hd_out.adder -> lake_scaled_out   (src/bin/adder_simulproc.rs:170-268)
+CPU only."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import adder_stream_np as S
+
+
+@pytest.fixture(scope="module")
+def golden_dir():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_get_frame_bytes_u8():
+    """integration_tests.rs:555-611: 25 events (d=5, t=5100) on a 5x5 plane, tpf = 50000/50 = 1000."""
+    fr = O.Framer(5, 5, 1, chunk_rows=64, tps=50000, ref_interval=1000, delta_t_max=1000, output_fps=50.0,
+                  codec_version=1, time_mode=O.DELTA_T, source_camera=O.FRAMED_U8)
+    assert fr.tpf == 1000
+    for i in range(5):
+        for j in range(5):
+            filled = fr.ingest_event(i, j, None, 5, 5100)
+            assert filled == (i == 4 and j == 4)
+        assert fr.is_frame_filled(0) == (i == 4)
+    out = fr.write_multi_frame_bytes()
+    assert len(out) == 150  # Ok(6) frames of 25 bytes
+    # 2^5 / 5100 * 1000 = 6.27 -> 6 in every pixel of every frame
+    assert set(out) == {6}
+
+
+def test_get_empty_frame():
+    """integration_tests.rs:782-820: an unfilled frame is still written (None -> 0)."""
+    fr = O.Framer(5, 5, 1, chunk_rows=64, tps=50000, ref_interval=1000, delta_t_max=1000, output_fps=50.0,
+                  codec_version=1, time_mode=O.DELTA_T, source_camera=O.FRAMED_U8)
+    assert fr.write_frame_bytes() == bytes(25)
+    assert fr.ingest_event(0, 0, None, 5, 500) is False
+
+
+@pytest.mark.parametrize("name", ["sample_3_ordered.adder", "sample_3_unordered.adder"])
+def test_sample_3(golden_dir, name):
+    """integration_tests.rs:822-975: 405 frames, byte-identical to sample_3.gray."""
+    meta, events, _ = S.read_adder(open(os.path.join(golden_dir, name), "rb").read())
+    want = open(os.path.join(golden_dir, "sample_3.gray"), "rb").read()
+    assert meta["tps"] // meta["ref_interval"] == 60
+    fr = O.Framer(meta["width"], meta["height"], meta["channels"], chunk_rows=64, tps=meta["tps"],
+                  ref_interval=meta["ref_interval"], delta_t_max=meta["delta_t_max"], output_fps=60.0,
+                  codec_version=meta["version"], time_mode=O.DELTA_T, source_camera=meta["source_camera"])
+    got = fr.ingest_events(events)
+    assert len(got) // (meta["width"] * meta["height"]) == 405
+    assert got == want
+
+
+def test_dark_lake(golden_dir):
+    """adder_simulproc.rs:170-268: the golden event file through SimulProcessor's framer
+    (codec_version 1, TimeMode::default(), reconstructed rate = source fps, chunk_rows 1 ->
+    ingest_events_events per input frame) equals lake_scaled_out."""
+    raw = gzip.open(os.path.join(golden_dir, "lake_scaled_hd_out.adder.gz")).read()
+    want = gzip.open(os.path.join(golden_dir, "lake_scaled_out.gz")).read()
+    meta, events, _ = S.read_adder(raw)
+    W, H = meta["width"], meta["height"]
+    # source fps: tps = (255 * fps) as u32 = 6113 (video.rs / framed.rs:101) -> 24000/1001
+    fps = np.float32(24000.0 / 1001.0)
+    assert int(np.float32(255.0) * fps) == meta["tps"]
+    fr = O.Framer(W, H, 1, chunk_rows=1, tps=meta["tps"], ref_interval=255, delta_t_max=meta["delta_t_max"],
+                  output_fps=float(fps), codec_version=1, time_mode=O.ABSOLUTE_T, source_camera=O.FRAMED_U8)
+    # per-input-frame Vec<Vec<Event>>: the frame boundaries of the golden stream are where the raster
+    # order restarts; within a frame one inner Vec per row (chunk_rows = 1)
+    key = events["y"].astype(np.int64) * W + events["x"]
+    starts = np.concatenate([[0], np.nonzero(np.diff(key) < 0)[0] + 1, [len(events)]])
+    got = b""
+    for a, b in zip(starts[:-1], starts[1:]):
+        seg = events[a:b]
+        offs = np.searchsorted(seg["y"], np.arange(H + 1), side="left").astype(np.uint64)
+        if fr.ingest_events_events(seg, offs):
+            got += fr.write_multi_frame_bytes()
+    assert len(want) % (W * H) == 0
+    n = min(len(got), len(want))
+    assert n > 0 and got[:n] == want[:n]
+    assert len(got) >= len(want)  # "the file might be larger" (adder_simulproc.rs:255-257)
