@@ -50,7 +50,29 @@ class AdderHipParams(C.Structure):
     ]
 
 
-# every symbol include/adder_hip.h declares: name -> (restype, argtypes)
+class AdderFramerParams(C.Structure):
+    """include/adder_framer.h::AdderFramerParams"""
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("width", C.c_uint16),
+        ("height", C.c_uint16),
+        ("channels", C.c_uint8),
+        ("codec_version", C.c_uint8),
+        ("time_mode", C.c_uint8),
+        ("reserved0", C.c_uint8),
+        ("row_begin", C.c_uint32),
+        ("row_end", C.c_uint32),
+        ("tps", C.c_uint32),
+        ("ref_interval", C.c_uint32),
+        ("delta_t_max", C.c_uint32),
+        ("output_fps", C.c_float),
+        ("source_camera", C.c_uint32),
+        ("ring_frames", C.c_uint32),
+        ("device_id", C.c_int32),
+    ]
+
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
 _vp, _u8, _u16, _u32, _u64, _f32, _i32, _sz = (
     C.c_void_p, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_size_t)
 SYMBOLS = {
@@ -88,6 +110,20 @@ SYMBOLS = {
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
     "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),
     "adder_raw_eof": (_sz, [_vp]),
+    # include/adder_framer.h
+    "adder_framer_default_params": (None, [C.POINTER(AdderFramerParams), _u16, _u16, _u8]),
+    "adder_framer_create": (_i32, [C.POINTER(AdderFramerParams), C.POINTER(_vp)]),
+    "adder_framer_destroy": (None, [_vp]),
+    "adder_framer_last_error": (C.c_char_p, [_vp]),
+    "adder_framer_tpf": (_u32, [_vp]),
+    "adder_framer_frames_written": (C.c_int64, [_vp]),
+    "adder_framer_ingest_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "adder_framer_ingest": (_i32, [_vp, _vp, _vp, _u32]),
+    "adder_framer_frames_ready": (_i32, [_vp, C.POINTER(_u32)]),
+    "adder_framer_pop_device": (_i32, [_vp, _vp, _u32, C.POINTER(_u32), _vp]),
+    "adder_framer_pop": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),
+    "adder_framer_write_frame": (_i32, [_vp, _vp]),
+    "adder_framer_flush": (_i32, [_vp, C.POINTER(_i32)]),
 }
 
 _lib = None
@@ -123,6 +159,12 @@ def load():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def check_framer(fr, rc):
+    if rc != OK:
+        msg = load().adder_framer_last_error(fr)
+        raise AdderHipError(rc, msg.decode() if msg else "")
 
 
 def check(ctx, rc):

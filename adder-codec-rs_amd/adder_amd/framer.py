@@ -1,0 +1,120 @@
+"""HipFramer -- ctypes plumbing over include/adder_framer.h (events -> u8 frames on the GPU).
+
+Mirrors FramerBuilder / FrameSequence<u8> (adder-codec-rs/src/framer/driver.rs:55-138, 261-981) for
+FramerMode::INSTANTANEOUS + FramedViewMode::Intensity.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+FRAMED_U8, DVS = 0, 6  # SourceCamera (adder-codec-core/src/lib.rs:35-47)
+
+
+class HipFramer:
+    def __init__(self, width, height, channels=1, *, tps, ref_interval, delta_t_max, output_fps=None,
+                 codec_version=1, time_mode=N.TIME_DELTA_T, source_camera=FRAMED_U8, row_begin=0, row_end=None,
+                 ring_frames=0, device_id=0):
+        self.L = N.load()
+        p = N.AdderFramerParams()
+        self.L.adder_framer_default_params(C.byref(p), width, height, channels)
+        p.codec_version, p.time_mode = codec_version, time_mode
+        p.row_begin, p.row_end = row_begin, height if row_end is None else row_end
+        p.tps, p.ref_interval, p.delta_t_max = tps, ref_interval, delta_t_max
+        p.output_fps = 0.0 if output_fps is None else float(output_fps)
+        p.source_camera, p.ring_frames, p.device_id = source_camera, ring_frames, device_id
+        h = C.c_void_p()
+        rc = self.L.adder_framer_create(C.byref(p), C.byref(h))
+        if rc != N.OK:
+            msg = self.L.adder_framer_last_error(None)
+            raise N.AdderHipError(rc, msg.decode() if msg else "")
+        self.h = h
+        self.width, self.height, self.channels = width, height, channels
+        self.rows = p.row_end - p.row_begin
+        self.frame_bytes = self.rows * width * channels
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.adder_framer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def tpf(self):
+        return self.L.adder_framer_tpf(self.h)
+
+    @property
+    def frames_written(self):
+        return self.L.adder_framer_frames_written(self.h)
+
+    def ingest(self, events, seg_offsets=None):
+        """events: host array (EVENT_DTYPE); seg_offsets: boundaries of segments inside which every
+        pixel-channel's events are contiguous (default: one segment)."""
+        events = np.ascontiguousarray(events, dtype=N.EVENT_DTYPE)
+        offs = np.array([0, len(events)], np.uint64) if seg_offsets is None else \
+            np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+        N.check_framer(self.h, self.L.adder_framer_ingest(self.h, events.ctypes.data, offs.ctypes.data, len(offs) - 1))
+
+    def ingest_device(self, d_events, seg_offsets, stream=None):
+        """d_events: CUDA tensor holding 12-byte events; seg_offsets: host array of event indices."""
+        offs = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+        N.check_framer(self.h, self.L.adder_framer_ingest_device(
+            self.h, d_events.data_ptr(), offs.ctypes.data, len(offs) - 1, C.c_void_p(stream) if stream else None))
+
+    def frames_ready(self):
+        n = C.c_uint32(0)
+        N.check_framer(self.h, self.L.adder_framer_frames_ready(self.h, C.byref(n)))
+        return n.value
+
+    def pop(self, max_frames=1 << 16):
+        """write_multi_frame_bytes: all complete frames -> bytes ([n][rows][W][C] u8)."""
+        out = []
+        while max_frames > 0:
+            step = min(max_frames, 256)
+            buf = np.empty(step * self.frame_bytes, np.uint8)
+            n = C.c_uint32(0)
+            N.check_framer(self.h, self.L.adder_framer_pop(self.h, buf.ctypes.data, step, C.byref(n)))
+            if not n.value:
+                break
+            out.append(buf[: n.value * self.frame_bytes].tobytes())
+            max_frames -= n.value
+            if n.value < step:
+                break
+        return b"".join(out)
+
+    def pop_device(self, d_out, max_frames, stream=None):
+        n = C.c_uint32(0)
+        N.check_framer(self.h, self.L.adder_framer_pop_device(self.h, d_out.data_ptr(), max_frames, C.byref(n),
+                                                              C.c_void_p(stream) if stream else None))
+        return n.value
+
+    def write_frame_bytes(self):
+        buf = np.empty(self.frame_bytes, np.uint8)
+        N.check_framer(self.h, self.L.adder_framer_write_frame(self.h, buf.ctypes.data))
+        return buf.tobytes()
+
+    def flush_frame_buffer(self):
+        r = C.c_int(0)
+        N.check_framer(self.h, self.L.adder_framer_flush(self.h, C.byref(r)))
+        return bool(r.value)
+
+
+def contiguous_run_segments(events):
+    """Greedy split of an arbitrary event stream into segments inside which every pixel-channel's
+    events are contiguous (what HipFramer.ingest needs); per-pixel order is untouched.  Streams
+    produced frame by frame by the transcoder do not need this: their frame offsets already are
+    such segments."""
+    ev = np.ascontiguousarray(events, dtype=N.EVENT_DTYPE)
+    c = np.where(ev["c"] == 0xFF, 0, ev["c"]).astype(np.int64)
+    key = (ev["y"].astype(np.int64) << 24) | (ev["x"].astype(np.int64) << 8) | c
+    offs = [0]
+    seen = {}
+    for i, k in enumerate(key.tolist()):
+        j = seen.get(k)
+        if j is not None and j >= offs[-1] and j != i - 1:
+            offs.append(i)  # the pixel already occurred in this segment, and not just before
+        seen[k] = i
+    offs.append(len(ev))
+    return np.array(offs, np.uint64)

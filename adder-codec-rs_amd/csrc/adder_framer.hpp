@@ -1,0 +1,68 @@
+// adder_framer.hpp -- per-pixel-channel step of the instantaneous framer (events -> u8 frames).
+//
+// One call = what ingest_event_for_chunk (adder-codec-rs/src/framer/driver.rs:984-1133) does to
+// the pixel's trackers for one event of that pixel: advance the pixel's clock, decide which
+// output frames the event covers, compute the intensity they get
+// (<u8 as FrameValue>::get_frame_value, Intensity arm, framer/scale_intensity.rs:54-72).
+// A pixel's frames are filled front to back, each exactly once, so the reference's
+// Option<u8> + filled_count bookkeeping reduces to `last_filled` per pixel: frame f holds a
+// value for the pixel iff last_filled >= f, and frame f is complete iff min over pixels of
+// last_filled >= f.  Compiled for the device and, by tests/cpu_sim, for the host.
+#pragma once
+#include <stdint.h>
+
+#include "adder_pixel.hpp"  // ADDER_HD, frame_value_u8
+
+namespace adder {
+
+struct FramerConsts {
+    uint32_t tpf;           // ticks per output frame (driver.rs:357-361)
+    uint32_t ref_interval;  // ticks per source frame; also the `tpf` argument of get_frame_value (:1034)
+    uint32_t abs_t;         // codec_version >= 2 && TimeMode::AbsoluteT (:1001, :1024-1030)
+    uint32_t round_up;      // codec_version >= 1 && framed source camera (:1093-1107)
+};
+
+struct FramerPx {
+    uint64_t ts;     // pixel_ts_tracker
+    int32_t lastf;   // last_filled_tracker (-1: none)
+    uint32_t lasti;  // last_frame_intensity_tracker
+};
+
+constexpr int32_t kFramerMaxFrame = 0x7ffffff0;
+
+// Returns true when frames (fill_from, fill_to] (absolute indices) take the value p.lasti.
+// `overflow` is raised when the frame index leaves the supported range.
+ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConsts &k, int32_t &fill_from,
+                          int32_t &fill_to, bool &overflow) {
+    const uint64_t prev_ts = p.ts;
+    bool fills = false;
+    if (k.abs_t) {
+        if (prev_ts >= (uint64_t)t) return false;  // an event from the pixel's past (:1002-1007)
+        p.ts = t;
+    } else {
+        p.ts = prev_ts + (uint64_t)t;
+    }
+    const uint64_t rm1 = p.ts ? p.ts - 1u : 0u;  // saturating_sub(1)
+    const uint64_t q = rm1 / (uint64_t)k.tpf;
+    if (q > (uint64_t)kFramerMaxFrame) {
+        overflow = true;
+    } else if ((int64_t)q > (int64_t)p.lastf) {
+        if (d != 255u) {  // D_EMPTY repeats the last intensity (:1017-1019)
+            uint32_t te = t;
+            if (k.abs_t) {
+                const uint32_t pr = (uint32_t)prev_ts;
+                te = t > pr ? t - pr : 0u;  // event.t.saturating_sub(prev_running_ts as u32)
+            }
+            p.lasti = frame_value_u8(d, te, (double)k.ref_interval);
+        }
+        fill_from = p.lastf;
+        fill_to = (int32_t)q;
+        p.lastf = (int32_t)q;
+        fills = true;
+    }
+    if (k.round_up && p.ts % (uint64_t)k.ref_interval > 0u)
+        p.ts = (p.ts / (uint64_t)k.ref_interval + 1u) * (uint64_t)k.ref_interval;
+    return fills;
+}
+
+}  // namespace adder

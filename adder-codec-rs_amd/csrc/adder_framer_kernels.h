@@ -1,0 +1,37 @@
+// adder_framer_kernels.h -- shared between the framer kernels and the framer C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "adder_framer.hpp"
+
+namespace adder {
+
+constexpr uint32_t kFramerStatusRing = 1u;       // an event reached past the frame ring
+constexpr uint32_t kFramerStatusMalformed = 2u;  // coordinates outside the plane / band
+constexpr uint32_t kFramerStatusRange = 4u;      // frame index out of range
+
+struct FramerArgs {
+    uint64_t *ts;        // [n_units]
+    int32_t *lastf;      // [n_units]
+    uint8_t *lasti;      // [n_units]
+    uint8_t *ring;       // [ring_frames][n_units]
+    uint32_t *status;
+    uint32_t n_units, width, channels, row_begin, rows;
+    uint32_t ring_frames;
+    int32_t frames_written;
+    FramerConsts k;
+};
+
+}  // namespace adder
+
+extern "C" {
+hipError_t adder_framer_launch_segment(const void *ev, uint64_t e0, uint64_t e1, const adder::FramerArgs *args,
+                                       hipStream_t s);
+hipError_t adder_framer_launch_minmax(const int32_t *lastf, uint32_t n, int32_t *out, hipStream_t s);
+hipError_t adder_framer_launch_pop(const uint8_t *ring, const int32_t *lastf, uint32_t n_units, uint32_t ring_frames,
+                                   int32_t f0, uint32_t nf, uint32_t masked, uint8_t *out, hipStream_t s);
+hipError_t adder_framer_launch_flush(uint8_t *ring, int32_t *lastf, const uint8_t *lasti, uint32_t n_units,
+                                     uint32_t ring_frames, int32_t f0, hipStream_t s);
+hipError_t adder_framer_launch_init(uint64_t *ts, int32_t *lastf, uint8_t *lasti, uint32_t n, hipStream_t s);
+}

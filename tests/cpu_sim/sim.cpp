@@ -182,3 +182,41 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     return rc;
 }
 }
+
+// ------------------------------------------------------------------------------------------
+// Host run of the framer's device step (csrc/adder_framer.hpp): the events are applied in
+// stream order with framer_step, frames are kept as a plain [frames][units] array and the
+// complete ones are min(last_filled) + 1 -- the formulation the GPU framer uses.  Compared
+// with the framer oracle (a literal restatement of the reference's deque machinery) on CPU.
+// ------------------------------------------------------------------------------------------
+#include "adder_framer.hpp"
+#include <vector>
+
+extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, uint32_t height, uint32_t channels,
+                                  uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
+                                  uint8_t *out, size_t out_cap_frames) {
+    using namespace adder;
+    const size_t units = (size_t)width * height * channels;
+    std::vector<FramerPx> px(units);
+    for (auto &p : px) { p.ts = 0; p.lastf = -1; p.lasti = 0; }
+    std::vector<uint8_t> frames;
+    FramerConsts k{tpf, ref_interval, abs_t, round_up};
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t c = ev[i].c == 0xFF ? 0u : ev[i].c;
+        if (ev[i].x >= width || ev[i].y >= height || c >= channels) return -1;
+        const size_t u = ((size_t)ev[i].y * width + ev[i].x) * channels + c;
+        int32_t from = 0, to = 0;
+        bool overflow = false;
+        if (framer_step(px[u], ev[i].d, ev[i].t, k, from, to, overflow)) {
+            if ((size_t)(to + 1) * units > frames.size()) frames.resize((size_t)(to + 1) * units, 0);
+            for (int32_t f = from + 1; f <= to; ++f) frames[(size_t)f * units + u] = (uint8_t)px[u].lasti;
+        }
+        if (overflow) return -2;
+    }
+    int32_t mn = 0x7fffffff;
+    for (auto &p : px) mn = p.lastf < mn ? p.lastf : mn;
+    const int64_t complete = (int64_t)mn + 1;
+    if (complete > (int64_t)out_cap_frames) return -3;
+    if (complete > 0) memcpy(out, frames.data(), (size_t)complete * units);
+    return complete;
+}

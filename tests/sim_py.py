@@ -22,7 +22,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_HDR))
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_HDR),
+                 os.path.getmtime(os.path.join(os.path.dirname(_HDR), "adder_framer.hpp")))
     if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
         subprocess.check_call([
             "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wextra",
@@ -46,8 +47,21 @@ def lib():
     L.sim_generic_steps.argtypes = [vp]
     L.sim_integrate.restype = i32
     L.sim_integrate.argtypes = [vp, vp, f32, vp, sz, C.POINTER(sz)]
+    L.sim_framer_run.restype = C.c_int64
+    L.sim_framer_run.argtypes = [vp, sz, u32, u32, u32, u32, u32, u32, u32, vp, sz]
     _lib = L
     return L
+
+
+def framer_run(events, width, height, channels, *, tpf, ref_interval, abs_t, round_up, max_frames=4096):
+    """All events through the device header's framer_step on the host -> bytes of the complete frames."""
+    ev = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+    out = np.zeros(max_frames * width * height * channels, np.uint8)
+    n = lib().sim_framer_run(ev.ctypes.data, len(ev), width, height, channels, tpf, ref_interval, int(abs_t),
+                             int(round_up), out.ctypes.data, max_frames)
+    if n < 0:
+        raise RuntimeError(f"sim_framer_run failed: {n}")
+    return out[: n * width * height * channels].tobytes()
 
 
 class Sim:

@@ -1,5 +1,5 @@
 """CPU-side checks of the boundary: the shared library loads, exports every symbol that
-include/adder_hip.h declares, refuses to run without a GPU (no silent fallback), and its
+include/*.h declare, refuses to run without a GPU (no silent fallback), and its
 raw sink reproduces the reference's container known answers."""
 import os
 import re
@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "adder_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(adder_(?:hip|raw)_\w+)\s*\(", hdr)))
+    names = set()
+    for h in ("adder_hip.h", "adder_framer.h"):
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names |= set(re.findall(r"\b(adder_(?:hip|raw|framer)_\w+)\s*\(", hdr))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

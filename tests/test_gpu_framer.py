@@ -1,0 +1,166 @@
+"""GPU framer (include/adder_framer.h) vs the framer oracle and the reference's golden frames.
+Calls go through the C-ABI (adder_amd.HipFramer is ctypes plumbing)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import adder_stream_np as S
+import clips
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    import adder_amd
+    return adder_amd
+
+
+@pytest.fixture(scope="module")
+def golden_dir():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_get_frame_bytes_u8_and_empty_frame():
+    """integration_tests.rs:555-611 and 782-820 through the HIP framer."""
+    A = _hip()
+    kw = dict(tps=50000, ref_interval=1000, delta_t_max=1000, output_fps=50.0, codec_version=1,
+              time_mode=A.TIME_DELTA_T, source_camera=A.FRAMED_U8)
+    fr = A.HipFramer(5, 5, 1, **kw)
+    assert fr.tpf == 1000
+    ev = np.zeros(25, A.EVENT_DTYPE)
+    k = 0
+    for i in range(5):
+        for j in range(5):
+            ev[k] = (i, j, 0xFF, 5, 0, 5100)
+            k += 1
+    fr.ingest(ev[:24])
+    assert fr.frames_ready() == 0
+    fr.ingest(ev[24:])
+    assert fr.frames_ready() == 6
+    out = fr.pop()
+    assert len(out) == 150 and set(out) == {6}
+    assert fr.frames_written == 6
+
+    fr2 = A.HipFramer(5, 5, 1, **kw)
+    assert fr2.write_frame_bytes() == bytes(25)
+    e = np.zeros(1, A.EVENT_DTYPE)
+    e[0] = (0, 0, 0xFF, 5, 0, 500)
+    fr2.ingest(e)
+    assert fr2.frames_ready() == 0
+
+
+@pytest.mark.parametrize("name", ["sample_3_ordered.adder", "sample_3_unordered.adder"])
+def test_sample_3(golden_dir, name):
+    """The reference's 405-frame vector; the unordered stream goes through contiguous_run_segments."""
+    A = _hip()
+    meta, events, _ = S.read_adder(open(os.path.join(golden_dir, name), "rb").read())
+    want = open(os.path.join(golden_dir, "sample_3.gray"), "rb").read()
+    fr = A.HipFramer(meta["width"], meta["height"], 1, tps=meta["tps"], ref_interval=meta["ref_interval"],
+                     delta_t_max=meta["delta_t_max"], output_fps=60.0, codec_version=meta["version"],
+                     time_mode=A.TIME_DELTA_T, source_camera=meta["source_camera"])
+    segs = A.contiguous_run_segments(events)
+    got = b""
+    for a in range(0, len(segs) - 1, 50):  # several ingest calls, popping in between
+        fr.ingest(events, segs[a:a + 51])
+        got += fr.pop()
+    assert got == want
+
+
+def test_dark_lake(golden_dir):
+    """adder_simulproc.rs:170-268: golden events -> the golden reconstructed frames."""
+    A = _hip()
+    raw = gzip.open(os.path.join(golden_dir, "lake_scaled_hd_out.adder.gz")).read()
+    want = gzip.open(os.path.join(golden_dir, "lake_scaled_out.gz")).read()
+    meta, events, _ = S.read_adder(raw)
+    fps = float(np.float32(24000.0 / 1001.0))
+    fr = A.HipFramer(200, 50, 1, tps=meta["tps"], ref_interval=255, delta_t_max=meta["delta_t_max"], output_fps=fps,
+                     codec_version=1, time_mode=A.TIME_ABSOLUTE_T, source_camera=A.FRAMED_U8)
+    assert fr.tpf == 254
+    key = events["y"].astype(np.int64) * 200 + events["x"]
+    starts = np.concatenate([[0], np.nonzero(np.diff(key) < 0)[0] + 1, [len(events)]]).astype(np.uint64)
+    got = b""
+    for a in range(0, len(starts) - 1, 16):  # 16 source frames per call, complete frames popped in between
+        fr.ingest(events, starts[a:a + 17])
+        got += fr.pop()
+    assert len(got) >= len(want) and got[: len(want)] == want
+
+
+@pytest.mark.parametrize("time_mode,multi_mode,dtm,channels", [
+    (O.DELTA_T, O.COLLAPSE, 255, 1), (O.ABSOLUTE_T, O.COLLAPSE, 2550, 1), (O.DELTA_T, O.NORMAL, 1020, 3),
+    (O.ABSOLUTE_T, O.NORMAL, 7650, 1), (O.ABSOLUTE_T, O.COLLAPSE, 7650, 3)])
+def test_transcode_then_frame_on_device(time_mode, multi_mode, dtm, channels):
+    """HipVideo events stay in HBM and feed HipFramer (frame_offsets = segments); the frames equal
+    the framer oracle fed with the transcode oracle's events.  Includes flush + forced pops."""
+    import torch
+    A = _hip()
+    W, H, T = 37, 23, 48
+    clip = clips.make_clip("runs", T, H, W, channels, seed=9)
+    ov = O.Video(W, H, channels, time_mode=time_mode, multi_mode=multi_mode, delta_t_max=dtm)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    ov.ensure_capacity(24)
+    ofr = O.Framer(W, H, channels, chunk_rows=64, tps=255 * 30, ref_interval=255, delta_t_max=dtm, output_fps=30.0,
+                   codec_version=3, time_mode=time_mode, source_camera=O.FRAMED_U8)
+    want = b""
+    for k in range(T):
+        want += ofr.ingest_events(ov.integrate_matrix(clip[k]))
+
+    hv = A.HipVideo(W, H, channels, time_mode=time_mode, multi_mode=multi_mode, delta_t_max=dtm,
+                    c_thresh_start=0, c_counter_start=0, max_depth=20)
+    hv.set_crf_parameters(0, 10)
+    fr = A.HipFramer(W, H, channels, tps=255 * 30, ref_interval=255, delta_t_max=dtm, output_fps=30.0,
+                     codec_version=3, time_mode=time_mode, source_camera=A.FRAMED_U8,
+                     # Collapse + DeltaT: the D_EMPTY filler events carry the ABSOLUTE running time
+                     # (event_pixel_tree.rs:259-263), which the framer adds to the pixel's clock as if it
+                     # were a delta, so those pixels run far ahead: the reference grows its frame deque,
+                     # here the ring has to be large enough
+                     ring_frames=4096)
+    st = torch.cuda.current_stream().cuda_stream
+    n_units = W * H * channels
+    got = b""
+    for k0 in range(0, T, 16):
+        d_frames = torch.from_numpy(clip[k0:k0 + 16].reshape(16, n_units)).cuda()
+        d_ev = torch.empty((n_units * 16 * 4, 3), dtype=torch.int32, device="cuda")
+        d_off = torch.zeros(17, dtype=torch.int64, device="cuda")
+        hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+        hv.finish()
+        fr.ingest_device(d_ev, d_off.cpu().numpy().astype(np.uint64), stream=st)
+        n = fr.frames_ready()
+        d_out = torch.empty((max(n, 1), n_units), dtype=torch.uint8, device="cuda")
+        m = fr.pop_device(d_out, n, stream=st)
+        torch.cuda.synchronize()
+        assert m == n
+        got += d_out[:m].cpu().numpy().tobytes()
+    assert got == want  # (may be empty in Collapse mode: a silent pixel holds every frame back)
+
+    # end of stream: flush_frame_buffer + write_frame_bytes, as a player does (driver.rs:632-677)
+    for _ in range(3):
+        a, b = ofr.flush_frame_buffer(), fr.flush_frame_buffer()
+        assert a == b
+        assert ofr.write_frame_bytes() == fr.write_frame_bytes()
+        assert ofr.frames_written == fr.frames_written
+
+
+def test_ring_overflow_is_reported():
+    A = _hip()
+    fr = A.HipFramer(4, 4, 1, tps=7650, ref_interval=255, delta_t_max=7650, output_fps=30.0, ring_frames=8)
+    e = np.zeros(1, A.EVENT_DTYPE)
+    e[0] = (1, 1, 0xFF, 3, 0, 255 * 20)  # covers 20 frames, the ring holds 8
+    with pytest.raises(A.AdderHipError) as ei:
+        fr.ingest(e)
+    assert ei.value.code == -4
+    with pytest.raises(A.AdderHipError):
+        fr.frames_ready()  # poisoned
+
+
+def test_malformed_event_is_reported():
+    A = _hip()
+    fr = A.HipFramer(4, 4, 1, tps=7650, ref_interval=255, delta_t_max=7650)
+    e = np.zeros(1, A.EVENT_DTYPE)
+    e[0] = (9, 1, 0xFF, 3, 0, 255)
+    with pytest.raises(A.AdderHipError) as ei:
+        fr.ingest(e)
+    assert ei.value.code == -1
