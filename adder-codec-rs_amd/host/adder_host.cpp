@@ -387,3 +387,129 @@ double Framed::get_running_input_bitrate() const {
 }
 
 }  // namespace adder_host
+
+// ================================================================ framer (framer/driver.rs)
+namespace adder_host {
+
+std::unique_ptr<FrameSequenceU8> FramerBuilder::finish() { return std::make_unique<FrameSequenceU8>(*this); }
+
+FrameSequenceU8::FrameSequenceU8(const FramerBuilder &b) : chunk_rows(b.chunk_rows_) {
+    if (b.chunk_rows_ == 0) throw SourceError(SourceError::BadParams, "chunk_rows must be > 0");  // assert (:306)
+    if (b.mode_ != FramerMode::INSTANTANEOUS)
+        throw SourceError(SourceError::BadParams, "only FramerMode::INSTANTANEOUS is built");
+    AdderFramerParams p;
+    adder_framer_default_params(&p, b.plane_.w(), b.plane_.h(), b.plane_.c());
+    p.codec_version = b.codec_version_;
+    p.time_mode = (uint8_t)b.time_mode_;
+    p.tps = b.tps_;
+    p.ref_interval = b.ref_interval_;
+    p.delta_t_max = b.delta_t_max_;
+    p.output_fps = b.output_fps_ ? *b.output_fps_ : 0.0f;
+    p.source_camera = (uint32_t)b.source_camera_;
+    p.device_id = b.device_id_ < 0 ? 0 : b.device_id_;
+    if (adder_framer_create(&p, &fr_) != ADDER_OK)
+        throw SourceError(SourceError::BadParams, std::string("framer: ") + adder_framer_last_error(nullptr));
+    num_chunks_ = (b.plane_.h() + b.chunk_rows_ - 1) / b.chunk_rows_;
+    frame_bytes_ = (size_t)b.plane_.w() * b.plane_.h() * b.plane_.c();
+}
+
+FrameSequenceU8::~FrameSequenceU8() { adder_framer_destroy(fr_); }
+uint32_t FrameSequenceU8::tpf() const { return adder_framer_tpf(fr_); }
+int64_t FrameSequenceU8::frames_written() const { return adder_framer_frames_written(fr_); }
+
+static void framer_check(AdderFramer *fr, int rc) {
+    if (rc != ADDER_OK) throw SourceError(SourceError::BadParams, std::string("framer: ") + adder_framer_last_error(fr));
+}
+
+bool FrameSequenceU8::is_frame_0_filled() {
+    uint32_t n = 0;
+    framer_check(fr_, adder_framer_frames_ready(fr_, &n));
+    return n > 0;
+}
+
+bool FrameSequenceU8::ingest_event(Event &event) {
+    const uint64_t offs[2] = {0, 1};
+    framer_check(fr_, adder_framer_ingest(fr_, &event, offs, 1));
+    return is_frame_0_filled();
+}
+
+bool FrameSequenceU8::ingest_events_events(const std::vector<std::vector<Event>> &events) {
+    // "Make sure that the chunk division is aligned between the source and the framer" (:566)
+    if (events.size() != num_chunks_) throw SourceError(SourceError::BadParams, "events.len() != number of framer chunks");
+    flat_.clear();
+    for (const auto &v : events) flat_.insert(flat_.end(), v.begin(), v.end());
+    // one source frame's events: raster order, every pixel's events contiguous = one segment
+    const uint64_t offs[2] = {0, flat_.size()};
+    framer_check(fr_, adder_framer_ingest(fr_, flat_.data(), offs, 1));
+    return is_frame_0_filled();
+}
+
+bool FrameSequenceU8::flush_frame_buffer() {
+    int ready = 0;
+    framer_check(fr_, adder_framer_flush(fr_, &ready));
+    return ready != 0;
+}
+
+void FrameSequenceU8::write_frame_bytes(std::ostream &writer) {
+    out_.resize(frame_bytes_);
+    framer_check(fr_, adder_framer_write_frame(fr_, out_.data()));
+    writer.write(reinterpret_cast<const char *>(out_.data()), (std::streamsize)frame_bytes_);
+}
+
+int FrameSequenceU8::write_multi_frame_bytes(std::ostream &writer) {
+    int frames = 0;
+    for (;;) {
+        out_.resize(frame_bytes_ * 64);
+        uint32_t n = 0;
+        framer_check(fr_, adder_framer_pop(fr_, out_.data(), 64, &n));
+        if (!n) break;
+        writer.write(reinterpret_cast<const char *>(out_.data()), (std::streamsize)(frame_bytes_ * n));
+        frames += (int)n;
+        if (n < 64) break;
+    }
+    return frames;
+}
+
+// ---------------------------------------------------------------- SimulProcessor (utils/simulproc.rs)
+SimulProcessor::SimulProcessor(Framed &source, uint32_t ref_time, std::ostream &frames_out, int32_t frame_max,
+                               uint8_t codec_version, TimeMode time_mode, int device_id)
+    : source_(source), out_(frames_out), frame_max_(frame_max) {
+    const float reconstructed_frame_rate = source.source_fps;
+    // "For instantaneous reconstruction, make sure the frame rate matches the source video rate" (:146-150)
+    if (source.get_video_ref().get_tps() / ref_time != (uint32_t)reconstructed_frame_rate)
+        throw SourceError(SourceError::BadParams, "tps / ref_time does not match the source frame rate");
+    const Video &v = source.get_video_ref();
+    framer_ = FramerBuilder(v.plane(), v.get_chunk_rows())
+                  .codec_version(codec_version, time_mode)
+                  .time_parameters(v.get_tps(), ref_time, v.get_delta_t_max(), reconstructed_frame_rate)
+                  .mode(FramerMode::INSTANTANEOUS)
+                  .source(SourceType::U8, SourceCamera::FramedU8)
+                  .device(device_id)
+                  .finish();
+}
+
+void SimulProcessor::run(uint32_t frame_max) {
+    int frame_count = 1;  // :174
+    bool framing = true;
+    uint32_t consumed = 0;
+    for (;;) {
+        std::vector<std::vector<Event>> events;
+        try {
+            events = source_.consume();
+        } catch (const SourceError &) {
+            break;  // Err(e) => break (:246-249)
+        }
+        ++consumed;
+        if (framing && framer_->ingest_events_events(events)) {
+            const int n = framer_->write_multi_frame_bytes(out_);
+            frame_count += n;
+            frames_written += n;
+            if (frame_count >= frame_max_ && frame_max_ > 0) framing = false;  // "Wrote max frames" (:208-211)
+        }
+        if (frame_max > 0 && consumed >= frame_max) break;  // :264-267
+    }
+    out_.flush();
+    source_.get_video_mut().end_write_stream();
+}
+
+}  // namespace adder_host

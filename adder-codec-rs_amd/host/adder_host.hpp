@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/adder_framer.h"
 #include "../../include/adder_hip.h"
 
 namespace adder_host {
@@ -164,6 +165,7 @@ class Video {
     uint32_t get_tps() const { return tps_; }
     uint32_t get_ref_time() const { return ref_time_; }
     uint32_t get_delta_t_max() const { return delta_t_max_; }
+    size_t get_chunk_rows() const { return chunk_rows_; }  // VideoState::chunk_rows
     PlaneSize plane() const { return plane_; }
 
     // :651-778 -- one frame in; Vec<Vec<Event>> out (one vector per row chunk, raster order);
@@ -244,6 +246,81 @@ class Framed : public Source {  // framed.rs:22-39
     Frame input_frame_;
     bool color_input_;
     Video video_;
+};
+
+// ---------------------------------------------------------------- framer (framer/driver.rs)
+enum class FramerMode { INSTANTANEOUS, INTEGRATION };  // driver.rs:20-28; only INSTANTANEOUS is built
+enum class SourceType { U8 };                          // lib.rs; only U8 is built
+
+class FrameSequenceU8;
+
+class FramerBuilder {  // driver.rs:36-147
+  public:
+    FramerBuilder(PlaneSize plane, size_t chunk_rows) : plane_(plane), chunk_rows_(chunk_rows) {}  // :57-75
+    FramerBuilder &time_parameters(uint32_t tps, uint32_t ref_interval, uint32_t delta_t_max,
+                                   std::optional<float> output_fps) {  // :77-90
+        tps_ = tps; ref_interval_ = ref_interval; delta_t_max_ = delta_t_max; output_fps_ = output_fps;
+        return *this;
+    }
+    FramerBuilder &mode(FramerMode m) { mode_ = m; return *this; }                                   // :98-102
+    FramerBuilder &source(SourceType, SourceCamera cam) { source_camera_ = cam; return *this; }     // :110-115
+    FramerBuilder &codec_version(uint8_t v, TimeMode tm) { codec_version_ = v; time_mode_ = tm; return *this; }  // :117-124
+    FramerBuilder &device(int device_id) { device_id_ = device_id; return *this; }
+    std::unique_ptr<FrameSequenceU8> finish();  // :126-138, T = u8
+
+  private:
+    friend class FrameSequenceU8;
+    PlaneSize plane_;
+    size_t chunk_rows_;
+    uint32_t tps_ = 150000, ref_interval_ = 5000, delta_t_max_ = 5000;  // FramerBuilder::new defaults (:60-65)
+    std::optional<float> output_fps_;
+    FramerMode mode_ = FramerMode::INSTANTANEOUS;
+    SourceCamera source_camera_ = SourceCamera::FramedU8;
+    uint8_t codec_version_ = 3;
+    TimeMode time_mode_ = TimeMode::AbsoluteT;
+    int device_id_ = -1;
+};
+
+// FrameSequence<u8> (driver.rs:261-981); the per-pixel work runs behind include/adder_framer.h
+class FrameSequenceU8 {
+  public:
+    explicit FrameSequenceU8(const FramerBuilder &b);
+    ~FrameSequenceU8();
+    FrameSequenceU8(const FrameSequenceU8 &) = delete;
+    FrameSequenceU8 &operator=(const FrameSequenceU8 &) = delete;
+    bool ingest_event(Event &event);                                          // :437-562 -> frame 0 filled?
+    bool ingest_events_events(const std::vector<std::vector<Event>> &events); // :564-626
+    bool flush_frame_buffer();                                                // :632-677
+    bool is_frame_0_filled();                                                 // :828-843
+    void write_frame_bytes(std::ostream &writer);                             // :935-962
+    int write_multi_frame_bytes(std::ostream &writer);                        // :970-981
+    uint32_t tpf() const;
+    int64_t frames_written() const;
+    size_t chunk_rows;
+
+  private:
+    AdderFramer *fr_ = nullptr;
+    size_t num_chunks_ = 0, frame_bytes_ = 0;
+    std::vector<Event> flat_;
+    std::vector<uint8_t> out_;
+};
+
+// utils/simulproc.rs:33-277 -- transcode a framed source and reconstruct frames from the events
+// at the same time.  The reference runs the framer on a second thread behind a channel; the
+// order of operations per source frame is the same here (consume -> ingest_events_events ->
+// write_multi_frame_bytes).
+class SimulProcessor {
+  public:
+    SimulProcessor(Framed &source, uint32_t ref_time, std::ostream &frames_out, int32_t frame_max,
+                   uint8_t codec_version, TimeMode time_mode, int device_id = -1);  // ::new :113-206
+    void run(uint32_t frame_max);                                                    // :233-277
+    int frames_written = 0;
+
+  private:
+    Framed &source_;
+    std::ostream &out_;
+    int32_t frame_max_;
+    std::unique_ptr<FrameSequenceU8> framer_;
 };
 
 // utils/cv.rs:215-232

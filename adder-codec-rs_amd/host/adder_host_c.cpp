@@ -65,6 +65,51 @@ long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, u
     }
 }
 
+// The reference's `dark` test end to end (src/bin/adder_simulproc.rs:170-268): Framed(gray) ->
+// crf(0) -> frame_start -> time_parameters((ref_time * fps) as u32, ref_time, dtm, None) ->
+// write_out(FramedU8, time_mode, multi_mode, None, Raw, {crf: Crf::new(Some(0))}) ->
+// SimulProcessor::new::<u8>(source, ref_time, frames path, frame_count_max, 1, 1, TimeMode::default())
+// -> run(0).  Writes the event file and the reconstructed frames; returns the frames written, or -1.
+long long adder_host_simulproc(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height, float fps,
+                               int crf, uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
+                               uint32_t chunk_rows, int32_t frame_count_max, uint8_t framer_codec_version,
+                               int framer_time_mode, const char *out_events_path, const char *out_frames_path) {
+    try {
+        FrameProvider cap;
+        cap.width = width;
+        cap.height = height;
+        cap.channels = 1;
+        cap.frame_rate = fps;
+        cap.frame_count = num_frames;
+        const size_t fsz = (size_t)width * height;
+        cap.decode = [=](uint64_t idx, Frame &out) {
+            if (idx >= num_frames) return false;
+            out.assign(frames + idx * fsz, frames + (idx + 1) * fsz);
+            return true;
+        };
+        Framed source(cap, false);
+        source.chunk_rows(chunk_rows ? chunk_rows : 1);
+        source.crf_builder((uint8_t)crf);
+        source.time_parameters((uint32_t)((double)ref_time * (double)source.source_fps), ref_time, delta_t_max,
+                               std::nullopt);
+        std::ofstream ev_file(out_events_path, std::ios::binary);
+        std::ofstream fr_file(out_frames_path, std::ios::binary);
+        if (!ev_file || !fr_file) throw SourceError(SourceError::BadParams, "cannot open output file");
+        const PlaneSize plane = source.get_video_ref().plane();
+        EncoderOptions opts = EncoderOptions::default_(plane);
+        opts.crf = Crf((uint8_t)crf, plane);
+        source.write_out(SourceCamera::FramedU8, (TimeMode)time_mode, (PixelMultiMode)multi_mode, std::nullopt,
+                         EncoderType::Raw, opts, &ev_file);
+        SimulProcessor proc(source, source.get_ref_time(), fr_file, frame_count_max, framer_codec_version,
+                            (TimeMode)framer_time_mode);
+        proc.run(0);
+        return proc.frames_written;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Decoder over a raw stream in memory: fills meta[10] = {version, width, height, channels, tps,
 // ref_interval, delta_t_max, event_size, source_camera|time_mode<<8, adu_interval} and up to cap
 // events; returns the number of events in the stream, or -1.

@@ -29,6 +29,10 @@ def lib():
         L.adder_host_encode_raw.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_int,
                                             C.c_void_p, C.c_size_t]
+        L.adder_host_simulproc.restype = C.c_longlong
+        L.adder_host_simulproc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_uint32,
+                                           C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int32, C.c_uint8, C.c_int,
+                                           C.c_char_p, C.c_char_p]
         _lib = L
     return _lib
 
@@ -73,3 +77,15 @@ def transcode_raw(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, 
     if n < 0:
         raise RuntimeError(err())
     return n, chunks.value
+
+
+def simulproc(frames, *, fps, crf, ref_time, delta_t_max, time_mode, multi_mode, chunk_rows=1, frame_count_max=0,
+              framer_codec_version=1, framer_time_mode=1, out_events, out_frames):
+    """SimulProcessor::new::<u8> + run over gray frames [T][H][W] (the reference's `dark` test)."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    T, H, W = frames.shape[:3]
+    n = lib().adder_host_simulproc(frames.ctypes.data, T, W, H, fps, crf, ref_time, delta_t_max, time_mode,
+                                   multi_mode, chunk_rows, frame_count_max, framer_codec_version, framer_time_mode,
+                                   out_events.encode(), out_frames.encode())
+    assert n >= 0, err()
+    return n
