@@ -5,7 +5,10 @@ with feature detection off, pixels never interact (integrate_for_px touches only
 video.rs:1318-1380).  So each rank owns a contiguous band of rows for the whole clip
 and NO collective is needed while integrating.  The only exchange is the one that
 concatenates the emitted events before the (unchanged, serial) sink: per frame the
-segments must appear in rank order, which is raster order.
+segments must appear in rank order, which is raster order.  Two forms:
+exchange_stream_layout() all-gathers the per-frame counts only (the payload stays sharded
+and each rank delivers its segments to their final position itself -- the default of
+bench.py), gather_event_stream() also funnels the payload to one rank over xGMI.
 
 Works on CUDA tensors over RCCL (backend "nccl") and on CPU tensors over gloo (tests).
 """
@@ -48,6 +51,39 @@ def merge_frame_major(segments):
         dest = torch.arange(n, device=dev) + shift[frame_id]
         out[dest] = ev
     return out, frame_base
+
+
+def exchange_stream_layout(offsets, group=None):
+    """The exchange that DEFINES the ordered concatenation without moving the payload: an all-gather of
+    every rank's frame offsets (T+1 int64 each).  Returns (frame_base [T+1], my_base [T]): the merged
+    stream's frame offsets, and for each frame the position of this rank's segment inside the merged
+    stream (= frame_base[f] + events of lower ranks in frame f).  A consumer that copies rank r's
+    segment of frame f to my_base_r[f] -- e.g. every rank's own D2H into one pinned host buffer, 8 PCIe
+    links instead of one xGMI funnel -- obtains exactly the single-context stream."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    offsets = offsets.contiguous()
+    if world == 1:
+        return offsets.clone(), offsets[:-1].clone()
+    all_offs = [torch.empty_like(offsets) for _ in range(world)]
+    dist.all_gather(all_offs, offsets, group=group)
+    counts = torch.stack([o[1:] - o[:-1] for o in all_offs])  # [R, T]
+    frame_base = torch.zeros_like(offsets)
+    frame_base[1:] = torch.cumsum(counts.sum(0), 0)
+    before = torch.cumsum(counts, 0) - counts
+    return frame_base, frame_base[:-1] + before[rank]
+
+
+def place_segments(out, events, offsets, my_base):
+    """Copies this rank's per-frame segments to their place in the merged stream `out` ([N, 3] int32 or
+    any row-indexable buffer).  Reference implementation of the consumer side (tests / host sink)."""
+    T = offsets.numel() - 1
+    for f in range(T):
+        a, b = int(offsets[f]), int(offsets[f + 1])
+        if b > a:
+            d = int(my_base[f])
+            out[d:d + (b - a)] = events[a:b]
+    return out
 
 
 def gather_event_stream(events, offsets, dst=0, group=None):

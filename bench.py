@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--channels", type=int, default=C)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-payload", action="store_true",
+                    help="N>1: also funnel every rank's events to rank 0 over RCCL inside the timed step "
+                         "(default: all-gather of the per-frame counts only; the payload stays sharded)")
     ap.add_argument("--skip-roofline", action="store_true",
                     help="no per-launch timing passes (used under rocprofv3 --pmc so that only default-depth launches are counted)")
     args = ap.parse_args()
@@ -61,11 +64,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Debug hook for boxes with ONE GPU: ADDER_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 and does the
+    # (tiny) layout exchange over gloo on host copies -- RCCL refuses two ranks on one device.  Never set
+    # by the driver; it only lets the N>1 code path be exercised where a single GPU is available.
+    share = os.environ.get("ADDER_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import adder_amd as A
     from adder_amd import sharding
@@ -100,7 +112,12 @@ def main():
         n = hv.finish()
         merged = None
         if world > 1:
-            merged = sharding.gather_event_stream(d_events[:n], d_offsets, dst=0)
+            if args.gather_payload:
+                merged = sharding.gather_event_stream(d_events[:n], d_offsets, dst=0)
+            else:
+                # the ordered concatenation is fixed by this exchange; rank r's segment of frame f
+                # belongs at my_base[f] of the merged stream
+                merged = sharding.exchange_stream_layout(d_offsets.cpu() if share else d_offsets)
         return n, merged
 
     def barrier():
@@ -121,14 +138,18 @@ def main():
 
     total_events = n_events
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if share else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        te = torch.tensor([n_events], dtype=torch.int64, device=dev)
+        te = torch.tensor([n_events], dtype=torch.int64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.SUM)
         total_events = int(te.item())
-        if rank == 0:
-            assert merged is not None and merged[0].shape[0] == total_events
+        if args.gather_payload:
+            if rank == 0:
+                assert merged is not None and merged[0].shape[0] == total_events
+        else:
+            assert int(merged[0][-1]) == total_events  # every rank knows the merged stream's layout
 
     # ---- roofline of the dominant kernel: one extra step with an event pair per launch ----
     launch_us, launch_frames, launch1_us = 0.0, 1.0, 0.0
@@ -192,7 +213,10 @@ def main():
             "plane": [W, H_total, Cn],
             "rows_per_gpu": H_BAND,
             "frames_per_step": T,
-            "sharding": "row bands, ordered RCCL gather of events to rank 0" if world > 1 else "single GPU",
+            "sharding": ("single GPU" if world == 1 else
+                         "row bands; ordered RCCL gather of the event payload to rank 0" if args.gather_payload else
+                         "row bands; RCCL all-gather of per-frame event counts fixes the ordered concatenation, "
+                         "the event payload stays sharded in HBM (each rank delivers its segments itself)"),
         },
         "events_per_s": round(total_events / (elapsed / args.steps), 1),
         "events_per_pixel_frame": round(e, 5),

@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo run of the row-band sharding + ordered event gather.
+"""N>1 path on CPU: world_size-2 gloo run of the row-band sharding, the layout exchange (per-frame
+counts only, each rank places its own segments) and the ordered event gather.
 Each rank integrates its band (the oracle stands in for the per-rank integrator here --
 the HIP integrator needs a GPU) and rank 0 must end up with exactly the stream a single
 context over the whole plane produces."""
@@ -46,8 +47,14 @@ def _worker(rank, world, port, chunk_rows, q):
         offs = torch.tensor(np.concatenate([[0], np.cumsum([len(e) for e in per])]), dtype=torch.int64)
         ev = np.concatenate(per)
         ev_t = torch.from_numpy(np.frombuffer(ev.tobytes(), dtype=np.int32).reshape(-1, 3).copy())
+        # layout-only exchange: every rank learns where its segments go in the merged stream
+        frame_base, my_base = sharding.exchange_stream_layout(offs)
+        lay = [torch.empty_like(frame_base) for _ in range(world)]
+        dist.all_gather(lay, frame_base)  # every rank must have computed the same merged frame offsets
         merged = sharding.gather_event_stream(ev_t, offs, dst=0)
         if rank == 0:
+            ok_layout = frame_base.tolist() == merged[1].tolist()
+            q.put(("layout", bool(ok_layout), lay[0].tolist() == lay[1].tolist()))
             full = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=510)
             full.set_crf_parameters(0, 10)
             full.reset_c_thresh(0)
@@ -59,6 +66,16 @@ def _worker(rank, world, port, chunk_rows, q):
             q.put(bool(ok))
         else:
             assert merged is None
+        # every rank places its own segments into a buffer of the merged size; rank 0 checks the union
+        total = int(frame_base[-1])
+        mine = torch.zeros((total, 3), dtype=torch.int32)
+        mask = torch.zeros(total, dtype=torch.int32)
+        sharding.place_segments(mine, ev_t, offs, my_base)
+        sharding.place_segments(mask, torch.ones(ev_t.shape[0], dtype=torch.int32), offs, my_base)
+        dist.reduce(mine, 0)
+        dist.reduce(mask, 0)
+        if rank == 0:
+            q.put(("placed", bool((mask == 1).all()) and torch.equal(mine, merged[0])))
     finally:
         dist.destroy_process_group()
 
@@ -74,7 +91,8 @@ def test_two_rank_band_sharding_matches_single_stream(chunk_rows):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    got = [q.get(timeout=5) for _ in range(3)]
+    assert ("layout", True, True) in got and True in got and ("placed", True) in got
 
 
 def test_row_bands_cover_plane():
