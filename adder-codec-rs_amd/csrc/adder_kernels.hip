@@ -405,35 +405,38 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
 
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock);
 
-// K1.  The grid holds `step_blocks` workgroups that step frames [f, f + nb) (a wave per
-// segment) and, interleaved with them in dispatch order (exp_q expansion workgroups after
-// every step workgroup, the remainder at the end), the workgroups that expand frames
+// K1.  The grid holds the workgroups that step frames [f, f + nb) (a wave per segment) and,
+// interleaved with them in dispatch order (the scarcer kind spread evenly through the other,
+// see adder_launch_frame), the workgroups that expand frames
 // [exp_f0, exp_f0 + exp_nf) of the PREVIOUS chunk (already scanned).  The expansion is
 // memory-bound and the step VALU-bound, so sharing the SIMDs overlaps them; nothing in one
 // role waits for the other.
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
-    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb, uint32_t step_blocks, uint32_t exp_f0,
-    uint32_t exp_blocks_per_frame, uint32_t exp_q) {
+    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb, uint32_t exp_f0, uint32_t exp_blocks_per_frame,
+    uint32_t grp_steps, uint32_t grp_exps, uint32_t groups, uint32_t rem_is_step) {
+    // dispatch order: `groups` groups of (grp_steps step workgroups, grp_exps expansion workgroups),
+    // then whatever is left of either kind
     uint32_t bid = blockIdx.x;
     if (exp_blocks_per_frame != 0u) {
-        const uint32_t span = exp_q + 1u;
-        const uint32_t inter = step_blocks * span;
-        uint32_t e;
-        bool is_step = false;
+        const uint32_t span = grp_steps + grp_exps;
+        const uint32_t inter = groups * span;
+        bool is_step;
+        uint32_t idx;
         if (bid < inter) {
             const uint32_t g = bid / span, k = bid - g * span;
-            is_step = k == 0u;
-            bid = g;
-            e = g * exp_q + (k - 1u);
-        } else {
-            e = step_blocks * exp_q + (bid - inter);
+            is_step = k < grp_steps;
+            idx = is_step ? g * grp_steps + k : g * grp_exps + (k - grp_steps);
+        } else {  // only one kind has a remainder (see adder_launch_frame)
+            is_step = rem_is_step != 0u;
+            idx = (is_step ? groups * grp_steps : groups * grp_exps) + (bid - inter);
         }
         if (!is_step) {
-            const uint32_t ef = e / exp_blocks_per_frame;
-            expand_block(b, exp_f0 + ef, e - ef * exp_blocks_per_frame);
+            const uint32_t ef = idx / exp_blocks_per_frame;
+            expand_block(b, exp_f0 + ef, idx - ef * exp_blocks_per_frame);
             return;
         }
+        bid = idx;
     }
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
@@ -746,7 +749,8 @@ __global__ __launch_bounds__(256) void adder_divtest_kernel(unsigned long long *
     if (f32_as_u32(fdiv_small(a, b)) != f32_as_u32(fdiv(a, b))) atomicAdd(bad, 1ull);
 }
 
-typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                              uint32_t);
 static FrameKernelFn pick_frame_kernel(uint32_t variant) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     if (collapse) {
@@ -763,12 +767,22 @@ extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
                                          uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
-    const uint32_t step_blocks = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;
     const uint32_t exp_bpf = exp_nf ? (num_waves + per_block - 1) / per_block : 0u;
-    const uint32_t exp_blocks = exp_bpf * exp_nf;
-    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(step_blocks + exp_blocks), dim3(kBlockThreads), 0, stream, b, f,
-                       nb, step_blocks, exp_f0, exp_bpf, exp_blocks / step_blocks);
+    const uint32_t E = exp_bpf * exp_nf;  // expansion workgroups
+    // spread the scarcer kind evenly through the dispatch order
+    uint32_t grp_steps = 1, grp_exps = 1, groups = 0, rem_is_step = 1;
+    if (E >= S) {
+        grp_exps = E / S;
+        groups = S;
+        rem_is_step = 0;
+    } else if (E) {
+        grp_steps = S / E;
+        groups = E;
+    }
+    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(S + E), dim3(kBlockThreads), 0, stream, b, f, nb, exp_f0, exp_bpf,
+                       grp_steps, grp_exps, groups, rem_is_step);
     return hipGetLastError();
 }
 
