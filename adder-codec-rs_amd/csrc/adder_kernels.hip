@@ -207,47 +207,61 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
 // is read from HBM once and written back once; per frame only the input bytes are loaded
 // (one frame ahead) and the segment's events are compacted into that frame's scratch slot.
 // nb > 1 is only used when no pixel can need the generic kernel.
+// A segment's state as loaded (one memory round trip, nothing consumed yet)
+struct RawSegment {
+    uint32_t hdrv[kUnitsPerLane];
+    float liv[kUnitsPerLane], ldv[kUnitsPerLane], lbv[kUnitsPerLane], lfv[kUnitsPerLane];
+    uint8_t bdv[kUnitsPerLane];
+    uint32_t vin_w;
+};
+
+// SPECULATE: level 0 is fetched together with the header word instead of after it (the
+// depth-1 kernels: one round trip instead of two; nearly every unit has a fired level)
+template <bool ABS_T, bool SPECULATE>
+__device__ __forceinline__ void load_raw(const FrameArgs &a, uint32_t u0, bool full, RawSegment &r) {
+    constexpr uint32_t N = kUnitsPerLane;
+    load_vec(a.hdr, u0, r.hdrv);
+    r.vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        r.liv[j] = r.ldv[j] = r.lbv[j] = r.lfv[j] = 0.0f;
+        r.bdv[j] = 0;
+    }
+    bool any = true;
+    if (!SPECULATE) {
+        uint32_t hor = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) hor |= r.hdrv[j];
+        any = (hor >> 24) & kFlagMMask;
+    }
+    if (any) {
+        load_vec(a.lv_integ, u0, r.liv);
+        load_vec(a.lv_dt, u0, r.ldv);
+        load_vec(a.lv_bdt, u0, r.lbv);
+        load_vec(a.lv_bd, u0, r.bdv);
+    }
+    if (ABS_T) load_vec(a.lastf, u0, r.lfv);
+}
+
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                            uint32_t u0, uint32_t gw, uint32_t lane) {
+                                            uint32_t u0, uint32_t gw, uint32_t lane, const RawSegment &raw) {
     constexpr uint32_t N = kUnitsPerLane;
     // whole wave inside the band: the common case takes the unguarded vector input load
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     FastPx px[N];
-    uint32_t vin_w;
-    {
-        uint32_t hdrv[N];
-        load_vec(a.hdr, u0, hdrv);
-        vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
-        uint32_t hor = 0u;
+    uint32_t vin_w = raw.vin_w;
 #pragma unroll
-        for (uint32_t j = 0; j < N; ++j) hor |= hdrv[j];
-        float liv[N], ldv[N], lbv[N], lfv[N];
-        uint8_t bdv[N];
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            liv[j] = ldv[j] = lbv[j] = lfv[j] = 0.0f;
-            bdv[j] = 0;
-        }
-        if ((hor >> 24) & kFlagMMask) {
-            load_vec(a.lv_integ, u0, liv);
-            load_vec(a.lv_dt, u0, ldv);
-            load_vec(a.lv_bdt, u0, lbv);
-            load_vec(a.lv_bd, u0, bdv);
-        }
-        if (ABS_T) load_vec(a.lastf, u0, lfv);
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            PxState st;
-            st.hdr = hdrv[j];
-            st.n0.integ = liv[j];
-            st.n0.dt = ldv[j];
-            st.n0.bdt = lbv[j];
-            st.n0.bd = bdv[j];
-            st.lastf = lfv[j];
-            px[j] = unpack_px(st);
-            if (GENERIC) px[j].has0 = (hdrv[j] >> 24) & kFlagMMask;  // keep the full m for the generic test
-        }
+    for (uint32_t j = 0; j < N; ++j) {
+        PxState st;
+        st.hdr = raw.hdrv[j];
+        st.n0.integ = raw.liv[j];
+        st.n0.dt = raw.ldv[j];
+        st.n0.bdt = raw.lbv[j];
+        st.n0.bd = raw.bdv[j];
+        st.lastf = raw.lfv[j];
+        px[j] = unpack_px(st);
+        if (GENERIC) px[j].has0 = (raw.hdrv[j] >> 24) & kFlagMMask;  // keep the full m for the generic test
     }
     StepConsts sc = a.sc;
     uint32_t gmask = 0;  // pixels left to the generic kernel (nb == 1 only)
@@ -443,7 +457,35 @@ __global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSi
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t gw = bid * kWavesPerBlock + tid / kWave;  // the wave's segment
     const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane);
+    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+    RawSegment raw;
+    load_raw<ABS_T, false>(a, u0, full, raw);
+    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane, raw);
+}
+
+// K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes TWO
+// consecutive segments and issues the loads of both before it steps the first, so the second
+// segment's memory round trip hides under the first one's step (with one segment per wave all
+// resident waves load, then all compute, then all store, in lock step).
+template <bool COLLAPSE, bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, 6) void adder_frame1_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * 2u;
+    if (gw0 >= a.num_waves) return;
+    RawSegment raw[2];
+#pragma unroll
+    for (uint32_t s = 0; s < 2u; ++s) {
+        const uint32_t gw = gw0 + s;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        load_raw<ABS_T, true>(a, gw * kWaveUnits + lane * kUnitsPerLane, full, raw[s]);
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < 2u; ++s) {
+        const uint32_t gw = gw0 + s;
+        run_segment<COLLAPSE, ABS_T, false>(b, a, 1u, gw * kWaveUnits + lane * kUnitsPerLane, gw, lane, raw[s]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,6 +809,16 @@ extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
                                          uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
+    if (nb == 1u && !(variant & 4u) && exp_nf == 0u && (num_waves & 1u) == 0u) {
+        const uint32_t grid = (num_waves / 2u + kWavesPerBlock - 1) / kWavesPerBlock;
+        switch (variant & 3u) {
+            case 0: hipLaunchKernelGGL((adder_frame1_kernel<false, false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
+            case 1: hipLaunchKernelGGL((adder_frame1_kernel<true, false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
+            case 2: hipLaunchKernelGGL((adder_frame1_kernel<false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
+            default: hipLaunchKernelGGL((adder_frame1_kernel<true, true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
+        }
+        return hipGetLastError();
+    }
     const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;
     const uint32_t exp_bpf = exp_nf ? (num_waves + per_block - 1) / per_block : 0u;
