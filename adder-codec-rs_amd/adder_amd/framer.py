@@ -63,6 +63,12 @@ class HipFramer:
         N.check_framer(self.h, self.L.adder_framer_ingest_device(
             self.h, d_events.data_ptr(), offs.ctypes.data, len(offs) - 1, C.c_void_p(stream) if stream else None))
 
+    def ingest_frames_device(self, d_events, frame_offsets, stream=None):
+        """The transcoder's output as it is: per-frame raster-ordered segments, one launch per batch."""
+        offs = np.ascontiguousarray(frame_offsets, dtype=np.uint64)
+        N.check_framer(self.h, self.L.adder_framer_ingest_frames_device(
+            self.h, d_events.data_ptr(), offs.ctypes.data, len(offs) - 1, C.c_void_p(stream) if stream else None))
+
     def frames_ready(self):
         n = C.c_uint32(0)
         N.check_framer(self.h, self.L.adder_framer_frames_ready(self.h, C.byref(n)))

@@ -28,6 +28,8 @@ struct FramerPx {
     uint32_t lasti;  // last_frame_intensity_tracker
 };
 
+static_assert(sizeof(FramerPx) == 16, "one 16-byte record per unit");
+
 constexpr int32_t kFramerMaxFrame = 0x7ffffff0;
 
 // Returns true when frames (fill_from, fill_to] (absolute indices) take the value p.lasti.
@@ -43,7 +45,10 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
         p.ts = prev_ts + (uint64_t)t;
     }
     const uint64_t rm1 = p.ts ? p.ts - 1u : 0u;  // saturating_sub(1)
-    const uint64_t q = rm1 / (uint64_t)k.tpf;
+    // 64-bit clocks, but they stay below 2^32 for ~150 hours of 30 fps video at 255 ticks per
+    // frame: divide in 32 bits then (a 64-bit division is a ~130-instruction routine on the GPU)
+    const bool small = (p.ts >> 32) == 0u;
+    const uint64_t q = small ? (uint64_t)((uint32_t)rm1 / k.tpf) : rm1 / (uint64_t)k.tpf;
     if (q > (uint64_t)kFramerMaxFrame) {
         overflow = true;
     } else if ((int64_t)q > (int64_t)p.lastf) {
@@ -60,8 +65,14 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
         p.lastf = (int32_t)q;
         fills = true;
     }
-    if (k.round_up && p.ts % (uint64_t)k.ref_interval > 0u)
-        p.ts = (p.ts / (uint64_t)k.ref_interval + 1u) * (uint64_t)k.ref_interval;
+    if (k.round_up) {
+        if (small) {
+            const uint32_t ts32 = (uint32_t)p.ts, qr = ts32 / k.ref_interval;
+            if (ts32 - qr * k.ref_interval > 0u) p.ts = ((uint64_t)qr + 1u) * (uint64_t)k.ref_interval;
+        } else if (p.ts % (uint64_t)k.ref_interval > 0u) {
+            p.ts = (p.ts / (uint64_t)k.ref_interval + 1u) * (uint64_t)k.ref_interval;
+        }
+    }
     return fills;
 }
 

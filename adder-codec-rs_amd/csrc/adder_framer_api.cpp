@@ -22,9 +22,7 @@ struct AdderFramer {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t rows = 0, n_units = 0, tpf = 0, ring_frames = 0;
-    uint64_t *ts = nullptr;
-    int32_t *lastf = nullptr;
-    uint8_t *lasti = nullptr;
+    FramerPx *px = nullptr;  // per-unit trackers
     uint8_t *ring = nullptr;
     uint32_t *status = nullptr;
     int32_t *minmax = nullptr;  // device {min, max}
@@ -32,6 +30,12 @@ struct AdderFramer {
     size_t d_events_cap = 0;
     uint8_t *d_out = nullptr;
     size_t d_out_cap = 0;
+    uint64_t *d_offs = nullptr;  // device copy of the frame offsets of adder_framer_ingest_frames_device
+    size_t d_offs_cap = 0;
+    uint64_t *h_offs = nullptr;  // pinned staging of the same
+    size_t h_offs_cap = 0;
+    hipEvent_t ingested = nullptr;  // recorded behind the last device operation (ingest / pop / flush) on its stream
+    bool op_pending = false;
     int64_t frames_written = 0;
     bool flushed_pending = false;
     bool poisoned = false;
@@ -63,9 +67,11 @@ static void framer_free(AdderFramer *fr) {
     if (!fr) return;
     (void)hipSetDevice(fr->device);
     if (fr->stream) (void)hipStreamSynchronize(fr->stream);
-    for (void *p : {(void *)fr->ts, (void *)fr->lastf, (void *)fr->lasti, (void *)fr->ring, (void *)fr->status,
-                    (void *)fr->minmax, (void *)fr->d_events, (void *)fr->d_out})
+    for (void *p : {(void *)fr->px, (void *)fr->ring, (void *)fr->status,
+                    (void *)fr->minmax, (void *)fr->d_events, (void *)fr->d_out, (void *)fr->d_offs})
         if (p) (void)hipFree(p);
+    if (fr->h_offs) (void)hipHostFree(fr->h_offs);
+    if (fr->ingested) (void)hipEventDestroy(fr->ingested);
     if (fr->stream) (void)hipStreamDestroy(fr->stream);
     delete fr;
 }
@@ -126,15 +132,14 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
     auto setup = [&]() -> int {
         FHIPCHK(fr, hipSetDevice(fr->device));
         FHIPCHK(fr, hipStreamCreateWithFlags(&fr->stream, hipStreamNonBlocking));
-        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->ts), (size_t)fr->n_units * sizeof(uint64_t)));
-        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->lastf), (size_t)fr->n_units * sizeof(int32_t)));
-        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->lasti), fr->n_units));
+        FHIPCHK(fr, hipEventCreateWithFlags(&fr->ingested, hipEventDisableTiming));
+        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->px), (size_t)fr->n_units * sizeof(FramerPx)));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->ring), (size_t)fr->ring_frames * fr->n_units));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->status), sizeof(uint32_t)));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->minmax), 2 * sizeof(int32_t)));
         FHIPCHK(fr, hipMemsetAsync(fr->status, 0, sizeof(uint32_t), fr->stream));
         FHIPCHK(fr, hipMemsetAsync(fr->ring, 0, (size_t)fr->ring_frames * fr->n_units, fr->stream));
-        FHIPCHK(fr, adder_framer_launch_init(fr->ts, fr->lastf, fr->lasti, fr->n_units, fr->stream));
+        FHIPCHK(fr, adder_framer_launch_init(fr->px, fr->n_units, fr->stream));
         FHIPCHK(fr, hipStreamSynchronize(fr->stream));
         return ADDER_OK;
     };
@@ -155,11 +160,20 @@ extern "C" const char *adder_framer_last_error(const AdderFramer *fr) {
 extern "C" uint32_t adder_framer_tpf(const AdderFramer *fr) { return fr ? fr->tpf : 0; }
 extern "C" int64_t adder_framer_frames_written(const AdderFramer *fr) { return fr ? fr->frames_written : 0; }
 
+template <class T>
+static int fensure(AdderFramer *fr, T **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return ADDER_OK;
+    if (*p) FHIPCHK(fr, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(need, 16)));
+    *cap = need;
+    return ADDER_OK;
+}
+
 static FramerArgs make_args(const AdderFramer *fr) {
     FramerArgs a{};
-    a.ts = fr->ts;
-    a.lastf = fr->lastf;
-    a.lasti = fr->lasti;
+    a.px = fr->px;
     a.ring = fr->ring;
     a.status = fr->status;
     a.n_units = fr->n_units;
@@ -176,7 +190,23 @@ static FramerArgs make_args(const AdderFramer *fr) {
     return a;
 }
 
+// Operations may be queued on different streams (the caller's, the context's): each one is ordered
+// behind the previous one through this event.
+static int after_last_op(AdderFramer *fr, hipStream_t s) {
+    if (fr->op_pending) FHIPCHK(fr, hipStreamWaitEvent(s, fr->ingested, 0));
+    return ADDER_OK;
+}
+static int mark_op(AdderFramer *fr, hipStream_t s) {
+    FHIPCHK(fr, hipEventRecord(fr->ingested, s));
+    fr->op_pending = true;
+    return ADDER_OK;
+}
+
 static int check_status(AdderFramer *fr) {
+    {
+        const int rc_ = after_last_op(fr, fr->stream);
+        if (rc_ != ADDER_OK) return rc_;
+    }
     uint32_t st = 0;
     FHIPCHK(fr, hipMemcpyAsync(&st, fr->status, sizeof st, hipMemcpyDeviceToHost, fr->stream));
     FHIPCHK(fr, hipStreamSynchronize(fr->stream));
@@ -198,23 +228,56 @@ extern "C" int adder_framer_ingest_device(AdderFramer *fr, const AdderEvent *d_e
     if (num_segments && (!seg_offsets || (!d_events && seg_offsets[num_segments] > seg_offsets[0])))
         return ffail(fr, ADDER_E_BAD_PARAMS, "null argument");
     FHIPCHK(fr, hipSetDevice(fr->device));
+    {
+        const int rc_ = after_last_op(fr, (hipStream_t)stream);
+        if (rc_ != ADDER_OK) return rc_;
+    }
     const FramerArgs a = make_args(fr);
     for (uint32_t s = 0; s < num_segments; ++s) {
         if (seg_offsets[s + 1] < seg_offsets[s]) return ffail(fr, ADDER_E_BAD_PARAMS, "segment offsets must not decrease");
         FHIPCHK(fr, adder_framer_launch_segment(d_events, seg_offsets[s], seg_offsets[s + 1], &a, (hipStream_t)stream));
     }
-    return ADDER_OK;
+    return mark_op(fr, (hipStream_t)stream);
 }
 
-template <class T>
-static int fensure(AdderFramer *fr, T **p, size_t *cap, size_t need) {
-    if (*cap >= need && *p) return ADDER_OK;
-    if (*p) FHIPCHK(fr, hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(need, 16)));
-    *cap = need;
-    return ADDER_OK;
+extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEvent *d_events,
+                                                 const uint64_t *frame_offsets, uint32_t num_frames, void *stream) {
+    if (!fr) return ADDER_E_BAD_PARAMS;
+    if (fr->poisoned) return ffail(fr, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", fr->err.c_str());
+    if (fr->flushed_pending) return ffail(fr, ADDER_E_BAD_PARAMS, "pop the flushed frame before ingesting more events");
+    if (!num_frames) return ADDER_OK;
+    if (!frame_offsets || (!d_events && frame_offsets[num_frames] > frame_offsets[0]))
+        return ffail(fr, ADDER_E_BAD_PARAMS, "null argument");
+    for (uint32_t s = 0; s < num_frames; ++s)
+        if (frame_offsets[s + 1] < frame_offsets[s]) return ffail(fr, ADDER_E_BAD_PARAMS, "frame offsets must not decrease");
+    FHIPCHK(fr, hipSetDevice(fr->device));
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const int rc_ = after_last_op(fr, s);
+        if (rc_ != ADDER_OK) return rc_;
+    }
+    const size_t bytes = ((size_t)num_frames + 1) * sizeof(uint64_t);
+    int rc = fensure(fr, &fr->d_offs, &fr->d_offs_cap, bytes);
+    if (rc != ADDER_OK) return rc;
+    if (fr->h_offs_cap < bytes) {
+        // the staging buffer may still feed an earlier asynchronous copy
+        FHIPCHK(fr, hipStreamSynchronize(s));
+        if (fr->h_offs) FHIPCHK(fr, hipHostFree(fr->h_offs));
+        fr->h_offs = nullptr;
+        fr->h_offs_cap = 0;
+        FHIPCHK(fr, hipHostMalloc(reinterpret_cast<void **>(&fr->h_offs), bytes, hipHostMallocDefault));
+        fr->h_offs_cap = bytes;
+    } else {
+        FHIPCHK(fr, hipStreamSynchronize(s));  // (same reason; the copy is tiny)
+    }
+    memcpy(fr->h_offs, frame_offsets, bytes);
+    FHIPCHK(fr, hipMemcpyAsync(fr->d_offs, fr->h_offs, bytes, hipMemcpyHostToDevice, s));
+    const FramerArgs a = make_args(fr);
+    for (uint32_t f0 = 0; f0 < num_frames; f0 += kFramerRowsMaxFrames) {
+        const uint32_t nf = std::min(kFramerRowsMaxFrames, num_frames - f0);
+        FHIPCHK(fr, adder_framer_launch_rows(d_events, fr->d_offs + f0, nf, &a, s));
+    }
+    return mark_op(fr, s);
 }
 
 extern "C" int adder_framer_ingest(AdderFramer *fr, const AdderEvent *events, const uint64_t *seg_offsets,
@@ -246,7 +309,7 @@ extern "C" int adder_framer_ingest(AdderFramer *fr, const AdderEvent *events, co
 static int minmax_sync(AdderFramer *fr, int32_t *mn, int32_t *mx, hipStream_t s) {
     const int32_t init[2] = {0x7fffffff, -0x7fffffff - 1};
     FHIPCHK(fr, hipMemcpyAsync(fr->minmax, init, sizeof init, hipMemcpyHostToDevice, s));
-    FHIPCHK(fr, adder_framer_launch_minmax(fr->lastf, fr->n_units, fr->minmax, s));
+    FHIPCHK(fr, adder_framer_launch_minmax(fr->px, fr->n_units, fr->minmax, s));
     int32_t h[2];
     FHIPCHK(fr, hipMemcpyAsync(h, fr->minmax, sizeof h, hipMemcpyDeviceToHost, s));
     FHIPCHK(fr, hipStreamSynchronize(s));
@@ -262,7 +325,9 @@ static int ready_count(AdderFramer *fr, uint32_t *n, hipStream_t s) {
         return ADDER_OK;
     }
     int32_t mn, mx;
-    const int rc = minmax_sync(fr, &mn, &mx, s);
+    int rc = after_last_op(fr, s);
+    if (rc != ADDER_OK) return rc;
+    rc = minmax_sync(fr, &mn, &mx, s);
     if (rc != ADDER_OK) return rc;
     const int64_t r = (int64_t)mn + 1 - fr->frames_written;
     *n = r > 0 ? (uint32_t)std::min<int64_t>(r, fr->ring_frames) : 0u;
@@ -291,8 +356,12 @@ extern "C" int adder_framer_pop_device(AdderFramer *fr, uint8_t *d_out, uint32_t
     if (rc != ADDER_OK) return rc;
     const uint32_t n = std::min(ready, max_frames);
     if (!n) return ADDER_OK;
-    FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->lastf, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, n,
+    FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->px, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, n,
                                         0u, d_out, s));
+    {
+        const int rc_ = mark_op(fr, s);
+        if (rc_ != ADDER_OK) return rc_;
+    }
     fr->frames_written += n;
     fr->flushed_pending = false;
     *n_popped = n;
@@ -332,7 +401,7 @@ extern "C" int adder_framer_write_frame(AdderFramer *fr, uint8_t *out) {
     if (rc != ADDER_OK) return rc;
     // frame 0 as it is: pixels that have no value yet read 0 (driver.rs:946-950); after a flush
     // every pixel has one
-    FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->lastf, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, 1u,
+    FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->px, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, 1u,
                                         fr->flushed_pending ? 0u : 1u, fr->d_out, fr->stream));
     FHIPCHK(fr, hipMemcpyAsync(out, fr->d_out, fr->n_units, hipMemcpyDeviceToHost, fr->stream));
     FHIPCHK(fr, hipStreamSynchronize(fr->stream));
@@ -357,7 +426,7 @@ extern "C" int adder_framer_flush(AdderFramer *fr, int *frame0_ready) {
     if (rc != ADDER_OK) return rc;
     // `any chunk.len() > 1` (driver.rs:635-639): some pixel has reached beyond frame 0
     if ((int64_t)mx > fr->frames_written) {
-        FHIPCHK(fr, adder_framer_launch_flush(fr->ring, fr->lastf, fr->lasti, fr->n_units, fr->ring_frames,
+        FHIPCHK(fr, adder_framer_launch_flush(fr->ring, fr->px, fr->n_units, fr->ring_frames,
                                               (int32_t)fr->frames_written, fr->stream));
         FHIPCHK(fr, hipStreamSynchronize(fr->stream));
         fr->flushed_pending = true;

@@ -10,11 +10,10 @@ namespace adder {
 constexpr uint32_t kFramerStatusRing = 1u;       // an event reached past the frame ring
 constexpr uint32_t kFramerStatusMalformed = 2u;  // coordinates outside the plane / band
 constexpr uint32_t kFramerStatusRange = 4u;      // frame index out of range
+constexpr uint32_t kFramerRowsMaxFrames = 256;  // frames per adder_framer_rows_kernel launch
 
 struct FramerArgs {
-    uint64_t *ts;        // [n_units]
-    int32_t *lastf;      // [n_units]
-    uint8_t *lasti;      // [n_units]
+    FramerPx *px;        // [n_units] {ts u64, last_filled i32, last_intensity u32}: one 16-byte record per unit
     uint8_t *ring;       // [ring_frames][n_units]
     uint32_t *status;
     uint32_t n_units, width, channels, row_begin, rows;
@@ -28,10 +27,12 @@ struct FramerArgs {
 extern "C" {
 hipError_t adder_framer_launch_segment(const void *ev, uint64_t e0, uint64_t e1, const adder::FramerArgs *args,
                                        hipStream_t s);
-hipError_t adder_framer_launch_minmax(const int32_t *lastf, uint32_t n, int32_t *out, hipStream_t s);
-hipError_t adder_framer_launch_pop(const uint8_t *ring, const int32_t *lastf, uint32_t n_units, uint32_t ring_frames,
+hipError_t adder_framer_launch_rows(const void *ev, const uint64_t *d_seg_offsets, uint32_t T, const adder::FramerArgs *args,
+                                    hipStream_t s);
+hipError_t adder_framer_launch_minmax(const adder::FramerPx *px, uint32_t n, int32_t *out, hipStream_t s);
+hipError_t adder_framer_launch_pop(const uint8_t *ring, const adder::FramerPx *px, uint32_t n_units, uint32_t ring_frames,
                                    int32_t f0, uint32_t nf, uint32_t masked, uint8_t *out, hipStream_t s);
-hipError_t adder_framer_launch_flush(uint8_t *ring, int32_t *lastf, const uint8_t *lasti, uint32_t n_units,
-                                     uint32_t ring_frames, int32_t f0, hipStream_t s);
-hipError_t adder_framer_launch_init(uint64_t *ts, int32_t *lastf, uint8_t *lasti, uint32_t n, hipStream_t s);
+hipError_t adder_framer_launch_flush(uint8_t *ring, adder::FramerPx *px, uint32_t n_units, uint32_t ring_frames, int32_t f0,
+                                     hipStream_t s);
+hipError_t adder_framer_launch_init(adder::FramerPx *px, uint32_t n, hipStream_t s);
 }

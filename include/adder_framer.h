@@ -64,6 +64,14 @@ int adder_framer_ingest_device(AdderFramer *fr, const AdderEvent *d_events, cons
 int adder_framer_ingest(AdderFramer *fr, const AdderEvent *events, const uint64_t *seg_offsets,
                         uint32_t num_segments);
 
+/* The same for the transcoder's own output -- `num_frames` per-frame segments, each in RASTER order
+ * (events sorted by y, then x, then c: what adder_hip_integrate* emits; frame_offsets = its frame_offsets,
+ * host memory).  One launch for the whole batch: every workgroup owns a few rows for all frames.  A
+ * stream that is not in raster order inside its segments is reported (ADDER_E_BAD_PARAMS), use
+ * adder_framer_ingest_device for those. */
+int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEvent *d_events, const uint64_t *frame_offsets,
+                                      uint32_t num_frames, void *stream);
+
 /* Number of complete frames waiting (is_frame_filled(0), (1), ...).  Synchronises. */
 int adder_framer_frames_ready(AdderFramer *fr, uint32_t *n_ready);
 

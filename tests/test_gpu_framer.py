@@ -88,10 +88,11 @@ def test_dark_lake(golden_dir):
     assert len(got) >= len(want) and got[: len(want)] == want
 
 
+@pytest.mark.parametrize("batch_kernel", [False, True])
 @pytest.mark.parametrize("time_mode,multi_mode,dtm,channels", [
     (O.DELTA_T, O.COLLAPSE, 255, 1), (O.ABSOLUTE_T, O.COLLAPSE, 2550, 1), (O.DELTA_T, O.NORMAL, 1020, 3),
     (O.ABSOLUTE_T, O.NORMAL, 7650, 1), (O.ABSOLUTE_T, O.COLLAPSE, 7650, 3)])
-def test_transcode_then_frame_on_device(time_mode, multi_mode, dtm, channels):
+def test_transcode_then_frame_on_device(time_mode, multi_mode, dtm, channels, batch_kernel):
     """HipVideo events stay in HBM and feed HipFramer (frame_offsets = segments); the frames equal
     the framer oracle fed with the transcode oracle's events.  Includes flush + forced pops."""
     import torch
@@ -127,7 +128,11 @@ def test_transcode_then_frame_on_device(time_mode, multi_mode, dtm, channels):
         d_off = torch.zeros(17, dtype=torch.int64, device="cuda")
         hv.integrate_device(d_frames, d_ev, d_off, stream=st)
         hv.finish()
-        fr.ingest_device(d_ev, d_off.cpu().numpy().astype(np.uint64), stream=st)
+        offs = d_off.cpu().numpy().astype(np.uint64)
+        if batch_kernel:  # one launch for the 16 frames (row-owning workgroups)
+            fr.ingest_frames_device(d_ev, offs, stream=st)
+        else:             # one launch per frame segment
+            fr.ingest_device(d_ev, offs, stream=st)
         n = fr.frames_ready()
         d_out = torch.empty((max(n, 1), n_units), dtype=torch.uint8, device="cuda")
         m = fr.pop_device(d_out, n, stream=st)
@@ -164,3 +169,52 @@ def test_malformed_event_is_reported():
     with pytest.raises(A.AdderHipError) as ei:
         fr.ingest(e)
     assert ei.value.code == -1
+
+
+def test_batch_kernel_rejects_unsorted_segments(golden_dir):
+    """ingest_frames_device needs raster order inside a segment; the unordered sample is reported."""
+    import torch
+    A = _hip()
+    meta, events, _ = S.read_adder(open(os.path.join(golden_dir, "sample_3_unordered.adder"), "rb").read())
+    fr = A.HipFramer(meta["width"], meta["height"], 1, tps=meta["tps"], ref_interval=meta["ref_interval"],
+                     delta_t_max=meta["delta_t_max"], output_fps=60.0, codec_version=0, time_mode=A.TIME_DELTA_T,
+                     ring_frames=2048)
+    ys = events["y"][:400]
+    assert (np.diff(ys.astype(np.int64)) < 0).any()
+    d_ev = torch.from_numpy(events[:400].view(np.uint8).copy()).cuda()
+    fr.ingest_frames_device(d_ev, np.array([0, 400], np.uint64), stream=torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(A.AdderHipError) as ei:
+        fr.frames_ready()
+    assert ei.value.code == -1
+
+
+def test_full_size_1080p_framer_paths_agree():
+    """1080p: the per-segment and the whole-batch ingest paths give the same frames."""
+    import torch
+    A = _hip()
+    W, H, T = 1920, 1080, 24
+    n_units = W * H
+    st = torch.cuda.current_stream().cuda_stream
+    d_frames = torch.empty((T, n_units), dtype=torch.uint8, device="cuda")
+    A.synth_clip_device(d_frames, A.CONTENT_NOISE, W, H, 1, num_frames=T, stream=st)
+    d_ev = torch.empty((int(n_units * T * 1.5), 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, delta_t_max=255,
+                    c_thresh_start=0, c_counter_start=0, max_depth=20)
+    hv.set_crf_parameters(0, 10)
+    hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+    hv.finish()
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    outs = []
+    for batch in (False, True):
+        fr = A.HipFramer(W, H, 1, tps=255 * 30, ref_interval=255, delta_t_max=255, output_fps=30.0, codec_version=3,
+                         time_mode=A.TIME_DELTA_T, ring_frames=T + 8)
+        (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
+        n = fr.frames_ready()
+        d_out = torch.empty((max(n, 1), n_units), dtype=torch.uint8, device="cuda")
+        assert fr.pop_device(d_out, n, stream=st) == n
+        torch.cuda.synchronize()
+        outs.append(d_out[:n].clone())
+        fr.close()
+    # (a pixel that is 0 in consecutive frames is silent, so the slowest pixel holds most frames back)
+    assert outs[0].shape[0] >= 1 and torch.equal(outs[0], outs[1])

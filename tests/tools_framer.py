@@ -25,7 +25,7 @@ for it in range(4):
     n = hv.finish()
     offs = d_off.cpu().numpy().astype(np.uint64)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    fr.ingest_device(d_ev, offs, stream=st)
+    (fr.ingest_frames_device if E.get("BATCH", "1") == "1" else fr.ingest_device)(d_ev, offs, stream=st)
     m = fr.pop_device(d_out, T + 8, stream=st)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     best = min(best, dt)
