@@ -107,14 +107,9 @@ struct EmitPark {
 };
 
 // ------------------------------------------------------------------------------------------
-// K1.  GENERIC = false is used when no pixel can ever be deeper than one fired level
-// (Collapse with delta_t_max <= time_spanned): the eligibility test, the slot reservation
-// for generic pixels and the worklist are compiled out.
-//
-// A wave owns kSegsPerWave consecutive 256-unit segments.  The loads of ALL its segments are
-// issued before any of them is processed, so while one segment is being stepped the next
-// one's state is already streaming in (the step is ~140 VALU instructions per pixel; without
-// this the kernel alternates between a bandwidth phase and a compute phase).
+// K1 building blocks.  GENERIC = false is used when no pixel can ever be deeper than one fired
+// level (Collapse with delta_t_max <= time_spanned): the eligibility test and the full arena
+// walk are compiled out.
 // ------------------------------------------------------------------------------------------
 // kUnitsPerLane consecutive values as one vector access
 template <class T, int N>
@@ -328,7 +323,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
 
         // ---------------- wave-level ordered compaction into the frame's segment ----------------
         // low half: events of the lane in the final stream; high half: events it parks (the
-        // fast ones from the LDS stack, then those of its generic units)
+        // fast ones held in registers, then those of its generic units)
         const uint32_t packed = lane_cnt | ((nl + ngen) << 16);
         const uint32_t incl = wave_inclusive_scan_dpp(packed);
         const size_t seg_idx = (size_t)slot * num_waves_u + sgw;  // uniform
