@@ -421,7 +421,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
 // memory-bound and the step VALU-bound, so sharing the SIMDs overlaps them; nothing in one
 // role waits for the other.
 template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads, GENERIC ? 3 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
+__global__ __launch_bounds__(kBlockThreads, GENERIC ? 4 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb, uint32_t exp_f0, uint32_t exp_blocks_per_frame,
     uint32_t grp_steps, uint32_t grp_exps, uint32_t groups, uint32_t rem_is_step) {
     // dispatch order: `groups` groups of (grp_steps step workgroups, grp_exps expansion workgroups),

@@ -43,7 +43,7 @@ def main():
             json.dump({
                 "kernel": k,
                 "source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
-                          "`ADDER_HIP_NO_GRAPH=1 bench.py --steps 1 --warmup 0 --frames 64 --no-cpu-baseline --skip-roofline` "
+                          "`ADDER_HIP_NO_GRAPH=1 bench.py --steps 1 --warmup 0 --frames 160 --no-cpu-baseline --skip-roofline` "
                           "(1920x1080 gray scene clip), averaged over the frame-kernel launches",
                 "fetch_size_kib_per_launch": round(fetch, 1),
                 "write_size_kib_per_launch": round(write, 1),

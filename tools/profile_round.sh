@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o bench -
     python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
 find "$OUT/stats2" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_default_depth_kernel_stats.csv" \;
 
-PMC_CMD="python $REPO/bench.py --steps 1 --warmup 0 --frames 64 --no-cpu-baseline --skip-roofline"
+PMC_CMD="python $REPO/bench.py --steps 1 --warmup 0 --frames 160 --no-cpu-baseline --skip-roofline"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
     tag=$(echo "$set" | tr ' ' '_' | cut -c1-40)
