@@ -458,3 +458,47 @@ def test_lake_golden_bytes_pipelined_stream(golden_dir):
     assert n_total == 201620 and raw[37:-11] == body
     with pytest.raises(Exception):
         hv.stream_collect()  # nothing in flight
+
+
+def test_batch_lengths_around_chunk_and_lag_boundaries():
+    """Fused expansion runs two chunks behind the step (scratch ring of three chunks, chunk = 16): batch
+    lengths on both sides of every boundary, several submission forms, consecutive batches on one
+    context -- always the oracle's stream and frame offsets."""
+    import subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "%s"); sys.path.insert(0, "%s/adder-codec-rs_amd"); sys.path.insert(0, "%s/tests")
+import torch
+import adder_amd as A
+from oracle import oracle as O
+import clips
+W, H = 70, 23
+lens = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 5]
+clip = clips.make_clip("runs", sum(lens), H, W, 1, seed=4)
+ov = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+ov.set_crf_parameters(0, 10); ov.reset_c_thresh(0)
+hv = A.HipVideo(W, H, 1, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
+                c_thresh_start=0, c_counter_start=0)
+hv.set_crf_parameters(0, 10)
+st = torch.cuda.current_stream().cuda_stream
+k0 = 0
+for T in lens:
+    sub = clip[k0:k0 + T]; k0 += T
+    per = [ov.integrate_matrix(f) for f in sub]
+    want = np.concatenate(per)
+    d_frames = torch.from_numpy(sub.reshape(T, -1)).cuda()
+    d_ev = torch.full((W * H * T * 4, 3), -1, dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+    n = hv.finish()
+    got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    assert n == len(want) and np.array_equal(got, want), T
+    assert d_off.cpu().tolist() == np.concatenate([[0], np.cumsum([len(p) for p in per])]).tolist(), T
+    assert int((d_ev[n:] != -1).sum()) == 0, T  # nothing written past the stream
+print("ok")
+''' % (ROOT, ROOT, ROOT)
+    for env in ({}, {"ADDER_HIP_NO_GRAPH": "1"}, {"ADDER_HIP_FUSE_EXPAND": "0"},
+                {"ADDER_HIP_FRAMES_PER_LAUNCH": "1"}, {"ADDER_HIP_FRAMES_PER_LAUNCH": "5"},
+                {"ADDER_HIP_CHUNK": "4", "ADDER_HIP_FRAMES_PER_LAUNCH": "4"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-2000:])
