@@ -781,9 +781,13 @@ static int batch_to_device(AdderHipCtx *c, const uint8_t *frames, uint32_t num_f
     if ((rc = ensure(c, &vp, &c->d_offsets_cap, ((size_t)num_frames + 1) * sizeof(uint64_t))) != ADDER_OK) return rc;
     c->d_offsets = (uint64_t *)vp;
 
-    for (uint32_t f = 0; f < num_frames; ++f)
-        HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * c->n_units, rowlen, frames + (size_t)f * frame_stride,
-                                   row_stride, rowlen, c->rows, hipMemcpyHostToDevice, c->stream));
+    if (row_stride == rowlen && frame_stride == rowlen * c->rows) {  // packed: one linear copy
+        HIPCHK(c, hipMemcpyAsync(c->d_frames, frames, (size_t)num_frames * c->n_units, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (uint32_t f = 0; f < num_frames; ++f)
+            HIPCHK(c, hipMemcpy2DAsync(c->d_frames + (size_t)f * c->n_units, rowlen, frames + (size_t)f * frame_stride,
+                                       row_stride, rowlen, c->rows, hipMemcpyHostToDevice, c->stream));
+    }
     rc = adder_hip_integrate_device(c, c->d_frames, num_frames, time_spanned, c->d_events, out_cap, c->d_offsets,
                                     c->stream);
     if (rc != ADDER_OK) return rc;
@@ -941,12 +945,19 @@ extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t 
     if (n_out) *n_out = n;
     if (rc != ADDER_OK) return rc;
     if (chunk_offsets) {
-        // events are in raster order, so chunk boundaries are boundaries in y
-        size_t i = 0;
+        // events are in raster order, so chunk boundaries are boundaries in y: a binary search per chunk
+        size_t lo = 0;
         for (uint32_t ch = 0; ch < c->num_chunks; ++ch) {
             const uint32_t y0 = c->p.row_begin + ch * c->p.chunk_rows;
-            while (i < n && out[i].y < y0) ++i;
-            chunk_offsets[ch] = (uint32_t)i;
+            size_t hi = n;
+            while (lo < hi) {
+                const size_t mid = lo + (hi - lo) / 2;
+                if (out[mid].y < y0)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            chunk_offsets[ch] = (uint32_t)lo;
         }
         chunk_offsets[c->num_chunks] = (uint32_t)n;
     }
