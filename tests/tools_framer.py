@@ -26,6 +26,7 @@ for it in range(4):
     offs = d_off.cpu().numpy().astype(np.uint64)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     (fr.ingest_frames_device if E.get("BATCH", "1") == "1" else fr.ingest_device)(d_ev, offs, stream=st)
+    ready = fr.frames_ready()  # (also surfaces a device-side status flag as an error)
     m = fr.pop_device(d_out, T + 8, stream=st)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     best = min(best, dt)
