@@ -599,6 +599,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.out_cap = out_cap;
     b.base.frame_offsets = d_offsets;
     b.base.generic = generic_possible ? 1u : 0u;
+    b.base.park4 = (!generic_possible && c->p.time_mode != ADDER_TIME_ABSOLUTE_T) ? 1u : 0u;
     b.base.sc = make_consts(c, time_spanned, 0.0f);
     b.frames = d_frames;
     b.running_t = c->d_rt;

@@ -68,6 +68,7 @@ struct FrameArgs {
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
     uint32_t generic;     // 1: pixels deeper than one fired level are possible (GENERIC kernel variants)
+    uint32_t park4;       // 1: the frame kernel parks compact 4-byte records (non-generic DeltaT variants)
     StepConsts sc;
 };
 

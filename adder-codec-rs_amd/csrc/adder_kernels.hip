@@ -36,6 +36,9 @@
 namespace adder {
 
 constexpr uint32_t kWave = 64;
+// compact parked records (non-generic DeltaT variants)
+constexpr uint32_t kParkWideT = 0x1ffffu;                 // t field marker: the value is in the overflow list
+constexpr uint32_t kParkOverflowBase = kParkPerWave;      // dword index of the overflow list in a segment's scratch
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
 
 __device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
@@ -242,6 +245,7 @@ template <bool COLLAPSE, bool ABS_T, bool GENERIC>
 __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                             uint32_t u0, uint32_t gw, uint32_t lane, const RawSegment &raw) {
     constexpr uint32_t N = kUnitsPerLane;
+    constexpr bool PARK4 = !GENERIC && !ABS_T;  // compact parked records (see below and expand_block)
     // whole wave inside the band: the common case takes the unguarded vector input load
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     FastPx px[N];
@@ -333,6 +337,46 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
         const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
         uint2 *const seg = park_ring_u + seg_idx * park_stride_u;  // uniform
+        if (PARK4) {
+            // compact 4-byte records {t (17 bits) | d << 17 | unit << 25}; the parked position IS the
+            // final in-segment offset here (every event of these variants is a fast one).  d = 255
+            // (D_EMPTY) carries no t: it is the frame's running_t, which the expansion knows.  A t that
+            // does not fit (>= 2^17 - 1 ticks: a run of more than 500 frames) is written as the marker
+            // kParkWideT and its value goes to the segment's overflow list (second half of the
+            // segment's scratch), at the rank of the record among the segment's marked records.
+            const uint32_t poff4 = (excl >> 16) * 4u;
+            uint32_t e = 0, wide = 0;  // wide: bit per event slot (3 per unit) whose t needs the overflow list
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                const uint32_t m = fe[j].mask;
+                const uint32_t tag = (lane * N + j) << 25;
+                const uint32_t ts[3] = {fe[j].ta, fe[j].tb, fe[j].tc};
+                const uint32_t ds[3] = {fe[j].da, fe[j].db, fe[j].dc};
+#pragma unroll
+                for (uint32_t q = 0; q < 3u; ++q) {
+                    const bool on = (m >> q) & 1u;
+                    const bool w = on && ds[q] != kDEmpty && ts[q] >= kParkWideT;
+                    const uint32_t tt = ds[q] == kDEmpty ? 0u : (w ? kParkWideT : ts[q]);
+                    if (on) gstore<uint32_t>(seg, poff4 + 4u * e, tt | (ds[q] << 17) | tag);
+                    wide |= w ? 1u << (3u * j + q) : 0u;
+                    e += on ? 1u : 0u;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(wide != 0u) != 0ull) {  // rare
+                const uint32_t nw = (uint32_t)__popc(wide);
+                uint32_t rank = wave_inclusive_scan_dpp(nw) - nw;  // marked records of lower lanes
+#pragma unroll
+                for (uint32_t j = 0; j < N; ++j) {
+                    const uint32_t ts[3] = {fe[j].ta, fe[j].tb, fe[j].tc};
+#pragma unroll
+                    for (uint32_t q = 0; q < 3u; ++q)
+                        if ((wide >> (3u * j + q)) & 1u) {
+                            gstore<uint32_t>(seg, (kParkOverflowBase + rank) * 4u, ts[q]);
+                            rank += 1u;
+                        }
+                }
+            }
+        } else {
         const uint32_t poff = (excl >> 16) * (uint32_t)sizeof(uint2);  // the lane's first parked slot
         // the lane's fast events -> its range of the segment, each with {t, d | unit << 8 |
         // final in-segment offset << 16}
@@ -352,6 +396,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 if (m & 4u) gstore(seg, poff + 8u * e, make_uint2(fe[j].tc, fe[j].dc | tag | (off << 16)));
                 e += m >> 2;
             }
+        }
         }
         if (GENERIC && gmask) {
             // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
@@ -569,11 +614,18 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint32_t row_begin = __builtin_amdgcn_readfirstlane(b->base.row_begin);
     const uint64_t out_cap = b->base.out_cap;
 
+    const bool park4 = __builtin_amdgcn_readfirstlane(b->base.park4) != 0u;  // compact 4-byte records (K1, PARK4)
+    const uint32_t rt_u32 = park4 ? __builtin_amdgcn_readfirstlane(f32_as_u32(b->running_t[f])) : 0u;  // t of D_EMPTY
+
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly)
     uint2 first[kExpandSegs];
 #pragma unroll
-    for (uint32_t q = 0; q < kExpandSegs; ++q)
-        first[q] = gload<uint2>(park + (size_t)q * park_stride, lane * (uint32_t)sizeof(uint2));
+    for (uint32_t q = 0; q < kExpandSegs; ++q) {
+        if (park4)
+            first[q] = make_uint2(gload<uint32_t>(park + (size_t)q * park_stride, lane * 4u), 0u);
+        else
+            first[q] = gload<uint2>(park + (size_t)q * park_stride, lane * (uint32_t)sizeof(uint2));
+    }
     uint32_t my_tot = 0u, my_pref = 0u;
     if (lane < kExpandSegs) {
         my_tot = gload<uint32_t>(wtot, lane * 4u);
@@ -596,30 +648,55 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t room = room64 > 0xffffffffull ? 0xffffffffu : (uint32_t)room64;  // events that still fit
         EventWords *const seg_out = reinterpret_cast<EventWords *>(out) + base;
         const uint2 *const seg_park = park + (size_t)q * park_stride;
-        for (uint32_t i = lane; i < parked; i += kWave) {
-            const uint2 sl = (i == lane) ? first[q] : gload<uint2>(seg_park, i * (uint32_t)sizeof(uint2));
-            uint32_t rem = rem0 + ((sl.y >> 8) & 0xffu);
+        uint32_t wide_seen = 0u;  // marked records in earlier rounds of this segment (uniform)
+        for (uint32_t i0 = 0; i0 < parked; i0 += kWave) {  // uniform trip count
+            const uint32_t i = i0 + lane;
+            const bool on = i < parked;
+            uint32_t ev_t, ev_d, unit, pos;
+            if (park4) {
+                const uint32_t rec = !on ? 0u : (i0 == 0u ? first[q].x : gload<uint32_t>(seg_park, i * 4u));
+                ev_t = rec & kParkWideT;
+                ev_d = (rec >> 17) & 0xffu;
+                unit = rec >> 25;
+                pos = i;
+                const bool marked = on && ev_d != kDEmpty && ev_t == kParkWideT;
+                const uint64_t mb = __builtin_amdgcn_ballot_w64(marked);
+                if (mb != 0ull) {  // rare: fetch the real t from the segment's overflow list
+                    const uint32_t rank = wide_seen + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                    if (marked) ev_t = gload<uint32_t>(seg_park, (kParkOverflowBase + rank) * 4u);
+                    wide_seen += (uint32_t)__popcll(mb);
+                }
+                ev_t = ev_d == kDEmpty ? rt_u32 : ev_t;
+            } else {
+                const uint2 sl = !on ? make_uint2(0u, 0u)
+                                     : (i0 == 0u ? first[q] : gload<uint2>(seg_park, i * (uint32_t)sizeof(uint2)));
+                ev_t = sl.x;
+                ev_d = sl.y & 0xffu;
+                unit = (sl.y >> 8) & 0xffu;
+                pos = sl.y >> 16;  // final offset inside the segment
+            }
+            if (!on) continue;
+            uint32_t rem = rem0 + unit;
             uint32_t y = y0;
             if (one_wrap) {
                 const bool wrap = rem >= rowlen;
                 rem -= wrap ? rowlen : 0u;
                 y += wrap ? 1u : 0u;
             } else {
-                const uint32_t d = rem / rowlen;
-                rem -= d * rowlen;
-                y += d;
+                const uint32_t dq = rem / rowlen;
+                rem -= dq * rowlen;
+                y += dq;
             }
             uint32_t x = rem, c = 0xffu;
             if (channels == 3u) {
                 x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
                 c = rem - 3u * x;
             }
-            const uint32_t pos = sl.y >> 16;  // final offset inside the segment
             if (pos < room) {
                 EventWords w;
                 w.xy = x | ((y + row_begin) << 16);
-                w.cd = c | ((sl.y & 0xffu) << 8);
-                w.t = sl.x;
+                w.cd = c | (ev_d << 8);
+                w.t = ev_t;
                 gstore(seg_out, pos * (uint32_t)sizeof(EventWords), w);
             } else {
                 dropped = true;

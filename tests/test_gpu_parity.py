@@ -131,6 +131,28 @@ def test_long_static_deep_arena():
     run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=7650, crf=CRFS[0], batch=True)
 
 
+def test_compact_park_records_overflow_list():
+    """Collapse / DeltaT / delta_t_max = ref_time is the variant that parks compact 4-byte records with a
+    17-bit t; a pixel that stays put for > 514 frames and then changes emits a larger t, which goes
+    through the segment's overflow list.  Several such pixels per segment, different run lengths, and
+    D_EMPTY events (their t is the frame's running_t, not stored) in the same frames."""
+    rng = np.random.default_rng(5)
+    T, H, W = 760, 6, 70
+    clip = np.broadcast_to(rng.integers(1, 256, (1, H, W, 1), dtype=np.uint8), (T, H, W, 1)).copy()
+    for (y, x, k) in [(0, 0, 600), (0, 1, 650), (0, 2, 700), (3, 40, 700), (3, 41, 701), (5, 69, 759), (2, 10, 530)]:
+        clip[k:, y, x, 0] = 255 - clip[0, y, x, 0]
+    clip[300:, 4, :, 0] = rng.integers(0, 256, (T - 300, W), dtype=np.uint8)  # a busy row next to them
+    # six neighbours (same lane pairs and different lanes of one segment) that all overflow in one frame
+    clip[:, 0, 1:7, 0] = clip[:650, 0, 1:2, 0][:1]
+    clip[650:, 0, 1:7, 0] = 255 - clip[0, 0, 1, 0]
+    ov = O.Video(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    wide = [int(((e["d"] != 255) & (e["t"] >= 0x1FFFF)).sum()) for e in (ov.integrate_matrix(f) for f in clip)]
+    assert max(wide) >= 6 and sum(w > 0 for w in wide) >= 3  # the case is really exercised
+    run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
+
+
 def test_lake_golden_bytes(golden_dir):
     """Reference golden: frames -> HIP path -> raw sink == lake_scaled_hd_out.adder byte for byte."""
     A = _hip()
