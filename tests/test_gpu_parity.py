@@ -151,6 +151,10 @@ def test_compact_park_records_overflow_list():
     wide = [int(((e["d"] != 255) & (e["t"] >= 0x1FFFF)).sum()) for e in (ov.integrate_matrix(f) for f in clip)]
     assert max(wide) >= 6 and sum(w > 0 for w in wide) >= 3  # the case is really exercised
     run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
+    # AbsoluteT keeps 8-byte records (a 17-bit distance-from-frame-end field was tried: noise 17.0 -> 15.3 us but
+    # scene 10.2 -> 10.6, SGPR spills); the same clip must still match
+    run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
+    run_pair(clip[:, :, :, :], time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[3], batch=True)
 
 
 def test_lake_golden_bytes(golden_dir):
