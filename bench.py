@@ -184,8 +184,10 @@ def main():
     units_per_launch = units * launch_frames
     achieved = bytes_per_unit * units_per_launch / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
     # at depth 1 the expansion is NOT fused (it runs as its own kernel on a second stream): the frame
-    # kernel's launch then moves the input, the state and the 8-byte parked records
-    bytes1 = 1 + 2 * S + 8 * e_rank0
+    # kernel's launch then moves the input, the state and the parked records (4 bytes each in the
+    # DeltaT / delta_t_max <= ref_time variants, 8 otherwise)
+    park_bytes = 4 if (tmode == A.TIME_DELTA_T and multi == A.MULTI_COLLAPSE and args.delta_t_max <= REF_TIME) else 8
+    bytes1 = 1 + 2 * S + park_bytes * e_rank0
     achieved1 = bytes1 * units / (launch1_us * 1e-6) / 1e9 if launch1_us > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -248,9 +250,9 @@ def main():
             "bytes_per_unit_frame": round(bytes1, 3),
             "units_per_launch": units,
             "launch_avg_us": round(launch1_us, 3),
-            "note": "state streamed from HBM every frame (per-frame consume contract); this launch parks 8-byte "
-                    "records (1 + 2*20 + 8e bytes per unit), the 12-byte events are written by the separate "
-                    "expansion kernel overlapped on a second stream",
+            "note": "state streamed from HBM every frame (per-frame consume contract); this launch parks compact "
+                    "records (1 + 2*20 + 4e bytes per unit; 8e in the AbsoluteT / generic variants), the 12-byte "
+                    "events are written by the separate expansion kernel overlapped on a second stream",
         },
     }
 
