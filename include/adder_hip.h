@@ -47,7 +47,7 @@ typedef enum AdderStatus {
     ADDER_E_OUT_CAPACITY = -4, /* event buffer too small; *n_out holds the required count.
                                   Pixel state HAS advanced: the context is poisoned. */
     ADDER_E_ARENA_DEPTH = -5,  /* a pixel needed more stored nodes than max_depth; poisoned */
-    ADDER_E_TIMEOUT = -6,      /* in-kernel bounded wait expired (should never happen); poisoned */
+    ADDER_E_TIMEOUT = -6,      /* reserved (no kernel of this library waits on another workgroup) */
     ADDER_E_POISONED = -7      /* a previous call failed after state had advanced */
 } AdderStatus;
 
