@@ -40,11 +40,8 @@ struct AdderHipCtx {
     uint8_t *lv_bd = nullptr;
     uint8_t *running = nullptr;
     bool running_enabled = false;
-    // compaction scratch
-    // ordered compaction scratch, double-buffered by frame parity so that the expand kernel
-    // of frame f can overlap the frame kernel of frame f+1
-    // compaction scratch: a ring of 2*chunk frames (the expand kernels of one chunk overlap the
-    // frame kernels of the next)
+    // ordered-compaction scratch: a ring of (kFuseLagChunks + 1) chunks of frames (a chunk is stepped
+    // while the one before it is scanned and the one before that is expanded)
     uint2 *park_ring = nullptr;      // [slots][num_waves][park_stride]
     uint32_t park_stride = 0;        // parked-event capacity of a segment
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
@@ -62,9 +59,9 @@ struct AdderHipCtx {
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
     hipEvent_t cap_e1 = nullptr, cap_e2[3] = {nullptr, nullptr, nullptr};
-    std::map<uint64_t, hipGraphExec_t> graphs;  // key: T | variant << 32
+    std::map<uint64_t, hipGraphExec_t> graphs;  // key: see get_graph
     bool use_graph = true;
-    bool fuse_expand = true;   // K1 expands the previous chunk (single stream); false: two streams
+    bool fuse_expand = true;   // the frame kernel's grid also expands an earlier chunk; false: separate launches
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
