@@ -460,13 +460,14 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
 //     (frame f+1 only needs frame f's pixel state),
 //   * one scan launch (a block per frame) + the frame_offsets chain,
 //   * the expansion of the chunk's parked events.
-// Fused form (default): everything on ONE stream; the expansion of chunk k is done by extra
-// workgroups inside the K1 launches of chunk k+1 (the memory-bound expansion shares the SIMDs
-// with K1's VALU-bound step), and a stand-alone expand launch only handles the batch's last chunk.  The scratch ring holds two
-// chunks.  Unfused two-stream form (s2 != nullptr): scan/offsets/expand of chunk k on s2 behind
-// the chunk's last K1; the K1s of chunk k+2 wait for it.
+// Fused form (default): the expansion of chunk k is done by extra workgroups inside the K1 launches
+// of chunk k + kFuseLagChunks (the memory-bound expansion shares the SIMDs with K1's VALU-bound step);
+// scan + offsets of chunk k run on s2 and overlap the K1s of chunk k+1; one stand-alone expand launch
+// handles the last kFuseLagChunks chunks of the batch.  The scratch ring holds kFuseLagChunks + 1
+// chunks.  Unfused form: scan/offsets/expand of chunk k on s2 (or on s when s2 is null) behind the
+// chunk's last K1; the K1s of chunk k+2 wait for it.
 // The expansion is fused into the frame kernel's grid only where the two complement each other:
-// not for generic batches (their K1 runs at 3 waves per SIMD and would drag the expansion
+// not for generic batches (their K1 runs at 4 waves per SIMD and would drag the expansion
 // workgroups down to the same occupancy), and not at temporal depths below 4, where K1 itself
 // is HBM-bound and the fused expansion only competes with it (measured at depth 1: 27.3 us per
 // 1080p frame fused vs 22.2 us with the expansion on a second stream).

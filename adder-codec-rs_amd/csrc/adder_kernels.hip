@@ -264,7 +264,7 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
     }
     StepConsts sc = a.sc;
     uint32_t gmask = 0;  // pixels left to the generic kernel (nb == 1 only)
-    // running_t of the launch's frames (nb <= 8): one load, then a lane read per frame
+    // running_t of the launch's frames (nb <= kMaxFramesPerLaunch <= 64): one load, then a lane read per frame
     const uint32_t rt_vec = (lane < kMaxFramesPerLaunch && lane < nb) ? __float_as_uint(b->running_t[a.frame_idx + lane]) : 0u;
 
     // wave-uniform bases of the per-frame accesses, in SGPRs
