@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "libadder_hip.so")
+# ADDER_HIP_LIB: A/B builds of the same library (tools/build_variants.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("ADDER_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "libadder_hip.so")
 
 ABI_VERSION = 1
 TIME_DELTA_T, TIME_ABSOLUTE_T, TIME_MIXED = 0, 1, 2

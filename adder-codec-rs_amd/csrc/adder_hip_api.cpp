@@ -33,35 +33,41 @@ struct AdderHipCtx {
     uint32_t rows = 0, n_units = 0, num_tiles = 0, num_chunks = 0, grid = 0, num_cus = 0;
     size_t n_pad = 0;
     uint32_t max_depth = 0;
-    // state planes
+    // state planes: level 0 = {hdr, integ0, dt0, bdt0}; levels >= 1 in the deep planes (allocated by the
+    // first generic batch: the lean variants never touch them)
     uint32_t *hdr = nullptr;
+    float *integ0 = nullptr, *dt0 = nullptr, *bdt0 = nullptr;
     float *lastf = nullptr;
-    float *lv_integ = nullptr, *lv_dt = nullptr, *lv_bdt = nullptr;
-    uint8_t *lv_bd = nullptr;
+    float *dv_integ = nullptr, *dv_dt = nullptr, *dv_bdt = nullptr;
+    uint8_t *dv_bd = nullptr;
     uint8_t *running = nullptr;
     bool running_enabled = false;
-    // ordered-compaction scratch: a ring of (kFuseLagChunks + 1) chunks of frames (a chunk is stepped
-    // while the one before it is scanned and the one before that is expanded)
-    uint2 *park_ring = nullptr;      // [slots][num_waves][park_stride]
-    uint32_t park_stride = 0;        // parked-event capacity of a segment
+    // c_thresh / c_increase_counter: identical in every pixel (adder_pixel.hpp header comment)
+    uint8_t c_thresh = 10, c_counter = 1;
+    // a generic batch has run since create / reset: pixels may hold more than one fired level, which only
+    // the generic kernels understand -- the lean variant is not chosen again until adder_hip_reset
+    bool generic_sticky = false;
+    // ordered-compaction scratch: a ring of two chunks of frames (a chunk is stepped while the one before
+    // it is scanned and expanded)
+    uint8_t *park_ring = nullptr;    // [slots][num_waves][park_bytes]
+    uint32_t park_bytes = 0;         // scratch of one segment of one frame
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2;
-    uint32_t frames_per_launch = 16;  // temporal blocking depth of the frame kernel (non-generic modes)
+    uint32_t frames_per_launch = kMaxFramesPerLaunch;  // temporal blocking depth of the frame kernels
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
     BatchArgs *d_batch = nullptr;
     BatchArgs *h_batch = nullptr;   // pinned
-    float *d_rt = nullptr;          // running_t table
-    float *h_rt = nullptr;          // pinned
-    size_t rt_cap = 0;              // entries
+    FrameTab *d_ftab = nullptr;     // per-frame uniforms (running_t, c_thresh)
+    FrameTab *h_ftab = nullptr;     // pinned
+    size_t ftab_cap = 0;            // entries
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
     hipEvent_t cap_e1 = nullptr, cap_e2[3] = {nullptr, nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: see get_graph
     bool use_graph = true;
-    bool fuse_expand = true;   // the frame kernel's grid also expands an earlier chunk; false: separate launches
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
@@ -140,8 +146,8 @@ static void free_ctx(AdderHipCtx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->hdr,     c->lastf,   c->lv_integ, c->lv_dt,
-                    c->lv_bdt,  c->lv_bd,   c->running, c->status,
+    void *ptrs[] = {c->hdr,     c->integ0,  c->dt0,      c->bdt0,   c->lastf,  c->dv_integ, c->dv_dt,
+                    c->dv_bdt,  c->dv_bd,   c->running,  c->status,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -159,8 +165,8 @@ static void free_ctx(AdderHipCtx *c) {
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->d_batch) (void)hipFree(c->d_batch);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
-    if (c->d_rt) (void)hipFree(c->d_rt);
-    if (c->h_rt) (void)hipHostFree(c->h_rt);
+    if (c->d_ftab) (void)hipFree(c->d_ftab);
+    if (c->h_ftab) (void)hipHostFree(c->h_ftab);
     for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1], c->cap_e2[2]})
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
@@ -194,16 +200,14 @@ extern "C" void adder_hip_default_params(AdderHipParams *p, uint16_t width, uint
     p->device_id = -1;
 }
 
-static StepConsts make_consts(const AdderHipCtx *c, float time_spanned, float running_t) {
+static StepConsts make_consts(const AdderHipCtx *c, float time_spanned) {
     StepConsts sc;
     sc.time_spanned = time_spanned;
-    sc.running_t = running_t;
-    sc.running_t_u32 = f32_as_u32(running_t);
+    sc.running_t = 0.0f;  // per frame: BatchArgs::ftab
+    sc.running_t_u32 = 0u;
     sc.dtm_f = (float)c->p.delta_t_max;
     sc.ref_time = c->p.ref_time;
-    sc.c_thresh_max = c->p.c_thresh_max;
-    sc.velocity_m1 = (uint8_t)(c->p.c_increase_velocity - 1);
-    sc.c_inc = (uint8_t)(f32_as_u32(time_spanned) / c->p.ref_time);
+    sc.cth = 0u;          // per frame: BatchArgs::ftab
     sc.collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE ? 1u : 0u;
     sc.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
     sc.max_depth = c->max_depth;
@@ -214,11 +218,14 @@ static StepConsts make_consts(const AdderHipCtx *c, float time_spanned, float ru
 static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     memset(a, 0, sizeof *a);
     a->hdr = c->hdr;
+    a->integ0 = c->integ0;
+    a->dt0 = c->dt0;
+    a->bdt0 = c->bdt0;
     a->lastf = c->lastf;
-    a->lv_integ = c->lv_integ;
-    a->lv_dt = c->lv_dt;
-    a->lv_bdt = c->lv_bdt;
-    a->lv_bd = c->lv_bd;
+    a->dv_integ = c->dv_integ;
+    a->dv_dt = c->dv_dt;
+    a->dv_bdt = c->dv_bdt;
+    a->dv_bd = c->dv_bd;
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
@@ -231,35 +238,29 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
 }
 
 // Video::new (video.rs:350-438): every pixel = PixelArena::new(1.0, coord): base_val 0,
-// c_thresh 10, counter 1, one pristine node, last_fired_t 0, running_t 0.
-static int init_state(AdderHipCtx *c, bool full) {
+// c_thresh 10, counter 1, one pristine node (m = 0), last_fired_t 0, running_t 0.
+static int init_state(AdderHipCtx *c) {
     const AdderHipParams &p = c->p;
-    // PixelArena::new(1.0, coord): base_val 0, c_thresh 10, counter 1, one pristine node
-    const uint32_t hdr0 = 0u | ((uint32_t)p.c_thresh_start << 8) | ((uint32_t)p.c_counter_start << 16);
-    HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, hdr0, c->stream));
+    // header word 0 = base_val 0, no fired level, not popped.  The level planes are only read where
+    // the header says they are live (or are selected away: lean step), so they need no clearing.
+    HIPCHK(c, hipMemsetAsync(c->hdr, 0, c->n_pad * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
-    // level planes are only read where the header says they are live (m > k), so a reset
-    // does not need to clear them
-    if (full) {
-    HIPCHK(c, hipMemsetAsync(c->lv_integ, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->lv_dt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->lv_bdt, 0, c->n_pad * c->max_depth * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->lv_bd, 0, c->n_pad * c->max_depth, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
-    }
+    if (c->running) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
+    c->c_thresh = p.c_thresh_start;
+    c->c_counter = p.c_counter_start;
+    c->generic_sticky = false;
     c->running_t = 0.0f;
     c->frames_done = 0;
     c->poisoned = false;
     return ADDER_OK;
 }
 
-// Fused expansion runs two chunks behind the step, so that the scan of chunk k (second stream)
-// overlaps the frame kernels of chunk k+1 instead of sitting between them; the scratch ring
-// therefore holds three chunks.
-constexpr uint32_t kFuseLagChunks = 2;
+// The scratch ring holds two chunks of frames: chunk k is stepped while chunk k-1 is scanned and expanded
+// (launch_frame_loop makes the step of chunk k wait for the expansion of chunk k-2).
+constexpr uint32_t kFuseLagChunks = 1;
 
-static int alloc_scratch(AdderHipCtx *c, uint32_t stride);
+static int alloc_scratch(AdderHipCtx *c, uint32_t bytes_per_segment);
 
 extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
     if (!out) return fail(nullptr, ADDER_E_BAD_PARAMS, "out is null");
@@ -336,13 +337,11 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipEventCreate(&c->ev_start));
         HIPCHK(c, hipEventCreate(&c->ev_stop));
         HIPCHK(c, dalloc(&c->hdr, c->n_pad));
+        HIPCHK(c, dalloc(&c->integ0, c->n_pad));
+        HIPCHK(c, dalloc(&c->dt0, c->n_pad));
+        HIPCHK(c, dalloc(&c->bdt0, c->n_pad));
         HIPCHK(c, dalloc(&c->lastf, c->n_pad));
-        HIPCHK(c, dalloc(&c->lv_integ, c->n_pad * c->max_depth));
-        HIPCHK(c, dalloc(&c->lv_dt, c->n_pad * c->max_depth));
-        HIPCHK(c, dalloc(&c->lv_bdt, c->n_pad * c->max_depth));
-        HIPCHK(c, dalloc(&c->lv_bd, c->n_pad * c->max_depth));
-        HIPCHK(c, dalloc(&c->running, c->n_pad));
-        { int rc_ = alloc_scratch(c, kParkPerWave); if (rc_ != ADDER_OK) return rc_; }
+        { int rc_ = alloc_scratch(c, kLeanParkBytes); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, dalloc(&c->d_batch, 1));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
@@ -355,12 +354,11 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
         }
-        if (const char *fe = getenv("ADDER_HIP_FUSE_EXPAND")) c->fuse_expand = atoi(fe) != 0;
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
-        { int rc_ = init_state(c, true); if (rc_ != ADDER_OK) return rc_; }
+        { int rc_ = init_state(c); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return ADDER_OK;
     };
@@ -390,9 +388,10 @@ extern "C" int adder_hip_set_crf_parameters(AdderHipCtx *c, uint8_t c_thresh_max
 
 extern "C" int adder_hip_reset_c_thresh(AdderHipCtx *c, uint8_t baseline) {
     if (!c) return ADDER_E_BAD_PARAMS;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, adder_launch_reset_c_thresh(c->hdr, c->n_pad, baseline, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // every pixel: c_thresh = baseline, c_increase_counter = 0 (video.rs:1247-1250,1283-1286); the pair
+    // is uniform across the plane, so it lives in the context
+    c->c_thresh = baseline;
+    c->c_counter = 0;
     return ADDER_OK;
 }
 
@@ -429,29 +428,45 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
-// (Re)allocates the compaction scratch ring for `stride` parked events per segment.  The
-// fast path parks at most 3 events per unit (kParkPerWave per segment); a generic batch can
-// park up to max_depth + 2 per unit.  Chunk = frames per scan launch: as many as ~12 GiB of
-// scratch allow (three chunks are in flight), at most kMaxChunk.
-static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
-    if (c->park_stride >= stride && c->park_ring) return ADDER_OK;
+// (Re)allocates the compaction scratch ring for `bytes` of parked records per segment and frame.
+// The lean step parks at most one 16-byte record per unit (kLeanParkBytes per segment); a generic
+// batch can park up to max_depth + 2 8-byte records per unit.  Chunk = frames per scan launch: as many
+// as the budget allows (kFuseLagChunks + 1 chunks are in flight), at most kMaxChunk.  The budget is a
+// quarter of what the device has free, at most 12 GiB.
+static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
+    if (c->park_bytes >= bytes && c->park_ring) return ADDER_OK;
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);  // they bake the chunking
     c->graphs.clear();
-    for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
-        if (p) HIPCHK(c, hipFree(p));
+    void *old[] = {c->park_ring, c->wtot_ring, c->wpref_ring, c->ftot_ring};
     c->park_ring = nullptr;
     c->wtot_ring = c->wpref_ring = c->ftot_ring = nullptr;
-    c->park_stride = 0;
-    const size_t per_frame = (size_t)c->num_waves * ((size_t)stride * sizeof(uint2) + 2 * sizeof(uint32_t));
-    size_t ch = ((size_t)12 << 30) / ((kFuseLagChunks + 1u) * per_frame);
+    c->park_bytes = 0;
+    for (void *p : old)
+        if (p) HIPCHK(c, hipFree(p));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::min<size_t>((size_t)12 << 30, free_b / 4);
+    const size_t per_frame = (size_t)c->num_waves * ((size_t)bytes + 2 * sizeof(uint32_t));
+    const size_t ch = budget / ((kFuseLagChunks + 1u) * per_frame);
     c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
     if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
     c->slots = (kFuseLagChunks + 1u) * c->chunk;
-    HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * stride));
+    HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * bytes));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->ftot_ring, c->slots));
-    c->park_stride = stride;
+    c->park_bytes = bytes;
+    return ADDER_OK;
+}
+
+// Levels >= 1 of the arena: only the generic kernels use them.
+static int alloc_deep_planes(AdderHipCtx *c) {
+    if (c->dv_integ) return ADDER_OK;
+    const size_t deep = std::max<uint32_t>(c->max_depth, 2u) - 1u;
+    HIPCHK(c, dalloc(&c->dv_integ, c->n_pad * deep));
+    HIPCHK(c, dalloc(&c->dv_dt, c->n_pad * deep));
+    HIPCHK(c, dalloc(&c->dv_bdt, c->n_pad * deep));
+    HIPCHK(c, dalloc(&c->dv_bd, c->n_pad * deep));
     return ADDER_OK;
 }
 
@@ -459,22 +474,12 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t stride) {
 //   * K1 launches back to back, each stepping up to frames_per_launch consecutive frames
 //     (frame f+1 only needs frame f's pixel state),
 //   * one scan launch (a block per frame) + the frame_offsets chain,
-//   * the expansion of the chunk's parked events.
-// Fused form (default): the expansion of chunk k is done by extra workgroups inside the K1 launches
-// of chunk k + kFuseLagChunks (the memory-bound expansion shares the SIMDs with K1's VALU-bound step);
-// scan + offsets of chunk k run on s2 and overlap the K1s of chunk k+1; one stand-alone expand launch
-// handles the last kFuseLagChunks chunks of the batch.  The scratch ring holds kFuseLagChunks + 1
-// chunks.  Unfused form: scan/offsets/expand of chunk k on s2 (or on s when s2 is null) behind the
-// chunk's last K1; the K1s of chunk k+2 wait for it.
-// The expansion is fused into the frame kernel's grid only where the two complement each other:
-// not for generic batches (their K1 runs at 4 waves per SIMD and would drag the expansion
-// workgroups down to the same occupancy), and not at temporal depths below 4, where K1 itself
-// is HBM-bound and the fused expansion only competes with it (measured at depth 1: 27.3 us per
-// 1080p frame fused vs 22.2 us with the expansion on a second stream).
+//   * the expansion of the chunk's parked records.
+// With a second stream (graph capture), scan/offsets/expand of chunk k go to s2 behind the chunk's last
+// K1, and the K1s of chunk k+2 wait for them (the scratch ring holds two chunks).  Running the
+// expansion inside K1's grid (round 1) no longer pays: with the lean step both kernels are bound by the
+// memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
-static bool fuse_for(const AdderHipCtx *c, uint32_t variant) {
-    return c->fuse_expand && !(variant & 4u) && launch_depth(c) >= 4u;
-}
 
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
@@ -482,23 +487,15 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
     // to their unit, so the lane's own program order keeps them consistent across frames.
     const uint32_t depth = launch_depth(c);
-    const bool fused = fuse_for(c, variant);
-    const uint32_t lag = kFuseLagChunks * c->chunk;  // frames between a step and its fused expansion
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
-        if (s2) {
-            if (fused && k >= kFuseLagChunks)  // the scan of the chunk this one expands
-                HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - kFuseLagChunks) % 3u], 0));
-            if (!fused && k >= 2)  // scratch reuse: the expansion of chunk k-2
-                HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 2u) % 3u], 0));
-        }
+        if (s2 && k >= 2)  // scratch reuse: the expansion of chunk k-2
+            HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 2u) % 3u], 0));
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
-            // fused: this launch also expands the frames `lag` back (same positions of an earlier chunk)
-            const bool fx = fused && f0 >= lag;
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, fx ? f - lag : 0u, fx ? nb : 0u, s));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, 0u, 0u, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
                 c->timed_launches += 1;
@@ -513,23 +510,16 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         }
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        if (!fused) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, t));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, t));
         if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 3u], s2));
     }
     if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 3u], 0));  // join (s2 is in-order)
-    if (fused) {
-        // frame f is expanded by the launch that steps frame f + lag; the last `lag` frames of
-        // the batch have no such launch
-        const uint32_t t0 = num_frames > lag ? num_frames - lag : 0u;
-        HIPCHK(c, adder_launch_expand(c->d_batch, t0, num_frames - t0, c->num_waves, s));
-    }
     return ADDER_OK;
 }
 
 static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     // everything the captured launch sequence depends on
-    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 40) |
-                         ((uint64_t)(c->fuse_expand ? 1u : 0u) << 48);
+    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 40);
     auto it = c->graphs.find(key);
     if (it != c->graphs.end()) {
         *out = it->second;
@@ -561,53 +551,65 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
 static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
                           AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
     // Pixels deeper than one fired level cannot occur when Collapse pops the root as soon as
-    // it has accumulated once (delta_t_max <= time_spanned): then the generic kernel is
-    // never needed (see fast_eligible in adder_pixel.hpp).
+    // it has accumulated once (delta_t_max <= time_spanned): then the lean kernel (adder_pixel.hpp
+    // lean_step) runs.  Once a generic batch has run, pixels may hold deeper arenas (or a root that
+    // the lean step's "time_spanned >= delta_t_max" folding does not describe), so the choice is sticky
+    // until adder_hip_reset: update_quality_manual can lower delta_t_max mid-stream (video.rs:1264-1287).
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
-    const bool generic_possible = !(collapse && (float)c->p.delta_t_max <= time_spanned);
+    const bool generic = c->generic_sticky || !(collapse && (float)c->p.delta_t_max <= time_spanned);
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
-                             (generic_possible ? 4u : 0u);
-
-    // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
-    if (generic_possible) {
-        int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2));
+                             (generic ? 4u : 0u);
+    if (generic) {
+        // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
+        int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2) * kGenRecBytes);
+        if (rc_ == ADDER_OK) rc_ = alloc_deep_planes(c);
         if (rc_ != ADDER_OK) return rc_;
+        c->generic_sticky = true;
+    }
+    if (c->running_enabled && !c->running) {
+        HIPCHK(c, dalloc(&c->running, c->n_pad));
+        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
 
     // ---- batch description -> device ----
-    if (c->rt_cap < num_frames) {
-        if (c->d_rt) HIPCHK(c, hipFree(c->d_rt));
-        if (c->h_rt) HIPCHK(c, hipHostFree(c->h_rt));
-        c->d_rt = nullptr;
-        c->h_rt = nullptr;
-        c->rt_cap = 0;
+    if (c->ftab_cap < num_frames) {
+        void *od = c->d_ftab, *oh = c->h_ftab;
+        c->d_ftab = nullptr;
+        c->h_ftab = nullptr;
+        c->ftab_cap = 0;
+        if (od) HIPCHK(c, hipFree(od));
+        if (oh) HIPCHK(c, hipHostFree(oh));
         const size_t cap = std::max<size_t>(num_frames, 64);
-        HIPCHK(c, dalloc(&c->d_rt, cap));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_rt), cap * sizeof(float), hipHostMallocDefault));
-        c->rt_cap = cap;
+        HIPCHK(c, dalloc(&c->d_ftab, cap));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ftab), cap * sizeof(FrameTab), hipHostMallocDefault));
+        c->ftab_cap = cap;
     }
     float rt = c->running_t;
+    uint8_t cth = c->c_thresh, cctr = c->c_counter;
     for (uint32_t f = 0; f < num_frames; ++f) {
-        c->h_rt[f] = rt;
-        rt += time_spanned;  // `self.running_t += time` (event_pixel_tree.rs:336), f32
+        c->h_ftab[f].running_t = rt;
+        c->h_ftab[f].cth = cth;  // the contrast test of frame f sees the value before its integrate
+        rt += time_spanned;      // `self.running_t += time` (event_pixel_tree.rs:336), f32
+        c_thresh_advance(cth, cctr, c->p.c_thresh_max, c->p.c_increase_velocity, time_spanned, c->p.ref_time);
     }
     BatchArgs &b = *c->h_batch;
     base_args(c, &b.base);
     b.base.out = reinterpret_cast<AdderEventPod *>(d_out);
     b.base.out_cap = out_cap;
     b.base.frame_offsets = d_offsets;
-    b.base.generic = generic_possible ? 1u : 0u;
-    b.base.park4 = (!generic_possible && c->p.time_mode != ADDER_TIME_ABSOLUTE_T) ? 1u : 0u;
-    b.base.sc = make_consts(c, time_spanned, 0.0f);
+    b.base.lean = generic ? 0u : 1u;
+    b.base.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
+    b.base.sc = make_consts(c, time_spanned);
     b.frames = d_frames;
-    b.running_t = c->d_rt;
+    b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
-    b.park_stride = c->park_stride;
+    b.park_bytes = c->park_bytes;
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;
     b.slots = c->slots;
-    HIPCHK(c, hipMemcpyAsync(c->d_rt, c->h_rt, num_frames * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ftab, c->h_ftab, num_frames * sizeof(FrameTab), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
 
@@ -642,6 +644,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     if (rc != ADDER_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_stop, stream));
     c->running_t = rt;
+    c->c_thresh = cth;
+    c->c_counter = cctr;
     c->frames_done += num_frames;
     return ADDER_OK;
 }
@@ -728,8 +732,7 @@ extern "C" int adder_hip_reset(AdderHipCtx *c) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = init_state(c, false);
-    if (rc == ADDER_OK && c->running_enabled) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+    int rc = init_state(c);
     if (rc != ADDER_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ADDER_OK;
@@ -983,6 +986,10 @@ extern "C" int adder_hip_running_intensities(AdderHipCtx *c, uint8_t *dst) {
     if (!c || !dst) return ADDER_E_BAD_PARAMS;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->running) {  // never enabled before a batch: the plane is still all zeros
+        memset(dst, 0, c->n_units);
+        return ADDER_OK;
+    }
     HIPCHK(c, hipMemcpy(dst, c->running, c->n_units, hipMemcpyDeviceToHost));
     return ADDER_OK;
 }

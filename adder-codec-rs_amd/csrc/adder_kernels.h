@@ -14,19 +14,24 @@ constexpr uint32_t kBlockThreads = 256;
 #define ADDER_UNITS_PER_LANE 2
 #endif
 #ifndef ADDER_EXPAND_SEGS
-#define ADDER_EXPAND_SEGS 8
+#define ADDER_EXPAND_SEGS 16
 #endif
-#ifndef ADDER_FRAME_WAVES_PER_SIMD
-#define ADDER_FRAME_WAVES_PER_SIMD 8
+#ifndef ADDER_LEAN_WAVES_PER_SIMD
+#define ADDER_LEAN_WAVES_PER_SIMD 8
 #endif
 constexpr uint32_t kUnitsPerLane = ADDER_UNITS_PER_LANE;           // pixel-channels per lane (2 or 4)
 constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // units per wave segment
 constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // units per K1 block
-constexpr uint32_t kSlotsPerLane = 3 * kUnitsPerLane;              // <= 3 fast-path events per pixel
-constexpr uint32_t kFrameKernelWavesPerSimd = ADDER_FRAME_WAVES_PER_SIMD;  // register budget of K1
-constexpr uint32_t kParkPerWave = 64 * kSlotsPerLane;              // parked-event capacity of a segment
-constexpr uint32_t kMaxChunk = 16;                                 // frames per scan/expand launch
-constexpr uint32_t kMaxFramesPerLaunch = 16;                       // temporal blocking depth of K1
+constexpr uint32_t kLeanWavesPerSimd = ADDER_LEAN_WAVES_PER_SIMD;  // register budget of the lean K1
+#ifndef ADDER_MAX_FRAMES_PER_LAUNCH
+#define ADDER_MAX_FRAMES_PER_LAUNCH 32
+#endif
+constexpr uint32_t kMaxFramesPerLaunch = ADDER_MAX_FRAMES_PER_LAUNCH;  // temporal blocking depth of K1 (<= 64)
+constexpr uint32_t kMaxChunk = kMaxFramesPerLaunch;                // frames per scan/expand launch
+// parked-record scratch of one segment of one frame, in BYTES
+constexpr uint32_t kLeanRecBytes = 16;                             // LeanRec: at most one per unit
+constexpr uint32_t kLeanParkBytes = kWaveUnits * kLeanRecBytes;
+constexpr uint32_t kGenRecBytes = 8;                               // generic variants: one per EVENT
 
 // bits of the device status word
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
@@ -40,15 +45,25 @@ struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint32_t t;
 };
 
+// what is uniform across the plane but changes per frame
+struct FrameTab {
+    float running_t;  // PixelArena::running_t BEFORE the frame's integrate
+    uint32_t cth;     // c_thresh of every pixel while the frame is tested (adder_pixel.hpp header comment)
+};
+
 // Everything the per-frame kernels need.  `f` = frame index inside the batch.
 struct FrameArgs {
-    // structure-of-arrays pixel state, resident in HBM across frames
-    uint32_t *hdr;      // [n_pad]
+    // structure-of-arrays pixel state, resident in HBM across frames.  Level 0 of a unit is the 16 bytes
+    // {hdr, integ0, dt0, bdt0}; levels k >= 1 (generic variants only) live in the deep planes at k - 1.
+    uint32_t *hdr;      // [n_pad] base_val | best_d(level 0) << 8 | m << 16 | popped << 21
+    float *integ0;      // [n_pad]
+    float *dt0;         // [n_pad]
+    float *bdt0;        // [n_pad]
     float *lastf;       // [n_pad] last_fired_t (AbsoluteT)
-    float *lv_integ;    // [max_depth][n_pad]
-    float *lv_dt;       // [max_depth][n_pad]
-    float *lv_bdt;      // [max_depth][n_pad]
-    uint8_t *lv_bd;     // [max_depth][n_pad]  best_d (d = fired_d(best_d))
+    float *dv_integ;    // [max_depth - 1][n_pad]   (nullptr until the first generic batch)
+    float *dv_dt;
+    float *dv_bdt;
+    uint8_t *dv_bd;     // best_d (d = fired_d(best_d))
     uint8_t *running;   // optional running_intensities side plane, or nullptr
     size_t plane_stride;  // n_pad
     // this frame
@@ -57,9 +72,9 @@ struct FrameArgs {
     uint64_t out_cap;
     uint64_t *frame_offsets;  // [frame_idx] = first event of the frame, [frame_idx+1] = end
     uint32_t frame_idx;
-    // ordered compaction, stage 1 (frame kernel): per wave segment of 256 units
-    uint2 *park;          // [num_waves][park_stride] {t, d | unit_in_wave<<8 | final_offset_in_wave<<16}
-    uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked events (high 16)
+    // ordered compaction, stage 1 (frame kernel): per wave segment
+    uint8_t *park;        // [num_waves][park_bytes] parked records (LeanRec, or {t, d | unit<<8 | offset<<16})
+    uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked records (high 16)
     // stage 2 (scan kernel): exclusive prefix of the low halves of wtot, frame total
     uint32_t *wpref;      // [num_waves]
     uint32_t *ftot;       // [1] events of the frame
@@ -67,21 +82,21 @@ struct FrameArgs {
     uint32_t n_units;
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t generic;     // 1: pixels deeper than one fired level are possible (GENERIC kernel variants)
-    uint32_t park4;       // 1: the frame kernel parks compact 4-byte records (non-generic DeltaT variants)
-    StepConsts sc;
+    uint32_t lean;        // 1: the batch runs the lean K1 (16-byte LeanRec records); 0: generic (8-byte per event)
+    uint32_t abs_t;       // TimeMode::AbsoluteT (record decoding)
+    StepConsts sc;        // running_t / cth are filled per frame from the table
 };
 
 // Device-resident description of one batch of frames.  The kernels take (BatchArgs*, f), so
 // a captured hipGraph of T frames can be replayed for ANY batch of T frames: the host only
-// rewrites this struct (and the running_t table) before launching the graph.
+// rewrites this struct (and the per-frame table) before launching the graph.
 struct BatchArgs {
-    FrameArgs base;           // per-frame fields (frame, frame_idx, park, wtot, wpref, ftot, sc.running_t) are derived
+    FrameArgs base;           // per-frame fields (frame, frame_idx, park, wtot, wpref, ftot, sc.running_t, sc.cth) are derived
     const uint8_t *frames;    // packed [T][n_units]
-    const float *running_t;   // [T] PixelArena::running_t before each frame's integrate
+    const FrameTab *ftab;     // [T]
     // compaction scratch: a ring of `slots` frames
-    uint2 *park_ring;         // [slots][num_waves][park_stride]
-    uint32_t park_stride;     // parked-event capacity of one segment (kParkPerWave, or more for generic batches)
+    uint8_t *park_ring;       // [slots][num_waves][park_bytes]
+    uint32_t park_bytes;      // scratch of one segment (kLeanParkBytes, or kGenRecBytes * parked-event capacity)
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [slots]
@@ -93,9 +108,10 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     const uint32_t slot = f % b->slots;
     a.frame = b->frames + (size_t)f * a.n_units;
     a.frame_idx = f;
-    a.sc.running_t = b->running_t[f];
+    a.sc.running_t = b->ftab[f].running_t;
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
-    a.park = b->park_ring + (size_t)slot * a.num_waves * b->park_stride;
+    a.sc.cth = b->ftab[f].cth;
+    a.park = b->park_ring + (size_t)slot * a.num_waves * b->park_bytes;
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
     a.ftot = b->ftot_ring + slot;
@@ -107,18 +123,17 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
 // K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking); the same grid also
-// expands frames [exp_f0, exp_f0 + exp_nf) of the previous, already scanned chunk (exp_nf may be 0)
+// expands frames [exp_f0, exp_f0 + exp_nf) of an earlier, already scanned chunk (exp_nf may be 0)
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
                               uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream);
-// frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked events
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
+// frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                               hipStream_t stream);
-hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream);
+                               uint32_t variant, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,
                                       uint32_t chunk_rows, uint32_t num_chunks, uint32_t *offsets,

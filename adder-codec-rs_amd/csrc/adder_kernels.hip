@@ -5,27 +5,26 @@
 // every pixel-channel runs integrate_for_px (video.rs:1318-1380) and the emitted events
 // are gathered in raster order (y, x, c, per-pixel emission order).
 //
-//   K1 adder_frame_kernel   one lane = 2 consecutive pixel-channels, one wave = one
-//        128-unit segment.  Loads the header word, the frame bytes and level 0 of the arena
-//        as 8-byte-per-lane vectors (structure-of-arrays state resident in HBM across
-//        frames, level-planar: plane k holds every pixel's k-th fired node, so the headline
-//        mode never goes past plane 0) and steps up to 16 consecutive frames with the state
-//        in registers.  Per frame: the lean step (step_fast) once per pixel, its <= 3 events
-//        held in registers, a DPP prefix scan over the WAVE (no barrier, no atomics, no
-//        LDS), the events written compacted into the wave's scratch segment, the segment's
-//        event count to wtot.
+//   K1 adder_lean_kernel / adder_frame_kernel   one lane = kUnitsPerLane consecutive
+//        pixel-channels, one wave = one segment.  Loads level 0 of the arena (16 bytes per
+//        unit, structure-of-arrays planes resident in HBM across frames) and the frame bytes as
+//        coalesced vectors and steps up to 16 consecutive frames with the state in registers.
+//        Per frame and unit the step leaves at most ONE 16-byte record (the lean variants: the raw
+//        material of its <= 3 events) -- the records are compacted per wave with ballot + mbcnt
+//        (no barrier, no atomics, no LDS) into the frame's scratch segment, the segment's event and
+//        record counts go to wtot.
 //   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block per
 //        frame) + adder_offsets_kernel (the frame_offsets chain); run once per CHUNK of frames.
-//   K2 expand_block         reads the parked events linearly and writes each 12-byte event
-//        to its final slot of the ordered stream (coordinates from the unit index).  Runs
-//        as extra workgroups inside K1's grid (the previous chunk's frames: memory-bound
+//   K2 expand_block         reads the parked records linearly, decodes them and writes each 12-byte
+//        event to its final slot of the ordered stream (coordinates from the unit index).  Runs
+//        as extra workgroups inside K1's grid (an earlier chunk's frames: memory-bound
 //        work sharing the SIMDs with K1's VALU-bound step) and as adder_expand_kernel for
-//        the last chunk of a batch.
+//        the last chunks of a batch.
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
 // loop and nothing that can hang.  Pixels whose arena is deeper than one fired level
 // (Normal mode, or delta_t_max > time_spanned) take the full arena walk (exec_step)
-// inside the GENERIC instantiations of K1.
+// inside the GENERIC instantiations (adder_frame_kernel).
 // HBM/VALU-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,9 +35,6 @@
 namespace adder {
 
 constexpr uint32_t kWave = 64;
-// compact parked records (non-generic DeltaT variants)
-constexpr uint32_t kParkWideT = 0x1ffffu;                 // t field marker: the value is in the overflow list
-constexpr uint32_t kParkOverflowBase = kParkPerWave;      // dword index of the overflow list in a segment's scratch
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
 
 __device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
@@ -54,20 +50,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, uint32_t lan
     return x;
 }
 
+// levels k >= 1 of one unit, straight from / to the deep planes (index k - 1)
 struct DeepGlobal {
     float *integ, *dt, *bdt;
     uint8_t *bd;
     size_t stride;
     size_t u;
     __device__ __forceinline__ void load(uint32_t k, Node &n) const {
-        const size_t i = (size_t)k * stride + u;
+        const size_t i = (size_t)(k - 1u) * stride + u;
         n.integ = integ[i];
         n.dt = dt[i];
         n.bdt = bdt[i];
         n.bd = bd[i];
     }
     __device__ __forceinline__ void store(uint32_t k, const Node &n) const {
-        const size_t i = (size_t)k * stride + u;
+        const size_t i = (size_t)(k - 1u) * stride + u;
         integ[i] = n.integ;
         dt[i] = n.dt;
         bdt[i] = n.bdt;
@@ -77,25 +74,6 @@ struct DeepGlobal {
 
 struct __attribute__((aligned(4))) EventWords {
     uint32_t xy, cd, t;
-};
-
-struct EmitGlobal {
-    EventWords *out;
-    uint64_t pos, cap;
-    uint32_t xy, c;
-    bool dropped;
-    __device__ __forceinline__ void operator()(uint32_t d, uint32_t t) {
-        if (pos < cap) {
-            EventWords w;
-            w.xy = xy;
-            w.cd = c | (d << 8);
-            w.t = t;
-            out[pos] = w;
-        } else {
-            dropped = true;
-        }
-        ++pos;
-    }
 };
 
 // exec_step's events of one generic unit, parked with their final in-segment offset
@@ -109,11 +87,6 @@ struct EmitPark {
     }
 };
 
-// ------------------------------------------------------------------------------------------
-// K1 building blocks.  GENERIC = false is used when no pixel can ever be deeper than one fired
-// level (Collapse with delta_t_max <= time_spanned): the eligibility test and the full arena
-// walk are compiled out.
-// ------------------------------------------------------------------------------------------
 // kUnitsPerLane consecutive values as one vector access
 template <class T, int N>
 struct VecOf;
@@ -200,79 +173,265 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
     return x;
 }
 
+// ------------------------------------------------------------------------------------------
+// K1, lean variants (Collapse with delta_t_max <= time_spanned: BASELINE configs 2-4).
 // One segment (64 lanes x kUnitsPerLane units) through `nb` consecutive frames starting at
 // a.frame_idx.  The pixel state lives in registers for the whole run (temporal blocking): it
 // is read from HBM once and written back once; per frame only the input bytes are loaded
-// (one frame ahead) and the segment's events are compacted into that frame's scratch slot.
-// nb > 1 is only used when no pixel can need the generic kernel.
-// A segment's state as loaded (one memory round trip, nothing consumed yet)
-struct RawSegment {
+// (one frame ahead) and the segment's records are compacted into that frame's scratch slot.
+// ------------------------------------------------------------------------------------------
+struct LeanRaw {  // a segment's state as loaded (one memory round trip, nothing consumed yet)
     uint32_t hdrv[kUnitsPerLane];
-    float liv[kUnitsPerLane], ldv[kUnitsPerLane], lbv[kUnitsPerLane], lfv[kUnitsPerLane];
-    uint8_t bdv[kUnitsPerLane];
+    float iv[kUnitsPerLane], dv[kUnitsPerLane], bv[kUnitsPerLane], lfv[kUnitsPerLane];
     uint32_t vin_w;
 };
 
-// SPECULATE: level 0 is fetched together with the header word instead of after it (the
-// depth-1 kernels: one round trip instead of two; nearly every unit has a fired level)
-template <bool ABS_T, bool SPECULATE>
-__device__ __forceinline__ void load_raw(const FrameArgs &a, uint32_t u0, bool full, RawSegment &r) {
-    constexpr uint32_t N = kUnitsPerLane;
+template <bool ABS_T>
+__device__ __forceinline__ void lean_load(const FrameArgs &a, uint32_t u0, bool full, LeanRaw &r) {
     load_vec(a.hdr, u0, r.hdrv);
     r.vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
+    // level 0 is fetched whether or not the unit has one (m == 0 leaves it unread by the step)
+    load_vec(a.integ0, u0, r.iv);
+    load_vec(a.dt0, u0, r.dv);
+    load_vec(a.bdt0, u0, r.bv);
+    if (ABS_T) {
+        load_vec(a.lastf, u0, r.lfv);
+    } else {
 #pragma unroll
-    for (uint32_t j = 0; j < N; ++j) {
-        r.liv[j] = r.ldv[j] = r.lbv[j] = r.lfv[j] = 0.0f;
-        r.bdv[j] = 0;
+        for (uint32_t j = 0; j < kUnitsPerLane; ++j) r.lfv[j] = 0.0f;
     }
-    bool any = true;
-    if (!SPECULATE) {
-        uint32_t hor = 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) hor |= r.hdrv[j];
-        any = (hor >> 24) & kFlagMMask;
-    }
-    if (any) {
-        load_vec(a.lv_integ, u0, r.liv);
-        load_vec(a.lv_dt, u0, r.ldv);
-        load_vec(a.lv_bdt, u0, r.lbv);
-        load_vec(a.lv_bd, u0, r.bdv);
-    }
-    if (ABS_T) load_vec(a.lastf, u0, r.lfv);
 }
 
-template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                            uint32_t u0, uint32_t gw, uint32_t lane, const RawSegment &raw) {
+// FULL: the whole wave lies inside the band (every wave but possibly the band's last ones): no
+// per-unit bounds handling inside the frame loop.
+template <bool ABS_T, bool FULL>
+__device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
+                                            uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
+                                            uint8_t *lds_in) {
     constexpr uint32_t N = kUnitsPerLane;
-    constexpr bool PARK4 = !GENERIC && !ABS_T;  // compact parked records (see below and expand_block)
-    // whole wave inside the band: the common case takes the unguarded vector input load
-    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-    FastPx px[N];
-    uint32_t vin_w = raw.vin_w;
+    using L = WaveLanes;
+    LeanPxT<L> px[N];
 #pragma unroll
-    for (uint32_t j = 0; j < N; ++j) {
-        PxState st;
-        st.hdr = raw.hdrv[j];
-        st.n0.integ = raw.liv[j];
-        st.n0.dt = raw.ldv[j];
-        st.n0.bdt = raw.lbv[j];
-        st.n0.bd = raw.bdv[j];
-        st.lastf = raw.lfv[j];
-        px[j] = unpack_px(st);
-        if (GENERIC) px[j].has0 = (raw.hdrv[j] >> 24) & kFlagMMask;  // keep the full m for the generic test
-    }
+    for (uint32_t j = 0; j < N; ++j) px[j] = lean_unpack<L>(raw.hdrv[j], raw.iv[j], raw.dv[j], raw.bv[j], raw.lfv[j]);
     StepConsts sc = a.sc;
-    uint32_t gmask = 0;  // pixels left to the generic kernel (nb == 1 only)
-    // running_t of the launch's frames (nb <= kMaxFramesPerLaunch <= 64): one load, then a lane read per frame
-    const uint32_t rt_vec = (lane < kMaxFramesPerLaunch && lane < nb) ? __float_as_uint(b->running_t[a.frame_idx + lane]) : 0u;
+    const float T = sc.time_spanned;
 
     // wave-uniform bases of the per-frame accesses, in SGPRs
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
+    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    const uint32_t f0 = __builtin_amdgcn_readfirstlane(a.frame_idx);
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(f0 % slots_u);
+    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
+    // the launch's rows of the per-frame table (nb <= kMaxFramesPerLaunch <= 64): one vector load, then a
+    // lane read per frame -- no memory wait inside the frame loop
+    uint32_t tab_cth = 0u, tab_rt = 0u;
+    if (lane < nb) {
+        const uint2 e = gload<uint2>(uniform_ptr(b->ftab), (f0 + lane) * (uint32_t)sizeof(FrameTab));
+        tab_rt = e.x;
+        tab_cth = e.y;
+    }
+    // the segment's scratch of the launch's first frame and the next frame's input bytes: 64-bit
+    // uniform pointers advanced by adds (the ring wraps at `slots`)
+    const size_t frame_park = (size_t)num_waves_u * park_bytes_u;
+    uint8_t *const park0 = uniform_ptr(b->park_ring) + (size_t)sgw * park_bytes_u;
+    uint8_t *seg = park0 + (size_t)slot0 * frame_park;
+    // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
+    // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
+    // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
+    // i.e. the acknowledgement of the previous frame's stores.  LDS reads wait on lgkmcnt instead, so the
+    // loop only ever issues stores to memory.
+    using InT = typename VecOf<uint8_t, N>::type;
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame][lane]
+    {
+        // (no control flow between the loads: frames past the launch's last one re-read that one)
+        const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+        uint32_t vin_all[kMaxFramesPerLaunch];
+#pragma unroll
+        for (uint32_t k = 0; k < kMaxFramesPerLaunch; ++k) {
+            const uint32_t kk = k < nb ? k : nb - 1u;  // uniform
+            vin_all[k] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kMaxFramesPerLaunch; ++k) in_lds[k * kWave] = (InT)vin_all[k];
+    }
+    uint32_t vin_w = raw.vin_w;
+    uint32_t slot = slot0;
+    uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
+    uint64_t active[N];  // units inside the band (the rest of the wave's segment is padding)
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
+
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t next_w = i + 1u < nb ? (uint32_t)in_lds[(i + 1u) * kWave] : 0u;  // one frame ahead
+        const uint32_t cth = __builtin_amdgcn_readlane(tab_cth, i);
+        if (ABS_T) sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
+
+        // ---------------- the step: <= one record per unit ----------------
+        LeanRec rec[N];
+        uint64_t mrec[N];
+        uint32_t nev = 0u, nrec = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            const uint32_t tag = (lane * N + j) << kLeanUnitShift;
+            LeanFlagsT<L> fl = lean_step<ABS_T, L>(px[j], v, cth, T, sc, tag, rec[j]);
+            if (!FULL) {
+                // units past the band's end are padding: their state may be stepped freely, only
+                // their events must be suppressed
+                fl.a &= active[j];
+                fl.b &= active[j];
+                fl.c &= active[j];
+            }
+            mrec[j] = fl.a | fl.c;
+            nrec += (uint32_t)__popcll(mrec[j]);
+            nev += (uint32_t)__popcll(fl.a) + (uint32_t)__popcll(fl.b) + (uint32_t)__popcll(fl.c);
+        }
+        // ---------------- wave-level ordered compaction into the frame's segment ----------------
+        // records of lower lanes (mbcnt over the record masks), then the lane's own earlier units
+        uint32_t pos = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j)
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mrec[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mrec[j], pos));
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const bool has = L::lane(mrec[j]);
+            if (has) gstore(seg, pos * kLeanRecBytes, make_uint4(rec[j].ta, rec[j].wa, rec[j].tc, rec[j].wc));
+            pos += has ? 1u : 0u;
+        }
+        wt = lane == i ? (nev | (nrec << 16)) : wt;
+        vin_w = next_w;
+        slot += 1u;
+        seg += frame_park;
+        if (slot == slots_u) {
+            slot = 0u;
+            seg = park0;
+        }
+    }
+
+    // ---------------- per-frame segment totals ----------------
+    if (lane < nb) {
+        uint32_t s = slot0 + lane;
+        s = s >= slots_u ? s - slots_u : s;
+        gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
+    }
+
+    // ---------------- state back to HBM ----------------
+    {
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N], lfv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            hdrv[j] = lean_hdr(px[j]);
+            iv[j] = px[j].integ;
+            dv[j] = px[j].dt;
+            bv[j] = px[j].bdt;
+            lfv[j] = px[j].lastf;
+        }
+        store_vec(a.hdr, u0, hdrv);
+        store_vec(a.integ0, u0, iv);
+        store_vec(a.dt0, u0, dv);
+        store_vec(a.bdt0, u0, bv);
+        if (ABS_T) store_vec(a.lastf, u0, lfv);
+        if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j)
+                if (L::lane(active[j] & px[j].has0))
+                    a.running[u0 + j] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(px[j].thr)),
+                                                                f32_as_u32(px[j].bdt), (double)sc.ref_time);
+        }
+    }
+}
+
+template <bool ABS_T>
+__device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
+                                                 uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
+                                                 uint8_t *lds_in) {
+    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+    if (full)
+        lean_frames<ABS_T, true>(b, a, nb, u0, gw, lane, raw, lds_in);
+    else
+        lean_frames<ABS_T, false>(b, a, nb, u0, gw, lane, raw, lds_in);
+}
+
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_kernel(
+    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
+    const uint32_t bid = blockIdx.x;
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t gw = bid * kWavesPerBlock + tid / kWave;  // the wave's segment
+    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
+    LeanRaw raw;
+    lean_load<ABS_T>(a, u0, full, raw);
+    lean_run_segment<ABS_T>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
+}
+
+// Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes TWO
+// consecutive segments and issues the loads of both before it steps the first, so the second
+// segment's memory round trip hides under the first one's step (with one segment per wave all
+// resident waves load, then all compute, then all store, in lock step).
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, 6) void adder_lean1_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * 2u;
+    if (gw0 >= a.num_waves) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kWaveUnits];  // nb == 1: one row
+    LeanRaw raw[2];
+#pragma unroll
+    for (uint32_t s = 0; s < 2u; ++s) {
+        const uint32_t gw = gw0 + s;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        lean_load<ABS_T>(a, gw * kWaveUnits + lane * kUnitsPerLane, full, raw[s]);
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < 2u; ++s) {
+        const uint32_t gw = gw0 + s;
+        lean_run_segment<ABS_T>(b, a, 1u, gw * kWaveUnits + lane * kUnitsPerLane, gw, lane, raw[s], s_in[tid / kWave]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, generic variants (Normal mode, or delta_t_max > time_spanned): any arena depth.  Units
+// with at most one fired level before and after the step take the branch-free step_fast, whose
+// <= 3 events stay in registers until a DPP prefix scan over the wave has ordered them; deeper
+// units are counted with plan_count before the scan and then stepped in place by the full arena
+// walk (exec_step, levels >= 1 straight from / to the deep planes), parking their events behind
+// the lane's fast ones.  Parked record: 8 bytes {t, d | unit << 8 | final offset << 16}.
+// ------------------------------------------------------------------------------------------
+template <bool COLLAPSE, bool ABS_T>
+__device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
+                                                uint32_t u0, uint32_t gw, uint32_t lane) {
+    constexpr uint32_t N = kUnitsPerLane;
+    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+    PxState px[N];
+    uint32_t vin_w;
+    {
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N], lfv[N];
+        load_vec(a.hdr, u0, hdrv);
+        vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
+        load_vec(a.integ0, u0, iv);
+        load_vec(a.dt0, u0, dv);
+        load_vec(a.bdt0, u0, bv);
+        if (ABS_T) load_vec(a.lastf, u0, lfv);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) px[j] = px_unpack(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
+    }
+    StepConsts sc = a.sc;
+
+    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
     const uint8_t *const frames_u = uniform_ptr(b->frames);
-    uint2 *const park_ring_u = uniform_ptr(b->park_ring);
+    const FrameTab *const ftab_u = uniform_ptr(b->ftab);
+    uint8_t *const park_ring_u = uniform_ptr(b->park_ring);
     uint32_t *const wtot_ring_u = uniform_ptr(b->wtot_ring);
-    const uint32_t park_stride_u = __builtin_amdgcn_readfirstlane(b->park_stride);
+    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
     const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
     const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
     const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
@@ -283,14 +442,16 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         uint32_t next_w = 0u;
         if (i + 1 < nb)
             next_w = load_input(frames_u + (size_t)(f + 1) * n_units_u, u0, full ? 0xffffffffu : n_units_u);
-        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(rt_vec, i));
+        const FrameTab ft = ftab_u[f];
+        sc.running_t = ft.running_t;
         sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
+        sc.cth = ft.cth;
 
         // ---------------- the step ----------------
         uint32_t nl = 0;    // events parked by this lane's fast units
         uint32_t ngen = 0;  // events its generic units will park
         uint32_t cnts = 0;  // per-pixel event counts, 8 bits each
-        gmask = 0;
+        uint32_t gmask = 0; // units left to exec_step
         FastEvents fe[N];   // <= 3 events per fast unit, kept in registers until the scan is done
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) fe[j].mask = 0u;
@@ -300,22 +461,14 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
             // units past the band's end are padding: their state may be stepped freely, only
             // their events must be suppressed
             const bool active = full || u0 + j < a.n_units;
-            bool fast = true;
-            PxState st;
-            if (GENERIC) {
-                st.hdr = (pack_hdr(px[j]) & 0x00ffffffu) | ((px[j].has0 | (px[j].popped << 5)) << 24);
-                st.n0 = px[j].n0;
-                st.lastf = px[j].lastf;
-                fast = fast_eligible<COLLAPSE>(st, v);
-            }
-            if (fast) {
+            if (fast_eligible<COLLAPSE>(px[j], v, sc.cth)) {
                 step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe[j]);
                 fe[j].mask = active ? fe[j].mask : 0u;
                 const uint32_t c = (uint32_t)__popc(fe[j].mask);
                 cnts |= c << (8 * j);
                 nl += c;
             } else if (active) {
-                const uint32_t planned = plan_count(st, v, sc);
+                const uint32_t planned = plan_count(px[j], v, sc);
                 cnts |= planned << (8 * j);
                 gmask |= 1u << j;
                 ngen += planned;
@@ -336,57 +489,15 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
         const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
         // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
         const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
-        uint2 *const seg = park_ring_u + seg_idx * park_stride_u;  // uniform
-        if (PARK4) {
-            // compact 4-byte records {t (17 bits) | d << 17 | unit << 25}; the parked position IS the
-            // final in-segment offset here (every event of these variants is a fast one).  d = 255
-            // (D_EMPTY) carries no t: it is the frame's running_t, which the expansion knows.  A t that
-            // does not fit (>= 2^17 - 1 ticks: a run of more than 500 frames) is written as the marker
-            // kParkWideT and its value goes to the segment's overflow list (second half of the
-            // segment's scratch), at the rank of the record among the segment's marked records.
-            const uint32_t poff4 = (excl >> 16) * 4u;
-            uint32_t e = 0, wide = 0;  // wide: bit per event slot (3 per unit) whose t needs the overflow list
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                const uint32_t m = fe[j].mask;
-                const uint32_t tag = (lane * N + j) << 25;
-                const uint32_t ts[3] = {fe[j].ta, fe[j].tb, fe[j].tc};
-                const uint32_t ds[3] = {fe[j].da, fe[j].db, fe[j].dc};
-#pragma unroll
-                for (uint32_t q = 0; q < 3u; ++q) {
-                    const bool on = (m >> q) & 1u;
-                    const bool w = on && ds[q] != kDEmpty && ts[q] >= kParkWideT;
-                    const uint32_t tt = ds[q] == kDEmpty ? 0u : (w ? kParkWideT : ts[q]);
-                    if (on) gstore<uint32_t>(seg, poff4 + 4u * e, tt | (ds[q] << 17) | tag);
-                    wide |= w ? 1u << (3u * j + q) : 0u;
-                    e += on ? 1u : 0u;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(wide != 0u) != 0ull) {  // rare
-                const uint32_t nw = (uint32_t)__popc(wide);
-                uint32_t rank = wave_inclusive_scan_dpp(nw) - nw;  // marked records of lower lanes
-#pragma unroll
-                for (uint32_t j = 0; j < N; ++j) {
-                    const uint32_t ts[3] = {fe[j].ta, fe[j].tb, fe[j].tc};
-#pragma unroll
-                    for (uint32_t q = 0; q < 3u; ++q)
-                        if ((wide >> (3u * j + q)) & 1u) {
-                            gstore<uint32_t>(seg, (kParkOverflowBase + rank) * 4u, ts[q]);
-                            rank += 1u;
-                        }
-                }
-            }
-        } else {
-        const uint32_t poff = (excl >> 16) * (uint32_t)sizeof(uint2);  // the lane's first parked slot
-        // the lane's fast events -> its range of the segment, each with {t, d | unit << 8 |
-        // final in-segment offset << 16}
+        uint8_t *const seg = park_ring_u + seg_idx * park_bytes_u;  // uniform
+        const uint32_t poff = (excl >> 16) * kGenRecBytes;  // the lane's first parked slot
         {
             uint32_t e = 0;
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
                 const uint32_t m = fe[j].mask;
                 const uint32_t tag = (lane * N + j) << 8;
-                uint32_t off = GENERIC ? lane_off + ((pre >> (8u * j)) & 0xffu) : lane_off + e;
+                uint32_t off = lane_off + ((pre >> (8u * j)) & 0xffu);
                 if (m & 1u) gstore(seg, poff + 8u * e, make_uint2(fe[j].ta, fe[j].da | tag | (off << 16)));
                 e += m & 1u;
                 off += m & 1u;
@@ -397,26 +508,19 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
                 e += m >> 2;
             }
         }
-        }
-        if (GENERIC && gmask) {
+        if (gmask) {
             // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
-            // straight from / to the level planes; their events are parked behind the lane's
+            // straight from / to the deep planes; their events are parked behind the lane's
             // fast ones (every parked event carries its final offset, so the order is free)
-            uint2 *gdst = seg + (excl >> 16) + nl;
+            uint2 *gdst = reinterpret_cast<uint2 *>(seg) + (excl >> 16) + nl;
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
                 if (!((gmask >> j) & 1u)) continue;
                 const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
-                PxState st;
-                st.hdr = pack_hdr(px[j]);
-                st.n0 = px[j].n0;
-                st.lastf = px[j].lastf;
-                DeepGlobal deep{a.lv_integ, a.lv_dt, a.lv_bdt, a.lv_bd, a.plane_stride, (size_t)u0 + j};
+                DeepGlobal deep{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
                 EmitPark em{gdst, (lane * N + j) << 8, lane_off + ((pre >> (8 * j)) & 0xffu)};
-                if (!exec_step(st, v, sc, deep, em)) raise(a.status, kStatusDepth);
+                if (!exec_step(px[j], v, sc, deep, em)) raise(a.status, kStatusDepth);
                 gdst = em.dst;
-                px[j] = unpack_px(st);
-                px[j].has0 = (st.hdr >> 24) & kFlagMMask;  // keep the full m
             }
         }
         vin_w = next_w;
@@ -425,107 +529,39 @@ __device__ __forceinline__ void run_segment(const BatchArgs *__restrict__ b, con
     // ---------------- state back to HBM ----------------
     {
         uint32_t hdrv[N];
-        float liv[N], ldv[N], lbv[N], lfv[N];
-        uint8_t bdv[N];
-        uint32_t hor = 0u;
+        float iv[N], dv[N], bv[N], lfv[N];
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            hdrv[j] = GENERIC ? ((pack_hdr(px[j]) & 0x00ffffffu) | ((px[j].has0 | (px[j].popped << 5)) << 24))
-                              : pack_hdr(px[j]);
-            hor |= hdrv[j];
-            liv[j] = px[j].n0.integ;
-            ldv[j] = px[j].n0.dt;
-            lbv[j] = px[j].n0.bdt;
-            bdv[j] = (uint8_t)px[j].n0.bd;
+            hdrv[j] = px_hdr(px[j]);
+            iv[j] = px[j].n0.integ;
+            dv[j] = px[j].n0.dt;
+            bv[j] = px[j].n0.bdt;
             lfv[j] = px[j].lastf;
         }
         store_vec(a.hdr, u0, hdrv);
-        if ((hor >> 24) & kFlagMMask) {
-            store_vec(a.lv_integ, u0, liv);
-            store_vec(a.lv_dt, u0, ldv);
-            store_vec(a.lv_bdt, u0, lbv);
-            store_vec(a.lv_bd, u0, bdv);
-        }
+        store_vec(a.integ0, u0, iv);
+        store_vec(a.dt0, u0, dv);
+        store_vec(a.bdt0, u0, bv);
         if (ABS_T) store_vec(a.lastf, u0, lfv);
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
-                if (u0 + j < a.n_units && ((hdrv[j] >> 24) & kFlagMMask))
+                if (u0 + j < a.n_units && px[j].m != 0u)
                     a.running[u0 + j] = (uint8_t)frame_value_u8(px[j].n0.bd, f32_as_u32(px[j].n0.bdt),
                                                                 (double)sc.ref_time);
         }
     }
 }
 
-__device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock);
-
-// K1.  The grid holds the workgroups that step frames [f, f + nb) (a wave per segment) and,
-// interleaved with them in dispatch order (the scarcer kind spread evenly through the other,
-// see adder_launch_frame), the workgroups that expand frames
-// [exp_f0, exp_f0 + exp_nf) of the PREVIOUS chunk (already scanned).  The expansion is
-// memory-bound and the step VALU-bound, so sharing the SIMDs overlaps them; nothing in one
-// role waits for the other.
-template <bool COLLAPSE, bool ABS_T, bool GENERIC>
-__global__ __launch_bounds__(kBlockThreads, GENERIC ? 4 : kFrameKernelWavesPerSimd) void adder_frame_kernel(
-    const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb, uint32_t exp_f0, uint32_t exp_blocks_per_frame,
-    uint32_t grp_steps, uint32_t grp_exps, uint32_t groups, uint32_t rem_is_step) {
-    // dispatch order: `groups` groups of (grp_steps step workgroups, grp_exps expansion workgroups),
-    // then whatever is left of either kind
-    uint32_t bid = blockIdx.x;
-    if (exp_blocks_per_frame != 0u) {
-        const uint32_t span = grp_steps + grp_exps;
-        const uint32_t inter = groups * span;
-        bool is_step;
-        uint32_t idx;
-        if (bid < inter) {
-            const uint32_t g = bid / span, k = bid - g * span;
-            is_step = k < grp_steps;
-            idx = is_step ? g * grp_steps + k : g * grp_exps + (k - grp_steps);
-        } else {  // only one kind has a remainder (see adder_launch_frame)
-            is_step = rem_is_step != 0u;
-            idx = (is_step ? groups * grp_steps : groups * grp_exps) + (bid - inter);
-        }
-        if (!is_step) {
-            const uint32_t ef = idx / exp_blocks_per_frame;
-            expand_block(b, exp_f0 + ef, idx - ef * exp_blocks_per_frame);
-            return;
-        }
-        bid = idx;
-    }
-    const FrameArgs a = frame_args(b, f);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw = bid * kWavesPerBlock + tid / kWave;  // the wave's segment
-    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-    RawSegment raw;
-    load_raw<ABS_T, false>(a, u0, full, raw);
-    run_segment<COLLAPSE, ABS_T, GENERIC>(b, a, nb, u0, gw, lane, raw);
-}
-
-// K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes TWO
-// consecutive segments and issues the loads of both before it steps the first, so the second
-// segment's memory round trip hides under the first one's step (with one segment per wave all
-// resident waves load, then all compute, then all store, in lock step).
 template <bool COLLAPSE, bool ABS_T>
-__global__ __launch_bounds__(kBlockThreads, 6) void adder_frame1_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+__global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f,
+                                                                      uint32_t nb) {
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * 2u;
-    if (gw0 >= a.num_waves) return;
-    RawSegment raw[2];
-#pragma unroll
-    for (uint32_t s = 0; s < 2u; ++s) {
-        const uint32_t gw = gw0 + s;
-        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        load_raw<ABS_T, true>(a, gw * kWaveUnits + lane * kUnitsPerLane, full, raw[s]);
-    }
-#pragma unroll
-    for (uint32_t s = 0; s < 2u; ++s) {
-        const uint32_t gw = gw0 + s;
-        run_segment<COLLAPSE, ABS_T, false>(b, a, 1u, gw * kWaveUnits + lane * kUnitsPerLane, gw, lane, raw[s]);
-    }
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
+    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+    gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -587,133 +623,258 @@ __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: parked events -> final 12-byte events of the ordered stream (blockIdx.y = frame
-// inside the chunk).  A segment parks only a few dozen events, so a wave per segment would
-// be nothing but start-up latency (kernel arguments -> metadata -> parked slots -> store).
-// Each wave therefore takes kExpandSegs consecutive segments and issues ALL their loads --
-// metadata and, speculatively, the first 64 parked slots of every segment -- before it
-// consumes any of them: one memory round trip per wave.
+// K2: parked records -> final 12-byte events of the ordered stream.  A segment parks only a few
+// dozen records, so a wave per segment would be nothing but start-up latency.  Each wave takes
+// kExpandSegs consecutive segments of one frame: their events are CONTIGUOUS in the stream (the scan
+// gave segment s the events [wpref[s], wpref[s+1])), so the wave decodes its records into an LDS
+// staging buffer in stream order and writes the buffer out with full-width, 16-byte aligned,
+// coalesced stores (a lane writing its own 12-byte events straight to HBM made the kernel
+// store-issue bound: three sparse dwordx3 stores per 64 records).
+// Lean batches park one LeanRec per unit with events: the wave decodes 64 records at a time
+// (lean_decode: <= 3 events each) and a DPP scan of the per-record event counts gives each
+// event its place; generic batches park one 8-byte record per event with its final offset.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
+constexpr uint32_t kXbufEvents = 640;                 // staging capacity of one wave, in events
+constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
+
+struct UnitCoord {  // (row, offset in row) of a segment's first unit + the plane geometry (uniform)
+    uint32_t y0, rem0, rowlen, channels, row_begin;
+    bool one_wrap;
+};
+__device__ __forceinline__ uint32_t coord_xy_c(const UnitCoord &uc, uint32_t unit, uint32_t &c) {
+    uint32_t rem = uc.rem0 + unit;
+    uint32_t y = uc.y0;
+    if (uc.one_wrap) {
+        const bool wrap = rem >= uc.rowlen;
+        rem -= wrap ? uc.rowlen : 0u;
+        y += wrap ? 1u : 0u;
+    } else {
+        const uint32_t dq = rem / uc.rowlen;
+        rem -= dq * uc.rowlen;
+        y += dq;
+    }
+    uint32_t x = rem;
+    c = 0xffu;
+    if (uc.channels == 3u) {
+        x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
+        c = rem - 3u * x;
+    }
+    return x | ((y + uc.row_begin) << 16);
+}
+
+// The wave's staging buffer -> the stream.  xb[phase .. phase + 3 n) holds n events whose first dword
+// goes to dword `gd0` of the output (phase == gd0 & 3, so 16-byte blocks of the buffer are 16-byte
+// blocks of the destination).  Uniform arguments; returns nothing, the caller resets its fill.
+__device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, uint32_t n, uint32_t *out_dw,
+                                           uint64_t gd0, uint32_t lane) {
+    const uint32_t nd = n * 3u;
+    uint32_t head = (4u - phase) & 3u;
+    head = head < nd ? head : nd;
+    uint32_t *const dst = out_dw + gd0;  // uniform 64-bit base; the lanes add 32-bit offsets
+    if (lane < head) gstore<uint32_t>(dst, lane * 4u, xb[phase + lane]);
+    const uint32_t body = (nd - head) >> 2;  // whole 16-byte blocks
+    const uint32_t b0 = phase + head;        // a multiple of 4
+    for (uint32_t k = lane; k < body; k += kWave) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
+        gstore<uint4>(dst, (head + 4u * k) * 4u, v);
+    }
+    const uint32_t tail = (nd - head) & 3u;
+    if (lane < tail) gstore<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
+}
+
+// Stages the <= 3 events of one decoded lean record at dword w of the buffer.
+__device__ __forceinline__ void stage_lean(uint32_t *xb, uint32_t w, const LeanEvents &e, uint32_t xy, uint32_t c) {
+    if (e.a) {
+        xb[w] = xy;
+        xb[w + 1u] = c | (e.da << 8);
+        xb[w + 2u] = e.ta;
+        w += 3u;
+    }
+    if (e.b) {
+        xb[w] = xy;
+        xb[w + 1u] = c | (kDEmpty << 8);
+        xb[w + 2u] = e.tb;
+        w += 3u;
+    }
+    if (e.c) {
+        xb[w] = xy;
+        xb[w + 1u] = c | (e.dc << 8);
+        xb[w + 2u] = e.tc;
+    }
+}
+
 // One workgroup's share of a frame's expansion: 4 waves x kExpandSegs segments.
+template <bool LEAN, bool ABS_T>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    // only the frame-independent part of the arguments is needed here (no running_t fetch)
+    __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
+    static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
+    // only the frame-independent part of the arguments is needed here
     const uint32_t slots = __builtin_amdgcn_readfirstlane(b->slots);
     const uint32_t slot = __builtin_amdgcn_readfirstlane(f % slots);
     const uint32_t num_waves = __builtin_amdgcn_readfirstlane(b->base.num_waves);
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + threadIdx.x / kWave) * kExpandSegs);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + wid) * kExpandSegs);
     if (seg0 >= num_waves) return;
-    const uint32_t park_stride = __builtin_amdgcn_readfirstlane(b->park_stride);
+    uint32_t *const xb = s_xbuf[wid];
+    const uint32_t park_bytes = __builtin_amdgcn_readfirstlane(b->park_bytes);
     // wave-uniform bases (SGPRs); the lanes add 32-bit byte offsets
-    const uint2 *park = uniform_ptr(b->park_ring) + ((size_t)slot * num_waves + seg0) * park_stride;
+    const uint8_t *park = uniform_ptr(b->park_ring) + ((size_t)slot * num_waves + seg0) * park_bytes;
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
-    const uint32_t rowlen = __builtin_amdgcn_readfirstlane(b->base.rowlen);
-    const uint32_t channels = __builtin_amdgcn_readfirstlane(b->base.channels);
-    const uint32_t row_begin = __builtin_amdgcn_readfirstlane(b->base.row_begin);
+    UnitCoord uc;
+    uc.rowlen = __builtin_amdgcn_readfirstlane(b->base.rowlen);
+    uc.channels = __builtin_amdgcn_readfirstlane(b->base.channels);
+    uc.row_begin = __builtin_amdgcn_readfirstlane(b->base.row_begin);
+    uc.one_wrap = uc.rowlen >= 2u * kWaveUnits;  // a pair of segments crosses at most one row end
     const uint64_t out_cap = b->base.out_cap;
+    const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
 
-    const bool park4 = __builtin_amdgcn_readfirstlane(b->base.park4) != 0u;  // compact 4-byte records (K1, PARK4)
-    const uint32_t rt_u32 = park4 ? __builtin_amdgcn_readfirstlane(f32_as_u32(b->running_t[f])) : 0u;  // t of D_EMPTY
-
-    // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly)
-    uint2 first[kExpandSegs];
+    // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
+    // segments' counts first, then exactly the records they hold (a speculative fetch of 64 records per
+    // segment moved 3.4x the bytes: a segment parks ~20 records of 16 bytes)
+    uint32_t my_tot = 0u;
+    if (lane < kExpandSegs) my_tot = gload<uint32_t>(wtot, lane * 4u);
+    const uint32_t pref0 = gload<uint32_t>(wpref, 0u);  // events of the frame before segment seg0
+    // Lean: segments go in PAIRS, lanes 0-31 on the even one and lanes 32-63 on the odd one (a segment
+    // parks ~20 records: one 64-lane round per segment would leave two thirds of the lanes idle); a pair
+    // with a segment of more than 32 records takes the one-segment-at-a-time path below.
+    const uint32_t half = lane >> 5, hl = lane & 31u;
+    uint4 first[LEAN ? kExpandSegs / 2u : kExpandSegs];
+    if (LEAN) {
 #pragma unroll
-    for (uint32_t q = 0; q < kExpandSegs; ++q) {
-        if (park4)
-            first[q] = make_uint2(gload<uint32_t>(park + (size_t)q * park_stride, lane * 4u), 0u);
-        else
-            first[q] = gload<uint2>(park + (size_t)q * park_stride, lane * (uint32_t)sizeof(uint2));
+        for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
+            const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
+            const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
+            first[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (hl < (half ? pb : pa))
+                first[p] = gload<uint4>(park + (size_t)(2 * p) * park_bytes, half * park_bytes + hl * kLeanRecBytes);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < kExpandSegs; ++q) {
+            const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
+            first[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < parked) {
+                const uint2 v = gload<uint2>(park + (size_t)q * park_bytes, lane * kGenRecBytes);
+                first[q] = make_uint4(v.x, v.y, 0u, 0u);
+            }
+        }
     }
-    uint32_t my_tot = 0u, my_pref = 0u;
-    if (lane < kExpandSegs) {
-        my_tot = gload<uint32_t>(wtot, lane * 4u);
-        my_pref = gload<uint32_t>(wpref, lane * 4u);
-    }
-    const uint64_t frame_base = b->base.frame_offsets[f];
-    AdderEventPod *const out = uniform_ptr(b->base.out);
+    uint32_t *const out_dw = reinterpret_cast<uint32_t *>(uniform_ptr(b->base.out));
+    // the wave's events occupy [gpos, gpos + sum of its segments' event counts) of the stream
+    uint64_t gpos = b->base.frame_offsets[f] + __builtin_amdgcn_readfirstlane(pref0);
+    uint32_t fill = 0u;                        // events staged (uniform)
+    uint32_t phase = (uint32_t)(gpos * 3u) & 3u;  // dword phase of the staging buffer's first event
     bool dropped = false;
+    // staged events -> stream; events past the caller's capacity are dropped and reported
+    auto flush = [&]() {
+        const uint64_t room64 = gpos < out_cap ? out_cap - gpos : 0ull;
+        const uint32_t n = (uint64_t)fill <= room64 ? fill : (uint32_t)room64;
+        dropped = dropped || n != fill;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n) xbuf_flush(xb, phase, n, out_dw, gpos * 3u, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        gpos += fill;
+        phase = (uint32_t)(gpos * 3u) & 3u;
+        fill = 0u;
+    };
+    // 64 lean records (or none) of ONE segment whose first unit is at (uc.y0, uc.rem0 + unit_shift)
+    auto lean_round = [&](const uint4 &rw, uint32_t unit_shift) {
+        if (fill + 3u * kWave > kXbufEvents) flush();  // room for this round's worst case
+        LeanRec r;
+        r.ta = rw.x;
+        r.wa = rw.y;
+        r.tc = rw.z;
+        r.wc = rw.w;
+        const LeanEvents e = lean_decode(r, ABS_T, rt_u32);  // an all-zero record decodes to no events
+        const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
+        const uint32_t incl = wave_inclusive_scan_dpp(n);
+        const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
+        fill += __builtin_amdgcn_readlane(incl, kWave - 1);
+        uint32_t c;
+        const uint32_t xy = coord_xy_c(uc, ((r.wa >> kLeanUnitShift) & 0x3ffu) + unit_shift, c);
+        stage_lean(xb, w, e, xy, c);
+    };
     // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
     // following segments advance it with scalar add/compare instead of dividing again
-    uint32_t y0 = __builtin_amdgcn_readfirstlane((seg0 * kWaveUnits) / rowlen);
-    uint32_t rem0 = seg0 * kWaveUnits - y0 * rowlen;
-    const bool one_wrap = rowlen >= kWaveUnits;
+    uc.y0 = __builtin_amdgcn_readfirstlane((seg0 * kWaveUnits) / uc.rowlen);
+    uc.rem0 = seg0 * kWaveUnits - uc.y0 * uc.rowlen;
+    auto next_segment = [&]() {  // uniform, scalar
+        uc.rem0 += kWaveUnits;
+        while (uc.rem0 >= uc.rowlen) {
+            uc.rem0 -= uc.rowlen;
+            ++uc.y0;
+        }
+    };
+    if (LEAN) {
 #pragma unroll
-    for (uint32_t q = 0; q < kExpandSegs; ++q) {
-        const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
-        // the segment's first event in the stream (uniform); the lanes address relative to it
-        const uint64_t base = frame_base + __builtin_amdgcn_readlane(my_pref, q);
-        const uint64_t room64 = base < out_cap ? out_cap - base : 0ull;
-        const uint32_t room = room64 > 0xffffffffull ? 0xffffffffu : (uint32_t)room64;  // events that still fit
-        EventWords *const seg_out = reinterpret_cast<EventWords *>(out) + base;
-        const uint2 *const seg_park = park + (size_t)q * park_stride;
-        uint32_t wide_seen = 0u;  // marked records in earlier rounds of this segment (uniform)
-        for (uint32_t i0 = 0; i0 < parked; i0 += kWave) {  // uniform trip count
-            const uint32_t i = i0 + lane;
-            const bool on = i < parked;
-            uint32_t ev_t, ev_d, unit, pos;
-            if (park4) {
-                const uint32_t rec = !on ? 0u : (i0 == 0u ? first[q].x : gload<uint32_t>(seg_park, i * 4u));
-                ev_t = rec & kParkWideT;
-                ev_d = (rec >> 17) & 0xffu;
-                unit = rec >> 25;
-                pos = i;
-                const bool marked = on && ev_d != kDEmpty && ev_t == kParkWideT;
-                const uint64_t mb = __builtin_amdgcn_ballot_w64(marked);
-                if (mb != 0ull) {  // rare: fetch the real t from the segment's overflow list
-                    const uint32_t rank = wide_seen + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                    if (marked) ev_t = gload<uint32_t>(seg_park, (kParkOverflowBase + rank) * 4u);
-                    wide_seen += (uint32_t)__popcll(mb);
+        for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
+            const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
+            const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
+            if (pa <= 32u && pb <= 32u) {
+                if (pa + pb != 0u) lean_round(first[p], half * kWaveUnits);
+                next_segment();
+                next_segment();
+            } else {
+                const uint32_t cnt[2] = {pa, pb};
+#pragma unroll
+                for (uint32_t h = 0; h < 2u; ++h) {
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * park_bytes;
+                    for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
+                        uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+                        if (i0 + lane < cnt[h]) rw = gload<uint4>(seg_park, (i0 + lane) * kLeanRecBytes);
+                        lean_round(rw, 0u);
+                    }
+                    next_segment();
                 }
-                ev_t = ev_d == kDEmpty ? rt_u32 : ev_t;
-            } else {
-                const uint2 sl = !on ? make_uint2(0u, 0u)
-                                     : (i0 == 0u ? first[q] : gload<uint2>(seg_park, i * (uint32_t)sizeof(uint2)));
-                ev_t = sl.x;
-                ev_d = sl.y & 0xffu;
-                unit = (sl.y >> 8) & 0xffu;
-                pos = sl.y >> 16;  // final offset inside the segment
-            }
-            if (!on) continue;
-            uint32_t rem = rem0 + unit;
-            uint32_t y = y0;
-            if (one_wrap) {
-                const bool wrap = rem >= rowlen;
-                rem -= wrap ? rowlen : 0u;
-                y += wrap ? 1u : 0u;
-            } else {
-                const uint32_t dq = rem / rowlen;
-                rem -= dq * rowlen;
-                y += dq;
-            }
-            uint32_t x = rem, c = 0xffu;
-            if (channels == 3u) {
-                x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
-                c = rem - 3u * x;
-            }
-            if (pos < room) {
-                EventWords w;
-                w.xy = x | ((y + row_begin) << 16);
-                w.cd = c | (ev_d << 8);
-                w.t = ev_t;
-                gstore(seg_out, pos * (uint32_t)sizeof(EventWords), w);
-            } else {
-                dropped = true;
             }
         }
-        // next segment starts kWaveUnits units later (uniform, scalar)
-        rem0 += kWaveUnits;
-        while (rem0 >= rowlen) {
-            rem0 -= rowlen;
-            ++y0;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < kExpandSegs; ++q) {
+            const uint32_t tot = __builtin_amdgcn_readlane(my_tot, q);
+            const uint32_t parked = tot >> 16;
+            const uint8_t *const seg_park = park + (size_t)q * park_bytes;
+            // every record carries its event's offset inside the segment; a segment's events are staged
+            // in pieces of the buffer's size (the segment total is known: tot & 0xffff)
+            const uint32_t seg_events = tot & 0xffffu;
+            for (uint32_t e0 = 0; e0 < seg_events; e0 += kXbufEvents) {
+                const uint32_t piece = seg_events - e0 < kXbufEvents ? seg_events - e0 : kXbufEvents;
+                if (fill + piece > kXbufEvents) flush();
+                for (uint32_t i0 = 0; i0 < parked; i0 += kWave) {
+                    const uint32_t i = i0 + lane;
+                    if (i >= parked) continue;
+                    uint2 sl;
+                    if (i0 == 0u)
+                        sl = make_uint2(first[q].x, first[q].y);
+                    else
+                        sl = gload<uint2>(seg_park, i * kGenRecBytes);
+                    const uint32_t pos = sl.y >> 16;  // final offset inside the segment
+                    if (pos < e0 || pos >= e0 + piece) continue;
+                    uint32_t c;
+                    const uint32_t xy = coord_xy_c(uc, (sl.y >> 8) & 0xffu, c);
+                    const uint32_t w = phase + (fill + pos - e0) * 3u;
+                    xb[w] = xy;
+                    xb[w + 1u] = c | ((sl.y & 0xffu) << 8);
+                    xb[w + 2u] = sl.x;
+                }
+                fill += piece;
+            }
+            next_segment();
         }
     }
+    flush();
     if (dropped) raise(b->base.status, kStatusCapacity);
 }
 
+// variant: bit 0 = lean records, bit 1 = AbsoluteT (lean decoding)
+template <bool LEAN, bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
-    expand_block(b, f0 + blockIdx.y, blockIdx.x);
+    expand_block<LEAN, ABS_T>(b, f0 + blockIdx.y, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,12 +937,6 @@ __global__ __launch_bounds__(256) void adder_wire_kernel(const uint32_t *__restr
         }
     }
     if (bad) raise(status, kStatusWire);
-}
-
-// update_crf / update_quality_manual per-pixel reset (video.rs:1247-1250,1283-1286)
-__global__ void adder_reset_c_thresh_kernel(uint32_t *hdr, size_t n, uint32_t baseline) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hdr[i] = (hdr[i] & 0xff0000ffu) | (baseline << 8);
 }
 
 __global__ void adder_fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
@@ -863,17 +1018,6 @@ __global__ __launch_bounds__(256) void adder_divtest_kernel(unsigned long long *
     if (f32_as_u32(fdiv_small(a, b)) != f32_as_u32(fdiv(a, b))) atomicAdd(bad, 1ull);
 }
 
-typedef void (*FrameKernelFn)(const BatchArgs *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                              uint32_t);
-static FrameKernelFn pick_frame_kernel(uint32_t variant) {
-    const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
-    if (collapse) {
-        if (generic) return abs_t ? adder_frame_kernel<true, true, true> : adder_frame_kernel<true, false, true>;
-        return abs_t ? adder_frame_kernel<true, true, false> : adder_frame_kernel<true, false, false>;
-    }
-    return abs_t ? adder_frame_kernel<false, true, true> : adder_frame_kernel<false, false, true>;
-}
-
 extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream) {
     hipLaunchKernelGGL(adder_divtest_kernel, dim3((1u << 24) / 256u, 255), dim3(256), 0, stream, d_bad);
     return hipGetLastError();
@@ -881,32 +1025,28 @@ extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
                                          uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
-    if (nb == 1u && !(variant & 4u) && exp_nf == 0u && (num_waves & 1u) == 0u) {
-        const uint32_t grid = (num_waves / 2u + kWavesPerBlock - 1) / kWavesPerBlock;
-        switch (variant & 3u) {
-            case 0: hipLaunchKernelGGL((adder_frame1_kernel<false, false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
-            case 1: hipLaunchKernelGGL((adder_frame1_kernel<true, false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
-            case 2: hipLaunchKernelGGL((adder_frame1_kernel<false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
-            default: hipLaunchKernelGGL((adder_frame1_kernel<true, true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f); break;
+    const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
+    const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
+    if (generic) {  // never fused with an expansion (adder_hip_api.cpp fuse_for)
+        if (exp_nf != 0u) return hipErrorInvalidValue;
+        if (collapse) {
+            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<true, true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+            else hipLaunchKernelGGL((adder_frame_kernel<true, false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+        } else {
+            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<false, true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+            else hipLaunchKernelGGL((adder_frame_kernel<false, false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
         }
         return hipGetLastError();
     }
-    const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
-    const uint32_t per_block = kWavesPerBlock * kExpandSegs;
-    const uint32_t exp_bpf = exp_nf ? (num_waves + per_block - 1) / per_block : 0u;
-    const uint32_t E = exp_bpf * exp_nf;  // expansion workgroups
-    // spread the scarcer kind evenly through the dispatch order
-    uint32_t grp_steps = 1, grp_exps = 1, groups = 0, rem_is_step = 1;
-    if (E >= S) {
-        grp_exps = E / S;
-        groups = S;
-        rem_is_step = 0;
-    } else if (E) {
-        grp_steps = S / E;
-        groups = E;
+    if (!collapse || exp_nf != 0u) return hipErrorInvalidValue;  // the lean step is Collapse-only
+    if (nb == 1u && (num_waves & 1u) == 0u) {
+        const uint32_t grid = (num_waves / 2u + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (abs_t) hipLaunchKernelGGL((adder_lean1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+        else hipLaunchKernelGGL((adder_lean1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(pick_frame_kernel(variant), dim3(S + E), dim3(kBlockThreads), 0, stream, b, f, nb, exp_f0, exp_bpf,
-                       grp_steps, grp_exps, groups, rem_is_step);
+    if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+    else hipLaunchKernelGGL((adder_lean_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
     return hipGetLastError();
 }
 
@@ -930,17 +1070,13 @@ extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint
 }
 
 extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                                          hipStream_t stream) {
+                                          uint32_t variant, hipStream_t stream) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
-    const uint32_t grid = (num_waves + per_block - 1) / per_block;
-    hipLaunchKernelGGL(adder_expand_kernel, dim3(grid, nf), dim3(kBlockThreads), 0, stream, b, f0);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t adder_launch_reset_c_thresh(uint32_t *hdr, size_t n, uint32_t baseline, hipStream_t stream) {
-    const uint32_t bs = 256;
-    hipLaunchKernelGGL(adder_reset_c_thresh_kernel, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, stream,
-                       hdr, n, baseline);
+    const dim3 grid((num_waves + per_block - 1) / per_block, nf);
+    const bool abs_t = variant & 2u, generic = variant & 4u;
+    if (generic) hipLaunchKernelGGL((adder_expand_kernel<false, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<true, true>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    else hipLaunchKernelGGL((adder_expand_kernel<true, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
     return hipGetLastError();
 }
 

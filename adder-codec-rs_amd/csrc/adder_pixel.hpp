@@ -25,12 +25,23 @@
 // child nothing (:468-469).  Consequently the zero-event and synthesised-event branches
 // of pop_top (:156-197) and the tail's zero event in pop_best (:225-230) are
 // unreachable here, and a pixel is fully described by
-//   hdr    : base_val | c_thresh<<8 | c_increase_counter<<16 | flags<<24
-//            flags = m (5 bits) | popped_dtm<<5
+//   hdr    : base_val | best_d(level 0) << 8 | m << 16 | popped_dtm << 21
 //   level k: (integration, delta_t, best_d, best_delta_t) for k < m; the node's d is a
-//            function of best_d (fired_d below)
+//            function of best_d (fired_d below).  Level 0's best_d rides in the header word
+//            so that level 0 is exactly 16 bytes {hdr, integration, delta_t, best_delta_t}.
 //   last_fired_t (AbsoluteT only);  running_t is identical for every pixel and is
 //   passed in.
+// c_thresh and c_increase_counter are NOT per-pixel state here: integrate() adapts them once
+// per call from (c_thresh_max, c_increase_velocity, time) alone (:402-412), every pixel
+// integrates exactly once per frame (video.rs:1318-1380), PixelArena::new gives every pixel
+// the same (10, 1) (:82-83) and update_crf / update_quality_manual reset every pixel to the
+// same baseline (video.rs:1247-1250,1283-1286) -- so the pair is identical in all pixels at
+// all times and the context carries ONE copy (c_thresh_advance below), handing each frame its
+// threshold as a uniform.  (Only the feature-driven rate control of video.rs:865-1112, which
+// this path does not run, would make them differ.)
+// With 8-bit input, integration never exceeds 2^33 (an f32 that large absorbs a further
+// + 255), so d stays <= 34 or is 128; the D_MAX clamps and the d == D_MAX pop (:395) are kept
+// in the generic step and provably idle in the lean one.
 // need_to_pop_top is never set between frames (integrate_for_px pops at its end),
 // dtm_reached is recomputed by every integrate, `alt` is only asserted on.
 // tests/cpu_sim + tests/test_device_logic_cpu.py check all of this against the literal
@@ -50,8 +61,15 @@ constexpr uint32_t kDMax = 127;
 constexpr uint32_t kDZero = 128;
 constexpr uint32_t kDEmpty = 255;
 
-constexpr uint32_t kFlagMMask = 0x1f;
-constexpr uint32_t kFlagPopped = 0x20;
+// header word layout
+constexpr uint32_t kHdrBdShift = 8;
+constexpr uint32_t kHdrMShift = 16;
+constexpr uint32_t kHdrMMask = 0x1f;
+constexpr uint32_t kHdrPopped = 1u << 21;
+ADDER_HD uint32_t hdr_m(uint32_t hdr) { return (hdr >> kHdrMShift) & kHdrMMask; }
+ADDER_HD uint32_t hdr_make(uint32_t base, uint32_t bd, uint32_t m, bool popped) {
+    return base | (bd << kHdrBdShift) | (m << kHdrMShift) | (popped ? kHdrPopped : 0u);
+}
 
 constexpr uint32_t kMaxDepthLimit = 31;
 
@@ -62,9 +80,7 @@ struct StepConsts {
     uint32_t running_t_u32;  // running_t as u32 (the t of a D_EMPTY event)
     float dtm_f;         // delta_t_max as f32 (event_pixel_tree.rs:394)
     uint32_t ref_time;
-    uint32_t c_thresh_max;
-    uint32_t velocity_m1;  // (c_increase_velocity - 1) as u8
-    uint32_t c_inc;        // ((time as u32) / ref_time) as u8   (:408-410)
+    uint32_t cth;          // c_thresh every pixel holds while this frame is tested (uniform, see above)
     uint32_t collapse;     // PixelMultiMode::Collapse
     uint32_t abs_t;        // TimeMode::AbsoluteT
     uint32_t max_depth;    // stored levels available
@@ -77,13 +93,6 @@ struct Node {
     float dt;
     float bdt;    // best_event.delta_t
     uint32_t bd;  // best_event.d
-};
-
-// Always-resident part of one pixel-channel.
-struct PxState {
-    uint32_t hdr;
-    Node n0;  // level 0, valid iff m > 0
-    float lastf;
 };
 
 ADDER_HD float bits_to_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -144,6 +153,46 @@ ADDER_HD float fsub(float a, float b) { return a - b; }
 ADDER_HD float fdiv(float a, float b) { return a / b; }
 ADDER_HD float fdiv_small(float a, float b) { return a / b; }
 #endif
+
+
+// Always-resident part of one pixel-channel (generic step).
+struct PxState {
+    uint32_t base;  // base_val
+    uint32_t m;     // fired levels
+    bool popped;    // popped_dtm
+    Node n0;        // level 0, valid iff m > 0
+    float lastf;
+};
+ADDER_HD PxState px_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
+    PxState s;
+    s.base = hdr & 0xffu;
+    s.m = hdr_m(hdr);
+    s.popped = (hdr & kHdrPopped) != 0u;
+    s.n0.integ = integ;
+    s.n0.dt = dt;
+    s.n0.bdt = bdt;
+    s.n0.bd = (hdr >> kHdrBdShift) & 0xffu;
+    s.lastf = lastf;
+    return s;
+}
+ADDER_HD uint32_t px_hdr(const PxState &s) { return hdr_make(s.base, s.n0.bd & 0xffu, s.m, s.popped); }
+
+// The c_thresh adaptation at the end of PixelArena::integrate (event_pixel_tree.rs:402-412), all
+// u8 with saturating adds; `time` is the integrate call's time argument.  Uniform across pixels
+// (see the header comment), so the host advances ONE pair per frame.
+ADDER_HD void c_thresh_advance(uint8_t &c_thresh, uint8_t &counter, uint8_t c_thresh_max, uint8_t velocity,
+                               float time, uint32_t ref_time) {
+    if (c_thresh < c_thresh_max) {
+        if (counter >= (uint8_t)(velocity - 1)) {
+            c_thresh = c_thresh == 255 ? (uint8_t)255 : (uint8_t)(c_thresh + 1);
+            counter = 0;
+        } else {
+            const uint32_t inc = (uint8_t)(f32_as_u32(time) / ref_time);
+            const uint32_t sum = (uint32_t)counter + inc;
+            counter = (uint8_t)(sum > 255u ? 255u : sum);
+        }
+    }
+}
 
 // The firing arm of integrate_main (event_pixel_tree.rs:427-473), FramePerfect: node with
 // (integ, dt) and current d fires on intensity I over `time`; s = integ + I >= 2^d.
@@ -213,10 +262,12 @@ ADDER_HD uint32_t event_time(float ev_dt, float &lastf, const StepConsts &sc) {
 
 // video.rs:1338-1340: frame_val outside [base (-sat) c_thresh, base (+sat) c_thresh].
 // v, base, c_thresh are u8, so the saturating bounds reduce to |v - base| > c_thresh.
-ADDER_HD bool contrast_exceeded(uint32_t v, uint32_t hdr) {
-    const uint32_t base = hdr & 0xffu;
-    const uint32_t cth = (hdr >> 8) & 0xffu;
+ADDER_HD bool contrast_exceeded(uint32_t v, uint32_t base, uint32_t cth) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t diff = __builtin_amdgcn_sad_u8(v, base, 0u);  // both below 256: |v - base| in one instruction
+#else
     const uint32_t diff = v > base ? v - base : base - v;
+#endif
     return diff > cth;
 }
 
@@ -226,10 +277,201 @@ ADDER_HD bool root_needs_pop(const Node &root, bool popped, const StepConsts &sc
 }
 
 // ---------------------------------------------------------------------------------------
-// FAST PATH: pixels whose arena has at most ONE fired level before the step and at most
-// one after it.  That is every pixel, always, when PixelMultiMode::Collapse is combined
-// with delta_t_max <= time_spanned (the headline configuration: the root pops as soon as
-// it has accumulated once), and the common case otherwise.
+// LEAN STEP: PixelMultiMode::Collapse with delta_t_max <= time_spanned (BASELINE config 2-4:
+// delta_t_max = ref_time = 255).  There the root pops the first time it has accumulated
+// (delta_t = time >= delta_t_max, :394-396) and, popped, nothing but the root integrates
+// (:360-362), so the arena never holds more than ONE fired level: m is 0 or 1 before and
+// after every step.  The step below is integrate_for_px for that case, folded:
+//   * the node's threshold 2^d is carried as the f32 `thr` (0 for d = 128) instead of d: the
+//     firing test is one compare, 2^new_d is `sum` with its mantissa cleared, the next
+//     threshold is that doubled; best_d is thr's exponent minus one (128 when thr is 0);
+//   * 8-bit input keeps every d below D_MAX (header comment), so `if node.state.d < D_MAX`
+//     (:449) reduces to "sum != 0" and the d == D_MAX pop (:395) never happens;
+//   * a node that has only ever seen zeros keeps delta_t 0 (the d = 128 firing does not
+//     accumulate, :449), so "delta_t >= delta_t_max" is exactly "sum != 0" once time >= dtm.
+// Its <= 3 events (A: pop_best's root event, B: the Collapse filler, C: pop_top's event) are
+// not materialised: the step hands back one 16-byte record with the raw (best_delta_t, thr)
+// pairs and the expansion kernel decodes it (lean_decode_*).  All of it is checked against
+// the literal oracle on the host by tests/cpu_sim.
+// ---------------------------------------------------------------------------------------
+// The step is written once over a "lanes" policy L: booleans are L::Mask values combined with
+// L::and_/or_/andnot/not_, a comparison enters with L::from() and a mask is consumed by a select
+// through L::lane().  ScalarLanes (Mask = bool) is the per-unit form the CPU harness runs;
+// WaveLanes (Mask = the wave's 64-bit lane mask, device only) makes every boolean of the step a
+// scalar-register mask: the logic runs on the scalar ALU, selects read the mask directly and the
+// kernel popcounts the event masks without a ballot.
+struct ScalarLanes {
+    using Mask = bool;
+    static ADDER_HD Mask from(bool c) { return c; }
+    static ADDER_HD bool lane(Mask m) { return m; }
+    static ADDER_HD Mask and_(Mask a, Mask b) { return a && b; }
+    static ADDER_HD Mask or_(Mask a, Mask b) { return a || b; }
+    static ADDER_HD Mask andnot(Mask a, Mask b) { return a && !b; }
+    static ADDER_HD Mask not_(Mask a) { return !a; }
+};
+#if defined(__HIPCC__)
+struct WaveLanes {  // every lane of the wave is live in the frame kernels (padding units included)
+    using Mask = uint64_t;
+    static __device__ __forceinline__ Mask from(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+    static __device__ __forceinline__ bool lane(Mask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    static __device__ __forceinline__ Mask and_(Mask a, Mask b) { return a & b; }
+    static __device__ __forceinline__ Mask or_(Mask a, Mask b) { return a | b; }
+    static __device__ __forceinline__ Mask andnot(Mask a, Mask b) { return a & ~b; }
+    static __device__ __forceinline__ Mask not_(Mask a) { return ~a; }
+};
+#endif
+
+template <class L>
+struct LeanPxT {
+    float integ, dt, bdt;
+    float thr;      // 2^d of level 0 (0.0 for d = 128); meaningful iff has0
+    uint32_t base;  // base_val
+    typename L::Mask has0;    // m == 1
+    typename L::Mask popped;  // popped_dtm
+    float lastf;    // last_fired_t (AbsoluteT)
+};
+using LeanPx = LeanPxT<ScalarLanes>;
+
+// One unit's output of one frame.  wa / wc = the threshold word (a power of two or 0: the low
+// 23 bits are free) | flag bits | unit tag; ta / tc = best_delta_t bits (DeltaT) or the event's
+// absolute t (AbsoluteT).
+constexpr uint32_t kLeanA = 1u;         // wa: event A present
+constexpr uint32_t kLeanB = 2u;         // wa: event B (D_EMPTY filler) present
+constexpr uint32_t kLeanC = 1u;         // wc: event C present
+constexpr uint32_t kLeanUnitShift = 2;  // wa: unit index inside the segment (<= 10 bits)
+struct LeanRec {
+    uint32_t ta, wa, tc, wc;
+};
+
+ADDER_HD float lean_thr_from_bd(uint32_t bd) { return pow2_d(fired_d(bd)); }
+// best_d of a fired node from its threshold word: thr = 2^(bd+1), or 0 for bd = 128
+ADDER_HD uint32_t lean_bd_from_thr(uint32_t thr_bits) {
+    const uint32_t e = (thr_bits >> 23) & 0xffu;
+    return e == 0u ? kDZero : e - 128u;
+}
+
+template <class L>
+ADDER_HD LeanPxT<L> lean_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
+    LeanPxT<L> p;
+    p.integ = integ;
+    p.dt = dt;
+    p.bdt = bdt;
+    p.thr = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
+    p.base = hdr & 0xffu;
+    p.has0 = L::from(hdr_m(hdr) != 0u);  // lean batches only ever see m <= 1
+    p.popped = L::from((hdr & kHdrPopped) != 0u);
+    p.lastf = lastf;
+    return p;
+}
+template <class L>
+ADDER_HD uint32_t lean_hdr(const LeanPxT<L> &p) {
+    return hdr_make(p.base, lean_bd_from_thr(f32_to_bits(p.thr)), L::lane(p.has0) ? 1u : 0u, L::lane(p.popped));
+}
+
+// Which events the unit produced this frame.
+template <class L>
+struct LeanFlagsT {
+    typename L::Mask a, b, c;
+};
+// `cth` is the frame's uniform contrast threshold, T = time_spanned >= delta_t_max (the lean
+// precondition).  The unit has a record iff flags.a || flags.c.
+template <bool ABS_T, class L>
+ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float T, const StepConsts &sc, uint32_t tag,
+                                 LeanRec &rec) {
+    using M = typename L::Mask;
+    const float I = (float)v;
+    // ---- pop_best_events (:213-287): A = the root's best event; popped + Collapse adds the
+    // D_EMPTY filler B and restarts the arena from a fresh node (:249-265) ----
+    const M flush = L::from(contrast_exceeded(v, p.base, cth));
+    const M a_valid = L::and_(flush, p.has0);
+    const M b_valid = L::and_(a_valid, p.popped);
+    uint32_t ta = f32_to_bits(p.bdt);
+    float lastf = p.lastf;
+    if (ABS_T) {
+        const float evdt = fadd(p.bdt, lastf);
+        const uint32_t t = f32_as_u32(evdt);
+        const float chained = (float)ceil_to_ref(t, sc.ref_time, sc.ref_magic);
+        const float nl = L::lane(b_valid) ? sc.running_t : chained;  // :122-129 / :257
+        lastf = L::lane(a_valid) ? nl : lastf;
+        ta = t;
+    }
+    const uint32_t wa =
+        f32_to_bits(p.thr) | tag | (L::lane(a_valid) ? kLeanA : 0u) | (L::lane(b_valid) ? kLeanB : 0u);
+    const M has0 = L::andnot(p.has0, flush);
+    const M popped = L::andnot(p.popped, flush);
+    p.base = L::lane(flush) ? v : p.base;
+
+    // ---- integrate (:317-413): arena index 0 is level 0 if present, else the pristine tail,
+    // which always fires; the walk stops there ----
+    const float integ0 = L::lane(has0) ? p.integ : 0.0f;
+    const float dt0 = L::lane(has0) ? p.dt : 0.0f;
+    const float sum = fadd(integ0, I);
+    const M keep = L::and_(has0, L::from(!(sum >= p.thr)));  // level 0 accumulates without firing
+    const M zero = L::from(sum == 0.0f);                     // get_d(sum) == 128
+    const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);  // 2^get_d(sum), 0 when zero
+    // prop (:431-437).  Where it is consumed (the node fires, nothing is zero) the numerator is
+    // an integer in [1, 255] and I an integer in [1, 255]: fdiv_small's domain.
+    const M unit_prop = L::or_(zero, L::and_(has0, L::from(p.thr == 0.0f)));
+    const float q = fdiv_small(fsub(p2, integ0), I);
+    const float prop = L::lane(unit_prop) ? 1.0f : q;
+    const float bdt_fire = fadd(dt0, fmul(T, prop));
+    const float dt_acc = fadd(dt0, T);
+    p.integ = sum;                                  // :450 (sum == integ0 when the d = 128 firing skips it)
+    p.dt = L::lane(zero) ? dt0 : dt_acc;            // :451
+    p.thr = L::lane(keep) ? p.thr : fadd(p2, p2);   // :454-461: the next power of two above sum
+    p.bdt = L::lane(keep) ? p.bdt : bdt_fire;
+    const M need_pop = L::not_(L::or_(popped, zero));  // :394-396 with delta_t = dt0 + T >= delta_t_max
+
+    // ---- pop_top_event (:139-210): C = the root's best event; the arena shifts left ----
+    uint32_t tc = f32_to_bits(p.bdt);
+    if (ABS_T) {
+        const float evdt = fadd(p.bdt, lastf);
+        const uint32_t t = f32_as_u32(evdt);
+        const float chained = (float)ceil_to_ref(t, sc.ref_time, sc.ref_magic);
+        lastf = L::lane(need_pop) ? chained : lastf;
+        tc = t;
+    }
+    rec.ta = ta;
+    rec.wa = wa;
+    rec.tc = tc;
+    rec.wc = f32_to_bits(p.thr) | (L::lane(need_pop) ? kLeanC : 0u);
+    p.has0 = L::not_(need_pop);
+    p.popped = L::or_(popped, need_pop);
+    p.lastf = lastf;
+    LeanFlagsT<L> fl;
+    fl.a = a_valid;
+    fl.b = b_valid;
+    fl.c = need_pop;
+    return fl;
+}
+
+// Decoding of a record (expansion kernel, CPU harness): the events in emission order are A, B, C.
+struct LeanEvents {
+    bool a, b, c;
+    uint32_t da, ta;  // A: pop_best's root event
+    uint32_t tb;      // B: {d: D_EMPTY, t: running_t as u32} (:259-263), absolute in every time mode
+    uint32_t dc, tc;  // C: pop_top's event
+};
+ADDER_HD LeanEvents lean_decode(const LeanRec &r, bool abs_t, uint32_t running_t_u32) {
+    LeanEvents e;
+    e.a = (r.wa & kLeanA) != 0u;
+    e.b = (r.wa & kLeanB) != 0u;
+    e.c = (r.wc & kLeanC) != 0u;
+    e.da = lean_bd_from_thr(r.wa);
+    e.dc = lean_bd_from_thr(r.wc);
+    const uint32_t ca = f32_as_u32(bits_to_f32(r.ta)), cc = f32_as_u32(bits_to_f32(r.tc));
+    e.ta = abs_t ? r.ta : ca;
+    e.tc = abs_t ? r.tc : cc;
+    e.tb = running_t_u32;
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------
+// GENERIC PATH (Normal mode, or delta_t_max > time_spanned): any arena depth.
+// fast_eligible / step_fast handle the units that have at most one fired level before the
+// step and at most one after it (the common case) branch-free; plan_count tells how many
+// events a deeper unit's step will emit (so the ordered compaction can reserve the slots
+// before the step runs), exec_step runs it.
 // ---------------------------------------------------------------------------------------
 
 // Events of one fast step, in emission order: A (pop_best's first event), B (the D_EMPTY
@@ -240,57 +482,27 @@ struct FastEvents {
 };
 
 template <bool COLLAPSE>
-ADDER_HD bool fast_eligible(const PxState &s, uint32_t v) {
-    const uint32_t flags = s.hdr >> 24;
-    const uint32_t m = flags & kFlagMMask;
-    if (m >= 2u) return false;
-    if (m == 0u) return true;
+ADDER_HD bool fast_eligible(const PxState &s, uint32_t v, uint32_t cth) {
+    if (s.m >= 2u) return false;
+    if (s.m == 0u) return true;
     // m == 1: the walk must stop at level 0 (else the tail fires and creates level 1)
-    if (contrast_exceeded(v, s.hdr)) return true;        // arena restarts from the tail
-    if (COLLAPSE && (flags & kFlagPopped)) return true;  // only the root integrates
+    if (contrast_exceeded(v, s.base, cth)) return true;  // arena restarts from the tail
+    if (COLLAPSE && s.popped) return true;               // only the root integrates
     return fadd(s.n0.integ, (float)v) >= pow2_d(fired_d(s.n0.bd));
 }
 
-// Unpacked form of PxState for the frame kernel: with temporal blocking the header word is
-// unpacked once per launch instead of once per frame.
-struct FastPx {
-    uint32_t base, cth, cctr;
-    uint32_t has0;    // m == 1 (0/1)
-    uint32_t popped;  // 0/1
-    Node n0;
-    float lastf;
-};
-
-ADDER_HD FastPx unpack_px(const PxState &s) {
-    FastPx p;
-    p.base = s.hdr & 0xffu;
-    p.cth = (s.hdr >> 8) & 0xffu;
-    p.cctr = (s.hdr >> 16) & 0xffu;
-    p.has0 = (s.hdr >> 24) & 1u;  // fast path: m is 0 or 1
-    p.popped = (s.hdr >> 29) & 1u;
-    p.n0 = s.n0;
-    p.lastf = s.lastf;
-    return p;
-}
-ADDER_HD uint32_t pack_hdr(const FastPx &p) {
-    return p.base | (p.cth << 8) | (p.cctr << 16) | ((p.has0 | (p.popped << 5)) << 24);
-}
-
-// Written branch-free on purpose: on CDNA a divergent `if` costs scalar exec-mask
-// bookkeeping per region, and with several pixels per lane and ~10% of the pixels flushing
-// every wave takes every path anyway.  Everything is computed unconditionally and selected.
+// Written branch-free: everything is computed unconditionally and selected.
 template <bool COLLAPSE, bool ABS_T>
-ADDER_HD void step_fast(FastPx &p, uint32_t v, const StepConsts &sc, FastEvents &ev) {
+ADDER_HD void step_fast(PxState &p, uint32_t v, const StepConsts &sc, FastEvents &ev) {
     const float I = (float)v;
     const float T = sc.time_spanned;
-    bool has0 = p.has0 != 0u;
-    bool popped = p.popped != 0u;
+    bool has0 = p.m != 0u;
+    bool popped = p.popped;
     float lastf = p.lastf;
 
     // ---- pop_best_events (event_pixel_tree.rs:213-287): A = level 0's best event; with
     // Collapse after a delta_t_max pop it is followed by the D_EMPTY filler B (:249-265) ----
-    const uint32_t diff = v > p.base ? v - p.base : p.base - v;
-    const bool flush = diff > p.cth;  // == the saturating-bounds test of video.rs:1338-1340
+    const bool flush = contrast_exceeded(v, p.base, sc.cth);
     const bool a_valid = flush && has0;
     const bool b_valid = COLLAPSE && a_valid && popped;
     {
@@ -314,14 +526,9 @@ ADDER_HD void step_fast(FastPx &p, uint32_t v, const StepConsts &sc, FastEvents 
     const float integ = has0 ? p.n0.integ : 0.0f;
     const float dt = has0 ? p.n0.dt : 0.0f;
     const float sum = fadd(integ, I);
-    // d of the node: fired_d(best_d) for level 0; for the tail floor(log2 I), which is get_d of
-    // the same `sum` (integ is 0 there)
     const uint32_t nd = get_d(sum);
     const uint32_t d = has0 ? fired_d(p.n0.bd) : nd;
     const bool fire = sum >= pow2_d(d);
-    // When prop is consumed (the node fires, I >= 1, no d = 128 involved) the numerator is an
-    // integer with 1 <= 2^nd - integ <= I + 1 <= 256 (2^d <= 2^nd <= integ + I), I an integer in
-    // [1, 255]: fdiv_small's domain.  Everywhere else the quotient is discarded.
     float prop = fdiv_small(fsub(pow2_d(nd), integ), I);
     prop = (nd == kDZero || d == kDZero || I < 1.1920929e-7f) ? 1.0f : prop;
     const float bdt_fire = fadd(dt, fmul(T, prop));
@@ -331,16 +538,6 @@ ADDER_HD void step_fast(FastPx &p, uint32_t v, const StepConsts &sc, FastEvents 
     p.n0.bd = fire ? nd : p.n0.bd;
     p.n0.bdt = fire ? bdt_fire : p.n0.bdt;
     const bool need_pop = fired_d(p.n0.bd) == kDMax || (p.n0.dt >= sc.dtm_f && !popped);  // :394-396
-
-    if (sc.c_thresh_max != 0u) {  // :402-412, u8 saturating; uniform branch
-        const bool adapt = p.cth < sc.c_thresh_max;
-        const bool bump = p.cctr >= sc.velocity_m1;
-        uint32_t cinc = p.cctr + sc.c_inc;
-        cinc = cinc > 255u ? 255u : cinc;
-        const uint32_t cth1 = p.cth >= 255u ? 255u : p.cth + 1u;
-        p.cth = (adapt && bump) ? cth1 : p.cth;
-        p.cctr = adapt ? (bump ? 0u : cinc) : p.cctr;
-    }
 
     // ---- pop_top_event (:139-210): C = the root's best event; the arena shifts left ----
     {
@@ -354,33 +551,18 @@ ADDER_HD void step_fast(FastPx &p, uint32_t v, const StepConsts &sc, FastEvents 
         ev.tc = f32_as_u32(evdt);
     }
     ev.mask = (a_valid ? 1u : 0u) | (b_valid ? 2u : 0u) | (need_pop ? 4u : 0u);
-    p.has0 = need_pop ? 0u : 1u;
-    p.popped = (popped || need_pop) ? 1u : 0u;
+    p.m = need_pop ? 0u : 1u;
+    p.popped = popped || need_pop;
     p.lastf = lastf;
 }
 
-// PxState front end (generic-capable kernels, CPU harness)
-template <bool COLLAPSE, bool ABS_T>
-ADDER_HD void step_fast(PxState &s, uint32_t v, const StepConsts &sc, FastEvents &ev) {
-    FastPx p = unpack_px(s);
-    step_fast<COLLAPSE, ABS_T>(p, v, sc, ev);
-    s.n0 = p.n0;
-    s.lastf = p.lastf;
-    s.hdr = pack_hdr(p);
-}
-
-// ---------------------------------------------------------------------------------------
-// GENERIC PATH: any arena depth.  plan_count tells how many events the step will emit
-// (so the ordered compaction can reserve the slots before the step runs), exec_step runs it.
-// ---------------------------------------------------------------------------------------
 ADDER_HD uint32_t plan_count(const PxState &s, uint32_t v, const StepConsts &sc) {
     const float I = (float)v;
-    const uint32_t flags = s.hdr >> 24;
-    const uint32_t m = flags & kFlagMMask;
-    bool popped = (flags & kFlagPopped) != 0u;
+    const uint32_t m = s.m;
+    bool popped = s.popped;
     uint32_t count = 0;
     bool from_tail = (m == 0u);
-    if (contrast_exceeded(v, s.hdr)) {
+    if (contrast_exceeded(v, s.base, sc.cth)) {
         count = (popped && sc.collapse && m > 0u) ? 2u : m;
         popped = false;
         from_tail = true;
@@ -401,16 +583,12 @@ template <bool ABS_T, class Deep, class Emit>
 ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
     const float I = (float)v;
     const float T = sc.time_spanned;
-    uint32_t flags = s.hdr >> 24;
-    uint32_t m = flags & kFlagMMask;
-    bool popped = (flags & kFlagPopped) != 0u;
-    uint32_t base = s.hdr & 0xffu;
-    uint32_t cth = (s.hdr >> 8) & 0xffu;
-    uint32_t cctr = (s.hdr >> 16) & 0xffu;
+    uint32_t m = s.m;
+    bool popped = s.popped;
     bool ok = true;
 
     // ---- pop_best_events ----
-    if (contrast_exceeded(v, s.hdr)) {
+    if (contrast_exceeded(v, s.base, sc.cth)) {
         if (popped && sc.collapse && m > 0u) {
             emit(s.n0.bd, f32_as_u32(ABS_T ? fadd(s.n0.bdt, s.lastf) : s.n0.bdt));
             s.lastf = sc.running_t;
@@ -425,7 +603,7 @@ ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &de
         }
         m = 0u;
         popped = false;
-        base = v;
+        s.base = v;
     }
 
     // ---- integrate: walk the fired levels from the root; the first one that fires
@@ -463,16 +641,6 @@ ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &de
     }
     const bool need_pop = m > 0u && root_needs_pop(s.n0, popped, sc);
 
-    if (sc.c_thresh_max != 0u && cth < sc.c_thresh_max) {
-        if (cctr >= sc.velocity_m1) {
-            cth = cth >= 255u ? 255u : cth + 1u;
-            cctr = 0u;
-        } else {
-            cctr += sc.c_inc;
-            cctr = cctr > 255u ? 255u : cctr;
-        }
-    }
-
     // ---- pop_top_event ----
     if (need_pop) {
         const uint32_t ed = s.n0.bd;
@@ -489,9 +657,8 @@ ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &de
         popped = true;
         emit(ed, event_time<ABS_T>(edt, s.lastf, sc));
     }
-
-    flags = m | (popped ? kFlagPopped : 0u);
-    s.hdr = base | (cth << 8) | (cctr << 16) | (flags << 24);
+    s.m = m;
+    s.popped = popped;
     return ok;
 }
 

@@ -160,10 +160,11 @@ def main():
         launch_frames = hv.last_launch_frames() or 1.0
         # the same kernel with one frame per launch (the per-frame `consume` contract, state
         # streamed from HBM every frame): this is the HBM-bound regime of SURVEY 8(d)
+        default_depth = int(launch_frames + 0.999)
         hv.set_frames_per_launch(1)
         step()
         launch1_us = hv.last_launch_avg_us()
-        hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "16")))
+        hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "0")) or default_depth)
         hv.set_launch_timing(False)
 
     if rank != 0:

@@ -108,6 +108,21 @@ static void evec_push(EventVec *v, OracleEvent e) {
     }
     v->data[v->len++] = e;
 }
+/* same, for a vector whose first `inline_cap` slots are caller-owned (stack) storage */
+static void evec_push_inl(EventVec *v, OracleEvent e, OracleEvent *inl) {
+    if (v->len == v->cap) {
+        size_t ncap = v->cap * 2;
+        if (v->data == inl) {
+            OracleEvent *nd = (OracleEvent *)malloc(ncap * sizeof(OracleEvent));
+            memcpy(nd, inl, v->len * sizeof(OracleEvent));
+            v->data = nd;
+        } else {
+            v->data = (OracleEvent *)realloc(v->data, ncap * sizeof(OracleEvent));
+        }
+        v->cap = ncap;
+    }
+    v->data[v->len++] = e;
+}
 
 /* rustc `f32 as u32`: truncate, saturate, NaN -> 0 */
 static uint32_t f32_as_u32(float f) {
@@ -258,17 +273,20 @@ static OracleEvent pop_top_event(PixelArena *p, float next_intensity, int mode, 
 /* event_pixel_tree.rs:213-287 */
 static void pop_best_events(PixelArena *p, EventVec *buffer, int mode, int multi_mode,
                             uint32_t ref_time, float intensity) {
-    EventVec local = {0, 0, 0};
+    /* `Vec::with_capacity(self.length)` (:221).  Small buffers live on the stack here so that the CPU
+     * baseline is not bound by malloc/free per flush; the contents and their order are the same. */
+    OracleEvent local_inline[8];
+    EventVec local = {local_inline, 0, 8};
     for (size_t node_idx = 0; node_idx < p->length; node_idx++) {
         if (!p->arena[node_idx].has_best) {
             if (p->arena[node_idx].delta_t > 0.0f && p->arena[node_idx].integration == 0.0f) {
                 Event32 e32 = get_zero_event(p, node_idx, 0, 0.0f);
-                evec_push(&local, delta_t_to_absolute_t(p, &e32, mode, ref_time));
+                evec_push_inl(&local, delta_t_to_absolute_t(p, &e32, mode, ref_time), local_inline);
             }
         } else {
             /* `Some(mut event)`: a copy; the node keeps its stored best_event */
             Event32 ev = p->arena[node_idx].best_event;
-            evec_push(&local, delta_t_to_absolute_t(p, &ev, mode, ref_time));
+            evec_push_inl(&local, delta_t_to_absolute_t(p, &ev, mode, ref_time), local_inline);
         }
     }
 
@@ -290,7 +308,7 @@ static void pop_best_events(PixelArena *p, EventVec *buffer, int mode, int multi
         p->arena[0] = p->arena[p->length - 1];
         p->arena[p->length - 1] = tmp;
     }
-    free(local.data);
+    if (local.data != local_inline) free(local.data);
     p->length = 1;
     p->need_to_pop_top = 0;
     p->dtm_reached = 0;
@@ -685,6 +703,7 @@ size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_
     }
     if (chunk_offsets) chunk_offsets[v->num_chunks] = (uint32_t)total;
     if (n_out) *n_out = total;
+    if (!out) return total; /* events stay in the chunk buffers */
     if (total > out_cap) return (size_t)-1;
     size_t off = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
@@ -692,6 +711,24 @@ size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_
         off += v->chunk_ev[ch].len;
     }
     return total;
+}
+
+/* The same frame loop as oracle_video_integrate_matrix, but the events stay in the per-chunk buffers --
+ * the reference's own return value is Vec<Vec<Event>> (video.rs:736-740), it never concatenates.  Used by
+ * the CPU-baseline timing; oracle_video_chunks_copy_out fetches them for checking. */
+size_t oracle_video_integrate_matrix_chunks(OracleVideo *v, const uint8_t *frame, size_t row_stride,
+                                            float time_spanned) {
+    size_t n = 0;
+    (void)oracle_video_integrate_matrix(v, frame, row_stride, time_spanned, NULL, (size_t)-1, &n, NULL);
+    return n;
+}
+size_t oracle_video_chunks_copy_out(const OracleVideo *v, OracleEvent *out) {
+    size_t off = 0;
+    for (size_t ch = 0; ch < v->num_chunks; ch++) {
+        memcpy(out + off, v->chunk_ev[ch].data, v->chunk_ev[ch].len * sizeof(OracleEvent));
+        off += v->chunk_ev[ch].len;
+    }
+    return off;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -727,6 +764,15 @@ size_t oracle_raw_header(uint8_t *dst, uint8_t codec_version, uint16_t width, ui
 }
 
 /* Serialises n events into dst (must hold n*(9|11) bytes); returns bytes written. */
+size_t oracle_raw_events(uint8_t *dst, const OracleEvent *ev, size_t n, uint8_t channels);
+/* the serial sink stage over the per-chunk buffers (video.rs:742-765: `for events in &big_buffer { for e in
+ * events { encoder.ingest_event(*e) } }`), for the CPU-baseline timing */
+size_t oracle_video_chunks_raw_events(const OracleVideo *v, uint8_t *dst) {
+    size_t off = 0;
+    for (size_t ch = 0; ch < v->num_chunks; ch++)
+        off += oracle_raw_events(dst + off, v->chunk_ev[ch].data, v->chunk_ev[ch].len, v->channels);
+    return off;
+}
 size_t oracle_raw_events(uint8_t *dst, const OracleEvent *ev, size_t n, uint8_t channels) {
     uint8_t *p = dst;
     if (channels == 1) {

@@ -89,6 +89,13 @@ def lib():
     L.oracle_video_integrate_matrix.restype = sz
     L.oracle_video_integrate_matrix.argtypes = [vp, vp, sz, f32, vp, sz, C.POINTER(sz), vp]
 
+    L.oracle_video_integrate_matrix_chunks.restype = sz
+    L.oracle_video_integrate_matrix_chunks.argtypes = [vp, vp, sz, f32]
+    L.oracle_video_chunks_copy_out.restype = sz
+    L.oracle_video_chunks_copy_out.argtypes = [vp, vp]
+    L.oracle_video_chunks_raw_events.restype = sz
+    L.oracle_video_chunks_raw_events.argtypes = [vp, vp]
+
     L.oracle_raw_header.restype = sz
     L.oracle_raw_header.argtypes = [vp, u8, u16, u16, u8, u32, u32, u32, u32, u32, u32]
     L.oracle_raw_events.restype = sz
@@ -253,6 +260,21 @@ class Video:
         if want_chunks:
             return ev, self._chunks.copy()
         return ev
+
+    # ---- CPU-baseline timing path (bench.py): events stay in the per-chunk buffers, like the
+    # reference's Vec<Vec<Event>> ----
+    def integrate_matrix_chunks(self, frame_ptr, row_stride, time_spanned):
+        return self.L.oracle_video_integrate_matrix_chunks(self.h, frame_ptr, row_stride, time_spanned)
+
+    def chunks_copy_out(self, n):
+        if n > self._cap:
+            self._cap = n
+            self._out = np.zeros(n, EVENT_DTYPE)
+        got = self.L.oracle_video_chunks_copy_out(self.h, self._out.ctypes.data)
+        return self._out[:got]
+
+    def chunks_raw_events(self, sink_ptr):
+        return self.L.oracle_video_chunks_raw_events(self.h, sink_ptr)
 
     def ensure_capacity(self, events_per_unit):
         cap = int(self.width * self.height * self.channels * events_per_unit) + 1024

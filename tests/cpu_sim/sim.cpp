@@ -28,30 +28,34 @@ struct Sim {
     uint32_t max_depth;
     uint32_t ref_time, dtm;
     uint32_t c_max, velocity;
+    uint8_t c_thresh, c_counter;  // ONE pair for the whole plane (adder_pixel.hpp header comment)
     uint32_t collapse, abs_t;
     float running_t;
+    // level 0 = {hdr, integ, dt, bdt}; levels k >= 1 in the deep planes at index k - 1
     std::vector<uint32_t> hdr;
+    std::vector<float> integ0, dt0, bdt0;
     std::vector<float> lastf;
-    std::vector<float> lv_integ, lv_dt, lv_bdt;  // [level][unit]
+    std::vector<float> lv_integ, lv_dt, lv_bdt;  // [level - 1][unit]
     std::vector<uint8_t> lv_bd;
     uint64_t plan_mismatch;
     uint32_t max_m;
     int use_fast;
-    uint64_t fast_steps, generic_steps, live_seen;
+    int generic_sticky;  // a generic batch has run since the last reset: lean batches are no longer allowed
+    uint64_t fast_steps, generic_steps, lean_steps;
 };
 
 struct DeepAcc {
     Sim *s;
     size_t u;
     void load(uint32_t k, Node &n) {
-        size_t i = (size_t)k * s->N + u;
+        size_t i = (size_t)(k - 1) * s->N + u;
         n.integ = s->lv_integ[i];
         n.dt = s->lv_dt[i];
         n.bdt = s->lv_bdt[i];
         n.bd = s->lv_bd[i];
     }
     void store(uint32_t k, const Node &n) {
-        size_t i = (size_t)k * s->N + u;
+        size_t i = (size_t)(k - 1) * s->N + u;
         s->lv_integ[i] = n.integ;
         s->lv_dt[i] = n.dt;
         s->lv_bdt[i] = n.bdt;
@@ -84,24 +88,31 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->max_depth = max_depth;
     s->ref_time = ref_time; s->dtm = dtm;
     s->c_max = 7; s->velocity = 7;
+    s->c_thresh = 10; s->c_counter = 1;  // PixelArena::new
     s->collapse = multi_mode == 1; s->abs_t = time_mode == 1;
     s->running_t = 0.0f;
-    s->hdr.assign(s->N, 0u | (10u << 8) | (1u << 16));  // base 0, c_thresh 10, counter 1
+    s->hdr.assign(s->N, hdr_make(0u, 0u, 0u, false));
+    s->integ0.assign(s->N, 0.0f);
+    s->dt0.assign(s->N, 0.0f);
+    s->bdt0.assign(s->N, 0.0f);
     s->lastf.assign(s->N, 0.0f);
-    s->lv_integ.assign(s->N * max_depth, 0.0f);
-    s->lv_dt.assign(s->N * max_depth, 0.0f);
-    s->lv_bdt.assign(s->N * max_depth, 0.0f);
-    s->lv_bd.assign(s->N * max_depth, 0);
+    const size_t deep = max_depth > 1 ? max_depth - 1 : 1;
+    s->lv_integ.assign(s->N * deep, 0.0f);
+    s->lv_dt.assign(s->N * deep, 0.0f);
+    s->lv_bdt.assign(s->N * deep, 0.0f);
+    s->lv_bd.assign(s->N * deep, 0);
     s->plan_mismatch = 0;
     s->max_m = 0;
     s->use_fast = 1;
-    s->fast_steps = s->generic_steps = s->live_seen = 0;
+    s->generic_sticky = 0;
+    s->fast_steps = s->generic_steps = s->lean_steps = 0;
     return s;
 }
 void sim_free(Sim *s) { delete s; }
 void sim_set_crf_parameters(Sim *s, uint8_t c_max, uint8_t velocity) { s->c_max = c_max; s->velocity = velocity; }
 void sim_reset_c_thresh(Sim *s, uint8_t baseline) {
-    for (size_t i = 0; i < s->N; i++) s->hdr[i] = (s->hdr[i] & 0xff0000ffu) | ((uint32_t)baseline << 8);
+    s->c_thresh = baseline;
+    s->c_counter = 0;
 }
 void sim_set_delta_t_max(Sim *s, uint32_t dtm) { s->dtm = dtm; }
 uint64_t sim_plan_mismatches(const Sim *s) { return s->plan_mismatch; }
@@ -109,7 +120,7 @@ uint32_t sim_max_m(const Sim *s) { return s->max_m; }
 void sim_set_use_fast(Sim *s, int on) { s->use_fast = on; }
 uint64_t sim_fast_steps(const Sim *s) { return s->fast_steps; }
 uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
-uint64_t sim_live_seen(const Sim *s) { return s->live_seen; }
+uint64_t sim_lean_steps(const Sim *s) { return s->lean_steps; }
 
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
@@ -119,13 +130,15 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     sc.running_t_u32 = f32_as_u32(s->running_t);
     sc.dtm_f = (float)s->dtm;
     sc.ref_time = s->ref_time;
-    sc.c_thresh_max = s->c_max;
-    sc.velocity_m1 = (uint8_t)(s->velocity - 1);
-    sc.c_inc = (uint8_t)(f32_as_u32(time_spanned) / s->ref_time);
+    sc.cth = s->c_thresh;
     sc.collapse = s->collapse;
     sc.abs_t = s->abs_t;
     sc.max_depth = s->max_depth;
     sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
+    // the product's variant choice (adder_hip_api.cpp enqueue_frames): lean iff Collapse with
+    // delta_t_max <= time_spanned and no generic batch has run since the last reset
+    const bool lean = s->collapse && (float)s->dtm <= time_spanned && !s->generic_sticky && s->use_fast;
+    if (!lean) s->generic_sticky = 1;
     int rc = 0;
     Emitter em;
     em.out = out; em.cap = cap; em.pos = 0;
@@ -133,24 +146,44 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     for (uint32_t y = 0; y < s->H; y++)
         for (uint32_t x = 0; x < s->W; x++)
             for (uint32_t c = 0; c < s->C; c++, u++) {
-                PxState p;
-                p.hdr = s->hdr[u];
-                uint32_t m = (p.hdr >> 24) & kFlagMMask;
-                if (m > 0) {
-                    p.n0.integ = s->lv_integ[u]; p.n0.dt = s->lv_dt[u]; p.n0.bdt = s->lv_bdt[u];
-                    p.n0.bd = s->lv_bd[u];
-                } else {
-                    // garbage on purpose: level 0 must not be read when m == 0
-                    p.n0.integ = -12345.0f; p.n0.dt = -777.0f; p.n0.bdt = -999.0f; p.n0.bd = 77;
+                const uint32_t hdr = s->hdr[u];
+                uint32_t m = hdr_m(hdr);
+                // garbage on purpose: level 0 must not be read when m == 0
+                const float gi = m ? s->integ0[u] : -12345.0f, gd = m ? s->dt0[u] : -777.0f,
+                            gb = m ? s->bdt0[u] : -999.0f;
+                const float glf = s->abs_t ? s->lastf[u] : -1.0f;
+                const uint32_t v = frame[u];
+                em.x = (uint16_t)x; em.y = (uint16_t)(y + s->row_begin); em.c = s->C == 1 ? 0xFF : (uint8_t)c;
+                if (lean) {
+                    LeanPx p = lean_unpack<ScalarLanes>(hdr, gi, gd, gb, glf);
+                    LeanRec rec;
+                    const uint32_t tag = (uint32_t)(u & 255u) << kLeanUnitShift;
+                    const LeanFlagsT<ScalarLanes> fl = s->abs_t ? lean_step<true>(p, v, sc.cth, time_spanned, sc, tag, rec)
+                                                                 : lean_step<false>(p, v, sc.cth, time_spanned, sc, tag, rec);
+                    if (fl.b && !fl.a) rc = -9;
+                    if (fl.a || fl.c) {
+                        if (((rec.wa >> kLeanUnitShift) & 255u) != (u & 255u)) rc = -9;  // the tag must survive
+                        const LeanEvents e = lean_decode(rec, s->abs_t != 0, sc.running_t_u32);
+                        if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
+                        if (e.a) em(e.da, e.ta);
+                        if (e.b) em(kDEmpty, e.tb);
+                        if (e.c) em(e.dc, e.tc);
+                    } else if ((rec.wa & (kLeanA | kLeanB)) || (rec.wc & kLeanC)) {
+                        rc = -9;
+                    }
+                    s->hdr[u] = lean_hdr(p);
+                    if (p.has0) { s->integ0[u] = p.integ; s->dt0[u] = p.dt; s->bdt0[u] = p.bdt; }
+                    if (s->abs_t) s->lastf[u] = p.lastf;
+                    if (p.has0 && s->max_m < 1) s->max_m = 1;
+                    s->lean_steps++;
+                    continue;
                 }
-                p.lastf = s->abs_t ? s->lastf[u] : -1.0f;
-                uint32_t v = frame[u];
+                PxState p = px_unpack(hdr, gi, gd, gb, glf);
                 uint32_t planned = plan_count(p, v, sc);
                 size_t before = em.pos;
-                em.x = (uint16_t)x; em.y = (uint16_t)(y + s->row_begin); em.c = s->C == 1 ? 0xFF : (uint8_t)c;
                 bool fast = false;
                 if (s->use_fast)
-                    fast = s->collapse ? fast_eligible<true>(p, v) : fast_eligible<false>(p, v);
+                    fast = s->collapse ? fast_eligible<true>(p, v, sc.cth) : fast_eligible<false>(p, v, sc.cth);
                 if (fast) {
                     FastEvents fe;
                     if (s->collapse && s->abs_t) step_fast<true, true>(p, v, sc, fe);
@@ -167,16 +200,14 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                     s->generic_steps++;
                 }
                 if (em.pos - before != planned) s->plan_mismatch++;
-                s->hdr[u] = p.hdr;
-                m = (p.hdr >> 24) & kFlagMMask;
+                s->hdr[u] = px_hdr(p);
+                m = p.m;
                 if (m > s->max_m) s->max_m = m;
-                if (m > 0) {
-                    s->lv_integ[u] = p.n0.integ; s->lv_dt[u] = p.n0.dt; s->lv_bdt[u] = p.n0.bdt;
-                    s->lv_bd[u] = (uint8_t)p.n0.bd;
-                }
+                if (m > 0) { s->integ0[u] = p.n0.integ; s->dt0[u] = p.n0.dt; s->bdt0[u] = p.n0.bdt; }
                 if (s->abs_t) s->lastf[u] = p.lastf;
             }
     s->running_t += time_spanned;
+    c_thresh_advance(s->c_thresh, s->c_counter, (uint8_t)s->c_max, (uint8_t)s->velocity, time_spanned, s->ref_time);
     *n_out = em.pos;
     if (em.pos > cap && rc == 0) rc = -4;
     return rc;

@@ -45,6 +45,8 @@ def lib():
     L.sim_fast_steps.argtypes = [vp]
     L.sim_generic_steps.restype = C.c_uint64
     L.sim_generic_steps.argtypes = [vp]
+    L.sim_lean_steps.restype = C.c_uint64
+    L.sim_lean_steps.argtypes = [vp]
     L.sim_integrate.restype = i32
     L.sim_integrate.argtypes = [vp, vp, f32, vp, sz, C.POINTER(sz)]
     L.sim_framer_run.restype = C.c_int64
@@ -98,6 +100,10 @@ class Sim:
     @property
     def generic_steps(self):
         return self.L.sim_generic_steps(self.h)
+
+    @property
+    def lean_steps(self):
+        return self.L.sim_lean_steps(self.h)
 
     @property
     def plan_mismatches(self):

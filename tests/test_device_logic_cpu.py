@@ -114,3 +114,70 @@ def test_depth_overflow_is_reported():
     sv.reset_c_thresh(0)
     rcs = [sv.integrate(clip[k], 255.0)[0] for k in range(200)]
     assert -5 in rcs
+
+
+def _pair(W, H, Cn, tm, mm, dtm, ref_time=255, max_depth=20):
+    ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=mm, ref_time=ref_time, delta_t_max=dtm)
+    sv = Sim(W, H, Cn, time_mode=tm, multi_mode=mm, ref_time=ref_time, delta_t_max=dtm, max_depth=max_depth)
+    ov.ensure_capacity(max_depth + 2)
+    return ov, sv
+
+
+def _same(ov, sv, frame, ts):
+    a = ov.integrate_matrix(frame, time_spanned=ts)
+    rc, b = sv.integrate(frame, ts)
+    assert rc == 0
+    assert len(a) == len(b) and np.array_equal(a, b)
+    return len(a)
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("crf", [0, 3, 9])
+def test_lean_step_is_the_path_of_the_headline_mode(time_mode, crf):
+    """Collapse with delta_t_max <= time_spanned runs lean_step + lean_decode (16-byte records) only."""
+    for kind in ("noise", "dark", "jitter", "runs", "steps", "static"):
+        clip = clips.make_clip(kind, 120, 5, 7, 1, seed=crf * 7 + time_mode)
+        ov, sv = _pair(7, 5, 1, time_mode, O.COLLAPSE, 255)
+        base, cmax, vel = CRFS[crf]
+        for v in (ov, sv):
+            v.set_crf_parameters(cmax, vel)
+            v.reset_c_thresh(base)
+        for k in range(len(clip)):
+            _same(ov, sv, clip[k], 255.0)
+        assert sv.lean_steps == 120 * 35 and sv.fast_steps == 0 and sv.generic_steps == 0
+
+
+def test_lean_step_time_spanned_above_delta_t_max_and_long_runs():
+    # time_spanned = 2 * ref_time (c_increase_counter advances by 2, :408-410); a 700-frame static
+    # stretch drives t past 2^17
+    clip = clips.make_clip("steps", 700, 3, 4, 1, seed=77)
+    clip[100:680] = clip[100]
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _pair(4, 3, 1, tm, O.COLLAPSE, 255)
+        for v in (ov, sv):
+            v.set_crf_parameters(7, 7)
+            v.reset_c_thresh(2)
+        for k in range(len(clip)):
+            _same(ov, sv, clip[k], 510.0 if k % 3 == 0 else 255.0)
+        assert sv.generic_steps == 0
+
+
+def test_quality_change_mid_stream_keeps_parity():
+    """update_quality_manual mid-stream (video.rs:1264-1287): after generic batches the lean variant
+    must not be chosen again even when delta_t_max drops to ref_time (pixels may hold m >= 2)."""
+    clip = clips.make_clip("runs", 150, 6, 6, 1, seed=99)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _pair(6, 6, 1, tm, O.COLLAPSE, 7650)
+        for v in (ov, sv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        for k in range(60):
+            _same(ov, sv, clip[k], 255.0)
+        assert sv.max_m >= 2
+        for v in (ov, sv):  # update_quality_manual(c_thresh_baseline=1, max=3, multiplier=1, velocity=4)
+            v.set_crf_parameters(3, 4)
+            v.set_delta_t_max(255)
+            v.reset_c_thresh(1)
+        for k in range(60, 150):
+            _same(ov, sv, clip[k], 255.0)
+        assert sv.lean_steps == 0
