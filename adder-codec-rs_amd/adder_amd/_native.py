@@ -100,6 +100,10 @@ SYMBOLS = {
     "adder_hip_set_launch_timing": (_i32, [_vp, _i32]),
     "adder_hip_last_launch_avg_us": (_f32, [_vp]),
     "adder_hip_last_launch_frames": (_f32, [_vp]),
+    "adder_hip_last_post_avg_us": (_f32, [_vp]),
+    "adder_hip_last_post_chunks": (_u32, [_vp]),
+    "adder_hip_chunk_frames": (_u32, [_vp]),
+    "adder_hip_last_batch_records": (_u64, [_vp]),
     "adder_hip_set_frames_per_launch": (_i32, [_vp, _u32]),
     "adder_hip_reset": (_i32, [_vp]),
     "adder_hip_wire_events_device": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
@@ -108,6 +112,9 @@ SYMBOLS = {
     "adder_hip_stream_collect": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_vp)]),
     "adder_hip_selftest_division": (_i32, [_vp]),
     "adder_hip_synth_clip_device": (_i32, [_vp, _i32, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
+    "adder_hip_merge_work_bytes": (_sz, [_u32, _u32]),
+    "adder_hip_merge_streams_device": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp]),
+    "adder_hip_check_status": (_i32, [_vp, _vp]),
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
     "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),
     "adder_raw_eof": (_sz, [_vp]),

@@ -1,0 +1,103 @@
+"""HipGather: ctypes binding of libadder_rccl.so (include/adder_gather.h) -- the multi-GPU ordered
+gather of the row bands' event streams over RCCL, as a Rust host would call it (no torch inside).
+
+The communicator is created from an RCCL unique id that rank 0 makes and the caller ships to the other
+ranks (bench.py / the tests broadcast it with torch.distributed; a Rust host would use its own means).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native as N
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libadder_rccl.so")
+UNIQUE_ID_BYTES = 128
+
+_vp, _i32, _u32, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+SYMBOLS = {
+    "adder_gather_unique_id": (_i32, [_vp]),
+    "adder_gather_create": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "adder_gather_create_from_id": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "adder_gather_destroy": (None, [_vp]),
+    "adder_gather_last_error": (C.c_char_p, [_vp]),
+    "adder_gather_world": (_i32, [_vp]),
+    "adder_gather_events": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _sz, _vp, C.POINTER(_sz), _vp]),
+    "adder_gather_layout": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
+}
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    N.load()  # libadder_hip.so first (and torch before it, see _native.load): one HIP / RCCL copy per process
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: build it with `make -C adder-codec-rs_amd`")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def unique_id():
+    """ncclGetUniqueId -> 128 bytes (rank 0 calls this and ships the bytes to the other ranks)."""
+    buf = np.zeros(UNIQUE_ID_BYTES, np.uint8)
+    rc = load().adder_gather_unique_id(buf.ctypes.data)
+    if rc != N.OK:
+        raise N.AdderHipError(rc, (load().adder_gather_last_error(None) or b"").decode())
+    return buf.tobytes()
+
+
+class HipGather:
+    def __init__(self, video, uid, rank, world):
+        self.L = load()
+        self.video = video  # keeps the context alive
+        h = C.c_void_p()
+        idbuf = np.frombuffer(uid, np.uint8).copy()
+        rc = self.L.adder_gather_create_from_id(video.h, idbuf.ctypes.data, rank, world, C.byref(h))
+        if rc != N.OK:
+            raise N.AdderHipError(rc, (self.L.adder_gather_last_error(None) or b"").decode())
+        self.h = h
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.adder_gather_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != N.OK:
+            raise N.AdderHipError(rc, (self.L.adder_gather_last_error(self.h) or b"").decode())
+
+    def gather_events(self, d_events, d_offsets, T, root=0, d_merged=None, d_merged_offsets=None, stream=None):
+        """d_events / d_offsets: this rank's stream (CUDA tensors); on root d_merged (uint8/int32 CUDA tensor
+        of 12*cap bytes) and d_merged_offsets (int64 [T+1]) receive the merged stream.  Returns its length."""
+        n = C.c_size_t(0)
+        cap = 0 if d_merged is None else d_merged.numel() * d_merged.element_size() // 12
+        rc = self.L.adder_gather_events(
+            self.h, d_events.data_ptr(), d_offsets.data_ptr(), T, root,
+            None if d_merged is None else d_merged.data_ptr(), cap,
+            None if d_merged_offsets is None else d_merged_offsets.data_ptr(), C.byref(n),
+            C.c_void_p(stream) if stream else None)
+        self.last_required = n.value
+        self._check(rc)
+        return n.value
+
+    def layout(self, d_offsets, T, stream=None):
+        """-> (merged frame offsets [T+1], this rank's base per frame [T]) as numpy uint64."""
+        merged = np.zeros(T + 1, np.uint64)
+        base = np.zeros(max(T, 1), np.uint64)
+        self._check(self.L.adder_gather_layout(self.h, d_offsets.data_ptr(), T, merged.ctypes.data, base.ctypes.data,
+                                               C.c_void_p(stream) if stream else None))
+        return merged, base[:T]

@@ -86,34 +86,64 @@ def place_segments(out, events, offsets, my_base):
     return out
 
 
-def gather_event_stream(events, offsets, dst=0, group=None):
+def gather_event_stream(events, offsets, dst=0, group=None, video=None):
     """Ordered variable-length gather of every rank's frame-major event segment to `dst`.
     events: int32 [n, 3] (the 12-byte records), offsets: int64 [T+1].  Returns the merged
-    (events, offsets) on dst and None elsewhere."""
+    (events, offsets) on dst and None elsewhere.
+
+    Transport: an all-gather of the offsets, then grouped point-to-point transfers (RCCL over xGMI
+    on CUDA tensors) straight into one staging buffer on dst, rank after rank.  Merge: on CUDA tensors
+    the HIP merge kernel of libadder_hip.so through `video` (a HipVideo on dst's device;
+    adder_hip_merge_streams_device); the torch index arithmetic of merge_frame_major only serves CPU
+    tensors (gloo tests)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return events, offsets
-    offsets = offsets.contiguous()
-    all_offs = [torch.empty_like(offsets) for _ in range(world)]
-    dist.all_gather(all_offs, offsets, group=group)
-    ops, segs = [], None
+    dev = events.device
+    # gloo has no device point-to-point: CUDA tensors then travel through host copies (single-GPU debug
+    # boxes, where RCCL cannot place two ranks on one device); the merge still runs on the device
+    via_host = events.is_cuda and dist.get_backend(group) == "gloo"
+    tdev = torch.device("cpu") if via_host else dev
+    offsets = offsets.contiguous().to(tdev)
+    T = offsets.numel() - 1
+    all_offs = torch.empty((world, T + 1), dtype=offsets.dtype, device=tdev)
+    if tdev.type == "cuda":
+        dist.all_gather_into_tensor(all_offs, offsets, group=group)
+    else:
+        dist.all_gather(list(all_offs.unbind(0)), offsets, group=group)
+    totals = all_offs[:, -1].tolist()
+    ops, stage = [], None
     if rank == dst:
-        segs = []
+        stage = torch.empty((int(sum(totals)), 3), dtype=torch.int32, device=tdev)
+        pos = 0
         for r in range(world):
+            n_r = int(totals[r])
             if r == dst:
-                segs.append((events, offsets))
-                continue
-            n_r = int(all_offs[r][-1])
-            buf = torch.empty((n_r, 3), dtype=torch.int32, device=events.device)
-            segs.append((buf, all_offs[r]))
-            if n_r:
-                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+                stage[pos:pos + n_r] = events[:n_r].to(tdev)
+            elif n_r:
+                ops.append(dist.P2POp(dist.irecv, stage[pos:pos + n_r], r, group))
+            pos += n_r
     elif events.shape[0]:
-        ops.append(dist.P2POp(dist.isend, events.contiguous(), dst, group))
+        ops.append(dist.P2POp(dist.isend, events.contiguous().to(tdev), dst, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     if rank != dst:
         return None
+    if via_host:
+        stage, all_offs = stage.to(dev), all_offs.to(dev)
+    if events.is_cuda:
+        if video is None:
+            raise ValueError("gather_event_stream on CUDA tensors needs video= (the HIP merge kernel's context)")
+        out = torch.empty_like(stage)
+        merged_offs = torch.empty(T + 1, dtype=torch.int64, device=events.device)
+        video.merge_streams_device(stage, all_offs, world, T, out, merged_offs,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+        return out, merged_offs
+    pos, segs = 0, []
+    for r in range(world):
+        n_r = int(totals[r])
+        segs.append((stage[pos:pos + n_r], all_offs[r]))
+        pos += n_r
     return merge_frame_major(segs)

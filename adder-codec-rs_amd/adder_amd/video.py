@@ -222,6 +222,18 @@ class HipVideo:
     def last_launch_avg_us(self):
         return float(self.L.adder_hip_last_launch_avg_us(self.h))
 
+    def last_post_avg_us(self):
+        return float(self.L.adder_hip_last_post_avg_us(self.h))
+
+    def last_post_chunks(self):
+        return int(self.L.adder_hip_last_post_chunks(self.h))
+
+    def chunk_frames(self):
+        return int(self.L.adder_hip_chunk_frames(self.h))
+
+    def last_batch_records(self):
+        return int(self.L.adder_hip_last_batch_records(self.h))
+
     def last_launch_frames(self):
         return float(self.L.adder_hip_last_launch_frames(self.h))
 
@@ -231,6 +243,23 @@ class HipVideo:
     def reset(self):
         """Back to the freshly constructed state (Video::new); parameters are kept."""
         N.check(self.h, self.L.adder_hip_reset(self.h))
+
+    def merge_streams_device(self, d_stage, d_rank_offsets, world, T, d_out, d_merged_offsets=None, stream=None):
+        """Multi-GPU merge (include/adder_hip.h): `world` frame-major streams laid back to back in d_stage
+        (rank offsets: int64 CUDA tensor [world, T+1]) -> one frame-major stream in d_out, rank order inside
+        every frame.  Asynchronous; check_status() reports a capacity overflow."""
+        import torch
+        need = self.L.adder_hip_merge_work_bytes(world, T)
+        if getattr(self, "_merge_work", None) is None or self._merge_work.numel() < need:
+            self._merge_work = torch.empty(max(need, 8), dtype=torch.uint8, device=d_out.device)
+        cap = d_out.numel() * d_out.element_size() // 12
+        N.check(self.h, self.L.adder_hip_merge_streams_device(
+            self.h, d_stage.data_ptr(), d_rank_offsets.data_ptr(), world, T, self._merge_work.data_ptr(),
+            d_out.data_ptr(), cap, None if d_merged_offsets is None else d_merged_offsets.data_ptr(),
+            C.c_void_p(stream) if stream else None))
+
+    def check_status(self, stream=None):
+        N.check(self.h, self.L.adder_hip_check_status(self.h, C.c_void_p(stream) if stream else None))
 
     def chunk_offsets_device(self, d_events_ptr, n_events, d_chunk_offsets, stream=None):
         N.check(self.h, self.L.adder_hip_chunk_offsets_device(

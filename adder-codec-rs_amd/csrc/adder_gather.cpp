@@ -1,0 +1,231 @@
+// adder_gather.cpp -- libadder_rccl.so: the multi-GPU event-stream gather (include/adder_gather.h).
+// RCCL collectives over xGMI + the merge kernel of libadder_hip.so; nothing here computes events.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adder_gather.h"
+
+static_assert(sizeof(ncclUniqueId) == ADDER_GATHER_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+struct AdderGather {
+    AdderHipCtx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owns_comm = false;
+    int rank = 0, world = 1, device = 0;
+    // device scratch, grown on demand
+    uint64_t *d_all_offs = nullptr;  // [world][T+1]
+    size_t all_offs_cap = 0;         // bytes
+    void *d_work = nullptr;          // merge layout
+    size_t work_cap = 0;
+    AdderEvent *d_stage = nullptr;   // root: the ranks' streams back to back
+    size_t stage_cap = 0;            // bytes
+    std::vector<uint64_t> h_offs;    // host copy of d_all_offs
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int gfail(AdderGather *g, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g)
+        g->err = buf;
+    else
+        g_err = buf;
+    return code;
+}
+
+#define GHIP(g, expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return gfail(g, ADDER_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define GNCCL(g, expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess)                                                                             \
+            return gfail(g, ADDER_E_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+static int grow(AdderGather *g, void **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return ADDER_OK;
+    void *old = *p;
+    *p = nullptr;
+    *cap = 0;
+    if (old) GHIP(g, hipFree(old));
+    GHIP(g, hipMalloc(p, std::max<size_t>(need, 256)));
+    *cap = need;
+    return ADDER_OK;
+}
+
+extern "C" int adder_gather_unique_id(uint8_t id_out[ADDER_GATHER_UNIQUE_ID_BYTES]) {
+    if (!id_out) return ADDER_E_BAD_PARAMS;
+    ncclUniqueId id;
+    GNCCL(nullptr, ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return ADDER_OK;
+}
+
+static int create_common(AdderHipCtx *ctx, int rank, int world, AdderGather **out, AdderGather **g_out) {
+    if (!out) return gfail(nullptr, ADDER_E_BAD_PARAMS, "out is null");
+    *out = nullptr;
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return gfail(nullptr, ADDER_E_BAD_PARAMS, "bad ctx / rank / world");
+    AdderGather *g = new (std::nothrow) AdderGather();
+    if (!g) return gfail(nullptr, ADDER_E_HIP, "out of host memory");
+    g->ctx = ctx;
+    g->rank = rank;
+    g->world = world;
+    if (hipGetDevice(&g->device) != hipSuccess) g->device = 0;
+    *g_out = g;
+    return ADDER_OK;
+}
+
+extern "C" int adder_gather_create(AdderHipCtx *ctx, void *nccl_comm, int rank, int world, AdderGather **out) {
+    if (!nccl_comm) return gfail(nullptr, ADDER_E_BAD_PARAMS, "nccl_comm is null");
+    AdderGather *g = nullptr;
+    int rc = create_common(ctx, rank, world, out, &g);
+    if (rc != ADDER_OK) return rc;
+    g->comm = (ncclComm_t)nccl_comm;
+    *out = g;
+    return ADDER_OK;
+}
+
+extern "C" int adder_gather_create_from_id(AdderHipCtx *ctx, const uint8_t id[ADDER_GATHER_UNIQUE_ID_BYTES], int rank,
+                                           int world, AdderGather **out) {
+    if (!id) return gfail(nullptr, ADDER_E_BAD_PARAMS, "id is null");
+    AdderGather *g = nullptr;
+    int rc = create_common(ctx, rank, world, out, &g);
+    if (rc != ADDER_OK) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = ncclCommInitRank(&g->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        g_err = std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r);
+        delete g;
+        return ADDER_E_HIP;
+    }
+    g->owns_comm = true;
+    *out = g;
+    return ADDER_OK;
+}
+
+extern "C" void adder_gather_destroy(AdderGather *g) {
+    if (!g) return;
+    if (g->d_all_offs) (void)hipFree(g->d_all_offs);
+    if (g->d_work) (void)hipFree(g->d_work);
+    if (g->d_stage) (void)hipFree(g->d_stage);
+    if (g->owns_comm && g->comm) (void)ncclCommDestroy(g->comm);
+    delete g;
+}
+
+extern "C" const char *adder_gather_last_error(const AdderGather *g) { return g ? g->err.c_str() : g_err.c_str(); }
+extern "C" int adder_gather_world(const AdderGather *g) { return g ? g->world : 0; }
+
+// all-gather of the ranks' frame offsets -> g->d_all_offs [world][T+1] and its host copy
+static int gather_offsets(AdderGather *g, const uint64_t *d_frame_offsets, uint32_t T, hipStream_t s) {
+    const size_t per = (size_t)T + 1;
+    void *p = g->d_all_offs;
+    int rc = grow(g, &p, &g->all_offs_cap, per * g->world * sizeof(uint64_t));
+    g->d_all_offs = (uint64_t *)p;
+    if (rc != ADDER_OK) return rc;
+    GNCCL(g, ncclAllGather(d_frame_offsets, g->d_all_offs, per, ncclUint64, g->comm, s));
+    g->h_offs.resize(per * g->world);
+    GHIP(g, hipMemcpyAsync(g->h_offs.data(), g->d_all_offs, per * g->world * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GHIP(g, hipStreamSynchronize(s));
+    return ADDER_OK;
+}
+
+extern "C" int adder_gather_layout(AdderGather *g, const uint64_t *d_frame_offsets, uint32_t T,
+                                   uint64_t *h_merged_offsets, uint64_t *h_my_base, void *stream) {
+    if (!g || !d_frame_offsets) return gfail(g, ADDER_E_BAD_PARAMS, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = gather_offsets(g, d_frame_offsets, T, s);
+    if (rc != ADDER_OK) return rc;
+    const size_t per = (size_t)T + 1;
+    uint64_t run = 0;
+    if (h_merged_offsets) h_merged_offsets[0] = 0;
+    for (uint32_t f = 0; f < T; ++f) {
+        uint64_t before = 0;
+        for (int r = 0; r < g->world; ++r) {
+            if (r == g->rank && h_my_base) h_my_base[f] = run + before;
+            before += g->h_offs[r * per + f + 1] - g->h_offs[r * per + f];
+        }
+        run += before;
+        if (h_merged_offsets) h_merged_offsets[f + 1] = run;
+    }
+    return ADDER_OK;
+}
+
+extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                   uint32_t T, int root, AdderEvent *d_merged, size_t merged_cap,
+                                   uint64_t *d_merged_offsets, size_t *n_merged, void *stream) {
+    if (n_merged) *n_merged = 0;
+    if (!g || !d_frame_offsets) return gfail(g, ADDER_E_BAD_PARAMS, "null argument");
+    if (root < 0 || root >= g->world) return gfail(g, ADDER_E_BAD_PARAMS, "bad root %d", root);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = gather_offsets(g, d_frame_offsets, T, s);
+    if (rc != ADDER_OK) return rc;
+    const size_t per = (size_t)T + 1;
+    std::vector<uint64_t> tot(g->world), base(g->world + 1, 0);
+    for (int r = 0; r < g->world; ++r) {
+        tot[r] = g->h_offs[r * per + T];
+        base[r + 1] = base[r] + tot[r];
+    }
+    const uint64_t total = base[g->world];
+    if (g->rank == root) {
+        if (total > merged_cap) {
+            if (n_merged) *n_merged = (size_t)total;
+            // still take part in the exchange below with a staging buffer, so that no rank hangs
+        }
+        void *p = g->d_stage;
+        rc = grow(g, &p, &g->stage_cap, (size_t)total * sizeof(AdderEvent));
+        g->d_stage = (AdderEvent *)p;
+        if (rc != ADDER_OK) return rc;
+    }
+    // payload: every rank -> root, back to back in rank order (ncclGroup of point-to-point transfers
+    // over xGMI; root's own stream is a device copy)
+    GNCCL(g, ncclGroupStart());
+    if (g->rank == root) {
+        for (int r = 0; r < g->world; ++r) {
+            if (r == root || tot[r] == 0) continue;
+            GNCCL(g, ncclRecv(g->d_stage + base[r], (size_t)tot[r] * sizeof(AdderEvent), ncclUint8, r, g->comm, s));
+        }
+    } else if (tot[g->rank] != 0) {
+        GNCCL(g, ncclSend(d_events, (size_t)tot[g->rank] * sizeof(AdderEvent), ncclUint8, root, g->comm, s));
+    }
+    GNCCL(g, ncclGroupEnd());
+    if (g->rank != root) {
+        GHIP(g, hipStreamSynchronize(s));
+        return ADDER_OK;
+    }
+    if (tot[root])
+        GHIP(g, hipMemcpyAsync(g->d_stage + base[root], d_events, (size_t)tot[root] * sizeof(AdderEvent),
+                               hipMemcpyDeviceToDevice, s));
+    if (n_merged) *n_merged = (size_t)total;
+    if (total > merged_cap) {
+        GHIP(g, hipStreamSynchronize(s));
+        return gfail(g, ADDER_E_OUT_CAPACITY, "merged buffer too small: need %llu events", (unsigned long long)total);
+    }
+    void *p = g->d_work;
+    rc = grow(g, &p, &g->work_cap, adder_hip_merge_work_bytes((uint32_t)g->world, T));
+    g->d_work = p;
+    if (rc != ADDER_OK) return rc;
+    rc = adder_hip_merge_streams_device(g->ctx, g->d_stage, g->d_all_offs, (uint32_t)g->world, T, g->d_work, d_merged,
+                                        merged_cap, d_merged_offsets, s);
+    if (rc != ADDER_OK) return gfail(g, rc, "merge: %s", adder_hip_last_error(g->ctx));
+    rc = adder_hip_check_status(g->ctx, s);
+    if (rc != ADDER_OK) return gfail(g, rc, "merge: %s", adder_hip_last_error(g->ctx));
+    return ADDER_OK;
+}

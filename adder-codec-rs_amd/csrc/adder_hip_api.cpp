@@ -70,6 +70,11 @@ struct AdderHipCtx {
     bool use_graph = true;
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
+    uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
+    uint64_t last_records = 0;
+    std::vector<hipEvent_t> post_events;  // launch timing: pairs around scan + offsets + expand of every chunk
+    uint32_t timed_posts = 0;
+    float last_post_avg_us = 0.0f;
     uint64_t *d_offsets = nullptr;  // internal frame offsets (host-buffer API)
     size_t d_offsets_cap = 0;       // all *_cap below are in BYTES
     // staging for the host-buffer API
@@ -162,6 +167,8 @@ static void free_ctx(AdderHipCtx *c) {
     }
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
+    if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->d_batch) (void)hipFree(c->d_batch);
     if (c->h_batch) (void)hipHostFree(c->h_batch);
@@ -357,6 +364,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->status, 1));
+        HIPCHK(c, dalloc(&c->d_rec_total, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -508,9 +516,14 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             HIPCHK(c, hipStreamWaitEvent(s2, c->cap_e1, 0));
             t = s2;
         }
+        if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, t));
+        if (timing) {
+            HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));
+            c->timed_posts += 1;
+        }
         if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 3u], s2));
     }
     if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 3u], 0));  // join (s2 is in-order)
@@ -609,18 +622,26 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;
     b.slots = c->slots;
+    b.rec_total = c->d_rec_total;
+    HIPCHK(c, hipMemsetAsync(c->d_rec_total, 0, sizeof(uint64_t), stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ftab, c->h_ftab, num_frames * sizeof(FrameTab), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
     HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
 
     c->timed_launches = 0;
     c->timed_frames = 0;
+    c->timed_posts = 0;
     const bool timing = c->launch_timing;
     if (timing) {
         while (c->launch_events.size() < 2 * (size_t)num_frames) {
             hipEvent_t e;
             HIPCHK(c, hipEventCreate(&e));
             c->launch_events.push_back(e);
+        }
+        while (c->post_events.size() < 2 * (size_t)num_frames) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->post_events.push_back(e);
         }
     }
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
@@ -687,6 +708,8 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
     HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));
     HIPCHK(c, hipMemcpyAsync(&total, c->pending_offsets + c->pending_frames, sizeof total, hipMemcpyDeviceToHost,
                              c->pending_stream));
+    HIPCHK(c, hipMemcpyAsync(&c->last_records, c->d_rec_total, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                             c->pending_stream));
     HIPCHK(c, hipStreamSynchronize(c->pending_stream));
     if (c->pending_frames)
         HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev_start, c->ev_stop));
@@ -702,6 +725,16 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
         }
         c->last_launch_avg_us = (float)(sum * 1000.0 / c->timed_launches);
     }
+    c->last_post_avg_us = 0.0f;
+    if (c->timed_posts) {
+        double sum = 0.0;
+        for (uint32_t k = 0; k < c->timed_posts; ++k) {
+            float ms = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->post_events[2 * k], c->post_events[2 * k + 1]));
+            sum += ms;
+        }
+        c->last_post_avg_us = (float)(sum * 1000.0 / c->timed_posts);
+    }
     if (n_out) *n_out = (size_t)total;
     return status_to_code(c, st);
 }
@@ -715,6 +748,11 @@ extern "C" int adder_hip_set_launch_timing(AdderHipCtx *c, int enable) {
 }
 
 extern "C" float adder_hip_last_launch_avg_us(AdderHipCtx *c) { return c ? c->last_launch_avg_us : 0.0f; }
+
+extern "C" float adder_hip_last_post_avg_us(AdderHipCtx *c) { return c ? c->last_post_avg_us : 0.0f; }
+extern "C" uint32_t adder_hip_last_post_chunks(AdderHipCtx *c) { return c ? c->timed_posts : 0u; }
+extern "C" uint64_t adder_hip_last_batch_records(AdderHipCtx *c) { return c ? c->last_records : 0ull; }
+extern "C" uint32_t adder_hip_chunk_frames(const AdderHipCtx *c) { return c ? c->chunk : 0u; }
 
 extern "C" float adder_hip_last_launch_frames(AdderHipCtx *c) {
     return (c && c->timed_launches) ? (float)c->timed_frames / (float)c->timed_launches : 0.0f;
@@ -1022,4 +1060,37 @@ extern "C" int adder_hip_synth_clip_device(uint8_t *d_dst, int content, uint64_t
         return ADDER_E_HIP;
     }
     return ADDER_OK;
+}
+
+// ---- multi-GPU: merge of the row bands' streams (include/adder_hip.h) ----
+extern "C" size_t adder_hip_merge_work_bytes(uint32_t world, uint32_t num_frames) {
+    return ((size_t)num_frames + 1 + (size_t)world * num_frames) * sizeof(uint64_t);
+}
+
+extern "C" int adder_hip_merge_streams_device(AdderHipCtx *c, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
+                                              uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
+                                              size_t out_cap, uint64_t *d_merged_offsets, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (!d_rank_offsets || !d_work || world == 0 || (!d_out && out_cap))
+        return fail(c, ADDER_E_BAD_PARAMS, "merge: null pointer or empty world");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (num_frames == 0) {
+        if (d_merged_offsets) HIPCHK(c, hipMemsetAsync(d_merged_offsets, 0, sizeof(uint64_t), s));
+        return ADDER_OK;
+    }
+    HIPCHK(c, adder_launch_merge(reinterpret_cast<const AdderEventPod *>(d_stage), d_rank_offsets, world, num_frames,
+                                 reinterpret_cast<uint64_t *>(d_work), reinterpret_cast<AdderEventPod *>(d_out), out_cap,
+                                 d_merged_offsets, c->status, s));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_check_status(AdderHipCtx *c, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return status_to_code(c, st);
 }

@@ -101,6 +101,7 @@ struct BatchArgs {
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [slots]
     uint32_t slots;
+    uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
 };
 
 __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) {
@@ -138,6 +139,10 @@ hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t 
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,
                                       uint32_t chunk_rows, uint32_t num_chunks, uint32_t *offsets,
                                       hipStream_t stream);
+// merge of `world` frame-major streams laid back to back in `stage` (offs = [world][T+1]); work = (T+1) + world*T uint64
+hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
+                              uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap, uint64_t *merged_offsets,
+                              uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_synth(uint8_t *dst, int content, uint64_t seed, uint32_t W, uint32_t H, uint32_t C,
                               uint32_t y0, uint32_t rows, uint32_t k0, uint32_t nframes, hipStream_t stream);
 }

@@ -204,7 +204,7 @@ __device__ __forceinline__ void lean_load(const FrameArgs &a, uint32_t u0, bool 
 
 // FULL: the whole wave lies inside the band (every wave but possibly the band's last ones): no
 // per-unit bounds handling inside the frame loop.
-template <bool ABS_T, bool FULL>
+template <bool ABS_T, bool FULL, uint32_t NB_MAX>
 __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                             uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
                                             uint8_t *lds_in) {
@@ -247,14 +247,14 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     {
         // (no control flow between the loads: frames past the launch's last one re-read that one)
         const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-        uint32_t vin_all[kMaxFramesPerLaunch];
+        uint32_t vin_all[NB_MAX];
 #pragma unroll
-        for (uint32_t k = 0; k < kMaxFramesPerLaunch; ++k) {
+        for (uint32_t k = 1; k < NB_MAX; ++k) {  // (row 0 is raw.vin_w, in a register already)
             const uint32_t kk = k < nb ? k : nb - 1u;  // uniform
             vin_all[k] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
         }
 #pragma unroll
-        for (uint32_t k = 0; k < kMaxFramesPerLaunch; ++k) in_lds[k * kWave] = (InT)vin_all[k];
+        for (uint32_t k = 1; k < NB_MAX; ++k) in_lds[k * kWave] = (InT)vin_all[k];
     }
     uint32_t vin_w = raw.vin_w;
     uint32_t slot = slot0;
@@ -264,7 +264,8 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
 
     for (uint32_t i = 0; i < nb; ++i) {
-        const uint32_t next_w = i + 1u < nb ? (uint32_t)in_lds[(i + 1u) * kWave] : 0u;  // one frame ahead
+        uint32_t next_w = 0u;
+        if (NB_MAX > 1u && i + 1u < nb) next_w = (uint32_t)in_lds[(i + 1u) * kWave];  // one frame ahead
         const uint32_t cth = __builtin_amdgcn_readlane(tab_cth, i);
         if (ABS_T) sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
 
@@ -344,15 +345,16 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     }
 }
 
-template <bool ABS_T>
+// NB_MAX: the most frames a launch of this kernel steps (1: no LDS is touched, lds_in may be null)
+template <bool ABS_T, uint32_t NB_MAX>
 __device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                  uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
                                                  uint8_t *lds_in) {
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     if (full)
-        lean_frames<ABS_T, true>(b, a, nb, u0, gw, lane, raw, lds_in);
+        lean_frames<ABS_T, true, NB_MAX>(b, a, nb, u0, gw, lane, raw, lds_in);
     else
-        lean_frames<ABS_T, false>(b, a, nb, u0, gw, lane, raw, lds_in);
+        lean_frames<ABS_T, false, NB_MAX>(b, a, nb, u0, gw, lane, raw, lds_in);
 }
 
 template <bool ABS_T>
@@ -368,32 +370,39 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
     LeanRaw raw;
     lean_load<ABS_T>(a, u0, full, raw);
-    lean_run_segment<ABS_T>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
+    lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
 }
 
-// Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes TWO
-// consecutive segments and issues the loads of both before it steps the first, so the second
-// segment's memory round trip hides under the first one's step (with one segment per wave all
+// Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes kLean1Segs
+// consecutive segments and issues the loads of all of them before it steps the first, so the later
+// segments' memory round trips hide under the first one's step (with one segment per wave all
 // resident waves load, then all compute, then all store, in lock step).
+#ifndef ADDER_LEAN1_SEGS
+#define ADDER_LEAN1_SEGS 4
+#endif
+#ifndef ADDER_LEAN1_WAVES
+#define ADDER_LEAN1_WAVES 4
+#endif
+constexpr uint32_t kLean1Segs = ADDER_LEAN1_SEGS;
 template <bool ABS_T>
-__global__ __launch_bounds__(kBlockThreads, 6) void adder_lean1_kernel(const BatchArgs *__restrict__ b, uint32_t f) {
+__global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1_WAVES) void adder_lean1_kernel(const BatchArgs *__restrict__ b,
+                                                                                      uint32_t f) {
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * 2u;
+    const uint32_t gw0 = (blockIdx.x * kWavesPerBlock + tid / kWave) * kLean1Segs;
     if (gw0 >= a.num_waves) return;
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kWaveUnits];  // nb == 1: one row
-    LeanRaw raw[2];
+    LeanRaw raw[kLean1Segs];
 #pragma unroll
-    for (uint32_t s = 0; s < 2u; ++s) {
+    for (uint32_t s = 0; s < kLean1Segs; ++s) {
         const uint32_t gw = gw0 + s;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
         lean_load<ABS_T>(a, gw * kWaveUnits + lane * kUnitsPerLane, full, raw[s]);
     }
 #pragma unroll
-    for (uint32_t s = 0; s < 2u; ++s) {
+    for (uint32_t s = 0; s < kLean1Segs; ++s) {
         const uint32_t gw = gw0 + s;
-        lean_run_segment<ABS_T>(b, a, 1u, gw * kWaveUnits + lane * kUnitsPerLane, gw, lane, raw[s], s_in[tid / kWave]);
+        lean_run_segment<ABS_T, 1u>(b, a, 1u, gw * kWaveUnits + lane * kUnitsPerLane, gw, lane, raw[s], nullptr);
     }
 }
 
@@ -582,10 +591,16 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     const uint32_t g1 = min(g0 + per, groups);
     const uint4 *src = reinterpret_cast<const uint4 *>(a.wtot);
     uint4 *dst = reinterpret_cast<uint4 *>(a.wpref);
-    uint32_t sum = 0;
+    uint32_t sum = 0, recs = 0;
     for (uint32_t g = g0; g < g1; ++g) {
         const uint4 v = src[g];
         sum += (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+        recs += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+    }
+    if (b->rec_total) {  // diagnostics: parked records of the batch (bench.py's byte accounting)
+#pragma unroll
+        for (uint32_t o = kWave / 2; o > 0; o >>= 1) recs += __shfl_down(recs, o, kWave);
+        if (lane == 0 && recs) atomicAdd(reinterpret_cast<unsigned long long *>(b->rec_total), (unsigned long long)recs);
     }
     const uint32_t incl = wave_inclusive_scan(sum, lane);
     if (lane == kWave - 1) s_part[wid] = incl;
@@ -965,6 +980,80 @@ __global__ void adder_chunk_offsets_kernel(const AdderEventPod *ev, uint32_t n, 
     offsets[c] = lo;
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-GPU: merge of the row bands' event streams (the reference's split is
+// video.rs:677-691).  Rank r's stream is frame-major with offsets offs[r][0..T]; the merged stream
+// is frame-major with, inside a frame, rank 0's events first, then rank 1's, ... = raster order.
+// `stage` holds the ranks' streams back to back (rank r at stage_base[r] = sum of the totals of
+// the lower ranks).  Two launches: the layout (one block), then the copy.
+// work layout (uint64): [0, T] merged frame offsets, then dst[r][f] for r < world, f < T.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adder_merge_layout_kernel(const uint64_t *__restrict__ offs, uint32_t world,
+                                                                 uint32_t T, uint64_t *__restrict__ work,
+                                                                 uint64_t *__restrict__ merged_offsets) {
+    // frame totals -> exclusive prefix over frames (serial per 256-frame tile; T is a few hundred)
+    __shared__ uint64_t s_tile[256];
+    __shared__ uint64_t s_carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        s_carry = 0;
+        work[0] = 0;
+        if (merged_offsets) merged_offsets[0] = 0;
+    }
+    __syncthreads();
+    for (uint32_t f0 = 0; f0 < T; f0 += 256u) {
+        const uint32_t f = f0 + tid;
+        uint64_t tot = 0;
+        if (f < T)
+            for (uint32_t r = 0; r < world; ++r) tot += offs[(size_t)r * (T + 1) + f + 1] - offs[(size_t)r * (T + 1) + f];
+        s_tile[tid] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t run = s_carry;
+            for (uint32_t k = 0; k < 256u; ++k) {
+                const uint64_t t = s_tile[k];
+                s_tile[k] = run;  // exclusive
+                run += t;
+            }
+            s_carry = run;
+        }
+        __syncthreads();
+        if (f < T) {
+            const uint64_t base = s_tile[tid];
+            uint64_t before = 0;
+            for (uint32_t r = 0; r < world; ++r) {
+                work[(T + 1) + (size_t)r * T + f] = base + before;
+                before += offs[(size_t)r * (T + 1) + f + 1] - offs[(size_t)r * (T + 1) + f];
+            }
+            work[f + 1] = base + before;
+            if (merged_offsets) merged_offsets[f + 1] = base + before;
+        }
+        __syncthreads();
+    }
+}
+
+// blockIdx.y = r * T + f: copies rank r's events of frame f (12-byte records, dword granularity).
+__global__ __launch_bounds__(256) void adder_merge_copy_kernel(const uint32_t *__restrict__ stage,
+                                                               const uint64_t *__restrict__ offs, uint32_t world,
+                                                               uint32_t T, const uint64_t *__restrict__ work,
+                                                               uint32_t *__restrict__ out, uint64_t out_cap,
+                                                               uint32_t *status) {
+    const uint32_t r = blockIdx.y / T, f = blockIdx.y - r * T;
+    uint64_t stage_base = 0;
+    for (uint32_t k = 0; k < r; ++k) stage_base += offs[(size_t)k * (T + 1) + T];
+    const uint64_t a = offs[(size_t)r * (T + 1) + f], e = offs[(size_t)r * (T + 1) + f + 1];
+    const uint64_t dst = work[(T + 1) + (size_t)r * T + f];
+    uint64_t n = e - a;
+    if (dst + n > out_cap) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) raise(status, kStatusCapacity);
+        n = dst < out_cap ? out_cap - dst : 0;
+    }
+    const uint32_t *src = stage + (stage_base + a) * 3u;
+    uint32_t *d = out + dst * 3u;
+    const uint64_t nd = n * 3u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nd; i += (uint64_t)gridDim.x * 256u) d[i] = src[i];
+}
+
 // ---- deterministic synthetic content ----
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -1039,8 +1128,8 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
     if (!collapse || exp_nf != 0u) return hipErrorInvalidValue;  // the lean step is Collapse-only
-    if (nb == 1u && (num_waves & 1u) == 0u) {
-        const uint32_t grid = (num_waves / 2u + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (nb == 1u && num_waves % kLean1Segs == 0u) {
+        const uint32_t grid = (num_waves / kLean1Segs + kWavesPerBlock - 1) / kWavesPerBlock;
         if (abs_t) hipLaunchKernelGGL((adder_lean1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         else hipLaunchKernelGGL((adder_lean1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         return hipGetLastError();
@@ -1105,5 +1194,16 @@ extern "C" hipError_t adder_launch_synth(uint8_t *dst, int content, uint64_t see
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(adder_synth_kernel, dim3((uint32_t)blocks), dim3(bs), 0, stream, dst, content, seed, W, H,
                        C, y0, rows, k0, total);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
+                                         uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap,
+                                         uint64_t *merged_offsets, uint32_t *status, hipStream_t stream) {
+    if (world == 0 || T == 0) return hipSuccess;
+    hipLaunchKernelGGL(adder_merge_layout_kernel, dim3(1), dim3(256), 0, stream, offs, world, T, work, merged_offsets);
+    hipLaunchKernelGGL(adder_merge_copy_kernel, dim3(64, world * T), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(stage), offs, world, T, work,
+                       reinterpret_cast<uint32_t *>(out), out_cap, status);
     return hipGetLastError();
 }

@@ -1,44 +1,51 @@
 #!/usr/bin/env python3
 """bench.py -- framed->ADDER transcode throughput on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one clip resident in HBM: config[1] of
+A "step" is one pass of the hot path over one clip resident in HBM: configs[1] of
 BASELINE.json -- 1920x1080 gray 8-bit, 300 frames, delta_t_max = 255 -- with the
 synthetic "scene" content of SURVEY.md 8(d), crf-0 numbers, FramePerfect, Collapse,
 DeltaT, raw 12-byte events written to an HBM buffer.  Each step starts from a freshly
 reset transcoder so every step does identical work.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): the plane is
-1920 x (1080*N) and rank r owns rows [1080 r, 1080 (r+1)) (weak scaling); no collective
-runs while integrating, then the per-rank event segments are gathered to rank 0 in
-frame-major raster order (adder_amd/sharding.py) inside the timed region.
+--gpus N (N > 1): the SAME 1080p clip is split into N contiguous row bands
+(adder_amd.sharding.row_bands; the reference's own split is video.rs:677-691), one rank per
+GPU, no collective while integrating; inside the timed step the bands' event streams are then
+gathered to rank 0 over RCCL/xGMI and merged into the single ordered stream (strong scaling:
+`value` = the clip's pixels / wall time).  Started without a launcher, bench.py re-executes
+itself under torch.distributed.run.
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields it carries
-  roofline     : algorithmic HBM bytes of the frame kernel / its mean launch duration
-                 (HIP event pair around every launch on the launch stream)
-  cpu_baseline : the CPU oracle (a literal port of the reference's rayon loop + serial
-                 raw sink) timed on this box's host cores over a bounded sample
+  roofline     : algorithmic HBM bytes of one chunk of frames / the duration of the chunk's
+                 kernels (frame kernel + scan + offsets + expansion), HIP event pairs on the
+                 launch stream
+  cpu_baseline : the CPU oracle (a literal port of the reference's rayon loop + serial raw
+                 sink) timed on this box's host cores over a bounded sample, thread sweep
+  end_to_end   : host-buffer legs (PCIe-inclusive), never `value`
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
+
+# thread placement of the CPU-baseline leg (must be in the environment before libgomp starts)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "adder-codec-rs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-W, H_BAND, C, FRAMES = 1920, 1080, 1, 300
+W, H, C, FRAMES = 1920, 1080, 1, 300
 REF_TIME, DTM = 255, 255
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+STATE_BYTES = 16       # level 0 of a unit: hdr + integration + delta_t + best_delta_t
+REC_BYTES = 16         # one parked record per unit with events (lean variants)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -49,24 +56,47 @@ def main():
     ap.add_argument("--time-mode", default="delta_t", choices=["delta_t", "absolute_t"])
     ap.add_argument("--delta-t-max", type=int, default=DTM)
     ap.add_argument("--channels", type=int, default=C)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-payload", action="store_true",
-                    help="N>1: also funnel every rank's events to rank 0 over RCCL inside the timed step "
-                         "(default: all-gather of the per-frame counts only; the payload stays sharded)")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--gather", default="torch", choices=["torch", "cabi", "layout"],
+                    help="N>1: how the bands' streams become one inside the timed step: 'torch' = torch.distributed "
+                         "(RCCL) transport + the HIP merge kernel; 'cabi' = libadder_rccl.so (adder_gather_events, the "
+                         "call a Rust host makes); 'layout' = all-gather of the per-frame counts only")
     ap.add_argument("--skip-roofline", action="store_true",
-                    help="no per-launch timing passes (used under rocprofv3 --pmc so that only default-depth launches are counted)")
-    args = ap.parse_args()
+                    help="no per-launch timing passes (used under rocprofv3 so that only default launches are seen)")
+    return ap.parse_args()
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` from a bare shell: one process per GPU via torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn_under_launcher(args)  # does not return
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # Debug hook for boxes with ONE GPU: ADDER_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 and does the
-    # (tiny) layout exchange over gloo on host copies -- RCCL refuses two ranks on one device.  Never set
-    # by the driver; it only lets the N>1 code path be exercised where a single GPU is available.
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Debug hook for boxes with ONE GPU: ADDER_BENCH_SHARE_DEVICE=1 runs every rank on cuda:0 over gloo --
+    # RCCL refuses two ranks on one device.  Never set by the driver; it only lets the N>1 code path be
+    # exercised where a single GPU is available.
     share = os.environ.get("ADDER_BENCH_SHARE_DEVICE") == "1"
     if share:
         local_rank = 0
@@ -82,88 +112,117 @@ def main():
     import adder_amd as A
     from adder_amd import sharding
 
-    T, Cn = args.frames, args.channels
-    H_total = H_BAND * world
-    y0, y1 = rank * H_BAND, (rank + 1) * H_BAND
-    units = H_BAND * W * Cn
+    T, Cn, Wd, Ht = args.frames, args.channels, args.width, args.height
+    y0, y1 = sharding.row_bands(Ht, world)[rank]  # strong scaling: the one plane, split by rows
+    rows = y1 - y0
+    units = rows * Wd * Cn
     content = {"static": A.CONTENT_STATIC, "noise": A.CONTENT_NOISE, "scene": A.CONTENT_SCENE}[args.content]
     multi = A.MULTI_COLLAPSE if args.multi_mode == "collapse" else A.MULTI_NORMAL
     tmode = A.TIME_DELTA_T if args.time_mode == "delta_t" else A.TIME_ABSOLUTE_T
 
     stream = torch.cuda.current_stream().cuda_stream
     d_frames = torch.empty((T, units), dtype=torch.uint8, device=dev)
-    A.synth_clip_device(d_frames, content, W, H_total, Cn, row_begin=y0, rows=H_BAND, frame_begin=0,
+    A.synth_clip_device(d_frames, content, Wd, Ht, Cn, row_begin=y0, rows=rows, frame_begin=0,
                         num_frames=T, stream=stream)
     cap = int(units * T * (1.25 if args.content == "noise" else 0.75)) + 1024
     d_events = torch.empty((cap, 3), dtype=torch.int32, device=dev)
     d_offsets = torch.zeros(T + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    hv = A.HipVideo(W, H_total, Cn, row_begin=y0, row_end=y1, time_mode=tmode, multi_mode=multi,
+    hv = A.HipVideo(Wd, Ht, Cn, row_begin=y0, row_end=y1, time_mode=tmode, multi_mode=multi,
                     ref_time=REF_TIME, delta_t_max=args.delta_t_max, device_id=local_rank,
                     c_thresh_start=0, c_counter_start=0)
     # CRF[0] = (0, 0, 10) (rate_controller.rs:9); pixels start at c_thresh 0 / counter 0, the
     # state `.crf(0)` leaves them in (video.rs:1247-1250), so reset() restores exactly that
     hv.set_crf_parameters(0, 10)
 
-    def step():
+    gather_mode = args.gather if world > 1 else "none"
+    if share and gather_mode == "cabi":
+        gather_mode = "torch"  # RCCL cannot put two ranks on one device
+    hg = None
+    d_merged = d_merged_offs = None
+    if gather_mode == "cabi":
+        from adder_amd.gather import HipGather, unique_id
+        uid = [unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hg = HipGather(hv, uid[0], rank, world)
+        if rank == 0:
+            d_merged = torch.empty((cap * world, 3), dtype=torch.int32, device=dev)
+            d_merged_offs = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+
+    def step(mode):
         hv.reset()
         hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
         n = hv.finish()
-        merged = None
-        if world > 1:
-            if args.gather_payload:
-                merged = sharding.gather_event_stream(d_events[:n], d_offsets, dst=0)
-            else:
-                # the ordered concatenation is fixed by this exchange; rank r's segment of frame f
-                # belongs at my_base[f] of the merged stream
-                merged = sharding.exchange_stream_layout(d_offsets.cpu() if share else d_offsets)
-        return n, merged
+        merged_total = n
+        if mode == "torch":
+            # all-gather of the offsets + point-to-point payload to rank 0 (RCCL over xGMI) + HIP merge kernel
+            out = sharding.gather_event_stream(d_events[:n], d_offsets, dst=0, video=hv)
+            if rank == 0:
+                hv.check_status(stream)  # synchronises: the merged stream is complete
+                merged_total = int(out[1][-1])
+        elif mode == "cabi":
+            merged_total = hg.gather_events(d_events, d_offsets, T, 0, d_merged, d_merged_offs, stream=stream)
+        elif mode == "layout":
+            lay = sharding.exchange_stream_layout(d_offsets.cpu() if share else d_offsets)
+            merged_total = int(lay[0][-1])
+        return n, merged_total
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    n_events = 0
-    for _ in range(args.steps):
-        n_events, merged = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(mode, steps, warmup):
+        for _ in range(warmup):
+            step(mode)
+        barrier()
+        t0 = time.perf_counter()
+        res = (0, 0)
+        for _ in range(steps):
+            res = step(mode)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            cdev = torch.device("cpu") if share else dev
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
+    elapsed, (n_events, merged_total) = timed(gather_mode, args.steps, args.warmup)
     kernel_ms = hv.last_batch_ms()  # HIP events around the last step's frame loop
+    records = hv.last_batch_records()
 
     total_events = n_events
+    layout_elapsed, layout_steps = None, max(2, args.steps // 2)
     if world > 1:
         cdev = torch.device("cpu") if share else dev
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         te = torch.tensor([n_events], dtype=torch.int64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.SUM)
         total_events = int(te.item())
-        if args.gather_payload:
-            if rank == 0:
-                assert merged is not None and merged[0].shape[0] == total_events
-        else:
-            assert int(merged[0][-1]) == total_events  # every rank knows the merged stream's layout
+        if rank == 0 and gather_mode != "layout":
+            assert merged_total == total_events, (merged_total, total_events)
+        if gather_mode != "layout":  # the cheaper exchange, as an extra key
+            layout_elapsed, _ = timed("layout", layout_steps, 1)
 
-    # ---- roofline of the dominant kernel: one extra step with an event pair per launch ----
-    launch_us, launch_frames, launch1_us = 0.0, 1.0, 0.0
+    # ---- roofline: one extra step with HIP event pairs around the launches ----
+    k1_us = post_us = k1_one_us = 0.0
+    k1_frames = 1.0
+    chunk_frames = hv.chunk_frames()
+    records1 = records
     if not args.skip_roofline:
         hv.set_launch_timing(True)
-        step()
-        launch_us = hv.last_launch_avg_us()
-        launch_frames = hv.last_launch_frames() or 1.0
-        # the same kernel with one frame per launch (the per-frame `consume` contract, state
-        # streamed from HBM every frame): this is the HBM-bound regime of SURVEY 8(d)
-        default_depth = int(launch_frames + 0.999)
+        step("none")
+        k1_us, k1_frames = hv.last_launch_avg_us(), hv.last_launch_frames() or 1.0
+        post_us = hv.last_post_avg_us()
+        default_depth = int(k1_frames + 0.999)
+        # the frame kernel alone with one frame per launch (the per-frame `consume` contract, state
+        # streamed from HBM every frame): the HBM-bound regime of SURVEY 8(d)
         hv.set_frames_per_launch(1)
-        step()
-        launch1_us = hv.last_launch_avg_us()
+        step("none")
+        k1_one_us = hv.last_launch_avg_us()
+        records1 = hv.last_batch_records()
         hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "0")) or default_depth)
         hv.set_launch_timing(False)
 
@@ -173,30 +232,30 @@ def main():
             dist.destroy_process_group()
         return
 
-    pixels_per_step = W * H_total * T
+    pixels_per_step = Wd * Ht * T
     ms_per_step = elapsed / args.steps * 1e3
     value = pixels_per_step / (elapsed / args.steps) / 1e6
-    e = total_events / float(units * world * T)
-    # B = 1 + (S_in + S_out)/T_launch + 12 e per pixel-channel-frame;
-    # S = 20 B (Collapse/DeltaT), +4 B with AbsoluteT; T_launch = frames one launch steps.
-    S = 20 + (4 if tmode == A.TIME_ABSOLUTE_T else 0)
-    e_rank0 = n_events / float(units * T)
-    bytes_per_unit = 1 + 2 * S / launch_frames + 12 * e_rank0
-    units_per_launch = units * launch_frames
-    achieved = bytes_per_unit * units_per_launch / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
-    # at depth 1 the expansion is NOT fused (it runs as its own kernel on a second stream): the frame
-    # kernel's launch then moves the input, the state and the parked records (4 bytes each in the
-    # DeltaT / delta_t_max <= ref_time variants, 8 otherwise)
-    park_bytes = 4 if (tmode == A.TIME_DELTA_T and multi == A.MULTI_COLLAPSE and args.delta_t_max <= REF_TIME) else 8
-    bytes1 = 1 + 2 * S + park_bytes * e_rank0
-    achieved1 = bytes1 * units / (launch1_us * 1e-6) / 1e9 if launch1_us > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    e_all = total_events / float(Wd * Ht * Cn * T)
+    e0 = n_events / float(units * T)
+    r0 = records / float(units * T)
+    abs_t = tmode == A.TIME_ABSOLUTE_T
+    lean = multi == A.MULTI_COLLAPSE and args.delta_t_max <= REF_TIME
+    # B = 1 (input) + (S_in + S_out) / T_launch + 12 e bytes per pixel-channel-frame, with the state
+    # this implementation really keeps (S = 16 B, +4 B last_fired_t in AbsoluteT) and T_launch = frames per launch.
+    S = STATE_BYTES + (4 if abs_t else 0)
+    # kernels of one (full) chunk of frames: its frame-kernel launches + scan + offsets + expansion
+    chunk_us = k1_us * (chunk_frames / max(k1_frames, 1.0)) + post_us
+    alg_b = 1 + 2 * S / max(k1_frames, 1.0) + 12 * e0
+    achieved = alg_b * units * chunk_frames / (chunk_us * 1e-6) / 1e9 if chunk_us > 0 else 0.0
+    # the frame kernel's own traffic (what it really moves): input + state + parked records
+    k1_b = 1 + 2 * S / max(k1_frames, 1.0) + REC_BYTES * r0
+    k1_gbs = k1_b * units * k1_frames / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
+    # the rest of the chunk: parked records in, 12-byte events out
+    post_b = REC_BYTES * r0 + 12 * e0
+    post_gbs = post_b * units * chunk_frames / (post_us * 1e-6) / 1e9 if post_us > 0 else 0.0
+    r1 = records1 / float(units * T)
+    one_b = 1 + 2 * S + REC_BYTES * r1
+    one_gbs = one_b * units / (k1_one_us * 1e-6) / 1e9 if k1_one_us > 0 else 0.0
 
     out = {
         "metric": "Mpixels/s framed->ADDER transcode (1080p, delta_t_max=255)",
@@ -207,113 +266,200 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{W}x{H_BAND}{'x3 RGB' if Cn == 3 else ' gray'} 8-bit per GPU, {T} frames, "
+            "workload": f"{Wd}x{Ht}{'x3 RGB' if Cn == 3 else ' gray'} 8-bit, {T} frames, "
                         f"delta_t_max={args.delta_t_max}, ref_time={REF_TIME}, content={args.content}, crf0 "
                         f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, raw events to HBM",
-            "plane": [W, H_total, Cn],
-            "rows_per_gpu": H_BAND,
+            "plane": [Wd, Ht, Cn],
+            "rows_per_gpu": rows,
             "frames_per_step": T,
             "sharding": ("single GPU" if world == 1 else
-                         "row bands; ordered RCCL gather of the event payload to rank 0" if args.gather_payload else
-                         "row bands; RCCL all-gather of per-frame event counts fixes the ordered concatenation, "
-                         "the event payload stays sharded in HBM (each rank delivers its segments itself)"),
+                         f"{world} row bands of the one plane; per step the bands' event streams are gathered to "
+                         f"rank 0 ({gather_mode}) inside the timed region"),
+            "world_size_seen": world,
+            "backend": "none" if world == 1 else ("gloo (shared-device debug)" if share else "nccl (RCCL)"),
         },
         "events_per_s": round(total_events / (elapsed / args.steps), 1),
-        "events_per_pixel_frame": round(e, 5),
+        "events_per_pixel_frame": round(e_all, 5),
+        "records_per_unit_frame": round(r0, 5),
         "frame_loop_ms_hip_events": round(kernel_ms, 3),
         "roofline": {
             "bound": "hbm",
-            "kernel": "adder_frame_kernel",
+            "kernel": ("one chunk of frames: adder_lean_kernel + adder_scan_kernel + adder_offsets_kernel + "
+                       "adder_expand_kernel") if lean else
+                      "one chunk of frames: adder_frame_kernel + adder_scan_kernel + adder_offsets_kernel + "
+                      "adder_expand_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "bytes_per_unit_frame": round(bytes_per_unit, 3),
-            "frames_per_launch": launch_frames,
-            "units_per_launch": int(units_per_launch),
-            "launch_avg_us": round(launch_us, 3),
-            "note": "default batches step 16 frames per launch with the state in registers: the kernel is then "
-                    "VALU-bound, not HBM-bound (DESIGN.md 4); roofline_one_frame_per_launch is the HBM-bound regime",
+            "traffic": None,  # PMC counters need separate rocprofv3 passes: see profiles/ (tools/profile_round.sh)
+            "bytes_per_unit_frame": round(alg_b, 3),
+            "frames_per_launch": k1_frames,
+            "frames_per_chunk": chunk_frames,
+            "units_per_chunk": int(units * chunk_frames),
+            "chunk_us": round(chunk_us, 3),
+            "frame_kernel_launch_us": round(k1_us, 3),
+            "scan_offsets_expand_us": round(post_us, 3),
+            "frame_kernel_actual_GBs": round(k1_gbs, 1),
+            "frame_kernel_actual_bytes_per_unit_frame": round(k1_b, 3),
+            "expansion_actual_GBs": round(post_gbs, 1),
+            "note": "algorithmic bytes (SURVEY 8(d) with the real 16-byte state: 1 + 32/T_launch + 12 e per unit-frame) "
+                    "over ALL kernels of a chunk; the pipeline really moves the parked records twice on top of that "
+                    "(frame_kernel_actual / expansion_actual are those kernels' own bytes over their own durations)",
         },
         "roofline_one_frame_per_launch": {
             "bound": "hbm",
-            "kernel": "adder_frame_kernel",
-            "achieved": round(achieved1, 1),
+            "kernel": "adder_lean1_kernel" if lean else "adder_frame_kernel",
+            "achieved": round(one_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved1 / HBM_PEAK_GBS, 4),
-            "bytes_per_unit_frame": round(bytes1, 3),
+            "frac": round(one_gbs / HBM_PEAK_GBS, 4),
+            "bytes_per_unit_frame": round(one_b, 3),
             "units_per_launch": units,
-            "launch_avg_us": round(launch1_us, 3),
-            "note": "state streamed from HBM every frame (per-frame consume contract); this launch parks compact "
-                    "records (1 + 2*20 + 4e bytes per unit; 8e in the AbsoluteT / generic variants), the 12-byte "
-                    "events are written by the separate expansion kernel overlapped on a second stream",
+            "launch_avg_us": round(k1_one_us, 3),
+            "note": "the frame kernel alone with the state streamed from HBM every frame (per-frame consume contract): "
+                    "bytes it really moves = 1 input + 16 state in + 16 state out + 16 per parked record",
         },
     }
+    if layout_elapsed is not None:
+        out["layout_only_exchange"] = {
+            "value": round(pixels_per_step / (layout_elapsed / layout_steps) / 1e6, 1),
+            "unit": "Mpixels/s",
+            "note": "same step with only the per-frame counts all-gathered (the payload stays sharded in HBM)"}
 
+    if world == 1 and not args.no_end_to_end:
+        out["end_to_end"] = end_to_end(hv, d_frames, T, units, Wd, Ht, Cn)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(d_frames, d_events, d_offsets, T, Cn, multi, tmode, args)
+        hv.reset()
+        hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
+        hv.finish()
+        out["cpu_baseline"] = cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, args)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, multi, tmode, args):
-    """The oracle (a port of the reference CPU path: per-row-chunk tasks collected in order,
-    then the serial 9/11-byte raw sink) on all host cores, over a bounded prefix of the SAME
-    clip; also used as the checker: the GPU events of those frames must equal it bit-for-bit."""
+def end_to_end(hv, d_frames, T, units, Wd, Ht, Cn):
+    """host buffers in, host buffers out (PCIe-inclusive) -- never `value`.
+    (1) pipelined batches: host frames -> H2D -> kernels -> wire serialisation on the device -> D2H of the
+        9/11-byte records (adder_hip_stream_submit / collect, two batches in flight);
+    (2) the literal per-frame drop-in call adder_hip_integrate (one frame in, its events out)."""
+    nb, bf = 4, 16  # 4 batches of 16 frames
+    if T < nb * bf + 1:
+        return {"skipped": "clip too short"}
+    host = d_frames[: nb * bf].cpu().numpy().reshape(nb, bf, units)
+    res = {}
+    try:
+        hv.reset()
+        hv.stream_submit(host[0])
+        hv.stream_collect(copy=False)  # warm: allocations, graph capture
+        hv.reset()
+        t0 = time.perf_counter()
+        ev = 0
+        hv.stream_submit(host[0])
+        for k in range(1, nb):
+            hv.stream_submit(host[k])
+            ev += hv.stream_collect(copy=False)[1]
+        ev += hv.stream_collect(copy=False)[1]
+        el = time.perf_counter() - t0
+        res["pipelined_raw_batches"] = {
+            "value": round(Wd * Ht * nb * bf / el / 1e6, 1), "unit": "Mpixels/s", "frames": nb * bf, "events": ev,
+            "note": "pageable numpy frames in, pinned wire bytes out; bound by PCIe (events are ~3.7 output bytes "
+                    "per input pixel)"}
+    except Exception as exc:  # never let an auxiliary leg take the headline down
+        res["pipelined_raw_batches"] = {"error": str(exc)[:200]}
+    try:
+        hv.reset()
+        frames = host.reshape(nb * bf, units)
+        hv.integrate_matrix(frames[0])
+        n_calls = 24
+        t0 = time.perf_counter()
+        for k in range(1, 1 + n_calls):
+            hv.integrate_matrix(frames[k])
+        el = time.perf_counter() - t0
+        res["per_frame_call"] = {
+            "value": round(el / n_calls * 1e6, 1), "unit": "us per adder_hip_integrate call", "calls": n_calls,
+            "mpixels_per_s": round(Wd * Ht * n_calls / el / 1e6, 1),
+            "note": "includes the Python wrapper's copy of the returned events"}
+    except Exception as exc:
+        res["per_frame_call"] = {"error": str(exc)[:200]}
+    hv.reset()
+    return res
+
+
+def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, args):
+    """The oracle (a port of the reference CPU path: per-row-chunk tasks whose events stay in per-chunk
+    buffers like the reference's Vec<Vec<Event>>, then the serial 9/11-byte raw sink) on this box's host
+    cores over a bounded prefix of the SAME clip: a thread sweep, best-of reported with its thread count.
+    It is also the checker: the GPU events of the frames it processes must equal it bit for bit."""
+    import numpy as np
     from oracle import oracle as O
 
-    threads = O.max_threads()
-    v = O.Video(W, H_BAND, Cn, time_mode=tmode, multi_mode=multi, ref_time=REF_TIME,
-                delta_t_max=args.delta_t_max, chunk_rows=1, threads=threads)
-    v.set_crf_parameters(0, 10)
-    v.reset_c_thresh(0)
-    v.ensure_capacity(3)
-    L = O.lib()
-    import ctypes as Ct
-    n = Ct.c_size_t(0)
-    sink = np.zeros(W * H_BAND * Cn * 3 * 11, np.uint8)
+    max_threads = O.max_threads()
+    sweep_threads = sorted({t for t in (1, 8, 32, max_threads) if t <= max_threads})
+    budget = args.cpu_seconds / (len(sweep_threads) + 3)
+    max_frames = min(T, 64)
+    host = d_frames[:max_frames].cpu().numpy()
+    sink = np.zeros(Wd * Ht * Cn * 3 * 11 + 64, np.uint8)
     offs = d_offsets.cpu().numpy()
-    frames_done, events, parity_ok = 0, 0, True
-    chunk = 8
-    t_total = 0.0
-    while frames_done < T and t_total < args.cpu_seconds:
-        k1 = min(T, frames_done + chunk)
-        host = d_frames[frames_done:k1].cpu().numpy()
-        counts = []
-        t0 = time.perf_counter()
-        got_parts = []
-        for f in host:
-            L.oracle_video_integrate_matrix(v.h, f.ctypes.data, W * Cn, float(REF_TIME), v._out.ctypes.data,
-                                            v._cap, Ct.byref(n), None)
-            L.oracle_raw_events(sink.ctypes.data, v._out.ctypes.data, n.value, Cn)  # serial sink stage
-            counts.append(n.value)
-            got_parts.append(v._out[: n.value].copy())
-        t_total += time.perf_counter() - t0
-        # checker: same events as the GPU produced for these frames
-        lo, hi = int(offs[frames_done]), int(offs[k1])
-        gpu = np.frombuffer(d_events[lo:hi].cpu().numpy().tobytes(), dtype=O.EVENT_DTYPE)
-        cpu = np.concatenate(got_parts) if got_parts else np.zeros(0, O.EVENT_DTYPE)
-        parity_ok = parity_ok and len(gpu) == len(cpu) and bool(np.array_equal(gpu, cpu))
-        events += sum(counts)
-        frames_done = k1
+
+    def fresh(threads, chunk_rows=1):
+        v = O.Video(Wd, Ht, Cn, time_mode=tmode, multi_mode=multi, ref_time=REF_TIME,
+                    delta_t_max=args.delta_t_max, chunk_rows=chunk_rows, threads=threads)
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+        return v
+
+    def run(threads, chunk_rows, with_sink, check):
+        v = fresh(threads, chunk_rows)
+        t_total, frames_done, events, ok = 0.0, 0, 0, True
+        while frames_done < max_frames and t_total < budget:
+            f = host[frames_done]
+            t0 = time.perf_counter()
+            n = v.integrate_matrix_chunks(f.ctypes.data, Wd * Cn, float(REF_TIME))
+            if with_sink:
+                v.chunks_raw_events(sink.ctypes.data)  # the serial sink stage
+            t_total += time.perf_counter() - t0
+            if check:  # outside the timed region
+                lo, hi = int(offs[frames_done]), int(offs[frames_done + 1])
+                gpu = np.frombuffer(d_events[lo:hi].cpu().numpy().tobytes(), dtype=O.EVENT_DTYPE)
+                cpu = v.chunks_copy_out(n)
+                ok = ok and len(gpu) == len(cpu) and bool(np.array_equal(gpu, cpu))
+            events += n
+            frames_done += 1
+        return Wd * Ht * frames_done / t_total / 1e6, frames_done, events, ok
+
+    sweep = []
+    for th in sweep_threads:
+        mp, fr, _, _ = run(th, 1, True, False)
+        sweep.append({"threads": th, "value": round(mp, 2), "frames": fr})
+    best = max(sweep, key=lambda s: s["value"])
+    # the best thread count again: without the sink stage, with chunk_rows = 64, and as the checker
+    mp_nosink, _, _, _ = run(best["threads"], 1, False, False)
+    mp_c64, _, _, _ = run(best["threads"], 64, True, False)
+    _, fr_chk, ev_chk, ok = run(best["threads"], 1, True, True)
     return {
-        "value": round(W * H_BAND * frames_done / t_total / 1e6, 2),
+        "value": best["value"],
         "unit": "Mpixels/s",
-        "cores": threads,
+        "cores": best["threads"],
         "kind": "port",
-        "sample": f"first {frames_done} of {T} frames of the same clip, OpenMP over row chunks "
-                  f"(chunk_rows=1) + serial raw sink; includes copies into its own buffers only",
-        "events": events,
-        "gpu_events_match_bit_exact": parity_ok,
+        "sample": f"first {best['frames']} frames of the same clip per sweep point (about {budget:.1f} s each), "
+                  f"OpenMP over row chunks (chunk_rows=1, OMP_PROC_BIND=close) + serial raw sink; events stay in "
+                  f"per-chunk buffers like the reference's Vec<Vec<Event>>",
+        "host_cores": max_threads,
+        "thread_sweep": sweep,
+        "one_thread": next((s["value"] for s in sweep if s["threads"] == 1), None),
+        "without_sink": round(mp_nosink, 2),
+        "chunk_rows_64": round(mp_c64, 2),
+        "checked_frames": fr_chk,
+        "checked_events": ev_chk,
+        "gpu_events_match_bit_exact": ok,
     }
 
 

@@ -1,0 +1,63 @@
+/* adder_gather.h -- C-ABI of the multi-GPU event-stream gather (libadder_rccl.so).
+ *
+ * a plane is split into contiguous row bands, one AdderHipCtx per GPU / rank
+ * (the reference's own split is the rayon row chunking of video.rs:677-691; pixels never interact
+ * with feature detection off, video.rs:1318-1380).  Nothing is exchanged while integrating.  This
+ * library does the one exchange the path has: the ordered concatenation of the ranks' event
+ * streams on one rank before the unchanged CPU sink (video.rs:742-765 writes the chunks' events in
+ * row order) -- an RCCL all-gather of the per-frame offsets, grouped ncclSend / ncclRecv of the
+ * payloads over xGMI, and the merge kernel of libadder_hip.so (adder_hip_merge_streams_device).
+ *
+ * A Rust host binds this with `extern "C"` and passes the ncclComm_t it created with RCCL; no torch,
+ * no Python.  The library links librccl only; libadder_hip.so has no RCCL dependency. */
+#ifndef ADDER_GATHER_H
+#define ADDER_GATHER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "adder_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct AdderGather AdderGather;
+
+#define ADDER_GATHER_UNIQUE_ID_BYTES 128
+
+/* ncclGetUniqueId for hosts that have no RCCL binding of their own: rank 0 calls this, ships the 128
+ * bytes to the other ranks by any means, every rank calls adder_gather_create_from_id. */
+int adder_gather_unique_id(uint8_t id_out[ADDER_GATHER_UNIQUE_ID_BYTES]);
+
+/* `nccl_comm`: an ncclComm_t owned by the caller (not destroyed by adder_gather_destroy).
+ * `ctx`: this rank's integration context (its device, its status word, its merge scratch). */
+int adder_gather_create(AdderHipCtx *ctx, void *nccl_comm, int rank, int world, AdderGather **out);
+/* Creates (and owns) a communicator from a unique id: ncclCommInitRank(world, id, rank). */
+int adder_gather_create_from_id(AdderHipCtx *ctx, const uint8_t id[ADDER_GATHER_UNIQUE_ID_BYTES], int rank,
+                                int world, AdderGather **out);
+void adder_gather_destroy(AdderGather *g);
+const char *adder_gather_last_error(const AdderGather *g);
+int adder_gather_world(const AdderGather *g);
+
+/* Ordered gather of one batch.  Every rank passes its own stream (d_events: n events, device;
+ * d_frame_offsets: device uint64[T+1], [T] == n) -- what adder_hip_integrate_device produced.  On `root`
+ * the merged frame-major stream is written to d_merged (capacity merged_cap events, device) and its
+ * offsets to d_merged_offsets (device uint64[T+1]); *n_merged = its length.  Other ranks pass NULL / 0
+ * for the merged buffers.  Collective: every rank of the communicator must call it with the same T
+ * and root.  Synchronises `stream` before returning (the totals are needed on the host). */
+int adder_gather_events(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                        uint32_t num_frames, int root, AdderEvent *d_merged, size_t merged_cap,
+                        uint64_t *d_merged_offsets, size_t *n_merged, void *stream);
+
+/* Layout-only exchange: all-gathers the per-frame offsets and returns, on every rank, the merged
+ * stream's frame offsets (h_merged_offsets, host uint64[T+1]) and where this rank's segment of each
+ * frame belongs in it (h_my_base, host uint64[T]).  The payload stays sharded: every rank can deliver
+ * its own segments (8 PCIe links instead of one xGMI funnel). */
+int adder_gather_layout(AdderGather *g, const uint64_t *d_frame_offsets, uint32_t num_frames,
+                        uint64_t *h_merged_offsets, uint64_t *h_my_base, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADDER_GATHER_H */

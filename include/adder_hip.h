@@ -168,11 +168,18 @@ float adder_hip_last_batch_ms(AdderHipCtx *ctx);
  * packets slow the batch down, so throughput runs leave it off). */
 int adder_hip_set_launch_timing(AdderHipCtx *ctx, int enable);
 float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
+/* Same run: mean duration of the scan + offsets + expansion launches of one chunk of frames (the other
+ * half of the frame loop), the number of chunks timed, and the frames one chunk holds. */
+float adder_hip_last_post_avg_us(AdderHipCtx *ctx);
+uint32_t adder_hip_last_post_chunks(AdderHipCtx *ctx);
+uint32_t adder_hip_chunk_frames(const AdderHipCtx *ctx);
+/* Parked records of the last device batch (diagnostics: the bytes the frame kernel really moved). */
+uint64_t adder_hip_last_batch_records(AdderHipCtx *ctx);
 /* Mean number of frames one timed frame-kernel launch stepped (see frames_per_launch). */
 float adder_hip_last_launch_frames(AdderHipCtx *ctx);
 
 /* Temporal blocking depth of the frame kernel: how many consecutive frames of a batch one
- * launch steps with the pixel state held in registers (1..16, default 16).  Results do not
+ * launch steps with the pixel state held in registers (1..32, default 32).  Results do not
  * depend on it.  Scratch is handled in chunks of at most 16 frames and a launch never spans
  * two chunks; batches that want the running-intensities side plane run one frame per launch. */
 int adder_hip_set_frames_per_launch(AdderHipCtx *ctx, uint32_t frames);
@@ -235,6 +242,21 @@ size_t adder_raw_header(uint8_t *dst, uint8_t codec_version, uint16_t width, uin
                         uint32_t source_camera, uint32_t time_mode, uint32_t adu_interval);
 size_t adder_raw_events(uint8_t *dst, const AdderEvent *events, size_t n, uint8_t channels);
 size_t adder_raw_eof(uint8_t *dst);
+
+/* --- multi-GPU: ordered merge of the row bands' streams -----------------------
+ * The reference splits a frame by rows (video.rs:677-691) and concatenates the chunks' events in row
+ * order (video.rs:742-765).  With one context per GPU / row band, rank r produces a frame-major stream
+ * with offsets offs_r[0..T]; the single-context stream is, per frame, rank 0's events, then rank 1's, ...
+ * d_stage: the ranks' streams back to back (rank r at the sum of the lower ranks' totals), e.g. the
+ * receive buffer of an ordered gather (include/adder_gather.h does that over RCCL);
+ * d_rank_offsets: device uint64 [world][T+1]; d_work: adder_hip_merge_work_bytes() bytes of device
+ * scratch; d_merged_offsets (may be NULL): device uint64 [T+1].  Asynchronous on `stream`; a capacity
+ * overflow is reported by adder_hip_check_status (which synchronises the stream). */
+size_t adder_hip_merge_work_bytes(uint32_t world, uint32_t num_frames);
+int adder_hip_merge_streams_device(AdderHipCtx *ctx, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
+                                   uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
+                                   size_t out_cap, uint64_t *d_merged_offsets, void *stream);
+int adder_hip_check_status(AdderHipCtx *ctx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -109,9 +109,9 @@ def test_ragged_tiny_and_odd_planes():
         run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.NORMAL, dtm=510, crf=CRFS[0], batch=True)
 
 
-def test_many_tiles_lookback_chain():
-    # > 2 x resident grid worth of tiles so the persistent blocks loop and the look-back
-    # crosses many tiles; noise makes every tile emit
+def test_many_segments_full_plane_noise():
+    # a full 1080p plane of noise: every one of the 16 200 wave segments parks a record per unit (the
+    # expansion's more-than-32-records path), and more workgroups than the chip holds at once
     clip = clips.make_clip("noise", 6, 1080, 1920, 1, seed=3)
     run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
     clip = clips.make_clip("runs", 12, 540, 960, 3, seed=4)
@@ -131,11 +131,11 @@ def test_long_static_deep_arena():
     run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=7650, crf=CRFS[0], batch=True)
 
 
-def test_compact_park_records_overflow_list():
-    """Collapse / DeltaT / delta_t_max = ref_time is the variant that parks compact 4-byte records with a
-    17-bit t; a pixel that stays put for > 514 frames and then changes emits a larger t, which goes
-    through the segment's overflow list.  Several such pixels per segment, different run lengths, and
-    D_EMPTY events (their t is the frame's running_t, not stored) in the same frames."""
+def test_long_runs_large_t_lean_records():
+    """Collapse / delta_t_max = ref_time (the lean kernel): pixels that stay put for > 514 frames and then
+    change emit t >= 2^17 (round 1's compact records needed an overflow list there; the 16-byte records
+    carry the full best_delta_t).  Several such pixels per segment, different run lengths, and D_EMPTY
+    events (their t is the frame's running_t, not stored) in the same frames."""
     rng = np.random.default_rng(5)
     T, H, W = 760, 6, 70
     clip = np.broadcast_to(rng.integers(1, 256, (1, H, W, 1), dtype=np.uint8), (T, H, W, 1)).copy()
@@ -151,8 +151,6 @@ def test_compact_park_records_overflow_list():
     wide = [int(((e["d"] != 255) & (e["t"] >= 0x1FFFF)).sum()) for e in (ov.integrate_matrix(f) for f in clip)]
     assert max(wide) >= 6 and sum(w > 0 for w in wide) >= 3  # the case is really exercised
     run_pair(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
-    # AbsoluteT keeps 8-byte records (a 17-bit distance-from-frame-end field was tried: noise 17.0 -> 15.3 us but
-    # scene 10.2 -> 10.6, SGPR spills); the same clip must still match
     run_pair(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0], batch=True)
     run_pair(clip[:, :, :, :], time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[3], batch=True)
 
@@ -336,8 +334,9 @@ import hashlib; print(hashlib.sha256(ev.tobytes() + offs.tobytes()).hexdigest())
     assert outs[0] == outs[1] == outs[2]
 
 
-def _oracle_events(clip, *, time_mode, multi_mode, dtm, crf=(0, 0, 10), threads=8):
+def _oracle_events(clip, *, time_mode, multi_mode, dtm, crf=(0, 0, 10), threads=None):
     T, H, W, Cn = clip.shape
+    threads = min(O.max_threads(), 64) if threads is None else threads
     ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm, threads=threads)
     ov.ensure_capacity(8)
     ov.set_crf_parameters(crf[1], crf[2])
@@ -387,21 +386,160 @@ def test_baseline_config_4_shape_row_bands_3840x2160():
 
 def test_baseline_config_5_shape_4k_rgb_lossy():
     """configs[4] shape: 3840x2160 RGB, crf-3 numbers (baseline 2, max 7, velocity 7), AbsoluteT,
-    Collapse, delta_t_max = 7650 (the generic kernel variants) -- a few frames against the oracle."""
+    Collapse, delta_t_max = 7650 (the generic kernel variants) -- 44 frames against the oracle: past the
+    delta_t_max pop of frame 30 (pop_top, popped_dtm, D_EMPTY fillers) and the whole c_thresh ramp."""
     import torch
     A = _hip()
-    T = 3
+    T = 44
     clip = O.synth_clip(O.CONTENT_SCENE, 3840, 2160, 3, T)
     hv = A.HipVideo(3840, 2160, 3, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=7650)
     hv.update_crf(3)
     d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
-    d_ev = torch.empty((int(d_frames.numel() * 0.5) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_ev = torch.empty((int(d_frames.numel() * 0.2) + 1024, 3), dtype=torch.int32, device="cuda")
     d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
     hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
     n = hv.finish()
     got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
-    want, _ = _oracle_events(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=(2, 7, 7))
+    want, woffs = _oracle_events(clip, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, dtm=7650, crf=(2, 7, 7))
+    assert np.array_equal(d_off.cpu().numpy(), woffs.astype(np.int64))
     assert n == len(want) and np.array_equal(got, want)
+    assert int((want["d"] == 255).sum()) > 0  # D_EMPTY fillers: collapsed flushes after the frame-30 pop happened
+
+
+def test_full_plane_long_run_1080p_540_frames():
+    """1920x1080, 540 frames, the lean kernel: a static plane (every pixel's run exceeds 514 frames, so the
+    t of its flush is >= 2^17) with a noisy band and scattered late changes, bit-exact against the oracle
+    over the whole clip."""
+    import torch
+    A = _hip()
+    T, H, W = 540, 1080, 1920
+    rng = np.random.default_rng(11)
+    base = rng.integers(1, 256, (H, W), dtype=np.uint8)
+    d_frames = torch.from_numpy(base).cuda().reshape(1, -1).repeat(T, 1)
+    view = d_frames.view(T, H, W)
+    view[200:, 500:520] = torch.from_numpy(rng.integers(0, 256, (T - 200, 20, W), dtype=np.uint8)).cuda()
+    late = torch.from_numpy(rng.random((H, W)) < 0.3).cuda()
+    for k in (520, 530, 539):  # 30 % of the plane flushes a > 514-frame run in each of these frames
+        view[k:] = torch.where(late, (255 - view[k - 1]).to(torch.uint8), view[k - 1]).unsqueeze(0)
+        late = ~late if k == 530 else late
+    clip = d_frames.cpu().numpy().reshape(T, H, W, 1)
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
+                    c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    want, woffs = _oracle_events(clip, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255)
+    d_ev = torch.empty((len(want) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
+    n = hv.finish()
+    got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    assert int(((want["d"] != 255) & (want["t"] >= 0x1FFFF)).sum()) > 500_000
+    assert np.array_equal(d_off.cpu().numpy(), woffs.astype(np.int64))
+    assert n == len(want) and np.array_equal(got, want)
+
+
+def test_quality_change_mid_stream_keeps_parity():
+    """update_quality_manual mid-stream (video.rs:1264-1287): generic batches at delta_t_max 7650 leave
+    pixels with several fired levels; lowering delta_t_max to ref_time afterwards must NOT switch to the
+    lean kernel (which only understands m <= 1) -- the variant choice is sticky until reset."""
+    A = _hip()
+    clip = clips.make_clip("runs", 150, 24, 40, 1, seed=99)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov = O.Video(40, 24, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+        hv = A.HipVideo(40, 24, 1, time_mode=tm, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=7650)
+        ov.ensure_capacity(22)
+        for v in (ov, hv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        want = [ov.integrate_matrix(f) for f in clip[:60]]
+        got, offs = hv.integrate_batch(clip[:60])
+        assert np.array_equal(got, np.concatenate(want))
+        ov.set_crf_parameters(3, 4)   # update_quality_manual(baseline 1, max 3, multiplier 1, velocity 4)
+        ov.set_delta_t_max(255)
+        ov.reset_c_thresh(1)
+        hv.update_quality_manual(1, 3, 1, 4)
+        want = [ov.integrate_matrix(f) for f in clip[60:]]
+        got, offs = hv.integrate_batch(clip[60:])
+        assert np.array_equal(got, np.concatenate(want)), tm
+        # after a reset the lean kernel is allowed again and still matches
+        hv.reset()
+        ov2 = O.Video(40, 24, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+        ov2.set_crf_parameters(3, 4)
+        ov2.reset_c_thresh(1)
+        hv.reset_c_thresh(1)
+        want = [ov2.integrate_matrix(f) for f in clip[:40]]
+        got, offs = hv.integrate_batch(clip[:40])
+        assert np.array_equal(got, np.concatenate(want)), tm
+
+
+def test_merge_kernel_equals_single_context_stream():
+    """adder_hip_merge_streams_device: three row bands' streams laid back to back -> one frame-major stream
+    == the whole-plane context's (the multi-GPU merge, on one GPU)."""
+    import torch
+    A = _hip()
+    from adder_amd import sharding
+    T, H, W = 37, 120, 200
+    clip = clips.make_clip("runs", T, H, W, 1, seed=21)
+    whole, offs = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255)
+    bands = sharding.row_bands(H, 3)
+    evs, oss = [], []
+    for (y0, y1) in bands:
+        ev, o = _events_device(A, clip, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, dtm=255, row_band=(y0, y1))
+        evs.append(np.frombuffer(ev.tobytes(), dtype=np.int32).reshape(-1, 3))
+        oss.append(o.astype(np.int64))
+    stage = torch.from_numpy(np.concatenate(evs)).cuda()
+    all_offs = torch.from_numpy(np.stack(oss)).cuda()
+    hv = A.HipVideo(W, H, 1)
+    out = torch.full((len(whole) + 5, 3), -1, dtype=torch.int32, device="cuda")
+    moffs = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.merge_streams_device(stage, all_offs, 3, T, out, moffs)
+    hv.check_status()
+    got = np.frombuffer(out[: len(whole)].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    assert np.array_equal(moffs.cpu().numpy(), offs.astype(np.int64)) and np.array_equal(got, whole)
+    assert int((out[len(whole):] != -1).sum()) == 0
+    # a merged buffer that is too small is reported, not overrun
+    small = torch.full((len(whole) - 7, 3), -1, dtype=torch.int32, device="cuda")
+    hv.merge_streams_device(stage, all_offs, 3, T, small, None)
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.check_status()
+    assert ei.value.code == A.E_OUT_CAPACITY
+
+
+def test_gather_cabi_single_rank_world():
+    """libadder_rccl.so (include/adder_gather.h) end to end with a real RCCL communicator of one rank: the
+    unique id, ncclCommInitRank, the offsets all-gather, the merge -- the calls a Rust host makes."""
+    import torch
+    A = _hip()
+    from adder_amd.gather import HipGather, unique_id
+    T, H, W = 20, 64, 96
+    clip = clips.make_clip("runs", T, H, W, 1, seed=5)
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
+                    c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    st = torch.cuda.current_stream().cuda_stream
+    d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_ev = torch.empty((W * H * T * 3, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+    n = hv.finish()
+    g = HipGather(hv, unique_id(), 0, 1)
+    d_m = torch.full((n + 3, 3), -1, dtype=torch.int32, device="cuda")
+    d_mo = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    assert g.gather_events(d_ev, d_off, T, 0, d_m, d_mo, stream=st) == n
+    assert torch.equal(d_m[:n], d_ev[:n]) and torch.equal(d_mo, d_off) and int((d_m[n:] != -1).sum()) == 0
+    merged, base = g.layout(d_off, T, stream=st)
+    assert np.array_equal(merged.astype(np.int64), d_off.cpu().numpy()) and np.array_equal(base, merged[:-1])
+    g.close()
+
+
+def test_two_ranks_hip_video_gather_shared_device():
+    """Two processes, one HipVideo per rank on its row band (both on cuda:0 over gloo: a 1-GPU box cannot
+    host two RCCL ranks), gather_event_stream with the HIP merge kernel == the single-context stream."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731",
+                        os.path.join(ROOT, "tests", "mp_hip_gather.py")],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "rank0 ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 @pytest.mark.gpu
@@ -487,9 +625,9 @@ def test_lake_golden_bytes_pipelined_stream(golden_dir):
 
 
 def test_batch_lengths_around_chunk_and_lag_boundaries():
-    """Fused expansion runs two chunks behind the step (scratch ring of three chunks, chunk = 16): batch
-    lengths on both sides of every boundary, several submission forms, consecutive batches on one
-    context -- always the oracle's stream and frame offsets."""
+    """The scratch ring holds two chunks of 32 frames and a launch steps up to 32 frames: batch lengths on
+    both sides of every boundary, several submission forms, consecutive batches on one context -- always
+    the oracle's stream and frame offsets."""
     import subprocess, sys
     code = r'''
 import sys, numpy as np
@@ -499,7 +637,7 @@ import adder_amd as A
 from oracle import oracle as O
 import clips
 W, H = 70, 23
-lens = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 5]
+lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 5]
 clip = clips.make_clip("runs", sum(lens), H, W, 1, seed=4)
 ov = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
 ov.set_crf_parameters(0, 10); ov.reset_c_thresh(0)
@@ -523,7 +661,7 @@ for T in lens:
     assert int((d_ev[n:] != -1).sum()) == 0, T  # nothing written past the stream
 print("ok")
 ''' % (ROOT, ROOT, ROOT)
-    for env in ({}, {"ADDER_HIP_NO_GRAPH": "1"}, {"ADDER_HIP_FUSE_EXPAND": "0"},
+    for env in ({}, {"ADDER_HIP_NO_GRAPH": "1"}, {"ADDER_HIP_NO_GRAPH": "2"},
                 {"ADDER_HIP_FRAMES_PER_LAUNCH": "1"}, {"ADDER_HIP_FRAMES_PER_LAUNCH": "5"},
                 {"ADDER_HIP_CHUNK": "4", "ADDER_HIP_FRAMES_PER_LAUNCH": "4"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
