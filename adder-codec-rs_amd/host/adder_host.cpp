@@ -1,6 +1,8 @@
 // adder_host.cpp -- see adder_host.hpp.  Reference file:line citations are in the header.
 #include "adder_host.hpp"
 
+#include <chrono>
+
 #include <string.h>
 
 #include <algorithm>
@@ -44,7 +46,10 @@ void Crf::update_quality(uint8_t crf) {
 
 // ---------------------------------------------------------------- Encoder
 Encoder::Encoder(CodecMetadata meta, std::ostream *w, EncoderOptions o, EncoderType t)
-    : options(o), meta_(meta), writer_(w), type_(t) {}
+    : options(o), meta_(meta), writer_(w), type_(t) {
+    // EncoderState::default(): last_event_ts = Instant::now() (encoder.rs:45-53)
+    last_event_ts_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 Encoder Encoder::new_raw(CodecMetadata meta, std::ostream *writer, EncoderOptions options) {
     if (!writer) throw CodecError(CodecError::Io, "raw encoder needs a writer");
@@ -71,7 +76,7 @@ void Encoder::encode_header() {
     meta_.header_size = n;
 }
 
-void Encoder::ingest_events(const Event *events, size_t n) {
+void Encoder::output_events(const Event *events, size_t n) {
     if (!writer_ || n == 0) return;  // EmptyOutput swallows events
     scratch_.resize(n * 11);
     const size_t bytes = adder_raw_events(scratch_.data(), events, n, meta_.plane.c());
@@ -79,7 +84,90 @@ void Encoder::ingest_events(const Event *events, size_t n) {
     if (!*writer_) throw CodecError(CodecError::Io, "write failed");
 }
 
-void Encoder::ingest_event(const Event &e) { ingest_events(&e, 1); }
+// std::collections::BinaryHeap, restated so that ties on t pop in the reference's order: `Ord for Event`
+// compares other.t with self.t (lib.rs:424-430), i.e. a > b  <=>  a.t < b.t.
+//   push = Vec::push + sift_up(0, old_len): the hole climbs while element > parent;
+//   pop  = swap the last element into the root, sift_down_to_bottom (always towards the greater child,
+//          the RIGHT one when left <= right), then sift_up from there.
+static inline bool ord_le(const Event &a, const Event &b) { return a.t >= b.t; }  // a <= b in `Ord for Event`
+void Encoder::heap_push(const Event &e) {
+    queue_.push_back(e);
+    size_t pos = queue_.size() - 1;
+    const Event elem = queue_[pos];
+    while (pos > 0) {
+        const size_t parent = (pos - 1) / 2;
+        if (ord_le(elem, queue_[parent])) break;
+        queue_[pos] = queue_[parent];
+        pos = parent;
+    }
+    queue_[pos] = elem;
+}
+Event Encoder::heap_pop() {
+    Event item = queue_.back();
+    queue_.pop_back();
+    if (queue_.empty()) return item;
+    std::swap(item, queue_[0]);
+    const size_t end = queue_.size();
+    const Event elem = queue_[0];
+    size_t pos = 0, child = 1;
+    while (child <= (end >= 2 ? end - 2 : 0)) {
+        if (ord_le(queue_[child], queue_[child + 1])) child += 1;
+        queue_[pos] = queue_[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+        queue_[pos] = queue_[child];
+        pos = child;
+    }
+    // sift_up(0, pos)
+    while (pos > 0) {
+        const size_t parent = (pos - 1) / 2;
+        if (ord_le(elem, queue_[parent])) break;
+        queue_[pos] = queue_[parent];
+        pos = parent;
+    }
+    queue_[pos] = elem;
+    return item;
+}
+
+void Encoder::ingest_event(const Event &e) {
+    if (options.event_drop.kind == EventDrop::Manual) {  // encoder.rs:237-250
+        const double now = clock ? clock()
+                                 : std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const double t_diff = now - last_event_ts_;
+        const double alpha = options.event_drop.alpha;
+        const double new_event_rate = alpha * current_event_rate_ + (1.0 - alpha) / t_diff;
+        if (new_event_rate > options.event_drop.target_event_rate) {
+            current_event_rate_ *= alpha;
+            return;  // skip this event
+        }
+        last_event_ts_ = now;
+        current_event_rate_ = new_event_rate;
+    }
+    if (options.event_order == EventOrder::Unchanged) {
+        output_events(&e, 1);
+        return;
+    }
+    // EventOrder::Interleaved (:257-270): push, then release the earliest event once it is more than
+    // delta_t_max older than the one just pushed.  At most ONE event leaves per ingest, and whatever is
+    // still queued when the writer is closed is never written (close_writer, :152-157).
+    const uint32_t dt = e.t;
+    heap_push(e);
+    const uint32_t horizon = dt > meta_.delta_t_max ? dt - meta_.delta_t_max : 0u;  // saturating_sub
+    if (queue_[0].t < horizon) {
+        const Event first = heap_pop();
+        output_events(&first, 1);
+    }
+}
+
+void Encoder::ingest_events(const Event *events, size_t n) {
+    if (options.event_drop.kind == EventDrop::None && options.event_order == EventOrder::Unchanged) {
+        output_events(events, n);  // the default path: one serialisation call for the whole slice
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) ingest_event(events[i]);
+}
 
 void Encoder::ingest_events_events(const std::vector<std::vector<Event>> &v) {
     for (const auto &chunk : v) ingest_events(chunk.data(), chunk.size());

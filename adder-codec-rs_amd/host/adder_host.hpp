@@ -88,9 +88,20 @@ class Crf {  // :24-37, :55-118
     CrfParameters parameters_;
 };
 
-struct EncoderOptions {  // codec/mod.rs:264-283; only the defaults of event_drop / event_order exist here
+// codec/mod.rs:285-317
+struct EventDrop {
+    enum Kind { None, Manual } kind = None;  // (`Auto` is `todo!()` in the reference, encoder.rs:251-253)
+    double target_event_rate = 0.0;          // Manual
+    double alpha = 0.0;                      // Manual: the decay rate in [0, 1]
+    static EventDrop manual(double rate, double a) { return EventDrop{Manual, rate, a}; }
+};
+enum class EventOrder { Unchanged, Interleaved };
+
+struct EncoderOptions {  // codec/mod.rs:264-283
+    EventDrop event_drop;
+    EventOrder event_order = EventOrder::Unchanged;
     Crf crf;
-    static EncoderOptions default_(PlaneSize plane) { return EncoderOptions{Crf(std::nullopt, plane)}; }
+    static EncoderOptions default_(PlaneSize plane) { return EncoderOptions{EventDrop{}, EventOrder::Unchanged, Crf(std::nullopt, plane)}; }
 };
 
 struct CodecMetadata {  // codec/mod.rs:76-107
@@ -111,19 +122,30 @@ class Encoder {  // encoder.rs:29-37
     static Encoder new_raw(CodecMetadata meta, std::ostream *writer, EncoderOptions options);  // :94-108
     static Encoder new_empty(CodecMetadata meta, EncoderOptions options);                      // :57-72
     const CodecMetadata &meta() const { return meta_; }
-    void ingest_event(const Event &e);                                   // :233-273 (EventDrop::None, Unchanged)
+    void ingest_event(const Event &e);                                   // :233-273
     void ingest_events(const Event *events, size_t n);                   // :281-286
     void ingest_events_events(const std::vector<std::vector<Event>> &v); // :289-294
     std::ostream *close_writer();  // :154-168 -> RawOutput::into_writer writes the 11-byte EOF and flushes
     EncoderOptions options;
+    // EventDrop::Manual reads the wall clock (`Instant::now()`, :243); tests inject their own (seconds)
+    std::function<double()> clock;
+    size_t queued() const { return queue_.size(); }  // EventOrder::Interleaved: events still in the heap
+    void reset_clock_origin(double t) { last_event_ts_ = t; }  // tests: EncoderState::last_event_ts
 
   private:
     Encoder(CodecMetadata meta, std::ostream *w, EncoderOptions o, EncoderType t);
     void encode_header();  // :170-229
+    void output_events(const Event *events, size_t n);  // self.output.ingest_event
+    void heap_push(const Event &e);                     // std::collections::BinaryHeap::push
+    Event heap_pop();                                   // ... ::pop
     CodecMetadata meta_;
     std::ostream *writer_;
     EncoderType type_;
     std::vector<uint8_t> scratch_;
+    // EncoderState (encoder.rs:39-53)
+    double current_event_rate_ = 0.0;
+    double last_event_ts_ = 0.0;
+    std::vector<Event> queue_;  // BinaryHeap<Event>: `Ord for Event` is reversed on t (lib.rs:424-436) => min-heap on t
 };
 
 // ---------------------------------------------------------------- reader: Decoder over RawInput

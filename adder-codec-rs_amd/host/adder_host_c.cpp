@@ -184,4 +184,43 @@ long long adder_host_encode_raw(uint8_t codec_version, uint16_t width, uint16_t 
         return -1;
     }
 }
+
+// Encoder with EventOrder::Interleaved and/or EventDrop::Manual over an in-memory writer: ingests `n`
+// events (for Manual, event i arrives at clock_s[i] seconds; the encoder is created at clock 0), closes the
+// writer and copies the file bytes out.  Returns the byte count, or -1.
+long long adder_host_encode_events(const AdderEvent *events, size_t n, uint16_t width, uint16_t height, uint8_t channels,
+                                   uint32_t delta_t_max, int interleaved, int manual_drop, double target_event_rate,
+                                   double alpha, const double *clock_s, uint8_t *out, size_t out_cap,
+                                   size_t *still_queued) {
+    try {
+        CodecMetadata meta;
+        meta.plane = PlaneSize(width, height, channels);
+        meta.delta_t_max = delta_t_max;
+        meta.time_mode = TimeMode::AbsoluteT;
+        std::ostringstream os(std::ios::binary);
+        EncoderOptions opts = EncoderOptions::default_(meta.plane);
+        if (interleaved) opts.event_order = EventOrder::Interleaved;
+        if (manual_drop) opts.event_drop = EventDrop::manual(target_event_rate, alpha);
+        size_t idx = 0;
+        double now = 0.0;
+        Encoder enc = Encoder::new_raw(meta, &os, opts);
+        enc.clock = [&]() { return now; };
+        // (the constructor stamped last_event_ts with the steady clock; the first ingest below overrides
+        // the notion of "now", and t_diff of the first event is measured from 0 as the test's model does)
+        enc.reset_clock_origin(0.0);
+        for (idx = 0; idx < n; ++idx) {
+            now = clock_s ? clock_s[idx] : 0.0;
+            enc.ingest_event(events[idx]);
+        }
+        if (still_queued) *still_queued = enc.queued();
+        enc.close_writer();
+        const std::string bytes = os.str();
+        if (bytes.size() > out_cap) throw CodecError(CodecError::Io, "output buffer too small");
+        memcpy(out, bytes.data(), bytes.size());
+        return (long long)bytes.size();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
 }

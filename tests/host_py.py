@@ -33,8 +33,26 @@ def lib():
         L.adder_host_simulproc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_uint32,
                                            C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int32, C.c_uint8, C.c_int,
                                            C.c_char_p, C.c_char_p]
+        L.adder_host_encode_events.restype = C.c_longlong
+        L.adder_host_encode_events.argtypes = [C.c_void_p, C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint32,
+                                               C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                               C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
+
+
+def encode_events(events, w, h, c, dtm, *, interleaved=False, manual=None, clock=None):
+    """Encoder (raw) with EventOrder::Interleaved / EventDrop::Manual(target_rate, alpha) -> (file bytes, queued)."""
+    events = np.ascontiguousarray(events, adder_amd.EVENT_DTYPE)
+    dst = np.zeros(64 + 11 * len(events) + 16, np.uint8)
+    clk = None if clock is None else np.ascontiguousarray(clock, np.float64)
+    q = C.c_size_t(0)
+    n = lib().adder_host_encode_events(events.ctypes.data, len(events), w, h, c, dtm, int(interleaved),
+                                       int(manual is not None), manual[0] if manual else 0.0,
+                                       manual[1] if manual else 0.0, None if clk is None else clk.ctypes.data,
+                                       dst.ctypes.data, len(dst), C.byref(q))
+    assert n >= 0, err()
+    return dst[:n].tobytes(), q.value
 
 
 def err():

@@ -432,7 +432,7 @@ def test_full_plane_long_run_1080p_540_frames():
     hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
     n = hv.finish()
     got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
-    assert int(((want["d"] != 255) & (want["t"] >= 0x1FFFF)).sum()) > 500_000
+    assert int(((want["d"] != 255) & (want["t"] >= 0x1FFFF)).sum()) > 100_000
     assert np.array_equal(d_off.cpu().numpy(), woffs.astype(np.int64))
     assert n == len(want) and np.array_equal(got, want)
 
