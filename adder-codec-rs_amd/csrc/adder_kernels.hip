@@ -23,8 +23,8 @@
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
 // loop and nothing that can hang.  Pixels whose arena is deeper than one fired level
-// (Normal mode, or delta_t_max > time_spanned) take the full arena walk (exec_step)
-// inside the GENERIC instantiations (adder_frame_kernel).
+// (Normal mode, or delta_t_max > time_spanned) run the phased generic step (gen_root / gen_emit /
+// gen_walk / gen_pop) of adder_frame_kernel, with levels 1..4 of the arena held in LDS for the launch.
 // HBM/VALU-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -76,7 +76,7 @@ struct __attribute__((aligned(4))) EventWords {
     uint32_t xy, cd, t;
 };
 
-// exec_step's events of one generic unit, parked with their final in-segment offset
+// gen_emit's events of one unit, parked in final order with their final in-segment offset
 struct EmitPark {
     uint2 *dst;     // next free parked slot of this lane
     uint32_t tag;   // unit_in_wave << 8
@@ -407,16 +407,44 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1_WAVES) void adder_lean1_
 }
 
 // ------------------------------------------------------------------------------------------
-// K1, generic variants (Normal mode, or delta_t_max > time_spanned): any arena depth.  Units
-// with at most one fired level before and after the step take the branch-free step_fast, whose
-// <= 3 events stay in registers until a DPP prefix scan over the wave has ordered them; deeper
-// units are counted with plan_count before the scan and then stepped in place by the full arena
-// walk (exec_step, levels >= 1 straight from / to the deep planes), parking their events behind
-// the lane's fast ones.  Parked record: 8 bytes {t, d | unit << 8 | final offset << 16}.
+// K1, generic variants (Normal mode, or delta_t_max > time_spanned): any arena depth.  Every unit runs the
+// four phases of the generic step (adder_pixel.hpp): gen_root on the register-resident level 0 (branch-
+// free; it also yields the unit's event count, so a DPP prefix scan over the wave can place the events
+// before they are produced), gen_emit (parks 8-byte records {t, d | unit << 8 | final offset << 16} in
+// final order), gen_walk over the deeper levels and gen_pop.  Levels 1..kGenLdsLevels of the wave's units
+// live in LDS for the whole launch (temporal blocking: fetched from the deep planes once, written back
+// once); deeper ones -- long static runs in Normal mode -- are accessed in the deep planes directly.
 // ------------------------------------------------------------------------------------------
+#ifndef ADDER_GEN_LDS_LEVELS
+#define ADDER_GEN_LDS_LEVELS 4
+#endif
+constexpr uint32_t kGenLdsLevels = ADDER_GEN_LDS_LEVELS;
+
+struct DeepHybrid {
+    uint4 *lds;     // the unit's level-1 slot in the wave's LDS slice; level k at lds[(k - 1) * kWaveUnits]
+    DeepGlobal g;   // levels beyond kGenLdsLevels
+    __device__ __forceinline__ void load(uint32_t k, Node &n) const {
+        if (k <= kGenLdsLevels) {
+            const uint4 r = lds[(k - 1u) * kWaveUnits];
+            n.integ = __uint_as_float(r.x);
+            n.dt = __uint_as_float(r.y);
+            n.bdt = __uint_as_float(r.z);
+            n.bd = r.w;
+        } else {
+            g.load(k, n);
+        }
+    }
+    __device__ __forceinline__ void store(uint32_t k, const Node &n) const {
+        if (k <= kGenLdsLevels)
+            lds[(k - 1u) * kWaveUnits] = make_uint4(__float_as_uint(n.integ), __float_as_uint(n.dt), __float_as_uint(n.bdt), n.bd);
+        else
+            g.store(k, n);
+    }
+};
+
 template <bool COLLAPSE, bool ABS_T>
 __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                                uint32_t u0, uint32_t gw, uint32_t lane) {
+                                                uint32_t u0, uint32_t gw, uint32_t lane, uint4 *lds_levels) {
     constexpr uint32_t N = kUnitsPerLane;
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     PxState px[N];
@@ -434,6 +462,18 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         for (uint32_t j = 0; j < N; ++j) px[j] = px_unpack(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
     }
     StepConsts sc = a.sc;
+    // the unit's LDS slot: [level][j][lane] (consecutive lanes -> consecutive 16-byte slots)
+    DeepHybrid deep[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        deep[j].lds = lds_levels + j * kWave + lane;
+        deep[j].g = DeepGlobal{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
+        for (uint32_t k = 1; k <= kGenLdsLevels && k < px[j].m; ++k) {  // levels 1.. of the launch's first frame
+            Node nk;
+            deep[j].g.load(k, nk);
+            deep[j].store(k, nk);
+        }
+    }
 
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
     const uint8_t *const frames_u = uniform_ptr(b->frames);
@@ -445,95 +485,59 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
     const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
     const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
     uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % slots_u);
+    bool depth_error = false;
 
     for (uint32_t i = 0; i < nb; ++i, slot = (slot + 1u == slots_u) ? 0u : slot + 1u) {
         const uint32_t f = a.frame_idx + i;
         uint32_t next_w = 0u;
         if (i + 1 < nb)
             next_w = load_input(frames_u + (size_t)(f + 1) * n_units_u, u0, full ? 0xffffffffu : n_units_u);
-        const FrameTab ft = ftab_u[f];
-        sc.running_t = ft.running_t;
+        const uint2 ft = gload<uint2>(ftab_u, f * (uint32_t)sizeof(FrameTab));
+        sc.running_t = __uint_as_float(__builtin_amdgcn_readfirstlane(ft.x));
         sc.running_t_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(sc.running_t));
-        sc.cth = ft.cth;
+        sc.cth = __builtin_amdgcn_readfirstlane(ft.y);
 
-        // ---------------- the step ----------------
-        uint32_t nl = 0;    // events parked by this lane's fast units
-        uint32_t ngen = 0;  // events its generic units will park
-        uint32_t cnts = 0;  // per-pixel event counts, 8 bits each
-        uint32_t gmask = 0; // units left to exec_step
-        FastEvents fe[N];   // <= 3 events per fast unit, kept in registers until the scan is done
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) fe[j].mask = 0u;
+        // ---------------- level 0 of every unit + the event counts ----------------
+        GenPlan plan[N];
+        uint32_t lane_cnt = 0;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            gen_root<COLLAPSE>(px[j], v, sc, plan[j]);
             // units past the band's end are padding: their state may be stepped freely, only
             // their events must be suppressed
-            const bool active = full || u0 + j < a.n_units;
-            if (fast_eligible<COLLAPSE>(px[j], v, sc.cth)) {
-                step_fast<COLLAPSE, ABS_T>(px[j], v, sc, fe[j]);
-                fe[j].mask = active ? fe[j].mask : 0u;
-                const uint32_t c = (uint32_t)__popc(fe[j].mask);
-                cnts |= c << (8 * j);
-                nl += c;
-            } else if (active) {
-                const uint32_t planned = plan_count(px[j], v, sc);
-                cnts |= planned << (8 * j);
-                gmask |= 1u << j;
-                ngen += planned;
+            if (!(full || u0 + j < a.n_units)) {
+                plan[j].count = 0u;
+                plan[j].flush = false;
+                plan[j].need_pop = false;
             }
+            lane_cnt += plan[j].count;
         }
-        uint32_t lane_cnt = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) lane_cnt += (cnts >> (8 * j)) & 0xffu;
-
         // ---------------- wave-level ordered compaction into the frame's segment ----------------
-        // low half: events of the lane in the final stream; high half: events it parks (the
-        // fast ones held in registers, then those of its generic units)
-        const uint32_t packed = lane_cnt | ((nl + ngen) << 16);
-        const uint32_t incl = wave_inclusive_scan_dpp(packed);
+        const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
         const size_t seg_idx = (size_t)slot * num_waves_u + sgw;  // uniform
-        if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl);
-        const uint32_t excl = incl - packed;
-        const uint32_t lane_off = excl & 0xffffu;  // final offset of the lane inside the segment
-        // exclusive prefix of the per-pixel counts, 8 bits each (sums stay below 256)
-        const uint32_t pre = (cnts << 8) + (cnts << 16) + (cnts << 24);
-        uint8_t *const seg = park_ring_u + seg_idx * park_bytes_u;  // uniform
-        const uint32_t poff = (excl >> 16) * kGenRecBytes;  // the lane's first parked slot
-        {
-            uint32_t e = 0;
+        // events of the segment (low half) = parked records (high half): one record per event, in final order
+        if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl | (incl << 16));
+        uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
+        uint2 *const seg = reinterpret_cast<uint2 *>(park_ring_u + seg_idx * park_bytes_u);  // uniform
 #pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                const uint32_t m = fe[j].mask;
-                const uint32_t tag = (lane * N + j) << 8;
-                uint32_t off = lane_off + ((pre >> (8u * j)) & 0xffu);
-                if (m & 1u) gstore(seg, poff + 8u * e, make_uint2(fe[j].ta, fe[j].da | tag | (off << 16)));
-                e += m & 1u;
-                off += m & 1u;
-                if (m & 2u) gstore(seg, poff + 8u * e, make_uint2(fe[j].tb, fe[j].db | tag | (off << 16)));
-                e += (m >> 1) & 1u;
-                off += (m >> 1) & 1u;
-                if (m & 4u) gstore(seg, poff + 8u * e, make_uint2(fe[j].tc, fe[j].dc | tag | (off << 16)));
-                e += m >> 2;
+        for (uint32_t j = 0; j < N; ++j) {
+            if (plan[j].count != 0u) {
+                EmitPark em{seg + off, (lane * N + j) << 8, off};
+                gen_emit<ABS_T>(px[j], plan[j], sc, deep[j], em);
             }
+            off += plan[j].count;
         }
-        if (gmask) {
-            // units deeper than one fired level: the full arena walk (exec_step), levels >= 1
-            // straight from / to the deep planes; their events are parked behind the lane's
-            // fast ones (every parked event carries its final offset, so the order is free)
-            uint2 *gdst = reinterpret_cast<uint2 *>(seg) + (excl >> 16) + nl;
+        // ---------------- the deeper levels ----------------
 #pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                if (!((gmask >> j) & 1u)) continue;
-                const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
-                DeepGlobal deep{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
-                EmitPark em{gdst, (lane * N + j) << 8, lane_off + ((pre >> (8 * j)) & 0xffu)};
-                if (!exec_step(px[j], v, sc, deep, em)) raise(a.status, kStatusDepth);
-                gdst = em.dst;
-            }
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            if (!gen_walk(px[j], v, plan[j], sc, deep[j])) depth_error = true;
+            gen_pop(px[j], plan[j], deep[j]);
         }
         vin_w = next_w;
     }
+    if (depth_error) raise(a.status, kStatusDepth);
 
     // ---------------- state back to HBM ----------------
     {
@@ -546,6 +550,11 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
             dv[j] = px[j].n0.dt;
             bv[j] = px[j].n0.bdt;
             lfv[j] = px[j].lastf;
+            for (uint32_t k = 1; k <= kGenLdsLevels && k < px[j].m; ++k) {
+                Node nk;
+                deep[j].load(k, nk);
+                deep[j].g.store(k, nk);
+            }
         }
         store_vec(a.hdr, u0, hdrv);
         store_vec(a.integ0, u0, iv);
@@ -565,12 +574,13 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
 template <bool COLLAPSE, bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const BatchArgs *__restrict__ b, uint32_t f,
                                                                       uint32_t nb) {
+    __shared__ __attribute__((aligned(16))) uint4 s_levels[kWavesPerBlock][kGenLdsLevels * kWaveUnits];
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
     const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane);
+    gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane, s_levels[tid / kWave]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -467,204 +467,136 @@ ADDER_HD LeanEvents lean_decode(const LeanRec &r, bool abs_t, uint32_t running_t
 }
 
 // ---------------------------------------------------------------------------------------
-// GENERIC PATH (Normal mode, or delta_t_max > time_spanned): any arena depth.
-// fast_eligible / step_fast handle the units that have at most one fired level before the
-// step and at most one after it (the common case) branch-free; plan_count tells how many
-// events a deeper unit's step will emit (so the ordered compaction can reserve the slots
-// before the step runs), exec_step runs it.
+// GENERIC STEP (Normal mode, or delta_t_max > time_spanned): any arena depth.  integrate_for_px
+// for one unit, split into the four phases the kernel runs wave-wide:
+//   gen_root  : pop_best_events' bookkeeping + the walk's visit of arena index 0, entirely on the
+//               register-resident level 0 and branch-free; leaves the number of events the unit will emit
+//               this frame (so the ordered compaction can place them before they exist) and whether
+//               the walk goes on to deeper levels;
+//   gen_emit  : the events, in emission order -- the flushed arena (root first, then levels 1.. or the
+//               Collapse filler), then pop_top's event;
+//   gen_walk  : integrate's loop over levels >= 1 (:340-392): levels accumulate until one fires, which
+//               truncates the arena behind it; if none does the pristine tail fires and becomes a level;
+//   gen_pop   : pop_top_event's arena shift (:199-207).
+// `deep` gives access to levels k >= 1 of this pixel (load(k, Node&), store(k, const Node&)); `emit(d, t)`
+// appends one event.  tests/cpu_sim runs exactly these functions against the literal oracle.
 // ---------------------------------------------------------------------------------------
-
-// Events of one fast step, in emission order: A (pop_best's first event), B (the D_EMPTY
-// filler of a collapsed pop_best), C (pop_top's event).
-struct FastEvents {
-    uint32_t mask;  // bit0 A, bit1 B, bit2 C
-    uint32_t da, ta, db, tb, dc, tc;
+struct GenPlan {
+    bool flush;        // pop_best_events ran this frame
+    bool collapsed;    // ... on a popped arena in Collapse mode: root event + D_EMPTY filler only (:249-265)
+    bool walk;         // the walk continues past arena index 0
+    bool need_pop;     // pop_top_event follows the integrate (:394-396)
+    uint32_t m_old;    // fired levels before the step
+    uint32_t old_bd;   // the old root's best event (valid iff m_old > 0)
+    float old_bdt;
+    uint32_t count;    // events of this unit this frame
 };
 
 template <bool COLLAPSE>
-ADDER_HD bool fast_eligible(const PxState &s, uint32_t v, uint32_t cth) {
-    if (s.m >= 2u) return false;
-    if (s.m == 0u) return true;
-    // m == 1: the walk must stop at level 0 (else the tail fires and creates level 1)
-    if (contrast_exceeded(v, s.base, cth)) return true;  // arena restarts from the tail
-    if (COLLAPSE && s.popped) return true;               // only the root integrates
-    return fadd(s.n0.integ, (float)v) >= pow2_d(fired_d(s.n0.bd));
-}
-
-// Written branch-free: everything is computed unconditionally and selected.
-template <bool COLLAPSE, bool ABS_T>
-ADDER_HD void step_fast(PxState &p, uint32_t v, const StepConsts &sc, FastEvents &ev) {
+ADDER_HD void gen_root(PxState &s, uint32_t v, const StepConsts &sc, GenPlan &p) {
     const float I = (float)v;
     const float T = sc.time_spanned;
-    bool has0 = p.m != 0u;
-    bool popped = p.popped;
-    float lastf = p.lastf;
-
-    // ---- pop_best_events (event_pixel_tree.rs:213-287): A = level 0's best event; with
-    // Collapse after a delta_t_max pop it is followed by the D_EMPTY filler B (:249-265) ----
-    const bool flush = contrast_exceeded(v, p.base, sc.cth);
-    const bool a_valid = flush && has0;
-    const bool b_valid = COLLAPSE && a_valid && popped;
-    {
-        float evdt = p.n0.bdt;
-        if (ABS_T) {
-            evdt = fadd(evdt, lastf);
-            const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
-            lastf = a_valid ? (b_valid ? sc.running_t : chained) : lastf;  // :122-129 / :257
-        }
-        ev.da = p.n0.bd;
-        ev.ta = f32_as_u32(evdt);
-        ev.db = kDEmpty;
-        ev.tb = sc.running_t_u32;
-    }
-    has0 = has0 && !flush;
-    popped = popped && !flush;
-    p.base = flush ? v : p.base;
-
-    // ---- integrate (:317-413): arena index 0 is level 0 if present, else the pristine
-    // tail, which always fires; the walk stops there (fast_eligible) ----
-    const float integ = has0 ? p.n0.integ : 0.0f;
-    const float dt = has0 ? p.n0.dt : 0.0f;
+    p.m_old = s.m;
+    p.old_bd = s.n0.bd;
+    p.old_bdt = s.n0.bdt;
+    p.flush = contrast_exceeded(v, s.base, sc.cth);
+    p.collapsed = COLLAPSE && p.flush && s.popped && s.m > 0u;
+    const uint32_t flushed = p.flush ? (p.collapsed ? 2u : s.m) : 0u;
+    const bool has0 = s.m != 0u && !p.flush;
+    const bool popped = s.popped && !p.flush;
+    s.base = p.flush ? v : s.base;
+    // arena index 0: level 0 if present, else the pristine tail (which always fires)
+    const float integ = has0 ? s.n0.integ : 0.0f;
+    const float dt = has0 ? s.n0.dt : 0.0f;
     const float sum = fadd(integ, I);
     const uint32_t nd = get_d(sum);
-    const uint32_t d = has0 ? fired_d(p.n0.bd) : nd;
+    const uint32_t d = has0 ? fired_d(s.n0.bd) : nd;
     const bool fire = sum >= pow2_d(d);
-    float prop = fdiv_small(fsub(pow2_d(nd), integ), I);
+    float prop = fdiv_small(fsub(pow2_d(nd), integ), I);  // consumed only inside fdiv_small's domain (lean_step)
     prop = (nd == kDZero || d == kDZero || I < 1.1920929e-7f) ? 1.0f : prop;
     const float bdt_fire = fadd(dt, fmul(T, prop));
     const bool acc = !fire || nd < kDMax;  // a node that fires at nd >= D_MAX keeps (integ, dt)
-    p.n0.integ = acc ? sum : integ;
-    p.n0.dt = acc ? fadd(dt, T) : dt;
-    p.n0.bd = fire ? nd : p.n0.bd;
-    p.n0.bdt = fire ? bdt_fire : p.n0.bdt;
-    const bool need_pop = fired_d(p.n0.bd) == kDMax || (p.n0.dt >= sc.dtm_f && !popped);  // :394-396
-
-    // ---- pop_top_event (:139-210): C = the root's best event; the arena shifts left ----
-    {
-        float evdt = p.n0.bdt;
-        if (ABS_T) {
-            evdt = fadd(evdt, lastf);
-            const float chained = (float)ceil_to_ref(f32_as_u32(evdt), sc.ref_time, sc.ref_magic);
-            lastf = need_pop ? chained : lastf;
-        }
-        ev.dc = p.n0.bd;
-        ev.tc = f32_as_u32(evdt);
-    }
-    ev.mask = (a_valid ? 1u : 0u) | (b_valid ? 2u : 0u) | (need_pop ? 4u : 0u);
-    p.m = need_pop ? 0u : 1u;
-    p.popped = popped || need_pop;
-    p.lastf = lastf;
+    s.n0.integ = acc ? sum : integ;
+    s.n0.dt = acc ? fadd(dt, T) : dt;
+    s.n0.bd = fire ? nd : s.n0.bd;
+    s.n0.bdt = fire ? bdt_fire : s.n0.bdt;
+    // a firing root truncates the arena to itself; otherwise the deeper levels are visited unless only the
+    // root integrates any more (:360-362)
+    p.walk = has0 && !fire && !(COLLAPSE && popped);
+    s.m = (fire || !has0) ? 1u : s.m;
+    s.popped = popped;
+    p.need_pop = root_needs_pop(s.n0, popped, sc);
+    p.count = flushed + (p.need_pop ? 1u : 0u);
 }
 
-ADDER_HD uint32_t plan_count(const PxState &s, uint32_t v, const StepConsts &sc) {
-    const float I = (float)v;
-    const uint32_t m = s.m;
-    bool popped = s.popped;
-    uint32_t count = 0;
-    bool from_tail = (m == 0u);
-    if (contrast_exceeded(v, s.base, sc.cth)) {
-        count = (popped && sc.collapse && m > 0u) ? 2u : m;
-        popped = false;
-        from_tail = true;
-    }
-    Node r = s.n0;
-    if (from_tail)
-        r = tail_fire(I, sc.time_spanned);
-    else
-        node_integrate(r, I, sc.time_spanned);
-    if (root_needs_pop(r, popped, sc)) count += 1u;
-    return count;
-}
-
-// `deep` gives access to levels k >= 1 of this pixel (load(k, Node&), store(k, const
-// Node&)); `emit(d, t)` appends one event of this pixel (in order).  Returns false if the
-// pixel needed more than sc.max_depth levels.
+// The unit's events of this frame.  Must run after gen_root and BEFORE gen_walk / gen_pop touch the
+// deep levels of other frames' state: a flushing unit does not walk, so its old levels are still in place.
 template <bool ABS_T, class Deep, class Emit>
-ADDER_HD bool exec_step_t(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
-    const float I = (float)v;
-    const float T = sc.time_spanned;
-    uint32_t m = s.m;
-    bool popped = s.popped;
-    bool ok = true;
-
-    // ---- pop_best_events ----
-    if (contrast_exceeded(v, s.base, sc.cth)) {
-        if (popped && sc.collapse && m > 0u) {
-            emit(s.n0.bd, f32_as_u32(ABS_T ? fadd(s.n0.bdt, s.lastf) : s.n0.bdt));
-            s.lastf = sc.running_t;
+ADDER_HD void gen_emit(PxState &s, const GenPlan &p, const StepConsts &sc, Deep &deep, Emit &emit) {
+    if (p.flush && p.m_old > 0u) {
+        if (p.collapsed) {
+            emit(p.old_bd, f32_as_u32(ABS_T ? fadd(p.old_bdt, s.lastf) : p.old_bdt));
+            s.lastf = sc.running_t;  // :257
             emit(kDEmpty, f32_as_u32(sc.running_t));
         } else {
-            if (m > 0u) emit(s.n0.bd, event_time<ABS_T>(s.n0.bdt, s.lastf, sc));
-            for (uint32_t k = 1; k < m; ++k) {
+            emit(p.old_bd, event_time<ABS_T>(p.old_bdt, s.lastf, sc));
+            for (uint32_t k = 1; k < p.m_old; ++k) {
                 Node nk;
                 deep.load(k, nk);
                 emit(nk.bd, event_time<ABS_T>(nk.bdt, s.lastf, sc));
             }
         }
-        m = 0u;
-        popped = false;
-        s.base = v;
     }
-
-    // ---- integrate: walk the fired levels from the root; the first one that fires
-    // truncates the arena behind it; if none does, the tail fires and becomes level m ----
-    bool stop = false;
-    if (m > 0u) {
-        if (node_integrate(s.n0, I, T)) {
-            m = 1u;
-            stop = true;
-        } else if (popped && sc.collapse) {
-            stop = true;  // :360-362 only the root keeps integrating
-        }
-        for (uint32_t k = 1; !stop && k < m; ++k) {
-            Node nk;
-            deep.load(k, nk);
-            const bool fired = node_integrate(nk, I, T);
-            deep.store(k, nk);
-            if (fired) {
-                m = k + 1u;
-                stop = true;
-            }
-        }
-    }
-    if (!stop) {
-        const Node t = tail_fire(I, T);
-        if (m >= sc.max_depth) {
-            ok = false;  // would need another stored level
-        } else {
-            if (m == 0u)
-                s.n0 = t;
-            else
-                deep.store(m, t);
-            m += 1u;
-        }
-    }
-    const bool need_pop = m > 0u && root_needs_pop(s.n0, popped, sc);
-
-    // ---- pop_top_event ----
-    if (need_pop) {
-        const uint32_t ed = s.n0.bd;
-        const float edt = s.n0.bdt;
-        for (uint32_t k = 1; k < m; ++k) {  // shift the arena left by one
-            Node nk;
-            deep.load(k, nk);
-            if (k == 1u)
-                s.n0 = nk;
-            else
-                deep.store(k - 1u, nk);
-        }
-        m -= 1u;
-        popped = true;
-        emit(ed, event_time<ABS_T>(edt, s.lastf, sc));
-    }
-    s.m = m;
-    s.popped = popped;
-    return ok;
+    if (p.need_pop) emit(s.n0.bd, event_time<ABS_T>(s.n0.bdt, s.lastf, sc));  // the root after this frame's integrate
 }
 
-template <class Deep, class Emit>
-ADDER_HD bool exec_step(PxState &s, uint32_t v, const StepConsts &sc, Deep &deep, Emit &emit) {
-    return sc.abs_t ? exec_step_t<true>(s, v, sc, deep, emit) : exec_step_t<false>(s, v, sc, deep, emit);
+// Returns false if the pixel needed more than sc.max_depth levels.
+template <class Deep>
+ADDER_HD bool gen_walk(PxState &s, uint32_t v, const GenPlan &p, const StepConsts &sc, Deep &deep) {
+    if (!p.walk) return true;
+    const float I = (float)v;
+    const float T = sc.time_spanned;
+    uint32_t k = 1;
+    Node nf;  // the node that fires: level k, or the pristine tail when k == m
+    nf.integ = 0.0f;
+    nf.dt = 0.0f;
+    nf.bdt = 0.0f;
+    nf.bd = 0u;
+    uint32_t d = get_d(I);  // the tail's d (:332-335)
+    for (; k < s.m; ++k) {
+        Node nk;
+        deep.load(k, nk);
+        const uint32_t dk = fired_d(nk.bd);
+        const float sk = fadd(nk.integ, I);
+        if (sk >= pow2_d(dk)) {
+            nf = nk;
+            d = dk;
+            break;
+        }
+        nk.integ = sk;
+        nk.dt = fadd(nk.dt, T);
+        deep.store(k, nk);
+    }
+    if (k >= sc.max_depth) return false;  // would need another stored level
+    node_fire(nf, d, fadd(nf.integ, I), I, T);
+    deep.store(k, nf);
+    s.m = k + 1u;
+    return true;
+}
+
+template <class Deep>
+ADDER_HD void gen_pop(PxState &s, const GenPlan &p, Deep &deep) {
+    if (!p.need_pop) return;
+    for (uint32_t k = 1; k < s.m; ++k) {  // shift the arena left by one
+        Node nk;
+        deep.load(k, nk);
+        if (k == 1u)
+            s.n0 = nk;
+        else
+            deep.store(k - 1u, nk);
+    }
+    s.m -= 1u;
+    s.popped = true;
 }
 
 // u8::get_frame_value for the running_intensities side plane (video.rs:713-730,

@@ -179,27 +179,15 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                     continue;
                 }
                 PxState p = px_unpack(hdr, gi, gd, gb, glf);
-                uint32_t planned = plan_count(p, v, sc);
                 size_t before = em.pos;
-                bool fast = false;
-                if (s->use_fast)
-                    fast = s->collapse ? fast_eligible<true>(p, v, sc.cth) : fast_eligible<false>(p, v, sc.cth);
-                if (fast) {
-                    FastEvents fe;
-                    if (s->collapse && s->abs_t) step_fast<true, true>(p, v, sc, fe);
-                    else if (s->collapse) step_fast<true, false>(p, v, sc, fe);
-                    else if (s->abs_t) step_fast<false, true>(p, v, sc, fe);
-                    else step_fast<false, false>(p, v, sc, fe);
-                    if (fe.mask & 1u) em(fe.da, fe.ta);
-                    if (fe.mask & 2u) em(fe.db, fe.tb);
-                    if (fe.mask & 4u) em(fe.dc, fe.tc);
-                    s->fast_steps++;
-                } else {
-                    DeepAcc deep{s, u};
-                    if (!exec_step(p, v, sc, deep, em)) rc = -5;
-                    s->generic_steps++;
-                }
-                if (em.pos - before != planned) s->plan_mismatch++;
+                DeepAcc deep{s, u};
+                GenPlan plan;
+                if (s->collapse) gen_root<true>(p, v, sc, plan); else gen_root<false>(p, v, sc, plan);
+                if (s->abs_t) gen_emit<true>(p, plan, sc, deep, em); else gen_emit<false>(p, plan, sc, deep, em);
+                if (!gen_walk(p, v, plan, sc, deep)) rc = -5;
+                gen_pop(p, plan, deep);
+                if (plan.walk) s->generic_steps++; else s->fast_steps++;
+                if (em.pos - before != plan.count) s->plan_mismatch++;
                 s->hdr[u] = px_hdr(p);
                 m = p.m;
                 if (m > s->max_m) s->max_m = m;
