@@ -73,6 +73,27 @@ class AdderFramerParams(C.Structure):
     ]
 
 
+class AdderCompressedParams(C.Structure):
+    """include/adder_compressed.h::AdderCompressedParams"""
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("width", C.c_uint16),
+        ("height", C.c_uint16),
+        ("channels", C.c_uint8),
+        ("codec_version", C.c_uint8),
+        ("time_mode", C.c_uint8),
+        ("write_header", C.c_uint8),
+        ("tps", C.c_uint32),
+        ("ref_interval", C.c_uint32),
+        ("delta_t_max", C.c_uint32),
+        ("adu_interval", C.c_uint32),
+        ("source_camera", C.c_uint32),
+        ("c_thresh_max", C.c_uint8),
+        ("reserved", C.c_uint8 * 3),
+        ("threads", C.c_uint32),
+    ]
+
+
 # every symbol include/*.h declares: name -> (restype, argtypes)
 _vp, _u8, _u16, _u32, _u64, _f32, _i32, _sz = (
     C.c_void_p, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_size_t)
@@ -118,6 +139,15 @@ SYMBOLS = {
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
     "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),
     "adder_raw_eof": (_sz, [_vp]),
+    # include/adder_compressed.h
+    "adder_compressed_default_params": (None, [C.POINTER(AdderCompressedParams), _u16, _u16, _u8]),
+    "adder_compressed_encoder_create": (_i32, [C.POINTER(AdderCompressedParams), C.POINTER(_vp)]),
+    "adder_compressed_encoder_destroy": (None, [_vp]),
+    "adder_compressed_last_error": (C.c_char_p, [_vp]),
+    "adder_compressed_encoder_ingest": (_i32, [_vp, _vp, _sz]),
+    "adder_compressed_encoder_close": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "adder_compressed_encoder_progress": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_sz)]),
+    "adder_compressed_decode": (_i32, [_vp, _sz, _i32, C.POINTER(AdderCompressedParams), _vp, _sz, C.POINTER(_sz)]),
     # include/adder_framer.h
     "adder_framer_default_params": (None, [C.POINTER(AdderFramerParams), _u16, _u16, _u8]),
     "adder_framer_create": (_i32, [C.POINTER(AdderFramerParams), C.POINTER(_vp)]),
