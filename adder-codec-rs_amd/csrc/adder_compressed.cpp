@@ -13,7 +13,7 @@
 //     event_adu.rs:95); the unused 65 536-symbol default context (context_switching.rs:20-33) is not built;
 //   * finished ADUs are compressed on a small pool of worker threads and appended to the stream in ADU order
 //     (the reference spawns one thread per ADU and reorders through a priority queue, stream.rs:78-104).
-// Byte-identical to oracle/compressed_oracle.py (tests/test_compressed_product.py).
+// Checked byte for byte against the test suite's literal restatement of the reference (tests/test_compressed_product.py).
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>

@@ -1,6 +1,8 @@
 // adder_host.cpp -- see adder_host.hpp.  Reference file:line citations are in the header.
 #include "adder_host.hpp"
 
+#include "../../include/adder_compressed.h"
+
 #include <chrono>
 
 #include <string.h>
@@ -59,6 +61,38 @@ Encoder Encoder::new_raw(CodecMetadata meta, std::ostream *writer, EncoderOption
     return e;
 }
 
+Encoder Encoder::new_compressed(CodecMetadata meta, std::ostream *writer, EncoderOptions options) {
+    if (!writer) throw CodecError(CodecError::Io, "compressed encoder needs a writer");
+    meta.event_size = meta.plane.c() == 1 ? 9 : 11;  // EventStreamHeader::new (header.rs:75-81)
+    Encoder e(meta, writer, options, EncoderType::Compressed);
+    AdderCompressedParams p;
+    adder_compressed_default_params(&p, meta.plane.w(), meta.plane.h(), meta.plane.c());
+    p.codec_version = meta.codec_version;
+    p.time_mode = (uint8_t)meta.time_mode;
+    p.tps = meta.tps;
+    p.ref_interval = meta.ref_interval;
+    p.delta_t_max = meta.delta_t_max;
+    p.adu_interval = (uint32_t)meta.adu_interval;
+    p.source_camera = (uint32_t)meta.source_camera;
+    p.c_thresh_max = options.crf.get_parameters().c_thresh_max;  // CompressedOutput::with_options (stream.rs:169-171)
+    if (adder_compressed_encoder_create(&p, &e.compressed_) != ADDER_OK)
+        throw CodecError(CodecError::BadFile, std::string("compressed encoder: ") + adder_compressed_last_error(nullptr));
+    e.meta_.header_size = 25 + 4 * (size_t)std::min<int>(meta.codec_version, 3);
+    return e;
+}
+
+Encoder::~Encoder() {
+    if (compressed_) adder_compressed_encoder_destroy(compressed_);
+}
+
+Encoder::Encoder(Encoder &&o) noexcept
+    : options(o.options), clock(std::move(o.clock)), meta_(o.meta_), writer_(o.writer_), type_(o.type_),
+      scratch_(std::move(o.scratch_)), current_event_rate_(o.current_event_rate_), last_event_ts_(o.last_event_ts_),
+      queue_(std::move(o.queue_)), compressed_(o.compressed_) {
+    o.compressed_ = nullptr;
+    o.writer_ = nullptr;
+}
+
 Encoder Encoder::new_empty(CodecMetadata meta, EncoderOptions options) {
     Encoder e(meta, nullptr, options, EncoderType::Empty);
     e.encode_header();
@@ -77,6 +111,11 @@ void Encoder::encode_header() {
 }
 
 void Encoder::output_events(const Event *events, size_t n) {
+    if (compressed_) {  // CompressedOutput::ingest_event (compressed/stream.rs:268-319)
+        if (adder_compressed_encoder_ingest(compressed_, events, n) != ADDER_OK)
+            throw CodecError(CodecError::Io, std::string("compressed encoder: ") + adder_compressed_last_error(compressed_));
+        return;
+    }
     if (!writer_ || n == 0) return;  // EmptyOutput swallows events
     scratch_.resize(n * 11);
     const size_t bytes = adder_raw_events(scratch_.data(), events, n, meta_.plane.c());
@@ -174,6 +213,19 @@ void Encoder::ingest_events_events(const std::vector<std::vector<Event>> &v) {
 }
 
 std::ostream *Encoder::close_writer() {
+    if (compressed_) {  // CompressedOutput::into_writer (compressed/stream.rs:179-262): the partial last ADU, no EOF event
+        const uint8_t *bytes = nullptr;
+        size_t n = 0;
+        if (adder_compressed_encoder_close(compressed_, &bytes, &n) != ADDER_OK)
+            throw CodecError(CodecError::Io, std::string("compressed encoder: ") + adder_compressed_last_error(compressed_));
+        writer_->write(reinterpret_cast<const char *>(bytes), (std::streamsize)n);
+        writer_->flush();
+        adder_compressed_encoder_destroy(compressed_);
+        compressed_ = nullptr;
+        std::ostream *w = writer_;
+        writer_ = nullptr;
+        return w;
+    }
     if (!writer_) return nullptr;  // EmptyOutput::into_writer -> None
     uint8_t eof[16];
     const size_t n = adder_raw_eof(eof);
@@ -293,9 +345,6 @@ Video &Video::time_parameters(uint32_t tps, uint32_t ref_time, uint32_t delta_t_
 Video &Video::write_out(std::optional<SourceCamera> source_camera, std::optional<TimeMode> time_mode,
                         std::optional<PixelMultiMode> pixel_multi_mode, std::optional<size_t> adu_interval,
                         EncoderType encoder_type, EncoderOptions encoder_options, std::ostream *write) {
-    if (encoder_type == EncoderType::Compressed)  // video.rs:586-593 when the feature is off
-        throw SourceError(SourceError::BadParams,
-                          "Compressed representation is experimental and is not enabled by default!");
     if (ctx_ && pixel_multi_mode.value_or(PixelMultiMode::Collapse) != multi_mode_)
         throw SourceError(SourceError::BadParams, "pixel_multi_mode cannot change after the first frame");
     multi_mode_ = pixel_multi_mode.value_or(PixelMultiMode::Collapse);
@@ -309,10 +358,13 @@ Video &Video::write_out(std::optional<SourceCamera> source_camera, std::optional
     meta.delta_t_max = delta_t_max_;
     meta.event_size = 0;
     meta.source_camera = source_camera.value_or(SourceCamera::FramedU8);
-    meta.adu_interval = 0;  // Default::default() for Raw / Empty (:612, :630)
-    (void)adu_interval;
-    encoder_.reset(new Encoder(encoder_type == EncoderType::Raw ? Encoder::new_raw(meta, write, encoder_options)
-                                                               : Encoder::new_empty(meta, encoder_options)));
+    // Default::default() for Raw / Empty (:612, :630); adu_interval.unwrap_or_default() for Compressed (:573)
+    meta.adu_interval = encoder_type == EncoderType::Compressed ? adu_interval.value_or(0) : 0;
+    if (encoder_type == EncoderType::Compressed)  // video.rs:556-579 (the reference's "compression" feature)
+        encoder_.reset(new Encoder(Encoder::new_compressed(meta, write, encoder_options)));
+    else
+        encoder_.reset(new Encoder(encoder_type == EncoderType::Raw ? Encoder::new_raw(meta, write, encoder_options)
+                                                                   : Encoder::new_empty(meta, encoder_options)));
     if (time_mode) {  // px.time_mode(time_mode) (:632-634)
         px_time_mode_ = *time_mode;
         if (ctx_) hip_check(ctx_, adder_hip_set_time_mode(ctx_, (uint8_t)*time_mode));

@@ -26,6 +26,8 @@
 #include "../../include/adder_framer.h"
 #include "../../include/adder_hip.h"
 
+struct AdderCompressedEncoder;  // include/adder_compressed.h
+
 namespace adder_host {
 
 // ---------------------------------------------------------------- errors (video.rs:55-122, codec/mod.rs:209-256)
@@ -121,6 +123,13 @@ class Encoder {  // encoder.rs:29-37
   public:
     static Encoder new_raw(CodecMetadata meta, std::ostream *writer, EncoderOptions options);  // :94-108
     static Encoder new_empty(CodecMetadata meta, EncoderOptions options);                      // :57-72
+    // :74-92 + CompressedOutput::new (compressed/stream.rs:126-166): the CPU compressed sink of libadder_hip.so
+    // (include/adder_compressed.h); the stream is written to `writer` when the writer is closed
+    static Encoder new_compressed(CodecMetadata meta, std::ostream *writer, EncoderOptions options);
+    ~Encoder();
+    Encoder(Encoder &&o) noexcept;
+    Encoder &operator=(Encoder &&) = delete;
+    Encoder(const Encoder &) = delete;
     const CodecMetadata &meta() const { return meta_; }
     void ingest_event(const Event &e);                                   // :233-273
     void ingest_events(const Event *events, size_t n);                   // :281-286
@@ -146,6 +155,7 @@ class Encoder {  // encoder.rs:29-37
     double current_event_rate_ = 0.0;
     double last_event_ts_ = 0.0;
     std::vector<Event> queue_;  // BinaryHeap<Event>: `Ord for Event` is reversed on t (lib.rs:424-436) => min-heap on t
+    ::AdderCompressedEncoder *compressed_ = nullptr;  // EncoderType::Compressed
 };
 
 // ---------------------------------------------------------------- reader: Decoder over RawInput

@@ -20,11 +20,13 @@ const char *adder_host_last_error() { return g_err.c_str(); }
 // Framed(gray) over `frames` ([T][h][w][channels_in] u8), builder calls in the order of the
 // reference's transcode test: crf -> (auto_)time_parameters -> write_out(raw, options) -> consume()
 // x T -> end_write_stream.  Returns the number of events, or -1.
-long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
-                                   uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
-                                   uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
-                                   uint32_t chunk_rows, int encoder_crf /* <0: EncoderOptions::default */,
-                                   const char *out_path, uint32_t *num_chunks_out) {
+// encoder_type: 0 = Compressed (adu_interval reference intervals per ADU), 1 = Raw
+long long adder_host_transcode(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
+                               uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
+                               uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
+                               uint32_t chunk_rows, int encoder_crf /* <0: EncoderOptions::default */,
+                               int encoder_type, uint32_t adu_interval, const char *out_path,
+                               uint32_t *num_chunks_out) {
     try {
         FrameProvider cap;
         cap.width = width;
@@ -47,8 +49,9 @@ long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, u
         const PlaneSize plane = source.get_video_ref().plane();
         EncoderOptions opts = EncoderOptions::default_(plane);
         if (encoder_crf >= 0) opts.crf = Crf((uint8_t)encoder_crf, plane);
-        source.write_out(SourceCamera::FramedU8, (TimeMode)time_mode, (PixelMultiMode)multi_mode, std::nullopt,
-                         EncoderType::Raw, opts, &file);
+        source.write_out(SourceCamera::FramedU8, (TimeMode)time_mode, (PixelMultiMode)multi_mode,
+                         encoder_type == 0 ? std::optional<size_t>(adu_interval) : std::nullopt,
+                         encoder_type == 0 ? EncoderType::Compressed : EncoderType::Raw, opts, &file);
         long long total = 0;
         uint32_t chunks = 0;
         for (uint32_t k = 0; k < num_frames; ++k) {
@@ -63,6 +66,16 @@ long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, u
         g_err = e.what();
         return -1;
     }
+}
+
+long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
+                                   uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
+                                   uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
+                                   uint32_t chunk_rows, int encoder_crf /* <0: EncoderOptions::default */,
+                                   const char *out_path, uint32_t *num_chunks_out) {
+    return adder_host_transcode(frames, num_frames, width, height, channels_in, color_input, fps, crf, ref_time,
+                                delta_t_max, time_mode, multi_mode, chunk_rows, encoder_crf, 1, 0, out_path,
+                                num_chunks_out);
 }
 
 // The reference's `dark` test end to end (src/bin/adder_simulproc.rs:170-268): Framed(gray) ->

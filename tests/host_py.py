@@ -21,6 +21,10 @@ def lib():
         L.adder_host_transcode_raw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                                C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                                C.c_uint32, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
+        L.adder_host_transcode.restype = C.c_longlong
+        L.adder_host_transcode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                           C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                           C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
         L.adder_host_decode_raw.restype = C.c_longlong
         L.adder_host_decode_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.adder_host_crf_parameters.restype = C.c_int
@@ -95,6 +99,20 @@ def transcode_raw(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, 
     if n < 0:
         raise RuntimeError(err())
     return n, chunks.value
+
+
+def transcode_compressed(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, delta_t_max=7650, time_mode=1,
+                         multi_mode=1, chunk_rows=1, encoder_crf=-1, adu_interval=30, out_path=None):
+    """Framed -> Video (GPU) -> Encoder::new_compressed -> file; returns the number of events ingested."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    T, H, W, Cin = frames.shape
+    chunks = C.c_uint32(0)
+    n = lib().adder_host_transcode(frames.ctypes.data, T, W, H, Cin, int(color_input), fps, crf, ref_time,
+                                   delta_t_max, time_mode, multi_mode, chunk_rows, encoder_crf, 0, adu_interval,
+                                   out_path.encode(), C.byref(chunks))
+    if n < 0:
+        raise RuntimeError(err())
+    return n
 
 
 def simulproc(frames, *, fps, crf, ref_time, delta_t_max, time_mode, multi_mode, chunk_rows=1, frame_count_max=0,

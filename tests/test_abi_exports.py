@@ -13,11 +13,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("adder_hip.h", "adder_framer.h"):
+    for h in ("adder_hip.h", "adder_framer.h", "adder_compressed.h"):
         hdr = open(os.path.join(ROOT, "include", h)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-        names |= set(re.findall(r"\b(adder_(?:hip|raw|framer)_\w+)\s*\(", hdr))
+        names |= set(re.findall(r"\b(adder_(?:hip|raw|framer|compressed)_\w+)\s*\(", hdr))
     return sorted(names)
+
+
+def test_gather_library_exports_every_declared_symbol():
+    """include/adder_gather.h <-> libadder_rccl.so (the multi-GPU gather a Rust host binds)."""
+    import ctypes
+    import adder_amd
+    from adder_amd import gather
+    hdr = open(os.path.join(ROOT, "include", "adder_gather.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(adder_gather_\w+)\s*\(", hdr))
+    assert len(names) >= 7 and names == set(gather.SYMBOLS)
+    adder_amd.load()
+    L = ctypes.CDLL(gather.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
 
 
 def test_library_exports_every_declared_symbol():

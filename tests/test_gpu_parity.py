@@ -666,3 +666,49 @@ print("ok")
                 {"ADDER_HIP_CHUNK": "4", "ADDER_HIP_FRAMES_PER_LAUNCH": "4"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_baseline_config_5_end_to_end_compressed_sink_4k_rgb():
+    """configs[4] end to end on one GPU at full plane size: 3840x2160 RGB, crf-3 numbers, AbsoluteT, Collapse,
+    delta_t_max 7650 -> events (HIP) -> adu_interval 30 compressed sink (CPU, include/adder_compressed.h) ->
+    decode: every ADU decodes, per pixel the d sequences survive and t stays within the lossy tolerance.
+    (Bit-exactness of the events is test_baseline_config_5_shape_4k_rgb_lossy; of the sink's bytes,
+    tests/test_compressed_product.py.)"""
+    import torch
+    A = _hip()
+    T = 36
+    clip = O.synth_clip(O.CONTENT_SCENE, 3840, 2160, 3, T)
+    hv = A.HipVideo(3840, 2160, 3, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=7650)
+    hv.update_crf(3)
+    d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_ev = torch.empty((int(d_frames.numel() * 0.2) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
+    n = hv.finish()
+    ev = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    enc = A.CompressedEncoder(3840, 2160, 3, tps=7650, ref_interval=255, delta_t_max=7650, adu_interval=30,
+                              time_mode=A.TIME_ABSOLUTE_T, c_thresh_max=7, threads=16)
+    offs = d_off.cpu().numpy()
+    for k in range(T):  # per frame, as Video::integrate_matrix hands its events to the encoder
+        enc.ingest(ev[int(offs[k]):int(offs[k + 1])])
+    blob = enc.close()
+    enc.destroy()
+    assert blob[:5] == b"addec" and len(blob) < n * 11 * 0.8
+    dec, p = A.compressed_decode(blob)
+    assert (p.width, p.height, p.channels) == (3840, 2160, 3) and 0.95 * n < len(dec) <= n
+    # a sample of pixels: same d sequence, t within one reference interval
+    key_in = (ev["y"].astype(np.int64) * 3840 + ev["x"]) * 3 + ev["c"]
+    key_out = (dec["y"].astype(np.int64) * 3840 + dec["x"]) * 3 + dec["c"]
+    oi, oo = np.argsort(key_in, kind="stable"), np.argsort(key_out, kind="stable")
+    ki, ko = key_in[oi], key_out[oo]
+    rng = np.random.default_rng(3)
+    checked = 0
+    for px in rng.choice(np.unique(ki), 3000, replace=False):
+        a = ev[oi[np.searchsorted(ki, px, "left"):np.searchsorted(ki, px, "right")]]
+        b = dec[oo[np.searchsorted(ko, px, "left"):np.searchsorted(ko, px, "right")]]
+        if len(a) != len(b):
+            continue  # the cube's drop rule removed an event of this pixel
+        assert np.array_equal(a["d"], b["d"])
+        assert np.all(np.abs(a["t"].astype(np.int64) - b["t"].astype(np.int64)) <= 255 * 8)
+        checked += 1
+    assert checked > 2500

@@ -97,3 +97,32 @@ def test_framed_color_to_gray_and_errors(tmp_path):
     assert n == len(want) and np.array_equal(ev, want)
     with pytest.raises(RuntimeError, match="multiple of ref_time"):
         Hst.transcode_raw(frames, crf=0, ref_time=255, delta_t_max=600, out_path=out)
+
+
+@pytest.mark.gpu
+def test_framed_transcode_to_compressed_sink_config5_mode(tmp_path):
+    """BASELINE configs[4]'s mode end to end through the C++ mirror on a small RGB plane: Framed (color) .crf(3)
+    .auto_time_parameters(255, 7650) .write_out(FramedU8, AbsoluteT, Collapse, adu_interval = 30, Compressed) ->
+    consume() per frame (GPU integration) -> Encoder::new_compressed (CPU sink).  The file must equal what the
+    oracle's compressed restatement makes of the raw transcode's events, and decode back to them within the
+    codec's tolerance."""
+    import adder_amd as A
+    import clips
+    from oracle import compressed_oracle as CO
+    T, H, W = 75, 36, 52
+    frames = clips.make_clip("jitter", T, H, W, 3, seed=31)
+    raw_path, cmp_path = str(tmp_path / "a.adder"), str(tmp_path / "a.addec")
+    kw = dict(color_input=True, fps=30.0, crf=3, ref_time=255, delta_t_max=7650, time_mode=1, multi_mode=1)
+    n_raw, _ = Hst.transcode_raw(frames, out_path=raw_path, **kw)
+    n_cmp = Hst.transcode_compressed(frames, adu_interval=30, out_path=cmp_path, **kw)
+    assert n_raw == n_cmp > 0
+    meta, ev = Hst.decode_raw(open(raw_path, "rb").read())
+    blob = open(cmp_path, "rb").read()
+    assert blob[:5] == b"addec" and len(blob) < n_raw * 11
+    co = CO.CompressedOutput(W, H, 3, tps=7650, ref_interval=255, delta_t_max=7650, adu_interval=30, time_mode=1,
+                             c_thresh_max=7)
+    for e in ev:
+        co.ingest_event(int(e["x"]), int(e["y"]), int(e["c"]), int(e["d"]), int(e["t"]))
+    assert blob == co.close()
+    dec, p = A.compressed_decode(blob)
+    assert (p.width, p.height, p.channels, p.adu_interval) == (W, H, 3, 30) and 0 < len(dec) <= len(ev)
