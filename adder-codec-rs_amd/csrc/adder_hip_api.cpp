@@ -42,6 +42,19 @@ struct AdderHipCtx {
     uint8_t *dv_bd = nullptr;
     uint8_t *running = nullptr;
     bool running_enabled = false;
+    // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
+    // case: an overflow then rolls the state back and the caller retries with the size reported
+    struct Snapshot {
+        uint32_t *hdr = nullptr;
+        float *integ0 = nullptr, *dt0 = nullptr, *bdt0 = nullptr, *lastf = nullptr;
+        float *dv_integ = nullptr, *dv_dt = nullptr, *dv_bdt = nullptr;
+        uint8_t *dv_bd = nullptr;
+        bool valid = false, deep = false;
+        float running_t = 0.0f;
+        uint8_t c_thresh = 0, c_counter = 0;
+        uint64_t frames_done = 0;
+        bool generic_sticky = false;
+    } snap;
     // c_thresh / c_increase_counter: identical in every pixel (adder_pixel.hpp header comment)
     uint8_t c_thresh = 10, c_counter = 1;
     // a generic batch has run since create / reset: pixels may hold more than one fired level, which only
@@ -166,6 +179,10 @@ static void free_ctx(AdderHipCtx *c) {
         if (sl.wired) (void)hipEventDestroy(sl.wired);
     }
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
+    for (void *p : {(void *)c->snap.hdr, (void *)c->snap.integ0, (void *)c->snap.dt0, (void *)c->snap.bdt0,
+                    (void *)c->snap.lastf, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
+                    (void *)c->snap.dv_bd})
+        if (p) (void)hipFree(p);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
@@ -422,8 +439,16 @@ extern "C" int adder_hip_set_time_mode(AdderHipCtx *c, uint8_t time_mode) {
 
 extern "C" uint32_t adder_hip_num_chunks(const AdderHipCtx *c) { return c ? c->num_chunks : 0; }
 
+// The most events one frame can emit: the lean step at most 3 per unit (root event, Collapse filler, pop_top's
+// event); the generic step its whole arena (<= max_depth levels) plus pop_top's event.
+static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
+    return !c->generic_sticky && c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned;
+}
+static size_t worst_case_events_per_frame(const AdderHipCtx *c, float time_spanned) {
+    return (size_t)c->n_units * (lean_possible(c, time_spanned) ? 3u : c->max_depth + 1u);
+}
 extern "C" size_t adder_hip_max_events_per_frame(const AdderHipCtx *c) {
-    return c ? (size_t)c->n_units * (c->max_depth + 2) : 0;
+    return c ? worst_case_events_per_frame(c, (float)c->p.ref_time) : 0;
 }
 
 static int status_to_code(AdderHipCtx *c, uint32_t st) {
@@ -560,6 +585,63 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     return ADDER_OK;
 }
 
+// ---- undo copy of the state (see AdderHipCtx::Snapshot) ----
+template <class T>
+static hipError_t snap_copy(T **dst, const T *src, size_t count, hipStream_t s) {
+    if (!*dst) {
+        hipError_t e = dalloc(dst, count);
+        if (e != hipSuccess) return e;
+    }
+    return hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyDeviceToDevice, s);
+}
+static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
+    AdderHipCtx::Snapshot &n = c->snap;
+    HIPCHK(c, snap_copy(&n.hdr, c->hdr, c->n_pad, s));
+    HIPCHK(c, snap_copy(&n.integ0, c->integ0, c->n_pad, s));
+    HIPCHK(c, snap_copy(&n.dt0, c->dt0, c->n_pad, s));
+    HIPCHK(c, snap_copy(&n.bdt0, c->bdt0, c->n_pad, s));
+    HIPCHK(c, snap_copy(&n.lastf, c->lastf, c->n_pad, s));
+    n.deep = deep && c->dv_integ;
+    if (n.deep) {
+        const size_t cnt = c->n_pad * (std::max<uint32_t>(c->max_depth, 2u) - 1u);
+        HIPCHK(c, snap_copy(&n.dv_integ, c->dv_integ, cnt, s));
+        HIPCHK(c, snap_copy(&n.dv_dt, c->dv_dt, cnt, s));
+        HIPCHK(c, snap_copy(&n.dv_bdt, c->dv_bdt, cnt, s));
+        HIPCHK(c, snap_copy(&n.dv_bd, c->dv_bd, cnt, s));
+    }
+    n.running_t = c->running_t;
+    n.c_thresh = c->c_thresh;
+    n.c_counter = c->c_counter;
+    n.frames_done = c->frames_done;
+    n.generic_sticky = c->generic_sticky;
+    n.valid = true;
+    return ADDER_OK;
+}
+static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
+    AdderHipCtx::Snapshot &n = c->snap;
+    HIPCHK(c, hipMemcpyAsync(c->hdr, n.hdr, c->n_pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->integ0, n.integ0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->dt0, n.dt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->bdt0, n.bdt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->lastf, n.lastf, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (n.deep) {
+        const size_t cnt = c->n_pad * (std::max<uint32_t>(c->max_depth, 2u) - 1u);
+        HIPCHK(c, hipMemcpyAsync(c->dv_integ, n.dv_integ, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->dv_dt, n.dv_dt, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->dv_bdt, n.dv_bdt, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->dv_bd, n.dv_bd, cnt, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->running_t = n.running_t;
+    c->c_thresh = n.c_thresh;
+    c->c_counter = n.c_counter;
+    c->frames_done = n.frames_done;
+    c->generic_sticky = n.generic_sticky;
+    n.valid = false;
+    return ADDER_OK;
+}
+
 // Queues `num_frames` frames on `stream`.
 static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
                           AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
@@ -569,6 +651,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // the lean step's "time_spanned >= delta_t_max" folding does not describe), so the choice is sticky
     // until adder_hip_reset: update_quality_manual can lower delta_t_max mid-stream (video.rs:1264-1287).
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
+    const bool sticky_before = c->generic_sticky;
     const bool generic = c->generic_sticky || !(collapse && (float)c->p.delta_t_max <= time_spanned);
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u);
@@ -578,6 +661,17 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         if (rc_ == ADDER_OK) rc_ = alloc_deep_planes(c);
         if (rc_ != ADDER_OK) return rc_;
         c->generic_sticky = true;
+    }
+    // an event buffer below the batch's worst case can overflow: keep an undo copy of the state so that the
+    // overflow is recoverable (adder_hip_finish rolls back and reports the size needed)
+    c->snap.valid = false;
+    {
+        const size_t per_frame = (size_t)c->n_units * (generic ? c->max_depth + 1u : 3u);
+        if (out_cap < per_frame * num_frames) {
+            int rc_ = take_snapshot(c, generic, stream);
+            if (rc_ != ADDER_OK) return rc_;
+            c->snap.generic_sticky = sticky_before;
+        }
     }
     if (c->running_enabled && !c->running) {
         HIPCHK(c, dalloc(&c->running, c->n_pad));
@@ -736,6 +830,17 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
         c->last_post_avg_us = (float)(sum * 1000.0 / c->timed_posts);
     }
     if (n_out) *n_out = (size_t)total;
+    if (st == kStatusCapacity && c->snap.valid) {
+        // the event buffer was too small: nothing else went wrong, and the state before the batch is at hand
+        int rc = restore_snapshot(c, c->pending_stream);
+        if (rc != ADDER_OK) {
+            c->poisoned = true;
+            return rc;
+        }
+        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: the batch needs %llu events (state rolled back, "
+                    "retry with a larger buffer)", (unsigned long long)total);
+    }
+    c->snap.valid = false;
     return status_to_code(c, st);
 }
 
@@ -832,11 +937,7 @@ static int batch_to_device(AdderHipCtx *c, const uint8_t *frames, uint32_t num_f
                                     c->stream);
     if (rc != ADDER_OK) return rc;
     rc = adder_hip_finish(c, total);
-    if (rc != ADDER_OK) return rc;
-    if (*total > out_cap) {  // defensive; the kernel reports this through the status word
-        c->poisoned = true;
-        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: need %zu", *total);
-    }
+    if (rc != ADDER_OK) return rc;  // ADDER_E_OUT_CAPACITY: rolled back, *total = the size needed
     return ADDER_OK;
 }
 

@@ -441,11 +441,16 @@ std::vector<std::vector<Event>> Video::integrate_matrix(const Frame &matrix, flo
     // in_interval_count starts at 1 (video.rs:231), so set_initial_d (:656-658) is never taken here
     in_interval_count_ += 1;
     const uint32_t num_chunks = adder_hip_num_chunks(ctx_);
-    buf_.resize(std::max<size_t>(buf_.size(), std::min<size_t>(adder_hip_max_events_per_frame(ctx_), 4 * plane_.volume() + 64)));
+    buf_.resize(std::max<size_t>(buf_.size(), std::min<size_t>(adder_hip_max_events_per_frame(ctx_), plane_.volume() + 64)));
     std::vector<uint32_t> offs(num_chunks + 1);
     size_t n = 0;
     int rc = adder_hip_integrate(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned, buf_.data(),
                                  buf_.size(), &n, offs.data());
+    if (rc == ADDER_E_OUT_CAPACITY) {  // recoverable: the state was rolled back, n = the events this frame emits
+        buf_.resize(n);
+        rc = adder_hip_integrate(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned, buf_.data(),
+                                 buf_.size(), &n, offs.data());
+    }
     hip_check(ctx_, rc);
     std::vector<std::vector<Event>> big_buffer(num_chunks);
     for (uint32_t ch = 0; ch < num_chunks; ++ch)
@@ -458,11 +463,17 @@ std::vector<Event> Video::integrate_frames(const uint8_t *frames, uint32_t num_f
                                            std::vector<uint64_t> *frame_offsets) {
     ensure_ctx();
     in_interval_count_ += num_frames;
-    std::vector<Event> out(std::min<size_t>(adder_hip_max_events_per_frame(ctx_), 2 * plane_.volume() + 64) * num_frames);
+    // start from a typical event density; a batch that needs more (a scene cut flushes every pixel's arena)
+    // comes back with ADDER_E_OUT_CAPACITY, the state rolled back and the size needed in n: retry with that
+    std::vector<Event> out(std::min<size_t>(adder_hip_max_events_per_frame(ctx_), plane_.volume() + 64) * num_frames);
     std::vector<uint64_t> offs(num_frames + 1);
     size_t n = 0;
-    hip_check(ctx_, adder_hip_integrate_batch(ctx_, frames, num_frames, 0, 0, time_spanned, out.data(), out.size(), &n,
-                                              offs.data()));
+    int rc = adder_hip_integrate_batch(ctx_, frames, num_frames, 0, 0, time_spanned, out.data(), out.size(), &n, offs.data());
+    if (rc == ADDER_E_OUT_CAPACITY) {
+        out.resize(n);
+        rc = adder_hip_integrate_batch(ctx_, frames, num_frames, 0, 0, time_spanned, out.data(), out.size(), &n, offs.data());
+    }
+    hip_check(ctx_, rc);
     out.resize(n);
     encoder_->ingest_events(out.data(), n);
     if (frame_offsets) *frame_offsets = offs;

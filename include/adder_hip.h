@@ -121,6 +121,12 @@ size_t adder_hip_max_events_per_frame(const AdderHipCtx *ctx);
 void *adder_hip_alloc_pinned(size_t bytes);
 void adder_hip_free_pinned(void *p);
 
+/* Event-buffer capacity.  Every integrate entry point takes the capacity of the caller's event buffer.  If a
+ * batch emits more, the call (or adder_hip_finish for the device-pointer form) returns ADDER_E_OUT_CAPACITY with
+ * the number of events the batch needs in *n_out, and the pixel state is ROLLED BACK to what it was before the
+ * call: retry with a buffer of that size.  (A buffer of adder_hip_max_events_per_frame() x frames can never
+ * overflow and costs no undo copy.) */
+
 /* --- one frame: the region video.rs:677-734 -------------------------------------
  * frame_hwc: host pointer to this band's rows, [rows][width][channels] u8 with
  * row_stride_bytes between rows.  Events come back in the reference's order

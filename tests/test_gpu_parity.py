@@ -211,7 +211,8 @@ def test_errors_are_loud():
         A.HipVideo(16, 16, 2)  # channels must be 1 or 3
     with pytest.raises(A.AdderHipError):
         A.HipVideo(16, 16, 1, delta_t_max=100)  # dtm < ref_time
-    # capacity overflow is reported with the required size, and poisons the context
+    # capacity overflow is reported with the required size and is RECOVERABLE: the pixel state is rolled back,
+    # the caller retries with a larger buffer (test_capacity_overflow_rolls_back_and_retry_matches)
     clip = clips.make_clip("noise", 3, 16, 16, 1, seed=1)
     hv = A.HipVideo(16, 16, 1, time_mode=A.TIME_DELTA_T, delta_t_max=255)
     hv.update_crf(0)
@@ -219,9 +220,7 @@ def test_errors_are_loud():
     with pytest.raises(A.AdderHipError) as ei:
         hv.integrate_matrix(clip[1], out_cap=10)
     assert ei.value.code == -4 and hv.last_required > 10
-    with pytest.raises(A.AdderHipError) as ei:
-        hv.integrate_matrix(clip[2])
-    assert ei.value.code == -7
+    hv.integrate_matrix(clip[1])
     # arena depth overflow
     clip = clips.make_clip("static", 100, 4, 4, 1, seed=1)
     hv = A.HipVideo(4, 4, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_NORMAL, delta_t_max=255, max_depth=3)
@@ -229,6 +228,37 @@ def test_errors_are_loud():
     with pytest.raises(A.AdderHipError) as ei:
         hv.integrate_batch(clip)
     assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("multi_mode,dtm", [(O.COLLAPSE, 255), (O.COLLAPSE, 7650), (O.NORMAL, 1020)])
+def test_capacity_overflow_rolls_back_and_retry_matches(multi_mode, dtm):
+    """An event buffer that is too small does not kill the stream: the call fails with ADDER_E_OUT_CAPACITY and
+    the size needed, the pixel state (all levels, c_thresh, running_t) is what it was before the call, and the
+    retry produces exactly the oracle's events -- per-frame calls and batches, lean and generic kernels."""
+    A = _hip()
+    clip = clips.make_clip("runs", 40, 20, 33, 1, seed=7)
+    clip[25] = 255 - clip[24]  # a scene cut: every pixel flushes its whole arena (> 2 events per pixel)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov = O.Video(33, 20, 1, time_mode=tm, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(33, 20, 1, time_mode=tm, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm)
+        ov.ensure_capacity(22)
+        for v in (ov, hv):
+            v.set_crf_parameters(3, 4)
+            v.reset_c_thresh(1)
+        want = [ov.integrate_matrix(f) for f in clip]
+        got, offs = hv.integrate_batch(clip[:20])
+        assert np.array_equal(got, np.concatenate(want[:20]))
+        for k in range(20, 30):  # per-frame calls with a hopeless buffer first
+            with pytest.raises(A.AdderHipError) as ei:
+                hv.integrate_matrix(clip[k], out_cap=max(len(want[k]) // 2, 1) if len(want[k]) > 1 else 0)
+            assert ei.value.code == A.E_OUT_CAPACITY and hv.last_required == len(want[k]), k
+            assert np.array_equal(hv.integrate_matrix(clip[k], out_cap=hv.last_required), want[k]), k
+        need = sum(len(w) for w in want[30:])
+        with pytest.raises(A.AdderHipError) as ei:  # a batch
+            hv.integrate_batch(clip[30:], out_cap=need - 1)
+        assert ei.value.code == A.E_OUT_CAPACITY and hv.last_required == need
+        got, offs = hv.integrate_batch(clip[30:], out_cap=need)
+        assert np.array_equal(got, np.concatenate(want[30:]))
 
 
 def test_synth_clip_matches_oracle_generator():

@@ -35,22 +35,22 @@ def main():
         print(f"{kernel},{cname},{n},{s / n:.1f}")
     if "--traffic" in sys.argv:
         out = sys.argv[sys.argv.index("--traffic") + 1]
-        fk = [k for (k, c) in acc if "adder_frame_kernel" in k and c == "FETCH_SIZE"]
-        if fk:
-            k = fk[0]
+        res = {"source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of an eager bench.py run "
+                         "(tools/profile_round.sh), averaged per kernel launch",
+               "correction": "FETCH_SIZE doubled (gfx950 counts wide coalesced reads at 1/2, MI355X_MICROARCH.md HBM "
+                             "section); WRITE_SIZE as reported; both are KiB",
+               "kernels": {}}
+        for (k, c) in sorted(acc):
+            if c != "FETCH_SIZE":
+                continue
             fetch = acc[(k, "FETCH_SIZE")][1] / acc[(k, "FETCH_SIZE")][0]
-            write = acc[(k, "WRITE_SIZE")][1] / max(acc[(k, "WRITE_SIZE")][0], 1)
-            json.dump({
-                "kernel": k,
-                "source": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
-                          "`ADDER_HIP_NO_GRAPH=1 bench.py --steps 1 --warmup 0 --frames 160 --no-cpu-baseline --skip-roofline` "
-                          "(1920x1080 gray scene clip), averaged over the frame-kernel launches",
-                "fetch_size_kib_per_launch": round(fetch, 1),
-                "write_size_kib_per_launch": round(write, 1),
-                "correction": "FETCH_SIZE doubled (gfx950 counts wide coalesced reads at 1/2, "
-                              "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both KiB",
-                "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-            }, open(out, "w"), indent=2)
+            w = acc.get((k, "WRITE_SIZE"), [1, 0.0])
+            write = w[1] / max(w[0], 1)
+            res["kernels"][k] = {"launches": acc[(k, "FETCH_SIZE")][0],
+                                 "fetch_size_kib_per_launch": round(fetch, 1),
+                                 "write_size_kib_per_launch": round(write, 1),
+                                 "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
+        json.dump(res, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":

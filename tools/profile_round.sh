@@ -1,11 +1,13 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r01
+#   tools/profile_round.sh r02
 # 1. kernel trace + stats of the default bench command,
-# 2. separate --pmc passes (never combined with other trace domains) of a 64-frame eager run,
+# 2. the same bench without its per-launch timing passes (every frame-kernel launch is a default-depth one),
+# 3. separate --pmc passes (never combined with other trace domains) of a 160-frame eager run at the default
+#    temporal depth, and of a 96-frame run with ONE frame per launch (the adder_lean1_kernel rows),
 # then writes summaries under gpurun_out/profiles_<round>/ (copy them into profiles/).
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p "$OUT"
@@ -17,21 +19,26 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_kernel_stats.csv" \;
 find "$OUT/stats" -name '*domain_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_domain_stats.csv" \;
 
-# the same bench without its per-launch timing passes: every frame-kernel launch is a default-depth one,
-# so the average duration here is directly comparable with bench.py's roofline.launch_avg_us
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o bench -- \
-    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
 find "$OUT/stats2" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_default_depth_kernel_stats.csv" \;
 
-PMC_CMD="python $REPO/bench.py --steps 1 --warmup 0 --frames 160 --no-cpu-baseline --skip-roofline"
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" \
-           "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
-    tag=$(echo "$set" | tr ' ' '_' | cut -c1-40)
-    ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_$tag" -o pmc -- \
-        $PMC_CMD > "$OUT/pmc_$tag.log" 2>&1
-done
-python "$REPO/tools/pmc_csv_summary.py" "$OUT" > "$OUT/${ROUND}_pmc_summary.csv"
-python "$REPO/tools/pmc_csv_summary.py" "$OUT" --traffic "$OUT/traffic_latest.json" > /dev/null
-# drop the bulky raw traces, keep logs + summaries
-rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/pmc_*/
+pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
+    local tag=$1 envs=$2; shift; shift
+    local cmd="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --skip-roofline $*"
+    mkdir -p "$OUT/$tag"
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES" \
+               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+               "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+        local st=$(echo "$set" | tr ' ' '_' | cut -c1-40)
+        env $envs ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$tag/pmc_$st" -o pmc -- \
+            $cmd > "$OUT/$tag/pmc_$st.log" 2>&1
+    done
+    python "$REPO/tools/pmc_csv_summary.py" "$OUT/$tag" --traffic "$OUT/${ROUND}_traffic_$tag.json" > "$OUT/${ROUND}_pmc_$tag.csv"
+    rm -rf "$OUT/$tag"/pmc_*/
+}
+pmc_passes default "A=1" --frames 160
+pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96
+pmc_passes generic_dtm7650_abs "A=1" --frames 60 --delta-t-max 7650 --time-mode absolute_t
+rm -rf "$OUT"/stats "$OUT"/stats2
 ls -la "$OUT"
