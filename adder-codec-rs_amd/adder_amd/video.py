@@ -25,7 +25,7 @@ class HipVideo:
     def __init__(self, width, height, channels=1, *, row_begin=0, row_end=None,
                  time_mode=N.TIME_ABSOLUTE_T, multi_mode=N.MULTI_COLLAPSE, ref_time=255,
                  delta_t_max=7650, chunk_rows=1, max_depth=16, device_id=-1,
-                 c_thresh_start=None, c_counter_start=None):
+                 c_thresh_start=None, c_counter_start=None, pixel_mode=0):
         self.L = N.load()
         p = N.AdderHipParams()
         self.L.adder_hip_default_params(C.byref(p), width, height, channels)
@@ -34,6 +34,7 @@ class HipVideo:
         p.time_mode, p.multi_mode = time_mode, multi_mode
         p.ref_time, p.delta_t_max = ref_time, delta_t_max
         p.chunk_rows, p.max_depth, p.device_id = chunk_rows, max_depth, device_id
+        p.pixel_mode = pixel_mode  # 0 = Mode::FramePerfect, 1 = Mode::Continuous
         if c_thresh_start is not None:
             p.c_thresh_start = c_thresh_start
         if c_counter_start is not None:

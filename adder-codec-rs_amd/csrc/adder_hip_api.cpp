@@ -40,6 +40,10 @@ struct AdderHipCtx {
     float *lastf = nullptr;
     float *dv_integ = nullptr, *dv_dt = nullptr, *dv_bdt = nullptr;
     uint8_t *dv_bd = nullptr;
+    // Mode::Continuous contexts: node planes of the general arena ([max_depth + 1][n_pad]); hdr holds the arena header
+    bool continuous = false;
+    float *cn_integ = nullptr, *cn_dt = nullptr, *cn_bdt = nullptr;
+    uint32_t *cn_meta = nullptr;
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
@@ -49,6 +53,8 @@ struct AdderHipCtx {
         float *integ0 = nullptr, *dt0 = nullptr, *bdt0 = nullptr, *lastf = nullptr;
         float *dv_integ = nullptr, *dv_dt = nullptr, *dv_bdt = nullptr;
         uint8_t *dv_bd = nullptr;
+        float *cn_integ = nullptr, *cn_dt = nullptr, *cn_bdt = nullptr;
+        uint32_t *cn_meta = nullptr;
         bool valid = false, deep = false;
         float running_t = 0.0f;
         uint8_t c_thresh = 0, c_counter = 0;
@@ -165,7 +171,8 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->hdr,     c->integ0,  c->dt0,      c->bdt0,   c->lastf,  c->dv_integ, c->dv_dt,
-                    c->dv_bdt,  c->dv_bd,   c->running,  c->status,
+                    c->dv_bdt,  c->dv_bd,   c->running,  c->status, c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
+                    c->snap.cn_integ, c->snap.cn_dt, c->snap.cn_bdt, c->snap.cn_meta,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -250,6 +257,12 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->dv_dt = c->dv_dt;
     a->dv_bdt = c->dv_bdt;
     a->dv_bd = c->dv_bd;
+    a->cn_integ = c->cn_integ;
+    a->cn_dt = c->cn_dt;
+    a->cn_bdt = c->cn_bdt;
+    a->cn_meta = c->cn_meta;
+    a->max_nodes = c->max_depth + 1u;
+    a->stage_events = c->max_depth + 3u;
     a->running = c->running_enabled ? c->running : nullptr;
     a->plane_stride = c->n_pad;
     a->status = c->status;
@@ -267,7 +280,17 @@ static int init_state(AdderHipCtx *c) {
     const AdderHipParams &p = c->p;
     // header word 0 = base_val 0, no fired level, not popped.  The level planes are only read where
     // the header says they are live (or are selected away: lean step), so they need no clearing.
-    HIPCHK(c, hipMemsetAsync(c->hdr, 0, c->n_pad * sizeof(uint32_t), c->stream));
+    if (c->continuous) {
+        // PixelArena::new(1.0): one node {d: 0, integration 0, delta_t 0, no best event}, length 1
+        const size_t cnt = c->n_pad * (c->max_depth + 1u);
+        HIPCHK(c, adder_launch_fill_u32(c->hdr, c->n_pad, apx_hdr(APx{0u, 1u, false, 0.0f}), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cn_integ, 0, cnt * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cn_dt, 0, cnt * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cn_bdt, 0, cnt * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cn_meta, 0, cnt * sizeof(uint32_t), c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->hdr, 0, c->n_pad * sizeof(uint32_t), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
     if (c->running) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
@@ -297,8 +320,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "invalid plane %ux%ux%u", p.width, p.height, p.channels);
     if (p.channels != 1 && p.channels != 3)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "channels must be 1 or 3 (got %u)", p.channels);
-    if (p.pixel_mode != ADDER_MODE_FRAME_PERFECT)
-        return fail(nullptr, ADDER_E_BAD_PARAMS, "only Mode::FramePerfect is implemented on this path");
+    if (p.pixel_mode != ADDER_MODE_FRAME_PERFECT && p.pixel_mode != ADDER_MODE_CONTINUOUS)
+        return fail(nullptr, ADDER_E_BAD_PARAMS, "bad pixel_mode");
     if (p.time_mode > ADDER_TIME_MIXED || p.multi_mode > ADDER_MULTI_COLLAPSE)
         return fail(nullptr, ADDER_E_BAD_PARAMS, "bad time_mode / multi_mode");
     if (p.row_begin == 0 && p.row_end == 0) p.row_end = p.height;
@@ -365,7 +388,16 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->dt0, c->n_pad));
         HIPCHK(c, dalloc(&c->bdt0, c->n_pad));
         HIPCHK(c, dalloc(&c->lastf, c->n_pad));
-        { int rc_ = alloc_scratch(c, kLeanParkBytes); if (rc_ != ADDER_OK) return rc_; }
+        c->continuous = p.pixel_mode == ADDER_MODE_CONTINUOUS;
+        if (c->continuous) {
+            const size_t cnt = c->n_pad * (c->max_depth + 1u);
+            HIPCHK(c, dalloc(&c->cn_integ, cnt));
+            HIPCHK(c, dalloc(&c->cn_dt, cnt));
+            HIPCHK(c, dalloc(&c->cn_bdt, cnt));
+            HIPCHK(c, dalloc(&c->cn_meta, cnt));
+        }
+        { int rc_ = alloc_scratch(c, c->continuous ? kWaveUnits + kWaveUnits * (c->max_depth + 3u) * kGenRecBytes
+                                                   : kLeanParkBytes); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, dalloc(&c->d_batch, 1));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
@@ -445,6 +477,7 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
     return !c->generic_sticky && c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned;
 }
 static size_t worst_case_events_per_frame(const AdderHipCtx *c, float time_spanned) {
+    if (c->continuous) return (size_t)c->n_units * (c->max_depth + 3u);
     return (size_t)c->n_units * (lean_possible(c, time_spanned) ? 3u : c->max_depth + 1u);
 }
 extern "C" size_t adder_hip_max_events_per_frame(const AdderHipCtx *c) {
@@ -601,6 +634,13 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
     HIPCHK(c, snap_copy(&n.dt0, c->dt0, c->n_pad, s));
     HIPCHK(c, snap_copy(&n.bdt0, c->bdt0, c->n_pad, s));
     HIPCHK(c, snap_copy(&n.lastf, c->lastf, c->n_pad, s));
+    if (c->continuous) {
+        const size_t cnt = c->n_pad * (c->max_depth + 1u);
+        HIPCHK(c, snap_copy(&n.cn_integ, c->cn_integ, cnt, s));
+        HIPCHK(c, snap_copy(&n.cn_dt, c->cn_dt, cnt, s));
+        HIPCHK(c, snap_copy(&n.cn_bdt, c->cn_bdt, cnt, s));
+        HIPCHK(c, snap_copy(&n.cn_meta, c->cn_meta, cnt, s));
+    }
     n.deep = deep && c->dv_integ;
     if (n.deep) {
         const size_t cnt = c->n_pad * (std::max<uint32_t>(c->max_depth, 2u) - 1u);
@@ -624,6 +664,13 @@ static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
     HIPCHK(c, hipMemcpyAsync(c->dt0, n.dt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->bdt0, n.bdt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->lastf, n.lastf, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c->continuous) {
+        const size_t cnt = c->n_pad * (c->max_depth + 1u);
+        HIPCHK(c, hipMemcpyAsync(c->cn_integ, n.cn_integ, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->cn_dt, n.cn_dt, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->cn_bdt, n.cn_bdt, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->cn_meta, n.cn_meta, cnt * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
     if (n.deep) {
         const size_t cnt = c->n_pad * (std::max<uint32_t>(c->max_depth, 2u) - 1u);
         HIPCHK(c, hipMemcpyAsync(c->dv_integ, n.dv_integ, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -652,9 +699,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // until adder_hip_reset: update_quality_manual can lower delta_t_max mid-stream (video.rs:1264-1287).
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
     const bool sticky_before = c->generic_sticky;
-    const bool generic = c->generic_sticky || !(collapse && (float)c->p.delta_t_max <= time_spanned);
+    const bool generic = !c->continuous && (c->generic_sticky || !(collapse && (float)c->p.delta_t_max <= time_spanned));
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
-                             (generic ? 4u : 0u);
+                             (generic ? 4u : 0u) | (c->continuous ? 8u : 0u);
     if (generic) {
         // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
         int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2) * kGenRecBytes);
@@ -666,7 +713,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // overflow is recoverable (adder_hip_finish rolls back and reports the size needed)
     c->snap.valid = false;
     {
-        const size_t per_frame = (size_t)c->n_units * (generic ? c->max_depth + 1u : 3u);
+        const size_t per_frame = (size_t)c->n_units * (c->continuous ? c->max_depth + 3u : generic ? c->max_depth + 1u : 3u);
         if (out_cap < per_frame * num_frames) {
             int rc_ = take_snapshot(c, generic, stream);
             if (rc_ != ADDER_OK) return rc_;
@@ -705,7 +752,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.out = reinterpret_cast<AdderEventPod *>(d_out);
     b.base.out_cap = out_cap;
     b.base.frame_offsets = d_offsets;
-    b.base.lean = generic ? 0u : 1u;
+    b.base.lean = (generic || c->continuous) ? 0u : 1u;
     b.base.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
     b.base.sc = make_consts(c, time_spanned);
     b.frames = d_frames;

@@ -64,6 +64,11 @@ struct FrameArgs {
     float *dv_dt;
     float *dv_bdt;
     uint8_t *dv_bd;     // best_d (d = fired_d(best_d))
+    // Mode::Continuous contexts: the general arena, node k of a unit at [k][unit] (hdr then holds the arena header)
+    float *cn_integ, *cn_dt, *cn_bdt;
+    uint32_t *cn_meta;  // d | best_d << 8 | has_best << 16
+    uint32_t max_nodes; // max_depth + 1
+    uint32_t stage_events;  // staged records per unit (max_depth + 3), see adder_cont_kernel
     uint8_t *running;   // optional running_intensities side plane, or nullptr
     size_t plane_stride;  // n_pad
     // this frame
@@ -122,7 +127,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 }  // namespace adder
 
 extern "C" {
-// variant = collapse | abs_t << 1 | generic << 2 (host copy of what BatchArgs holds)
+// variant = collapse | abs_t << 1 | generic << 2 | continuous << 3 (host copy of what BatchArgs holds)
 // K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking); the same grid also
 // expands frames [exp_f0, exp_f0 + exp_nf) of an earlier, already scanned chunk (exp_nf may be 0)
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,

@@ -584,6 +584,85 @@ __global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const Bat
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, Mode::Continuous: the general arena step (adder_pixel.hpp cont_step), a unit's nodes
+// straight from / to the node planes.  A first, correct version -- the sources that use this mode are sparse
+// event cameras; nothing here is tuned.  A unit's events cannot be counted before they are produced, so they
+// are STAGED: 8-byte {t, d} records at a fixed slot range per unit plus a per-unit count; the expansion
+// (format 2) orders them.  Segment scratch: [kWaveUnits] u8 counts, then [kWaveUnits][stage_events] records.
+// ------------------------------------------------------------------------------------------
+struct ContGlobal {
+    float *integ, *dt, *bdt;
+    uint32_t *meta;
+    size_t stride, u;
+    __device__ __forceinline__ ANode load(uint32_t k) const {
+        const size_t i = (size_t)k * stride + u;
+        ANode n;
+        n.integ = integ[i];
+        n.dt = dt[i];
+        n.bdt = bdt[i];
+        anode_set_meta(n, meta[i]);
+        return n;
+    }
+    __device__ __forceinline__ void store(uint32_t k, const ANode &n) const {
+        const size_t i = (size_t)k * stride + u;
+        integ[i] = n.integ;
+        dt[i] = n.dt;
+        bdt[i] = n.bdt;
+        meta[i] = anode_meta(n);
+    }
+};
+struct EmitStage {
+    uint2 *dst;
+    uint32_t n, cap;
+    __device__ __forceinline__ void operator()(uint32_t d, uint32_t t) {
+        if (n < cap) dst[n] = make_uint2(t, d);
+        ++n;
+    }
+};
+
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchArgs *__restrict__ b, uint32_t f0,
+                                                                   uint32_t nb) {
+    constexpr uint32_t N = kUnitsPerLane;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;
+    const uint32_t u0 = gw * kWaveUnits + lane * N;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const FrameArgs a = frame_args(b, f0 + i);
+        uint8_t *const seg = a.park + (size_t)gw * b->park_bytes;
+        uint32_t lane_cnt = 0;
+        bool bad = false;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t u = u0 + j;
+            uint32_t cnt = 0;
+            if (u < a.n_units) {
+                APx s = apx_unpack(a.hdr[u], a.lastf[u]);
+                ContGlobal acc{a.cn_integ, a.cn_dt, a.cn_bdt, a.cn_meta, a.plane_stride, u};
+                EmitStage em{reinterpret_cast<uint2 *>(seg + kWaveUnits) + (size_t)(lane * N + j) * a.stage_events, 0u,
+                             a.stage_events};
+                const uint32_t v = a.frame[u];
+                const bool ok = cont_step<ABS_T>(s, acc, v, (float)v, a.sc.time_spanned, a.sc, a.max_nodes, em);
+                bad = bad || !ok || em.n > em.cap;
+                cnt = em.n < em.cap ? em.n : em.cap;
+                a.hdr[u] = apx_hdr(s);
+                a.lastf[u] = s.lastf;
+                if (a.running) {  // side plane (video.rs:713-730): the root's best event, if it has one
+                    const ANode r = acc.load(0);
+                    if (r.has_best) a.running[u] = (uint8_t)frame_value_u8(r.bd, f32_as_u32(r.bdt), (double)a.sc.ref_time);
+                }
+            }
+            seg[lane * N + j] = (uint8_t)cnt;
+            lane_cnt += cnt;
+        }
+        const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
+        if (lane == kWave - 1) a.wtot[gw] = incl | 0xffff0000u;  // records: staged (the expansion reads the counts)
+        if (bad) raise(a.status, kStatusDepth);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Scan: exclusive prefix of the per-segment event counts of one frame per block
 // (blockIdx.x = frame inside the chunk) and the frame's total.
 // ------------------------------------------------------------------------------------------
@@ -730,8 +809,11 @@ __device__ __forceinline__ void stage_lean(uint32_t *xb, uint32_t w, const LeanE
 }
 
 // One workgroup's share of a frame's expansion: 4 waves x kExpandSegs segments.
-template <bool LEAN, bool ABS_T>
+// FORMAT of the parked records: 0 = generic (8 bytes per event with its final offset), 1 = lean (one 16-byte
+// LeanRec per unit), 2 = staged (Mode::Continuous: per-unit counts + 8-byte {t, d} records at fixed slots)
+template <int FORMAT, bool ABS_T>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
+    constexpr bool LEAN = FORMAT == 1;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
     // only the frame-independent part of the arguments is needed here
@@ -776,7 +858,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             if (hl < (half ? pb : pa))
                 first[p] = gload<uint4>(park + (size_t)(2 * p) * park_bytes, half * park_bytes + hl * kLeanRecBytes);
         }
-    } else {
+    } else if (FORMAT == 0) {
 #pragma unroll
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
             const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
@@ -858,6 +940,42 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 }
             }
         }
+    } else if (FORMAT == 2) {
+        // staged: a lane owns kUnitsPerLane units of the segment; a DPP scan of its event counts places them.
+        // Written straight to the stream (no LDS staging: this mode is not tuned).
+        const uint32_t stage_events = __builtin_amdgcn_readfirstlane(b->base.stage_events);
+#pragma unroll 1
+        for (uint32_t q = 0; q < kExpandSegs; ++q) {
+            const uint32_t seg_events = __builtin_amdgcn_readlane(my_tot, q) & 0xffffu;
+            const uint8_t *const seg_park = park + (size_t)q * park_bytes;
+            if (seg_events != 0u) {
+                uint32_t cnt[kUnitsPerLane], lane_cnt = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kUnitsPerLane; ++j) {
+                    cnt[j] = gload<uint8_t>(seg_park, lane * kUnitsPerLane + j);
+                    lane_cnt += cnt[j];
+                }
+                uint32_t pos = wave_inclusive_scan_dpp(lane_cnt) - lane_cnt;
+                const uint64_t room64 = gpos < out_cap ? out_cap - gpos : 0ull;
+                EventWords *const seg_out = reinterpret_cast<EventWords *>(out_dw) + gpos;
+#pragma unroll
+                for (uint32_t j = 0; j < kUnitsPerLane; ++j) {
+                    uint32_t c;
+                    const uint32_t xy = coord_xy_c(uc, lane * kUnitsPerLane + j, c);
+                    for (uint32_t e = 0; e < cnt[j]; ++e, ++pos) {
+                        const uint2 r = gload<uint2>(seg_park, kWaveUnits + ((lane * kUnitsPerLane + j) * stage_events + e) * 8u);
+                        if ((uint64_t)pos < room64) {
+                            EventWords w{xy, c | ((r.y & 0xffu) << 8), r.x};
+                            gstore(seg_out, pos * (uint32_t)sizeof(EventWords), w);
+                        } else {
+                            dropped = true;
+                        }
+                    }
+                }
+                gpos += seg_events;
+            }
+            next_segment();
+        }
     } else {
 #pragma unroll
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
@@ -896,10 +1014,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     if (dropped) raise(b->base.status, kStatusCapacity);
 }
 
-// variant: bit 0 = lean records, bit 1 = AbsoluteT (lean decoding)
-template <bool LEAN, bool ABS_T>
+template <int FORMAT, bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
-    expand_block<LEAN, ABS_T>(b, f0 + blockIdx.y, blockIdx.x);
+    expand_block<FORMAT, ABS_T>(b, f0 + blockIdx.y, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1126,6 +1243,11 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
                                          uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
+    if (variant & 8u) {  // Mode::Continuous
+        if (abs_t) hipLaunchKernelGGL((adder_cont_kernel<true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_cont_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+        return hipGetLastError();
+    }
     if (generic) {  // never fused with an expansion (adder_hip_api.cpp fuse_for)
         if (exp_nf != 0u) return hipErrorInvalidValue;
         if (collapse) {
@@ -1172,10 +1294,11 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
                                           uint32_t variant, hipStream_t stream) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const dim3 grid((num_waves + per_block - 1) / per_block, nf);
-    const bool abs_t = variant & 2u, generic = variant & 4u;
-    if (generic) hipLaunchKernelGGL((adder_expand_kernel<false, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
-    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<true, true>), grid, dim3(kBlockThreads), 0, stream, b, f0);
-    else hipLaunchKernelGGL((adder_expand_kernel<true, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u;
+    if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
     return hipGetLastError();
 }
 

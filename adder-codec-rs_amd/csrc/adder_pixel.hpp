@@ -599,6 +599,241 @@ ADDER_HD void gen_pop(PxState &s, const GenPlan &p, Deep &deep) {
     s.popped = true;
 }
 
+// ---------------------------------------------------------------------------------------
+// GENERAL ARENA STEP -- Mode::Continuous (the mode of the event-camera sources,
+// prophesee.rs:65, davis.rs:116-117, and of Video::integrate_matrix when they feed it frames).
+// There a firing node hands the REST of the intensity and time to its child, which keeps integrating it
+// (event_pixel_tree.rs:340-385, 468-471), so the tail is no longer pristine, a flush can meet nodes that
+// hold time but no intensity (zero events, :96-111, :225-230), pop_best is followed by
+// set_d_for_continuous (:289-312) and pop_top can meet a root without a best event (:156-197).  None of
+// the FramePerfect reductions above hold: this step keeps the reference's node as it is
+// {d, integration, delta_t, best_event} and walks the arena through an accessor
+// (acc.load(k) -> ANode, acc.store(k, ANode)), emitting through emit(d, t).
+// tests/cpu_sim runs it against the literal oracle; the reference's 13 PixelArena unit tests pin the oracle.
+// ---------------------------------------------------------------------------------------
+struct ANode {
+    float integ, dt, bdt;
+    uint32_t d, bd;
+    bool has_best;
+};
+// node meta word in HBM: d | best_d << 8 | has_best << 16
+ADDER_HD uint32_t anode_meta(const ANode &n) { return n.d | (n.bd << 8) | (n.has_best ? 1u << 16 : 0u); }
+ADDER_HD void anode_set_meta(ANode &n, uint32_t w) {
+    n.d = w & 0xffu;
+    n.bd = (w >> 8) & 0xffu;
+    n.has_best = ((w >> 16) & 1u) != 0u;
+}
+ADDER_HD ANode anode_new(float intensity) {  // PixelNode::new (:501-514)
+    ANode n;
+    n.integ = 0.0f;
+    n.dt = 0.0f;
+    n.bdt = 0.0f;
+    n.d = get_d(intensity);
+    n.bd = 0u;
+    n.has_best = false;
+    return n;
+}
+// arena header word in HBM (continuous contexts): base_val | length << 8 | popped_dtm << 16
+struct APx {
+    uint32_t base, length;
+    bool popped;
+    float lastf;
+};
+ADDER_HD uint32_t apx_hdr(const APx &s) { return s.base | (s.length << 8) | (s.popped ? 1u << 16 : 0u); }
+ADDER_HD APx apx_unpack(uint32_t hdr, float lastf) {
+    APx s;
+    s.base = hdr & 0xffu;
+    s.length = (hdr >> 8) & 0xffu;
+    s.popped = ((hdr >> 16) & 1u) != 0u;
+    s.lastf = lastf;
+    return s;
+}
+
+// delta_t_to_absolute_t with Mode::Continuous (:113-137): no rounding of last_fired_t
+template <bool ABS_T>
+ADDER_HD uint32_t cont_event_time(float ev_dt, float &lastf) {
+    if (ABS_T) {
+        ev_dt = fadd(ev_dt, lastf);
+        lastf = ev_dt;
+    }
+    return f32_as_u32(ev_dt);
+}
+
+// integrate_main (:418-479), Mode::Continuous.  Returns true if the node fired; the remainder for the child
+// is left in (next_i, next_t).
+ADDER_HD bool cont_integrate_main(ANode &n, float intensity, float time, float &next_i, float &next_t) {
+    const float s = fadd(n.integ, intensity);
+    if (s >= pow2_d(n.d)) {
+        const uint32_t nd = get_d(s);
+        float prop = fdiv(fsub(pow2_d(nd), n.integ), intensity);
+        if (nd == kDZero || n.d == kDZero || intensity < 1.1920929e-7f) prop = 1.0f;
+        n.d = nd;
+        n.has_best = true;
+        n.bd = nd;
+        n.bdt = fadd(n.dt, fmul(time, prop));
+        if (nd < kDMax) {
+            n.integ = s;
+            n.dt = fadd(n.dt, time);
+            // loop { d += 1; if D_SHIFT[d] > integration as u128 { break } } (:454-460); D_SHIFT[128] = 0
+            uint32_t d = nd;
+            const float tr = (float)(uint64_t)n.integ;  // trunc for the values reachable here (< 2^63)
+            for (;;) {
+                d += 1u;
+                if (d >= 128u || pow2_d(d) > tr) break;
+            }
+            n.d = d > 128u ? 128u : d;
+        }
+        const float rest = fsub(intensity, fmul(intensity, prop));
+        if (rest >= 0.0f) {
+            next_i = rest;
+            next_t = fsub(time, fmul(time, prop));
+        } else {
+            next_i = 0.0f;
+            next_t = 0.0f;
+        }
+        return true;
+    }
+    n.integ = s;
+    n.dt = fadd(n.dt, time);
+    return false;
+}
+
+// integrate_for_px (video.rs:1318-1380) with pixel_tree_mode = Continuous.  `max_nodes` = nodes the arena may
+// hold; returns false if it needed more.
+template <bool ABS_T, class Acc, class Emit>
+ADDER_HD bool cont_step(APx &s, Acc &acc, uint32_t v, float intensity, float time, const StepConsts &sc,
+                        uint32_t max_nodes, Emit &emit) {
+    bool ok = true;
+    // ---- pop_best_events (:213-287) + set_d_for_continuous (:289-312) ----
+    if (contrast_exceeded(v, s.base, sc.cth)) {
+        const bool collapsed = s.popped && sc.collapse;
+        uint32_t count = 0, first_d = 0, first_t = 0;
+        for (uint32_t k = 0; k < s.length; ++k) {
+            ANode n = acc.load(k);
+            uint32_t ed;
+            float edt;
+            if (n.has_best) {
+                ed = n.bd;
+                edt = n.bdt;
+            } else if (n.dt > 0.0f && n.integ == 0.0f) {  // get_zero_event(idx, None) (:96-111)
+                ed = kDZero;
+                edt = n.dt;
+                n.dt = 0.0f;
+                acc.store(k, n);
+            } else {
+                continue;
+            }
+            const uint32_t t = cont_event_time<ABS_T>(edt, s.lastf);
+            if (collapsed) {
+                if (count == 0u) {
+                    first_d = ed;
+                    first_t = t;
+                }
+            } else {
+                emit(ed, t);
+            }
+            count += 1u;
+        }
+        if (collapsed && count != 0u) {
+            emit(first_d, first_t);
+            s.lastf = sc.running_t;
+            emit(kDEmpty, f32_as_u32(sc.running_t));
+            acc.store(0, anode_new(intensity));
+        } else {
+            const ANode a = acc.load(0), z = acc.load(s.length - 1u);  // swap(arena[0], arena[length - 1])
+            acc.store(0, z);
+            acc.store(s.length - 1u, a);
+        }
+        s.length = 1u;
+        s.popped = false;
+        s.base = v;
+        ANode r = acc.load(0);
+        const uint32_t next_d = get_d(intensity);
+        if (next_d < r.d && r.dt > 0.0f) {
+            emit(kDEmpty, cont_event_time<ABS_T>(r.dt, s.lastf));
+            r.dt = 0.0f;
+            r.integ = 0.0f;
+        }
+        r.d = next_d;
+        acc.store(0, r);
+    }
+    // ---- integrate (:317-413) ----
+    {
+        ANode tail = acc.load(s.length - 1u);
+        if (tail.dt == 0.0f && tail.integ == 0.0f) {
+            tail.d = get_d(intensity);
+            acc.store(s.length - 1u, tail);
+        }
+    }
+    {
+        float I = intensity, T = time;
+        uint32_t idx = 0;
+        for (uint32_t count = 0; count < 31u; ++count) {
+            ANode n = acc.load(idx);
+            float next_i = 0.0f, next_t = 0.0f;
+            const bool filled = cont_integrate_main(n, I, T, next_i, next_t);
+            acc.store(idx, n);
+            if (filled) {
+                if (idx + 1u >= max_nodes) {
+                    ok = false;
+                    break;
+                }
+                acc.store(idx + 1u, anode_new(I));
+                s.length = idx + 2u;
+                I = next_i;
+                T = next_t;
+            }
+            idx += 1u;
+            if (s.popped && sc.collapse) break;
+            if (filled) {
+                if (T > (float)sc.ref_time) {
+                    ANode c = acc.load(idx);
+                    c.d = get_d(I);
+                    acc.store(idx, c);
+                }
+                if (I == 0.0f) break;
+            }
+            if (idx >= s.length) break;
+        }
+    }
+    // ---- pop_top_event (:139-210) ----
+    ANode root = acc.load(0);
+    if (root.d == kDMax || (root.dt >= sc.dtm_f && !s.popped)) {
+        bool shifted = true;
+        uint32_t ed;
+        float edt;
+        if (!root.has_best) {
+            if (root.integ == 0.0f && root.dt > 0.0f) {  // get_zero_event(0, Some(next_intensity))
+                ed = kDZero;
+                edt = root.dt;
+                root.dt = 0.0f;
+                root.d = get_d(intensity);
+                acc.store(0, root);
+                shifted = false;
+            } else {  // synthesise the root's event, start a fresh node behind it
+                root.has_best = true;
+                root.bd = root.integ < 1.0f ? kDZero : get_d(root.integ);
+                root.bdt = root.dt;
+                if (max_nodes < 2u) ok = false;
+                acc.store(1, anode_new(intensity));
+                s.length = 2u;
+                ed = root.bd;
+                edt = root.bdt;
+            }
+        } else {
+            ed = root.bd;
+            edt = root.bdt;
+        }
+        if (shifted) {
+            for (uint32_t i = 0; i + 1u < s.length; ++i) acc.store(i, acc.load(i + 1u));
+            s.length -= 1u;
+        }
+        s.popped = true;
+        emit(ed, cont_event_time<ABS_T>(edt, s.lastf));
+    }
+    return ok;
+}
+
 // u8::get_frame_value for the running_intensities side plane (video.rs:713-730,
 // framer/scale_intensity.rs:58-72,262-270): ((2^d / t) * ref_time) as u8 in f64.
 ADDER_HD uint32_t frame_value_u8(uint32_t d, uint32_t t, double tpf) {

@@ -301,7 +301,8 @@ static void hip_check(AdderHipCtx *ctx, int rc) {
                       std::string("adder_hip: ") + (m ? m : "") + " (" + std::to_string(rc) + ")");
 }
 
-Video::Video(PlaneSize plane, std::ostream *writer, int device_id) : plane_(plane), device_id_(device_id) {
+Video::Video(PlaneSize plane, std::ostream *writer, int device_id, Mode pixel_tree_mode)
+    : plane_(plane), device_id_(device_id), pixel_tree_mode_(pixel_tree_mode) {
     CodecMetadata meta;  // video.rs:391-402
     meta.codec_version = LATEST_CODEC_VERSION;
     meta.header_size = 0;
@@ -423,6 +424,7 @@ void Video::ensure_ctx() {
     p.c_increase_velocity = encoder_->options.crf.get_parameters().c_increase_velocity;
     p.chunk_rows = (uint32_t)chunk_rows_;
     p.device_id = device_id_;
+    p.pixel_mode = (uint8_t)pixel_tree_mode_;
     const int rc = adder_hip_create(&p, &ctx_);
     if (rc != ADDER_OK) {
         ctx_ = nullptr;

@@ -47,6 +47,7 @@ enum class SourceCamera : uint32_t {                                      // lib
     FramedU8 = 0, FramedU16, FramedU32, FramedU64, FramedF32, FramedF64, Dvs, DavisU8, Atis, Asint
 };
 enum class EncoderType { Compressed, Raw, Empty };  // codec/mod.rs
+enum class Mode { FramePerfect = 0, Continuous = 1 };  // lib.rs:196-205
 constexpr uint8_t LATEST_CODEC_VERSION = 3;         // codec/mod.rs:74
 
 struct PlaneSize {  // lib.rs:86-178
@@ -175,7 +176,10 @@ class Decoder {  // decoder.rs:22-29
 // ---------------------------------------------------------------- Video (video.rs:322-346)
 class Video {
   public:
-    Video(PlaneSize plane, std::ostream *writer /* may be null: EmptyOutput */, int device_id = -1);  // ::new :350-438
+    // ::new :350-438 -- Video::new(plane, pixel_tree_mode, writer): framed sources pass Mode::FramePerfect
+    // (framed.rs:67), the event-camera sources Mode::Continuous (prophesee.rs:65)
+    Video(PlaneSize plane, std::ostream *writer /* may be null: EmptyOutput */, int device_id = -1,
+          Mode pixel_tree_mode = Mode::FramePerfect);
     ~Video();
     Video(const Video &) = delete;
     Video &operator=(const Video &) = delete;
@@ -211,6 +215,7 @@ class Video {
     void ensure_ctx();  // (re)creates the device context once every builder call has been made
     PlaneSize plane_;
     int device_id_;
+    Mode pixel_tree_mode_ = Mode::FramePerfect;
     uint32_t tps_ = 7650, ref_time_ = 255, delta_t_max_ = 7650;  // VideoState/VideoStateParams::default
     size_t chunk_rows_ = 1;
     PixelMultiMode multi_mode_ = PixelMultiMode::Collapse;

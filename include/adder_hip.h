@@ -31,7 +31,9 @@ extern "C" {
 /* adder-codec-core/src/lib.rs:72-83 (TimeMode), :196-213 (Mode, PixelMultiMode) */
 enum { ADDER_TIME_DELTA_T = 0, ADDER_TIME_ABSOLUTE_T = 1, ADDER_TIME_MIXED = 2 };
 enum { ADDER_MULTI_NORMAL = 0, ADDER_MULTI_COLLAPSE = 1 };
-enum { ADDER_MODE_FRAME_PERFECT = 0 }; /* framed sources always use FramePerfect: framed.rs:67 */
+/* Mode (lib.rs:196-205): framed sources always use FramePerfect (framed.rs:67); Continuous is the mode of the
+ * event-camera sources (prophesee.rs:65, davis.rs:116-117) and of Video::integrate_matrix when they feed it frames */
+enum { ADDER_MODE_FRAME_PERFECT = 0, ADDER_MODE_CONTINUOUS = 1 };
 
 /* adder-codec-core/src/lib.rs:181-193 */
 #define ADDER_D_MAX 127
@@ -73,7 +75,7 @@ typedef struct AdderHipParams {
     uint8_t channels;      /* 1 (c = None) or 3 */
     uint8_t time_mode;     /* ADDER_TIME_* ; pixels default to AbsoluteT (event_pixel_tree.rs:76) */
     uint8_t multi_mode;    /* ADDER_MULTI_* ; write_out defaults to Collapse (video.rs:598) */
-    uint8_t pixel_mode;    /* ADDER_MODE_FRAME_PERFECT only */
+    uint8_t pixel_mode;    /* ADDER_MODE_FRAME_PERFECT or ADDER_MODE_CONTINUOUS (a first, untuned kernel) */
     uint32_t row_begin;    /* this context integrates rows [row_begin,row_end) of the plane */
     uint32_t row_end;      /*   (0,0 => the whole plane); events carry absolute y          */
     uint32_t ref_time;     /* ticks per input frame (VideoStateParams::ref_time)            */

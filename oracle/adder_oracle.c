@@ -642,6 +642,8 @@ void oracle_video_set_time_mode(OracleVideo *v, int time_mode) {
     size_t n = (size_t)v->width * v->height * v->channels;
     for (size_t i = 0; i < n; i++) v->px[i].time_mode = (uint8_t)time_mode;
 }
+/* Video::new(plane, pixel_tree_mode, ..) (video.rs:350-438): 0 = FramePerfect (every framed source), 1 = Continuous */
+void oracle_video_set_pixel_mode(OracleVideo *v, int mode) { v->sp.pixel_tree_mode = mode; }
 void oracle_video_set_threads(OracleVideo *v, int threads) { v->threads = threads > 0 ? threads : 1; }
 const uint8_t *oracle_video_running_intensities(const OracleVideo *v) { return v->running_intensities; }
 

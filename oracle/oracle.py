@@ -84,6 +84,7 @@ def lib():
     L.oracle_video_set_delta_t_max.argtypes = [vp, u32]
     L.oracle_video_set_time_mode.argtypes = [vp, i32]
     L.oracle_video_set_threads.argtypes = [vp, i32]
+    L.oracle_video_set_pixel_mode.argtypes = [vp, i32]
     L.oracle_video_running_intensities.restype = vp
     L.oracle_video_running_intensities.argtypes = [vp]
     L.oracle_video_integrate_matrix.restype = sz
@@ -236,6 +237,10 @@ class Video:
 
     def set_threads(self, n):
         self.L.oracle_video_set_threads(self.h, n)
+
+    def set_pixel_mode(self, mode):
+        """0 = Mode::FramePerfect (default), 1 = Mode::Continuous (lib.rs:196-205)."""
+        self.L.oracle_video_set_pixel_mode(self.h, mode)
 
     def running_intensities(self):
         p = self.L.oracle_video_running_intensities(self.h)

@@ -41,6 +41,9 @@ struct Sim {
     uint32_t max_m;
     int use_fast;
     int generic_sticky;  // a generic batch has run since the last reset: lean batches are no longer allowed
+    int continuous;      // Mode::Continuous: the general arena step (cont_step), its own state planes
+    std::vector<uint32_t> c_hdr, c_meta;           // [unit], [node][unit]
+    std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
     uint64_t fast_steps, generic_steps, lean_steps;
 };
 
@@ -60,6 +63,27 @@ struct DeepAcc {
         s->lv_dt[i] = n.dt;
         s->lv_bdt[i] = n.bdt;
         s->lv_bd[i] = (uint8_t)n.bd;
+    }
+};
+
+struct ContAcc {
+    Sim *s;
+    size_t u;
+    ANode load(uint32_t k) const {
+        const size_t i = (size_t)k * s->N + u;
+        ANode n;
+        n.integ = s->c_integ[i];
+        n.dt = s->c_dt[i];
+        n.bdt = s->c_bdt[i];
+        anode_set_meta(n, s->c_meta[i]);
+        return n;
+    }
+    void store(uint32_t k, const ANode &n) const {
+        const size_t i = (size_t)k * s->N + u;
+        s->c_integ[i] = n.integ;
+        s->c_dt[i] = n.dt;
+        s->c_bdt[i] = n.bdt;
+        s->c_meta[i] = anode_meta(n);
     }
 };
 
@@ -105,10 +129,21 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->max_m = 0;
     s->use_fast = 1;
     s->generic_sticky = 0;
+    s->continuous = 0;
     s->fast_steps = s->generic_steps = s->lean_steps = 0;
     return s;
 }
 void sim_free(Sim *s) { delete s; }
+// Video::new(plane, Mode::Continuous, ..): every pixel = PixelArena::new(1.0): one node {d: 0}, length 1
+void sim_set_continuous(Sim *s) {
+    s->continuous = 1;
+    const size_t nodes = s->max_depth + 1;
+    s->c_hdr.assign(s->N, apx_hdr(APx{0u, 1u, false, 0.0f}));
+    s->c_meta.assign(s->N * nodes, anode_meta(anode_new(1.0f)));
+    s->c_integ.assign(s->N * nodes, 0.0f);
+    s->c_dt.assign(s->N * nodes, 0.0f);
+    s->c_bdt.assign(s->N * nodes, 0.0f);
+}
 void sim_set_crf_parameters(Sim *s, uint8_t c_max, uint8_t velocity) { s->c_max = c_max; s->velocity = velocity; }
 void sim_reset_c_thresh(Sim *s, uint8_t baseline) {
     s->c_thresh = baseline;
@@ -154,6 +189,17 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                 const float glf = s->abs_t ? s->lastf[u] : -1.0f;
                 const uint32_t v = frame[u];
                 em.x = (uint16_t)x; em.y = (uint16_t)(y + s->row_begin); em.c = s->C == 1 ? 0xFF : (uint8_t)c;
+                if (s->continuous) {
+                    APx p = apx_unpack(s->c_hdr[u], s->lastf[u]);
+                    ContAcc acc{s, u};
+                    const bool ok = s->abs_t ? cont_step<true>(p, acc, v, (float)v, time_spanned, sc, s->max_depth + 1, em)
+                                             : cont_step<false>(p, acc, v, (float)v, time_spanned, sc, s->max_depth + 1, em);
+                    if (!ok) rc = -5;
+                    s->c_hdr[u] = apx_hdr(p);
+                    s->lastf[u] = p.lastf;
+                    if (p.length > s->max_m) s->max_m = p.length;
+                    continue;
+                }
                 if (lean) {
                     LeanPx p = lean_unpack<ScalarLanes>(hdr, gi, gd, gb, glf);
                     LeanRec rec;

@@ -34,6 +34,7 @@ def lib():
     L.sim_new.argtypes = [u32, u32, u32, u32, i32, i32, u32, u32, u32]
     L.sim_free.argtypes = [vp]
     L.sim_set_crf_parameters.argtypes = [vp, u8, u8]
+    L.sim_set_continuous.argtypes = [vp]
     L.sim_reset_c_thresh.argtypes = [vp, u8]
     L.sim_set_delta_t_max.argtypes = [vp, u32]
     L.sim_plan_mismatches.restype = C.c_uint64
@@ -83,6 +84,9 @@ class Sim:
 
     def set_crf_parameters(self, c_max, velocity):
         self.L.sim_set_crf_parameters(self.h, c_max, velocity)
+
+    def set_continuous(self):
+        self.L.sim_set_continuous(self.h)
 
     def reset_c_thresh(self, baseline):
         self.L.sim_reset_c_thresh(self.h, baseline)

@@ -181,3 +181,25 @@ def test_quality_change_mid_stream_keeps_parity():
         for k in range(60, 150):
             _same(ov, sv, clip[k], 255.0)
         assert sv.lean_steps == 0
+
+
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_continuous_mode_general_arena_step(multi_mode, time_mode):
+    """Mode::Continuous (SURVEY 8(f)3): the device header's general arena step (cont_step: remainders handed to the
+    child, zero events, set_d_for_continuous, pop_top on a root without a best event) against the oracle, whose
+    Continuous paths the reference's own PixelArena unit tests pin (tests/test_oracle_kat.py)."""
+    for kind in ("noise", "dark", "jitter", "runs", "steps", "static"):
+        clip = clips.make_clip(kind, 90, 5, 7, 1, seed=len(kind) * 10 + multi_mode)
+        for dtm, crf in ((255, 0), (1020, 0), (7650, 3), (7650, 9)):
+            ov, sv = _pair(7, 5, 1, time_mode, multi_mode, dtm, max_depth=24)
+            ov.set_pixel_mode(1)
+            sv.set_continuous()
+            base, cmax, vel = CRFS[crf]
+            for v in (ov, sv):
+                v.set_crf_parameters(cmax, vel)
+                v.reset_c_thresh(base)
+            total = 0
+            for k in range(len(clip)):
+                total += _same(ov, sv, clip[k], 255.0 if k % 7 else 510.0)
+            assert total > 0 or kind == "static"

@@ -742,3 +742,44 @@ def test_baseline_config_5_end_to_end_compressed_sink_4k_rgb():
         assert np.all(np.abs(a["t"].astype(np.int64) - b["t"].astype(np.int64)) <= 255 * 8)
         checked += 1
     assert checked > 2500
+
+
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_continuous_mode_kernel(multi_mode, time_mode):
+    """SURVEY 8(f)3: Mode::Continuous through the C-ABI (adder_cont_kernel + the staged expansion) against the
+    oracle, whose Continuous paths are pinned by the reference's PixelArena unit tests: remainders handed to the
+    child, zero events, set_d_for_continuous, pop_top on a root without a best event -- per-frame calls (with chunk
+    offsets), batches, RGB, ragged planes, a row band, the running-intensities side plane."""
+    A = _hip()
+    cases = [("dark", 21, 13, 1, 255, 0), ("runs", 33, 20, 1, 7650, 3), ("jitter", 9, 130, 3, 1020, 9),
+             ("noise", 40, 40, 1, 255, 0), ("steps", 16, 17, 3, 7650, 0)]
+    for kind, H, W, Cn, dtm, crf in cases:
+        clip = clips.make_clip(kind, 70, H, W, Cn, seed=H * 7 + dtm)
+        y0, y1 = (0, H) if kind != "runs" else (5, 17)
+        sub = clip[:, y0:y1]
+        ov = O.Video(W, y1 - y0, Cn, row_begin=y0, time_mode=time_mode, multi_mode=multi_mode, ref_time=255,
+                     delta_t_max=dtm, chunk_rows=3)
+        ov.set_pixel_mode(1)
+        hv = A.HipVideo(W, H, Cn, row_begin=y0, row_end=y1, time_mode=time_mode, multi_mode=multi_mode, ref_time=255,
+                        delta_t_max=dtm, chunk_rows=3, max_depth=24, pixel_mode=1)
+        ov.ensure_capacity(28)
+        base, cmax, vel = CRFS[crf]
+        for v in (ov, hv):
+            v.set_crf_parameters(cmax, vel)
+            v.reset_c_thresh(base)
+        if kind == "dark":
+            hv.enable_running_intensities(True)
+        total = 0
+        for k in range(30):
+            a, ca = ov.integrate_matrix(sub[k], want_chunks=True)
+            b, cb = hv.integrate_matrix(sub[k], want_chunks=True)
+            assert np.array_equal(a, b) and np.array_equal(ca, cb), (kind, k)
+            total += len(a)
+        if kind == "dark":
+            assert np.array_equal(hv.running_intensities(), ov.running_intensities())
+        want = [ov.integrate_matrix(f) for f in sub[30:]]
+        got, offs = hv.integrate_batch(sub[30:])
+        assert np.array_equal(got, np.concatenate(want)), kind
+        assert [int(offs[i + 1] - offs[i]) for i in range(40)] == [len(w) for w in want]
+        assert total + len(got) > 0
