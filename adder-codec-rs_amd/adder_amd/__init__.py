@@ -11,6 +11,6 @@ from ._native import (  # noqa: F401
     CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE, D_EMPTY, D_ZERO_INTEGRATION, D_MAX, C_NONE,
     OK, E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED,
 )
-from .video import CRF, HipVideo, raw_header, raw_events, raw_eof, synth_clip_device  # noqa: F401
+from .video import CRF, crf_feature_radius, HipVideo, raw_header, raw_events, raw_eof, synth_clip_device  # noqa: F401
 from .framer import HipFramer, contiguous_run_segments, FRAMED_U8, DVS  # noqa: F401
 from .compressed import CompressedEncoder, compressed_decode  # noqa: F401

@@ -104,6 +104,12 @@ SYMBOLS = {
     "adder_hip_last_error": (C.c_char_p, [_vp]),
     "adder_hip_set_crf_parameters": (_i32, [_vp, _u8, _u8]),
     "adder_hip_reset_c_thresh": (_i32, [_vp, _u8]),
+    "adder_hip_update_detect_features": (_i32, [_vp, _i32, _i32]),
+    "adder_hip_set_feature_parameters": (_i32, [_vp, _u8, _u16]),
+    "adder_hip_update_roi": (_i32, [_vp, _i32, _u16, _u16, _u16, _u16]),
+    "adder_hip_feature_set": (_i32, [_vp, _vp]),
+    "adder_hip_c_thresh_plane": (_i32, [_vp, _vp]),
+    "adder_hip_last_new_features": (_u32, [_vp]),
     "adder_hip_set_delta_t_max": (_i32, [_vp, _u32]),
     "adder_hip_set_time_mode": (_i32, [_vp, _u8]),
     "adder_hip_alloc_pinned": (_vp, [_sz]),

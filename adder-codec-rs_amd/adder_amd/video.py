@@ -18,7 +18,14 @@ CRF = [
     (0, 0, 10), (0, 1, 9), (1, 3, 8), (2, 7, 7), (5, 9, 6),
     (6, 10, 5), (7, 13, 4), (8, 16, 3), (10, 20, 2), (15, 25, 1),
 ]
+# feature radius column of the same table: X * min resolution, in pixels, evaluated in f32 (:5-18, :66-67)
+CRF_FEATURE_RADIUS = [np.float32(1e-9)] + [np.float32(1.0) / np.float32(k) for k in (12, 14, 15, 18, 20, 25, 30, 30, 30)]
 DEFAULT_CRF_QUALITY = 3
+
+
+def crf_feature_radius(crf, width, height):
+    """(CRF[crf][3] * plane.min_resolution() as f32) as u16 (rate_controller.rs:66-67)."""
+    return int(np.float32(CRF_FEATURE_RADIUS[crf]) * np.float32(min(width, height)))
 
 
 class HipVideo:
@@ -78,13 +85,54 @@ class HipVideo:
         """Video::update_crf (video.rs:1241-1251)."""
         base, cmax, vel = CRF[crf]
         self.set_crf_parameters(cmax, vel)
+        self.set_feature_parameters(base, crf_feature_radius(crf, self.width, self.height))
         self.reset_c_thresh(base)
 
-    def update_quality_manual(self, c_thresh_baseline, c_thresh_max, delta_t_max_multiplier, c_increase_velocity):
-        """Video::update_quality_manual (video.rs:1264-1287)."""
+    def update_quality_manual(self, c_thresh_baseline, c_thresh_max, delta_t_max_multiplier, c_increase_velocity,
+                              feature_c_radius=None):
+        """Video::update_quality_manual (video.rs:1264-1287); feature_c_radius: the absolute pixel count
+        (None leaves the current one, for callers that do not use feature-driven rate control)."""
         self.set_crf_parameters(c_thresh_max, c_increase_velocity)
+        if feature_c_radius is not None:
+            self.set_feature_parameters(c_thresh_baseline, int(feature_c_radius))
+        else:
+            self._baseline_only(c_thresh_baseline)
         N.check(self.h, self.L.adder_hip_set_delta_t_max(self.h, delta_t_max_multiplier * self.ref_time))
         self.reset_c_thresh(c_thresh_baseline)
+
+    # ---- feature-driven rate control, ROI (SURVEY 8(f)4) ------------------------------------
+    def update_detect_features(self, detect_features, feature_rate_adjustment=False):
+        """Video::update_detect_features (video.rs:825-837)."""
+        N.check(self.h, self.L.adder_hip_update_detect_features(self.h, int(detect_features),
+                                                               int(feature_rate_adjustment)))
+
+    def set_feature_parameters(self, c_thresh_baseline, feature_c_radius):
+        self._feature_radius = int(feature_c_radius)
+        N.check(self.h, self.L.adder_hip_set_feature_parameters(self.h, c_thresh_baseline, int(feature_c_radius)))
+
+    def _baseline_only(self, c_thresh_baseline):
+        r = getattr(self, "_feature_radius", crf_feature_radius(DEFAULT_CRF_QUALITY, self.width, self.height))
+        self.set_feature_parameters(c_thresh_baseline, r)
+
+    def update_roi(self, roi):
+        """Video::update_roi (video.rs:1291-1293); roi = (start_x, start_y, end_x, end_y) inclusive, or None."""
+        if roi is None:
+            N.check(self.h, self.L.adder_hip_update_roi(self.h, 0, 0, 0, 0, 0))
+        else:
+            N.check(self.h, self.L.adder_hip_update_roi(self.h, 1, *[int(v) for v in roi]))
+
+    def feature_set(self):
+        out = np.zeros((self.rows, self.width), np.uint8)
+        N.check(self.h, self.L.adder_hip_feature_set(self.h, out.ctypes.data))
+        return out
+
+    def c_thresh_plane(self):
+        out = np.zeros(self.n_units, np.uint8)
+        N.check(self.h, self.L.adder_hip_c_thresh_plane(self.h, out.ctypes.data))
+        return out.reshape(self.rows, self.width, self.channels)
+
+    def last_new_features(self):
+        return int(self.L.adder_hip_last_new_features(self.h))
 
     def set_delta_t_max(self, dtm):
         N.check(self.h, self.L.adder_hip_set_delta_t_max(self.h, dtm))

@@ -60,7 +60,20 @@ struct AdderHipCtx {
         uint8_t c_thresh = 0, c_counter = 0;
         uint64_t frames_done = 0;
         bool generic_sticky = false;
+        uint8_t *cth_px = nullptr, *cctr_px = nullptr, *fset = nullptr, *running = nullptr;
+        bool perpx = false, has_running = false;
     } snap;
+    // feature-driven rate control + ROI (video.rs:825-837, 865-1112, 1291-1293)
+    bool feat_detect = false, feat_adjust = false;
+    uint8_t c_thresh_baseline = 2;   // Crf::new(None): CRF[3][0] (rate_controller.rs:21,62)
+    uint16_t feature_c_radius = 0;   // CRF[3][3] * min_resolution, set in create
+    bool roi_on = false;
+    uint16_t roi[4] = {0, 0, 0, 0};  // start.x, start.y, end.x, end.y (inclusive)
+    uint8_t *cth_px = nullptr, *cctr_px = nullptr;  // per-unit pair once it stops being uniform (perpx)
+    uint8_t *fset = nullptr;         // [rows][width] VideoState::features membership
+    uint32_t *d_feat_counters = nullptr;
+    uint32_t last_new_features = 0;
+    bool perpx = false;              // sticky until adder_hip_reset / reset_c_thresh
     // c_thresh / c_increase_counter: identical in every pixel (adder_pixel.hpp header comment)
     uint8_t c_thresh = 10, c_counter = 1;
     // a generic batch has run since create / reset: pixels may hold more than one fired level, which only
@@ -173,7 +186,9 @@ static void free_ctx(AdderHipCtx *c) {
     void *ptrs[] = {c->hdr,     c->integ0,  c->dt0,      c->bdt0,   c->lastf,  c->dv_integ, c->dv_dt,
                     c->dv_bdt,  c->dv_bd,   c->running,  c->status, c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
                     c->snap.cn_integ, c->snap.cn_dt, c->snap.cn_bdt, c->snap.cn_meta,
-                    c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire};
+                    c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire,
+                    c->cth_px, c->cctr_px, c->fset, c->d_feat_counters, c->snap.cth_px, c->snap.cctr_px, c->snap.fset,
+                    c->snap.running};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
@@ -264,6 +279,10 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->max_nodes = c->max_depth + 1u;
     a->stage_events = c->max_depth + 3u;
     a->running = c->running_enabled ? c->running : nullptr;
+    a->cth_px = c->perpx ? c->cth_px : nullptr;
+    a->cctr_px = c->perpx ? c->cctr_px : nullptr;
+    a->c_max = c->p.c_thresh_max;
+    a->c_vel = c->p.c_increase_velocity;
     a->plane_stride = c->n_pad;
     a->status = c->status;
     a->n_units = c->n_units;
@@ -297,6 +316,8 @@ static int init_state(AdderHipCtx *c) {
     c->c_thresh = p.c_thresh_start;
     c->c_counter = p.c_counter_start;
     c->generic_sticky = false;
+    c->perpx = false;
+    if (c->fset) HIPCHK(c, hipMemsetAsync(c->fset, 0, (size_t)c->rows * p.width, c->stream));
     c->running_t = 0.0f;
     c->frames_done = 0;
     c->poisoned = false;
@@ -376,6 +397,9 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
     c->num_waves = (uint32_t)(c->n_pad / kWaveUnits);
     c->num_chunks = (c->rows + p.chunk_rows - 1) / p.chunk_rows;
     c->max_depth = p.max_depth;
+    // Crf::new(None, plane): quality 3 -> feature_c_radius = (CRF[3][3] * min_resolution as f32) as u16
+    // (rate_controller.rs:17,66-67)
+    c->feature_c_radius = (uint16_t)((1.0f / 15.0f) * (float)std::min<uint32_t>(p.width, p.height));
 
     int rc = ADDER_OK;
     auto setup = [&]() -> int {
@@ -449,6 +473,105 @@ extern "C" int adder_hip_reset_c_thresh(AdderHipCtx *c, uint8_t baseline) {
     // is uniform across the plane, so it lives in the context
     c->c_thresh = baseline;
     c->c_counter = 0;
+    c->perpx = false;  // uniform again; the next frame of a feature / ROI batch re-creates the planes from the pair
+    return ADDER_OK;
+}
+
+// ---- feature-driven rate control + ROI ----
+static bool feature_path(const AdderHipCtx *c) { return c->feat_detect || c->roi_on; }
+static bool feature_needs_perpx(const AdderHipCtx *c) {
+    return c->roi_on || (c->feat_detect && c->feat_adjust && c->feature_c_radius > 0);
+}
+static int whole_plane_only(AdderHipCtx *c, const char *what) {
+    if (c->continuous) return fail(c, ADDER_E_BAD_PARAMS, "%s: FramePerfect contexts only", what);
+    if (c->p.row_begin != 0 || c->p.row_end != c->p.height)
+        return fail(c, ADDER_E_BAD_PARAMS, "%s couples pixels across rows: the context must own the whole plane", what);
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_update_detect_features(AdderHipCtx *c, int detect_features, int feature_rate_adjustment) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (detect_features) {
+        int rc = whole_plane_only(c, "feature detection");
+        if (rc != ADDER_OK) return rc;
+    }
+    c->feat_detect = detect_features != 0;
+    c->feat_adjust = feature_rate_adjustment != 0;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_set_feature_parameters(AdderHipCtx *c, uint8_t c_thresh_baseline, uint16_t feature_c_radius) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    c->c_thresh_baseline = c_thresh_baseline;
+    c->feature_c_radius = feature_c_radius;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_update_roi(AdderHipCtx *c, int enable, uint16_t x0, uint16_t y0, uint16_t x1, uint16_t y1) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (enable) {
+        int rc = whole_plane_only(c, "a region of interest");
+        if (rc != ADDER_OK) return rc;
+    }
+    c->roi_on = enable != 0;
+    c->roi[0] = x0;
+    c->roi[1] = y0;
+    c->roi[2] = x1;
+    c->roi[3] = y1;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_feature_set(AdderHipCtx *c, uint8_t *dst) {
+    if (!c || !dst) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    const size_t n = (size_t)c->rows * c->p.width;
+    if (!c->fset) {
+        memset(dst, 0, n);
+        return ADDER_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->fset, n, hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_c_thresh_plane(AdderHipCtx *c, uint8_t *dst) {
+    if (!c || !dst) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (!c->perpx) {
+        memset(dst, c->c_thresh, c->n_units);
+        return ADDER_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(dst, c->cth_px, c->n_units, hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
+
+extern "C" uint32_t adder_hip_last_new_features(const AdderHipCtx *c) { return c ? c->last_new_features : 0u; }
+
+// planes of the feature path, on first use
+static int prepare_feature_set(AdderHipCtx *c, hipStream_t s) {
+    if (!c->fset) {
+        HIPCHK(c, dalloc(&c->fset, (size_t)c->rows * c->p.width));
+        HIPCHK(c, hipMemsetAsync(c->fset, 0, (size_t)c->rows * c->p.width, s));
+    }
+    if (!c->d_feat_counters) HIPCHK(c, dalloc(&c->d_feat_counters, 4));
+    HIPCHK(c, hipMemsetAsync(c->d_feat_counters, 0, 4 * sizeof(uint32_t), s));
+    return ADDER_OK;
+}
+// the per-unit (c_thresh, c_increase_counter) pair starts from the uniform one
+static int prepare_per_unit_c_thresh(AdderHipCtx *c, hipStream_t s) {
+    if (feature_needs_perpx(c) && !c->perpx) {
+        if (!c->cth_px) {
+            HIPCHK(c, dalloc(&c->cth_px, c->n_pad));
+            HIPCHK(c, dalloc(&c->cctr_px, c->n_pad));
+        }
+        HIPCHK(c, hipMemsetAsync(c->cth_px, c->c_thresh, c->n_pad, s));
+        HIPCHK(c, hipMemsetAsync(c->cctr_px, c->c_counter, c->n_pad, s));
+        c->perpx = true;
+    }
     return ADDER_OK;
 }
 
@@ -474,7 +597,8 @@ extern "C" uint32_t adder_hip_num_chunks(const AdderHipCtx *c) { return c ? c->n
 // The most events one frame can emit: the lean step at most 3 per unit (root event, Collapse filler, pop_top's
 // event); the generic step its whole arena (<= max_depth levels) plus pop_top's event.
 static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
-    return !c->generic_sticky && c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned;
+    return !c->generic_sticky && !c->perpx && !feature_needs_perpx(c) && c->p.multi_mode == ADDER_MULTI_COLLAPSE &&
+           (float)c->p.delta_t_max <= time_spanned;
 }
 static size_t worst_case_events_per_frame(const AdderHipCtx *c, float time_spanned) {
     if (c->continuous) return (size_t)c->n_units * (c->max_depth + 3u);
@@ -546,6 +670,31 @@ static int alloc_deep_planes(AdderHipCtx *c) {
 // expansion inside K1's grid (round 1) no longer pays: with the lean step both kernels are bound by the
 // memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
+
+// Feature path: frame f+1's contrast thresholds depend on the features frame f's EVENTS reveal, so the whole
+// pipeline runs frame by frame: step, scan, offsets, expansion, features.
+static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s) {
+    FeatureArgs fa{};
+    fa.fset = c->fset;
+    fa.counters = c->d_feat_counters;
+    fa.chunk_rows = c->p.chunk_rows;
+    fa.detect = c->feat_detect ? 1u : 0u;
+    fa.radius = (c->feat_detect && c->feat_adjust) ? c->feature_c_radius : 0u;
+    fa.low = std::min<uint32_t>(c->c_thresh_baseline, 2u);
+    fa.roi_on = c->roi_on ? 1u : 0u;
+    fa.rx0 = c->roi[0];
+    fa.ry0 = c->roi[1];
+    fa.rx1 = c->roi[2];
+    fa.ry1 = c->roi[3];
+    for (uint32_t f = 0; f < num_frames; ++f) {
+        HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, 0u, s));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, s));
+        HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1u, s));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, s));
+        HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
+    }
+    return ADDER_OK;
+}
 
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
@@ -649,6 +798,14 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
         HIPCHK(c, snap_copy(&n.dv_bdt, c->dv_bdt, cnt, s));
         HIPCHK(c, snap_copy(&n.dv_bd, c->dv_bd, cnt, s));
     }
+    n.perpx = c->perpx;
+    if (c->perpx) {
+        HIPCHK(c, snap_copy(&n.cth_px, c->cth_px, c->n_pad, s));
+        HIPCHK(c, snap_copy(&n.cctr_px, c->cctr_px, c->n_pad, s));
+    }
+    if (c->fset) HIPCHK(c, snap_copy(&n.fset, c->fset, (size_t)c->rows * c->p.width, s));
+    n.has_running = c->running != nullptr;
+    if (c->running) HIPCHK(c, snap_copy(&n.running, c->running, c->n_pad, s));
     n.running_t = c->running_t;
     n.c_thresh = c->c_thresh;
     n.c_counter = c->c_counter;
@@ -678,6 +835,13 @@ static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
         HIPCHK(c, hipMemcpyAsync(c->dv_bdt, n.dv_bdt, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->dv_bd, n.dv_bd, cnt, hipMemcpyDeviceToDevice, s));
     }
+    if (n.perpx) {
+        HIPCHK(c, hipMemcpyAsync(c->cth_px, n.cth_px, c->n_pad, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->cctr_px, n.cctr_px, c->n_pad, hipMemcpyDeviceToDevice, s));
+    }
+    if (c->fset && n.fset) HIPCHK(c, hipMemcpyAsync(c->fset, n.fset, (size_t)c->rows * c->p.width, hipMemcpyDeviceToDevice, s));
+    c->perpx = n.perpx;
+    if (c->running && n.has_running) HIPCHK(c, hipMemcpyAsync(c->running, n.running, c->n_pad, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->running_t = n.running_t;
@@ -699,7 +863,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // until adder_hip_reset: update_quality_manual can lower delta_t_max mid-stream (video.rs:1264-1287).
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
     const bool sticky_before = c->generic_sticky;
-    const bool generic = !c->continuous && (c->generic_sticky || !(collapse && (float)c->p.delta_t_max <= time_spanned));
+    const bool fpath = feature_path(c);
+    const bool generic = !c->continuous && (c->generic_sticky || c->perpx || feature_needs_perpx(c) ||
+                                            !(collapse && (float)c->p.delta_t_max <= time_spanned));
+    if (fpath) {  // the corner test reads the running intensities (video.rs:736-744)
+        c->running_enabled = true;
+        int rc_ = prepare_feature_set(c, stream);
+        if (rc_ != ADDER_OK) return rc_;
+    }
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u);
     if (generic) {
@@ -711,6 +882,11 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     }
     // an event buffer below the batch's worst case can overflow: keep an undo copy of the state so that the
     // overflow is recoverable (adder_hip_finish rolls back and reports the size needed)
+    if (c->running_enabled && !c->running) {
+        HIPCHK(c, dalloc(&c->running, c->n_pad));
+        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->snap.valid = false;
     {
         const size_t per_frame = (size_t)c->n_units * (c->continuous ? c->max_depth + 3u : generic ? c->max_depth + 1u : 3u);
@@ -720,10 +896,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
             c->snap.generic_sticky = sticky_before;
         }
     }
-    if (c->running_enabled && !c->running) {
-        HIPCHK(c, dalloc(&c->running, c->n_pad));
-        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fpath) {
+        int rc_ = prepare_per_unit_c_thresh(c, stream);
+        if (rc_ != ADDER_OK) return rc_;
     }
 
     // ---- batch description -> device ----
@@ -787,7 +962,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     }
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     int rc = ADDER_OK;
-    if (c->use_graph && !timing) {
+    if (fpath) {
+        rc = launch_feature_loop(c, num_frames, variant, stream);
+    } else if (c->use_graph && !timing) {
         hipGraphExec_t exec = nullptr;
         rc = get_graph(c, num_frames, variant, &exec);
         if (rc == ADDER_OK) HIPCHK(c, hipGraphLaunch(exec, stream));
@@ -851,6 +1028,10 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
                              c->pending_stream));
     HIPCHK(c, hipMemcpyAsync(&c->last_records, c->d_rec_total, sizeof(uint64_t), hipMemcpyDeviceToHost,
                              c->pending_stream));
+    c->last_new_features = 0;
+    if (c->d_feat_counters && feature_path(c))
+        HIPCHK(c, hipMemcpyAsync(&c->last_new_features, c->d_feat_counters, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 c->pending_stream));
     HIPCHK(c, hipStreamSynchronize(c->pending_stream));
     if (c->pending_frames)
         HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev_start, c->ev_stop));

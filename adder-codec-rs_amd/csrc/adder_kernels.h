@@ -70,6 +70,10 @@ struct FrameArgs {
     uint32_t max_nodes; // max_depth + 1
     uint32_t stage_events;  // staged records per unit (max_depth + 3), see adder_cont_kernel
     uint8_t *running;   // optional running_intensities side plane, or nullptr
+    // feature-driven rate control / ROI: c_thresh and c_increase_counter per unit, generic K1 only;
+    // nullptr while they are uniform (FrameTab::cth)
+    uint8_t *cth_px, *cctr_px;
+    uint32_t c_max, c_vel;  // CrfParameters::{c_thresh_max, c_increase_velocity} of the per-unit adaptation
     size_t plane_stride;  // n_pad
     // this frame
     const uint8_t *frame;  // n_units bytes, packed [rows][width][channels]
@@ -107,6 +111,17 @@ struct BatchArgs {
     uint32_t *ftot_ring;      // [slots]
     uint32_t slots;
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
+};
+
+// handle_features / handle_roi of one context (video.rs:865-1112)
+struct FeatureArgs {
+    uint8_t *fset;        // [rows][width] membership of VideoState::features (0 / 1)
+    uint32_t *counters;   // [0] features found new since the batch began
+    uint32_t chunk_rows;  // the event windows are circular per row chunk
+    uint32_t detect;      // VideoState::feature_detection
+    uint32_t radius;      // feature_c_radius if feature_rate_adjustment, else 0
+    uint32_t low;         // min(c_thresh_baseline, 2)
+    uint32_t roi_on, rx0, ry0, rx1, ry1;  // Roi {start, end}, inclusive, plane coordinates
 };
 
 __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) {
@@ -148,6 +163,10 @@ hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n
 hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
                               uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap, uint64_t *merged_offsets,
                               uint32_t *status, hipStream_t stream);
+// after frame f's events are in place: FAST features at the events' pixels -> membership plane, c_thresh reset
+// around the new ones, ROI (video.rs:865-1112)
+hipError_t adder_launch_features(const adder::BatchArgs *b, uint32_t f, const adder::FeatureArgs *fa,
+                                 hipStream_t stream);
 hipError_t adder_launch_synth(uint8_t *dst, int content, uint64_t seed, uint32_t W, uint32_t H, uint32_t C,
                               uint32_t y0, uint32_t rows, uint32_t k0, uint32_t nframes, hipStream_t stream);
 }

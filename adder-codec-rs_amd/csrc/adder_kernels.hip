@@ -462,6 +462,16 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         for (uint32_t j = 0; j < N; ++j) px[j] = px_unpack(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
     }
     StepConsts sc = a.sc;
+    // c_thresh / c_increase_counter per unit once feature-driven rate control or an ROI has made them differ
+    const bool perpx = a.cth_px != nullptr;  // uniform
+    uint8_t cthv[N], cctrv[N];
+    if (perpx) {
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            cthv[j] = a.cth_px[u0 + j];
+            cctrv[j] = a.cctr_px[u0 + j];
+        }
+    }
     // the unit's LDS slot: [level][j][lane] (consecutive lanes -> consecutive 16-byte slots)
     DeepHybrid deep[N];
 #pragma unroll
@@ -503,6 +513,10 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            if (perpx) {
+                sc.cth = cthv[j];
+                c_thresh_advance(cthv[j], cctrv[j], (uint8_t)a.c_max, (uint8_t)a.c_vel, sc.time_spanned, sc.ref_time);
+            }
             gen_root<COLLAPSE>(px[j], v, sc, plan[j]);
             // units past the band's end are padding: their state may be stepped freely, only
             // their events must be suppressed
@@ -561,6 +575,20 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         store_vec(a.dt0, u0, dv);
         store_vec(a.bdt0, u0, bv);
         if (ABS_T) store_vec(a.lastf, u0, lfv);
+        if (perpx) {
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                a.cth_px[u0 + j] = cthv[j];
+                a.cctr_px[u0 + j] = cctrv[j];
+            }
+        }
+        if (perpx) {
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                a.cth_px[u0 + j] = cthv[j];
+                a.cctr_px[u0 + j] = cctrv[j];
+            }
+        }
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
@@ -1108,6 +1136,76 @@ __global__ void adder_chunk_offsets_kernel(const AdderEventPod *ev, uint32_t n, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Feature-driven rate control (video.rs:883-1112 handle_features, :866-882 handle_roi), run once
+// per frame after the frame's events are in place and before the next frame is stepped.  A lane per event:
+// an event is looked at if it is the last of its pixel's run (`e1.coord != e2.coord` over the row chunk's
+// CIRCULAR windows), on channel 0 / None and not a D_EMPTY filler; FAST 9_16 on the running intensities decides
+// whether its pixel joins or leaves the feature set.  A pixel is looked at once per frame at most, so the
+// membership plane needs no atomics.  Around each NEW feature the wave then sets c_thresh = min(baseline, 2)
+// over the clamped square of radius feature_c_radius, all channels; every writer stores the same value.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void feature_fill_rect(uint8_t *cth, uint32_t width, uint32_t channels, uint32_t x0,
+                                                  uint32_t y0, uint32_t x1, uint32_t y1, uint32_t low, uint32_t lane) {
+    const uint32_t span = (x1 - x0 + 1u) * channels;
+    for (uint32_t y = y0; y <= y1; ++y) {
+        uint8_t *row = cth + ((size_t)y * width + x0) * channels;
+        for (uint32_t i = lane; i < span; i += kWave) row[i] = (uint8_t)low;
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const BatchArgs *__restrict__ b, uint32_t f,
+                                                                      const FeatureArgs fa) {
+    const FrameArgs &a = b->base;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave, nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t rows = a.n_units / a.rowlen;
+    if (fa.detect) {
+        const uint64_t begin = a.frame_offsets[f];
+        uint64_t end = a.frame_offsets[f + 1];
+        if (end > a.out_cap) end = a.out_cap;  // the overflow is on record in the status word
+        const AdderEventPod *const ev = a.out;
+        for (uint64_t base = begin + (uint64_t)wave * kWave; base < end; base += (uint64_t)nwaves * kWave) {
+            const uint64_t i = base + lane;
+            bool is_new = false;
+            uint32_t x = 0, y = 0;
+            if (i < end) {
+                x = ev[i].x;
+                y = ev[i].y - a.row_begin;
+                const bool look = feature_looked_at(ev, begin, end, i, a.row_begin, fa.chunk_rows);
+                if (look) {
+                    uint8_t *member = fa.fset + (size_t)y * a.width + x;
+                    if (fast9_is_feature(a.running, a.width, rows, a.channels, x, y)) {
+                        is_new = *member == 0u;
+                        *member = 1u;
+                    } else {
+                        *member = 0u;
+                    }
+                }
+            }
+            uint64_t m = __ballot(is_new);
+            if (m != 0ull && lane == 0) atomicAdd(fa.counters, (uint32_t)__popcll(m));
+            if (fa.radius != 0u) {
+                while (m != 0ull) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const uint32_t fx = __builtin_amdgcn_readlane(x, src), fy = __builtin_amdgcn_readlane(y, src);
+                    const uint32_t x0 = fx > fa.radius ? fx - fa.radius : 0u, y0 = fy > fa.radius ? fy - fa.radius : 0u;
+                    const uint32_t x1 = min(fx + fa.radius, a.width - 1u), y1 = min(fy + fa.radius, rows - 1u);
+                    feature_fill_rect(a.cth_px, a.width, a.channels, x0, y0, x1, y1, fa.low, lane);
+                }
+            }
+        }
+    }
+    if (fa.roi_on) {  // plane coordinates -> rows of this context
+        const uint32_t y_lo = max(fa.ry0, a.row_begin), y_hi = min(fa.ry1, a.row_begin + rows - 1u);
+        const uint32_t x1 = min(fa.rx1, a.width - 1u);
+        if (fa.rx0 <= x1)
+            for (uint32_t y = y_lo + wave; y <= y_hi && y_lo <= y_hi; y += nwaves)
+                feature_fill_rect(a.cth_px, a.width, a.channels, fa.rx0, y - a.row_begin, x1, y - a.row_begin, fa.low, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Multi-GPU: merge of the row bands' event streams (the reference's split is
 // video.rs:677-691).  Rank r's stream is frame-major with offsets offs[r][0..T]; the merged stream
 // is frame-major with, inside a frame, rank 0's events first, then rank 1's, ... = raster order.
@@ -1314,6 +1412,11 @@ extern "C" hipError_t adder_launch_chunk_offsets(const AdderEventPod *ev, uint32
     const uint32_t bs = 256;
     hipLaunchKernelGGL(adder_chunk_offsets_kernel, dim3((num_chunks + 1 + bs - 1) / bs), dim3(bs), 0, stream, ev,
                        n, row_begin, chunk_rows, num_chunks, offsets);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_features(const BatchArgs *b, uint32_t f, const FeatureArgs *fa, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_feature_kernel, dim3(512), dim3(kBlockThreads), 0, stream, b, f, *fa);
     return hipGetLastError();
 }
 

@@ -851,4 +851,68 @@ ADDER_HD uint32_t frame_value_u8(uint32_t d, uint32_t t, double tpf) {
     return (uint32_t)val;
 }
 
+// ------------------------------------------------------------------------------------------
+// Feature-driven rate control.  FAST 9_16 corner test on the running-intensities plane
+// (utils/cv.rs:56-212, the OpenCV-style scan with its quick rejects): the reference's answer is exactly
+// "some arc of >= 9 contiguous pixels on the radius-3 Bresenham circle is entirely brighter than
+// centre + 30, or entirely darker than centre - 30" (its rejects and the k == 17 early exit never change
+// that; tests/test_features.py checks the literal restatement in the oracle against both).  Here: two 16-bit
+// ring masks and an AND of rotations.
+// ------------------------------------------------------------------------------------------
+constexpr int kFastThreshold = 30;  // cv.rs:21 INTENSITY_THRESHOLD
+constexpr uint32_t kFastArc = 9;    // cv.rs:32 STREAK_SIZE
+constexpr uint32_t kFastBorder = 3; // cv.rs:57 is_border(.., 3)
+
+ADDER_HD bool fast_arc9(uint32_t m) {  // m: 16 ring flags; true if 9 circularly contiguous bits are set
+    m |= m << 16;
+    m &= m >> 1;   // runs of 2
+    m &= m >> 2;   // runs of 4
+    m &= m >> 4;   // runs of 8
+    m &= m >> 1;   // runs of 9
+    return (m & 0xffffu) != 0u;
+}
+
+// img = [h][w][channels] u8, channel 0 is the one looked at (cv.rs:67-69: coord.c is None or 0)
+ADDER_HD bool fast9_is_feature(const uint8_t *img, uint32_t w, uint32_t h, uint32_t channels, uint32_t x, uint32_t y) {
+    if (x < kFastBorder || x + kFastBorder >= w || y < kFastBorder || y + kFastBorder >= h) return false;
+    // cv.rs:25-30 CIRCLE3 as (dx, dy), nibble-packed with a +3 bias
+    constexpr uint64_t kDx = 0x2100012345666543ull, kDy = 0x6543210001234566ull;
+    const int c = (int)img[((size_t)y * w + x) * channels];
+    uint32_t bright = 0u, dark = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        const int dx = (int)((kDx >> (4 * k)) & 0xfu) - 3, dy = (int)((kDy >> (4 * k)) & 0xfu) - 3;
+        const int p = (int)img[((size_t)((int)y + dy) * w + (size_t)((int)x + dx)) * channels];
+        bright |= (p > c + kFastThreshold ? 1u : 0u) << k;
+        dark |= (p < c - kFastThreshold ? 1u : 0u) << k;
+    }
+    return fast_arc9(bright) || fast_arc9(dark);
+}
+
+// handle_features' filter (video.rs:893-906) for event i of a frame whose events are ev[begin, end), in raster
+// order: the reference walks each row chunk's events as CIRCULAR pairs (e1, e2) and looks at e1 when it is on
+// channel 0 / None, is not a D_EMPTY filler and e1.coord != e2.coord -- i.e. e1 is the last event of its pixel's
+// run, where the chunk's last event is paired with the chunk's first.
+template <class Ev>
+ADDER_HD bool feature_looked_at(const Ev *ev, uint64_t begin, uint64_t end, uint64_t i, uint32_t row_begin,
+                                uint32_t chunk_rows) {
+    const Ev e1 = ev[i];
+    if (!((e1.c == 0xffu || e1.c == 0u) && e1.d != kDEmpty)) return false;
+    const uint32_t chunk = (e1.y - row_begin) / chunk_rows;
+    uint64_t nxt = i + 1;
+    if (nxt >= end || (ev[nxt].y - row_begin) / chunk_rows != chunk) {
+        // e1 closes its chunk: the window wraps to the chunk's first event
+        const uint32_t cy0 = row_begin + chunk * chunk_rows;
+        uint64_t lo = begin, hi = i;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (ev[mid].y < cy0) lo = mid + 1;
+            else hi = mid;
+        }
+        nxt = lo;
+    }
+    const Ev e2 = ev[nxt];
+    return !(e2.x == e1.x && e2.y == e1.y && e2.c == e1.c);
+}
+
 }  // namespace adder

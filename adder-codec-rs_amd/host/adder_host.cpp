@@ -392,7 +392,43 @@ void Video::update_crf(uint8_t crf) {
         hip_check(ctx_, adder_hip_set_crf_parameters(ctx_, p.c_thresh_max, p.c_increase_velocity));
         hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, p.c_thresh_baseline));
         px_c_thresh_reset_.reset();
+        sync_feature_controls();
     }
+}
+
+void Video::update_detect_features(bool detect_features, ShowFeatureMode, bool feature_rate_adjustment, bool) {
+    feature_detection_ = detect_features;
+    feature_rate_adjustment_ = feature_rate_adjustment;
+    if (ctx_) sync_feature_controls();
+}
+
+void Video::update_roi(std::optional<Roi> roi) {
+    roi_ = roi;
+    if (ctx_) sync_feature_controls();
+}
+
+// the device context's copy of {feature_detection, feature_rate_adjustment, roi} and of the two CrfParameters the
+// feedback reads (video.rs:1085-1105, 866-882)
+void Video::sync_feature_controls() {
+    const CrfParameters &p = encoder_->options.crf.get_parameters();
+    hip_check(ctx_, adder_hip_set_feature_parameters(ctx_, p.c_thresh_baseline, p.feature_c_radius));
+    hip_check(ctx_, adder_hip_update_detect_features(ctx_, feature_detection_, feature_rate_adjustment_));
+    const Roi r = roi_.value_or(Roi{});
+    hip_check(ctx_, adder_hip_update_roi(ctx_, roi_.has_value(), r.start_x, r.start_y, r.end_x, r.end_y));
+}
+
+std::vector<uint8_t> Video::feature_set() {
+    ensure_ctx();
+    std::vector<uint8_t> out((size_t)plane_.w() * plane_.h());
+    hip_check(ctx_, adder_hip_feature_set(ctx_, out.data()));
+    return out;
+}
+
+std::vector<uint8_t> Video::running_intensities() {
+    ensure_ctx();
+    std::vector<uint8_t> out(plane_.volume());
+    hip_check(ctx_, adder_hip_running_intensities(ctx_, out.data()));
+    return out;
 }
 
 void Video::update_quality_manual(uint8_t c_thresh_baseline, uint8_t c_thresh_max, uint32_t delta_t_max_multiplier,
@@ -409,6 +445,7 @@ void Video::update_quality_manual(uint8_t c_thresh_baseline, uint8_t c_thresh_ma
         hip_check(ctx_, adder_hip_set_delta_t_max(ctx_, delta_t_max_));
         hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, c_thresh_baseline));
         px_c_thresh_reset_.reset();
+        sync_feature_controls();
     }
 }
 
@@ -434,6 +471,7 @@ void Video::ensure_ctx() {
         hip_check(ctx_, adder_hip_reset_c_thresh(ctx_, *px_c_thresh_reset_));
         px_c_thresh_reset_.reset();
     }
+    if (pixel_tree_mode_ == Mode::FramePerfect) sync_feature_controls();
 }
 
 std::vector<std::vector<Event>> Video::integrate_matrix(const Frame &matrix, float time_spanned) {

@@ -173,6 +173,12 @@ class Decoder {  // decoder.rs:22-29
     CodecMetadata meta_;
 };
 
+// utils/viz.rs:76-86 -- display only; kept so that update_detect_features reads like the reference's
+enum class ShowFeatureMode { Off, Instant, Hold };
+struct Roi {  // video.rs:219-223: start / end coordinates, inclusive
+    uint16_t start_x = 0, start_y = 0, end_x = 0, end_y = 0;
+};
+
 // ---------------------------------------------------------------- Video (video.rs:322-346)
 class Video {
   public:
@@ -195,6 +201,14 @@ class Video {
     void update_crf(uint8_t crf);      // :1241-1251
     void update_quality_manual(uint8_t c_thresh_baseline, uint8_t c_thresh_max, uint32_t delta_t_max_multiplier,
                                uint8_t c_increase_velocity, float feature_c_radius);  // :1264-1287
+    // :825-837 -- feature detection on the running intensities + c_thresh reset around new features
+    // (show_features / feature_cluster drive displays and are not kept)
+    void update_detect_features(bool detect_features, ShowFeatureMode show_features, bool feature_rate_adjustment,
+                                bool feature_cluster);
+    void update_roi(std::optional<Roi> roi);  // :1291-1293
+    // VideoState::features as a membership plane [h][w] (1 = feature), running_intensities [h][w][c]
+    std::vector<uint8_t> feature_set();
+    std::vector<uint8_t> running_intensities();
     EncoderOptions get_encoder_options() const { return encoder_->options; }
     TimeMode get_time_mode() const { return encoder_->meta().time_mode; }
     uint8_t get_event_size() const { return encoder_->meta().event_size; }
@@ -213,6 +227,9 @@ class Video {
 
   private:
     void ensure_ctx();  // (re)creates the device context once every builder call has been made
+    void sync_feature_controls();
+    bool feature_detection_ = false, feature_rate_adjustment_ = false;
+    std::optional<Roi> roi_;
     PlaneSize plane_;
     int device_id_;
     Mode pixel_tree_mode_ = Mode::FramePerfect;

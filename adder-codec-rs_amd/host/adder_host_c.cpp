@@ -68,6 +68,57 @@ long long adder_host_transcode(const uint8_t *frames, uint32_t num_frames, uint3
     }
 }
 
+// The same flow with the controls of adder-viz's transcoder tab (adder-viz/src/transcoder/adder.rs: update_crf /
+// update_detect_features / update_roi on the source's Video before the frames are consumed): feature-driven rate
+// control and an optional region of interest.  roi = {start_x, start_y, end_x, end_y} or null.  Writes a raw
+// file; feature_set_out (may be null) receives VideoState::features as [h][w] membership bytes.
+long long adder_host_transcode_features(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
+                                        uint32_t channels_in, int color_input, float fps, int crf,
+                                        uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,
+                                        uint32_t chunk_rows, int detect_features, int feature_rate_adjustment,
+                                        const uint16_t *roi, const char *out_path, uint8_t *feature_set_out) {
+    try {
+        FrameProvider cap;
+        cap.width = width;
+        cap.height = height;
+        cap.channels = channels_in;
+        cap.frame_rate = fps;
+        cap.frame_count = num_frames;
+        const size_t fsz = (size_t)width * height * channels_in;
+        cap.decode = [=](uint64_t idx, Frame &out) {
+            if (idx >= num_frames) return false;
+            out.assign(frames + idx * fsz, frames + (idx + 1) * fsz);
+            return true;
+        };
+        Framed source(cap, color_input != 0);
+        source.chunk_rows(chunk_rows ? chunk_rows : 1);
+        source.crf_builder((uint8_t)crf);
+        source.auto_time_parameters(ref_time, delta_t_max, std::nullopt);
+        std::ofstream file(out_path, std::ios::binary);
+        if (!file) throw SourceError(SourceError::BadParams, "cannot open output file");
+        const PlaneSize plane = source.get_video_ref().plane();
+        EncoderOptions opts = EncoderOptions::default_(plane);
+        opts.crf = Crf((uint8_t)crf, plane);
+        source.write_out(SourceCamera::FramedU8, (TimeMode)time_mode, (PixelMultiMode)multi_mode, std::nullopt,
+                         EncoderType::Raw, opts, &file);
+        Video &video = source.get_video_mut();
+        video.update_detect_features(detect_features != 0, ShowFeatureMode::Off, feature_rate_adjustment != 0, false);
+        if (roi) video.update_roi(Roi{roi[0], roi[1], roi[2], roi[3]});
+        long long total = 0;
+        for (uint32_t k = 0; k < num_frames; ++k)
+            for (auto &v : source.consume()) total += (long long)v.size();
+        if (feature_set_out) {
+            const std::vector<uint8_t> fs = video.feature_set();
+            memcpy(feature_set_out, fs.data(), fs.size());
+        }
+        video.end_write_stream();
+        return total;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
                                    uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
                                    uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,

@@ -106,6 +106,28 @@ int adder_hip_set_crf_parameters(AdderHipCtx *ctx, uint8_t c_thresh_max, uint8_t
 /* Per-pixel reset performed by update_crf / update_quality_manual (video.rs:1247-1250,
  * :1283-1286): every pixel's c_thresh = baseline, c_increase_counter = 0. */
 int adder_hip_reset_c_thresh(AdderHipCtx *ctx, uint8_t c_thresh_baseline);
+/* ---- Feature-driven rate control and ROI.  The only cross-pixel coupling of the transcoder: after
+ * each frame's events exist, the FAST 9_16 corner test (utils/cv.rs:56-212) runs on the running intensities at the
+ * pixels that fired (video.rs:883-1085), VideoState::features is updated, and -- with feature_rate_adjustment
+ * and a radius > 0 -- every pixel within feature_c_radius of a NEW feature gets c_thresh = min(c_thresh_baseline,
+ * 2) (:1089-1105); handle_roi (:866-882) does the same for the region of interest after every frame.  From then
+ * on c_thresh differs between pixels, so the context switches (until adder_hip_reset / adder_hip_reset_c_thresh) to
+ * the generic kernels with one (c_thresh, c_increase_counter) pair per pixel, and steps frame by frame.  The
+ * context must own the whole plane (row_begin = 0, row_end = height).
+ * Video::update_detect_features (video.rs:825-837; show_features / feature_cluster only drive displays): */
+int adder_hip_update_detect_features(AdderHipCtx *ctx, int detect_features, int feature_rate_adjustment);
+/* CrfParameters::{c_thresh_baseline, feature_c_radius} (rate_controller.rs:40-53; update_quality_manual
+ * video.rs:1264-1279).  Defaults: Crf::new(None) = quality 3: baseline 2, radius min(width, height) / 15. */
+int adder_hip_set_feature_parameters(AdderHipCtx *ctx, uint8_t c_thresh_baseline, uint16_t feature_c_radius);
+/* Video::update_roi (video.rs:1291-1293); Roi {start, end} inclusive, plane coordinates. */
+int adder_hip_update_roi(AdderHipCtx *ctx, int enable, uint16_t start_x, uint16_t start_y, uint16_t end_x,
+                         uint16_t end_y);
+/* VideoState::features as a membership plane: dst = [rows][width] bytes, 1 = the pixel is a feature. */
+int adder_hip_feature_set(AdderHipCtx *ctx, uint8_t *dst);
+/* every pixel's c_thresh as the NEXT frame will test it: dst = [rows][width][channels] bytes */
+int adder_hip_c_thresh_plane(AdderHipCtx *ctx, uint8_t *dst);
+/* features the last finished batch found new (diagnostics) */
+uint32_t adder_hip_last_new_features(const AdderHipCtx *ctx);
 /* update_quality_manual's delta_t_max = multiplier * ref_time (video.rs:1280). */
 int adder_hip_set_delta_t_max(AdderHipCtx *ctx, uint32_t delta_t_max);
 /* time_parameters / write_out `px.time_mode(..)` (video.rs:499-503,632-634); only

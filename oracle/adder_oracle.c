@@ -572,6 +572,17 @@ typedef struct {
     EventVec *chunk_ev; /* per row-chunk buffers */
     size_t num_chunks;
     int threads;
+    /* feature-driven rate control (video.rs:196-216, 865-1112): VideoState.feature_detection,
+     * feature_rate_adjustment, features (one HashSet<Coord> per chunk: a coordinate belongs to one chunk, so a
+     * plane-sized membership map is the same thing), roi; CrfParameters.{c_thresh_baseline, feature_c_radius} */
+    int feature_detection, feature_rate_adjustment;
+    uint8_t *feature_set; /* [h][w] */
+    uint32_t *new_features; /* x | y << 16 of the features found new by the last frame */
+    size_t n_new_features, new_features_cap;
+    int has_roi;
+    uint16_t roi_x0, roi_y0, roi_x1, roi_y1;
+    uint8_t c_thresh_baseline;
+    uint16_t feature_c_radius;
 } OracleVideo;
 
 /* video.rs:350-438 (Video::new), :471-479 (chunk_rows), :493-537 (time_parameters),
@@ -620,6 +631,8 @@ void oracle_video_free(OracleVideo *v) {
     free(v->chunk_ev);
     free(v->px);
     free(v->running_intensities);
+    free(v->feature_set);
+    free(v->new_features);
     free(v);
 }
 
@@ -660,6 +673,157 @@ static uint8_t frame_value_u8(uint8_t d, uint32_t t, double tpf) {
     if (!(val > 0.0)) return 0;
     if (val >= 255.0) return 255;
     return (uint8_t)val;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Feature-driven rate control: utils/cv.rs:19-212 (FAST 9_16 on the running     */
+/* intensities), video.rs:865-1112 (handle_features), :866-882 (handle_roi)      */
+/* ------------------------------------------------------------------------- */
+#define FAST_INTENSITY_THRESHOLD 30 /* cv.rs:21 */
+#define FAST_STREAK_SIZE 9          /* cv.rs:32 */
+static const int FAST_CIRCLE3[16][2] = {/* cv.rs:25-30: [dx, dy] */
+    {0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+    {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+/* THRESHOLD_TABLE[i + 255] (cv.rs:34-50) */
+static uint8_t fast_tab(int i) { return i < -FAST_INTENSITY_THRESHOLD ? 1 : (i > FAST_INTENSITY_THRESHOLD ? 2 : 0); }
+
+/* cv.rs:56-212 is_feature: img = running intensities [h][w][c], channel 0 is looked at */
+static int fast_is_feature(const uint8_t *img, uint32_t w, uint32_t h, uint32_t channels, uint32_t x, uint32_t y,
+                           uint32_t c) {
+    if (x < 3 || x >= w - 3 || y < 3 || y >= h - 3 || c != 0) return 0; /* Coord::is_border(.., 3) */
+#define FAST_PX(k) ((int)img[((size_t)(y + FAST_CIRCLE3[(k)][1]) * w + (x + FAST_CIRCLE3[(k)][0])) * channels])
+    const int candidate = (int)img[((size_t)y * w + x) * channels];
+    /* tab = &THRESHOLD_TABLE[-candidate + 255]; *tab.offset(p) = THRESHOLD_TABLE[p - candidate + 255] */
+#define FAST_T(k) fast_tab(FAST_PX(k) - candidate)
+    int d = FAST_T(0) | FAST_T(8);
+    if (d == 0) return 0;
+    d &= FAST_T(2) | FAST_T(10);
+    d &= FAST_T(4) | FAST_T(12);
+    d &= FAST_T(6) | FAST_T(14);
+    if (d == 0) return 0;
+    d &= FAST_T(1) | FAST_T(9);
+    d &= FAST_T(3) | FAST_T(11);
+    d &= FAST_T(5) | FAST_T(13);
+    d &= FAST_T(7) | FAST_T(15);
+    if (d & 1) { /* a dark streak */
+        const int vt = candidate - FAST_INTENSITY_THRESHOLD;
+        int count = 0;
+        for (int k = 0; k < 16; k++) {
+            if (FAST_PX(k) < vt) {
+                if (++count == FAST_STREAK_SIZE) return 1;
+            } else {
+                count = 0;
+            }
+        }
+        for (int k = 16; k < 25; k++) {
+            if (FAST_PX(k - 16) < vt) {
+                if (++count == FAST_STREAK_SIZE) return 1;
+            } else {
+                count = 0;
+                if (k == 17) return 0;
+            }
+        }
+    }
+    if (d & 2) { /* a bright streak */
+        const int vt = candidate + FAST_INTENSITY_THRESHOLD;
+        int count = 0;
+        for (int k = 0; k < 16; k++) {
+            if (FAST_PX(k) > vt) {
+                if (++count == FAST_STREAK_SIZE) return 1;
+            } else {
+                count = 0;
+            }
+        }
+        for (int k = 16; k < 25; k++) {
+            if (FAST_PX(k - 16) > vt) {
+                if (++count == FAST_STREAK_SIZE) return 1;
+            } else {
+                count = 0;
+                if (k == 17) return 0;
+            }
+        }
+    }
+#undef FAST_T
+#undef FAST_PX
+    return 0;
+}
+int oracle_fast_is_feature(const uint8_t *img, uint32_t w, uint32_t h, uint32_t channels, uint32_t x, uint32_t y) {
+    return fast_is_feature(img, w, h, channels, x, y, 0);
+}
+
+/* video.rs:883-1112 handle_features (the logging / display / clustering branches left out: they do not feed back) */
+static void handle_features(OracleVideo *v) {
+    if (!v->feature_detection) return;
+    v->n_new_features = 0;
+    for (size_t ch = 0; ch < v->num_chunks; ch++) {
+        const EventVec *ev = &v->chunk_ev[ch];
+        for (size_t i = 0; i < ev->len; i++) { /* circular_tuple_windows: (e[i], e[(i + 1) % len]) */
+            const OracleEvent *e1 = &ev->data[i], *e2 = &ev->data[(i + 1) % ev->len];
+            const int same = e1->x == e2->x && e1->y == e2->y && e1->c == e2->c;
+            if ((e1->c == 0xFF || e1->c == 0) && !same && e1->d != D_EMPTY) {
+                const uint32_t x = e1->x, y = e1->y - v->row_begin;
+                uint8_t *member = &v->feature_set[(size_t)y * v->width + x];
+                if (fast_is_feature(v->running_intensities, v->width, v->height, v->channels, x, y, 0)) {
+                    if (!*member) { /* feature_set.insert(coord) returned true */
+                        *member = 1;
+                        if (v->n_new_features == v->new_features_cap) {
+                            v->new_features_cap = v->new_features_cap ? v->new_features_cap * 2 : 256;
+                            v->new_features = (uint32_t *)realloc(v->new_features, v->new_features_cap * sizeof(uint32_t));
+                        }
+                        v->new_features[v->n_new_features++] = x | (y << 16);
+                    }
+                } else {
+                    *member = 0; /* feature_set.remove(coord) */
+                }
+            }
+        }
+    }
+    if (v->feature_rate_adjustment && v->feature_c_radius > 0) { /* :1089-1105 */
+        const int radius = (int)v->feature_c_radius;
+        const uint8_t low = v->c_thresh_baseline < 2 ? v->c_thresh_baseline : 2;
+        for (size_t f = 0; f < v->n_new_features; f++) {
+            const int fx = (int)(v->new_features[f] & 0xffffu), fy = (int)(v->new_features[f] >> 16);
+            for (int row = fy - radius < 0 ? 0 : fy - radius; row <= (fy + radius > (int)v->height - 1 ? (int)v->height - 1 : fy + radius); row++)
+                for (int col = fx - radius < 0 ? 0 : fx - radius; col <= (fx + radius > (int)v->width - 1 ? (int)v->width - 1 : fx + radius); col++)
+                    for (uint32_t c = 0; c < v->channels; c++)
+                        v->px[((size_t)row * v->width + col) * v->channels + c].c_thresh = low;
+        }
+    }
+}
+
+/* video.rs:866-882 handle_roi */
+static void handle_roi(OracleVideo *v) {
+    if (!v->has_roi) return;
+    const uint8_t low = v->c_thresh_baseline < 2 ? v->c_thresh_baseline : 2;
+    for (uint32_t y = v->roi_y0; y <= v->roi_y1 && y < v->height; y++)
+        for (uint32_t x = v->roi_x0; x <= v->roi_x1 && x < v->width; x++)
+            for (uint32_t c = 0; c < v->channels; c++) v->px[((size_t)y * v->width + x) * v->channels + c].c_thresh = low;
+}
+
+/* Video::update_detect_features (:825-840); CrfParameters.{c_thresh_baseline, feature_c_radius} (rate_controller.rs:40-53) */
+void oracle_video_update_detect_features(OracleVideo *v, int detect, int rate_adjustment, uint8_t c_thresh_baseline,
+                                         uint16_t feature_c_radius) {
+    v->feature_detection = detect;
+    v->feature_rate_adjustment = rate_adjustment;
+    v->c_thresh_baseline = c_thresh_baseline;
+    v->feature_c_radius = feature_c_radius;
+    if (!v->feature_set) v->feature_set = (uint8_t *)calloc((size_t)v->width * v->height, 1);
+}
+void oracle_video_set_roi(OracleVideo *v, int enable, uint16_t x0, uint16_t y0, uint16_t x1, uint16_t y1,
+                          uint8_t c_thresh_baseline) {
+    v->has_roi = enable;
+    v->roi_x0 = x0; v->roi_y0 = y0; v->roi_x1 = x1; v->roi_y1 = y1;
+    v->c_thresh_baseline = c_thresh_baseline;
+}
+size_t oracle_video_new_features(const OracleVideo *v, uint32_t *out, size_t cap) {
+    for (size_t i = 0; i < v->n_new_features && i < cap; i++) out[i] = v->new_features[i];
+    return v->n_new_features;
+}
+const uint8_t *oracle_video_feature_set(const OracleVideo *v) { return v->feature_set; }
+void oracle_video_c_thresh_plane(const OracleVideo *v, uint8_t *out) {
+    size_t n = (size_t)v->width * v->height * v->channels;
+    for (size_t i = 0; i < n; i++) out[i] = v->px[i].c_thresh;
 }
 
 /* video.rs:651-778.  frame = [h][w][c] u8 with row stride in bytes.  Events are
@@ -705,6 +869,8 @@ size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_
     }
     if (chunk_offsets) chunk_offsets[v->num_chunks] = (uint32_t)total;
     if (n_out) *n_out = total;
+    handle_features(v); /* video.rs:744 */
+    handle_roi(v);      /* video.rs:776 */
     if (!out) return total; /* events stay in the chunk buffers */
     if (total > out_cap) return (size_t)-1;
     size_t off = 0;

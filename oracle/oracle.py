@@ -85,6 +85,15 @@ def lib():
     L.oracle_video_set_time_mode.argtypes = [vp, i32]
     L.oracle_video_set_threads.argtypes = [vp, i32]
     L.oracle_video_set_pixel_mode.argtypes = [vp, i32]
+    L.oracle_video_update_detect_features.argtypes = [vp, i32, i32, u8, u16]
+    L.oracle_video_set_roi.argtypes = [vp, i32, u16, u16, u16, u16, u8]
+    L.oracle_video_new_features.restype = sz
+    L.oracle_video_new_features.argtypes = [vp, vp, sz]
+    L.oracle_video_feature_set.restype = vp
+    L.oracle_video_feature_set.argtypes = [vp]
+    L.oracle_video_c_thresh_plane.argtypes = [vp, vp]
+    L.oracle_fast_is_feature.restype = i32
+    L.oracle_fast_is_feature.argtypes = [vp, u32, u32, u32, u32, u32]
     L.oracle_video_running_intensities.restype = vp
     L.oracle_video_running_intensities.argtypes = [vp]
     L.oracle_video_integrate_matrix.restype = sz
@@ -237,6 +246,32 @@ class Video:
 
     def set_threads(self, n):
         self.L.oracle_video_set_threads(self.h, n)
+
+    def update_detect_features(self, detect, rate_adjustment, c_thresh_baseline, feature_c_radius):
+        """Video::update_detect_features + the CrfParameters the feedback uses (video.rs:825-840, 1085-1105)."""
+        self.L.oracle_video_update_detect_features(self.h, int(detect), int(rate_adjustment), c_thresh_baseline,
+                                                   feature_c_radius)
+
+    def set_roi(self, roi, c_thresh_baseline):
+        if roi is None:
+            self.L.oracle_video_set_roi(self.h, 0, 0, 0, 0, 0, c_thresh_baseline)
+        else:
+            self.L.oracle_video_set_roi(self.h, 1, roi[0], roi[1], roi[2], roi[3], c_thresh_baseline)
+
+    def new_features(self):
+        buf = np.zeros(self.width * self.height, np.uint32)
+        n = self.L.oracle_video_new_features(self.h, buf.ctypes.data, len(buf))
+        return buf[:n].copy()
+
+    def feature_set(self):
+        p = self.L.oracle_video_feature_set(self.h)
+        n = self.width * self.height
+        return np.frombuffer((C.c_uint8 * n).from_address(p), dtype=np.uint8).reshape(self.height, self.width).copy()
+
+    def c_thresh_plane(self):
+        out = np.zeros(self.width * self.height * self.channels, np.uint8)
+        self.L.oracle_video_c_thresh_plane(self.h, out.ctypes.data)
+        return out.reshape(self.height, self.width, self.channels)
 
     def set_pixel_mode(self, mode):
         """0 = Mode::FramePerfect (default), 1 = Mode::Continuous (lib.rs:196-205)."""

@@ -33,4 +33,22 @@ def make_clip(kind, frames, H, W, C, seed):
             cur = np.where(change, newv, cur)
             out[k] = cur
         return out
+    if kind == "corners":  # bright / dark rectangles drifting over a textured background: FAST corners that move
+        out = np.zeros(shape, np.uint8)
+        bg = rng.integers(90, 110, (H, W, C)).astype(np.int64)
+        nrect = max(2, (H * W) // 400)
+        rx = rng.integers(0, W, nrect).astype(np.float64)
+        ry = rng.integers(0, H, nrect).astype(np.float64)
+        rw = rng.integers(5, max(6, W // 3), nrect)
+        rh = rng.integers(5, max(6, H // 3), nrect)
+        vx = rng.uniform(-0.7, 0.7, nrect)
+        vy = rng.uniform(-0.7, 0.7, nrect)
+        val = rng.choice(np.array([5, 20, 200, 250]), nrect)
+        for k in range(frames):
+            img = bg + rng.integers(-2, 3, (H, W, C))
+            for r in range(nrect):
+                x0, y0 = int(rx[r] + vx[r] * k) % W, int(ry[r] + vy[r] * k) % H
+                img[y0:min(H, y0 + rh[r]), x0:min(W, x0 + rw[r])] = val[r]
+            out[k] = np.clip(img, 0, 255).astype(np.uint8)
+        return out
     raise ValueError(kind)

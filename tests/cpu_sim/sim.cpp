@@ -45,6 +45,11 @@ struct Sim {
     std::vector<uint32_t> c_hdr, c_meta;           // [unit], [node][unit]
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
     uint64_t fast_steps, generic_steps, lean_steps;
+    // feature-driven rate control (the kernel-side flow of adder_feature_kernel, serially)
+    int feat_detect, feat_adjust, roi_on, perpx;
+    uint32_t baseline, radius, chunk_rows, roi[4];
+    std::vector<uint8_t> cth_px, cctr_px, running, fset;
+    uint32_t new_features;
 };
 
 struct DeepAcc {
@@ -131,6 +136,11 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->generic_sticky = 0;
     s->continuous = 0;
     s->fast_steps = s->generic_steps = s->lean_steps = 0;
+    s->feat_detect = s->feat_adjust = s->roi_on = s->perpx = 0;
+    s->baseline = 2; s->radius = 0; s->chunk_rows = 1;
+    s->running.assign(s->N, 0);
+    s->fset.assign((size_t)W * H, 0);
+    s->new_features = 0;
     return s;
 }
 void sim_free(Sim *s) { delete s; }
@@ -144,11 +154,30 @@ void sim_set_continuous(Sim *s) {
     s->c_dt.assign(s->N * nodes, 0.0f);
     s->c_bdt.assign(s->N * nodes, 0.0f);
 }
+// the device header's corner test, a whole plane at once: out[y][x] = fast9_is_feature
+void sim_fast9_plane(const uint8_t *img, uint32_t w, uint32_t h, uint32_t channels, uint8_t *out) {
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) out[(size_t)y * w + x] = fast9_is_feature(img, w, h, channels, x, y) ? 1 : 0;
+}
 void sim_set_crf_parameters(Sim *s, uint8_t c_max, uint8_t velocity) { s->c_max = c_max; s->velocity = velocity; }
 void sim_reset_c_thresh(Sim *s, uint8_t baseline) {
     s->c_thresh = baseline;
     s->c_counter = 0;
+    s->perpx = 0;
 }
+void sim_update_detect_features(Sim *s, int detect, int adjust, uint32_t baseline, uint32_t radius, uint32_t chunk_rows) {
+    s->feat_detect = detect; s->feat_adjust = adjust; s->baseline = baseline; s->radius = radius;
+    s->chunk_rows = chunk_rows ? chunk_rows : 1;
+}
+void sim_update_roi(Sim *s, int on, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t baseline) {
+    s->roi_on = on; s->roi[0] = x0; s->roi[1] = y0; s->roi[2] = x1; s->roi[3] = y1; s->baseline = baseline;
+}
+void sim_feature_set(const Sim *s, uint8_t *out) { memcpy(out, s->fset.data(), s->fset.size()); }
+void sim_c_thresh_plane(const Sim *s, uint8_t *out) {
+    if (s->perpx) memcpy(out, s->cth_px.data(), s->N);
+    else memset(out, s->c_thresh, s->N);
+}
+uint32_t sim_new_features(const Sim *s) { return s->new_features; }
 void sim_set_delta_t_max(Sim *s, uint32_t dtm) { s->dtm = dtm; }
 uint64_t sim_plan_mismatches(const Sim *s) { return s->plan_mismatch; }
 uint32_t sim_max_m(const Sim *s) { return s->max_m; }
@@ -172,7 +201,15 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
     sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
     // the product's variant choice (adder_hip_api.cpp enqueue_frames): lean iff Collapse with
     // delta_t_max <= time_spanned and no generic batch has run since the last reset
-    const bool lean = s->collapse && (float)s->dtm <= time_spanned && !s->generic_sticky && s->use_fast;
+    // feature path (adder_hip_api.cpp prepare_per_unit_c_thresh): one pair per unit from the first frame that can
+    // make them differ
+    const bool needs_perpx = s->roi_on || (s->feat_detect && s->feat_adjust && s->radius > 0);
+    if (needs_perpx && !s->perpx) {
+        s->cth_px.assign(s->N, s->c_thresh);
+        s->cctr_px.assign(s->N, s->c_counter);
+        s->perpx = 1;
+    }
+    const bool lean = s->collapse && (float)s->dtm <= time_spanned && !s->generic_sticky && s->use_fast && !s->perpx;
     if (!lean) s->generic_sticky = 1;
     int rc = 0;
     Emitter em;
@@ -200,6 +237,11 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                     if (p.length > s->max_m) s->max_m = p.length;
                     continue;
                 }
+                if (s->perpx) {
+                    sc.cth = s->cth_px[u];
+                    c_thresh_advance(s->cth_px[u], s->cctr_px[u], (uint8_t)s->c_max, (uint8_t)s->velocity, time_spanned,
+                                     s->ref_time);
+                }
                 if (lean) {
                     LeanPx p = lean_unpack<ScalarLanes>(hdr, gi, gd, gb, glf);
                     LeanRec rec;
@@ -221,6 +263,9 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                     if (p.has0) { s->integ0[u] = p.integ; s->dt0[u] = p.dt; s->bdt0[u] = p.bdt; }
                     if (s->abs_t) s->lastf[u] = p.lastf;
                     if (p.has0 && s->max_m < 1) s->max_m = 1;
+                    if (p.has0)  // the side plane as adder_lean1_kernel writes it
+                        s->running[u] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(p.thr)), f32_as_u32(p.bdt),
+                                                               (double)s->ref_time);
                     s->lean_steps++;
                     continue;
                 }
@@ -239,7 +284,41 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                 if (m > s->max_m) s->max_m = m;
                 if (m > 0) { s->integ0[u] = p.n0.integ; s->dt0[u] = p.n0.dt; s->bdt0[u] = p.n0.bdt; }
                 if (s->abs_t) s->lastf[u] = p.lastf;
+                if (m != 0u) s->running[u] = (uint8_t)frame_value_u8(p.n0.bd, f32_as_u32(p.n0.bdt), (double)s->ref_time);
             }
+    // ---- adder_feature_kernel, serially ----
+    if (s->feat_detect && em.pos <= cap) {
+        const uint32_t low = s->baseline < 2 ? s->baseline : 2;
+        const uint32_t radius = s->feat_adjust ? s->radius : 0u;
+        for (uint64_t i = 0; i < em.pos; ++i) {
+            if (!feature_looked_at(out, 0, em.pos, i, s->row_begin, s->chunk_rows)) continue;
+            const uint32_t x = out[i].x, y = out[i].y - s->row_begin;
+            uint8_t *member = &s->fset[(size_t)y * s->W + x];
+            if (fast9_is_feature(s->running.data(), s->W, s->H, s->C, x, y)) {
+                const bool is_new = *member == 0;
+                *member = 1;
+                if (is_new) {
+                    s->new_features++;
+                    if (radius) {
+                        const uint32_t x0 = x > radius ? x - radius : 0u, y0 = y > radius ? y - radius : 0u;
+                        const uint32_t x1 = x + radius < s->W - 1 ? x + radius : s->W - 1;
+                        const uint32_t y1 = y + radius < s->H - 1 ? y + radius : s->H - 1;
+                        for (uint32_t yy = y0; yy <= y1; ++yy)
+                            for (uint32_t xx = x0; xx <= x1; ++xx)
+                                for (uint32_t cc = 0; cc < s->C; ++cc) s->cth_px[((size_t)yy * s->W + xx) * s->C + cc] = (uint8_t)low;
+                    }
+                }
+            } else {
+                *member = 0;
+            }
+        }
+    }
+    if (s->roi_on) {
+        const uint32_t low = s->baseline < 2 ? s->baseline : 2;
+        for (uint32_t yy = s->roi[1]; yy <= s->roi[3] && yy < s->H; ++yy)
+            for (uint32_t xx = s->roi[0]; xx <= s->roi[2] && xx < s->W; ++xx)
+                for (uint32_t cc = 0; cc < s->C; ++cc) s->cth_px[((size_t)yy * s->W + xx) * s->C + cc] = (uint8_t)low;
+    }
     s->running_t += time_spanned;
     c_thresh_advance(s->c_thresh, s->c_counter, (uint8_t)s->c_max, (uint8_t)s->velocity, time_spanned, s->ref_time);
     *n_out = em.pos;

@@ -25,6 +25,10 @@ def lib():
         L.adder_host_transcode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                            C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                            C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32)]
+        L.adder_host_transcode_features.restype = C.c_longlong
+        L.adder_host_transcode_features.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                    C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                    C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p]
         L.adder_host_decode_raw.restype = C.c_longlong
         L.adder_host_decode_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.adder_host_crf_parameters.restype = C.c_int
@@ -99,6 +103,21 @@ def transcode_raw(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, 
     if n < 0:
         raise RuntimeError(err())
     return n, chunks.value
+
+
+def transcode_features(frames, *, color_input=False, fps=30.0, crf=3, ref_time=255, delta_t_max=7650, time_mode=1,
+                       multi_mode=1, chunk_rows=1, detect=True, rate_adjustment=True, roi=None, out_path=None):
+    """Framed + update_detect_features / update_roi on its Video -> raw file; returns (events, feature set)."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    T, H, W, Cin = frames.shape
+    fs = np.zeros((H, W), np.uint8)
+    r = None if roi is None else (C.c_uint16 * 4)(*roi)
+    n = lib().adder_host_transcode_features(frames.ctypes.data, T, W, H, Cin, int(color_input), fps, crf,
+                                            ref_time, delta_t_max, time_mode, multi_mode, chunk_rows, int(detect),
+                                            int(rate_adjustment), r, out_path.encode(), fs.ctypes.data)
+    if n < 0:
+        raise RuntimeError(err())
+    return n, fs
 
 
 def transcode_compressed(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, delta_t_max=7650, time_mode=1,

@@ -35,6 +35,13 @@ def lib():
     L.sim_free.argtypes = [vp]
     L.sim_set_crf_parameters.argtypes = [vp, u8, u8]
     L.sim_set_continuous.argtypes = [vp]
+    L.sim_fast9_plane.argtypes = [vp, u32, u32, u32, vp]
+    L.sim_update_detect_features.argtypes = [vp, i32, i32, u32, u32, u32]
+    L.sim_update_roi.argtypes = [vp, i32, u32, u32, u32, u32, u32]
+    L.sim_feature_set.argtypes = [vp, vp]
+    L.sim_c_thresh_plane.argtypes = [vp, vp]
+    L.sim_new_features.restype = u32
+    L.sim_new_features.argtypes = [vp]
     L.sim_reset_c_thresh.argtypes = [vp, u8]
     L.sim_set_delta_t_max.argtypes = [vp, u32]
     L.sim_plan_mismatches.restype = C.c_uint64
@@ -54,6 +61,16 @@ def lib():
     L.sim_framer_run.argtypes = [vp, sz, u32, u32, u32, u32, u32, u32, u32, vp, sz]
     _lib = L
     return L
+
+
+def fast9_plane(img):
+    """fast9_is_feature (adder_pixel.hpp) at every pixel of img = [h][w] or [h][w][c] u8."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.zeros((h, w), np.uint8)
+    lib().sim_fast9_plane(img.ctypes.data, w, h, ch, out.ctypes.data)
+    return out
 
 
 def framer_run(events, width, height, channels, *, tpf, ref_interval, abs_t, round_up, max_frames=4096):
@@ -93,6 +110,29 @@ class Sim:
 
     def set_delta_t_max(self, dtm):
         self.L.sim_set_delta_t_max(self.h, dtm)
+
+    def update_detect_features(self, detect, adjust, baseline, radius, chunk_rows=1):
+        self.L.sim_update_detect_features(self.h, int(detect), int(adjust), baseline, radius, chunk_rows)
+
+    def update_roi(self, roi, baseline):
+        if roi is None:
+            self.L.sim_update_roi(self.h, 0, 0, 0, 0, 0, baseline)
+        else:
+            self.L.sim_update_roi(self.h, 1, *[int(v) for v in roi], baseline)
+
+    def feature_set(self, width, height):
+        out = np.zeros((height, width), np.uint8)
+        self.L.sim_feature_set(self.h, out.ctypes.data)
+        return out
+
+    def c_thresh_plane(self):
+        out = np.zeros(self.n, np.uint8)
+        self.L.sim_c_thresh_plane(self.h, out.ctypes.data)
+        return out
+
+    @property
+    def new_features(self):
+        return self.L.sim_new_features(self.h)
 
     def set_use_fast(self, on):
         self.L.sim_set_use_fast(self.h, int(on))

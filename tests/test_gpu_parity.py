@@ -783,3 +783,161 @@ def test_continuous_mode_kernel(multi_mode, time_mode):
         assert np.array_equal(got, np.concatenate(want)), kind
         assert [int(offs[i + 1] - offs[i]) for i in range(40)] == [len(w) for w in want]
         assert total + len(got) > 0
+
+
+def _feature_pair(A, W, H, Cn, *, multi_mode, dtm, time_mode=O.ABSOLUTE_T, chunk_rows=1, crf=(13, 4), baseline=6,
+                  detect=True, adjust=True, radius=3, roi=None, max_depth=30):
+    ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm,
+                 chunk_rows=chunk_rows)
+    hv = A.HipVideo(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=255, delta_t_max=dtm,
+                    chunk_rows=chunk_rows, max_depth=max_depth)
+    ov.ensure_capacity(max_depth + 2)
+    for v in (ov, hv):
+        v.set_crf_parameters(*crf)
+        v.reset_c_thresh(baseline)
+    ov.update_detect_features(detect, adjust, baseline, radius)
+    ov.set_roi(roi, baseline)
+    hv.update_detect_features(detect, adjust)
+    hv.set_feature_parameters(baseline, radius)
+    hv.update_roi(roi)
+    return ov, hv
+
+
+def _same_feature_state(ov, hv, detect=True):
+    assert np.array_equal(hv.c_thresh_plane(), ov.c_thresh_plane())
+    if detect:
+        assert np.array_equal(hv.feature_set(), ov.feature_set())
+        assert np.array_equal(hv.running_intensities(), ov.running_intensities())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("multi_mode,dtm", [(O.COLLAPSE, 255), (O.COLLAPSE, 7650), (O.NORMAL, 2550)])
+@pytest.mark.parametrize("channels", [1, 3])
+def test_feature_driven_rate_control(multi_mode, dtm, channels):
+    """SURVEY 8(f)4: FAST 9_16 on the running intensities at the pixels that fired, VideoState::features, and the
+    c_thresh reset around new features (adder_feature_kernel + the per-pixel c_thresh planes of the generic K1)
+    against the oracle's handle_features -- per-frame calls, then a batch (frame f+1 must see frame f's resets
+    inside ONE C-ABI call), ragged planes, row chunks of several sizes."""
+    A = _hip()
+    for (H, W, chunk_rows, tm) in [(40, 56, 1, O.ABSOLUTE_T), (67, 131, 5, O.DELTA_T)]:
+        clip = clips.make_clip("corners", 40, H, W, channels, seed=H + channels)
+        ov, hv = _feature_pair(A, W, H, channels, multi_mode=multi_mode, dtm=dtm, time_mode=tm, chunk_rows=chunk_rows)
+        new = 0
+        for k in range(14):
+            a, ca = ov.integrate_matrix(clip[k], want_chunks=True)
+            b, cb = hv.integrate_matrix(clip[k], want_chunks=True)
+            assert np.array_equal(a, b) and np.array_equal(ca, cb), k
+            assert hv.last_new_features() == len(ov.new_features()), k
+            new += len(ov.new_features())
+            if k % 4 == 0:
+                _same_feature_state(ov, hv)
+        assert new > 20
+        want = []
+        batch_new = 0
+        for f in clip[14:]:
+            want.append(ov.integrate_matrix(f))
+            batch_new += len(ov.new_features())
+        got, offs = hv.integrate_batch(clip[14:])
+        assert np.array_equal(got, np.concatenate(want))
+        assert [int(offs[i + 1] - offs[i]) for i in range(len(want))] == [len(w) for w in want]
+        assert hv.last_new_features() == batch_new
+        _same_feature_state(ov, hv)
+
+
+@pytest.mark.gpu
+def test_feature_detection_without_adjustment_keeps_the_lean_kernel_and_the_stream():
+    A = _hip()
+    clip = clips.make_clip("corners", 24, 48, 64, 1, seed=3)
+    ov, hv = _feature_pair(A, 64, 48, 1, multi_mode=O.COLLAPSE, dtm=255, adjust=False)
+    plain = A.HipVideo(64, 48, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255,
+                       max_depth=30)
+    plain.set_crf_parameters(13, 4)
+    plain.reset_c_thresh(6)
+    want = [ov.integrate_matrix(f) for f in clip]
+    got, _ = hv.integrate_batch(clip)
+    ref, _ = plain.integrate_batch(clip)
+    assert np.array_equal(got, np.concatenate(want)) and np.array_equal(got, ref)
+    _same_feature_state(ov, hv)
+    assert ov.feature_set().sum() > 0 and len(np.unique(hv.c_thresh_plane())) == 1
+
+
+@pytest.mark.gpu
+def test_roi_and_mode_switches_mid_stream():
+    """update_roi / update_detect_features / update_crf between calls: uniform thresholds -> per-pixel (ROI) ->
+    features on top -> update_crf makes them uniform again (video.rs:1241-1251), all against the oracle."""
+    A = _hip()
+    W, H = 72, 50
+    clip = clips.make_clip("corners", 50, H, W, 1, seed=21)
+    ov, hv = _feature_pair(A, W, H, 1, multi_mode=O.COLLAPSE, dtm=255, detect=False, adjust=False, radius=0,
+                           baseline=9, crf=(20, 2))
+    def step(lo, hi, detect):
+        want = [ov.integrate_matrix(f) for f in clip[lo:hi]]
+        got, _ = hv.integrate_batch(clip[lo:hi])
+        assert np.array_equal(got, np.concatenate(want)), (lo, hi)
+        _same_feature_state(ov, hv, detect)
+    step(0, 10, False)  # lean kernel, uniform
+    roi = (10, 8, 40, 30)
+    ov.set_roi(roi, 9)
+    hv.update_roi(roi)
+    step(10, 20, False)
+    assert (hv.c_thresh_plane()[8:31, 10:41] == 2).all()
+    ov.update_detect_features(True, True, 9, 5)
+    hv.update_detect_features(True, True)
+    hv.set_feature_parameters(9, 5)
+    step(20, 32, True)
+    ov.set_roi(None, 9)
+    hv.update_roi(None)
+    step(32, 40, True)
+    # update_crf(6): baseline 7, max 13, velocity 4, every pixel back to the baseline; features stay on
+    ov.set_crf_parameters(13, 4)
+    ov.reset_c_thresh(7)
+    ov.update_detect_features(True, True, 7, A.video.crf_feature_radius(6, W, H))
+    hv.update_crf(6)
+    step(40, 50, True)
+
+
+@pytest.mark.gpu
+def test_features_at_1080p_default_radius():
+    """Full plane, the default feature radius of quality 3 (1080 / 15 = 72 px): thousands of new features on the
+    first frames, each resetting a 145 x 145 neighbourhood."""
+    A = _hip()
+    W, H = 1920, 1080
+    clip = clips.make_clip("corners", 5, H, W, 1, seed=1)
+    ov, hv = _feature_pair(A, W, H, 1, multi_mode=O.COLLAPSE, dtm=255, chunk_rows=64, crf=(7, 7), baseline=2,
+                           radius=A.video.crf_feature_radius(3, W, H))
+    ov.set_threads(8)
+    want = []
+    new = 0
+    for f in clip:
+        want.append(ov.integrate_matrix(f))
+        new += len(ov.new_features())
+    got, offs = hv.integrate_batch(clip)
+    assert np.array_equal(got, np.concatenate(want))
+    assert hv.last_new_features() == new and new > 1000
+    _same_feature_state(ov, hv)
+
+
+@pytest.mark.gpu
+def test_feature_path_errors_and_rollback():
+    A = _hip()
+    band = A.HipVideo(64, 48, 1, row_begin=8, row_end=40)
+    with pytest.raises(A.AdderHipError):
+        band.update_detect_features(True, True)
+    with pytest.raises(A.AdderHipError):
+        band.update_roi((1, 1, 5, 5))
+    cont = A.HipVideo(64, 48, 1, pixel_mode=1)
+    with pytest.raises(A.AdderHipError):
+        cont.update_detect_features(True, False)
+    # an event buffer that is too small: the per-pixel thresholds, the feature set and the side plane roll back too
+    clip = clips.make_clip("corners", 20, 40, 56, 1, seed=13)
+    ov, hv = _feature_pair(A, 56, 40, 1, multi_mode=O.COLLAPSE, dtm=255)
+    want = [ov.integrate_matrix(f) for f in clip]
+    got, _ = hv.integrate_batch(clip[:8])
+    assert np.array_equal(got, np.concatenate(want[:8]))
+    need = sum(len(w) for w in want[8:])
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.integrate_batch(clip[8:], out_cap=need // 2)
+    assert ei.value.code == A.E_OUT_CAPACITY
+    got, _ = hv.integrate_batch(clip[8:], out_cap=need)
+    assert np.array_equal(got, np.concatenate(want[8:]))
+    _same_feature_state(ov, hv)

@@ -126,3 +126,32 @@ def test_framed_transcode_to_compressed_sink_config5_mode(tmp_path):
     assert blob == co.close()
     dec, p = A.compressed_decode(blob)
     assert (p.width, p.height, p.channels, p.adu_interval) == (W, H, 3, 30) and 0 < len(dec) <= len(ev)
+
+
+@pytest.mark.gpu
+def test_framed_transcode_with_feature_rate_control_and_roi(tmp_path):
+    """SURVEY 8(f)4 through the C++ mirror: Framed .crf(6) ... write_out(Raw), then update_detect_features(true, Off,
+    true, false) and update_roi on the source's Video (what adder-viz's transcoder tab does), consume() per frame.
+    The quality's own parameters drive the feedback: c_thresh_baseline 7 -> reset value 2, feature_c_radius =
+    min_resolution / 25."""
+    from oracle import oracle as O
+    import adder_amd as A
+    import clips
+    T, H, W = 30, 50, 75
+    frames = clips.make_clip("corners", T, H, W, 1, seed=6)
+    for roi in (None, (30, 20, 60, 45)):
+        out = str(tmp_path / "f.adder")
+        n, fs = Hst.transcode_features(frames, crf=6, ref_time=255, delta_t_max=7650, time_mode=1, multi_mode=1,
+                                       chunk_rows=4, detect=True, rate_adjustment=True, roi=roi, out_path=out)
+        v = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650, chunk_rows=4)
+        v.ensure_capacity(40)
+        v.set_crf_parameters(13, 4)
+        v.reset_c_thresh(7)
+        radius = A.crf_feature_radius(6, W, H)
+        assert radius == 2
+        v.update_detect_features(True, True, 7, radius)
+        v.set_roi(roi, 7)
+        want = np.concatenate([v.integrate_matrix(f) for f in frames])
+        meta, ev = Hst.decode_raw(open(out, "rb").read())
+        assert n == len(want) and np.array_equal(ev, want)
+        assert np.array_equal(fs, v.feature_set()) and fs.sum() > 0
