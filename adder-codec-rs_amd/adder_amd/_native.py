@@ -110,6 +110,10 @@ SYMBOLS = {
     "adder_hip_feature_set": (_i32, [_vp, _vp]),
     "adder_hip_c_thresh_plane": (_i32, [_vp, _vp]),
     "adder_hip_last_new_features": (_u32, [_vp]),
+    "adder_hip_frames_configure": (_i32, [_vp, _u32, _sz]),
+    "adder_hip_frame_submit": (_i32, [_vp, _vp, _sz, _f32]),
+    "adder_hip_frame_collect": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp)]),
+    "adder_hip_frames_in_flight": (_u32, [_vp]),
     "adder_hip_set_delta_t_max": (_i32, [_vp, _u32]),
     "adder_hip_set_time_mode": (_i32, [_vp, _u8]),
     "adder_hip_alloc_pinned": (_vp, [_sz]),

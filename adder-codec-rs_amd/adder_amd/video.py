@@ -63,10 +63,10 @@ class HipVideo:
         self._pinned = None
 
     def close(self):
-        self._free_pinned()
         if getattr(self, "h", None):
-            self.L.adder_hip_destroy(self.h)
+            self.L.adder_hip_destroy(self.h)  # waits for whatever is still in flight
             self.h = None
+        self._free_pinned(frames_too=True)
 
     def __del__(self):
         try:
@@ -161,7 +161,11 @@ class HipVideo:
             self._out = np.frombuffer(buf, dtype=N.EVENT_DTYPE)
         return self._out
 
-    def _free_pinned(self):
+    def _free_pinned(self, frames_too=False):
+        if frames_too:
+            for ptr in getattr(self, "_pinned_frames", []):
+                self.L.adder_hip_free_pinned(ptr)
+            self._pinned_frames = []
         if getattr(self, "_pinned", None):
             self._out = None
             self.L.adder_hip_free_pinned(self._pinned)
@@ -181,6 +185,42 @@ class HipVideo:
         N.check(self.h, rc)
         ev = _copy_events(out, n.value)
         return (ev, chunks) if want_chunks else ev
+
+    # ---- per-frame ring: submit returns once the work is queued, collect hands back the oldest frame --------
+    def frames_configure(self, slots=0, events_per_slot=0):
+        N.check(self.h, self.L.adder_hip_frames_configure(self.h, slots, events_per_slot))
+
+    def pinned_frame(self):
+        """A page-locked [rows][width*channels] u8 array to put input frames in (uploads then run asynchronously)."""
+        ptr = self.L.adder_hip_alloc_pinned(self.n_units)
+        if not ptr:
+            raise MemoryError("adder_hip_alloc_pinned failed")
+        self._pinned_frames = getattr(self, "_pinned_frames", []) + [ptr]
+        buf = (C.c_uint8 * self.n_units).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.rows, self.width * self.channels)
+
+    def frame_submit(self, frame, time_spanned=None):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(self.rows, self.width * self.channels)
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        self._inflight = getattr(self, "_inflight", []) + [frame]  # keep the source alive until it is collected
+        N.check(self.h, self.L.adder_hip_frame_submit(self.h, frame.ctypes.data, frame.strides[0], ts))
+
+    def frame_collect(self, want_chunks=False, copy=True):
+        ev, n, ch = C.c_void_p(), C.c_size_t(0), C.c_void_p()
+        rc = self.L.adder_hip_frame_collect(self.h, C.byref(ev), C.byref(n), C.byref(ch))
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
+        self.last_required = n.value
+        N.check(self.h, rc)
+        events = np.frombuffer((C.c_uint8 * (n.value * 12)).from_address(ev.value), dtype=N.EVENT_DTYPE) if n.value \
+            else np.zeros(0, N.EVENT_DTYPE)
+        chunks = np.frombuffer((C.c_uint32 * (self.num_chunks + 1)).from_address(ch.value), dtype=np.uint32)
+        if copy:
+            events, chunks = events.copy(), chunks.copy()
+        return (events, chunks) if want_chunks else events
+
+    def frames_in_flight(self):
+        return int(self.L.adder_hip_frames_in_flight(self.h))
 
     def integrate_batch(self, frames, time_spanned=None, out_cap=None):
         """T frames (host array [T, rows, W, C]) -> (events, frame_offsets[T+1])."""

@@ -132,6 +132,26 @@ struct AdderHipCtx {
     } slot[2];
     hipStream_t out_s = nullptr;     // wire + D2H stream of the pipeline
     uint64_t submitted = 0, collected = 0;
+    // per-frame `consume` ring (adder_hip_frame_submit / _collect): every slot owns its frame, its events on
+    // the device and in page-locked host memory, and its own batch description (the host-side copies are read
+    // by the DMA engine after submit has returned)
+    struct FrameSlot {
+        uint8_t *d_frame = nullptr;
+        AdderEvent *d_events = nullptr, *h_events = nullptr;
+        size_t cap = 0;                 // events
+        uint8_t *h_hdr = nullptr;       // pinned: FrameResult, then chunk offsets [num_chunks + 1]
+        uint64_t *d_offsets = nullptr;  // [2]
+        BatchArgs *d_batch = nullptr, *h_batch = nullptr;
+        FrameTab *d_ftab = nullptr, *h_ftab = nullptr;
+        hipEvent_t done = nullptr;
+        AdderEvent *out = nullptr;      // where the events were sent (h_events, or the caller's pinned buffer)
+        size_t out_cap = 0;
+    } fslot[4];
+    uint32_t f_slots = 3;
+    size_t f_events_per_slot = 0;    // 0: the mode's worst case, at most 2 GiB of events
+    uint64_t f_submitted = 0, f_collected = 0;
+    hipEvent_t frame_e = nullptr;
+    bool no_snapshot = false;
     uint32_t *d_chunks = nullptr;
     // running state
     float running_t = 0.0f;  // PixelArena::running_t (identical for all pixels)
@@ -200,6 +220,14 @@ static void free_ctx(AdderHipCtx *c) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.wired) (void)hipEventDestroy(sl.wired);
     }
+    for (auto &fs : c->fslot) {
+        for (void *p : {(void *)fs.d_frame, (void *)fs.d_events, (void *)fs.d_offsets, (void *)fs.d_batch, (void *)fs.d_ftab})
+            if (p) (void)hipFree(p);
+        for (void *p : {(void *)fs.h_events, (void *)fs.h_hdr, (void *)fs.h_batch, (void *)fs.h_ftab})
+            if (p) (void)hipHostFree(p);
+        if (fs.done) (void)hipEventDestroy(fs.done);
+    }
+    if (c->frame_e) (void)hipEventDestroy(c->frame_e);
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
     for (void *p : {(void *)c->snap.hdr, (void *)c->snap.integ0, (void *)c->snap.dt0, (void *)c->snap.bdt0,
                     (void *)c->snap.lastf, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
@@ -890,7 +918,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->snap.valid = false;
     {
         const size_t per_frame = (size_t)c->n_units * (c->continuous ? c->max_depth + 3u : generic ? c->max_depth + 1u : 3u);
-        if (out_cap < per_frame * num_frames) {
+        if (out_cap < per_frame * num_frames && !c->no_snapshot) {
             int rc_ = take_snapshot(c, generic, stream);
             if (rc_ != ADDER_OK) return rc_;
             c->snap.generic_sticky = sticky_before;
@@ -995,6 +1023,8 @@ extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frame
     if (!c) return ADDER_E_BAD_PARAMS;
     if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "previous device batch not finished (call adder_hip_finish)");
+    if (c->f_submitted != c->f_collected)
+        return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight (call adder_hip_frame_collect)");
     if (!d_frames || !d_frame_offsets || (!d_out && out_cap)) return fail(c, ADDER_E_BAD_PARAMS, "null pointer");
     if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1307,8 +1337,183 @@ extern "C" int adder_hip_stream_collect(AdderHipCtx *c, const uint8_t **bytes, s
     return status_to_code(c, sl.status);
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-frame `consume` contract without a blocking round trip (framed.rs:127-157 calls integrate_matrix once per
+// decoded frame).  submit(k) queues upload, integration and hand-over of frame k and returns; collect() waits for
+// the oldest frame in flight and returns pointers into its slot of page-locked host memory.  The hand-over
+// (adder_frame_out_kernel: events + row-chunk offsets + result header) runs on a second stream, so frame k's
+// PCIe transfer overlaps frame k+1's integration.
+// ------------------------------------------------------------------------------------------
+static bool device_visible_host(const void *p, void **dev) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *dev = a.devicePointer;
+    return true;
+}
+
+static size_t frame_slot_events(const AdderHipCtx *c, float time_spanned) {
+    if (c->f_events_per_slot) return c->f_events_per_slot;
+    const size_t budget = ((size_t)2 << 30) / sizeof(AdderEvent);
+    return std::min(worst_case_events_per_frame(c, time_spanned), budget);
+}
+
+static int frame_slot_prepare(AdderHipCtx *c, AdderHipCtx::FrameSlot &fs, size_t need, bool need_host_events) {
+    if (!fs.d_frame) {
+        HIPCHK(c, dalloc(&fs.d_frame, c->n_units + 16));
+        HIPCHK(c, dalloc(&fs.d_offsets, 2));
+        HIPCHK(c, dalloc(&fs.d_batch, 1));
+        HIPCHK(c, dalloc(&fs.d_ftab, 64));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_batch), sizeof(BatchArgs), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_ftab), 64 * sizeof(FrameTab), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_hdr),
+                                sizeof(FrameResult) + ((size_t)c->num_chunks + 1) * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&fs.done, hipEventDisableTiming));
+    }
+    if (fs.cap < need) {
+        if (fs.d_events) HIPCHK(c, hipFree(fs.d_events));
+        if (fs.h_events) HIPCHK(c, hipHostFree(fs.h_events));
+        fs.d_events = nullptr;
+        fs.h_events = nullptr;
+        fs.cap = 0;
+        HIPCHK(c, dalloc(&fs.d_events, need));
+        fs.cap = need;
+    }
+    if (need_host_events && !fs.h_events)
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_events), std::max<size_t>(fs.cap, 1) * sizeof(AdderEvent),
+                                hipHostMallocDefault));
+    return ADDER_OK;
+}
+
+// direct_out: page-locked memory of the caller that takes the events instead of the slot's own (device view), or null
+static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
+                             AdderEvent *direct_out, size_t direct_cap) {
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
+    if (c->submitted != c->collected) return fail(c, ADDER_E_BAD_PARAMS, "a raw stream batch is in flight");
+    if (!frame) return fail(c, ADDER_E_BAD_PARAMS, "frame is null");
+    if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
+    if (c->f_submitted - c->f_collected >= c->f_slots)
+        return fail(c, ADDER_E_BAD_PARAMS, "%u frames are in flight: call adder_hip_frame_collect first", c->f_slots);
+    const size_t rowlen = (size_t)c->p.width * c->p.channels;
+    if (row_stride == 0) row_stride = rowlen;
+    if (row_stride < rowlen) return fail(c, ADDER_E_BAD_PARAMS, "row_stride_bytes smaller than a row");
+    HIPCHK(c, hipSetDevice(c->device));
+    AdderHipCtx::FrameSlot &fs = c->fslot[c->f_submitted % c->f_slots];
+    const size_t need = direct_out ? std::min(direct_cap, worst_case_events_per_frame(c, time_spanned))
+                                   : frame_slot_events(c, time_spanned);
+    int rc = frame_slot_prepare(c, fs, need, direct_out == nullptr);
+    if (rc != ADDER_OK) return rc;
+    if (!c->out_s) HIPCHK(c, hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
+    if (!c->frame_e) HIPCHK(c, hipEventCreateWithFlags(&c->frame_e, hipEventDisableTiming));
+    if (row_stride == rowlen)
+        HIPCHK(c, hipMemcpyAsync(fs.d_frame, frame, c->n_units, hipMemcpyHostToDevice, c->stream));
+    else
+        HIPCHK(c, hipMemcpy2DAsync(fs.d_frame, rowlen, frame, row_stride, rowlen, c->rows, hipMemcpyHostToDevice, c->stream));
+    // the slot's own batch description: the shared one may still be read by the copy engine for the frame before
+    struct Swap {
+        AdderHipCtx *c;
+        BatchArgs *db, *hb;
+        FrameTab *dt, *ht;
+        size_t cap;
+        bool graph, snap;
+        ~Swap() {
+            c->d_batch = db; c->h_batch = hb; c->d_ftab = dt; c->h_ftab = ht; c->ftab_cap = cap;
+            c->use_graph = graph; c->no_snapshot = snap;
+        }
+    } swap{c, c->d_batch, c->h_batch, c->d_ftab, c->h_ftab, c->ftab_cap, c->use_graph, c->no_snapshot};
+    c->d_batch = fs.d_batch;
+    c->h_batch = fs.h_batch;
+    c->d_ftab = fs.d_ftab;
+    c->h_ftab = fs.h_ftab;
+    c->ftab_cap = 64;
+    c->use_graph = false;   // the captured graphs point at the shared description
+    c->no_snapshot = true;  // frames behind this one are submitted before its outcome is known: no rollback
+    rc = enqueue_frames(c, fs.d_frame, 1, time_spanned, fs.d_events, need, fs.d_offsets, c->stream);
+    if (rc != ADDER_OK) {
+        c->poisoned = true;
+        return rc;
+    }
+    fs.out = direct_out ? direct_out : fs.h_events;
+    fs.out_cap = need;
+    HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
+    HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
+                                     reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
+                                     reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
+                                     c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s));
+    HIPCHK(c, hipEventRecord(fs.done, c->out_s));
+    c->f_submitted += 1;
+    return ADDER_OK;
+}
+
+static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t *n_events, const uint32_t **chunk_offsets) {
+    if (c->f_collected == c->f_submitted) return fail(c, ADDER_E_BAD_PARAMS, "no frame in flight");
+    HIPCHK(c, hipSetDevice(c->device));
+    AdderHipCtx::FrameSlot &fs = c->fslot[c->f_collected % c->f_slots];
+    HIPCHK(c, hipEventSynchronize(fs.done));
+    c->f_collected += 1;
+    const FrameResult *res = reinterpret_cast<const FrameResult *>(fs.h_hdr);
+    if (events) *events = fs.out;
+    if (n_events) *n_events = (size_t)res->produced;
+    if (chunk_offsets) *chunk_offsets = reinterpret_cast<const uint32_t *>(fs.h_hdr + sizeof(FrameResult));
+    if (res->status == kStatusCapacity) {
+        c->poisoned = true;  // later frames were stepped on top of this one: there is nothing to roll back to
+        return fail(c, ADDER_E_OUT_CAPACITY, "frame slot too small: the frame produced %llu events, the slot holds %zu "
+                    "(adder_hip_frames_configure)", (unsigned long long)res->produced, fs.out_cap);
+    }
+    return status_to_code(c, res->status);
+}
+
+extern "C" int adder_hip_frames_configure(AdderHipCtx *c, uint32_t slots, size_t events_per_slot) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->f_submitted != c->f_collected) return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight");
+    if (slots > 4) return fail(c, ADDER_E_BAD_PARAMS, "at most 4 frame slots");
+    c->f_slots = slots ? slots : 3u;
+    c->f_events_per_slot = events_per_slot;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_frame_submit(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    return frame_submit_impl(c, frame, row_stride, time_spanned, nullptr, 0);
+}
+
+extern "C" int adder_hip_frame_collect(AdderHipCtx *c, const AdderEvent **events, size_t *n_events,
+                                       const uint32_t **chunk_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    return frame_collect_impl(c, events, n_events, chunk_offsets);
+}
+
+extern "C" uint32_t adder_hip_frames_in_flight(const AdderHipCtx *c) {
+    return c ? (uint32_t)(c->f_submitted - c->f_collected) : 0u;
+}
+
 extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
                                    AdderEvent *out, size_t out_cap, size_t *n_out, uint32_t *chunk_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_out) *n_out = 0;
+    // a buffer that holds the frame's worst case needs no rollback: submit + collect, the events sent straight
+    // into `out` when the device can see it (adder_hip_alloc_pinned / hipHostRegister), else through a slot
+    if (out && c->f_submitted == c->f_collected && !c->pending && c->submitted == c->collected && !c->poisoned &&
+        time_spanned >= 0.0f && out_cap >= worst_case_events_per_frame(c, time_spanned)) {
+        void *dev = nullptr;
+        const bool direct = device_visible_host(out, &dev);
+        int rc = frame_submit_impl(c, frame, row_stride, time_spanned, direct ? (AdderEvent *)dev : nullptr, out_cap);
+        if (rc != ADDER_OK) return rc;
+        const AdderEvent *ev = nullptr;
+        const uint32_t *ch = nullptr;
+        size_t n = 0;
+        rc = frame_collect_impl(c, &ev, &n, &ch);
+        if (n_out) *n_out = n;
+        if (rc != ADDER_OK) return rc;
+        if (!direct && n) memcpy(out, ev, n * sizeof(AdderEvent));
+        if (chunk_offsets) memcpy(chunk_offsets, ch, ((size_t)c->num_chunks + 1) * sizeof(uint32_t));
+        return ADDER_OK;
+    }
     size_t n = 0;
     int rc = adder_hip_integrate_batch(c, frame, 1, 0, row_stride, time_spanned, out, out_cap, &n, nullptr);
     if (n_out) *n_out = n;

@@ -113,6 +113,13 @@ struct BatchArgs {
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
 };
 
+// result header of one frame handed to the host (adder_frame_out_kernel), in page-locked host memory
+struct FrameResult {
+    uint64_t produced;  // events the frame produced (may exceed the slot's capacity: then status has kStatusCapacity)
+    uint32_t status;
+    uint32_t pad;
+};
+
 // handle_features / handle_roi of one context (video.rs:865-1112)
 struct FeatureArgs {
     uint8_t *fset;        // [rows][width] membership of VideoState::features (0 / 1)
@@ -163,6 +170,10 @@ hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n
 hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
                               uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap, uint64_t *merged_offsets,
                               uint32_t *status, hipStream_t stream);
+hipError_t adder_launch_frame_out(const adder::AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
+                                  adder::AdderEventPod *h_ev, adder::FrameResult *h_res, uint32_t *h_chunks,
+                                  const uint32_t *status, uint32_t row_begin, uint32_t chunk_rows, uint32_t num_chunks,
+                                  hipStream_t stream);
 // after frame f's events are in place: FAST features at the events' pixels -> membership plane, c_thresh reset
 // around the new ones, ROI (video.rs:865-1112)
 hipError_t adder_launch_features(const adder::BatchArgs *b, uint32_t f, const adder::FeatureArgs *fa,

@@ -1206,6 +1206,57 @@ __global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const Batc
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-frame `consume` contract (framed.rs:127-157; adder_hip_frame_submit): hands one frame's events to the
+// host without the host knowing their number in advance.  Blocks [0, copy_blocks) stream the events from the
+// device buffer into page-locked host memory (16-byte stores over PCIe), the others compute the row chunks'
+// offsets (Vec<Vec<Event>> structure, video.rs:677-691) and the result header.  d_offsets[0..1] = the frame's
+// range in d_ev.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPod *__restrict__ d_ev,
+                                                              const uint64_t *__restrict__ d_offsets, uint64_t cap,
+                                                              AdderEventPod *__restrict__ h_ev, FrameResult *h_res,
+                                                              uint32_t *__restrict__ h_chunks,
+                                                              const uint32_t *__restrict__ status, uint32_t row_begin,
+                                                              uint32_t chunk_rows, uint32_t num_chunks,
+                                                              uint32_t copy_blocks) {
+    const uint64_t begin = d_offsets[0];
+    const uint64_t produced = d_offsets[1] - begin;
+    const uint64_t n = produced < cap ? produced : cap;
+    const AdderEventPod *const ev = d_ev + begin;
+    if (blockIdx.x < copy_blocks) {
+        const uint64_t dwords = n * 3ull, quads = dwords >> 2;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(ev);  // begin == 0 in every caller: 16-byte aligned
+        u32x4 *dst = reinterpret_cast<u32x4 *>(h_ev);
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < quads; i += (uint64_t)copy_blocks * 256u)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+        if (blockIdx.x == 0 && threadIdx.x < (dwords & 3ull)) {
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(ev);
+            reinterpret_cast<uint32_t *>(h_ev)[quads * 4 + threadIdx.x] = s32[quads * 4 + threadIdx.x];
+        }
+        return;
+    }
+    const uint32_t c = (blockIdx.x - copy_blocks) * 256u + threadIdx.x;
+    if (c == 0) {
+        h_res->produced = produced;
+        h_res->status = *status | (produced > cap ? kStatusCapacity : 0u);
+    }
+    if (c > num_chunks) return;
+    if (c == num_chunks) {
+        h_chunks[c] = (uint32_t)n;
+        return;
+    }
+    const uint32_t y0 = row_begin + c * chunk_rows;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ev[mid].y < y0) lo = mid + 1;
+        else hi = mid;
+    }
+    h_chunks[c] = (uint32_t)lo;
+}
+
+// ------------------------------------------------------------------------------------------
 // Multi-GPU: merge of the row bands' event streams (the reference's split is
 // video.rs:677-691).  Rank r's stream is frame-major with offsets offs[r][0..T]; the merged stream
 // is frame-major with, inside a frame, rank 0's events first, then rank 1's, ... = raster order.
@@ -1412,6 +1463,17 @@ extern "C" hipError_t adder_launch_chunk_offsets(const AdderEventPod *ev, uint32
     const uint32_t bs = 256;
     hipLaunchKernelGGL(adder_chunk_offsets_kernel, dim3((num_chunks + 1 + bs - 1) / bs), dim3(bs), 0, stream, ev,
                        n, row_begin, chunk_rows, num_chunks, offsets);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
+                                             AdderEventPod *h_ev, FrameResult *h_res, uint32_t *h_chunks,
+                                             const uint32_t *status, uint32_t row_begin, uint32_t chunk_rows,
+                                             uint32_t num_chunks, hipStream_t stream) {
+    const uint32_t copy_blocks = 128;  // a slice of the chip keeps a x16 link busy
+    const uint32_t chunk_blocks = (num_chunks + 1 + 255) / 256;
+    hipLaunchKernelGGL(adder_frame_out_kernel, dim3(copy_blocks + chunk_blocks), dim3(256), 0, stream, d_ev, d_offsets,
+                       cap, h_ev, h_res, h_chunks, status, row_begin, chunk_rows, num_chunks, copy_blocks);
     return hipGetLastError();
 }
 

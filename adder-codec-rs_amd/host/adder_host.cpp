@@ -481,21 +481,17 @@ std::vector<std::vector<Event>> Video::integrate_matrix(const Frame &matrix, flo
     // in_interval_count starts at 1 (video.rs:231), so set_initial_d (:656-658) is never taken here
     in_interval_count_ += 1;
     const uint32_t num_chunks = adder_hip_num_chunks(ctx_);
-    buf_.resize(std::max<size_t>(buf_.size(), std::min<size_t>(adder_hip_max_events_per_frame(ctx_), plane_.volume() + 64)));
-    std::vector<uint32_t> offs(num_chunks + 1);
+    // one frame through the ring: the events come back as a view of a page-locked slot that holds the mode's
+    // worst case, so nothing can overflow and nothing is copied before the per-chunk vectors are built
+    hip_check(ctx_, adder_hip_frame_submit(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned));
+    const AdderEvent *ev = nullptr;
+    const uint32_t *offs = nullptr;
     size_t n = 0;
-    int rc = adder_hip_integrate(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned, buf_.data(),
-                                 buf_.size(), &n, offs.data());
-    if (rc == ADDER_E_OUT_CAPACITY) {  // recoverable: the state was rolled back, n = the events this frame emits
-        buf_.resize(n);
-        rc = adder_hip_integrate(ctx_, matrix.data(), (size_t)plane_.w() * plane_.c(), time_spanned, buf_.data(),
-                                 buf_.size(), &n, offs.data());
-    }
-    hip_check(ctx_, rc);
+    hip_check(ctx_, adder_hip_frame_collect(ctx_, &ev, &n, &offs));
+    const Event *events = reinterpret_cast<const Event *>(ev);
     std::vector<std::vector<Event>> big_buffer(num_chunks);
-    for (uint32_t ch = 0; ch < num_chunks; ++ch)
-        big_buffer[ch].assign(buf_.begin() + offs[ch], buf_.begin() + offs[ch + 1]);
-    encoder_->ingest_events(buf_.data(), n);  // for events in &big_buffer { encoder.ingest_event } (:736-740)
+    for (uint32_t ch = 0; ch < num_chunks; ++ch) big_buffer[ch].assign(events + offs[ch], events + offs[ch + 1]);
+    encoder_->ingest_events(events, n);  // for events in &big_buffer { encoder.ingest_event } (:736-740)
     return big_buffer;
 }
 

@@ -160,6 +160,25 @@ int adder_hip_integrate(AdderHipCtx *ctx, const uint8_t *frame_hwc, size_t row_s
                         float time_spanned, AdderEvent *out, size_t out_cap, size_t *n_out,
                         uint32_t *chunk_offsets);
 
+/* With out_cap >= adder_hip_max_events_per_frame() the call cannot overflow and takes the short route: upload,
+ * integrate, and a device kernel that stores the events straight into `out` when `out` is page-locked
+ * (adder_hip_alloc_pinned, or hipHostRegister'ed by the caller), else into a page-locked slot that is then copied. */
+
+/* --- one frame, without the blocking round trip: the `consume` loop of a live source (framed.rs:127-157) ------
+ * adder_hip_frame_submit queues frame k (upload, integration, hand-over of events + row-chunk offsets to a slot
+ * of page-locked host memory) and returns; adder_hip_frame_collect waits for the OLDEST frame in flight and
+ * returns pointers into its slot, valid until `slots` more frames have been submitted.  Frame k's transfer
+ * overlaps frame k+1's integration.  `frame_hwc` should be page-locked (adder_hip_alloc_pinned) -- a pageable
+ * frame makes the upload synchronous.  At most `slots` frames are in flight (default 3); a slot holds the mode's
+ * worst case of events, at most 2 GiB (adder_hip_frames_configure(ctx, slots, events_per_slot), 0 = default).
+ * There is no rollback on this route: a frame that overflows its slot fails with ADDER_E_OUT_CAPACITY in collect
+ * and poisons the context.  Other entry points refuse to run while frames are in flight. */
+int adder_hip_frames_configure(AdderHipCtx *ctx, uint32_t slots, size_t events_per_slot);
+int adder_hip_frame_submit(AdderHipCtx *ctx, const uint8_t *frame_hwc, size_t row_stride_bytes, float time_spanned);
+int adder_hip_frame_collect(AdderHipCtx *ctx, const AdderEvent **events, size_t *n_events,
+                            const uint32_t **chunk_offsets);
+uint32_t adder_hip_frames_in_flight(const AdderHipCtx *ctx);
+
 /* --- T frames, host buffers: same stream, frame-major; frame_offsets gets T+1 entries. */
 int adder_hip_integrate_batch(AdderHipCtx *ctx, const uint8_t *frames_hwc, uint32_t num_frames,
                               size_t frame_stride_bytes, size_t row_stride_bytes,

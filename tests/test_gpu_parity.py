@@ -941,3 +941,85 @@ def test_feature_path_errors_and_rollback():
     got, _ = hv.integrate_batch(clip[8:], out_cap=need)
     assert np.array_equal(got, np.concatenate(want[8:]))
     _same_feature_state(ov, hv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lean", "generic", "normal_rgb", "continuous", "features"])
+def test_frame_ring_submit_collect(case):
+    """The per-frame `consume` contract without a blocking round trip (adder_hip_frame_submit / _collect): up to
+    three frames in flight, each handed over by adder_frame_out_kernel into page-locked host memory together with
+    its row-chunk offsets -- events and chunks equal the oracle's per frame, in every kernel family."""
+    A = _hip()
+    W, H, Cn, mm, dtm, tm, pm = 131, 67, 1, O.COLLAPSE, 255, O.ABSOLUTE_T, 0
+    if case == "generic":
+        dtm, tm = 7650, O.DELTA_T
+    elif case == "normal_rgb":
+        Cn, mm, dtm = 3, O.NORMAL, 2550
+    elif case == "continuous":
+        pm, dtm = 1, 1020
+    clip = clips.make_clip("corners" if case == "features" else "runs", 45, H, W, Cn, seed=17)
+    ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, chunk_rows=7)
+    hv = A.HipVideo(W, H, Cn, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, chunk_rows=7, max_depth=30,
+                    pixel_mode=pm)
+    ov.ensure_capacity(34)
+    if pm:
+        ov.set_pixel_mode(1)
+    for v in (ov, hv):
+        v.set_crf_parameters(7, 7)
+        v.reset_c_thresh(2)
+    if case == "features":
+        ov.update_detect_features(True, True, 2, 3)
+        hv.update_detect_features(True, True)
+        hv.set_feature_parameters(2, 3)
+    want = [ov.integrate_matrix(f, want_chunks=True) for f in clip]
+    pinned = [hv.pinned_frame() for _ in range(3)]
+    got = []
+    for k, f in enumerate(clip):
+        if hv.frames_in_flight() == 3:
+            got.append(hv.frame_collect(want_chunks=True))
+        pinned[k % 3][...] = f.reshape(H, W * Cn)
+        hv.frame_submit(pinned[k % 3])
+    while hv.frames_in_flight():
+        got.append(hv.frame_collect(want_chunks=True))
+    assert len(got) == len(want)
+    for k, ((a, ca), (b, cb)) in enumerate(zip(want, got)):
+        assert np.array_equal(a, b) and np.array_equal(ca, cb), (case, k)
+    # the blocking call afterwards continues the same stream (pageable frame, pageable and pinned `out`)
+    extra = clips.make_clip("runs", 4, H, W, Cn, seed=18)
+    for f in extra:
+        a, ca = ov.integrate_matrix(f, want_chunks=True)
+        b, cb = hv.integrate_matrix(f, want_chunks=True)
+        assert np.array_equal(a, b) and np.array_equal(ca, cb)
+
+
+@pytest.mark.gpu
+def test_frame_ring_rules_and_overflow():
+    A = _hip()
+    clip = clips.make_clip("noise", 6, 20, 33, 1, seed=1)
+    hv = A.HipVideo(33, 20, 1, delta_t_max=255)
+    with pytest.raises(A.AdderHipError):
+        hv.frame_collect()
+    hv.frames_configure(2, 0)
+    hv.frame_submit(clip[0])
+    hv.frame_submit(clip[1])
+    with pytest.raises(A.AdderHipError, match="in flight"):
+        hv.frame_submit(clip[2])
+    with pytest.raises(A.AdderHipError, match="in flight"):
+        hv.integrate_batch(clip[2:4])
+    with pytest.raises(A.AdderHipError, match="in flight"):
+        hv.frames_configure(3, 0)
+    a = hv.frame_collect()
+    b = hv.frame_collect()
+    ov = O.Video(33, 20, 1, delta_t_max=255)
+    assert np.array_equal(a, ov.integrate_matrix(clip[0])) and np.array_equal(b, ov.integrate_matrix(clip[1]))
+    got, _ = hv.integrate_batch(clip[2:4])  # the ring is empty again: other entry points work
+    assert np.array_equal(got, np.concatenate([ov.integrate_matrix(f) for f in clip[2:4]]))
+    # a slot that is too small: the frame fails at collect with the size it needed, and the context is poisoned
+    hv.frames_configure(2, 50)
+    hv.frame_submit(clip[4])
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.frame_collect()
+    assert ei.value.code == A.E_OUT_CAPACITY and hv.last_required == len(ov.integrate_matrix(clip[4])) > 50
+    with pytest.raises(A.AdderHipError) as ei:
+        hv.frame_submit(clip[5])
+    assert ei.value.code == A.E_POISONED
