@@ -15,12 +15,43 @@
 
 namespace adder {
 
+// Exact n / d for every u32 n and an invariant d >= 1 (Granlund & Montgomery's round-up method): the two
+// divisions of the step are by per-stream constants, and a u32 division is a ~40-instruction routine on the GPU.
+struct FastDivU32 {
+    uint32_t d, magic, sh1, sh2;
+};
+ADDER_HD FastDivU32 fast_div_make(uint32_t d) {
+    FastDivU32 f;
+    f.d = d;
+    uint32_t l = 0;
+    while (l < 32u && ((uint64_t)1 << l) < (uint64_t)d) ++l;  // ceil(log2 d)
+    f.magic = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1u);
+    f.sh1 = l < 1u ? l : 1u;
+    f.sh2 = l > 1u ? l - 1u : 0u;
+    return f;
+}
+ADDER_HD uint32_t fast_div(uint32_t n, const FastDivU32 &f) {
+    const uint32_t t1 = (uint32_t)(((uint64_t)f.magic * n) >> 32);
+    return (t1 + ((n - t1) >> f.sh1)) >> f.sh2;
+}
+
 struct FramerConsts {
     uint32_t tpf;           // ticks per output frame (driver.rs:357-361)
     uint32_t ref_interval;  // ticks per source frame; also the `tpf` argument of get_frame_value (:1034)
     uint32_t abs_t;         // codec_version >= 2 && TimeMode::AbsoluteT (:1001, :1024-1030)
     uint32_t round_up;      // codec_version >= 1 && framed source camera (:1093-1107)
+    FastDivU32 by_tpf, by_ref;
 };
+ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up) {
+    FramerConsts k;
+    k.tpf = tpf;
+    k.ref_interval = ref_interval;
+    k.abs_t = abs_t;
+    k.round_up = round_up;
+    k.by_tpf = fast_div_make(tpf);
+    k.by_ref = fast_div_make(ref_interval);
+    return k;
+}
 
 struct FramerPx {
     uint64_t ts;     // pixel_ts_tracker
@@ -48,7 +79,7 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
     // 64-bit clocks, but they stay below 2^32 for ~150 hours of 30 fps video at 255 ticks per
     // frame: divide in 32 bits then (a 64-bit division is a ~130-instruction routine on the GPU)
     const bool small = (p.ts >> 32) == 0u;
-    const uint64_t q = small ? (uint64_t)((uint32_t)rm1 / k.tpf) : rm1 / (uint64_t)k.tpf;
+    const uint64_t q = small ? (uint64_t)fast_div((uint32_t)rm1, k.by_tpf) : rm1 / (uint64_t)k.tpf;
     if (q > (uint64_t)kFramerMaxFrame) {
         overflow = true;
     } else if ((int64_t)q > (int64_t)p.lastf) {
@@ -67,7 +98,7 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
     }
     if (k.round_up) {
         if (small) {
-            const uint32_t ts32 = (uint32_t)p.ts, qr = ts32 / k.ref_interval;
+            const uint32_t ts32 = (uint32_t)p.ts, qr = fast_div(ts32, k.by_ref);
             if (ts32 - qr * k.ref_interval > 0u) p.ts = ((uint64_t)qr + 1u) * (uint64_t)k.ref_interval;
         } else if (p.ts % (uint64_t)k.ref_interval > 0u) {
             p.ts = (p.ts / (uint64_t)k.ref_interval + 1u) * (uint64_t)k.ref_interval;

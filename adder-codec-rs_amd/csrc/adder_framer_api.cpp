@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/adder_framer.h"
@@ -34,6 +35,9 @@ struct AdderFramer {
     size_t d_offs_cap = 0;
     uint64_t *h_offs = nullptr;  // pinned staging of the same
     size_t h_offs_cap = 0;
+    uint64_t *d_tile_off = nullptr;  // [frames of a launch][tiles + 1] slice offsets (adder_framer_slices_kernel)
+    size_t d_tile_off_cap = 0;
+    uint32_t window_rows = 8;        // LDS window of the tiles kernel: covers delta_t_max / tpf frames of lag
     hipEvent_t ingested = nullptr;  // recorded behind the last device operation (ingest / pop / flush) on its stream
     bool op_pending = false;
     int64_t frames_written = 0;
@@ -68,7 +72,7 @@ static void framer_free(AdderFramer *fr) {
     (void)hipSetDevice(fr->device);
     if (fr->stream) (void)hipStreamSynchronize(fr->stream);
     for (void *p : {(void *)fr->px, (void *)fr->ring, (void *)fr->status,
-                    (void *)fr->minmax, (void *)fr->d_events, (void *)fr->d_out, (void *)fr->d_offs})
+                    (void *)fr->minmax, (void *)fr->d_events, (void *)fr->d_out, (void *)fr->d_offs, (void *)fr->d_tile_off})
         if (p) (void)hipFree(p);
     if (fr->h_offs) (void)hipHostFree(fr->h_offs);
     if (fr->ingested) (void)hipEventDestroy(fr->ingested);
@@ -128,6 +132,14 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
     }
     fr->n_units = (uint32_t)units;
     fr->tpf = tpf;
+    {   // a pixel lags the newest frame by at most delta_t_max ticks: the window should hold that many rows
+        // (DeltaT clocks are per-pixel sums of event times and drift apart: a wider window for those streams)
+        const uint64_t lag = (uint64_t)p.delta_t_max / tpf + (p.time_mode == ADDER_TIME_ABSOLUTE_T ? 4u : 24u);
+        uint32_t k = 16;
+        while (k < 32u && k < lag) k <<= 1;  // (64 rows cost more in occupancy than the stragglers they save)
+        if (const char *e = getenv("ADDER_FRAMER_WINDOW")) k = (uint32_t)atoi(e);  // 8 / 16 / 32 / 64 (tuning)
+        fr->window_rows = k;
+    }
     fr->ring_frames = p.ring_frames ? p.ring_frames : (uint32_t)std::min<uint64_t>(p.delta_t_max / tpf + 80u, 1u << 20);
     auto setup = [&]() -> int {
         FHIPCHK(fr, hipSetDevice(fr->device));
@@ -182,11 +194,11 @@ static FramerArgs make_args(const AdderFramer *fr) {
     a.row_begin = fr->p.row_begin;
     a.rows = fr->rows;
     a.ring_frames = fr->ring_frames;
+    a.by_ring = fast_div_make(fr->ring_frames);
     a.frames_written = (int32_t)fr->frames_written;
-    a.k.tpf = fr->tpf;
-    a.k.ref_interval = fr->p.ref_interval;
-    a.k.abs_t = (fr->p.codec_version >= 2 && fr->p.time_mode == ADDER_TIME_ABSOLUTE_T) ? 1u : 0u;
-    a.k.round_up = (fr->p.codec_version >= 1 && fr->p.source_camera <= 5u) ? 1u : 0u;
+    a.k = framer_consts(fr->tpf, fr->p.ref_interval,
+                        (fr->p.codec_version >= 2 && fr->p.time_mode == ADDER_TIME_ABSOLUTE_T) ? 1u : 0u,
+                        (fr->p.codec_version >= 1 && fr->p.source_camera <= 5u) ? 1u : 0u);
     return a;
 }
 
@@ -273,9 +285,13 @@ extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEve
     memcpy(fr->h_offs, frame_offsets, bytes);
     FHIPCHK(fr, hipMemcpyAsync(fr->d_offs, fr->h_offs, bytes, hipMemcpyHostToDevice, s));
     const FramerArgs a = make_args(fr);
+    const uint32_t per_launch = std::min(kFramerRowsMaxFrames, num_frames);
+    rc = fensure(fr, &fr->d_tile_off, &fr->d_tile_off_cap,
+                 (size_t)per_launch * (adder_framer_num_tiles(fr->n_units) + 1u) * sizeof(uint64_t));
+    if (rc != ADDER_OK) return rc;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += kFramerRowsMaxFrames) {
         const uint32_t nf = std::min(kFramerRowsMaxFrames, num_frames - f0);
-        FHIPCHK(fr, adder_framer_launch_rows(d_events, fr->d_offs + f0, nf, &a, s));
+        FHIPCHK(fr, adder_framer_launch_tiles(d_events, fr->d_offs + f0, nf, fr->d_tile_off, fr->window_rows, &a, s));
     }
     return mark_op(fr, s);
 }

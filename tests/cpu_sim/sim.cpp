@@ -336,6 +336,14 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
 #include "adder_framer.hpp"
 #include <vector>
 
+// fast_div against the hardware division: returns the number of mismatches over n[0..count)
+extern "C" uint64_t sim_fast_div_check(uint32_t d, const uint32_t *n, size_t count) {
+    const adder::FastDivU32 f = adder::fast_div_make(d);
+    uint64_t bad = 0;
+    for (size_t i = 0; i < count; ++i) bad += adder::fast_div(n[i], f) != n[i] / d;
+    return bad;
+}
+
 extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, uint32_t height, uint32_t channels,
                                   uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
                                   uint8_t *out, size_t out_cap_frames) {
@@ -344,7 +352,7 @@ extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, 
     std::vector<FramerPx> px(units);
     for (auto &p : px) { p.ts = 0; p.lastf = -1; p.lasti = 0; }
     std::vector<uint8_t> frames;
-    FramerConsts k{tpf, ref_interval, abs_t, round_up};
+    const FramerConsts k = framer_consts(tpf, ref_interval, abs_t, round_up);
     for (size_t i = 0; i < n; ++i) {
         const uint32_t c = ev[i].c == 0xFF ? 0u : ev[i].c;
         if (ev[i].x >= width || ev[i].y >= height || c >= channels) return -1;

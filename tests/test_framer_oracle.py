@@ -83,3 +83,23 @@ def test_dark_lake(golden_dir):
     n = min(len(got), len(want))
     assert n > 0 and got[:n] == want[:n]
     assert len(got) >= len(want)  # "the file might be larger" (adder_simulproc.rs:255-257)
+
+
+def test_fast_division_by_stream_constants_is_exact():
+    """framer_step divides by tpf and ref_interval with a multiply-and-shift (adder_framer.hpp fast_div); it must be the
+    hardware quotient for every u32 numerator -- edge numerators for a spread of divisors, plus random ones."""
+    import ctypes as C
+    import sim_py
+    L = sim_py.lib()
+    L.sim_fast_div_check.restype = C.c_uint64
+    L.sim_fast_div_check.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(0)
+    divisors = [1, 2, 3, 5, 7, 255, 256, 257, 1000, 5000, 7650, 65535, 65536, 65537, 2**31 - 1, 2**31, 2**31 + 1,
+                2**32 - 2, 2**32 - 1] + [int(x) for x in rng.integers(1, 2**32, 200)]
+    for d in divisors:
+        ks = rng.integers(0, max(1, 2**32 // d), 2000, dtype=np.uint64)
+        edge = np.concatenate([ks * d, ks * d + d - 1, np.minimum(ks * d + 1, 2**32 - 1)])
+        n = np.concatenate([edge[edge < 2**32], rng.integers(0, 2**32, 4000, dtype=np.uint64),
+                            np.array([0, 1, d - 1, d, 2**32 - 1], np.uint64)]).astype(np.uint32)
+        n = np.ascontiguousarray(n)
+        assert L.sim_fast_div_check(d, n.ctypes.data, len(n)) == 0, d

@@ -218,3 +218,72 @@ def test_full_size_1080p_framer_paths_agree():
         fr.close()
     # (a pixel that is 0 in consecutive frames is silent, so the slowest pixel holds most frames back)
     assert outs[0].shape[0] >= 1 and torch.equal(outs[0], outs[1])
+
+
+def _synthetic_stream(rng, W, H, Cn, T, *, abs_t, big_t=False, long_runs=False, density=0.3):
+    """T raster-ordered segments with runs of 1..6 events per unit (some far longer than a wave), D_EMPTY fillers,
+    zero and repeated timestamps; AbsoluteT streams get events from the pixel's past, `big_t` values beyond 2^23."""
+    n_units = W * H * Cn
+    segs, clock = [], np.zeros(n_units, np.int64)
+    for k in range(T):
+        hit = np.flatnonzero(rng.random(n_units) < density)
+        runs = rng.integers(1, 7, len(hit))
+        if long_runs and len(hit):
+            runs[rng.integers(0, len(hit), 3)] = rng.integers(70, 200, 3)
+        units = np.repeat(hit, runs)
+        n = len(units)
+        ev = np.zeros(n, dtype=[("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("d", "u1"), ("pad", "<u2"), ("t", "<u4")])
+        ev["c"] = 0xFF if Cn == 1 else units % Cn
+        ev["x"] = (units // Cn) % W
+        ev["y"] = units // (Cn * W)
+        ev["d"] = rng.choice(np.array([0, 1, 3, 7, 8, 12, 128, 255], np.uint8), n, p=[.1, .1, .2, .2, .15, .1, .05, .1])
+        dt = rng.choice(np.array([0, 1, 17, 254, 255, 256, 700, 5000]), n)
+        if big_t:
+            dt = np.where(rng.random(n) < 0.02, rng.integers(1 << 23, 1 << 26, n), dt)
+        if abs_t:  # mostly moving forward per unit, sometimes stuck or in the past
+            base = clock[units] + np.cumsum(dt) - np.repeat(np.cumsum(dt)[np.cumsum(runs) - runs] - dt[np.cumsum(runs) - runs], runs)
+            back = rng.random(n) < 0.1
+            t = np.where(back, np.maximum(base - 900, 0), base)
+            np.maximum.at(clock, units, t)
+            ev["t"] = np.minimum(t, 2**32 - 1).astype(np.uint32)
+        else:
+            ev["t"] = dt.astype(np.uint32)
+        segs.append(ev)
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint64)
+    return np.concatenate(segs), offs
+
+
+@pytest.mark.parametrize("abs_t,Cn,kw", [(False, 1, {}), (True, 1, {}), (False, 3, {"long_runs": True}),
+                                          (True, 3, {"long_runs": True}), (False, 1, {"big_t": True}),
+                                          (True, 1, {"big_t": True}), (False, 1, {"density": 0.02})])
+def test_batch_kernel_equals_per_segment_kernel_and_the_host_run(abs_t, Cn, kw):
+    """The lane-parallel batch kernel (segmented scans over a unit's adjacent events, trackers and a window of output
+    rows in LDS) against the one-thread-per-run segment kernel and the device header's serial framer_step on the host:
+    same complete frames, same trackers afterwards (the flushed frames depend on all of them)."""
+    import torch
+    import sim_py
+    A = _hip()
+    rng = np.random.default_rng(5 + Cn + 2 * abs_t)
+    W, H, T = 61, 37, 70  # 2257 * Cn units: several tiles, a ragged last one; more frames than one search group
+    ev, offs = _synthetic_stream(rng, W, H, Cn, T, abs_t=abs_t, **kw)
+    tm = A.TIME_ABSOLUTE_T if abs_t else A.TIME_DELTA_T
+    # (clocks that jump by up to 2^26 ticks need long output frames to stay inside the ring)
+    kwf = dict(tps=7650, ref_interval=255, delta_t_max=7650, output_fps=0.01 if kw.get("big_t") else 30.0,
+               codec_version=3, time_mode=tm, source_camera=A.FRAMED_U8, ring_frames=1 << 15)
+    st = torch.cuda.current_stream().cuda_stream
+    d_ev = torch.from_numpy(ev.view(np.uint8).copy()).cuda()
+    outs = []
+    for batch in (True, False):
+        fr = A.HipFramer(W, H, Cn, **kwf)
+        for a0 in range(0, T, 32):  # three calls: the window and the trackers carry over
+            seg = offs[a0:a0 + 33]
+            (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, seg, stream=st)
+        n = fr.frames_ready()
+        got = fr.pop(max_frames=n)
+        tail = [(fr.flush_frame_buffer(), fr.write_frame_bytes()) for _ in range(4)]
+        outs.append((n, got, tail))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    if not kw.get("big_t"):
+        want = sim_py.framer_run(ev, W, H, Cn, tpf=255, ref_interval=255, abs_t=abs_t, round_up=True, max_frames=1 << 15)
+        got = outs[0][1]
+        assert len(got) == outs[0][0] * W * H * Cn and got == want[: len(got)]
