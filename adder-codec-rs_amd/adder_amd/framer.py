@@ -51,9 +51,10 @@ class HipFramer:
 
     def ingest(self, events, seg_offsets=None):
         """events: host array (EVENT_DTYPE); seg_offsets: boundaries of segments inside which every
-        pixel-channel's events are contiguous (default: one segment)."""
+        pixel-channel's events are contiguous (default: computed here -- a new segment wherever a
+        pixel-channel shows up again, so an arbitrary stream is safe to pass)."""
         events = np.ascontiguousarray(events, dtype=N.EVENT_DTYPE)
-        offs = np.array([0, len(events)], np.uint64) if seg_offsets is None else \
+        offs = contiguous_run_segments(events) if seg_offsets is None else \
             np.ascontiguousarray(seg_offsets, dtype=np.uint64)
         N.check_framer(self.h, self.L.adder_framer_ingest(self.h, events.ctypes.data, offs.ctypes.data, len(offs) - 1))
 

@@ -86,7 +86,8 @@ struct AdderHipCtx {
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
-    uint32_t chunk = 1, slots = 2;
+    uint32_t chunk = 1, slots = 2, ring_chunks = 3;
+    uint32_t lean_blocks_per_cu = 5, expand_blocks_per_cu = 3;
     uint32_t frames_per_launch = kMaxFramesPerLaunch;  // temporal blocking depth of the frame kernels
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
@@ -97,7 +98,7 @@ struct AdderHipCtx {
     size_t ftab_cap = 0;            // entries
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
-    hipEvent_t cap_e1 = nullptr, cap_e2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t cap_e1 = nullptr, cap_e2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::map<uint64_t, hipGraphExec_t> graphs;  // key: see get_graph
     bool use_graph = true;
     bool eager_two_streams = false;
@@ -241,7 +242,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->d_ftab) (void)hipFree(c->d_ftab);
     if (c->h_ftab) (void)hipHostFree(c->h_ftab);
-    for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1], c->cap_e2[2]})
+    for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1], c->cap_e2[2], c->cap_e2[3], c->cap_e2[4]})
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
     if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
@@ -354,7 +355,7 @@ static int init_state(AdderHipCtx *c) {
 
 // The scratch ring holds two chunks of frames: chunk k is stepped while chunk k-1 is scanned and expanded
 // (launch_frame_loop makes the step of chunk k wait for the expansion of chunk k-2).
-constexpr uint32_t kFuseLagChunks = 1;
+
 
 static int alloc_scratch(AdderHipCtx *c, uint32_t bytes_per_segment);
 
@@ -453,14 +454,26 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, dalloc(&c->d_batch, 1));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s2, hipStreamNonBlocking));
+        {
+            // scan / offsets / expansion of chunk k share the chip with the frame kernel of chunk k+1: the short
+            // scan must not queue behind a grid that fills every CU, or the expansion starts a whole kernel late
+            int lo_prio = 0, hi_prio = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            const char *pe = getenv("ADDER_HIP_S2_PRIORITY");
+            const int prio = pe ? atoi(pe) : hi_prio;
+            HIPCHK(c, hipStreamCreateWithPriority(&c->cap_s2, hipStreamNonBlocking, prio));
+        }
         HIPCHK(c, hipEventCreateWithFlags(&c->cap_e1, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[0], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[1], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->cap_e2[2], hipEventDisableTiming));
+        for (hipEvent_t &e : c->cap_e2) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char *ng = getenv("ADDER_HIP_NO_GRAPH")) {
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
+        }
+        {
+            // workgroups per CU of the lean frame kernel and of the expansion when they share the chip (0: full grids)
+            const char *lb = getenv("ADDER_HIP_LEAN_BLOCKS_PER_CU"), *eb = getenv("ADDER_HIP_EXPAND_BLOCKS_PER_CU");
+            c->lean_blocks_per_cu = lb ? (uint32_t)atoi(lb) : 5u;
+            c->expand_blocks_per_cu = eb ? (uint32_t)atoi(eb) : 3u;
         }
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
@@ -665,10 +678,12 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::min<size_t>((size_t)12 << 30, free_b / 4);
     const size_t per_frame = (size_t)c->num_waves * ((size_t)bytes + 2 * sizeof(uint32_t));
-    const size_t ch = budget / ((kFuseLagChunks + 1u) * per_frame);
+    c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
+    if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
+    const size_t ch = budget / (c->ring_chunks * per_frame);
     c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
     if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
-    c->slots = (kFuseLagChunks + 1u) * c->chunk;
+    c->slots = c->ring_chunks * c->chunk;
     HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * bytes));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
@@ -715,10 +730,10 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
     fa.rx1 = c->roi[2];
     fa.ry1 = c->roi[3];
     for (uint32_t f = 0; f < num_frames; ++f) {
-        HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, 0u, s));
+        HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, s));
         HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1u, s));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, s));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, 0u, s));
         HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
     }
     return ADDER_OK;
@@ -730,15 +745,22 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
     // to their unit, so the lane's own program order keeps them consistent across frames.
     const uint32_t depth = launch_depth(c);
+    // With a second stream the expansion of chunk k runs beside the frame kernel of chunk k+1.  The frame kernel is
+    // bound by instruction issue, the expansion by memory, and two grids that each fill the chip would simply run one
+    // after the other (measured: the scan queued behind the resident frame kernel for a whole kernel time): both are
+    // launched with a few workgroups per CU that walk their work, so that both are resident on every CU.
+    const bool share = s2 != nullptr && num_frames > c->chunk;
+    const uint32_t lean_cap = share ? c->lean_blocks_per_cu * c->num_cus : 0u;
+    const uint32_t expand_cap = share ? c->expand_blocks_per_cu * c->num_cus : 0u;
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
-        if (s2 && k >= 2)  // scratch reuse: the expansion of chunk k-2
-            HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 2u) % 3u], 0));
+        if (s2 && k >= c->ring_chunks)  // scratch reuse: the expansion of the chunk that held these slots
+            HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - c->ring_chunks) % 5u], 0));
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, 0u, 0u, s));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, lean_cap, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
                 c->timed_launches += 1;
@@ -754,14 +776,14 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, t));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));
             c->timed_posts += 1;
         }
-        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 3u], s2));
+        if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], s2));
     }
-    if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 3u], 0));  // join (s2 is in-order)
+    if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 5u], 0));  // join (s2 is in-order)
     return ADDER_OK;
 }
 

@@ -150,10 +150,11 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 
 extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 | continuous << 3 (host copy of what BatchArgs holds)
-// K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking); the same grid also
-// expands frames [exp_f0, exp_f0 + exp_nf) of an earlier, already scanned chunk (exp_nf may be 0)
+// K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking).  grid_cap (0 = none) bounds the number of
+// workgroups of the lean kernel / of the expansion: the workgroups then walk their work items, which leaves room
+// for the other kernel to be resident on the same CUs
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                              uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream);
+                              uint32_t num_waves, uint32_t grid_cap, hipStream_t stream);
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
@@ -161,7 +162,7 @@ hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                               uint32_t variant, hipStream_t stream);
+                               uint32_t variant, uint32_t grid_cap, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,
                                       uint32_t chunk_rows, uint32_t num_chunks, uint32_t *offsets,

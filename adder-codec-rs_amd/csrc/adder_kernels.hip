@@ -358,19 +358,26 @@ __device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b
 }
 
 template <bool ABS_T>
+#ifdef ADDER_LEAN_MAX_WAVES
+__attribute__((amdgpu_waves_per_eu(1, ADDER_LEAN_MAX_WAVES)))
+#endif
 __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
-    const uint32_t bid = blockIdx.x;
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw = bid * kWavesPerBlock + tid / kWave;  // the wave's segment
-    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
-    LeanRaw raw;
-    lean_load<ABS_T>(a, u0, full, raw);
-    lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
+    // The grid may be smaller than the number of segments (a few workgroups per CU that walk the segments): this
+    // kernel is bound by instruction issue and the expansion of the chunk before by memory, so the two are meant
+    // to be resident side by side -- two grids that each fill the chip would run one after the other.  Nothing
+    // below is shared between waves, so the walk needs no barrier.
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
+        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        LeanRaw raw;
+        lean_load<ABS_T>(a, u0, full, raw);
+        lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
+    }
 }
 
 // Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes kLean1Segs
@@ -1043,8 +1050,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
 }
 
 template <int FORMAT, bool ABS_T>
-__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
-    expand_block<FORMAT, ABS_T>(b, f0 + blockIdx.y, blockIdx.x);
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0,
+                                                                     uint32_t xblocks, uint32_t nf) {
+    // (frame, group of segments) pairs, frame-major; a grid smaller than their number walks them (see the lean kernel)
+    for (uint32_t w = blockIdx.x; w < xblocks * nf; w += gridDim.x) expand_block<FORMAT, ABS_T>(b, f0 + w / xblocks, w % xblocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1389,7 +1398,7 @@ extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_
 }
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                                         uint32_t num_waves, uint32_t exp_f0, uint32_t exp_nf, hipStream_t stream) {
+                                         uint32_t num_waves, uint32_t grid_cap, hipStream_t stream) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
     if (variant & 8u) {  // Mode::Continuous
@@ -1397,8 +1406,7 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         else hipLaunchKernelGGL((adder_cont_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
         return hipGetLastError();
     }
-    if (generic) {  // never fused with an expansion (adder_hip_api.cpp fuse_for)
-        if (exp_nf != 0u) return hipErrorInvalidValue;
+    if (generic) {
         if (collapse) {
             if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<true, true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
             else hipLaunchKernelGGL((adder_frame_kernel<true, false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
@@ -1408,15 +1416,16 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         }
         return hipGetLastError();
     }
-    if (!collapse || exp_nf != 0u) return hipErrorInvalidValue;  // the lean step is Collapse-only
+    if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
     if (nb == 1u && num_waves % kLean1Segs == 0u) {
         const uint32_t grid = (num_waves / kLean1Segs + kWavesPerBlock - 1) / kWavesPerBlock;
         if (abs_t) hipLaunchKernelGGL((adder_lean1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         else hipLaunchKernelGGL((adder_lean1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         return hipGetLastError();
     }
-    if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
-    else hipLaunchKernelGGL((adder_lean_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+    const uint32_t SL = grid_cap && grid_cap < S ? grid_cap : S;  // (only the blocked lean kernel walks: see its comment)
+    if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+    else hipLaunchKernelGGL((adder_lean_kernel<false>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
     return hipGetLastError();
 }
 
@@ -1440,14 +1449,17 @@ extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint
 }
 
 extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                                          uint32_t variant, hipStream_t stream) {
+                                          uint32_t variant, uint32_t grid_cap, hipStream_t stream) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
-    const dim3 grid((num_waves + per_block - 1) / per_block, nf);
+    const uint32_t xblocks = (num_waves + per_block - 1) / per_block;
+    uint32_t total = xblocks * nf;
+    if (grid_cap && grid_cap < total) total = grid_cap;
+    const dim3 grid(total);
     const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u;
-    if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
-    else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
-    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0);
-    else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0);
+    if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     return hipGetLastError();
 }
 
