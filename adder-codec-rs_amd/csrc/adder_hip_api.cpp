@@ -145,6 +145,7 @@ struct AdderHipCtx {
         BatchArgs *d_batch = nullptr, *h_batch = nullptr;
         FrameTab *d_ftab = nullptr, *h_ftab = nullptr;
         hipEvent_t done = nullptr;
+        uint32_t *d_counters = nullptr; // feature path: this frame's counters (the shared ones are reset per enqueue)
         AdderEvent *out = nullptr;      // where the events were sent (h_events, or the caller's pinned buffer)
         size_t out_cap = 0;
     } fslot[4];
@@ -222,7 +223,8 @@ static void free_ctx(AdderHipCtx *c) {
         if (sl.wired) (void)hipEventDestroy(sl.wired);
     }
     for (auto &fs : c->fslot) {
-        for (void *p : {(void *)fs.d_frame, (void *)fs.d_events, (void *)fs.d_offsets, (void *)fs.d_batch, (void *)fs.d_ftab})
+        for (void *p : {(void *)fs.d_frame, (void *)fs.d_events, (void *)fs.d_offsets, (void *)fs.d_batch, (void *)fs.d_ftab,
+                        (void *)fs.d_counters})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)fs.h_events, (void *)fs.h_hdr, (void *)fs.h_batch, (void *)fs.h_ftab})
             if (p) (void)hipHostFree(p);
@@ -1389,6 +1391,7 @@ static int frame_slot_prepare(AdderHipCtx *c, AdderHipCtx::FrameSlot &fs, size_t
         HIPCHK(c, dalloc(&fs.d_offsets, 2));
         HIPCHK(c, dalloc(&fs.d_batch, 1));
         HIPCHK(c, dalloc(&fs.d_ftab, 64));
+        HIPCHK(c, dalloc(&fs.d_counters, 4));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_batch), sizeof(BatchArgs), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_ftab), 64 * sizeof(FrameTab), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_hdr),
@@ -1442,11 +1445,13 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         FrameTab *dt, *ht;
         size_t cap;
         bool graph, snap;
+        uint32_t *counters;
         ~Swap() {
             c->d_batch = db; c->h_batch = hb; c->d_ftab = dt; c->h_ftab = ht; c->ftab_cap = cap;
-            c->use_graph = graph; c->no_snapshot = snap;
+            c->use_graph = graph; c->no_snapshot = snap; c->d_feat_counters = counters;
         }
-    } swap{c, c->d_batch, c->h_batch, c->d_ftab, c->h_ftab, c->ftab_cap, c->use_graph, c->no_snapshot};
+    } swap{c, c->d_batch, c->h_batch, c->d_ftab, c->h_ftab, c->ftab_cap, c->use_graph, c->no_snapshot, c->d_feat_counters};
+    c->d_feat_counters = fs.d_counters;
     c->d_batch = fs.d_batch;
     c->h_batch = fs.h_batch;
     c->d_ftab = fs.d_ftab;
@@ -1466,7 +1471,7 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
                                      reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
-                                     c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s));
+                                     feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s));
     HIPCHK(c, hipEventRecord(fs.done, c->out_s));
     c->f_submitted += 1;
     return ADDER_OK;
@@ -1479,6 +1484,7 @@ static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t 
     HIPCHK(c, hipEventSynchronize(fs.done));
     c->f_collected += 1;
     const FrameResult *res = reinterpret_cast<const FrameResult *>(fs.h_hdr);
+    c->last_new_features = res->new_features;
     if (events) *events = fs.out;
     if (n_events) *n_events = (size_t)res->produced;
     if (chunk_offsets) *chunk_offsets = reinterpret_cast<const uint32_t *>(fs.h_hdr + sizeof(FrameResult));

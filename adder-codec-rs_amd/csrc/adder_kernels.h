@@ -117,7 +117,7 @@ struct BatchArgs {
 struct FrameResult {
     uint64_t produced;  // events the frame produced (may exceed the slot's capacity: then status has kStatusCapacity)
     uint32_t status;
-    uint32_t pad;
+    uint32_t new_features;  // feature-driven rate control: features this frame found new
 };
 
 // handle_features / handle_roi of one context (video.rs:865-1112)
@@ -173,8 +173,8 @@ hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t 
                               uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_frame_out(const adder::AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
                                   adder::AdderEventPod *h_ev, adder::FrameResult *h_res, uint32_t *h_chunks,
-                                  const uint32_t *status, uint32_t row_begin, uint32_t chunk_rows, uint32_t num_chunks,
-                                  hipStream_t stream);
+                                  const uint32_t *status, const uint32_t *counters, uint32_t row_begin, uint32_t chunk_rows,
+                                  uint32_t num_chunks, hipStream_t stream);
 // after frame f's events are in place: FAST features at the events' pixels -> membership plane, c_thresh reset
 // around the new ones, ROI (video.rs:865-1112)
 hipError_t adder_launch_features(const adder::BatchArgs *b, uint32_t f, const adder::FeatureArgs *fa,

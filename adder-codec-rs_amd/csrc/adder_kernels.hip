@@ -1225,7 +1225,8 @@ __global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPo
                                                               const uint64_t *__restrict__ d_offsets, uint64_t cap,
                                                               AdderEventPod *__restrict__ h_ev, FrameResult *h_res,
                                                               uint32_t *__restrict__ h_chunks,
-                                                              const uint32_t *__restrict__ status, uint32_t row_begin,
+                                                              const uint32_t *__restrict__ status,
+                                                              const uint32_t *__restrict__ counters, uint32_t row_begin,
                                                               uint32_t chunk_rows, uint32_t num_chunks,
                                                               uint32_t copy_blocks) {
     const uint64_t begin = d_offsets[0];
@@ -1249,6 +1250,7 @@ __global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPo
     if (c == 0) {
         h_res->produced = produced;
         h_res->status = *status | (produced > cap ? kStatusCapacity : 0u);
+        h_res->new_features = counters ? counters[0] : 0u;
     }
     if (c > num_chunks) return;
     if (c == num_chunks) {
@@ -1480,12 +1482,12 @@ extern "C" hipError_t adder_launch_chunk_offsets(const AdderEventPod *ev, uint32
 
 extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
                                              AdderEventPod *h_ev, FrameResult *h_res, uint32_t *h_chunks,
-                                             const uint32_t *status, uint32_t row_begin, uint32_t chunk_rows,
-                                             uint32_t num_chunks, hipStream_t stream) {
+                                             const uint32_t *status, const uint32_t *counters, uint32_t row_begin,
+                                             uint32_t chunk_rows, uint32_t num_chunks, hipStream_t stream) {
     const uint32_t copy_blocks = 128;  // a slice of the chip keeps a x16 link busy
     const uint32_t chunk_blocks = (num_chunks + 1 + 255) / 256;
     hipLaunchKernelGGL(adder_frame_out_kernel, dim3(copy_blocks + chunk_blocks), dim3(256), 0, stream, d_ev, d_offsets,
-                       cap, h_ev, h_res, h_chunks, status, row_begin, chunk_rows, num_chunks, copy_blocks);
+                       cap, h_ev, h_res, h_chunks, status, counters, row_begin, chunk_rows, num_chunks, copy_blocks);
     return hipGetLastError();
 }
 
