@@ -23,6 +23,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o bench -
     python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
 find "$OUT/stats2" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_default_depth_kernel_stats.csv" \;
 
+# 2b. the same, eager on ONE stream (ADDER_HIP_NO_GRAPH=1): the kernels run one after the other at full grids, which is
+#     what bench.py's HIP-event pairs time for its `roofline` block (in the default run the frame kernel and the
+#     expansion share the chip, so their trace durations overlap and are longer)
+ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -o bench -- \
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end > "$OUT/bench_eager_under_rocprof.log" 2>&1
+find "$OUT/stats3" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_eager_serial_kernel_stats.csv" \;
+
 pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
     local tag=$1 envs=$2; shift; shift
     local cmd="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --skip-roofline $*"
@@ -40,5 +47,5 @@ pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
 pmc_passes default "A=1" --frames 160
 pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96
 pmc_passes generic_dtm7650_abs "A=1" --frames 60 --delta-t-max 7650 --time-mode absolute_t
-rm -rf "$OUT"/stats "$OUT"/stats2
+rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3
 ls -la "$OUT"
