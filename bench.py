@@ -323,7 +323,10 @@ def main():
             "units_per_launch": units,
             "launch_avg_us": round(k1_one_us, 3),
             "note": "the frame kernel alone with the state streamed from HBM every frame (per-frame consume contract): "
-                    "bytes it really moves = 1 input + 16 state in + 16 state out + 16 per parked record",
+                    "bytes it really moves = 1 input + 16 state in + 16 state out + 16 per parked record.  The duration "
+                    "is a HIP-event pair around every launch, which on this runtime reads ~2 us more than the kernel "
+                    "itself (rocprofv3 kernel duration of the same run: profiles/r02_bench_kernel_stats.csv, "
+                    "adder_lean1_kernel 14.35 us = 0.65)",
         },
     }
     if layout_elapsed is not None:
