@@ -269,7 +269,40 @@ Decoder::Decoder(const uint8_t *data, size_t size) : data_(data), size_(size) {
     meta_.header_size = pos_;
 }
 
+Decoder Decoder::new_compressed(const uint8_t *data, size_t size) {
+    if (size < 5 || memcmp(data, "addec", 5) != 0) throw CodecError(CodecError::WrongMagic, "not a compressed ADDER stream");
+    Decoder d;
+    d.data_ = data;
+    d.size_ = size;
+    d.compressed_ = true;
+    AdderCompressedParams p;
+    adder_compressed_default_params(&p, 1, 1, 1);
+    size_t n = 0;
+    int rc = adder_compressed_decode(data, size, 1, &p, nullptr, 0, &n);  // a counting pass: fills p from the header
+    if (rc != ADDER_OK && rc != ADDER_E_OUT_CAPACITY) throw CodecError(CodecError::Deserialize, "malformed compressed stream");
+    d.decoded_.resize(n);
+    if (n) {
+        rc = adder_compressed_decode(data, size, 1, &p, d.decoded_.data(), n, &n);
+        if (rc != ADDER_OK) throw CodecError(CodecError::Deserialize, "malformed compressed stream");
+    }
+    d.meta_.codec_version = p.codec_version;
+    d.meta_.plane = PlaneSize(p.width, p.height, p.channels);
+    d.meta_.tps = p.tps;
+    d.meta_.ref_interval = p.ref_interval;
+    d.meta_.delta_t_max = p.delta_t_max;
+    d.meta_.event_size = 0;  // (compressed streams carry no fixed-size records: header.rs writes 0)
+    d.meta_.time_mode = (TimeMode)p.time_mode;
+    d.meta_.source_camera = (SourceCamera)p.source_camera;
+    d.meta_.adu_interval = p.adu_interval;
+    return d;
+}
+
 bool Decoder::digest_event(Event *out) {
+    if (compressed_) {
+        if (pos_ >= decoded_.size()) return false;
+        *out = decoded_[pos_++];
+        return true;
+    }
     const size_t es = meta_.event_size;
     if (pos_ + es > size_) return false;
     const uint8_t *p = data_ + pos_;

@@ -163,14 +163,20 @@ class Encoder {  // encoder.rs:29-37
 class Decoder {  // decoder.rs:22-29
   public:
     Decoder(const uint8_t *data, size_t size);  // Decoder::new_raw + decode_header (:102-203)
+    // Decoder::new_compressed (:35-51): the "addec" header, then CompressedInput::digest_event (compressed/stream.rs:
+    // 377-424) over the ADUs -- decoded by the compressed source of libadder_hip.so (adder_compressed_decode)
+    static Decoder new_compressed(const uint8_t *data, size_t size);
     const CodecMetadata &meta() const { return meta_; }
     bool digest_event(Event *out);  // raw/stream.rs:177-201 ; false at the EOF event / end of data
     size_t position() const { return pos_; }
 
   private:
-    const uint8_t *data_;
-    size_t size_, pos_ = 0;
+    Decoder() = default;
+    const uint8_t *data_ = nullptr;
+    size_t size_ = 0, pos_ = 0;
     CodecMetadata meta_;
+    bool compressed_ = false;
+    std::vector<Event> decoded_;  // compressed: all events of the stream, in stream order
 };
 
 // utils/viz.rs:76-86 -- display only; kept so that update_detect_features reads like the reference's

@@ -179,7 +179,9 @@ long long adder_host_simulproc(const uint8_t *frames, uint32_t num_frames, uint3
 // events; returns the number of events in the stream, or -1.
 long long adder_host_decode_raw(const uint8_t *data, size_t size, uint32_t *meta, AdderEvent *events, size_t cap) {
     try {
-        Decoder dec(data, size);
+        // (Decoder::new_raw or Decoder::new_compressed by the magic, as the reference's players do: adder-viz
+        // player/adder.rs tries the compressed decoder first)
+        Decoder dec = size >= 5 && memcmp(data, "addec", 5) == 0 ? Decoder::new_compressed(data, size) : Decoder(data, size);
         const CodecMetadata &m = dec.meta();
         meta[0] = m.codec_version;
         meta[1] = m.plane.w();

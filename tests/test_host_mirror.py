@@ -126,6 +126,10 @@ def test_framed_transcode_to_compressed_sink_config5_mode(tmp_path):
     assert blob == co.close()
     dec, p = A.compressed_decode(blob)
     assert (p.width, p.height, p.channels, p.adu_interval) == (W, H, 3, 30) and 0 < len(dec) <= len(ev)
+    # the mirror's Decoder::new_compressed reads the file back: header fields and every event of the source
+    meta2, ev2 = Hst.decode_raw(blob)  # meta: version, w, h, c, tps, ref, dtm, event_size, camera | time_mode << 8, adu
+    assert (int(meta2[1]), int(meta2[2]), int(meta2[3]), int(meta2[9])) == (W, H, 3, 30)
+    assert int(meta2[8]) >> 8 == 1 and np.array_equal(ev2, dec)
 
 
 @pytest.mark.gpu
@@ -155,3 +159,27 @@ def test_framed_transcode_with_feature_rate_control_and_roi(tmp_path):
         meta, ev = Hst.decode_raw(open(out, "rb").read())
         assert n == len(want) and np.array_equal(ev, want)
         assert np.array_equal(fs, v.feature_set()) and fs.sum() > 0
+
+
+def test_decoder_new_compressed_reads_what_the_compressed_encoder_wrote():
+    """Decoder::new_compressed (decoder.rs:35-51) in the mirror: the "addec" header and every event of a stream written
+    by the compressed sink, equal to what the C-ABI source returns (the compressed codec is CPU code: no device)."""
+    import adder_amd as A
+    rng = np.random.default_rng(0)
+    for Cn in (1, 3):
+        W, H, n = 40, 30, 4000
+        enc = A.CompressedEncoder(W, H, Cn, tps=7650, ref_interval=255, delta_t_max=7650, adu_interval=10, time_mode=1,
+                                  c_thresh_max=0)
+        ev = np.zeros(n, A.EVENT_DTYPE)
+        ev["x"], ev["y"] = rng.integers(0, W, n), rng.integers(0, H, n)
+        ev["c"] = 0xFF if Cn == 1 else rng.integers(0, 3, n)
+        ev["d"] = rng.integers(0, 12, n)
+        ev["t"] = np.sort(rng.integers(1, 7650 * 3, n))
+        enc.ingest(ev)
+        blob = enc.close()
+        dec, p = A.compressed_decode(blob)
+        meta, ev2 = Hst.decode_raw(blob)
+        assert [int(v) for v in meta[:7]] == [3, W, H, Cn, 7650, 255, 7650] and int(meta[9]) == 10
+        assert int(meta[8]) >> 8 == 1 and len(ev2) == len(dec) > 0 and np.array_equal(ev2, dec)
+    with pytest.raises(AssertionError):
+        Hst.decode_raw(b"addec" + bytes(3))  # a truncated header is an error, not a crash
