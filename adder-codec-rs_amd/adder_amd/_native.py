@@ -70,6 +70,10 @@ class AdderFramerParams(C.Structure):
         ("source_camera", C.c_uint32),
         ("ring_frames", C.c_uint32),
         ("device_id", C.c_int32),
+        ("view_mode", C.c_uint8),
+        ("source_type", C.c_uint8),
+        ("reserved1", C.c_uint8 * 2),
+        ("practical_d_max", C.c_float),
     ]
 
 

@@ -15,7 +15,7 @@ FRAMED_U8, DVS = 0, 6  # SourceCamera (adder-codec-core/src/lib.rs:35-47)
 class HipFramer:
     def __init__(self, width, height, channels=1, *, tps, ref_interval, delta_t_max, output_fps=None,
                  codec_version=1, time_mode=N.TIME_DELTA_T, source_camera=FRAMED_U8, row_begin=0, row_end=None,
-                 ring_frames=0, device_id=0):
+                 ring_frames=0, device_id=0, view_mode=0, source_type=0, practical_d_max=0.0):
         self.L = N.load()
         p = N.AdderFramerParams()
         self.L.adder_framer_default_params(C.byref(p), width, height, channels)
@@ -24,6 +24,8 @@ class HipFramer:
         p.tps, p.ref_interval, p.delta_t_max = tps, ref_interval, delta_t_max
         p.output_fps = 0.0 if output_fps is None else float(output_fps)
         p.source_camera, p.ring_frames, p.device_id = source_camera, ring_frames, device_id
+        # FramedViewMode 0 Intensity / 1 D / 2 DeltaT / 3 SAE; SourceType 0 U8 .. 3 U64; practical_d_max for the D view
+        p.view_mode, p.source_type, p.practical_d_max = view_mode, source_type, float(practical_d_max)
         h = C.c_void_p()
         rc = self.L.adder_framer_create(C.byref(p), C.byref(h))
         if rc != N.OK:

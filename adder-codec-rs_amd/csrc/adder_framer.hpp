@@ -41,8 +41,17 @@ struct FramerConsts {
     uint32_t abs_t;         // codec_version >= 2 && TimeMode::AbsoluteT (:1001, :1024-1030)
     uint32_t round_up;      // codec_version >= 1 && framed source camera (:1093-1107)
     FastDivU32 by_tpf, by_ref;
+    // what a frame's byte shows (<u8 as FrameValue>::get_frame_value, scale_intensity.rs:54-109)
+    uint32_t view_mode;      // FramedViewMode: 0 Intensity, 1 D, 2 DeltaT, 3 SAE (video.rs:144-158)
+    uint32_t source_type;    // SourceType of the intensities: 0 U8, 1 U16, 2 U32, 3 U64 (Intensity view)
+    float practical_d_max;   // D view: log2_raw(255 * (delta_t_max / ref_interval)), computed by the caller (:1020-1021)
+    uint32_t delta_t_max;    // DeltaT / SAE views
 };
-ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up) {
+constexpr uint32_t kViewIntensity = 0, kViewD = 1, kViewDeltaT = 2, kViewSae = 3;
+
+ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
+                                    uint32_t view_mode = 0, uint32_t source_type = 0, float practical_d_max = 0.0f,
+                                    uint32_t delta_t_max = 0) {
     FramerConsts k;
     k.tpf = tpf;
     k.ref_interval = ref_interval;
@@ -50,7 +59,25 @@ ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_
     k.round_up = round_up;
     k.by_tpf = fast_div_make(tpf);
     k.by_ref = fast_div_make(ref_interval);
+    k.view_mode = view_mode;
+    k.source_type = source_type;
+    k.practical_d_max = practical_d_max;
+    k.delta_t_max = delta_t_max;
     return k;
+}
+
+// <u8 as FrameValue>::get_frame_value for an event that sets a pixel's intensity (driver.rs:1017-1044): `te` = event.t
+// as the framer hands it over (AbsoluteT streams: minus the pixel's previous clock, except in the SAE view, :1022-1028),
+// clock / prev_clock = the pixel's running timestamp after / before the event, as u32 (`as DeltaT`).
+ADDER_HD uint32_t framer_value_u8(uint32_t d, uint32_t te, uint32_t clock, uint32_t prev_clock, const FramerConsts &k) {
+    if (k.view_mode == kViewD) return f32_as_u8((float)d / k.practical_d_max * 255.0f);
+    if (k.view_mode == kViewDeltaT) return f32_as_u8((float)te / (float)k.delta_t_max * 255.0f);
+    if (k.view_mode == kViewSae) return f32_as_u8((float)(clock - prev_clock) / (float)k.delta_t_max * 255.0f);
+    const double intensity = event_intensity_f64(d, te);
+    const double tpf = (double)k.ref_interval;
+    if (k.source_type == 0u) return f64_as_u8(intensity * tpf);
+    const double full = k.source_type == 1u ? 65535.0 : k.source_type == 2u ? 4294967295.0 : 18446744073709551616.0;
+    return f64_as_u8(intensity / full * tpf * 255.0);
 }
 
 struct FramerPx {
@@ -85,11 +112,11 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
     } else if ((int64_t)q > (int64_t)p.lastf) {
         if (d != 255u) {  // D_EMPTY repeats the last intensity (:1017-1019)
             uint32_t te = t;
-            if (k.abs_t) {
+            if (k.abs_t && k.view_mode != kViewSae) {
                 const uint32_t pr = (uint32_t)prev_ts;
                 te = t > pr ? t - pr : 0u;  // event.t.saturating_sub(prev_running_ts as u32)
             }
-            p.lasti = frame_value_u8(d, te, (double)k.ref_interval);
+            p.lasti = framer_value_u8(d, te, (uint32_t)p.ts, (uint32_t)prev_ts, k);
         }
         fill_from = p.lastf;
         fill_to = (int32_t)q;

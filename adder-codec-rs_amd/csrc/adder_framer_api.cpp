@@ -109,6 +109,7 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
     if (p.row_begin >= p.row_end || p.row_end > p.height) return ffail(nullptr, ADDER_E_BAD_PARAMS, "bad row band");
     if (!p.ref_interval || !p.tps) return ffail(nullptr, ADDER_E_BAD_PARAMS, "tps and ref_interval must be non-zero");
     if (p.time_mode > ADDER_TIME_MIXED) return ffail(nullptr, ADDER_E_BAD_PARAMS, "bad time_mode");
+    if (p.view_mode > ADDER_VIEW_SAE || p.source_type > 3) return ffail(nullptr, ADDER_E_BAD_PARAMS, "bad view_mode / source_type");
     // FrameSequence::new (driver.rs:357-361)
     uint32_t tpf = p.ref_interval;
     if (p.output_fps > 0.0f) {
@@ -198,7 +199,8 @@ static FramerArgs make_args(const AdderFramer *fr) {
     a.frames_written = (int32_t)fr->frames_written;
     a.k = framer_consts(fr->tpf, fr->p.ref_interval,
                         (fr->p.codec_version >= 2 && fr->p.time_mode == ADDER_TIME_ABSOLUTE_T) ? 1u : 0u,
-                        (fr->p.codec_version >= 1 && fr->p.source_camera <= 5u) ? 1u : 0u);
+                        (fr->p.codec_version >= 1 && fr->p.source_camera <= 5u) ? 1u : 0u, fr->p.view_mode,
+                        fr->p.source_type, fr->p.practical_d_max, fr->p.delta_t_max);
     return a;
 }
 

@@ -199,7 +199,7 @@ __device__ __forceinline__ FramerLaneOut framer_batch_step_short(bool active, ui
     };
     const uint32_t ts0 = (uint32_t)p0.ts;
     const bool p1 = npred >= 1u, p2 = npred >= 2u, p3 = npred >= 3u;
-    uint32_t ts_pre, ts_post, te = t;
+    uint32_t ts_pre, ts_post, te = t, prev_clock;
     bool ignored = false;
     if (k.abs_t) {
         const uint32_t r = active ? rnd(t) : 0u;
@@ -211,13 +211,15 @@ __device__ __forceinline__ FramerLaneOut framer_batch_step_short(bool active, ui
         ignored = prev >= t;
         ts_pre = t;
         ts_post = ignored ? prev : r;
-        te = t > prev ? t - prev : 0u;
+        if (k.view_mode != kViewSae) te = t > prev ? t - prev : 0u;
+        prev_clock = prev;
     } else {
         const uint32_t inc = !active ? 0u : npred == 0u ? rnd(ts0 + t) - ts0 : rnd(t);
         const uint32_t i1 = wave_shr1(inc), i2 = wave_shr1(i1), i3 = wave_shr1(i2);
         const uint32_t excl = (p1 ? i1 : 0u) + (p2 ? i2 : 0u) + (p3 ? i3 : 0u);
         ts_pre = ts0 + excl + t;
         ts_post = ts0 + excl + inc;
+        prev_clock = ts0 + excl;
     }
     const uint32_t qq = fast_div(ts_pre ? ts_pre - 1u : 0u, k.by_tpf);
     const bool overflow = active && !ignored && qq > (uint32_t)kFramerMaxFrame;
@@ -235,7 +237,7 @@ __device__ __forceinline__ FramerLaneOut framer_batch_step_short(bool active, ui
     o.to = (int32_t)qq;
     o.lastf_post = qv > lastf_prev ? qv : lastf_prev;
     const bool own = o.fills && d != 255u;
-    const uint32_t enc = own ? 0x100u | frame_value_u8(d, te, (double)k.ref_interval) : 0u;
+    const uint32_t enc = own ? 0x100u | framer_value_u8(d, te, ts_pre, prev_clock, k) : 0u;
     const uint32_t e1 = wave_shr1(enc), e2 = wave_shr1(e1), e3 = wave_shr1(e2);
     o.value = own ? enc & 0xffu
               : (p1 && (e1 & 0x100u)) ? e1 & 0xffu
@@ -274,14 +276,15 @@ __device__ __forceinline__ FramerLaneOut framer_batch_step(bool active, uint32_t
         ts_pre = (TS)t;
         ts_post = ignored ? prev : r;
         const uint32_t pr = (uint32_t)prev;
-        te = t > pr ? t - pr : 0u;
+        if (k.view_mode != kViewSae) te = t > pr ? t - pr : 0u;
     } else {
         // after its first event of the batch the clock is a multiple of ref_interval (or nothing is rounded), so
         // the later events add their own rounded t: a prefix sum
         const TS inc = !active ? (TS)0 : lane == head ? (TS)(rnd(ts0 + (TS)t) - ts0) : rnd((TS)t);
         const TS incl = framer_seg_scan(inc, lane, head, [](TS x, TS y) { return (TS)(x + y); });
         ts_post = ts0 + incl;
-        ts_pre = ts0 + (incl - inc) + (TS)t;
+        prev = ts0 + (incl - inc);
+        ts_pre = prev + (TS)t;
     }
     const TS rm1 = ts_pre ? ts_pre - 1 : 0;
     TS qq;
@@ -300,7 +303,7 @@ __device__ __forceinline__ FramerLaneOut framer_batch_step(bool active, uint32_t
     o.lastf_post = qm > p0.lastf ? qm : p0.lastf;
     // the intensity a fill takes: this event's, or for a D_EMPTY filler the last one before it (:1017-1019)
     const bool own = o.fills && d != 255u;
-    const uint32_t enc = own ? ((lane + 1u) << 8) | frame_value_u8(d, te, (double)k.ref_interval) : 0u;
+    const uint32_t enc = own ? ((lane + 1u) << 8) | framer_value_u8(d, te, (uint32_t)ts_pre, (uint32_t)prev, k) : 0u;
     const uint32_t em = framer_seg_scan(enc, lane, head, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
     o.value = em ? (em & 0xffu) : p0.lasti;
     o.ts_post = (uint64_t)ts_post;

@@ -834,22 +834,27 @@ ADDER_HD bool cont_step(APx &s, Acc &acc, uint32_t v, float intensity, float tim
     return ok;
 }
 
-// u8::get_frame_value for the running_intensities side plane (video.rs:713-730,
-// framer/scale_intensity.rs:58-72,262-270): ((2^d / t) * ref_time) as u8 in f64.
-ADDER_HD uint32_t frame_value_u8(uint32_t d, uint32_t t, double tpf) {
-    double intensity;
-    if (d >= 129u) {
-        intensity = 0.0;
-    } else {
-        const double shift =
-            d == 128u ? 0.0 : __builtin_bit_cast(double, (uint64_t)(d + 1023u) << 52);
-        intensity = t == 0u ? shift : shift / (double)t;
-    }
-    const double val = intensity * tpf;
+// event_to_intensity (framer/scale_intensity.rs:262-270): 2^d / t in f64 (t = 0 counts as 1; d beyond the table: 0)
+ADDER_HD double event_intensity_f64(uint32_t d, uint32_t t) {
+    if (d >= 129u) return 0.0;
+    const double shift = d == 128u ? 0.0 : __builtin_bit_cast(double, (uint64_t)(d + 1023u) << 52);
+    return t == 0u ? shift : shift / (double)t;
+}
+// Rust's `as u8` from a float: saturating, NaN -> 0
+ADDER_HD uint32_t f64_as_u8(double val) {
     if (!(val > 0.0)) return 0u;
     if (val >= 255.0) return 255u;
     return (uint32_t)val;
 }
+ADDER_HD uint32_t f32_as_u8(float val) {
+    if (!(val > 0.0f)) return 0u;
+    if (val >= 255.0f) return 255u;
+    return (uint32_t)val;
+}
+
+// u8::get_frame_value, Intensity view of a U8 source, for the running_intensities side plane (video.rs:713-730,
+// framer/scale_intensity.rs:58-72): ((2^d / t) * ref_time) as u8 in f64.
+ADDER_HD uint32_t frame_value_u8(uint32_t d, uint32_t t, double tpf) { return f64_as_u8(event_intensity_f64(d, t) * tpf); }
 
 // ------------------------------------------------------------------------------------------
 // Feature-driven rate control.  FAST 9_16 corner test on the running-intensities plane

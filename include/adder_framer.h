@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ADDER_FRAMER_ABI_VERSION 1u
+#define ADDER_FRAMER_ABI_VERSION 2u
 
 typedef struct AdderFramerParams {
     uint32_t abi_version;   /* ADDER_FRAMER_ABI_VERSION */
@@ -43,7 +43,18 @@ typedef struct AdderFramerParams {
     uint32_t source_camera; /* SourceCamera discriminant (adder-codec-core/src/lib.rs:35-47); 0..5 = framed */
     uint32_t ring_frames;   /* frames kept on the device; 0 = delta_t_max / tpf + 80 */
     int32_t device_id;
+    /* what a frame's byte shows: <u8 as FrameValue>::get_frame_value (framer/scale_intensity.rs:54-109) */
+    uint8_t view_mode;      /* FramedViewMode (video.rs:144-158): 0 Intensity, 1 D, 2 DeltaT, 3 SAE */
+    uint8_t source_type;    /* SourceType of the intensities (Intensity view): 0 U8, 1 U16, 2 U32, 3 U64 */
+    uint8_t reserved1[2];
+    float practical_d_max;  /* D view: fast_math::log2_raw(255.0 * (delta_t_max / ref_interval) as f32), computed by
+                             * the caller (driver.rs:1020-1021; the approximation belongs to a third-party crate) */
 } AdderFramerParams;
+
+#define ADDER_VIEW_INTENSITY 0
+#define ADDER_VIEW_D 1
+#define ADDER_VIEW_DELTA_T 2
+#define ADDER_VIEW_SAE 3
 
 typedef struct AdderFramer AdderFramer;
 

@@ -66,6 +66,10 @@ typedef struct {
     uint8_t *chunk_filled;
     int has_buffer_limit;
     uint32_t buffer_limit;
+    /* FramerBuilder::view_mode / ::source (driver.rs:104-107, 132-140); practical_d_max as the caller computes it
+     * (fast_math::log2_raw, a third-party approximation that is not restated here) */
+    int view_mode, source_type;
+    float practical_d_max;
 } OracleFramer;
 
 static void frame_init(OFrame *f, size_t px) {
@@ -153,6 +157,11 @@ void oracle_framer_buffer_limit(OracleFramer *f, int has, uint32_t limit) {
     f->has_buffer_limit = has;
     f->buffer_limit = limit;
 }
+void oracle_framer_set_view(OracleFramer *f, int view_mode, int source_type, float practical_d_max) {
+    f->view_mode = view_mode;
+    f->source_type = source_type;
+    f->practical_d_max = practical_d_max;
+}
 uint32_t oracle_framer_tpf(const OracleFramer *f) { return f->tpf; }
 int64_t oracle_framer_frames_written(const OracleFramer *f) { return f->frames_written; }
 size_t oracle_framer_num_chunks(const OracleFramer *f) { return f->num_chunks; }
@@ -175,6 +184,45 @@ static uint8_t frame_value_u8(uint8_t d, uint32_t t, double tpf) {
     if (!(v > 0.0)) return 0;
     if (v >= 255.0) return 255;
     return (uint8_t)v;
+}
+
+/* Rust's `as u8` from f32: saturating, NaN -> 0 */
+static uint8_t f32_as_u8(float v) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+static uint8_t f64_as_u8(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+static double event_to_intensity(uint8_t d, uint32_t t) { /* scale_intensity.rs:262-270 */
+    if (d >= 129) return 0.0;
+    double shift = 0.0; /* D_SHIFT_F64[128] = 0 */
+    if (d < 128) {
+        shift = 1.0;
+        for (unsigned i = 0; i < d; ++i) shift *= 2.0;
+    }
+    return t == 0 ? shift : shift / (double)t;
+}
+/* <u8 as FrameValue>::get_frame_value, every arm (scale_intensity.rs:54-109); px = SaeTime {running_t, last_fired_t}.
+ * view: 0 Intensity, 1 D, 2 DeltaT, 3 SAE (FramedViewMode, video.rs:144-158); source: 0 U8, 1 U16, 2 U32, 3 U64 */
+static uint8_t get_frame_value_u8(uint8_t d, uint32_t t, int source, double tpf, float practical_d_max,
+                                  uint32_t delta_t_max, int view, uint32_t running_t, uint32_t last_fired_t) {
+    switch (view) {
+    case 1: return f32_as_u8(((float)d / practical_d_max) * 255.0f);
+    case 2: return f32_as_u8(((float)t / (float)delta_t_max) * 255.0f);
+    case 3: return f32_as_u8(((float)(running_t - last_fired_t) / (float)delta_t_max) * 255.0f);
+    default: break;
+    }
+    const double intensity = event_to_intensity(d, t);
+    switch (source) {
+    case 0: return f64_as_u8(intensity * tpf);
+    case 1: return f64_as_u8(intensity / 65535.0 * tpf * 255.0);
+    case 2: return f64_as_u8(intensity / 4294967295.0 * tpf * 255.0);
+    default: return f64_as_u8(intensity / 18446744073709551615.0 * tpf * 255.0); /* u64::MAX as f64 */
+    }
 }
 
 static int is_framed_camera(uint32_t cam) { return cam <= 5u; } /* FramedU8..FramedF64 (lib.rs:35-47) */
@@ -203,11 +251,16 @@ static int ingest_event_for_chunk(OracleFramer *f, OracleEvent *ev, ODeque *chun
     const uint64_t rm1 = *running_ts ? *running_ts - 1 : 0; /* saturating_sub(1) */
     if ((int64_t)rm1 / (int64_t)f->tpf > *last_filled) {
         if (ev->d != D_EMPTY) {
-            if (abs_t) { /* view_mode != SAE */
+            if (abs_t && f->view_mode != 3) { /* :1022-1028 */
                 const uint32_t p = (uint32_t)prev_running_ts;
                 ev->t = ev->t > p ? ev->t - p : 0u; /* saturating_sub */
             }
-            *last_intensity = frame_value_u8(ev->d, ev->t, (double)f->ref_interval);
+            if (f->view_mode == 0 && f->source_type == 0)
+                *last_intensity = frame_value_u8(ev->d, ev->t, (double)f->ref_interval);
+            else
+                *last_intensity = get_frame_value_u8(ev->d, ev->t, f->source_type, (double)f->ref_interval,
+                                                     f->practical_d_max, f->source_dtm, f->view_mode,
+                                                     (uint32_t)*running_ts, (uint32_t)prev_running_ts);
         }
         *last_filled = (int64_t)rm1 / (int64_t)f->tpf;
 

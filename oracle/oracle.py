@@ -342,6 +342,11 @@ class Framer:
         self.chunk_rows = chunk_rows
         self.num_chunks = self.L.oracle_framer_num_chunks(self.h)
 
+    def set_view(self, view_mode, source_type=0, practical_d_max=0.0):
+        """FramerBuilder::view_mode / ::source: 0 Intensity, 1 D, 2 DeltaT, 3 SAE; source 0 U8 .. 3 U64."""
+        self.L.oracle_framer_set_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+        self.L.oracle_framer_set_view(self.h, view_mode, source_type, practical_d_max)
+
     def __del__(self):
         if getattr(self, "h", None):
             self.L.oracle_framer_free(self.h)

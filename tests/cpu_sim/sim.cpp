@@ -344,6 +344,16 @@ extern "C" uint64_t sim_fast_div_check(uint32_t d, const uint32_t *n, size_t cou
     return bad;
 }
 
+static uint32_t g_view_mode = 0, g_source_type = 0, g_view_dtm = 0;
+static float g_practical_d_max = 0.0f;
+// what the next sim_framer_run shows (FramedViewMode / SourceType; 0, 0 = the U8 Intensity view)
+extern "C" void sim_framer_set_view(uint32_t view_mode, uint32_t source_type, float practical_d_max, uint32_t delta_t_max) {
+    g_view_mode = view_mode;
+    g_source_type = source_type;
+    g_practical_d_max = practical_d_max;
+    g_view_dtm = delta_t_max;
+}
+
 extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, uint32_t height, uint32_t channels,
                                   uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
                                   uint8_t *out, size_t out_cap_frames) {
@@ -352,7 +362,7 @@ extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, 
     std::vector<FramerPx> px(units);
     for (auto &p : px) { p.ts = 0; p.lastf = -1; p.lasti = 0; }
     std::vector<uint8_t> frames;
-    const FramerConsts k = framer_consts(tpf, ref_interval, abs_t, round_up);
+    const FramerConsts k = framer_consts(tpf, ref_interval, abs_t, round_up, g_view_mode, g_source_type, g_practical_d_max, g_view_dtm);
     for (size_t i = 0; i < n; ++i) {
         const uint32_t c = ev[i].c == 0xFF ? 0u : ev[i].c;
         if (ev[i].x >= width || ev[i].y >= height || c >= channels) return -1;

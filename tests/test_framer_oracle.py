@@ -103,3 +103,51 @@ def test_fast_division_by_stream_constants_is_exact():
                             np.array([0, 1, d - 1, d, 2**32 - 1], np.uint64)]).astype(np.uint32)
         n = np.ascontiguousarray(n)
         assert L.sim_fast_div_check(d, n.ctypes.data, len(n)) == 0, d
+
+
+def _view_stream(rng, W, H, T, abs_t):
+    """T raster-ordered segments: every pixel fires at least every few frames, with D_EMPTY fillers and repeats."""
+    segs, clock = [], np.zeros(W * H, np.int64)
+    for k in range(T):
+        hit = np.flatnonzero(rng.random(W * H) < 0.6)
+        runs = rng.integers(1, 4, len(hit))
+        units = np.repeat(hit, runs)
+        ev = np.zeros(len(units), O.EVENT_DTYPE)
+        ev["c"], ev["x"], ev["y"] = 0xFF, units % W, units // W
+        ev["d"] = rng.choice(np.array([0, 2, 5, 7, 9, 13, 20, 128, 255], np.uint8), len(units))
+        dt = rng.choice(np.array([1, 40, 254, 255, 300, 900]), len(units))
+        if abs_t:
+            first = np.r_[True, units[1:] != units[:-1]]
+            seg_start = np.maximum.accumulate(np.where(first, np.arange(len(units)), 0))
+            cs = np.cumsum(dt)
+            t = clock[units] + cs - (cs[seg_start] - dt[seg_start])
+            np.maximum.at(clock, units, t)
+            ev["t"] = t
+        else:
+            ev["t"] = dt
+        segs.append(ev)
+    return np.concatenate(segs)
+
+
+@pytest.mark.parametrize("abs_t", [False, True])
+@pytest.mark.parametrize("view,source,dmax", [(1, 0, 12.99), (1, 0, 0.0), (2, 0, 0.0), (3, 0, 0.0), (0, 1, 0.0),
+                                              (0, 2, 0.0), (0, 3, 0.0)])
+def test_view_modes_and_source_types_of_the_device_step_equal_the_oracle(abs_t, view, source, dmax):
+    """The other arms of <u8 as FrameValue>::get_frame_value (scale_intensity.rs:73-109: D, DeltaT and SAE views,
+    U16 / U32 / U64 sources): the device header's framer_value_u8 against the oracle's literal restatement.  No
+    reference vector exists for them (its tests use the U8 Intensity view only), so this is oracle parity."""
+    import sim_py
+    rng = np.random.default_rng(view * 7 + source + 3 * abs_t)
+    W, H, T = 9, 7, 40
+    ev = _view_stream(rng, W, H, T, abs_t)
+    fr = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                  codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
+    fr.set_view(view, source, dmax)
+    want = fr.ingest_events(ev)
+    got = sim_py.framer_run(ev, W, H, 1, tpf=255, ref_interval=255, abs_t=abs_t, round_up=True, max_frames=1 << 14,
+                            view_mode=view, source_type=source, practical_d_max=dmax, delta_t_max=2550)
+    assert len(want) > 10 * W * H and got[: len(want)] == want
+    if view or source:  # and the view really differs from the U8 intensity one
+        fr0 = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                       codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
+        assert fr0.ingest_events(ev) != want

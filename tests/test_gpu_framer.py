@@ -287,3 +287,29 @@ def test_batch_kernel_equals_per_segment_kernel_and_the_host_run(abs_t, Cn, kw):
         want = sim_py.framer_run(ev, W, H, Cn, tpf=255, ref_interval=255, abs_t=abs_t, round_up=True, max_frames=1 << 15)
         got = outs[0][1]
         assert len(got) == outs[0][0] * W * H * Cn and got == want[: len(got)]
+
+
+@pytest.mark.parametrize("abs_t", [False, True])
+@pytest.mark.parametrize("view,source,dmax", [(1, 0, 12.99), (2, 0, 0.0), (3, 0, 0.0), (0, 1, 0.0), (0, 3, 0.0)])
+def test_view_modes_on_the_device(abs_t, view, source, dmax):
+    """FramedViewMode D / DeltaT / SAE and the U16 / U64 source scalings (scale_intensity.rs:73-109) through both
+    ingest kernels against the framer oracle."""
+    import torch
+    A = _hip()
+    rng = np.random.default_rng(11 + view + source)
+    W, H, T = 45, 31, 40
+    ev, offs = _synthetic_stream(rng, W, H, 1, T, abs_t=abs_t, density=0.7)
+    tm = A.TIME_ABSOLUTE_T if abs_t else A.TIME_DELTA_T
+    ofr = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                   codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
+    ofr.set_view(view, source, dmax)
+    want = ofr.ingest_events(ev.view(O.EVENT_DTYPE) if ev.dtype != O.EVENT_DTYPE else ev)
+    st = torch.cuda.current_stream().cuda_stream
+    d_ev = torch.from_numpy(ev.view(np.uint8).copy()).cuda()
+    for batch in (True, False):
+        fr = A.HipFramer(W, H, 1, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3,
+                         time_mode=tm, source_camera=A.FRAMED_U8, ring_frames=1 << 14, view_mode=view,
+                         source_type=source, practical_d_max=dmax)
+        (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
+        got = fr.pop(max_frames=fr.frames_ready())
+        assert len(want) > 0 and got[: len(want)] == want and len(got) >= len(want), (batch, len(got), len(want))
