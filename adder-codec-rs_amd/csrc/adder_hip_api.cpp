@@ -662,7 +662,7 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 }
 
 // (Re)allocates the compaction scratch ring for `bytes` of parked records per segment and frame.
-// The lean step parks at most one 16-byte record per unit (kLeanParkBytes per segment); a generic
+// The lean step parks at most one 12-byte record per unit (kLeanParkBytes per segment); a generic
 // batch can park up to max_depth + 2 8-byte records per unit.  Chunk = frames per scan launch: as many
 // as the budget allows (kFuseLagChunks + 1 chunks are in flight), at most kMaxChunk.  The budget is a
 // quarter of what the device has free, at most 12 GiB.

@@ -29,7 +29,7 @@ constexpr uint32_t kLeanWavesPerSimd = ADDER_LEAN_WAVES_PER_SIMD;  // register b
 constexpr uint32_t kMaxFramesPerLaunch = ADDER_MAX_FRAMES_PER_LAUNCH;  // temporal blocking depth of K1 (<= 64)
 constexpr uint32_t kMaxChunk = kMaxFramesPerLaunch;                // frames per scan/expand launch
 // parked-record scratch of one segment of one frame, in BYTES
-constexpr uint32_t kLeanRecBytes = 16;                             // LeanRec: at most one per unit
+constexpr uint32_t kLeanRecBytes = 12;                             // LeanRec: at most one per unit
 constexpr uint32_t kLeanParkBytes = kWaveUnits * kLeanRecBytes;
 constexpr uint32_t kGenRecBytes = 8;                               // generic variants: one per EVENT
 
@@ -91,7 +91,7 @@ struct FrameArgs {
     uint32_t n_units;
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t lean;        // 1: the batch runs the lean K1 (16-byte LeanRec records); 0: generic (8-byte per event)
+    uint32_t lean;        // 1: the batch runs the lean K1 (12-byte LeanRec records); 0: generic (8-byte per event)
     uint32_t abs_t;       // TimeMode::AbsoluteT (record decoding)
     StepConsts sc;        // running_t / cth are filled per frame from the table
 };

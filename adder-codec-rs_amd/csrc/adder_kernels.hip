@@ -9,7 +9,7 @@
 //        pixel-channels, one wave = one segment.  Loads level 0 of the arena (16 bytes per
 //        unit, structure-of-arrays planes resident in HBM across frames) and the frame bytes as
 //        coalesced vectors and steps up to 16 consecutive frames with the state in registers.
-//        Per frame and unit the step leaves at most ONE 16-byte record (the lean variants: the raw
+//        Per frame and unit the step leaves at most ONE 12-byte record (the lean variants: the raw
 //        material of its <= 3 events) -- the records are compacted per wave with ballot + mbcnt
 //        (no barrier, no atomics, no LDS) into the frame's scratch segment, the segment's event and
 //        record counts go to wtot.
@@ -298,7 +298,7 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
-            if (has) gstore(seg, pos * kLeanRecBytes, make_uint4(rec[j].ta, rec[j].wa, rec[j].tc, rec[j].wc));
+            if (has) gstore(seg, pos * kLeanRecBytes, rec[j]);
             pos += has ? 1u : 0u;
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
@@ -883,15 +883,17 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // parks ~20 records: one 64-lane round per segment would leave two thirds of the lanes idle); a pair
     // with a segment of more than 32 records takes the one-segment-at-a-time path below.
     const uint32_t half = lane >> 5, hl = lane & 31u;
-    uint4 first[LEAN ? kExpandSegs / 2u : kExpandSegs];
+    uint4 first[LEAN ? kExpandSegs / 2u : kExpandSegs];  // (lean: {ta, tc, w, -})
     if (LEAN) {
 #pragma unroll
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             first[p] = make_uint4(0u, 0u, 0u, 0u);
-            if (hl < (half ? pb : pa))
-                first[p] = gload<uint4>(park + (size_t)(2 * p) * park_bytes, half * park_bytes + hl * kLeanRecBytes);
+            if (hl < (half ? pb : pa)) {
+                const LeanRec r = gload<LeanRec>(park + (size_t)(2 * p) * park_bytes, half * park_bytes + hl * kLeanRecBytes);
+                first[p] = make_uint4(r.ta, r.tc, r.w, 0u);
+            }
         }
     } else if (FORMAT == 0) {
 #pragma unroll
@@ -929,16 +931,15 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         if (fill + 3u * kWave > kXbufEvents) flush();  // room for this round's worst case
         LeanRec r;
         r.ta = rw.x;
-        r.wa = rw.y;
-        r.tc = rw.z;
-        r.wc = rw.w;
+        r.tc = rw.y;
+        r.w = rw.z;
         const LeanEvents e = lean_decode(r, ABS_T, rt_u32);  // an all-zero record decodes to no events
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
         const uint32_t incl = wave_inclusive_scan_dpp(n);
         const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t xy = coord_xy_c(uc, ((r.wa >> kLeanUnitShift) & 0x3ffu) + unit_shift, c);
+        const uint32_t xy = coord_xy_c(uc, ((r.w >> kLeanUnitShift) & 0x3ffu) + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
     // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
@@ -968,7 +969,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     const uint8_t *const seg_park = park + (size_t)(2 * p + h) * park_bytes;
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
-                        if (i0 + lane < cnt[h]) rw = gload<uint4>(seg_park, (i0 + lane) * kLeanRecBytes);
+                        if (i0 + lane < cnt[h]) {
+                            const LeanRec r = gload<LeanRec>(seg_park, (i0 + lane) * kLeanRecBytes);
+                            rw = make_uint4(r.ta, r.tc, r.w, 0u);
+                        }
                         lean_round(rw, 0u);
                     }
                     next_segment();

@@ -332,23 +332,23 @@ struct LeanPxT {
 };
 using LeanPx = LeanPxT<ScalarLanes>;
 
-// One unit's output of one frame.  wa / wc = the threshold word (a power of two or 0: the low
-// 23 bits are free) | flag bits | unit tag; ta / tc = best_delta_t bits (DeltaT) or the event's
-// absolute t (AbsoluteT).
-constexpr uint32_t kLeanA = 1u;         // wa: event A present
-constexpr uint32_t kLeanB = 2u;         // wa: event B (D_EMPTY filler) present
-constexpr uint32_t kLeanC = 1u;         // wc: event C present
-constexpr uint32_t kLeanUnitShift = 2;  // wa: unit index inside the segment (<= 10 bits)
+// One unit's output of one frame, 12 bytes.  ta / tc = best_delta_t bits (DeltaT) or the event's absolute t
+// (AbsoluteT) of events A / C; w = flag bits | unit tag | the exponent bytes of the two thresholds (a threshold
+// is a power of two or 0, so its exponent field is all of it).
+constexpr uint32_t kLeanA = 1u;          // event A present
+constexpr uint32_t kLeanB = 2u;          // event B (D_EMPTY filler) present
+constexpr uint32_t kLeanC = 4u;          // event C present
+constexpr uint32_t kLeanUnitShift = 3;   // unit index inside the segment (10 bits)
+constexpr uint32_t kLeanExpAShift = 13;  // exponent byte of A's threshold (thr bits >> 10)
+constexpr uint32_t kLeanExpCShift = 21;  // exponent byte of C's threshold (thr bits >> 2)
 struct LeanRec {
-    uint32_t ta, wa, tc, wc;
+    uint32_t ta, tc, w;
 };
 
 ADDER_HD float lean_thr_from_bd(uint32_t bd) { return pow2_d(fired_d(bd)); }
 // best_d of a fired node from its threshold word: thr = 2^(bd+1), or 0 for bd = 128
-ADDER_HD uint32_t lean_bd_from_thr(uint32_t thr_bits) {
-    const uint32_t e = (thr_bits >> 23) & 0xffu;
-    return e == 0u ? kDZero : e - 128u;
-}
+ADDER_HD uint32_t lean_bd_from_exp(uint32_t e) { return e == 0u ? kDZero : e - 128u; }
+ADDER_HD uint32_t lean_bd_from_thr(uint32_t thr_bits) { return lean_bd_from_exp((thr_bits >> 23) & 0xffu); }
 
 template <class L>
 ADDER_HD LeanPxT<L> lean_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
@@ -396,7 +396,7 @@ ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float 
         ta = t;
     }
     const uint32_t wa =
-        f32_to_bits(p.thr) | tag | (L::lane(a_valid) ? kLeanA : 0u) | (L::lane(b_valid) ? kLeanB : 0u);
+        (f32_to_bits(p.thr) >> 10) | tag | (L::lane(a_valid) ? kLeanA : 0u) | (L::lane(b_valid) ? kLeanB : 0u);
     const M has0 = L::andnot(p.has0, flush);
     const M popped = L::andnot(p.popped, flush);
     p.base = L::lane(flush) ? v : p.base;
@@ -432,9 +432,8 @@ ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float 
         tc = t;
     }
     rec.ta = ta;
-    rec.wa = wa;
     rec.tc = tc;
-    rec.wc = f32_to_bits(p.thr) | (L::lane(need_pop) ? kLeanC : 0u);
+    rec.w = wa | (f32_to_bits(p.thr) >> 2) | (L::lane(need_pop) ? kLeanC : 0u);
     p.has0 = L::not_(need_pop);
     p.popped = L::or_(popped, need_pop);
     p.lastf = lastf;
@@ -454,11 +453,11 @@ struct LeanEvents {
 };
 ADDER_HD LeanEvents lean_decode(const LeanRec &r, bool abs_t, uint32_t running_t_u32) {
     LeanEvents e;
-    e.a = (r.wa & kLeanA) != 0u;
-    e.b = (r.wa & kLeanB) != 0u;
-    e.c = (r.wc & kLeanC) != 0u;
-    e.da = lean_bd_from_thr(r.wa);
-    e.dc = lean_bd_from_thr(r.wc);
+    e.a = (r.w & kLeanA) != 0u;
+    e.b = (r.w & kLeanB) != 0u;
+    e.c = (r.w & kLeanC) != 0u;
+    e.da = lean_bd_from_exp((r.w >> kLeanExpAShift) & 0xffu);
+    e.dc = lean_bd_from_exp((r.w >> kLeanExpCShift) & 0xffu);
     const uint32_t ca = f32_as_u32(bits_to_f32(r.ta)), cc = f32_as_u32(bits_to_f32(r.tc));
     e.ta = abs_t ? r.ta : ca;
     e.tc = abs_t ? r.tc : cc;

@@ -42,7 +42,7 @@ W, H, C, FRAMES = 1920, 1080, 1, 300
 REF_TIME, DTM = 255, 255
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 STATE_BYTES = 16       # level 0 of a unit: hdr + integration + delta_t + best_delta_t
-REC_BYTES = 16         # one parked record per unit with events (lean variants)
+REC_BYTES = 12         # one parked record per unit with events (lean variants)
 
 
 def parse_args():
@@ -323,7 +323,7 @@ def main():
             "units_per_launch": units,
             "launch_avg_us": round(k1_one_us, 3),
             "note": "the frame kernel alone with the state streamed from HBM every frame (per-frame consume contract): "
-                    "bytes it really moves = 1 input + 16 state in + 16 state out + 16 per parked record.  The duration "
+                    "bytes it really moves = 1 input + 16 state in + 16 state out + 12 per parked record.  The duration "
                     "is a HIP-event pair around every launch, which on this runtime reads ~2 us more than the kernel "
                     "itself (rocprofv3 kernel duration of the same run: profiles/r02_bench_kernel_stats.csv, "
                     "adder_lean1_kernel 14.35 us = 0.65)",

@@ -250,13 +250,13 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                                                                  : lean_step<false>(p, v, sc.cth, time_spanned, sc, tag, rec);
                     if (fl.b && !fl.a) rc = -9;
                     if (fl.a || fl.c) {
-                        if (((rec.wa >> kLeanUnitShift) & 255u) != (u & 255u)) rc = -9;  // the tag must survive
+                        if (((rec.w >> kLeanUnitShift) & 255u) != (u & 255u)) rc = -9;  // the tag must survive
                         const LeanEvents e = lean_decode(rec, s->abs_t != 0, sc.running_t_u32);
                         if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
                         if (e.a) em(e.da, e.ta);
                         if (e.b) em(kDEmpty, e.tb);
                         if (e.c) em(e.dc, e.tc);
-                    } else if ((rec.wa & (kLeanA | kLeanB)) || (rec.wc & kLeanC)) {
+                    } else if (rec.w & (kLeanA | kLeanB | kLeanC)) {
                         rc = -9;
                     }
                     s->hdr[u] = lean_hdr(p);
