@@ -308,6 +308,9 @@ class HipVideo:
     def set_launch_timing(self, on=True):
         N.check(self.h, self.L.adder_hip_set_launch_timing(self.h, int(on)))
 
+    def launch_plan_settled(self):
+        return bool(self.L.adder_hip_launch_plan_settled(self.h))
+
     def last_launch_avg_us(self):
         return float(self.L.adder_hip_last_launch_avg_us(self.h))
 

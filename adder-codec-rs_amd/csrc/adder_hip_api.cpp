@@ -44,6 +44,7 @@ struct AdderHipCtx {
     bool continuous = false;
     float *cn_integ = nullptr, *cn_dt = nullptr, *cn_bdt = nullptr;
     uint32_t *cn_meta = nullptr;
+    uint8_t *state_slab = nullptr;  // hdr, integ0, dt0, bdt0, lastf live in here
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
@@ -95,11 +96,30 @@ struct AdderHipCtx {
     BatchArgs *h_batch = nullptr;   // pinned
     FrameTab *d_ftab = nullptr;     // per-frame uniforms (running_t, c_thresh)
     FrameTab *h_ftab = nullptr;     // pinned
+    // the batch description and the frame table share one device block and one pinned block (one upload per batch)
+    uint8_t *d_desc = nullptr, *h_desc = nullptr;
+    BatchResult *h_result = nullptr;  // pinned: adder_publish_kernel writes it, finish() reads it
+    hipEvent_t reset_e = nullptr;     // adder_hip_reset's memsets (queued on the context's stream, not waited for)
+    bool reset_pending = false;
     size_t ftab_cap = 0;            // entries
     // capture streams/events and the cache of instantiated frame-loop graphs
     hipStream_t cap_s = nullptr, cap_s2 = nullptr;
     hipEvent_t cap_e1 = nullptr, cap_e2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::map<uint64_t, hipGraphExec_t> graphs;  // key: see get_graph
+    // One cached launch sequence.  How well the two branches of an instantiated graph overlap is decided when it is
+    // instantiated (the runtime binds the branches to hardware queues then; measured: the same graph comes out at
+    // 1.86 or 2.08 ms per 300-frame step from one instantiation to the next, stable for the life of the exec), so a
+    // key keeps a few candidates, runs each on real batches while it is new, and settles on the fastest.
+    struct GraphTune {
+        std::vector<hipGraphExec_t> cand;
+        std::vector<float> ms;    // best batch time seen per candidate
+        std::vector<int> runs;
+        int chosen = -1;          // settled
+        int last = -1;            // candidate of the batch in flight
+    };
+    std::map<uint64_t, GraphTune> graphs;  // key: see get_graph
+    uint64_t tune_key = 0;
+    bool tune_pending = false;
+    uint32_t graph_candidates = 6;
     bool use_graph = true;
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
@@ -205,7 +225,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->hdr,     c->integ0,  c->dt0,      c->bdt0,   c->lastf,  c->dv_integ, c->dv_dt,
+    void *ptrs[] = {c->state_slab, c->dv_integ, c->dv_dt,
                     c->dv_bdt,  c->dv_bd,   c->running,  c->status, c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
                     c->snap.cn_integ, c->snap.cn_dt, c->snap.cn_bdt, c->snap.cn_meta,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire,
@@ -239,11 +259,13 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
-    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
-    if (c->d_batch) (void)hipFree(c->d_batch);
-    if (c->h_batch) (void)hipHostFree(c->h_batch);
-    if (c->d_ftab) (void)hipFree(c->d_ftab);
-    if (c->h_ftab) (void)hipHostFree(c->h_ftab);
+    for (auto &kv : c->graphs)
+        for (hipGraphExec_t e : kv.second.cand)
+            if (e) (void)hipGraphExecDestroy(e);
+    if (c->d_desc) (void)hipFree(c->d_desc);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->reset_e) (void)hipEventDestroy(c->reset_e);
     for (hipEvent_t e : {c->cap_e1, c->cap_e2[0], c->cap_e2[1], c->cap_e2[2], c->cap_e2[3], c->cap_e2[4]})
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
@@ -361,6 +383,27 @@ static int init_state(AdderHipCtx *c) {
 
 static int alloc_scratch(AdderHipCtx *c, uint32_t bytes_per_segment);
 
+// BatchArgs followed (256-byte aligned) by the frame table, on the device and in page-locked host memory
+constexpr size_t kBatchDescBytes = (sizeof(BatchArgs) + 255) & ~(size_t)255;
+static int alloc_batch_desc(AdderHipCtx *c, size_t frames) {
+    uint8_t *od = c->d_desc, *oh = c->h_desc;
+    c->d_desc = c->h_desc = nullptr;
+    c->d_batch = c->h_batch = nullptr;
+    c->d_ftab = c->h_ftab = nullptr;
+    c->ftab_cap = 0;
+    if (od) HIPCHK(c, hipFree(od));
+    if (oh) HIPCHK(c, hipHostFree(oh));
+    const size_t bytes = kBatchDescBytes + frames * sizeof(FrameTab);
+    HIPCHK(c, dalloc(&c->d_desc, bytes));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_desc), bytes, hipHostMallocDefault));
+    c->d_batch = reinterpret_cast<BatchArgs *>(c->d_desc);
+    c->h_batch = reinterpret_cast<BatchArgs *>(c->h_desc);
+    c->d_ftab = reinterpret_cast<FrameTab *>(c->d_desc + kBatchDescBytes);
+    c->h_ftab = reinterpret_cast<FrameTab *>(c->h_desc + kBatchDescBytes);
+    c->ftab_cap = frames;
+    return ADDER_OK;
+}
+
 extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out) {
     if (!out) return fail(nullptr, ADDER_E_BAD_PARAMS, "out is null");
     *out = nullptr;
@@ -438,11 +481,22 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreate(&c->ev_start));
         HIPCHK(c, hipEventCreate(&c->ev_stop));
-        HIPCHK(c, dalloc(&c->hdr, c->n_pad));
-        HIPCHK(c, dalloc(&c->integ0, c->n_pad));
-        HIPCHK(c, dalloc(&c->dt0, c->n_pad));
-        HIPCHK(c, dalloc(&c->bdt0, c->n_pad));
-        HIPCHK(c, dalloc(&c->lastf, c->n_pad));
+        {
+            // The five level-0 planes come from one allocation, each pushed a few KiB further than the one before:
+            // separate allocations of this size all start on the same 2 MiB boundary, a wave then reads the same
+            // offset of four planes at once, and whether those four streams fall on the same HBM channels was left
+            // to the allocator (measured: the same build ran at 1.82 or 1.97 ms per step from context to context).
+            size_t skew = 4352;
+            if (const char *e = getenv("ADDER_HIP_PLANE_SKEW")) skew = (size_t)atoi(e) & ~(size_t)255;
+            const size_t plane = (c->n_pad * sizeof(uint32_t) + 255) & ~(size_t)255;
+            HIPCHK(c, dalloc(&c->state_slab, 5 * (plane + skew)));
+            uint8_t *q = c->state_slab;
+            c->hdr = reinterpret_cast<uint32_t *>(q);
+            c->integ0 = reinterpret_cast<float *>(q + 1 * (plane + skew));
+            c->dt0 = reinterpret_cast<float *>(q + 2 * (plane + skew));
+            c->bdt0 = reinterpret_cast<float *>(q + 3 * (plane + skew));
+            c->lastf = reinterpret_cast<float *>(q + 4 * (plane + skew));
+        }
         c->continuous = p.pixel_mode == ADDER_MODE_CONTINUOUS;
         if (c->continuous) {
             const size_t cnt = c->n_pad * (c->max_depth + 1u);
@@ -453,8 +507,10 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         }
         { int rc_ = alloc_scratch(c, c->continuous ? kWaveUnits + kWaveUnits * (c->max_depth + 3u) * kGenRecBytes
                                                    : kLeanParkBytes); if (rc_ != ADDER_OK) return rc_; }
-        HIPCHK(c, dalloc(&c->d_batch, 1));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_batch), sizeof(BatchArgs), hipHostMallocDefault));
+        { int rc_ = alloc_batch_desc(c, 1024); if (rc_ != ADDER_OK) return rc_; }
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_result), sizeof(BatchResult), hipHostMallocDefault));
+        memset(c->h_result, 0, sizeof(BatchResult));
+        HIPCHK(c, hipEventCreateWithFlags(&c->reset_e, hipEventDisableTiming));
         HIPCHK(c, hipStreamCreateWithFlags(&c->cap_s, hipStreamNonBlocking));
         {
             // scan / offsets / expansion of chunk k share the chip with the frame kernel of chunk k+1: the short
@@ -477,6 +533,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->lean_blocks_per_cu = lb ? (uint32_t)atoi(lb) : 5u;
             c->expand_blocks_per_cu = eb ? (uint32_t)atoi(eb) : 3u;
         }
+        if (const char *gc = getenv("ADDER_HIP_GRAPH_CANDIDATES")) c->graph_candidates = (uint32_t)std::max(1, atoi(gc));
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->status, 1));
@@ -517,6 +574,15 @@ extern "C" int adder_hip_reset_c_thresh(AdderHipCtx *c, uint8_t baseline) {
     c->c_thresh = baseline;
     c->c_counter = 0;
     c->perpx = false;  // uniform again; the next frame of a feature / ROI batch re-creates the planes from the pair
+    return ADDER_OK;
+}
+
+// adder_hip_reset does not wait for its memsets: host-side readers of the state do
+static int settle_reset(AdderHipCtx *c) {
+    if (c->reset_pending) {
+        HIPCHK(c, hipEventSynchronize(c->reset_e));
+        c->reset_pending = false;
+    }
     return ADDER_OK;
 }
 
@@ -576,6 +642,7 @@ extern "C" int adder_hip_feature_set(AdderHipCtx *c, uint8_t *dst) {
         return ADDER_OK;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = settle_reset(c); if (rc_ != ADDER_OK) return rc_; }
     HIPCHK(c, hipMemcpy(dst, c->fset, n, hipMemcpyDeviceToHost));
     return ADDER_OK;
 }
@@ -588,6 +655,7 @@ extern "C" int adder_hip_c_thresh_plane(AdderHipCtx *c, uint8_t *dst) {
         return ADDER_OK;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = settle_reset(c); if (rc_ != ADDER_OK) return rc_; }
     HIPCHK(c, hipMemcpy(dst, c->cth_px, c->n_units, hipMemcpyDeviceToHost));
     return ADDER_OK;
 }
@@ -668,8 +736,11 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 // quarter of what the device has free, at most 12 GiB.
 static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     if (c->park_bytes >= bytes && c->park_ring) return ADDER_OK;
-    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);  // they bake the chunking
+    for (auto &kv : c->graphs)  // they bake the chunking
+        for (hipGraphExec_t e : kv.second.cand)
+            if (e) (void)hipGraphExecDestroy(e);
     c->graphs.clear();
+    c->tune_pending = false;
     void *old[] = {c->park_ring, c->wtot_ring, c->wpref_ring, c->ftot_ring};
     c->park_ring = nullptr;
     c->wtot_ring = c->wpref_ring = c->ftot_ring = nullptr;
@@ -689,8 +760,11 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * bytes));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
-    HIPCHK(c, dalloc(&c->ftot_ring, c->slots));
+    HIPCHK(c, dalloc(&c->ftot_ring, 2 * (size_t)c->slots));  // events, then parked records per frame
     c->park_bytes = bytes;
+    if (getenv("ADDER_HIP_DEBUG_ADDRS"))
+        fprintf(stderr, "[adder_hip] slab %p park %p wtot %p wpref %p ftot %p\n", (void *)c->state_slab, (void *)c->park_ring,
+                (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring);
     return ADDER_OK;
 }
 
@@ -738,6 +812,7 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
         HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, 0u, s));
         HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
     }
+    HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, s));
     return ADDER_OK;
 }
 
@@ -786,17 +861,11 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         if (s2) HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], s2));
     }
     if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 5u], 0));  // join (s2 is in-order)
+    HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, s));
     return ADDER_OK;
 }
 
-static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
-    // everything the captured launch sequence depends on
-    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 40);
-    auto it = c->graphs.find(key);
-    if (it != c->graphs.end()) {
-        *out = it->second;
-        return ADDER_OK;
-    }
+static int instantiate_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
     int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
@@ -806,17 +875,81 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
         return rc;
     }
     HIPCHK(c, e);
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCHK(c, e);
-    if (c->graphs.size() >= 8) {  // keep the cache small
-        (void)hipGraphExecDestroy(c->graphs.begin()->second);
-        c->graphs.erase(c->graphs.begin());
-    }
-    c->graphs[key] = exec;
-    *out = exec;
     return ADDER_OK;
+}
+
+constexpr int kTuneRunsPerCandidate = 2;  // the first run of an exec also uploads it
+
+static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
+    // everything the captured launch sequence depends on
+    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 40);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        if (c->graphs.size() >= 8) {  // keep the cache small
+            for (hipGraphExec_t e : c->graphs.begin()->second.cand)
+                if (e) (void)hipGraphExecDestroy(e);
+            c->graphs.erase(c->graphs.begin());
+        }
+        it = c->graphs.emplace(key, AdderHipCtx::GraphTune{}).first;
+    }
+    AdderHipCtx::GraphTune &g = it->second;
+    c->tune_pending = false;
+    if (g.chosen >= 0) {
+        *out = g.cand[g.chosen];
+        return ADDER_OK;
+    }
+    // still choosing: the newest candidate until it has had its runs, then one more candidate
+    // (a batch of a single chunk has no second branch to overlap: one candidate is all it needs)
+    const uint32_t want = num_frames > c->chunk ? std::max(1u, c->graph_candidates) : 1u;
+    int use = (int)g.cand.size() - 1;
+    if (use < 0 || g.runs[use] >= kTuneRunsPerCandidate) {
+        if (g.cand.size() < want) {
+            hipGraphExec_t exec = nullptr;
+            int rc = instantiate_graph(c, num_frames, variant, &exec);
+            if (rc != ADDER_OK) return rc;
+            g.cand.push_back(exec);
+            g.ms.push_back(1e30f);
+            g.runs.push_back(0);
+            use = (int)g.cand.size() - 1;
+        }
+    }
+    g.last = use;
+    c->tune_key = key;
+    c->tune_pending = true;
+    *out = g.cand[use];
+    return ADDER_OK;
+}
+
+// the batch of a graph that is still being chosen has finished in `ms`
+static void graph_tune_report(AdderHipCtx *c, float ms) {
+    if (!c->tune_pending) return;
+    c->tune_pending = false;
+    auto it = c->graphs.find(c->tune_key);
+    if (it == c->graphs.end()) return;
+    AdderHipCtx::GraphTune &g = it->second;
+    if (g.last < 0 || g.chosen >= 0) return;
+    g.runs[g.last] += 1;
+    if (g.runs[g.last] > 1 || kTuneRunsPerCandidate == 1) g.ms[g.last] = std::min(g.ms[g.last], ms);
+    const uint32_t want = c->pending_frames > c->chunk ? std::max(1u, c->graph_candidates) : 1u;
+    if (g.cand.size() >= want && g.runs.back() >= kTuneRunsPerCandidate) {
+        int best = 0;
+        for (int k = 1; k < (int)g.cand.size(); ++k)
+            if (g.ms[k] < g.ms[best]) best = k;
+        for (int k = 0; k < (int)g.cand.size(); ++k)
+            if (k != best) {
+                (void)hipGraphExecDestroy(g.cand[k]);
+                g.cand[k] = nullptr;
+            }
+        g.chosen = best;
+        if (getenv("ADDER_HIP_DEBUG_TUNE")) {
+            fprintf(stderr, "[adder_hip] graph candidates (ms):");
+            for (float v : g.ms) fprintf(stderr, " %.3f", v);
+            fprintf(stderr, " -> %d\n", best);
+        }
+    }
 }
 
 // ---- undo copy of the state (see AdderHipCtx::Snapshot) ----
@@ -913,6 +1046,10 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // lean_step) runs.  Once a generic batch has run, pixels may hold deeper arenas (or a root that
     // the lean step's "time_spanned >= delta_t_max" folding does not describe), so the choice is sticky
     // until adder_hip_reset: update_quality_manual can lower delta_t_max mid-stream (video.rs:1264-1287).
+    if (c->reset_pending) {  // adder_hip_reset queued its memsets on the context's stream
+        HIPCHK(c, hipStreamWaitEvent(stream, c->reset_e, 0));
+        c->reset_pending = false;
+    }
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
     const bool sticky_before = c->generic_sticky;
     const bool fpath = feature_path(c);
@@ -955,16 +1092,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
 
     // ---- batch description -> device ----
     if (c->ftab_cap < num_frames) {
-        void *od = c->d_ftab, *oh = c->h_ftab;
-        c->d_ftab = nullptr;
-        c->h_ftab = nullptr;
-        c->ftab_cap = 0;
-        if (od) HIPCHK(c, hipFree(od));
-        if (oh) HIPCHK(c, hipHostFree(oh));
-        const size_t cap = std::max<size_t>(num_frames, 64);
-        HIPCHK(c, dalloc(&c->d_ftab, cap));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ftab), cap * sizeof(FrameTab), hipHostMallocDefault));
-        c->ftab_cap = cap;
+        // (the captured graphs hold the description's address)
+        for (auto &kv : c->graphs)
+            for (hipGraphExec_t e : kv.second.cand)
+                if (e) (void)hipGraphExecDestroy(e);
+        c->graphs.clear();
+        c->tune_pending = false;
+        int rc_ = alloc_batch_desc(c, std::max<size_t>(num_frames, 2 * c->ftab_cap));
+        if (rc_ != ADDER_OK) return rc_;
     }
     float rt = c->running_t;
     uint8_t cth = c->c_thresh, cctr = c->c_counter;
@@ -990,11 +1125,17 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;
     b.slots = c->slots;
+    b.chunk = c->chunk;
     b.rec_total = c->d_rec_total;
-    HIPCHK(c, hipMemsetAsync(c->d_rec_total, 0, sizeof(uint64_t), stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ftab, c->h_ftab, num_frames * sizeof(FrameTab), hipMemcpyHostToDevice, stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
-    HIPCHK(c, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+    // (frame_offsets[0] and the record count are started by the first chunk's offsets kernel: nothing to clear here)
+    if (reinterpret_cast<uint8_t *>(c->d_ftab) == reinterpret_cast<uint8_t *>(c->d_batch) + kBatchDescBytes &&
+        reinterpret_cast<uint8_t *>(c->h_ftab) == reinterpret_cast<uint8_t *>(c->h_batch) + kBatchDescBytes) {
+        HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, kBatchDescBytes + num_frames * sizeof(FrameTab),
+                                 hipMemcpyHostToDevice, stream));
+    } else {  // a frame slot's own pair
+        HIPCHK(c, hipMemcpyAsync(c->d_ftab, c->h_ftab, num_frames * sizeof(FrameTab), hipMemcpyHostToDevice, stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, sizeof(BatchArgs), hipMemcpyHostToDevice, stream));
+    }
 
     c->timed_launches = 0;
     c->timed_frames = 0;
@@ -1012,6 +1153,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
             c->post_events.push_back(e);
         }
     }
+    c->h_result->valid = 0u;
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     int rc = ADDER_OK;
     if (fpath) {
@@ -1077,20 +1219,31 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t st = 0;
     uint64_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));
-    HIPCHK(c, hipMemcpyAsync(&total, c->pending_offsets + c->pending_frames, sizeof total, hipMemcpyDeviceToHost,
-                             c->pending_stream));
-    HIPCHK(c, hipMemcpyAsync(&c->last_records, c->d_rec_total, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                             c->pending_stream));
     c->last_new_features = 0;
-    if (c->d_feat_counters && feature_path(c))
-        HIPCHK(c, hipMemcpyAsync(&c->last_new_features, c->d_feat_counters, sizeof(uint32_t), hipMemcpyDeviceToHost,
+    if (c->pending_frames && !(c->d_feat_counters && feature_path(c))) {
+        // the batch's last node wrote {events, records, status} into page-locked memory: wait for the event behind
+        // it, no copies
+        HIPCHK(c, hipEventSynchronize(c->ev_stop));
+        if (!c->h_result->valid) return fail(c, ADDER_E_HIP, "the batch finished without publishing its result");
+        st = c->h_result->status;
+        total = c->h_result->total_events;
+        c->last_records = c->h_result->records;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));
+        HIPCHK(c, hipMemcpyAsync(&total, c->pending_offsets + c->pending_frames, sizeof total, hipMemcpyDeviceToHost,
                                  c->pending_stream));
-    HIPCHK(c, hipStreamSynchronize(c->pending_stream));
+        HIPCHK(c, hipMemcpyAsync(&c->last_records, c->d_rec_total, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 c->pending_stream));
+        if (c->d_feat_counters && feature_path(c))
+            HIPCHK(c, hipMemcpyAsync(&c->last_new_features, c->d_feat_counters, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                     c->pending_stream));
+        HIPCHK(c, hipStreamSynchronize(c->pending_stream));
+    }
     if (c->pending_frames)
         HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev_start, c->ev_stop));
     else
         c->last_ms = 0.0f;
+    graph_tune_report(c, c->last_ms);
     c->last_launch_avg_us = 0.0f;
     if (c->timed_launches) {
         double sum = 0.0;
@@ -1128,6 +1281,12 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
 
 extern "C" float adder_hip_last_batch_ms(AdderHipCtx *c) { return c ? c->last_ms : 0.0f; }
 
+extern "C" int adder_hip_launch_plan_settled(const AdderHipCtx *c) {
+    if (!c) return 1;
+    auto it = c->graphs.find(c->tune_key);
+    return it == c->graphs.end() || it->second.chosen >= 0 ? 1 : 0;
+}
+
 extern "C" int adder_hip_set_launch_timing(AdderHipCtx *c, int enable) {
     if (!c) return ADDER_E_BAD_PARAMS;
     c->launch_timing = enable != 0;
@@ -1159,7 +1318,10 @@ extern "C" int adder_hip_reset(AdderHipCtx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = init_state(c);
     if (rc != ADDER_OK) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the memsets are queued on the context's stream; whoever touches the state next orders itself behind them
+    // (enqueue_frames: a stream wait; the host-side accessors: settle_reset)
+    HIPCHK(c, hipEventRecord(c->reset_e, c->stream));
+    c->reset_pending = true;
     return ADDER_OK;
 }
 
@@ -1590,6 +1752,7 @@ extern "C" int adder_hip_running_intensities(AdderHipCtx *c, uint8_t *dst) {
         memset(dst, 0, c->n_units);
         return ADDER_OK;
     }
+    { int rc_ = settle_reset(c); if (rc_ != ADDER_OK) return rc_; }
     HIPCHK(c, hipMemcpy(dst, c->running, c->n_units, hipMemcpyDeviceToHost));
     return ADDER_OK;
 }

@@ -82,7 +82,7 @@ struct FrameArgs {
     uint64_t *frame_offsets;  // [frame_idx] = first event of the frame, [frame_idx+1] = end
     uint32_t frame_idx;
     // ordered compaction, stage 1 (frame kernel): per wave segment
-    uint8_t *park;        // [num_waves][park_bytes] parked records (LeanRec, or {t, d | unit<<8 | offset<<16})
+    uint8_t *park;        // the frame's parked records of segment 0 (LeanRec, or {t, d | unit<<8 | offset<<16}); see park_offset
     uint32_t *wtot;       // [num_waves] events of the segment (low 16) | parked records (high 16)
     // stage 2 (scan kernel): exclusive prefix of the low halves of wtot, frame total
     uint32_t *wpref;      // [num_waves]
@@ -108,9 +108,28 @@ struct BatchArgs {
     uint32_t park_bytes;      // scratch of one segment (kLeanParkBytes, or kGenRecBytes * parked-event capacity)
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
-    uint32_t *ftot_ring;      // [slots]
+    uint32_t *ftot_ring;      // [2][slots]: events per frame, then parked records per frame
     uint32_t slots;
+    uint32_t chunk;           // frames per chunk; slots = chunks in the ring * chunk
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
+};
+
+// Where (frame slot, segment) parks its records, in bytes from park_ring.  Layout [chunk of the ring][segment][frame
+// of the chunk][park_bytes]: the frames a wave steps in one launch are CONTIGUOUS (it touches one or two pages of
+// the ring instead of one per frame -- with [slot][segment] a segment's 32 frames lay 25 MB apart), and the 16
+// segments an expansion wave reads lie chunk * park_bytes apart.
+__host__ __device__ __forceinline__ size_t park_offset(uint32_t slot, uint32_t seg, uint32_t chunk, uint32_t num_waves,
+                                                       uint32_t park_bytes) {
+    const uint32_t cir = slot / chunk, fi = slot - cir * chunk;
+    return ((size_t)(cir * num_waves + seg) * chunk + fi) * park_bytes;
+}
+
+// what the host reads after a batch (adder_publish_kernel), in page-locked host memory
+struct BatchResult {
+    uint64_t total_events;  // frame_offsets[num_frames]
+    uint64_t records;       // parked records (diagnostics)
+    uint32_t status;
+    uint32_t valid;         // set last
 };
 
 // result header of one frame handed to the host (adder_frame_out_kernel), in page-locked host memory
@@ -139,7 +158,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     a.sc.running_t = b->ftab[f].running_t;
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.sc.cth = b->ftab[f].cth;
-    a.park = b->park_ring + (size_t)slot * a.num_waves * b->park_bytes;
+    a.park = b->park_ring + park_offset(slot, 0u, b->chunk, a.num_waves, b->park_bytes);  // segment s: + s * chunk * park_bytes
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
     a.ftot = b->ftot_ring + slot;
@@ -160,6 +179,7 @@ hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_
                              hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
+hipError_t adder_launch_publish(const adder::BatchArgs *b, uint32_t num_frames, adder::BatchResult *h, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                uint32_t variant, uint32_t grid_cap, hipStream_t stream);

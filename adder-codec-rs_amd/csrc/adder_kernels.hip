@@ -234,9 +234,9 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     }
     // the segment's scratch of the launch's first frame and the next frame's input bytes: 64-bit
     // uniform pointers advanced by adds (the ring wraps at `slots`)
-    const size_t frame_park = (size_t)num_waves_u * park_bytes_u;
-    uint8_t *const park0 = uniform_ptr(b->park_ring) + (size_t)sgw * park_bytes_u;
-    uint8_t *seg = park0 + (size_t)slot0 * frame_park;
+    // (a launch never crosses a chunk boundary, so the segment's frames are contiguous: park_offset)
+    const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
+    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u);
     // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
     // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
     // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
@@ -257,7 +257,6 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
         for (uint32_t k = 1; k < NB_MAX; ++k) in_lds[k * kWave] = (InT)vin_all[k];
     }
     uint32_t vin_w = raw.vin_w;
-    uint32_t slot = slot0;
     uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
     uint64_t active[N];  // units inside the band (the rest of the wave's segment is padding)
 #pragma unroll
@@ -303,12 +302,7 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
         vin_w = next_w;
-        slot += 1u;
-        seg += frame_park;
-        if (slot == slots_u) {
-            slot = 0u;
-            seg = park0;
-        }
+        seg += park_bytes_u;
     }
 
     // ---------------- per-frame segment totals ----------------
@@ -540,7 +534,8 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         // events of the segment (low half) = parked records (high half): one record per event, in final order
         if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl | (incl << 16));
         uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
-        uint2 *const seg = reinterpret_cast<uint2 *>(park_ring_u + seg_idx * park_bytes_u);  // uniform
+        uint2 *const seg = reinterpret_cast<uint2 *>(
+            park_ring_u + park_offset(slot, sgw, __builtin_amdgcn_readfirstlane(b->chunk), num_waves_u, park_bytes_u));  // uniform
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u) {
@@ -665,7 +660,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
     const uint32_t u0 = gw * kWaveUnits + lane * N;
     for (uint32_t i = 0; i < nb; ++i) {
         const FrameArgs a = frame_args(b, f0 + i);
-        uint8_t *const seg = a.park + (size_t)gw * b->park_bytes;
+        uint8_t *const seg = a.park + (size_t)gw * b->chunk * b->park_bytes;
         uint32_t lane_cnt = 0;
         bool bad = false;
 #pragma unroll
@@ -721,20 +716,21 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
         sum += (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
         recs += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
     }
-    if (b->rec_total) {  // diagnostics: parked records of the batch (bench.py's byte accounting)
+    // parked records of the frame (diagnostics: bench.py's byte accounting); the offsets kernel adds the frames up
+    __shared__ uint32_t s_recs[kScanThreads / kWave];
 #pragma unroll
-        for (uint32_t o = kWave / 2; o > 0; o >>= 1) recs += __shfl_down(recs, o, kWave);
-        if (lane == 0 && recs) atomicAdd(reinterpret_cast<unsigned long long *>(b->rec_total), (unsigned long long)recs);
-    }
+    for (uint32_t o = kWave / 2; o > 0; o >>= 1) recs += __shfl_down(recs, o, kWave);
+    if (lane == 0) s_recs[wid] = recs;
     const uint32_t incl = wave_inclusive_scan(sum, lane);
     if (lane == kWave - 1) s_part[wid] = incl;
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t base = 0, total = 0, rec_total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < kScanThreads / kWave; ++w) {
         const uint32_t t = s_part[w];
         if (w < wid) base += t;
         total += t;
+        rec_total += s_recs[w];
     }
     uint32_t run = base + incl - sum;
     for (uint32_t g = g0; g < g1; ++g) {
@@ -747,18 +743,39 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
         run = o.w + (v.w & 0xffffu);
         dst[g] = o;
     }
-    if (tid == 0) *a.ftot = total;
+    if (tid == 0) {
+        *a.ftot = total;
+        a.ftot[b->slots] = rec_total;  // second half of the ring: records per frame
+    }
 }
 
 // frame_offsets[f+1] = frame_offsets[f] + events(f) for the frames of the chunk, in order.
+// The batch's first chunk also starts the chain (frame_offsets[0] = 0) and the record count, so the host queues no
+// memset in front of a batch.
 __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t nf) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint64_t *offs = b->base.frame_offsets;
-    uint64_t run = offs[f0];
+    uint64_t run = f0 == 0u ? 0ull : offs[f0];
+    uint64_t recs = (f0 == 0u || !b->rec_total) ? 0ull : *b->rec_total;
+    if (f0 == 0u) offs[0] = 0ull;
     for (uint32_t i = 0; i < nf; ++i) {
-        run += b->ftot_ring[(f0 + i) % b->slots];
+        const uint32_t slot = (f0 + i) % b->slots;
+        run += b->ftot_ring[slot];
+        recs += b->ftot_ring[b->slots + slot];
         offs[f0 + i + 1] = run;
     }
+    if (b->rec_total) *b->rec_total = recs;
+}
+
+// Last node of a batch: what the host needs to know about it, written straight into page-locked host memory (the
+// host then only waits for the batch's last event: no device-to-host copies).
+__global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t num_frames, BatchResult *h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    h->total_events = b->base.frame_offsets[num_frames];
+    h->records = b->rec_total ? *b->rec_total : 0ull;
+    h->status = *b->base.status;
+    __threadfence_system();
+    h->valid = 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -862,7 +879,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     uint32_t *const xb = s_xbuf[wid];
     const uint32_t park_bytes = __builtin_amdgcn_readfirstlane(b->park_bytes);
     // wave-uniform bases (SGPRs); the lanes add 32-bit byte offsets
-    const uint8_t *park = uniform_ptr(b->park_ring) + ((size_t)slot * num_waves + seg0) * park_bytes;
+    const uint32_t chunk_frames = __builtin_amdgcn_readfirstlane(b->chunk);
+    const uint8_t *park = uniform_ptr(b->park_ring) + park_offset(slot, seg0, chunk_frames, num_waves, park_bytes);
+    const uint32_t seg_stride = chunk_frames * park_bytes;  // bytes between consecutive segments of one frame
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
     UnitCoord uc;
@@ -891,7 +910,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             first[p] = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                const LeanRec r = gload<LeanRec>(park + (size_t)(2 * p) * park_bytes, half * park_bytes + hl * kLeanRecBytes);
+                const LeanRec r = gload<LeanRec>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * kLeanRecBytes);
                 first[p] = make_uint4(r.ta, r.tc, r.w, 0u);
             }
         }
@@ -901,7 +920,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
             first[q] = make_uint4(0u, 0u, 0u, 0u);
             if (lane < parked) {
-                const uint2 v = gload<uint2>(park + (size_t)q * park_bytes, lane * kGenRecBytes);
+                const uint2 v = gload<uint2>(park + (size_t)q * seg_stride, lane * kGenRecBytes);
                 first[q] = make_uint4(v.x, v.y, 0u, 0u);
             }
         }
@@ -966,7 +985,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 const uint32_t cnt[2] = {pa, pb};
 #pragma unroll
                 for (uint32_t h = 0; h < 2u; ++h) {
-                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * park_bytes;
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride;
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
@@ -986,7 +1005,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
 #pragma unroll 1
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
             const uint32_t seg_events = __builtin_amdgcn_readlane(my_tot, q) & 0xffffu;
-            const uint8_t *const seg_park = park + (size_t)q * park_bytes;
+            const uint8_t *const seg_park = park + (size_t)q * seg_stride;
             if (seg_events != 0u) {
                 uint32_t cnt[kUnitsPerLane], lane_cnt = 0;
 #pragma unroll
@@ -1020,7 +1039,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
             const uint32_t tot = __builtin_amdgcn_readlane(my_tot, q);
             const uint32_t parked = tot >> 16;
-            const uint8_t *const seg_park = park + (size_t)q * park_bytes;
+            const uint8_t *const seg_park = park + (size_t)q * seg_stride;
             // every record carries its event's offset inside the segment; a segment's events are staged
             // in pieces of the buffer's size (the segment total is known: tot & 0xffff)
             const uint32_t seg_events = tot & 0xffffu;
@@ -1446,6 +1465,11 @@ extern "C" hipError_t adder_launch_wire(const AdderEventPod *ev, uint64_t n, uin
 
 extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream) {
     hipLaunchKernelGGL(adder_scan_kernel, dim3(nf), dim3(kScanThreads), 0, stream, b, f0);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_publish(const BatchArgs *b, uint32_t num_frames, BatchResult *h, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_publish_kernel, dim3(1), dim3(64), 0, stream, b, num_frames, h);
     return hipGetLastError();
 }
 

@@ -190,6 +190,16 @@ def main():
             el = float(t.item())
         return el, res
 
+    # One-time set-up of the context, like its allocations and the graph capture: the first batches of a new length try
+    # a few instances of the captured graph and keep the fastest (include/adder_hip.h, adder_hip_launch_plan_settled).
+    # Not timed and not counted as warmup; every rank runs the same number of them (a fixed bound, no data-dependent
+    # exit, so multi-rank runs stay in step).
+    plan_steps = 0
+    for _ in range(int(os.environ.get("ADDER_BENCH_PLAN_STEPS", "14"))):
+        step("none")
+        plan_steps += 1
+    plan_settled = hv.launch_plan_settled()
+
     elapsed, (n_events, merged_total) = timed(gather_mode, args.steps, args.warmup)
     kernel_ms = hv.last_batch_ms()  # HIP events around the last step's frame loop
     records = hv.last_batch_records()
@@ -287,6 +297,10 @@ def main():
         "events_per_pixel_frame": round(e_all, 5),
         "records_per_unit_frame": round(r0, 5),
         "frame_loop_ms_hip_events": round(kernel_ms, 3),
+        "launch_plan": {"setup_steps_untimed": plan_steps, "settled": bool(plan_settled),
+                        "note": "the captured graph of a batch length is instantiated up to 6 times on the first batches "
+                                "and the fastest instance kept (the runtime binds the graph's two branches to hardware "
+                                "queues at instantiation; measured 1.86 vs 2.08 ms per step between instances)"},
         "roofline": {
             "bound": "hbm",
             "kernel": ("one chunk of frames: adder_lean_kernel + adder_scan_kernel + adder_offsets_kernel + "

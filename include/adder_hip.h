@@ -210,6 +210,12 @@ int adder_hip_enable_running_intensities(AdderHipCtx *ctx, int enable);
 /* Duration in milliseconds of the kernels of the last adder_hip_integrate_device
  * batch, measured with HIP events on the launch stream (0 if none). */
 float adder_hip_last_batch_ms(AdderHipCtx *ctx);
+/* Device batches of more than one chunk are replayed from a captured graph whose two branches (the frame kernel of
+ * chunk k+1 beside scan / offsets / expansion of chunk k) the runtime binds to hardware queues when the graph is
+ * instantiated -- well or badly, for the life of the instance.  The first batches of a given length therefore try
+ * a few instances (2 batches each, 6 instances) and keep the fastest; this returns 1 once the last batch's length
+ * has settled (always 1 for single-chunk batches and with ADDER_HIP_NO_GRAPH). */
+int adder_hip_launch_plan_settled(const AdderHipCtx *ctx);
 
 /* Mean duration in microseconds of the frame-kernel launches of the last device batch,
  * measured with one HIP event pair around EVERY launch on the launch stream; only

@@ -15,12 +15,13 @@ for rep in range(int(os.environ.get("REPS", 6))):
     hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
     hv.set_crf_parameters(0, 10)
     ts = []
-    for k in range(24):
+    skip = 2 * int(os.environ.get("ADDER_HIP_GRAPH_CANDIDATES", 6)) + 3
+    for k in range(skip + 16):
         hv.reset()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         hv.integrate_device(d_frames, d_ev, d_off, stream=st); hv.finish()
         ts.append(time.perf_counter() - t0)
-    ts = np.array(ts[4:]) * 1e3
-    res.append((round(float(np.median(ts)), 3), round(float(ts.min()), 3), hex(d_ev.data_ptr() & 0xffffff), hex(d_frames.data_ptr() & 0xffffff)))
+    ts = np.array(ts[skip:]) * 1e3
+    res.append((round(float(np.median(ts)), 3), round(float(ts.min()), 3), hex(d_ev.data_ptr()), hex(d_frames.data_ptr())))
     hv.close(); del d_frames, d_ev, d_off
 print(os.environ.get("ADDER_HIP_PARK_PAD", "0"), res)
