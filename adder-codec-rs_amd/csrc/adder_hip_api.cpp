@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <new>
 #include <string>
@@ -1223,6 +1224,15 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
     if (c->pending_frames && !(c->d_feat_counters && feature_path(c))) {
         // the batch's last node wrote {events, records, status} into page-locked memory: wait for the event behind
         // it, no copies
+        // (a short spin on the flag the last node sets: an event wait parks the thread and wakes up tens of
+        // microseconds late; the event is behind the flag in the same stream, so the wait below is then immediate)
+        {
+            volatile uint32_t *flag = &c->h_result->valid;
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+            uint32_t spins = 0;
+            while (!*flag && ((++spins & 1023u) != 0u || std::chrono::steady_clock::now() < t_end)) {
+            }
+        }
         HIPCHK(c, hipEventSynchronize(c->ev_stop));
         if (!c->h_result->valid) return fail(c, ADDER_E_HIP, "the batch finished without publishing its result");
         st = c->h_result->status;
