@@ -45,7 +45,8 @@ struct AdderHipCtx {
     bool continuous = false;
     float *cn_integ = nullptr, *cn_dt = nullptr, *cn_bdt = nullptr;
     uint32_t *cn_meta = nullptr;
-    uint8_t *state_slab = nullptr;  // hdr, integ0, dt0, bdt0, lastf live in here
+    uint8_t *state_slab = nullptr;  // hdr, lastf, status, integ0, dt0, bdt0 live in here
+    size_t reset_bytes = 0;         // hdr .. status: one memset per reset
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
@@ -227,7 +228,7 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->state_slab, c->dv_integ, c->dv_dt,
-                    c->dv_bdt,  c->dv_bd,   c->running,  c->status, c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
+                    c->dv_bdt,  c->dv_bd,   c->running,  c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
                     c->snap.cn_integ, c->snap.cn_dt, c->snap.cn_bdt, c->snap.cn_meta,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire,
                     c->cth_px, c->cctr_px, c->fset, c->d_feat_counters, c->snap.cth_px, c->snap.cctr_px, c->snap.fset,
@@ -361,12 +362,12 @@ static int init_state(AdderHipCtx *c) {
         HIPCHK(c, hipMemsetAsync(c->cn_dt, 0, cnt * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(c->cn_bdt, 0, cnt * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(c->cn_meta, 0, cnt * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
     } else {
-        HIPCHK(c, hipMemsetAsync(c->hdr, 0, c->n_pad * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->state_slab, 0, c->reset_bytes, c->stream));  // hdr, last_fired_t, status
     }
-    HIPCHK(c, hipMemsetAsync(c->lastf, 0, c->n_pad * sizeof(float), c->stream));
     if (c->running) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), c->stream));
     c->c_thresh = p.c_thresh_start;
     c->c_counter = p.c_counter_start;
     c->generic_sticky = false;
@@ -490,13 +491,17 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             size_t skew = 4352;
             if (const char *e = getenv("ADDER_HIP_PLANE_SKEW")) skew = (size_t)atoi(e) & ~(size_t)255;
             const size_t plane = (c->n_pad * sizeof(uint32_t) + 255) & ~(size_t)255;
-            HIPCHK(c, dalloc(&c->state_slab, 5 * (plane + skew)));
+            HIPCHK(c, dalloc(&c->state_slab, 5 * (plane + skew) + 256));
+            // header plane, last_fired_t plane and the status word first: what a reset clears is one range
             uint8_t *q = c->state_slab;
             c->hdr = reinterpret_cast<uint32_t *>(q);
-            c->integ0 = reinterpret_cast<float *>(q + 1 * (plane + skew));
-            c->dt0 = reinterpret_cast<float *>(q + 2 * (plane + skew));
-            c->bdt0 = reinterpret_cast<float *>(q + 3 * (plane + skew));
-            c->lastf = reinterpret_cast<float *>(q + 4 * (plane + skew));
+            c->lastf = reinterpret_cast<float *>(q + 1 * (plane + skew));
+            c->status = reinterpret_cast<uint32_t *>(q + 2 * (plane + skew));
+            c->reset_bytes = 2 * (plane + skew) + 256;
+            q += 256;
+            c->integ0 = reinterpret_cast<float *>(q + 2 * (plane + skew));
+            c->dt0 = reinterpret_cast<float *>(q + 3 * (plane + skew));
+            c->bdt0 = reinterpret_cast<float *>(q + 4 * (plane + skew));
         }
         c->continuous = p.pixel_mode == ADDER_MODE_CONTINUOUS;
         if (c->continuous) {
@@ -537,7 +542,6 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *gc = getenv("ADDER_HIP_GRAPH_CANDIDATES")) c->graph_candidates = (uint32_t)std::max(1, atoi(gc));
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
-        HIPCHK(c, dalloc(&c->status, 1));
         HIPCHK(c, dalloc(&c->d_rec_total, 1));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c); if (rc_ != ADDER_OK) return rc_; }
