@@ -47,13 +47,13 @@ struct AdderHipCtx {
     uint32_t *cn_meta = nullptr;
     uint8_t *state_slab = nullptr;  // hdr, lastf, status, integ0, dt0, bdt0 live in here
     size_t reset_bytes = 0;         // hdr .. status: one memset per reset
+    size_t slab_bytes = 0;
     uint8_t *running = nullptr;
     bool running_enabled = false;
     // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
     // case: an overflow then rolls the state back and the caller retries with the size reported
     struct Snapshot {
-        uint32_t *hdr = nullptr;
-        float *integ0 = nullptr, *dt0 = nullptr, *bdt0 = nullptr, *lastf = nullptr;
+        uint8_t *slab = nullptr;  // copy of state_slab
         float *dv_integ = nullptr, *dv_dt = nullptr, *dv_bdt = nullptr;
         uint8_t *dv_bd = nullptr;
         float *cn_integ = nullptr, *cn_dt = nullptr, *cn_bdt = nullptr;
@@ -254,8 +254,7 @@ static void free_ctx(AdderHipCtx *c) {
     }
     if (c->frame_e) (void)hipEventDestroy(c->frame_e);
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
-    for (void *p : {(void *)c->snap.hdr, (void *)c->snap.integ0, (void *)c->snap.dt0, (void *)c->snap.bdt0,
-                    (void *)c->snap.lastf, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
+    for (void *p : {(void *)c->snap.slab, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
                     (void *)c->snap.dv_bd})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
@@ -491,7 +490,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             size_t skew = 4352;
             if (const char *e = getenv("ADDER_HIP_PLANE_SKEW")) skew = (size_t)atoi(e) & ~(size_t)255;
             const size_t plane = (c->n_pad * sizeof(uint32_t) + 255) & ~(size_t)255;
-            HIPCHK(c, dalloc(&c->state_slab, 5 * (plane + skew) + 256));
+            c->slab_bytes = 5 * (plane + skew) + 256;
+            HIPCHK(c, dalloc(&c->state_slab, c->slab_bytes));
             // header plane, last_fired_t plane and the status word first: what a reset clears is one range
             uint8_t *q = c->state_slab;
             c->hdr = reinterpret_cast<uint32_t *>(q);
@@ -968,11 +968,7 @@ static hipError_t snap_copy(T **dst, const T *src, size_t count, hipStream_t s) 
 }
 static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
     AdderHipCtx::Snapshot &n = c->snap;
-    HIPCHK(c, snap_copy(&n.hdr, c->hdr, c->n_pad, s));
-    HIPCHK(c, snap_copy(&n.integ0, c->integ0, c->n_pad, s));
-    HIPCHK(c, snap_copy(&n.dt0, c->dt0, c->n_pad, s));
-    HIPCHK(c, snap_copy(&n.bdt0, c->bdt0, c->n_pad, s));
-    HIPCHK(c, snap_copy(&n.lastf, c->lastf, c->n_pad, s));
+    HIPCHK(c, snap_copy(&n.slab, c->state_slab, c->slab_bytes, s));  // the five level-0 planes + status, one copy
     if (c->continuous) {
         const size_t cnt = c->n_pad * (c->max_depth + 1u);
         HIPCHK(c, snap_copy(&n.cn_integ, c->cn_integ, cnt, s));
@@ -1006,11 +1002,7 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
 }
 static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
     AdderHipCtx::Snapshot &n = c->snap;
-    HIPCHK(c, hipMemcpyAsync(c->hdr, n.hdr, c->n_pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->integ0, n.integ0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->dt0, n.dt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->bdt0, n.bdt0, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->lastf, n.lastf, c->n_pad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->state_slab, n.slab, c->slab_bytes, hipMemcpyDeviceToDevice, s));
     if (c->continuous) {
         const size_t cnt = c->n_pad * (c->max_depth + 1u);
         HIPCHK(c, hipMemcpyAsync(c->cn_integ, n.cn_integ, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
