@@ -91,6 +91,7 @@ struct AdderHipCtx {
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2, ring_chunks = 3;
     uint32_t lean_blocks_per_cu = 5, expand_blocks_per_cu = 3;
+    uint32_t gen_blocks_per_cu = 0, gen_expand_blocks_per_cu = 0;  // generic variants: 0 = full grids
     uint32_t frames_per_launch = kMaxFramesPerLaunch;  // temporal blocking depth of the frame kernels
     uint32_t num_waves = 0;
     // device-resident batch description (kernels take {BatchArgs*, f}) + its pinned host mirror
@@ -539,6 +540,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->lean_blocks_per_cu = lb ? (uint32_t)atoi(lb) : 5u;
             c->expand_blocks_per_cu = eb ? (uint32_t)atoi(eb) : 3u;
         }
+        if (const char *e = getenv("ADDER_HIP_GEN_BLOCKS_PER_CU")) c->gen_blocks_per_cu = (uint32_t)atoi(e);
+        if (const char *e = getenv("ADDER_HIP_GEN_EXPAND_BLOCKS_PER_CU")) c->gen_expand_blocks_per_cu = (uint32_t)atoi(e);
         if (const char *gc = getenv("ADDER_HIP_GRAPH_CANDIDATES")) c->graph_candidates = (uint32_t)std::max(1, atoi(gc));
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
@@ -832,8 +835,9 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     // after the other (measured: the scan queued behind the resident frame kernel for a whole kernel time): both are
     // launched with a few workgroups per CU that walk their work, so that both are resident on every CU.
     const bool share = s2 != nullptr && num_frames > c->chunk;
-    const uint32_t lean_cap = share ? c->lean_blocks_per_cu * c->num_cus : 0u;
-    const uint32_t expand_cap = share ? c->expand_blocks_per_cu * c->num_cus : 0u;
+    const bool gen = (variant & 4u) != 0u;
+    const uint32_t lean_cap = share ? (gen ? c->gen_blocks_per_cu : c->lean_blocks_per_cu) * c->num_cus : 0u;
+    const uint32_t expand_cap = share ? (gen ? c->gen_expand_blocks_per_cu : c->expand_blocks_per_cu) * c->num_cus : 0u;
     uint32_t k = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
         const uint32_t nf = std::min(c->chunk, num_frames - f0);

@@ -608,9 +608,11 @@ __global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const Bat
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave;  // the wave's segment
-    const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-    gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane, s_levels[tid / kWave]);
+    // (a capped grid walks the segments, like the lean kernel; the wave's LDS slice is its own, no barrier needed)
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
+        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+        gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane, s_levels[tid / kWave]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1432,12 +1434,13 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
     if (generic) {
+        const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
         if (collapse) {
-            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<true, true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
-            else hipLaunchKernelGGL((adder_frame_kernel<true, false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<true, true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+            else hipLaunchKernelGGL((adder_frame_kernel<true, false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
         } else {
-            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<false, true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
-            else hipLaunchKernelGGL((adder_frame_kernel<false, false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+            if (abs_t) hipLaunchKernelGGL((adder_frame_kernel<false, true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+            else hipLaunchKernelGGL((adder_frame_kernel<false, false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
         }
         return hipGetLastError();
     }
