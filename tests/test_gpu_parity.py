@@ -1023,3 +1023,37 @@ def test_frame_ring_rules_and_overflow():
     with pytest.raises(A.AdderHipError) as ei:
         hv.frame_submit(clip[5])
     assert ei.value.code == A.E_POISONED
+
+
+@pytest.mark.gpu
+def test_graph_instances_are_interchangeable_and_the_plan_settles():
+    """A batch length of several chunks tries up to six instances of its captured graph on the first batches and keeps
+    the fastest (include/adder_hip.h, adder_hip_launch_plan_settled): every one of those batches must produce the same
+    stream, the choice must be made after twelve of them, and reset / finish without host copies must keep working."""
+    import torch
+    A = _hip()
+    W, H, T = 640, 360, 100  # 4 chunks of 32 frames
+    st = torch.cuda.current_stream().cuda_stream
+    d_frames = torch.empty((T, W * H), dtype=torch.uint8, device="cuda")
+    A.synth_clip_device(d_frames, A.CONTENT_SCENE, W, H, 1, num_frames=T, stream=st)
+    d_ev = torch.empty((W * H * T, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    ref = None
+    settled_at = None
+    for k in range(15):
+        hv.reset()
+        hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+        n = hv.finish()
+        digest = hashlib.sha256(d_ev[:n].cpu().numpy().tobytes() + d_off.cpu().numpy().tobytes()).hexdigest()
+        ref = ref or (n, digest)
+        assert (n, digest) == ref, k
+        if settled_at is None and hv.launch_plan_settled():
+            settled_at = k
+    assert settled_at is not None and settled_at <= 12
+    clip = d_frames.cpu().numpy().reshape(T, H, W, 1)
+    want, _ = _oracle_events(clip[:8], time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, dtm=255)
+    offs = d_off.cpu().numpy()
+    got = d_ev[: int(offs[8])].cpu().numpy().view(A.EVENT_DTYPE).reshape(-1)
+    assert np.array_equal(got, want)
