@@ -133,6 +133,7 @@ SYMBOLS = {
     "adder_hip_enable_running_intensities": (_i32, [_vp, _i32]),
     "adder_hip_last_batch_ms": (_f32, [_vp]),
     "adder_hip_launch_plan_settled": (_i32, [_vp]),
+    "adder_hip_debug_timeline": (_i32, [_vp, _vp]),
     "adder_hip_set_launch_timing": (_i32, [_vp, _i32]),
     "adder_hip_last_launch_avg_us": (_f32, [_vp]),
     "adder_hip_last_launch_frames": (_f32, [_vp]),

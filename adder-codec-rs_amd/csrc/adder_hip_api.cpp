@@ -127,6 +127,7 @@ struct AdderHipCtx {
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
+    unsigned long long *d_timeline = nullptr;  // ADDER_HIP_TIMELINE diagnostics
     uint64_t last_records = 0;
     std::vector<hipEvent_t> post_events;  // launch timing: pairs around scan + offsets + expand of every chunk
     uint32_t timed_posts = 0;
@@ -261,6 +262,7 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
+    if (c->d_timeline) (void)hipFree(c->d_timeline);
     for (auto &kv : c->graphs)
         for (hipGraphExec_t e : kv.second.cand)
             if (e) (void)hipGraphExecDestroy(e);
@@ -853,6 +855,10 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
                 c->timed_frames += nb;
             }
         }
+        // (scan + offsets on a third stream of their own -- they depend on the chunk's frame kernels only -- was
+        // tried: they then run at once instead of behind the previous expansion, and the expansions, now back to
+        // back, take as much longer as was gained: the two big kernels compete for the same thing; in-kernel
+        // timestamps, tools/timeline_probe.py)
         hipStream_t t = s;
         if (s2) {
             HIPCHK(c, hipEventRecord(c->cap_e1, s));
@@ -1128,6 +1134,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.slots = c->slots;
     b.chunk = c->chunk;
     b.rec_total = c->d_rec_total;
+    b.timeline = nullptr;
+    if (getenv("ADDER_HIP_TIMELINE")) {  // diagnostics (tools/timeline_probe.py)
+        if (!c->d_timeline) HIPCHK(c, dalloc(&c->d_timeline, 4 * kTimelineChunks * 2));
+        std::vector<unsigned long long> init(4 * kTimelineChunks * 2);
+        for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+        HIPCHK(c, hipMemcpy(c->d_timeline, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        b.timeline = c->d_timeline;
+    }
     // (frame_offsets[0] and the record count are started by the first chunk's offsets kernel: nothing to clear here)
     if (reinterpret_cast<uint8_t *>(c->d_ftab) == reinterpret_cast<uint8_t *>(c->d_batch) + kBatchDescBytes &&
         reinterpret_cast<uint8_t *>(c->h_ftab) == reinterpret_cast<uint8_t *>(c->h_batch) + kBatchDescBytes) {
@@ -1290,6 +1304,13 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
 }
 
 extern "C" float adder_hip_last_batch_ms(AdderHipCtx *c) { return c ? c->last_ms : 0.0f; }
+
+// diagnostics: the last batch's kernel timeline (ADDER_HIP_TIMELINE=1), [4 kinds][64 chunks][start, end] in 10 ns ticks
+extern "C" int adder_hip_debug_timeline(AdderHipCtx *c, unsigned long long *dst) {
+    if (!c || !dst || !c->d_timeline) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipMemcpy(dst, c->d_timeline, 4 * kTimelineChunks * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ADDER_OK;
+}
 
 extern "C" int adder_hip_launch_plan_settled(const AdderHipCtx *c) {
     if (!c) return 1;

@@ -112,7 +112,11 @@ struct BatchArgs {
     uint32_t slots;
     uint32_t chunk;           // frames per chunk; slots = chunks in the ring * chunk
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
+    // diagnostics (null in normal operation): first start / last end of every kernel of the batch on the 100 MHz
+    // constant clock, [kernel kind 0 frame, 1 scan, 2 offsets, 3 expansion][chunk][2]  (tools/timeline_probe.py)
+    unsigned long long *timeline;
 };
+constexpr uint32_t kTimelineChunks = 64;
 
 // Where (frame slot, segment) parks its records, in bytes from park_ring.  Layout [chunk of the ring][segment][frame
 // of the chunk][park_bytes]: the frames a wave steps in one launch are CONTIGUOUS (it touches one or two pages of

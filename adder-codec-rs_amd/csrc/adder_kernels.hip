@@ -37,6 +37,17 @@ namespace adder {
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
 
+// diagnostics: a workgroup's start / end into the batch's timeline (no-ops when the batch has none)
+__device__ __forceinline__ void timeline_mark(const BatchArgs *b, uint32_t kind, uint32_t f, bool end) {
+    if (!b->timeline || threadIdx.x != 0) return;
+    const uint32_t chunk = f / b->chunk;
+    if (chunk >= kTimelineChunks) return;
+    unsigned long long *slot = b->timeline + ((size_t)kind * kTimelineChunks + chunk) * 2u + (end ? 1u : 0u);
+    const unsigned long long t = wall_clock64();
+    if (end) atomicMax(slot, t);
+    else atomicMin(slot, t);
+}
+
 __device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
     __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -361,6 +372,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
+    timeline_mark(b, 0u, f, false);
     // The grid may be smaller than the number of segments (a few workgroups per CU that walk the segments): this
     // kernel is bound by instruction issue and the expansion of the chunk before by memory, so the two are meant
     // to be resident side by side -- two grids that each fill the chip would run one after the other.  Nothing
@@ -372,6 +384,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
         lean_load<ABS_T>(a, u0, full, raw);
         lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
     }
+    timeline_mark(b, 0u, f, true);
 }
 
 // Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes kLean1Segs
@@ -701,6 +714,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
 constexpr uint32_t kScanThreads = 1024;
 __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
     const FrameArgs a = frame_args(b, f0 + blockIdx.x);
+    timeline_mark(b, 1u, f0, false);
     __shared__ uint32_t s_part[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
@@ -749,6 +763,7 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
         *a.ftot = total;
         a.ftot[b->slots] = rec_total;  // second half of the ring: records per frame
     }
+    timeline_mark(b, 1u, f0, true);
 }
 
 // frame_offsets[f+1] = frame_offsets[f] + events(f) for the frames of the chunk, in order.
@@ -756,6 +771,7 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
 // memset in front of a batch.
 __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t nf) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    timeline_mark(b, 2u, f0, false);
     uint64_t *offs = b->base.frame_offsets;
     uint64_t run = f0 == 0u ? 0ull : offs[f0];
     uint64_t recs = (f0 == 0u || !b->rec_total) ? 0ull : *b->rec_total;
@@ -767,6 +783,7 @@ __global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f
         offs[f0 + i + 1] = run;
     }
     if (b->rec_total) *b->rec_total = recs;
+    timeline_mark(b, 2u, f0, true);
 }
 
 // Last node of a batch: what the host needs to know about it, written straight into page-locked host memory (the
@@ -1078,7 +1095,9 @@ template <int FORMAT, bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0,
                                                                      uint32_t xblocks, uint32_t nf) {
     // (frame, group of segments) pairs, frame-major; a grid smaller than their number walks them (see the lean kernel)
+    timeline_mark(b, 3u, f0, false);
     for (uint32_t w = blockIdx.x; w < xblocks * nf; w += gridDim.x) expand_block<FORMAT, ABS_T>(b, f0 + w / xblocks, w % xblocks);
+    timeline_mark(b, 3u, f0, true);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -216,6 +216,9 @@ float adder_hip_last_batch_ms(AdderHipCtx *ctx);
  * a few instances (2 batches each, 6 instances) and keep the fastest; this returns 1 once the last batch's length
  * has settled (always 1 for single-chunk batches and with ADDER_HIP_NO_GRAPH). */
 int adder_hip_launch_plan_settled(const AdderHipCtx *ctx);
+/* Diagnostics (environment ADDER_HIP_TIMELINE=1): first start / last end of the kernels of the last batch, in 10 ns
+ * ticks of the device's constant clock: dst[4 kinds: frame, scan, offsets, expansion][64 chunks][2]. */
+int adder_hip_debug_timeline(AdderHipCtx *ctx, unsigned long long *dst);
 
 /* Mean duration in microseconds of the frame-kernel launches of the last device batch,
  * measured with one HIP event pair around EVERY launch on the launch stream; only
