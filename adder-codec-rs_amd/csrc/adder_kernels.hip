@@ -8,18 +8,17 @@
 //   K1 adder_lean_kernel / adder_frame_kernel   one lane = kUnitsPerLane consecutive
 //        pixel-channels, one wave = one segment.  Loads level 0 of the arena (16 bytes per
 //        unit, structure-of-arrays planes resident in HBM across frames) and the frame bytes as
-//        coalesced vectors and steps up to 16 consecutive frames with the state in registers.
+//        coalesced vectors and steps up to 32 consecutive frames with the state in registers.
 //        Per frame and unit the step leaves at most ONE 12-byte record (the lean variants: the raw
 //        material of its <= 3 events) -- the records are compacted per wave with ballot + mbcnt
 //        (no barrier, no atomics, no LDS) into the frame's scratch segment, the segment's event and
 //        record counts go to wtot.
 //   Ks adder_scan_kernel    exclusive prefix over the per-segment counts (one block per
 //        frame) + adder_offsets_kernel (the frame_offsets chain); run once per CHUNK of frames.
-//   K2 expand_block         reads the parked records linearly, decodes them and writes each 12-byte
-//        event to its final slot of the ordered stream (coordinates from the unit index).  Runs
-//        as extra workgroups inside K1's grid (an earlier chunk's frames: memory-bound
-//        work sharing the SIMDs with K1's VALU-bound step) and as adder_expand_kernel for
-//        the last chunks of a batch.
+//   K2 adder_expand_kernel  reads the parked records linearly, decodes them and writes each 12-byte
+//        event to its final slot of the ordered stream (coordinates from the unit index).  Its own
+//        kernel, on a second stream beside the frame kernel of the next chunk; both are launched with
+//        a few workgroups per CU that walk their work, so both are resident on every CU.
 //
 // No kernel waits on another workgroup, so there is no residency requirement, no spin
 // loop and nothing that can hang.  Pixels whose arena is deeper than one fired level
