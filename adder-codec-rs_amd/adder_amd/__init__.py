@@ -6,7 +6,7 @@ drive it.  The C++ mirror of the reference's Source/Video/Encoder surface lives 
 ../host/.
 """
 from ._native import (  # noqa: F401
-    AdderHipError, AdderHipParams, AdderFramerParams, AdderCompressedParams, EVENT_DTYPE, LIB_PATH, load,
+    AdderHipError, AdderHipParams, AdderFramerParams, AdderCompressedParams, EVENT_DTYPE, SPARSE_STEP_DTYPE, LIB_PATH, load,
     TIME_DELTA_T, TIME_ABSOLUTE_T, TIME_MIXED, MULTI_NORMAL, MULTI_COLLAPSE,
     CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE, D_EMPTY, D_ZERO_INTEGRATION, D_MAX, C_NONE,
     OK, E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED,

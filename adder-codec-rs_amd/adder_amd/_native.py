@@ -51,6 +51,10 @@ class AdderHipParams(C.Structure):
     ]
 
 
+SPARSE_STEP_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("frame_val", "u1"), ("pad", "<u2"),
+                              ("intensity", "<f4"), ("time", "<f4")])  # AdderSparseStep
+
+
 class AdderFramerParams(C.Structure):
     """include/adder_framer.h::AdderFramerParams"""
     _fields_ = [
@@ -133,6 +137,8 @@ SYMBOLS = {
     "adder_hip_enable_running_intensities": (_i32, [_vp, _i32]),
     "adder_hip_last_batch_ms": (_f32, [_vp]),
     "adder_hip_launch_plan_settled": (_i32, [_vp]),
+    "adder_hip_integrate_sparse": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "adder_hip_integrate_sparse_device": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "adder_hip_debug_timeline": (_i32, [_vp, _vp]),
     "adder_hip_set_launch_timing": (_i32, [_vp, _i32]),
     "adder_hip_last_launch_avg_us": (_f32, [_vp]),

@@ -186,6 +186,17 @@ class HipVideo:
         ev = _copy_events(out, n.value)
         return (ev, chunks) if want_chunks else ev
 
+    def integrate_sparse(self, steps, out_cap=None):
+        """Event-camera sources: one integrate_for_px call per step (N.SPARSE_STEP_DTYPE), in order -> events."""
+        steps = np.ascontiguousarray(steps, dtype=N.SPARSE_STEP_DTYPE)
+        cap = max(len(steps), 1) * (self.params.max_depth + 3) if out_cap is None else out_cap
+        out = np.zeros(cap, N.EVENT_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.adder_hip_integrate_sparse(self.h, steps.ctypes.data, len(steps), out.ctypes.data, cap, C.byref(n))
+        self.last_required = n.value
+        N.check(self.h, rc)
+        return out[: n.value].copy()
+
     # ---- per-frame ring: submit returns once the work is queued, collect hands back the oldest frame --------
     def frames_configure(self, slots=0, events_per_slot=0):
         N.check(self.h, self.L.adder_hip_frames_configure(self.h, slots, events_per_slot))

@@ -128,6 +128,17 @@ struct AdderHipCtx {
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
     unsigned long long *d_timeline = nullptr;  // ADDER_HIP_TIMELINE diagnostics
+    // sparse steps (adder_hip_integrate_sparse): running_t per unit, and the work buffers of a call
+    bool sparse_mode = false;  // c_thresh / counter / running_t live per unit from the first sparse call on
+    float *rt_px = nullptr;
+    struct SparseWork {
+        SparseStep *steps = nullptr;
+        uint32_t *keys0 = nullptr, *keys1 = nullptr, *idx0 = nullptr, *idx1 = nullptr, *count = nullptr, *offs = nullptr;
+        uint2 *stage = nullptr;
+        void *temp = nullptr;
+        unsigned long long *total = nullptr;
+        size_t cap = 0, temp_bytes = 0;  // steps
+    } sw;
     uint64_t last_records = 0;
     std::vector<hipEvent_t> post_events;  // launch timing: pairs around scan + offsets + expand of every chunk
     uint32_t timed_posts = 0;
@@ -263,6 +274,10 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_timeline) (void)hipFree(c->d_timeline);
+    for (void *p : {(void *)c->rt_px, (void *)c->sw.steps, (void *)c->sw.keys0, (void *)c->sw.keys1, (void *)c->sw.idx0,
+                    (void *)c->sw.idx1, (void *)c->sw.count, (void *)c->sw.offs, (void *)c->sw.stage, c->sw.temp,
+                    (void *)c->sw.total})
+        if (p) (void)hipFree(p);
     for (auto &kv : c->graphs)
         for (hipGraphExec_t e : kv.second.cand)
             if (e) (void)hipGraphExecDestroy(e);
@@ -374,6 +389,7 @@ static int init_state(AdderHipCtx *c) {
     c->c_counter = p.c_counter_start;
     c->generic_sticky = false;
     c->perpx = false;
+    c->sparse_mode = false;
     if (c->fset) HIPCHK(c, hipMemsetAsync(c->fset, 0, (size_t)c->rows * p.width, c->stream));
     c->running_t = 0.0f;
     c->frames_done = 0;
@@ -736,6 +752,7 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
         return fail(c, ADDER_E_ARENA_DEPTH, "a pixel needed more than max_depth=%u stored nodes", c->max_depth);
     if (st & kStatusWire)
         return fail(c, ADDER_E_BAD_PARAMS, "wire serialisation: an event without a channel on a multi-channel plane");
+    if (st & kStatusSparse) return fail(c, ADDER_E_BAD_PARAMS, "a sparse step names a pixel outside the plane / row band");
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
@@ -1057,6 +1074,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         HIPCHK(c, hipStreamWaitEvent(stream, c->reset_e, 0));
         c->reset_pending = false;
     }
+    if (c->sparse_mode)
+        return fail(c, ADDER_E_BAD_PARAMS, "dense frames after sparse steps: the pixels' c_thresh and running_t have "
+                    "diverged (pass every pixel as a sparse step, or adder_hip_reset)");
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
     const bool sticky_before = c->generic_sticky;
     const bool fpath = feature_path(c);
@@ -1756,6 +1776,139 @@ extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t 
         }
         chunk_offsets[c->num_chunks] = (uint32_t)n;
     }
+    return ADDER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sparse steps of event-camera sources (adder_sparse.hip): integrate_for_px(px, &mut 0, frame_val, intensity,
+// time) per step, in the caller's order; all events into one buffer.
+// ------------------------------------------------------------------------------------------
+static int sparse_prepare(AdderHipCtx *c, size_t n, hipStream_t s) {
+    if (!c->continuous) return fail(c, ADDER_E_BAD_PARAMS, "sparse steps need a Mode::Continuous context (pixel_mode)");
+    if (n > 0x7fffffffull) return fail(c, ADDER_E_BAD_PARAMS, "too many steps for one call");
+    if (!c->sparse_mode) {
+        // c_thresh, its counter and running_t advance per integrate call: from here on they differ between pixels
+        if (!c->cth_px) {
+            HIPCHK(c, dalloc(&c->cth_px, c->n_pad));
+            HIPCHK(c, dalloc(&c->cctr_px, c->n_pad));
+        }
+        if (!c->rt_px) HIPCHK(c, dalloc(&c->rt_px, c->n_pad));
+        HIPCHK(c, hipMemsetAsync(c->cth_px, c->c_thresh, c->n_pad, s));
+        HIPCHK(c, hipMemsetAsync(c->cctr_px, c->c_counter, c->n_pad, s));
+        uint32_t bits;
+        memcpy(&bits, &c->running_t, sizeof bits);
+        HIPCHK(c, adder_launch_fill_u32(reinterpret_cast<uint32_t *>(c->rt_px), c->n_pad, bits, s));
+        c->sparse_mode = true;
+    }
+    AdderHipCtx::SparseWork &w = c->sw;
+    if (w.cap < n) {
+        for (void *p : {(void *)w.steps, (void *)w.keys0, (void *)w.keys1, (void *)w.idx0, (void *)w.idx1, (void *)w.count,
+                        (void *)w.offs, (void *)w.stage, w.temp})
+            if (p) HIPCHK(c, hipFree(p));
+        w = AdderHipCtx::SparseWork{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.total, 0, 0};
+        const size_t cap = std::max<size_t>(n, 4096);
+        HIPCHK(c, dalloc(&w.steps, cap));
+        HIPCHK(c, dalloc(&w.keys0, cap));
+        HIPCHK(c, dalloc(&w.keys1, cap));
+        HIPCHK(c, dalloc(&w.idx0, cap));
+        HIPCHK(c, dalloc(&w.idx1, cap));
+        HIPCHK(c, dalloc(&w.count, cap));
+        HIPCHK(c, dalloc(&w.offs, cap));
+        HIPCHK(c, dalloc(&w.stage, cap * (c->max_depth + 3u)));
+        w.temp_bytes = adder_sparse_temp_bytes((uint32_t)cap);
+        HIPCHK(c, hipMalloc(&w.temp, w.temp_bytes));
+        w.cap = cap;
+    }
+    if (!w.total) HIPCHK(c, dalloc(&w.total, 1));
+    return ADDER_OK;
+}
+
+static SparseArgs sparse_args(AdderHipCtx *c) {
+    SparseArgs a{};
+    a.hdr = c->hdr;
+    a.lastf = c->lastf;
+    a.cn_integ = c->cn_integ;
+    a.cn_dt = c->cn_dt;
+    a.cn_bdt = c->cn_bdt;
+    a.cn_meta = c->cn_meta;
+    a.plane_stride = c->n_pad;
+    a.cth_px = c->cth_px;
+    a.cctr_px = c->cctr_px;
+    a.rt_px = c->rt_px;
+    a.running = c->running_enabled ? c->running : nullptr;
+    a.status = c->status;
+    a.c_max = c->p.c_thresh_max;
+    a.c_vel = c->p.c_increase_velocity;
+    a.max_nodes = c->max_depth + 1u;
+    a.stage_events = c->max_depth + 3u;
+    a.width = c->p.width;
+    a.channels = c->p.channels;
+    a.row_begin = c->p.row_begin;
+    a.rows = c->rows;
+    a.sc = make_consts(c, 0.0f);
+    return a;
+}
+
+// d_steps / d_out: device memory; synchronises `stream` to hand back the count
+extern "C" int adder_hip_integrate_sparse_device(AdderHipCtx *c, const AdderSparseStep *d_steps, size_t n, AdderEvent *d_out,
+                                                 size_t out_cap, size_t *n_out, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_out) *n_out = 0;
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending || c->f_submitted != c->f_collected) return fail(c, ADDER_E_BAD_PARAMS, "work is in flight on this context");
+    if ((!d_steps && n) || (!d_out && out_cap)) return fail(c, ADDER_E_BAD_PARAMS, "null pointer");
+    if (n == 0) return ADDER_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (c->reset_pending) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->reset_e, 0));
+        c->reset_pending = false;
+    }
+    int rc = sparse_prepare(c, n, s);
+    if (rc != ADDER_OK) return rc;
+    if (c->running_enabled && !c->running) {
+        HIPCHK(c, dalloc(&c->running, c->n_pad));
+        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, s));
+    }
+    const SparseArgs a = sparse_args(c);
+    AdderHipCtx::SparseWork &w = c->sw;
+    HIPCHK(c, adder_sparse_run(&a, reinterpret_cast<const SparseStep *>(d_steps), (uint32_t)n, w.keys0, w.keys1, w.idx0, w.idx1,
+                               w.temp, w.temp_bytes, w.stage, w.count, w.offs, reinterpret_cast<AdderEventPod *>(d_out),
+                               out_cap, w.total, s));
+    unsigned long long total = 0;
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, w.total, sizeof total, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (n_out) *n_out = (size_t)total;
+    c->frames_done += 1;
+    if (st & kStatusCapacity) {
+        c->poisoned = true;  // the pixels have been stepped: there is no undo on this route
+        return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small: the steps produced %llu events (a buffer of "
+                    "n * (max_depth + 3) events cannot overflow)", total);
+    }
+    return status_to_code(c, st);
+}
+
+extern "C" int adder_hip_integrate_sparse(AdderHipCtx *c, const AdderSparseStep *steps, size_t n, AdderEvent *out,
+                                          size_t out_cap, size_t *n_out) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_out) *n_out = 0;
+    if (!steps && n) return fail(c, ADDER_E_BAD_PARAMS, "steps is null");
+    if (n == 0) return ADDER_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sparse_prepare(c, n, c->stream);
+    if (rc != ADDER_OK) return rc;
+    void *vp = c->d_events;
+    if ((rc = ensure(c, &vp, &c->d_events_cap, std::max<size_t>(out_cap, 1) * sizeof(AdderEvent))) != ADDER_OK) return rc;
+    c->d_events = (AdderEvent *)vp;
+    HIPCHK(c, hipMemcpyAsync(c->sw.steps, steps, n * sizeof(SparseStep), hipMemcpyHostToDevice, c->stream));
+    size_t total = 0;
+    rc = adder_hip_integrate_sparse_device(c, reinterpret_cast<const AdderSparseStep *>(c->sw.steps), n, c->d_events, out_cap,
+                                           &total, c->stream);
+    if (n_out) *n_out = total;
+    if (rc != ADDER_OK) return rc;
+    if (total) HIPCHK(c, hipMemcpy(out, c->d_events, total * sizeof(AdderEvent), hipMemcpyDeviceToHost));
     return ADDER_OK;
 }
 

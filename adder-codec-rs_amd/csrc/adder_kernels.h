@@ -37,6 +37,7 @@ constexpr uint32_t kGenRecBytes = 8;                               // generic va
 constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the output buffer
 constexpr uint32_t kStatusWire = 4u;      // wire serialisation met c = None on a multi-channel plane
 constexpr uint32_t kStatusDepth = 2u;     // a pixel needed more than max_depth stored levels
+constexpr uint32_t kStatusSparse = 8u;    // a sparse step names a pixel outside the plane / band
 
 struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint16_t x, y;
@@ -143,6 +144,29 @@ struct FrameResult {
     uint32_t new_features;  // feature-driven rate control: features this frame found new
 };
 
+// One integrate_for_px call of an event-camera source (same layout as AdderSparseStep, include/adder_hip.h)
+struct SparseStep {
+    uint16_t x, y;
+    uint8_t c, frame_val;
+    uint16_t pad;
+    float intensity, time;
+};
+// what the sparse kernels need of a Mode::Continuous context (adder_sparse.hip)
+struct SparseArgs {
+    uint32_t *hdr;
+    float *lastf;
+    float *cn_integ, *cn_dt, *cn_bdt;
+    uint32_t *cn_meta;
+    size_t plane_stride;
+    uint8_t *cth_px, *cctr_px;  // c_thresh / c_increase_counter per unit
+    float *rt_px;               // PixelArena::running_t per unit
+    uint8_t *running;           // side plane or nullptr
+    uint32_t *status;
+    uint32_t c_max, c_vel, max_nodes, stage_events;
+    uint32_t width, channels, row_begin, rows;
+    StepConsts sc;              // (time_spanned, running_t, cth are set per step)
+};
+
 // handle_features / handle_roi of one context (video.rs:865-1112)
 struct FeatureArgs {
     uint8_t *fset;        // [rows][width] membership of VideoState::features (0 / 1)
@@ -183,6 +207,11 @@ hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_
                              hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
+size_t adder_sparse_temp_bytes(uint32_t n);
+hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseStep *d_steps, uint32_t n, uint32_t *keys0,
+                            uint32_t *keys1, uint32_t *idx0, uint32_t *idx1, void *d_temp, size_t temp_bytes, uint2 *stage,
+                            uint32_t *count, uint32_t *offs, adder::AdderEventPod *d_out, uint64_t out_cap,
+                            unsigned long long *d_total, hipStream_t stream);
 hipError_t adder_launch_publish(const adder::BatchArgs *b, uint32_t num_frames, adder::BatchResult *h, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,

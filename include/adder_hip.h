@@ -179,6 +179,27 @@ int adder_hip_frame_collect(AdderHipCtx *ctx, const AdderEvent **events, size_t 
                             const uint32_t **chunk_offsets);
 uint32_t adder_hip_frames_in_flight(const AdderHipCtx *ctx);
 
+/* --- sparse sources (event cameras; Mode::Continuous contexts) ------------------------------------------------
+ * One step = one `integrate_for_px(px, &mut 0, frame_val, intensity, time, &mut events, ..)` call of the reference's
+ * event-camera sources (prophesee.rs:196-254, 343-358; davis.rs), i.e. what a camera event makes of its pixel: the
+ * host keeps the camera-side state (last timestamp, log intensity) and hands over the steps in the camera's order.
+ * All events go to ONE buffer in step order (the sources return `vec![events]`).  A pixel's c_thresh, its counter
+ * and running_t advance per call, so after the first sparse call they differ between pixels: dense frames are then
+ * refused until adder_hip_reset (the dense start-up frames of Prophesee::consume, :117-131, come first).  A buffer
+ * of n * (max_depth + 3) events cannot overflow; an overflow poisons the context (no rollback on this route). */
+typedef struct AdderSparseStep {
+    uint16_t x, y;      /* plane coordinates */
+    uint8_t c;          /* channel, ADDER_C_NONE on a 1-channel plane */
+    uint8_t frame_val;  /* compared with c_thresh (base_val is 0 for every call) */
+    uint16_t pad;
+    float intensity;    /* intensity to integrate */
+    float time;         /* over this many ticks */
+} AdderSparseStep;
+int adder_hip_integrate_sparse(AdderHipCtx *ctx, const AdderSparseStep *steps, size_t n, AdderEvent *out, size_t out_cap,
+                               size_t *n_out);
+int adder_hip_integrate_sparse_device(AdderHipCtx *ctx, const AdderSparseStep *d_steps, size_t n, AdderEvent *d_out,
+                                      size_t out_cap, size_t *n_out, void *stream);
+
 /* --- T frames, host buffers: same stream, frame-major; frame_offsets gets T+1 entries. */
 int adder_hip_integrate_batch(AdderHipCtx *ctx, const uint8_t *frames_hwc, uint32_t num_frames,
                               size_t frame_stride_bytes, size_t row_stride_bytes,

@@ -660,6 +660,49 @@ void oracle_video_set_pixel_mode(OracleVideo *v, int mode) { v->sp.pixel_tree_mo
 void oracle_video_set_threads(OracleVideo *v, int threads) { v->threads = threads > 0 ? threads : 1; }
 const uint8_t *oracle_video_running_intensities(const OracleVideo *v) { return v->running_intensities; }
 
+static uint8_t frame_value_u8(uint8_t d, uint32_t t, double tpf);
+/* ------------------------------------------------------------------------- */
+/* Sparse sources (event cameras): prophesee.rs:170-258, 330-372 call              */
+/* integrate_for_px(px, &mut 0, frame_val, intensity, time, ..) pixel by pixel,    */
+/* in the order of the camera's events; all events go to ONE buffer.               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint16_t x, y;
+    uint8_t c; /* 0xFF = None */
+    uint8_t frame_val;
+    uint16_t pad;
+    float intensity, time;
+} OracleSparseStep;
+
+int oracle_video_integrate_sparse(OracleVideo *v, const OracleSparseStep *steps, size_t n, OracleEvent *out, size_t cap,
+                                  size_t *n_out) {
+    EventVec ev = {0};
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t c = steps[i].c == 0xFF ? 0u : steps[i].c;
+        if (steps[i].x >= v->width || steps[i].y < v->row_begin || steps[i].y - v->row_begin >= v->height ||
+            c >= v->channels) {
+            free(ev.data);
+            return -1;
+        }
+        PixelArena *px = &v->px[((size_t)(steps[i].y - v->row_begin) * v->width + steps[i].x) * v->channels + c];
+        px->base_val = 0; /* `let mut base_val = 0;` right before every call (prophesee.rs:204,242,343) */
+        integrate_for_px(px, steps[i].frame_val, steps[i].intensity, steps[i].time, &ev, &v->sp);
+        /* the side plane (prophesee.rs:259-283): the root's best event, if it has one */
+        if (px->arena[0].has_best)
+            v->running_intensities[((size_t)(steps[i].y - v->row_begin) * v->width + steps[i].x) * v->channels + c] =
+                frame_value_u8(px->arena[0].best_event.d, f32_as_u32(px->arena[0].best_event.delta_t), (double)v->sp.ref_time);
+    }
+    if (n_out) *n_out = ev.len;
+    int rc = 0;
+    if (ev.len > cap) rc = -4;
+    else if (ev.len) memcpy(out, ev.data, ev.len * sizeof(OracleEvent));
+    free(ev.data);
+    return rc;
+}
+void oracle_video_fill_running_intensities(OracleVideo *v, uint8_t value) {
+    memset(v->running_intensities, value, (size_t)v->width * v->height * v->channels);
+}
+
 /* scale_intensity.rs:58-72,262-270 : u8::get_frame_value(Intensity view, SourceType::U8) */
 static uint8_t frame_value_u8(uint8_t d, uint32_t t, double tpf) {
     double intensity;

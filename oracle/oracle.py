@@ -209,6 +209,10 @@ class Pixel:
         )
 
 
+SPARSE_STEP_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("c", "u1"), ("frame_val", "u1"), ("pad", "<u2"),
+                              ("intensity", "<f4"), ("time", "<f4")])
+
+
 class Video:
     """Video<W> driver state + integrate_matrix (video.rs:350-438, 651-778)."""
 
@@ -272,6 +276,25 @@ class Video:
         out = np.zeros(self.width * self.height * self.channels, np.uint8)
         self.L.oracle_video_c_thresh_plane(self.h, out.ctypes.data)
         return out.reshape(self.height, self.width, self.channels)
+
+    def integrate_sparse(self, steps):
+        """integrate_for_px(px, &mut 0, frame_val, intensity, time) per step, in order (prophesee.rs:170-258):
+        steps = array of SPARSE_STEP_DTYPE; returns the events of all steps in one buffer."""
+        steps = np.ascontiguousarray(steps, SPARSE_STEP_DTYPE)
+        self.L.oracle_video_integrate_sparse.restype = C.c_int
+        self.L.oracle_video_integrate_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                         C.POINTER(C.c_size_t)]
+        cap = max(1024, len(steps) * 24)
+        out = np.zeros(cap, EVENT_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.oracle_video_integrate_sparse(self.h, steps.ctypes.data, len(steps), out.ctypes.data, cap, C.byref(n))
+        if rc != 0:
+            raise ValueError(f"oracle_video_integrate_sparse failed: {rc}")
+        return out[: n.value].copy()
+
+    def fill_running_intensities(self, value):
+        self.L.oracle_video_fill_running_intensities.argtypes = [C.c_void_p, C.c_uint8]
+        self.L.oracle_video_fill_running_intensities(self.h, value)
 
     def set_pixel_mode(self, mode):
         """0 = Mode::FramePerfect (default), 1 = Mode::Continuous (lib.rs:196-205)."""

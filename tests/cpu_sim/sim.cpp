@@ -50,6 +50,9 @@ struct Sim {
     uint32_t baseline, radius, chunk_rows, roi[4];
     std::vector<uint8_t> cth_px, cctr_px, running, fset;
     uint32_t new_features;
+    // sparse steps (event-camera sources): running_t per unit as well, from the first sparse call on
+    int sparse;
+    std::vector<float> rt_px;
 };
 
 struct DeepAcc {
@@ -141,6 +144,7 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->running.assign(s->N, 0);
     s->fset.assign((size_t)W * H, 0);
     s->new_features = 0;
+    s->sparse = 0;
     return s;
 }
 void sim_free(Sim *s) { delete s; }
@@ -185,6 +189,57 @@ void sim_set_use_fast(Sim *s, int on) { s->use_fast = on; }
 uint64_t sim_fast_steps(const Sim *s) { return s->fast_steps; }
 uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
 uint64_t sim_lean_steps(const Sim *s) { return s->lean_steps; }
+
+// integrate_for_px(px, &mut 0, frame_val, intensity, time) per step, in order (the flow of adder_sparse_run_kernel,
+// serially): Continuous contexts; c_thresh, its counter and running_t are per unit from the first call on
+struct SimSparseStep {
+    uint16_t x, y;
+    uint8_t c, frame_val;
+    uint16_t pad;
+    float intensity, time;
+};
+int sim_integrate_sparse(Sim *s, const SimSparseStep *steps, size_t n, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!s->continuous) return -1;
+    if (!s->sparse) {
+        s->cth_px.assign(s->N, s->c_thresh);
+        s->cctr_px.assign(s->N, s->c_counter);
+        s->rt_px.assign(s->N, s->running_t);
+        s->sparse = 1;
+    }
+    StepConsts sc;
+    sc.dtm_f = (float)s->dtm;
+    sc.ref_time = s->ref_time;
+    sc.collapse = s->collapse;
+    sc.abs_t = s->abs_t;
+    sc.max_depth = s->max_depth;
+    sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
+    int rc = 0;
+    Emitter em;
+    em.out = out; em.cap = cap; em.pos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t c = steps[i].c == 0xFF ? 0u : steps[i].c;
+        if (steps[i].x >= s->W || steps[i].y < s->row_begin || steps[i].y - s->row_begin >= s->H || c >= s->C) return -1;
+        const size_t u = ((size_t)(steps[i].y - s->row_begin) * s->W + steps[i].x) * s->C + c;
+        em.x = steps[i].x; em.y = steps[i].y; em.c = steps[i].c;
+        APx p = apx_unpack(s->c_hdr[u], s->lastf[u]);
+        p.base = 0u;  // `let mut base_val = 0;` before every call (prophesee.rs:204,242,343)
+        sc.time_spanned = steps[i].time;
+        sc.running_t = s->rt_px[u];
+        sc.running_t_u32 = f32_as_u32(sc.running_t);
+        sc.cth = s->cth_px[u];
+        ContAcc acc{s, u};
+        const bool ok = s->abs_t ? cont_step<true>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em)
+                                 : cont_step<false>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em);
+        if (!ok) rc = -5;
+        s->c_hdr[u] = apx_hdr(p);
+        s->lastf[u] = p.lastf;
+        s->rt_px[u] += steps[i].time;
+        c_thresh_advance(s->cth_px[u], s->cctr_px[u], (uint8_t)s->c_max, (uint8_t)s->velocity, steps[i].time, s->ref_time);
+    }
+    *n_out = em.pos;
+    if (em.pos > cap && rc == 0) rc = -4;
+    return rc;
+}
 
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {

@@ -114,6 +114,18 @@ class Sim:
     def set_delta_t_max(self, dtm):
         self.L.sim_set_delta_t_max(self.h, dtm)
 
+    def integrate_sparse(self, steps):
+        """steps: array with the oracle's SPARSE_STEP_DTYPE layout; returns (rc, events)."""
+        steps = np.ascontiguousarray(steps)
+        cap = max(1024, len(steps) * 24)
+        out = np.zeros(cap, EVENT_DTYPE)
+        n = C.c_size_t(0)
+        self.L.sim_integrate_sparse.restype = C.c_int
+        self.L.sim_integrate_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_size_t)]
+        rc = self.L.sim_integrate_sparse(self.h, steps.ctypes.data, len(steps), out.ctypes.data, cap, C.byref(n))
+        return rc, out[: n.value].copy()
+
     def update_detect_features(self, detect, adjust, baseline, radius, chunk_rows=1):
         self.L.sim_update_detect_features(self.h, int(detect), int(adjust), baseline, radius, chunk_rows)
 

@@ -203,3 +203,52 @@ def test_continuous_mode_general_arena_step(multi_mode, time_mode):
             for k in range(len(clip)):
                 total += _same(ov, sv, clip[k], 255.0 if k % 7 else 510.0)
             assert total > 0 or kind == "static"
+
+
+def _sparse_steps(rng, W, H, Cn, n, *, hot=0.3):
+    """Steps of an event-camera source: a few hot pixels fire again and again, long and short spans, values around
+    and far from the previous one (base_val restarts at 0 for every call, so frame_val > c_thresh flushes)."""
+    st = np.zeros(n, O.SPARSE_STEP_DTYPE)
+    hotpx = rng.integers(0, W * H, max(2, int(W * H * 0.05)))
+    pix = np.where(rng.random(n) < hot, hotpx[rng.integers(0, len(hotpx), n)], rng.integers(0, W * H, n))
+    st["x"], st["y"] = pix % W, pix // W
+    st["c"] = 0xFF if Cn == 1 else rng.integers(0, Cn, n)
+    val = rng.choice(np.array([0, 1, 3, 9, 40, 128, 200, 255]), n)
+    span = rng.choice(np.array([1, 1, 1, 2, 5, 40, 700]), n)
+    st["frame_val"] = val
+    st["intensity"] = (val * span).astype(np.float32)
+    st["time"] = (span * 20).astype(np.float32)
+    return st
+
+
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_sparse_steps_of_event_camera_sources(multi_mode, time_mode):
+    """SURVEY 8(f)3, the sparse half: integrate_for_px(px, &mut 0, frame_val, intensity, time) pixel by pixel in the
+    order of a camera's events (prophesee.rs:170-258), after the two dense start-up frames of Prophesee::consume
+    (:117-131).  The device flow (cont_step with c_thresh, its counter and running_t per unit) on the host against
+    the oracle: every step's events, in order."""
+    rng = np.random.default_rng(7 * multi_mode + time_mode)
+    W, H = 11, 7
+    for Cn, crf in ((1, (7, 7)), (3, (0, 10))):
+        ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=20, delta_t_max=40)
+        ov.set_pixel_mode(1)
+        sv = Sim(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=20, delta_t_max=40, max_depth=24)
+        sv.set_continuous()
+        ov.ensure_capacity(30)
+        for v in (ov, sv):
+            v.set_crf_parameters(*crf)
+        start = np.full((H, W, Cn), 128, np.uint8)
+        for _ in range(2):
+            a = ov.integrate_matrix(start, time_spanned=20.0)
+            rc, b = sv.integrate(start, 20.0)
+            assert rc == 0 and np.array_equal(a, b)
+        total = 0
+        for k in range(6):
+            st = _sparse_steps(rng, W, H, Cn, 400)
+            a = ov.integrate_sparse(st)
+            rc, b = sv.integrate_sparse(st)
+            assert rc == 0, (k, rc)
+            assert len(a) == len(b) and np.array_equal(a, b), k
+            total += len(a)
+        assert total > 500

@@ -1057,3 +1057,54 @@ def test_graph_instances_are_interchangeable_and_the_plan_settles():
     offs = d_off.cpu().numpy()
     got = d_ev[: int(offs[8])].cpu().numpy().view(A.EVENT_DTYPE).reshape(-1)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_sparse_steps_of_event_camera_sources(multi_mode, time_mode):
+    """SURVEY 8(f)3, the sparse half (adder_hip_integrate_sparse: stable sort by pixel, a thread per pixel run with
+    cont_step and per-pixel c_thresh / running_t, scan of the counts in step order, scatter): the flow of
+    Prophesee::consume -- two dense start-up frames, then steps in the camera's order, hot pixels repeating inside a
+    call -- against the oracle, plus the side plane, the refusal of dense frames afterwards, and reset."""
+    from test_device_logic_cpu import _sparse_steps
+    A = _hip()
+    rng = np.random.default_rng(17 * multi_mode + time_mode)
+    for (W, H, Cn, crf, nsteps) in ((37, 23, 1, (7, 7), 3000), (130, 9, 3, (0, 10), 20000)):
+        ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=20, delta_t_max=40)
+        ov.set_pixel_mode(1)
+        hv = A.HipVideo(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=20, delta_t_max=40, max_depth=24,
+                        pixel_mode=1)
+        ov.ensure_capacity(30)
+        for v in (ov, hv):
+            v.set_crf_parameters(*crf)
+        hv.enable_running_intensities(True)
+        start = np.full((H, W, Cn), 128, np.uint8)
+        for _ in range(2):
+            assert np.array_equal(ov.integrate_matrix(start, time_spanned=20.0), hv.integrate_matrix(start, time_spanned=20.0))
+        total = 0
+        for k in range(4):
+            st = _sparse_steps(rng, W, H, Cn, nsteps)
+            a, b = ov.integrate_sparse(st), hv.integrate_sparse(st)
+            assert len(a) == len(b) and np.array_equal(a, b), k
+            total += len(a)
+        assert total > nsteps
+        assert np.array_equal(hv.running_intensities(), ov.running_intensities())
+        with pytest.raises(A.AdderHipError, match="dense frames after sparse"):
+            hv.integrate_matrix(start, time_spanned=20.0)
+        bad = _sparse_steps(rng, W, H, Cn, 10)
+        bad["x"][3] = W
+        hv2 = A.HipVideo(W, H, Cn, pixel_mode=1, ref_time=20, delta_t_max=40)
+        with pytest.raises(A.AdderHipError):
+            hv2.integrate_sparse(bad)
+        hv.reset()  # a fresh transcoder again: dense frames work, and so do sparse steps after them
+        ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=multi_mode, ref_time=20, delta_t_max=40)
+        ov.set_pixel_mode(1)
+        ov.ensure_capacity(30)
+        ov.set_crf_parameters(*crf)
+        assert np.array_equal(ov.integrate_matrix(start, time_spanned=20.0), hv.integrate_matrix(start, time_spanned=20.0))
+        st = _sparse_steps(rng, W, H, Cn, 500)
+        assert np.array_equal(ov.integrate_sparse(st), hv.integrate_sparse(st))
+    fp = A.HipVideo(16, 16, 1)
+    with pytest.raises(A.AdderHipError, match="Continuous"):
+        fp.integrate_sparse(_sparse_steps(rng, 16, 16, 1, 5))
