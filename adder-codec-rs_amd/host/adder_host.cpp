@@ -1,6 +1,8 @@
 // adder_host.cpp -- see adder_host.hpp.  Reference file:line citations are in the header.
 #include "adder_host.hpp"
 
+#include <cmath>
+
 #include "../../include/adder_compressed.h"
 
 #include <chrono>
@@ -547,6 +549,114 @@ std::vector<Event> Video::integrate_frames(const uint8_t *frames, uint32_t num_f
     encoder_->ingest_events(out.data(), n);
     if (frame_offsets) *frame_offsets = offs;
     return out;
+}
+
+std::vector<Event> Video::integrate_sparse(const std::vector<AdderSparseStep> &steps) {
+    ensure_ctx();
+    std::vector<Event> out(steps.size() * (size_t)(adder_hip_max_events_per_frame(ctx_) / plane_.volume() + 2));
+    size_t n = 0;
+    hip_check(ctx_, adder_hip_integrate_sparse(ctx_, steps.data(), steps.size(), out.data(), out.size(), &n));
+    out.resize(n);
+    encoder_->ingest_events(out.data(), n);
+    return out;
+}
+
+// ---------------------------------------------------------------- Prophesee (prophesee.rs)
+static void mid_clamp_u8(double &frame_val, double &last_val_ln) {  // utils/cv.rs:444-449
+    if (frame_val < 0.0 || frame_val > 255.0) {
+        frame_val = 128.0;
+        last_val_ln = std::log1p(128.0 / 255.0);
+    }
+}
+static uint8_t f64_as_u8(double v) { return !(v > 0.0) ? 0 : (v >= 255.0 ? 255 : (uint8_t)v); }  // `as u8`
+
+Prophesee::Prophesee(uint32_t ref_time, uint16_t width, uint16_t height, std::function<bool(DvsEvent &)> decode_event,
+                     int device_id)
+    : decode_event_(std::move(decode_event)), video_(PlaneSize(width, height, 1), nullptr, device_id, Mode::Continuous) {
+    video_.chunk_rows(1);
+    video_.time_parameters(ref_time * PROPHESEE_SOURCE_TPS, ref_time, ref_time * 2, TimeMode::AbsoluteT);
+    const size_t n = video_.plane().volume();
+    dvs_last_timestamps_.assign(n, 2u);
+    dvs_last_ln_val_.assign(n, std::log1p(128.0 / 255.0));
+}
+
+std::vector<std::vector<Event>> Prophesee::consume() {
+    const uint32_t ref_time = video_.get_ref_time();
+    const size_t W = video_.plane().w();
+    if (running_t_ == 0) {  // :117-131: two frames of the start intensities
+        const Frame start(video_.plane().volume(), 128);
+        video_.integrate_matrix(start, (float)ref_time);
+        size_t first = 0;
+        for (auto &v : video_.integrate_matrix(start, (float)ref_time)) first += v.size();
+        if (first != video_.plane().volume()) throw SourceError(SourceError::Codec, "assert_eq!(first_events.len(), volume)");
+        running_t_ = 2;
+    }
+    const uint32_t view_interval = PROPHESEE_SOURCE_TPS / 60;  // :136
+    std::vector<DvsEvent> dvs_events;
+    const uint32_t start_running_t = running_t_;
+    for (;;) {  // :142-168
+        DvsEvent e;
+        if (!decode_event_(e)) {
+            end_events();
+            throw SourceError(SourceError::NoData, "End of input file");
+        }
+        e.t -= t_subtract_;
+        if (e.t > running_t_) running_t_ = e.t;
+        dvs_events.push_back(e);
+        if (e.t > start_running_t + view_interval) break;
+    }
+    // :174-258 -- for every DVS event, the pixel's previous intensity over the time since its last event, then one
+    // source time unit of the new one
+    std::vector<AdderSparseStep> steps;
+    steps.reserve(dvs_events.size() * 2);
+    for (const DvsEvent &e : dvs_events) {
+        if (e.x >= W || e.y >= video_.plane().h()) throw SourceError(SourceError::BadParams, "DVS event outside the plane");
+        const size_t px = (size_t)e.y * W + e.x;
+        const uint32_t t = e.t, last_t = dvs_last_timestamps_[px];
+        if (t < last_t) continue;
+        double last_ln_val = dvs_last_ln_val_[px];
+        if (t > last_t + 1) {
+            double last_val = (std::exp(last_ln_val) - 1.0) * 255.0;
+            mid_clamp_u8(last_val, last_ln_val);
+            const uint32_t time_spanned = (t - last_t - 1) * ref_time;
+            const double intensity_to_integrate = last_val * (double)(t - last_t - 1);
+            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, f64_as_u8(last_val), 0, (float)intensity_to_integrate,
+                                            (float)time_spanned});
+        }
+        if (e.p > 1) throw SourceError(SourceError::BadParams, "Invalid polarity");
+        double new_ln_val = e.p == 0 ? last_ln_val - camera_theta_ : last_ln_val + camera_theta_;
+        dvs_last_ln_val_[px] = new_ln_val;
+        dvs_last_timestamps_[px] = t;
+        if (t > last_t) {
+            double new_val = (std::exp(new_ln_val) - 1.0) * 255.0;
+            mid_clamp_u8(new_val, new_ln_val);
+            dvs_last_ln_val_[px] = new_ln_val;
+            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, f64_as_u8(new_val), 0, (float)new_val, (float)ref_time});
+        }
+    }
+    // "just wrap the vec in another vec" (:302-304); Video::integrate_sparse has pushed them through the encoder (:308-312)
+    std::vector<std::vector<Event>> nested(1);
+    nested[0] = video_.integrate_sparse(steps);
+    return nested;
+}
+
+void Prophesee::end_events() {  // :332-372: every pixel's last intensity up to the end of the recording
+    const uint32_t ref_time = video_.get_ref_time();
+    const size_t W = video_.plane().w(), H = video_.plane().h();
+    std::vector<AdderSparseStep> steps;
+    steps.reserve(W * H);
+    for (size_t y = 0; y < H; ++y)
+        for (size_t x = 0; x < W; ++x) {
+            const size_t px = y * W + x;
+            const double last_val = (std::exp(dvs_last_ln_val_[px]) - 1.0) * 255.0;
+            if (!(running_t_ - dvs_last_timestamps_[px] > 0))
+                throw SourceError(SourceError::Codec, "assert!(running_t - dvs_last_timestamps > 0)");
+            const uint32_t time_spanned = (running_t_ - dvs_last_timestamps_[px]) * ref_time;
+            const double intensity_to_integrate = last_val * (double)time_spanned;
+            steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, f64_as_u8(last_val), 0,
+                                            (float)intensity_to_integrate, (float)time_spanned});
+        }
+    last_end_events_ = video_.integrate_sparse(steps);
 }
 
 // ---------------------------------------------------------------- Framed

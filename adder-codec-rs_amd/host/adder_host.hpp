@@ -230,6 +230,9 @@ class Video {
     // the same for T packed frames in one boundary call (events of all frames, frame-major)
     std::vector<Event> integrate_frames(const uint8_t *frames, uint32_t num_frames, float time_spanned,
                                         std::vector<uint64_t> *frame_offsets);
+    // what the event-camera sources do with their pixels: one `integrate_for_px(px, &mut 0, frame_val, intensity,
+    // time, &mut events, ..)` per step, in order (prophesee.rs:196-254); the events are also pushed through the encoder
+    std::vector<Event> integrate_sparse(const std::vector<AdderSparseStep> &steps);
 
   private:
     void ensure_ctx();  // (re)creates the device context once every builder call has been made
@@ -306,6 +309,43 @@ class Framed : public Source {  // framed.rs:22-39
     Frame input_frame_;
     bool color_input_;
     Video video_;
+};
+
+// ---------------------------------------------------------------- Prophesee (prophesee.rs:18-372)
+// The DVS-to-ADDER source.  The `.dat` reader (parse_header / decode_event, :374-452: file parsing) is replaced by a
+// provider of decoded events; the camera-side state -- last timestamp and log intensity per pixel -- lives here,
+// the pixels' arenas on the device.
+struct DvsEvent {  // :45-51
+    uint32_t t;
+    uint16_t x, y;
+    uint8_t p;
+};
+constexpr uint32_t PROPHESEE_SOURCE_TPS = 1000000;  // :22
+class Prophesee : public Source {
+  public:
+    // ::new :56-113 -- Video::new(plane, Continuous, None).chunk_rows(1).time_parameters(ref_time * 1e6, ref_time,
+    // ref_time * 2, Some(AbsoluteT)); running_intensities = 128, last timestamps = 2, last ln = ln_1p(128 / 255)
+    Prophesee(uint32_t ref_time, uint16_t width, uint16_t height, std::function<bool(DvsEvent &)> decode_event,
+              int device_id = -1);
+    std::vector<std::vector<Event>> consume() override;  // :116-330; throws SourceError::NoData at the end of the input
+    void crf(uint8_t crf) override { video_.update_crf(crf); }
+    Video &get_video_mut() override { return video_; }
+    const Video &get_video_ref() const override { return video_; }
+    const Frame *get_input() const override { return nullptr; }
+    double get_running_input_bitrate() const override { return 0.0; }
+
+    // the events end_events() produced when the input ran out (the reference only feeds them to the encoder)
+    const std::vector<Event> &last_end_events() const { return last_end_events_; }
+
+  private:
+    void end_events();  // :332-372
+    std::vector<Event> last_end_events_;
+    std::function<bool(DvsEvent &)> decode_event_;
+    Video video_;
+    uint32_t running_t_ = 0, t_subtract_ = 0;
+    std::vector<uint32_t> dvs_last_timestamps_;
+    std::vector<double> dvs_last_ln_val_;
+    double camera_theta_ = 0.02;  // "A fixed assumption" (:107)
 };
 
 // ---------------------------------------------------------------- framer (framer/driver.rs)

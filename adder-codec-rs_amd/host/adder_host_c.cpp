@@ -119,6 +119,50 @@ long long adder_host_transcode_features(const uint8_t *frames, uint32_t num_fram
     }
 }
 
+// Prophesee::new(ref_time, file) + consume() until the input runs out (prophesee.rs), with the decoded DVS events handed
+// over in memory instead of a `.dat` file: dvs = n records {t u32, x u16, y u16, p u8, pad u8}.  out receives the
+// events of every consume() in order, then those of end_events(); *n_consumes = consume() calls that returned events.
+long long adder_host_prophesee(const uint8_t *dvs, size_t n, uint16_t width, uint16_t height, uint32_t ref_time,
+                               AdderEvent *out, size_t cap, uint32_t *n_consumes) {
+    try {
+        size_t pos = 0;
+        auto decode = [&](DvsEvent &e) {
+            if (pos >= n) return false;
+            const uint8_t *r = dvs + pos * 10;
+            memcpy(&e.t, r, 4);
+            memcpy(&e.x, r + 4, 2);
+            memcpy(&e.y, r + 6, 2);
+            e.p = r[8];
+            ++pos;
+            return true;
+        };
+        Prophesee source(ref_time, width, height, decode);
+        long long total = 0;
+        uint32_t calls = 0;
+        auto take = [&](const std::vector<Event> &v) {
+            for (const Event &e : v) {
+                if ((size_t)total < cap) out[total] = e;
+                ++total;
+            }
+        };
+        for (;;) {
+            try {
+                for (auto &v : source.consume()) take(v);
+                ++calls;
+            } catch (const SourceError &err) {
+                if (err.kind != SourceError::NoData) throw;
+                take(source.last_end_events());
+                break;
+            }
+        }
+        if (n_consumes) *n_consumes = calls;
+        return total;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
                                    uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
                                    uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,

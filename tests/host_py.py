@@ -29,6 +29,9 @@ def lib():
         L.adder_host_transcode_features.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                                     C.c_float, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                                     C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p]
+        L.adder_host_prophesee.restype = C.c_longlong
+        L.adder_host_prophesee.argtypes = [C.c_void_p, C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p,
+                                           C.c_size_t, C.POINTER(C.c_uint32)]
         L.adder_host_decode_raw.restype = C.c_longlong
         L.adder_host_decode_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.adder_host_crf_parameters.restype = C.c_int
@@ -118,6 +121,22 @@ def transcode_features(frames, *, color_input=False, fps=30.0, crf=3, ref_time=2
     if n < 0:
         raise RuntimeError(err())
     return n, fs
+
+
+DVS_DTYPE = np.dtype([("t", "<u4"), ("x", "<u2"), ("y", "<u2"), ("p", "u1"), ("pad", "u1")])
+
+
+def prophesee(dvs, width, height, ref_time):
+    """Prophesee source of the C++ mirror over in-memory DVS events -> (all ADDER events in order, consume() calls)."""
+    dvs = np.ascontiguousarray(dvs, DVS_DTYPE)
+    cap = max(4096, (len(dvs) * 2 + 3 * width * height) * 8)
+    out = np.zeros(cap, adder_amd.EVENT_DTYPE)
+    calls = C.c_uint32(0)
+    n = lib().adder_host_prophesee(dvs.ctypes.data, len(dvs), width, height, ref_time, out.ctypes.data, cap, C.byref(calls))
+    if n < 0:
+        raise RuntimeError(err())
+    assert n <= cap
+    return out[:n].copy(), calls.value
 
 
 def transcode_compressed(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, delta_t_max=7650, time_mode=1,

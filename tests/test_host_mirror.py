@@ -183,3 +183,100 @@ def test_decoder_new_compressed_reads_what_the_compressed_encoder_wrote():
         assert int(meta[8]) >> 8 == 1 and len(ev2) == len(dec) > 0 and np.array_equal(ev2, dec)
     with pytest.raises(AssertionError):
         Hst.decode_raw(b"addec" + bytes(3))  # a truncated header is an error, not a crash
+
+
+def _prophesee_restatement(dvs, W, H, ref_time):
+    """Prophesee::new + consume() until the input ends + end_events (prophesee.rs:56-372), restated over the oracle's
+    Continuous Video and its sparse driver.  f64 exp / ln_1p are libm's on both sides."""
+    import math
+    from oracle import oracle as O
+    v = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=2 * ref_time)
+    v.set_pixel_mode(1)
+    v.ensure_capacity(40)
+    v.set_crf_parameters(7, 7)  # EncoderOptions::default -> quality 3 (the pixels keep PixelArena::new's 10 / 1)
+    last_t = np.full(W * H, 2, np.int64)
+    last_ln = np.full(W * H, math.log1p(128.0 / 255.0))
+    theta, view = 0.02, 1000000 // 60
+    out, running_t, pos, calls = [], 0, 0, 0
+
+    def as_u8(x):
+        return 0 if not x > 0.0 else (255 if x >= 255.0 else int(x))
+
+    def step(x, y, val, intensity, time):
+        return (x, y, 0xFF, as_u8(val), 0, np.float32(intensity), np.float32(time))
+
+    while True:
+        if running_t == 0:
+            start = np.full((H, W, 1), 128, np.uint8)
+            v.integrate_matrix(start, time_spanned=float(ref_time))
+            assert len(v.integrate_matrix(start, time_spanned=float(ref_time))) == W * H
+            running_t = 2
+        batch, start_t, ended = [], running_t, False
+        while True:
+            if pos >= len(dvs):
+                ended = True
+                break
+            e = dvs[pos]
+            pos += 1
+            running_t = max(running_t, int(e["t"]))
+            batch.append(e)
+            if int(e["t"]) > start_t + view:
+                break
+        if ended:
+            steps = []
+            for y in range(H):
+                for x in range(W):
+                    p = y * W + x
+                    val = (math.exp(last_ln[p]) - 1.0) * 255.0
+                    assert running_t - last_t[p] > 0
+                    span = (running_t - int(last_t[p])) * ref_time
+                    steps.append(step(x, y, val, val * float(span), span))
+            out.append(v.integrate_sparse(np.array(steps, O.SPARSE_STEP_DTYPE)))
+            break
+        steps = []
+        for e in batch:
+            x, y, t = int(e["x"]), int(e["y"]), int(e["t"])
+            p = y * W + x
+            if t < last_t[p]:
+                continue
+            ln = last_ln[p]
+            if t > last_t[p] + 1:
+                val = (math.exp(ln) - 1.0) * 255.0
+                if val < 0.0 or val > 255.0:
+                    val, ln = 128.0, math.log1p(128.0 / 255.0)
+                gap = t - int(last_t[p]) - 1
+                steps.append(step(x, y, val, val * float(gap), gap * ref_time))
+            new_ln = ln - theta if int(e["p"]) == 0 else ln + theta
+            last_ln[p] = new_ln
+            was = int(last_t[p])
+            last_t[p] = t
+            if t > was:
+                val = (math.exp(new_ln) - 1.0) * 255.0
+                if val < 0.0 or val > 255.0:
+                    val, new_ln = 128.0, math.log1p(128.0 / 255.0)
+                last_ln[p] = new_ln
+                steps.append(step(x, y, val, val, ref_time))
+        out.append(v.integrate_sparse(np.array(steps, O.SPARSE_STEP_DTYPE)) if steps else np.zeros(0, O.EVENT_DTYPE))
+        calls += 1
+    return np.concatenate(out), calls
+
+
+@pytest.mark.gpu
+def test_prophesee_source_dvs_events_to_adder(tmp_path):
+    """SURVEY 8(f)3 end to end through the C++ mirror: a DVS recording (decoded events; the `.dat` reader is file
+    parsing and not built) -> Prophesee::consume per 1/60 s of camera time -> sparse steps on the device
+    (adder_hip_integrate_sparse) -> ADDER events, then end_events.  Against a restatement of the same driver over the
+    oracle.  The driver itself has no reference vector: oracle parity."""
+    rng = np.random.default_rng(12)
+    W, H, n = 46, 30, 60000
+    dvs = np.zeros(n, Hst.DVS_DTYPE)
+    dvs["t"] = np.sort(rng.integers(3, 200000, n))  # 0.2 s of camera time: a dozen consume() calls
+    hot = rng.integers(0, W * H, 40)
+    pix = np.where(rng.random(n) < 0.5, hot[rng.integers(0, 40, n)], rng.integers(0, W * H, n))
+    dvs["x"], dvs["y"] = pix % W, pix // W
+    dvs["p"] = rng.integers(0, 2, n)
+    dvs["t"][100:140] = dvs["t"][100]  # a burst with one timestamp: t == last_t skips the new-intensity step
+    got, calls = Hst.prophesee(dvs, W, H, 20)
+    want, want_calls = _prophesee_restatement(dvs, W, H, 20)
+    assert calls == want_calls >= 10
+    assert len(got) == len(want) > n and np.array_equal(got, want)
