@@ -725,8 +725,7 @@ std::unique_ptr<FrameSequenceU8> FramerBuilder::finish() { return std::make_uniq
 
 FrameSequenceU8::FrameSequenceU8(const FramerBuilder &b) : chunk_rows(b.chunk_rows_) {
     if (b.chunk_rows_ == 0) throw SourceError(SourceError::BadParams, "chunk_rows must be > 0");  // assert (:306)
-    if (b.mode_ != FramerMode::INSTANTANEOUS)
-        throw SourceError(SourceError::BadParams, "only FramerMode::INSTANTANEOUS is built");
+    (void)b.mode_;  // driver.rs:270,383: stored and never read, INTEGRATION ingests like INSTANTANEOUS
     AdderFramerParams p;
     adder_framer_default_params(&p, b.plane_.w(), b.plane_.h(), b.plane_.c());
     p.codec_version = b.codec_version_;
@@ -737,10 +736,18 @@ FrameSequenceU8::FrameSequenceU8(const FramerBuilder &b) : chunk_rows(b.chunk_ro
     p.output_fps = b.output_fps_ ? *b.output_fps_ : 0.0f;
     p.source_camera = (uint32_t)b.source_camera_;
     p.device_id = b.device_id_ < 0 ? 0 : b.device_id_;
+    p.ring_frames = b.ring_frames_;
+    p.view_mode = (uint8_t)b.view_mode_;
+    p.source_type = (uint8_t)b.source_type_;
+    p.practical_d_max = b.practical_d_max_ ? *b.practical_d_max_
+                                           : std::log2f(255.0f * (float)(b.delta_t_max_ / (b.ref_interval_ ? b.ref_interval_ : 1u)));
     if (adder_framer_create(&p, &fr_) != ADDER_OK)
         throw SourceError(SourceError::BadParams, std::string("framer: ") + adder_framer_last_error(nullptr));
     num_chunks_ = (b.plane_.h() + b.chunk_rows_ - 1) / b.chunk_rows_;
     frame_bytes_ = (size_t)b.plane_.w() * b.plane_.h() * b.plane_.c();
+    width_ = b.plane_.w();
+    height_ = b.plane_.h();
+    channels_ = b.plane_.c();
 }
 
 FrameSequenceU8::~FrameSequenceU8() { adder_framer_destroy(fr_); }
@@ -768,9 +775,26 @@ bool FrameSequenceU8::ingest_events_events(const std::vector<std::vector<Event>>
     if (events.size() != num_chunks_) throw SourceError(SourceError::BadParams, "events.len() != number of framer chunks");
     flat_.clear();
     for (const auto &v : events) flat_.insert(flat_.end(), v.begin(), v.end());
-    // one source frame's events: raster order, every pixel's events contiguous = one segment
-    const uint64_t offs[2] = {0, flat_.size()};
-    framer_check(fr_, adder_framer_ingest(fr_, flat_.data(), offs, 1));
+    // The device wants segments in which a pixel-channel's events are contiguous.  One source frame's events (what
+    // SimulProcessor hands over) are one such segment; any other list is cut where a pixel comes back.
+    seg_offs_.assign(1, 0);
+    seen_.assign(frame_bytes_, 0xffffffffu);
+    uint32_t seg = 0;
+    size_t prev = SIZE_MAX;
+    for (size_t i = 0; i < flat_.size(); ++i) {
+        const Event &e = flat_[i];
+        const size_t ch = e.c == 0xff ? 0 : e.c;
+        if (e.x >= width_ || e.y >= height_ || ch >= channels_) continue;  // reported by the device
+        const size_t u = ((size_t)e.y * width_ + e.x) * channels_ + ch;
+        if (u != prev && seen_[u] == seg) {
+            seg_offs_.push_back(i);
+            ++seg;
+        }
+        seen_[u] = seg;
+        prev = u;
+    }
+    seg_offs_.push_back(flat_.size());
+    framer_check(fr_, adder_framer_ingest(fr_, flat_.data(), seg_offs_.data(), (uint32_t)seg_offs_.size() - 1));
     return is_frame_0_filled();
 }
 

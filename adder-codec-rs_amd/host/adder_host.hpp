@@ -349,8 +349,9 @@ class Prophesee : public Source {
 };
 
 // ---------------------------------------------------------------- framer (framer/driver.rs)
-enum class FramerMode { INSTANTANEOUS, INTEGRATION };  // driver.rs:20-28; only INSTANTANEOUS is built
-enum class SourceType { U8 };                          // lib.rs; only U8 is built
+enum class FramerMode { INSTANTANEOUS, INTEGRATION };  // driver.rs:20-28; stored, never read by the reference's ingest: both behave alike
+enum class SourceType { U8, U16, U32, U64 };           // what the Intensity view divides by (scale_intensity.rs:68-75); F32 / F64 panic there
+enum class FramedViewMode { Intensity, D, DeltaT, SAE };  // video.rs:144-158
 
 class FrameSequenceU8;
 
@@ -363,9 +364,16 @@ class FramerBuilder {  // driver.rs:36-147
         return *this;
     }
     FramerBuilder &mode(FramerMode m) { mode_ = m; return *this; }                                   // :98-102
-    FramerBuilder &source(SourceType, SourceCamera cam) { source_camera_ = cam; return *this; }     // :110-115
+    FramerBuilder &view_mode(FramedViewMode v) { view_mode_ = v; return *this; }                      // :104-108
+    FramerBuilder &source(SourceType t, SourceCamera cam) { source_type_ = t; source_camera_ = cam; return *this; }  // :110-115
+    // D view only: the reference divides by fast_math::log2_raw(255 * (delta_t_max / ref_interval) as f32) (:1020-1021),
+    // a third-party approximation of log2; a caller that wants the reference's bytes passes that crate's value, the
+    // default is the exact log2f
+    FramerBuilder &practical_d_max(float v) { practical_d_max_ = v; return *this; }
     FramerBuilder &codec_version(uint8_t v, TimeMode tm) { codec_version_ = v; time_mode_ = tm; return *this; }  // :117-124
     FramerBuilder &device(int device_id) { device_id_ = device_id; return *this; }
+    // frames the device ring holds (the reference's VecDeque grows without bound, :1066-1090); 0 = delta_t_max / tpf + 80
+    FramerBuilder &ring_frames(uint32_t n) { ring_frames_ = n; return *this; }
     std::unique_ptr<FrameSequenceU8> finish();  // :126-138, T = u8
 
   private:
@@ -375,10 +383,14 @@ class FramerBuilder {  // driver.rs:36-147
     uint32_t tps_ = 150000, ref_interval_ = 5000, delta_t_max_ = 5000;  // FramerBuilder::new defaults (:60-65)
     std::optional<float> output_fps_;
     FramerMode mode_ = FramerMode::INSTANTANEOUS;
+    FramedViewMode view_mode_ = FramedViewMode::Intensity;
+    SourceType source_type_ = SourceType::U8;
+    std::optional<float> practical_d_max_;
     SourceCamera source_camera_ = SourceCamera::FramedU8;
     uint8_t codec_version_ = 3;
     TimeMode time_mode_ = TimeMode::AbsoluteT;
     int device_id_ = -1;
+    uint32_t ring_frames_ = 0;
 };
 
 // FrameSequence<u8> (driver.rs:261-981); the per-pixel work runs behind include/adder_framer.h
@@ -401,7 +413,10 @@ class FrameSequenceU8 {
   private:
     AdderFramer *fr_ = nullptr;
     size_t num_chunks_ = 0, frame_bytes_ = 0;
+    size_t width_ = 0, height_ = 0, channels_ = 0;
     std::vector<Event> flat_;
+    std::vector<uint64_t> seg_offs_;
+    std::vector<uint32_t> seen_;
     std::vector<uint8_t> out_;
 };
 

@@ -218,6 +218,42 @@ long long adder_host_simulproc(const uint8_t *frames, uint32_t num_frames, uint3
     }
 }
 
+// FramerBuilder -> FrameSequence<u8> over events in memory: one ingest_events_events call (chunk_offsets has
+// n_chunks + 1 entries, the framer's chunk division), write_multi_frame_bytes, then `flushes` rounds of
+// flush_frame_buffer + write_frame_bytes.  params = {tps, ref_interval, delta_t_max, codec_version, time_mode,
+// framer mode, view mode, source type, chunk_rows}.  Returns the bytes written to out (needs <= cap), or -1.
+long long adder_host_frame_events(const AdderEvent *events, const uint64_t *chunk_offsets, uint32_t n_chunks,
+                                  uint16_t width, uint16_t height, uint8_t channels, const uint32_t *params,
+                                  float output_fps, float practical_d_max, uint32_t flushes, uint8_t *out, size_t cap) {
+    try {
+        PlaneSize plane(width, height, channels);
+        FramerBuilder b(plane, params[8]);
+        b.time_parameters(params[0], params[1], params[2], output_fps > 0.0f ? std::optional<float>(output_fps) : std::nullopt)
+            .codec_version((uint8_t)params[3], (TimeMode)params[4])
+            .mode((FramerMode)params[5])
+            .view_mode((FramedViewMode)params[6])
+            .source((SourceType)params[7], SourceCamera::FramedU8)
+            .ring_frames(1u << 14);
+        if (practical_d_max > 0.0f) b.practical_d_max(practical_d_max);
+        auto fr = b.finish();
+        std::vector<std::vector<Event>> chunks(n_chunks);
+        for (uint32_t k = 0; k < n_chunks; ++k) chunks[k].assign(events + chunk_offsets[k], events + chunk_offsets[k + 1]);
+        std::ostringstream os;
+        if (fr->ingest_events_events(chunks)) fr->write_multi_frame_bytes(os);
+        for (uint32_t i = 0; i < flushes; ++i) {
+            fr->flush_frame_buffer();
+            fr->write_frame_bytes(os);
+        }
+        const std::string bytes = os.str();
+        if (bytes.size() > cap) throw SourceError(SourceError::BadParams, "output buffer too small");
+        memcpy(out, bytes.data(), bytes.size());
+        return (long long)bytes.size();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 // Decoder over a raw stream in memory: fills meta[10] = {version, width, height, channels, tps,
 // ref_interval, delta_t_max, event_size, source_camera|time_mode<<8, adu_interval} and up to cap
 // events; returns the number of events in the stream, or -1.

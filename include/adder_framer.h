@@ -1,6 +1,6 @@
-/* adder_framer.h -- C-ABI of the MI355X-native instantaneous framer (ADDER events -> u8 frames).
+/* adder_framer.h -- C-ABI of the MI355X-native framer (ADDER events -> u8 frames).
  *
- * Replaces, for T = u8 / FramerMode::INSTANTANEOUS / FramedViewMode::Intensity / SourceType::U8, the
+ * Replaces, for T = u8, the
  * reference's FrameSequence<u8> (adder-codec-rs/src/framer/driver.rs):
  *   FramerBuilder::new / time_parameters / codec_version / source / finish   driver.rs:55-138
  *   Framer::ingest_event / ingest_events_events                               driver.rs:437-626 (+ :984-1133)
@@ -13,8 +13,11 @@
  * every pixel has a value in it, and each (pixel, frame) is written once), so this ABI ingests whole
  * batches and pops complete frames afterwards; the bytes equal the reference's output stream.
  *
- * Not built: FramerMode::INTEGRATION, the D / DeltaT / SAE views, u16/u32/u64/EventCoordless
- * frame values, feature detection, buffer_limit.
+ * Views: every arm of <u8 as FrameValue>::get_frame_value (scale_intensity.rs:54-109) -- Intensity for U8 / U16 /
+ * U32 / U64 sources, D, DeltaT, SAE -- through view_mode / source_type below.  FramerMode::INTEGRATION needs no
+ * switch: the reference stores the mode (driver.rs:270, 383) and never reads it, both modes ingest alike.
+ * Not built: u16/u32/u64/EventCoordless frame element types (the reference's own writers and tests use u8),
+ * feature detection on frames, buffer_limit.
  */
 #ifndef ADDER_FRAMER_H
 #define ADDER_FRAMER_H

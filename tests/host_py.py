@@ -32,6 +32,9 @@ def lib():
         L.adder_host_prophesee.restype = C.c_longlong
         L.adder_host_prophesee.argtypes = [C.c_void_p, C.c_size_t, C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p,
                                            C.c_size_t, C.POINTER(C.c_uint32)]
+        L.adder_host_frame_events.restype = C.c_longlong
+        L.adder_host_frame_events.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint8,
+                                              C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_size_t]
         L.adder_host_decode_raw.restype = C.c_longlong
         L.adder_host_decode_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.adder_host_crf_parameters.restype = C.c_int
@@ -137,6 +140,22 @@ def prophesee(dvs, width, height, ref_time):
         raise RuntimeError(err())
     assert n <= cap
     return out[:n].copy(), calls.value
+
+
+def frame_events(events, chunk_offsets, width, height, channels, *, tps, ref_interval, delta_t_max, codec_version,
+                 time_mode, chunk_rows, output_fps=0.0, framer_mode=0, view_mode=0, source_type=0, practical_d_max=0.0,
+                 flushes=0, cap=1 << 26):
+    """FramerBuilder ... finish() -> ingest_events_events -> write_multi_frame_bytes (+ flushes) of the C++ mirror."""
+    ev = np.ascontiguousarray(events, adder_amd.EVENT_DTYPE)
+    offs = np.ascontiguousarray(chunk_offsets, np.uint64)
+    params = np.array([tps, ref_interval, delta_t_max, codec_version, time_mode, framer_mode, view_mode, source_type,
+                       chunk_rows], np.uint32)
+    out = np.zeros(cap, np.uint8)
+    n = lib().adder_host_frame_events(ev.ctypes.data, offs.ctypes.data, len(offs) - 1, width, height, channels,
+                                      params.ctypes.data, output_fps, practical_d_max, flushes, out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError(err())
+    return out[:n].tobytes()
 
 
 def transcode_compressed(frames, *, color_input=False, fps=30.0, crf=-1, ref_time=255, delta_t_max=7650, time_mode=1,

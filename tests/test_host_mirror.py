@@ -280,3 +280,33 @@ def test_prophesee_source_dvs_events_to_adder(tmp_path):
     want, want_calls = _prophesee_restatement(dvs, W, H, 20)
     assert calls == want_calls >= 10
     assert len(got) == len(want) > n and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("view,source,dmax,mode", [(0, 0, 0.0, 1), (1, 0, 12.99, 0), (2, 0, 0.0, 0), (3, 0, 0.0, 1), (0, 1, 0.0, 0)])
+def test_framer_builder_views_and_integration_mode(view, source, dmax, mode):
+    """FramerBuilder::mode / view_mode / source of the C++ mirror (driver.rs:98-115): FramerMode::INTEGRATION is stored
+    and never read by the reference, so it must frame exactly like INSTANTANEOUS; the views go through
+    get_frame_value (scale_intensity.rs:54-109).  ingest_events_events + write_multi_frame_bytes + 3 flushes against
+    the framer oracle on the same chunk division."""
+    from oracle import oracle as O
+    from test_gpu_framer import _synthetic_stream
+    rng = np.random.default_rng(40 + view + source)
+    W, H, T, rows = 45, 31, 40, 8
+    ev, _ = _synthetic_stream(rng, W, H, 1, T, abs_t=True, density=0.7)
+    ev = ev.view(O.EVENT_DTYPE) if ev.dtype != O.EVENT_DTYPE else ev
+    chunk = ev["y"].astype(np.int64) // rows
+    order = np.argsort(chunk, kind="stable")
+    ev = ev[order]
+    n_chunks = (H + rows - 1) // rows
+    offs = np.searchsorted(chunk[order], np.arange(n_chunks + 1)).astype(np.uint64)
+    kw = dict(tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3)
+    ofr = O.Framer(W, H, 1, chunk_rows=rows, time_mode=O.ABSOLUTE_T, source_camera=O.FRAMED_U8, **kw)
+    ofr.set_view(view, source, dmax)
+    want = ofr.write_multi_frame_bytes() if ofr.ingest_events_events(ev, offs) else b""
+    for _ in range(3):
+        ofr.flush_frame_buffer()
+        want += ofr.write_frame_bytes()
+    got = Hst.frame_events(ev, offs, W, H, 1, time_mode=1, chunk_rows=rows, framer_mode=mode, view_mode=view,
+                           source_type=source, practical_d_max=dmax, flushes=3, **kw)
+    assert len(want) > 20 * W * H and got == want
