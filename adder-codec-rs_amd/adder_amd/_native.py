@@ -179,6 +179,7 @@ SYMBOLS = {
     "adder_framer_frames_written": (C.c_int64, [_vp]),
     "adder_framer_ingest_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "adder_framer_ingest_frames_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "adder_framer_ingest_frames_device_offsets": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "adder_framer_ingest": (_i32, [_vp, _vp, _vp, _u32]),
     "adder_framer_frames_ready": (_i32, [_vp, C.POINTER(_u32)]),
     "adder_framer_pop_device": (_i32, [_vp, _vp, _u32, C.POINTER(_u32), _vp]),

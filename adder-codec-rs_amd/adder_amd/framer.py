@@ -72,6 +72,12 @@ class HipFramer:
         N.check_framer(self.h, self.L.adder_framer_ingest_frames_device(
             self.h, d_events.data_ptr(), offs.ctypes.data, len(offs) - 1, C.c_void_p(stream) if stream else None))
 
+    def ingest_frames_device_offsets(self, d_events, d_frame_offsets, num_frames, stream=None):
+        """The same with the frame offsets where integrate_device left them (int64 / uint64 CUDA tensor of
+        num_frames + 1 entries): nothing crosses the bus, the call only queues."""
+        N.check_framer(self.h, self.L.adder_framer_ingest_frames_device_offsets(
+            self.h, d_events.data_ptr(), d_frame_offsets.data_ptr(), num_frames, C.c_void_p(stream) if stream else None))
+
     def frames_ready(self):
         n = C.c_uint32(0)
         N.check_framer(self.h, self.L.adder_framer_frames_ready(self.h, C.byref(n)))

@@ -18,6 +18,9 @@ using namespace adder;
 
 static thread_local std::string g_framer_create_error;
 
+constexpr uint32_t kOffsSlots = 4;
+constexpr size_t kOffsSlotEntries = (size_t)kFramerRowsMaxFrames + 1u;
+
 struct AdderFramer {
     AdderFramerParams p{};
     int device = 0;
@@ -33,7 +36,11 @@ struct AdderFramer {
     size_t d_out_cap = 0;
     uint64_t *d_offs = nullptr;  // device copy of the frame offsets of adder_framer_ingest_frames_device
     size_t d_offs_cap = 0;
-    uint64_t *h_offs = nullptr;  // pinned staging of the same
+    uint64_t *h_offs = nullptr;  // pinned staging of the same: kOffsSlots slots of kOffsSlotEntries, used in turn
+    hipEvent_t h_offs_done[4] = {nullptr, nullptr, nullptr, nullptr};  // ... each free again once its copy has run
+    bool h_offs_busy[4] = {false, false, false, false};
+    uint32_t h_offs_next = 0;
+    uint64_t *h_offs_big = nullptr;  // batches of more frames than a slot holds (synchronous path)
     size_t h_offs_cap = 0;
     uint64_t *d_tile_off = nullptr;  // [frames of a launch][tiles + 1] slice offsets (adder_framer_slices_kernel)
     size_t d_tile_off_cap = 0;
@@ -75,6 +82,9 @@ static void framer_free(AdderFramer *fr) {
                     (void *)fr->minmax, (void *)fr->d_events, (void *)fr->d_out, (void *)fr->d_offs, (void *)fr->d_tile_off})
         if (p) (void)hipFree(p);
     if (fr->h_offs) (void)hipHostFree(fr->h_offs);
+    if (fr->h_offs_big) (void)hipHostFree(fr->h_offs_big);
+    for (hipEvent_t e : fr->h_offs_done)
+        if (e) (void)hipEventDestroy(e);
     if (fr->ingested) (void)hipEventDestroy(fr->ingested);
     if (fr->stream) (void)hipStreamDestroy(fr->stream);
     delete fr;
@@ -150,6 +160,15 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->ring), (size_t)fr->ring_frames * fr->n_units));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->status), sizeof(uint32_t)));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->minmax), 2 * sizeof(int32_t)));
+        // everything a batch of <= 64 frames needs exists from here on (longer ones grow the slice table once): an
+        // ingest call neither allocates nor waits for the device
+        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->d_offs), kOffsSlotEntries * sizeof(uint64_t)));
+        fr->d_offs_cap = kOffsSlotEntries * sizeof(uint64_t);
+        fr->d_tile_off_cap = (size_t)std::min(kFramerRowsMaxFrames, 64u) * (adder_framer_num_tiles(fr->n_units) + 1u) * sizeof(uint64_t);
+        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->d_tile_off), fr->d_tile_off_cap));
+        FHIPCHK(fr, hipHostMalloc(reinterpret_cast<void **>(&fr->h_offs), kOffsSlots * kOffsSlotEntries * sizeof(uint64_t),
+                                  hipHostMallocDefault));
+        for (hipEvent_t &e : fr->h_offs_done) FHIPCHK(fr, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         FHIPCHK(fr, hipMemsetAsync(fr->status, 0, sizeof(uint32_t), fr->stream));
         FHIPCHK(fr, hipMemsetAsync(fr->ring, 0, (size_t)fr->ring_frames * fr->n_units, fr->stream));
         FHIPCHK(fr, adder_framer_launch_init(fr->px, fr->n_units, fr->stream));
@@ -254,6 +273,9 @@ extern "C" int adder_framer_ingest_device(AdderFramer *fr, const AdderEvent *d_e
     return mark_op(fr, (hipStream_t)stream);
 }
 
+static int ingest_frames_launch(AdderFramer *fr, const AdderEvent *d_events, const uint64_t *d_offs, uint32_t num_frames,
+                                hipStream_t s);
+
 extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEvent *d_events,
                                                  const uint64_t *frame_offsets, uint32_t num_frames, void *stream) {
     if (!fr) return ADDER_E_BAD_PARAMS;
@@ -273,19 +295,51 @@ extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEve
     const size_t bytes = ((size_t)num_frames + 1) * sizeof(uint64_t);
     int rc = fensure(fr, &fr->d_offs, &fr->d_offs_cap, bytes);
     if (rc != ADDER_OK) return rc;
-    if (fr->h_offs_cap < bytes) {
-        // the staging buffer may still feed an earlier asynchronous copy
-        FHIPCHK(fr, hipStreamSynchronize(s));
-        if (fr->h_offs) FHIPCHK(fr, hipHostFree(fr->h_offs));
-        fr->h_offs = nullptr;
-        fr->h_offs_cap = 0;
-        FHIPCHK(fr, hipHostMalloc(reinterpret_cast<void **>(&fr->h_offs), bytes, hipHostMallocDefault));
-        fr->h_offs_cap = bytes;
+    if (num_frames + 1u <= kOffsSlotEntries) {
+        // pinned staging slots in turn: a slot is reused four calls later, when its copy has long run
+        const uint32_t slot = fr->h_offs_next;
+        fr->h_offs_next = (slot + 1u) % kOffsSlots;
+        if (fr->h_offs_busy[slot]) FHIPCHK(fr, hipEventSynchronize(fr->h_offs_done[slot]));
+        uint64_t *stage = fr->h_offs + (size_t)slot * kOffsSlotEntries;
+        memcpy(stage, frame_offsets, bytes);
+        FHIPCHK(fr, hipMemcpyAsync(fr->d_offs, stage, bytes, hipMemcpyHostToDevice, s));
+        FHIPCHK(fr, hipEventRecord(fr->h_offs_done[slot], s));
+        fr->h_offs_busy[slot] = true;
     } else {
-        FHIPCHK(fr, hipStreamSynchronize(s));  // (same reason; the copy is tiny)
+        FHIPCHK(fr, hipStreamSynchronize(s));  // the big staging buffer may still feed an earlier copy
+        if (fr->h_offs_cap < bytes) {
+            if (fr->h_offs_big) FHIPCHK(fr, hipHostFree(fr->h_offs_big));
+            fr->h_offs_big = nullptr;
+            fr->h_offs_cap = 0;
+            FHIPCHK(fr, hipHostMalloc(reinterpret_cast<void **>(&fr->h_offs_big), bytes, hipHostMallocDefault));
+            fr->h_offs_cap = bytes;
+        }
+        memcpy(fr->h_offs_big, frame_offsets, bytes);
+        FHIPCHK(fr, hipMemcpyAsync(fr->d_offs, fr->h_offs_big, bytes, hipMemcpyHostToDevice, s));
     }
-    memcpy(fr->h_offs, frame_offsets, bytes);
-    FHIPCHK(fr, hipMemcpyAsync(fr->d_offs, fr->h_offs, bytes, hipMemcpyHostToDevice, s));
+    return ingest_frames_launch(fr, d_events, fr->d_offs, num_frames, s);
+}
+
+// frame_offsets in device memory (what adder_hip_integrate_device leaves there): nothing crosses the bus, the
+// transcoder's batch and its framing queue back to back.  The offsets are checked on the device.
+extern "C" int adder_framer_ingest_frames_device_offsets(AdderFramer *fr, const AdderEvent *d_events,
+                                                         const uint64_t *d_frame_offsets, uint32_t num_frames,
+                                                         void *stream) {
+    if (!fr) return ADDER_E_BAD_PARAMS;
+    if (fr->poisoned) return ffail(fr, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", fr->err.c_str());
+    if (fr->flushed_pending) return ffail(fr, ADDER_E_BAD_PARAMS, "pop the flushed frame before ingesting more events");
+    if (!num_frames) return ADDER_OK;
+    if (!d_frame_offsets || !d_events) return ffail(fr, ADDER_E_BAD_PARAMS, "null argument");
+    FHIPCHK(fr, hipSetDevice(fr->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = after_last_op(fr, s);
+    if (rc != ADDER_OK) return rc;
+    return ingest_frames_launch(fr, d_events, d_frame_offsets, num_frames, s);
+}
+
+static int ingest_frames_launch(AdderFramer *fr, const AdderEvent *d_events, const uint64_t *d_offs, uint32_t num_frames,
+                                hipStream_t s) {
+    int rc;
     const FramerArgs a = make_args(fr);
     const uint32_t per_launch = std::min(kFramerRowsMaxFrames, num_frames);
     rc = fensure(fr, &fr->d_tile_off, &fr->d_tile_off_cap,
@@ -293,7 +347,7 @@ extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEve
     if (rc != ADDER_OK) return rc;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += kFramerRowsMaxFrames) {
         const uint32_t nf = std::min(kFramerRowsMaxFrames, num_frames - f0);
-        FHIPCHK(fr, adder_framer_launch_tiles(d_events, fr->d_offs + f0, nf, fr->d_tile_off, fr->window_rows, &a, s));
+        FHIPCHK(fr, adder_framer_launch_tiles(d_events, d_offs + f0, nf, fr->d_tile_off, fr->window_rows, &a, s));
     }
     return mark_op(fr, s);
 }

@@ -136,7 +136,12 @@ __global__ __launch_bounds__(256) void adder_framer_slices_kernel(const uint32_t
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= (uint64_t)T * (ntiles + 1u)) return;
     const uint32_t f = (uint32_t)(idx / (ntiles + 1u)), tile = (uint32_t)(idx % (ntiles + 1u));
-    const uint64_t b0 = seg_offsets[f], b1 = seg_offsets[f + 1];
+    const uint64_t b0 = seg_offsets[f];
+    uint64_t b1 = seg_offsets[f + 1];
+    if (b1 < b0) {  // offsets that live on the device are first looked at here
+        if (tile == 0u) atomicOr(a.status, kFramerStatusMalformed);
+        b1 = b0;
+    }
     // (an interpolated start + galloping was tried: slower, events cluster where the picture moves)
     tile_off[idx] = tile == 0u ? b0 : tile == ntiles ? b1 : framer_lower_bound_unit(ev, b0, b1, tile * kTileUnits, a);
 }
@@ -319,7 +324,11 @@ struct FramerCursor {  // wave-uniform: frame f of the group, its slice [lo, hi)
     uint64_t lo, hi, base;
 };
 
-__global__ __launch_bounds__(64) void adder_framer_tiles_kernel(const uint32_t *__restrict__ ev,
+#ifndef ADDER_FRAMER_WAVES
+#define ADDER_FRAMER_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ADDER_FRAMER_WAVES, ADDER_FRAMER_WAVES)))
+void adder_framer_tiles_kernel(const uint32_t *__restrict__ ev,
                                                                 const uint64_t *__restrict__ tile_off, uint32_t T,
                                                                 uint32_t ntiles, uint32_t K, FramerArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];

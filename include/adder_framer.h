@@ -86,6 +86,12 @@ int adder_framer_ingest(AdderFramer *fr, const AdderEvent *events, const uint64_
 int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEvent *d_events, const uint64_t *frame_offsets,
                                       uint32_t num_frames, void *stream);
 
+/* The same with frame_offsets in DEVICE memory (where adder_hip_integrate_device leaves them): the transcoder's batch
+ * and its framing queue back to back on one stream, nothing crosses the bus and the host does not wait.  Offsets that
+ * decrease are reported by the next call that synchronises (frames_ready / pop / flush). */
+int adder_framer_ingest_frames_device_offsets(AdderFramer *fr, const AdderEvent *d_events,
+                                              const uint64_t *d_frame_offsets, uint32_t num_frames, void *stream);
+
 /* Number of complete frames waiting (is_frame_filled(0), (1), ...).  Synchronises. */
 int adder_framer_frames_ready(AdderFramer *fr, uint32_t *n_ready);
 

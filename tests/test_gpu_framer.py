@@ -206,10 +206,14 @@ def test_full_size_1080p_framer_paths_agree():
     hv.finish()
     offs = d_off.cpu().numpy().astype(np.uint64)
     outs = []
-    for batch in (False, True):
+    for batch in (0, 1, 2):
         fr = A.HipFramer(W, H, 1, tps=255 * 30, ref_interval=255, delta_t_max=255, output_fps=30.0, codec_version=3,
                          time_mode=A.TIME_DELTA_T, ring_frames=T + 8)
-        (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
+        if batch == 2:  # offsets stay on the device, in two calls (the second one starts inside the tensor)
+            fr.ingest_frames_device_offsets(d_ev, d_off, 10, stream=st)
+            fr.ingest_frames_device_offsets(d_ev, d_off[10:], T - 10, stream=st)
+        else:
+            (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
         n = fr.frames_ready()
         d_out = torch.empty((max(n, 1), n_units), dtype=torch.uint8, device="cuda")
         assert fr.pop_device(d_out, n, stream=st) == n
@@ -217,7 +221,15 @@ def test_full_size_1080p_framer_paths_agree():
         outs.append(d_out[:n].clone())
         fr.close()
     # (a pixel that is 0 in consecutive frames is silent, so the slowest pixel holds most frames back)
-    assert outs[0].shape[0] >= 1 and torch.equal(outs[0], outs[1])
+    assert outs[0].shape[0] >= 1 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # offsets on the device are checked there
+    fr = A.HipFramer(W, H, 1, tps=255 * 30, ref_interval=255, delta_t_max=255, output_fps=30.0, codec_version=3,
+                     time_mode=A.TIME_DELTA_T, ring_frames=T + 8)
+    bad = d_off.clone()
+    bad[3] = bad[5] + 1
+    fr.ingest_frames_device_offsets(d_ev, bad, T, stream=st)
+    with pytest.raises(A.AdderHipError):
+        fr.frames_ready()
 
 
 def _synthetic_stream(rng, W, H, Cn, T, *, abs_t, big_t=False, long_runs=False, density=0.3):

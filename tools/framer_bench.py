@@ -27,7 +27,9 @@ for it in range(4):
     fr = A.HipFramer(W, H, 1, tps=255 * 30, ref_interval=255, delta_t_max=dtm, output_fps=30.0, codec_version=3,
                      time_mode=tmode, ring_frames=T + dtm // 255 + 16)
     ingest = fr.ingest_frames_device if E.get("BATCH", "1") == "1" else fr.ingest_device
-    ingest(d_ev, offs[:2], stream=st)  # first call: allocations
+    if E.get("OFFS") == "device":  # frame offsets stay in HBM (adder_framer_ingest_frames_device_offsets)
+        ingest = lambda ev, o, stream: fr.ingest_frames_device_offsets(ev, d_off[int(o[0] != offs[0]):], len(o) - 1, stream=stream)
+    ingest(d_ev, offs[:2], stream=st)  # first call: the source's first frame
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     e0.record()
