@@ -1088,7 +1088,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         if (rc_ != ADDER_OK) return rc_;
     }
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
-                             (generic ? 4u : 0u) | (c->continuous ? 8u : 0u);
+                             (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
+                             (c->n_units >= 4u ? 16u : 0u);  // 16: the 4-units-per-lane one-frame kernel may run
     if (generic) {
         // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
         int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2) * kGenRecBytes);

@@ -16,6 +16,9 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef ADDER_EXPAND_SEGS
 #define ADDER_EXPAND_SEGS 16
 #endif
+#ifndef ADDER_LEAN1_WIDE
+#define ADDER_LEAN1_WIDE 1  // one frame per launch: the 4-units-per-lane kernel (16-byte accesses)
+#endif
 #ifndef ADDER_LEAN_WAVES_PER_SIMD
 #define ADDER_LEAN_WAVES_PER_SIMD 8
 #endif
@@ -196,7 +199,8 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 }  // namespace adder
 
 extern "C" {
-// variant = collapse | abs_t << 1 | generic << 2 | continuous << 3 (host copy of what BatchArgs holds)
+// variant = collapse | abs_t << 1 | generic << 2 | continuous << 3 (host copy of what BatchArgs holds) | the band
+// has >= 4 units << 4
 // K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking).  grid_cap (0 = none) bounds the number of
 // workgroups of the lean kernel / of the expansion: the workgroups then walk their work items, which leaves room
 // for the other kernel to be resident on the same CUs

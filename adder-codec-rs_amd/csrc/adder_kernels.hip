@@ -419,6 +419,161 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1_WAVES) void adder_lean1_
     }
 }
 
+// Lean K1 at temporal depth 1 with 16-byte accesses: one lane = 4 consecutive units, so every state access of
+// the wave is a global_load/store_dwordx4 over 1 KiB of one plane (8-byte accesses reach 0.54-0.70 of the
+// 16-byte rate on this memory system) and the input is one dword per lane.  A wave then covers a PAIR of
+// segments (lanes 0-31 / 32-63): the records are compacted per half into the two segments' scratch slots, so
+// scan and expansion see exactly what the 2-unit kernels leave.  kLean1wPairs pairs per wave, all loads first.
+#if ADDER_UNITS_PER_LANE == 2
+#ifndef ADDER_LEAN1W_PAIRS
+#define ADDER_LEAN1W_PAIRS 2
+#endif
+#ifndef ADDER_LEAN1W_WAVES
+#define ADDER_LEAN1W_WAVES 4
+#endif
+constexpr uint32_t kLean1wPairs = ADDER_LEAN1W_PAIRS;
+constexpr uint32_t kWideUnits = 4;
+struct WideRaw {
+    uint4 hdr;
+    float4 iv, dv, bv, lfv;
+    uint32_t vin;
+};
+
+// All of a pair's loads, no control flow: the input dword of a lane that straddles the band's end is read
+// from the band's last four bytes and shifted down (the bytes past the end belong to padding units, whose
+// events are suppressed; the launcher keeps bands below four units on the 2-unit kernel).
+template <bool ABS_T>
+__device__ __forceinline__ void wide_load(const FrameArgs &st, const uint8_t *frame, uint32_t n_units, uint32_t u0,
+                                          WideRaw &r) {
+    r.hdr = gload<uint4>(uniform_ptr(st.hdr), u0 * 4u);
+    const uint32_t ua = min(u0, n_units - kWideUnits);
+    r.vin = gload<uint32_t>(frame, ua) >> (8u * min(u0 - ua, 3u));
+    r.iv = gload<float4>(uniform_ptr(st.integ0), u0 * 4u);
+    r.dv = gload<float4>(uniform_ptr(st.dt0), u0 * 4u);
+    r.bv = gload<float4>(uniform_ptr(st.bdt0), u0 * 4u);
+    if (ABS_T) r.lfv = gload<float4>(uniform_ptr(st.lastf), u0 * 4u);
+    else r.lfv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+template <bool ABS_T, bool FULL>
+__device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t gw0,
+                                               uint32_t lane, const WideRaw &raw) {
+    constexpr uint32_t N = kWideUnits;
+    using L = WaveLanes;
+    const uint32_t u0 = gw0 * kWaveUnits + lane * N;
+    const uint32_t hdrv[N] = {raw.hdr.x, raw.hdr.y, raw.hdr.z, raw.hdr.w};
+    const float iv[N] = {raw.iv.x, raw.iv.y, raw.iv.z, raw.iv.w}, dv[N] = {raw.dv.x, raw.dv.y, raw.dv.z, raw.dv.w};
+    const float bv[N] = {raw.bv.x, raw.bv.y, raw.bv.z, raw.bv.w}, lv[N] = {raw.lfv.x, raw.lfv.y, raw.lfv.z, raw.lfv.w};
+    LeanPxT<L> px[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) px[j] = lean_unpack<L>(hdrv[j], iv[j], dv[j], bv[j], lv[j]);
+    const StepConsts sc = a.sc;  // (running_t and cth are this frame's: frame_args)
+    const float T = sc.time_spanned;
+    const uint32_t cth = __builtin_amdgcn_readfirstlane(sc.cth);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    const bool upper = lane >= 32u;
+
+    LeanRec rec[N];
+    uint64_t mrec[N], active[N];
+    uint32_t nev_lo = 0u, nev_hi = 0u, nrec_lo = 0u, nrec_hi = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
+        const uint32_t v = (raw.vin >> (8 * j)) & 0xffu;
+        const uint32_t tag = ((lane & 31u) * N + j) << kLeanUnitShift;
+        LeanFlagsT<L> fl = lean_step<ABS_T, L>(px[j], v, cth, T, sc, tag, rec[j]);
+        if (!FULL) {
+            fl.a &= active[j];
+            fl.b &= active[j];
+            fl.c &= active[j];
+        }
+        mrec[j] = fl.a | fl.c;
+        nrec_lo += (uint32_t)__popc((uint32_t)mrec[j]);
+        nrec_hi += (uint32_t)__popc((uint32_t)(mrec[j] >> 32));
+        nev_lo += (uint32_t)__popc((uint32_t)fl.a) + (uint32_t)__popc((uint32_t)fl.b) + (uint32_t)__popc((uint32_t)fl.c);
+        nev_hi += (uint32_t)__popc((uint32_t)(fl.a >> 32)) + (uint32_t)__popc((uint32_t)(fl.b >> 32)) +
+                  (uint32_t)__popc((uint32_t)(fl.c >> 32));
+    }
+    // ordered compaction per half: records of the lower lanes of the lane's own half, then its earlier units
+    uint32_t pos = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j)
+        pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mrec[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mrec[j], pos));
+    pos -= upper ? nrec_lo : 0u;  // (for lanes >= 32 mbcnt_lo counted the whole lower half)
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % b->slots);
+    const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
+    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
+    uint8_t *const seg = uniform_ptr(b->park_ring) +
+                         park_offset(slot, __builtin_amdgcn_readfirstlane(gw0), chunk_u,
+                                     __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u);
+    uint32_t off = (upper ? chunk_u * park_bytes_u : 0u) + pos * kLeanRecBytes;  // segment gw0 + 1: + chunk * park_bytes
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        const bool has = L::lane(mrec[j]);
+        if (has) gstore(seg, off, rec[j]);
+        off += has ? kLeanRecBytes : 0u;
+    }
+    if (lane == 0u)
+        gstore<uint2>(uniform_ptr(a.wtot), __builtin_amdgcn_readfirstlane(gw0) * 4u,
+                      make_uint2(nev_lo | (nrec_lo << 16), nev_hi | (nrec_hi << 16)));
+
+    // ---------------- state back to HBM ----------------
+    uint32_t ho[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) ho[j] = lean_hdr(px[j]);
+    gstore<uint4>(a.hdr, u0 * 4u, make_uint4(ho[0], ho[1], ho[2], ho[3]));
+    gstore<float4>(a.integ0, u0 * 4u, make_float4(px[0].integ, px[1].integ, px[2].integ, px[3].integ));
+    gstore<float4>(a.dt0, u0 * 4u, make_float4(px[0].dt, px[1].dt, px[2].dt, px[3].dt));
+    gstore<float4>(a.bdt0, u0 * 4u, make_float4(px[0].bdt, px[1].bdt, px[2].bdt, px[3].bdt));
+    if (ABS_T) gstore<float4>(a.lastf, u0 * 4u, make_float4(px[0].lastf, px[1].lastf, px[2].lastf, px[3].lastf));
+    if (a.running) {
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j)
+            if (L::lane(active[j] & px[j].has0))
+                a.running[u0 + j] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(px[j].thr)),
+                                                            f32_as_u32(px[j].bdt), (double)sc.ref_time);
+    }
+}
+
+#define ADDER_CONSTANT __attribute__((address_space(4)))
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1W_WAVES) void adder_lean1w_kernel(const BatchArgs *__restrict__ b,
+                                                                                        uint32_t f) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t n_units = b->base.n_units;
+    const uint32_t num_pairs = b->base.num_waves / 2u;
+    const uint32_t gp0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + tid / kWave) * kLean1wPairs);
+    if (gp0 >= num_pairs) return;
+    // the frame's row of the table as a scalar load (uploaded with the batch description before the launch)
+    using TabRaw = typename RawOf<sizeof(FrameTab)>::type;
+    const TabRaw tab = *reinterpret_cast<const ADDER_CONSTANT TabRaw *>((const ADDER_CONSTANT char *)(uint64_t)b->ftab +
+                                                                        (size_t)f * sizeof(FrameTab));
+    const uint8_t *const frame = uniform_ptr(b->frames) + (size_t)f * n_units;
+    WideRaw raw[kLean1wPairs];
+#pragma unroll
+    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
+        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);  // (a wave past the end re-reads the last pair)
+        wide_load<ABS_T>(b->base, frame, n_units, gw * kWaveUnits + lane * kWideUnits, raw[s]);
+    }
+    // every load is in flight before the first value is consumed (left to itself the scheduler unpacks the
+    // first header between the loads and waits for ALL of them before it issues the last one)
+    __builtin_amdgcn_sched_barrier(0);
+    FrameArgs a = frame_args(b, f);
+    a.sc.running_t = __uint_as_float(tab[0]);
+    a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
+    a.sc.cth = tab[1];
+#pragma unroll
+    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
+        if (gp0 + s >= num_pairs) break;
+        const uint32_t gw = 2u * (gp0 + s);
+        const bool full = gw * kWaveUnits + 2u * kWaveUnits <= n_units;
+        if (full) wide_step_pair<ABS_T, true>(b, a, gw, lane, raw[s]);
+        else wide_step_pair<ABS_T, false>(b, a, gw, lane, raw[s]);
+    }
+}
+#endif  // ADDER_UNITS_PER_LANE == 2
+
 // ------------------------------------------------------------------------------------------
 // K1, generic variants (Normal mode, or delta_t_max > time_spanned): any arena depth.  Every unit runs the
 // four phases of the generic step (adder_pixel.hpp): gen_root on the register-resident level 0 (branch-
@@ -1463,6 +1618,15 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
+#if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
+    if (nb == 1u && num_waves % 2u == 0u && (variant & 16u)) {
+        const uint32_t waves = (num_waves / 2u + kLean1wPairs - 1u) / kLean1wPairs;
+        const uint32_t grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (abs_t) hipLaunchKernelGGL((adder_lean1w_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+        else hipLaunchKernelGGL((adder_lean1w_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+        return hipGetLastError();
+    }
+#endif
     if (nb == 1u && num_waves % kLean1Segs == 0u) {
         const uint32_t grid = (num_waves / kLean1Segs + kWavesPerBlock - 1) / kWavesPerBlock;
         if (abs_t) hipLaunchKernelGGL((adder_lean1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
