@@ -204,9 +204,9 @@ struct AdderHipCtx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float last_ms = 0.0f;
     // optional per-launch timing (one HIP event pair around every frame launch)
-    bool launch_timing = false;
+    int launch_timing = 0;  // 1: a pair around every frame-kernel launch; 2: a pair around a chunk's run of them
     std::vector<hipEvent_t> launch_events;
-    uint32_t timed_launches = 0, timed_frames = 0;
+    uint32_t timed_launches = 0, timed_frames = 0, timed_pairs = 0;
     float last_launch_avg_us = 0.0f;
 };
 
@@ -862,15 +862,24 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         const uint32_t nf = std::min(c->chunk, num_frames - f0);
         if (s2 && k >= c->ring_chunks)  // scratch reuse: the expansion of the chunk that held these slots
             HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - c->ring_chunks) % 5u], 0));
+        const bool per_chunk = timing && c->launch_timing == 2;
+        if (per_chunk) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs], s));
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
-            if (timing) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches], s));
+            if (timing && !per_chunk) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs], s));
             HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, lean_cap, s));
             if (timing) {  // the pair brackets the frame kernel (K1) only
-                HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_launches + 1], s));
+                if (!per_chunk) {
+                    HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs + 1], s));
+                    c->timed_pairs += 1;
+                }
                 c->timed_launches += 1;
                 c->timed_frames += nb;
             }
+        }
+        if (per_chunk) {  // ... or the chunk's whole run of them (no event packets between the launches)
+            HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs + 1], s));
+            c->timed_pairs += 1;
         }
         // (scan + offsets on a third stream of their own -- they depend on the chunk's frame kernels only -- was
         // tried: they then run at once instead of behind the previous expansion, and the expansions, now back to
@@ -1174,9 +1183,10 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     }
 
     c->timed_launches = 0;
+    c->timed_pairs = 0;
     c->timed_frames = 0;
     c->timed_posts = 0;
-    const bool timing = c->launch_timing;
+    const bool timing = c->launch_timing != 0;
     if (timing) {
         while (c->launch_events.size() < 2 * (size_t)num_frames) {
             hipEvent_t e;
@@ -1292,7 +1302,7 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
     c->last_launch_avg_us = 0.0f;
     if (c->timed_launches) {
         double sum = 0.0;
-        for (uint32_t f = 0; f < c->timed_launches; ++f) {
+        for (uint32_t f = 0; f < c->timed_pairs; ++f) {
             float ms = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&ms, c->launch_events[2 * f], c->launch_events[2 * f + 1]));
             sum += ms;
@@ -1341,7 +1351,7 @@ extern "C" int adder_hip_launch_plan_settled(const AdderHipCtx *c) {
 
 extern "C" int adder_hip_set_launch_timing(AdderHipCtx *c, int enable) {
     if (!c) return ADDER_E_BAD_PARAMS;
-    c->launch_timing = enable != 0;
+    c->launch_timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return ADDER_OK;
 }
 

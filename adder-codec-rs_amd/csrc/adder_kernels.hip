@@ -549,20 +549,22 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1W_WAVES) void adder_lean1
     using TabRaw = typename RawOf<sizeof(FrameTab)>::type;
     const TabRaw tab = *reinterpret_cast<const ADDER_CONSTANT TabRaw *>((const ADDER_CONSTANT char *)(uint64_t)b->ftab +
                                                                         (size_t)f * sizeof(FrameTab));
-    const uint8_t *const frame = uniform_ptr(b->frames) + (size_t)f * n_units;
-    WideRaw raw[kLean1wPairs];
-#pragma unroll
-    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
-        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);  // (a wave past the end re-reads the last pair)
-        wide_load<ABS_T>(b->base, frame, n_units, gw * kWaveUnits + lane * kWideUnits, raw[s]);
-    }
-    // every load is in flight before the first value is consumed (left to itself the scheduler unpacks the
-    // first header between the loads and waits for ALL of them before it issues the last one)
-    __builtin_amdgcn_sched_barrier(0);
     FrameArgs a = frame_args(b, f);
     a.sc.running_t = __uint_as_float(tab[0]);
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.sc.cth = tab[1];
+    const uint8_t *const frame = uniform_ptr(b->frames) + (size_t)f * n_units;
+    // All pairs' loads first.  Measured on top of this (each one slower or equal, A/B inside one run): a
+    // scheduling barrier that holds the vector loads until the scalar prologue has landed (+0.3 ... 0.6 us of
+    // 14), one that keeps every load ahead of the first consumer (+-0), waiting for the next pair's loads
+    // before this pair's stores so that no wait falls behind uncounted stores (+0.4), the second pair's loads
+    // issued when the first pair's have landed (+-0); 1 / 3 / 4 pairs per wave, 3 / 5 waves per SIMD.
+    WideRaw raw[kLean1wPairs];
+#pragma unroll
+    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
+        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);  // (a wave past the end re-reads the last pair)
+        wide_load<ABS_T>(a, frame, n_units, gw * kWaveUnits + lane * kWideUnits, raw[s]);
+    }
 #pragma unroll
     for (uint32_t s = 0; s < kLean1wPairs; ++s) {
         if (gp0 + s >= num_pairs) break;

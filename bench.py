@@ -217,7 +217,7 @@ def main():
             layout_elapsed, _ = timed("layout", layout_steps, 1)
 
     # ---- roofline: one extra step with HIP event pairs around the launches ----
-    k1_us = post_us = k1_one_us = 0.0
+    k1_us = post_us = k1_one_us = k1_one_pair_us = 0.0
     k1_frames = 1.0
     chunk_frames = hv.chunk_frames()
     records1 = records
@@ -230,6 +230,11 @@ def main():
         # the frame kernel alone with one frame per launch (the per-frame `consume` contract, state
         # streamed from HBM every frame): the HBM-bound regime of SURVEY 8(d)
         hv.set_frames_per_launch(1)
+        step("none")
+        k1_one_pair_us = hv.last_launch_avg_us()
+        # ... and with ONE event pair around each chunk's run of 32 launches (no event packets between the
+        # kernels: what is left on top of the kernel time is the gap between two dependent launches)
+        hv.set_launch_timing(2)
         step("none")
         k1_one_us = hv.last_launch_avg_us()
         records1 = hv.last_batch_records()
@@ -328,7 +333,7 @@ def main():
         },
         "roofline_one_frame_per_launch": {
             "bound": "hbm",
-            "kernel": "adder_lean1_kernel" if lean else "adder_frame_kernel",
+            "kernel": "adder_lean1w_kernel" if lean else "adder_frame_kernel",
             "achieved": round(one_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -336,11 +341,13 @@ def main():
             "bytes_per_unit_frame": round(one_b, 3),
             "units_per_launch": units,
             "launch_avg_us": round(k1_one_us, 3),
+            "launch_avg_us_event_pair_per_launch": round(k1_one_pair_us, 3),
             "note": "the frame kernel alone with the state streamed from HBM every frame (per-frame consume contract): "
-                    "bytes it really moves = 1 input + 16 state in + 16 state out + 12 per parked record.  The duration "
-                    "is a HIP-event pair around every launch, which on this runtime reads ~2 us more than the kernel "
-                    "itself (rocprofv3 kernel duration of the same run: profiles/r02_bench_kernel_stats.csv, "
-                    "adder_lean1_kernel 14.35 us = 0.65)",
+                    "bytes it really moves = 1 input + 16 state in + 16 state out + 12 per parked record.  launch_avg_us "
+                    "= one HIP-event pair around each chunk's run of 32 back-to-back launches / 32 (kernel + the gap "
+                    "to the next dependent launch); with a pair around EVERY launch the event packets themselves add "
+                    "~2 us (launch_avg_us_event_pair_per_launch).  rocprofv3's kernel duration of the same command is "
+                    "in profiles/ (kernel stats, adder_lean1w_kernel)",
         },
     }
     if layout_elapsed is not None:

@@ -244,7 +244,9 @@ int adder_hip_debug_timeline(AdderHipCtx *ctx, unsigned long long *dst);
 /* Mean duration in microseconds of the frame-kernel launches of the last device batch,
  * measured with one HIP event pair around EVERY launch on the launch stream; only
  * collected while adder_hip_set_launch_timing(ctx, 1) is in effect (the extra event
- * packets slow the batch down, so throughput runs leave it off). */
+ * packets slow the batch down, so throughput runs leave it off).  enable = 2: one pair around
+ * each chunk's RUN of frame-kernel launches instead (no event packets between the launches;
+ * the mean then holds the gaps between consecutive kernels, not the events' own cost). */
 int adder_hip_set_launch_timing(AdderHipCtx *ctx, int enable);
 float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
 /* Same run: mean duration of the scan + offsets + expansion launches of one chunk of frames (the other
