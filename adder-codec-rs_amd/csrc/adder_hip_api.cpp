@@ -1158,6 +1158,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
     b.park_bytes = c->park_bytes;
+    // ring layout (park_offset): batches launched one frame at a time park frame-major
+    if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
+        b.park_seg_stride = c->park_bytes;
+        b.park_frame_stride = c->num_waves * c->park_bytes;
+    } else {
+        b.park_seg_stride = c->chunk * c->park_bytes;
+        b.park_frame_stride = c->park_bytes;
+    }
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;

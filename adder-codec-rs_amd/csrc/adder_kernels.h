@@ -110,6 +110,8 @@ struct BatchArgs {
     // compaction scratch: a ring of `slots` frames
     uint8_t *park_ring;       // [slots][num_waves][park_bytes]
     uint32_t park_bytes;      // scratch of one segment (kLeanParkBytes, or kGenRecBytes * parked-event capacity)
+    uint32_t park_seg_stride;    // bytes between consecutive segments of one frame slot   (see park_offset)
+    uint32_t park_frame_stride;  // bytes between consecutive frame slots of one segment
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [2][slots]: events per frame, then parked records per frame
@@ -122,14 +124,19 @@ struct BatchArgs {
 };
 constexpr uint32_t kTimelineChunks = 64;
 
-// Where (frame slot, segment) parks its records, in bytes from park_ring.  Layout [chunk of the ring][segment][frame
-// of the chunk][park_bytes]: the frames a wave steps in one launch are CONTIGUOUS (it touches one or two pages of
-// the ring instead of one per frame -- with [slot][segment] a segment's 32 frames lay 25 MB apart), and the 16
-// segments an expansion wave reads lie chunk * park_bytes apart.
+// Where (frame slot, segment) parks its records, in bytes from park_ring.  Within one chunk of the ring the layout
+// is one of two, chosen per batch by the two strides:
+//   segment-major [segment][frame][park_bytes]  (seg stride = chunk * park_bytes, frame stride = park_bytes): the
+//     frames a wave steps in ONE launch are contiguous -- it touches one or two pages of the ring instead of one per
+//     frame; what temporal blocking wants;
+//   frame-major   [frame][segment][park_bytes]  (seg stride = park_bytes, frame stride = num_waves * park_bytes):
+//     batches launched one frame at a time.  There a launch writes one short run of records per segment, and
+//     segment-major puts consecutive segments 48 KiB apart: 16 200 scattered partial lines per 1080p frame cost the
+//     one-frame kernel 2.6 of its 14.7 us; frame-major puts them 1.5 KiB apart.
 __host__ __device__ __forceinline__ size_t park_offset(uint32_t slot, uint32_t seg, uint32_t chunk, uint32_t num_waves,
-                                                       uint32_t park_bytes) {
+                                                       uint32_t park_bytes, uint32_t seg_stride, uint32_t frame_stride) {
     const uint32_t cir = slot / chunk, fi = slot - cir * chunk;
-    return ((size_t)(cir * num_waves + seg) * chunk + fi) * park_bytes;
+    return (size_t)cir * num_waves * chunk * park_bytes + (size_t)seg * seg_stride + (size_t)fi * frame_stride;
 }
 
 // what the host reads after a batch (adder_publish_kernel), in page-locked host memory
@@ -189,7 +196,8 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     a.sc.running_t = b->ftab[f].running_t;
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.sc.cth = b->ftab[f].cth;
-    a.park = b->park_ring + park_offset(slot, 0u, b->chunk, a.num_waves, b->park_bytes);  // segment s: + s * chunk * park_bytes
+    a.park = b->park_ring + park_offset(slot, 0u, b->chunk, a.num_waves, b->park_bytes, b->park_seg_stride,
+                                         b->park_frame_stride);  // segment s: + s * park_seg_stride
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
     a.ftot = b->ftot_ring + slot;

@@ -246,7 +246,10 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     // uniform pointers advanced by adds (the ring wraps at `slots`)
     // (a launch never crosses a chunk boundary, so the segment's frames are contiguous: park_offset)
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
-    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u);
+    const uint32_t seg_stride_u = __builtin_amdgcn_readfirstlane(b->park_seg_stride);
+    const uint32_t frame_stride_u = __builtin_amdgcn_readfirstlane(b->park_frame_stride);
+    uint8_t *seg = uniform_ptr(b->park_ring) +
+                   park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, seg_stride_u, frame_stride_u);
     // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
     // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
     // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
@@ -312,7 +315,7 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
         vin_w = next_w;
-        seg += park_bytes_u;
+        seg += frame_stride_u;
     }
 
     // ---------------- per-frame segment totals ----------------
@@ -481,7 +484,14 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
         active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
         const uint32_t v = (raw.vin >> (8 * j)) & 0xffu;
         const uint32_t tag = ((lane & 31u) * N + j) << kLeanUnitShift;
+#ifdef ADDER_DBG_NOSTEP
+        LeanFlagsT<L> fl;
+        px[j].integ += (float)v; px[j].dt += T; px[j].bdt += 1.0f;
+        fl.a = L::from(px[j].integ > 1e9f); fl.b = 0; fl.c = L::from((v & 7u) == 0u);
+        rec[j].ta = tag; rec[j].tc = v; rec[j].w = cth;
+#else
         LeanFlagsT<L> fl = lean_step<ABS_T, L>(px[j], v, cth, T, sc, tag, rec[j]);
+#endif
         if (!FULL) {
             fl.a &= active[j];
             fl.b &= active[j];
@@ -503,14 +513,18 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
     const uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % b->slots);
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
     const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
+    const uint32_t seg_stride_u = __builtin_amdgcn_readfirstlane(b->park_seg_stride);
     uint8_t *const seg = uniform_ptr(b->park_ring) +
                          park_offset(slot, __builtin_amdgcn_readfirstlane(gw0), chunk_u,
-                                     __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u);
-    uint32_t off = (upper ? chunk_u * park_bytes_u : 0u) + pos * kLeanRecBytes;  // segment gw0 + 1: + chunk * park_bytes
+                                     __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u, seg_stride_u,
+                                     __builtin_amdgcn_readfirstlane(b->park_frame_stride));
+    uint32_t off = (upper ? seg_stride_u : 0u) + pos * kLeanRecBytes;  // (the upper half is segment gw0 + 1)
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
         const bool has = L::lane(mrec[j]);
+#ifndef ADDER_DBG_NOREC
         if (has) gstore(seg, off, rec[j]);
+#endif
         off += has ? kLeanRecBytes : 0u;
     }
     if (lane == 0u)
@@ -704,7 +718,9 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl | (incl << 16));
         uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
         uint2 *const seg = reinterpret_cast<uint2 *>(
-            park_ring_u + park_offset(slot, sgw, __builtin_amdgcn_readfirstlane(b->chunk), num_waves_u, park_bytes_u));  // uniform
+            park_ring_u + park_offset(slot, sgw, __builtin_amdgcn_readfirstlane(b->chunk), num_waves_u, park_bytes_u,
+                                      __builtin_amdgcn_readfirstlane(b->park_seg_stride),
+                                      __builtin_amdgcn_readfirstlane(b->park_frame_stride)));  // uniform
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u) {
@@ -831,7 +847,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
     const uint32_t u0 = gw * kWaveUnits + lane * N;
     for (uint32_t i = 0; i < nb; ++i) {
         const FrameArgs a = frame_args(b, f0 + i);
-        uint8_t *const seg = a.park + (size_t)gw * b->chunk * b->park_bytes;
+        uint8_t *const seg = a.park + (size_t)gw * b->park_seg_stride;
         uint32_t lane_cnt = 0;
         bool bad = false;
 #pragma unroll
@@ -1055,8 +1071,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint32_t park_bytes = __builtin_amdgcn_readfirstlane(b->park_bytes);
     // wave-uniform bases (SGPRs); the lanes add 32-bit byte offsets
     const uint32_t chunk_frames = __builtin_amdgcn_readfirstlane(b->chunk);
-    const uint8_t *park = uniform_ptr(b->park_ring) + park_offset(slot, seg0, chunk_frames, num_waves, park_bytes);
-    const uint32_t seg_stride = chunk_frames * park_bytes;  // bytes between consecutive segments of one frame
+    const uint32_t seg_stride = __builtin_amdgcn_readfirstlane(b->park_seg_stride);  // between consecutive segments of one frame
+    const uint8_t *park = uniform_ptr(b->park_ring) +
+                          park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, seg_stride,
+                                      __builtin_amdgcn_readfirstlane(b->park_frame_stride));
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
     UnitCoord uc;
