@@ -817,9 +817,14 @@ static int alloc_deep_planes(AdderHipCtx *c) {
 // memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
 
+static Lean1wArgs lean1w_args(const AdderHipCtx *c) {
+    return Lean1wArgs{c->hdr, c->integ0, c->dt0, c->bdt0, c->lastf, c->n_units, c->num_waves};
+}
+
 // Feature path: frame f+1's contrast thresholds depend on the features frame f's EVENTS reveal, so the whole
 // pipeline runs frame by frame: step, scan, offsets, expansion, features.
 static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s) {
+    const Lean1wArgs wide = lean1w_args(c);
     FeatureArgs fa{};
     fa.fset = c->fset;
     fa.counters = c->d_feat_counters;
@@ -833,7 +838,7 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
     fa.rx1 = c->roi[2];
     fa.ry1 = c->roi[3];
     for (uint32_t f = 0; f < num_frames; ++f) {
-        HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, s));
+        HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, s, &wide));
         HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, 0u, s));
@@ -849,6 +854,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     // semantics).  Generic batches block too: levels >= 1 stay in HBM, but they are private
     // to their unit, so the lane's own program order keeps them consistent across frames.
     const uint32_t depth = launch_depth(c);
+    const Lean1wArgs wide = lean1w_args(c);
     // With a second stream the expansion of chunk k runs beside the frame kernel of chunk k+1.  The frame kernel is
     // bound by instruction issue, the expansion by memory, and two grids that each fill the chip would simply run one
     // after the other (measured: the scan queued behind the resident frame kernel for a whole kernel time): both are
@@ -867,7 +873,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing && !per_chunk) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs], s));
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, lean_cap, s));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, lean_cap, s, &wide));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 if (!per_chunk) {
                     HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs + 1], s));

@@ -100,6 +100,13 @@ struct FrameArgs {
     StepConsts sc;        // running_t / cth are filled per frame from the table
 };
 
+// What adder_lean1w_kernel takes as kernel arguments (by value): the level-0 planes and the band's size.
+struct Lean1wArgs {
+    uint32_t *hdr;
+    float *integ0, *dt0, *bdt0, *lastf;
+    uint32_t n_units, num_waves;
+};
+
 // Device-resident description of one batch of frames.  The kernels take (BatchArgs*, f), so
 // a captured hipGraph of T frames can be replayed for ANY batch of T frames: the host only
 // rewrites this struct (and the per-frame table) before launching the graph.
@@ -213,7 +220,8 @@ extern "C" {
 // workgroups of the lean kernel / of the expansion: the workgroups then walk their work items, which leaves room
 // for the other kernel to be resident on the same CUs
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                              uint32_t num_waves, uint32_t grid_cap, hipStream_t stream);
+                              uint32_t num_waves, uint32_t grid_cap, hipStream_t stream,
+                              const adder::Lean1wArgs *wide);  // (host copy of the level-0 planes, or null)
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);

@@ -446,16 +446,17 @@ struct WideRaw {
 // from the band's last four bytes and shifted down (the bytes past the end belong to padding units, whose
 // events are suppressed; the launcher keeps bands below four units on the 2-unit kernel).
 template <bool ABS_T>
-__device__ __forceinline__ void wide_load(const FrameArgs &st, const uint8_t *frame, uint32_t n_units, uint32_t u0,
-                                          WideRaw &r) {
-    r.hdr = gload<uint4>(uniform_ptr(st.hdr), u0 * 4u);
+__device__ __forceinline__ void wide_load_state(const Lean1wArgs &st, uint32_t u0, WideRaw &r) {
+    r.hdr = gload<uint4>(st.hdr, u0 * 4u);
+    r.iv = gload<float4>(st.integ0, u0 * 4u);
+    r.dv = gload<float4>(st.dt0, u0 * 4u);
+    r.bv = gload<float4>(st.bdt0, u0 * 4u);
+    if (ABS_T) r.lfv = gload<float4>(st.lastf, u0 * 4u);
+    else r.lfv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__device__ __forceinline__ void wide_load_input(const uint8_t *frame, uint32_t n_units, uint32_t u0, WideRaw &r) {
     const uint32_t ua = min(u0, n_units - kWideUnits);
     r.vin = gload<uint32_t>(frame, ua) >> (8u * min(u0 - ua, 3u));
-    r.iv = gload<float4>(uniform_ptr(st.integ0), u0 * 4u);
-    r.dv = gload<float4>(uniform_ptr(st.dt0), u0 * 4u);
-    r.bv = gload<float4>(uniform_ptr(st.bdt0), u0 * 4u);
-    if (ABS_T) r.lfv = gload<float4>(uniform_ptr(st.lastf), u0 * 4u);
-    else r.lfv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 template <bool ABS_T, bool FULL>
@@ -550,15 +551,24 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
 }
 
 #define ADDER_CONSTANT __attribute__((address_space(4)))
+// The state planes and the band's size come as kernel arguments (constant for the life of the context, so a
+// captured graph may hold them): the state loads go out one scalar round trip after the wave starts instead of
+// three (kernel arguments -> batch description -> its fields).
 template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1W_WAVES) void adder_lean1w_kernel(const BatchArgs *__restrict__ b,
-                                                                                        uint32_t f) {
+                                                                                        uint32_t f, Lean1wArgs st) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t n_units = b->base.n_units;
-    const uint32_t num_pairs = b->base.num_waves / 2u;
+    const uint32_t n_units = st.n_units;
+    const uint32_t num_pairs = st.num_waves / 2u;
     const uint32_t gp0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + tid / kWave) * kLean1wPairs);
     if (gp0 >= num_pairs) return;
+    WideRaw raw[kLean1wPairs];
+#pragma unroll
+    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
+        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);  // (a wave past the end re-reads the last pair)
+        wide_load_state<ABS_T>(st, gw * kWaveUnits + lane * kWideUnits, raw[s]);
+    }
     // the frame's row of the table as a scalar load (uploaded with the batch description before the launch)
     using TabRaw = typename RawOf<sizeof(FrameTab)>::type;
     const TabRaw tab = *reinterpret_cast<const ADDER_CONSTANT TabRaw *>((const ADDER_CONSTANT char *)(uint64_t)b->ftab +
@@ -568,17 +578,16 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LEAN1W_WAVES) void adder_lean1
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.sc.cth = tab[1];
     const uint8_t *const frame = uniform_ptr(b->frames) + (size_t)f * n_units;
+#pragma unroll
+    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
+        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);
+        wide_load_input(frame, n_units, gw * kWaveUnits + lane * kWideUnits, raw[s]);
+    }
     // All pairs' loads first.  Measured on top of this (each one slower or equal, A/B inside one run): a
     // scheduling barrier that holds the vector loads until the scalar prologue has landed (+0.3 ... 0.6 us of
     // 14), one that keeps every load ahead of the first consumer (+-0), waiting for the next pair's loads
     // before this pair's stores so that no wait falls behind uncounted stores (+0.4), the second pair's loads
     // issued when the first pair's have landed (+-0); 1 / 3 / 4 pairs per wave, 3 / 5 waves per SIMD.
-    WideRaw raw[kLean1wPairs];
-#pragma unroll
-    for (uint32_t s = 0; s < kLean1wPairs; ++s) {
-        const uint32_t gw = 2u * min(gp0 + s, num_pairs - 1u);  // (a wave past the end re-reads the last pair)
-        wide_load<ABS_T>(a, frame, n_units, gw * kWaveUnits + lane * kWideUnits, raw[s]);
-    }
 #pragma unroll
     for (uint32_t s = 0; s < kLean1wPairs; ++s) {
         if (gp0 + s >= num_pairs) break;
@@ -1618,7 +1627,8 @@ extern "C" hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_
 }
 
 extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
-                                         uint32_t num_waves, uint32_t grid_cap, hipStream_t stream) {
+                                         uint32_t num_waves, uint32_t grid_cap, hipStream_t stream,
+                                         const Lean1wArgs *wide) {
     const bool collapse = variant & 1u, abs_t = variant & 2u, generic = variant & 4u;
     const uint32_t S = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // step workgroups
     if (variant & 8u) {  // Mode::Continuous
@@ -1639,11 +1649,11 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
 #if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
-    if (nb == 1u && num_waves % 2u == 0u && (variant & 16u)) {
+    if (nb == 1u && num_waves % 2u == 0u && (variant & 16u) && wide) {
         const uint32_t waves = (num_waves / 2u + kLean1wPairs - 1u) / kLean1wPairs;
         const uint32_t grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-        if (abs_t) hipLaunchKernelGGL((adder_lean1w_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
-        else hipLaunchKernelGGL((adder_lean1w_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
+        if (abs_t) hipLaunchKernelGGL((adder_lean1w_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f, *wide);
+        else hipLaunchKernelGGL((adder_lean1w_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f, *wide);
         return hipGetLastError();
     }
 #endif
