@@ -85,6 +85,7 @@ struct AdderHipCtx {
     // ordered-compaction scratch: a ring of two chunks of frames (a chunk is stepped while the one before
     // it is scanned and expanded)
     uint8_t *park_ring = nullptr;    // [slots][num_waves][park_bytes]
+    uint32_t park_group_shift = 0;   // ring layout of temporally blocked batches (park_offset)
     uint32_t park_bytes = 0;         // scratch of one segment of one frame
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
@@ -780,6 +781,11 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     const size_t per_frame = (size_t)c->num_waves * ((size_t)bytes + 2 * sizeof(uint32_t));
     c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
     if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
+    if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
+        const int sh = atoi(e);
+        c->park_group_shift = sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
+        static_assert(ADDER_EXPAND_SEGS == 16, "a group must hold whole expansion waves");
+    }
     const size_t ch = budget / (c->ring_chunks * per_frame);
     c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
     if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
@@ -1164,13 +1170,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
     b.park_bytes = c->park_bytes;
-    // ring layout (park_offset): batches launched one frame at a time park frame-major
+    // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
+    // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
-        b.park_seg_stride = c->park_bytes;
-        b.park_frame_stride = c->num_waves * c->park_bytes;
+        b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes};
     } else {
-        b.park_seg_stride = c->chunk * c->park_bytes;
-        b.park_frame_stride = c->park_bytes;
+        uint32_t sh = c->park_group_shift;
+        while (sh && ((c->num_waves & ((1u << sh) - 1u)) || ((uint64_t)c->chunk * c->park_bytes << sh) > 0xffffffffull)) --sh;
+        b.park_layout = ParkLayout{sh, (c->chunk * c->park_bytes) << sh, c->park_bytes << sh, c->park_bytes};
     }
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;

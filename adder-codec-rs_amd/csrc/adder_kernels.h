@@ -100,6 +100,13 @@ struct FrameArgs {
     StepConsts sc;        // running_t / cth are filled per frame from the table
 };
 
+struct ParkLayout {
+    uint32_t group_shift;   // log2 of the segments per group (31: one group = frame-major)
+    uint32_t group_stride;  // bytes between consecutive groups
+    uint32_t frame_stride;  // bytes between consecutive frame slots of one segment
+    uint32_t seg_stride;    // bytes between consecutive segments inside a group
+};
+
 // What adder_lean1w_kernel takes as kernel arguments (by value): the level-0 planes and the band's size.
 struct Lean1wArgs {
     uint32_t *hdr;
@@ -117,8 +124,7 @@ struct BatchArgs {
     // compaction scratch: a ring of `slots` frames
     uint8_t *park_ring;       // [slots][num_waves][park_bytes]
     uint32_t park_bytes;      // scratch of one segment (kLeanParkBytes, or kGenRecBytes * parked-event capacity)
-    uint32_t park_seg_stride;    // bytes between consecutive segments of one frame slot   (see park_offset)
-    uint32_t park_frame_stride;  // bytes between consecutive frame slots of one segment
+    ParkLayout park_layout;   // where (frame slot, segment) lies inside a chunk of the ring (park_offset)
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [2][slots]: events per frame, then parked records per frame
@@ -131,19 +137,23 @@ struct BatchArgs {
 };
 constexpr uint32_t kTimelineChunks = 64;
 
-// Where (frame slot, segment) parks its records, in bytes from park_ring.  Within one chunk of the ring the layout
-// is one of two, chosen per batch by the two strides:
-//   segment-major [segment][frame][park_bytes]  (seg stride = chunk * park_bytes, frame stride = park_bytes): the
-//     frames a wave steps in ONE launch are contiguous -- it touches one or two pages of the ring instead of one per
-//     frame; what temporal blocking wants;
-//   frame-major   [frame][segment][park_bytes]  (seg stride = park_bytes, frame stride = num_waves * park_bytes):
-//     batches launched one frame at a time.  There a launch writes one short run of records per segment, and
-//     segment-major puts consecutive segments 48 KiB apart: 16 200 scattered partial lines per 1080p frame cost the
-//     one-frame kernel 2.6 of its 14.7 us; frame-major puts them 1.5 KiB apart.
+// Where (frame slot, segment) parks its records, in bytes from park_ring.  Within one chunk of the ring, segments
+// come in groups of G = 2^group_shift; a group holds [frame][segment of the group][park_bytes]:
+//   offset = chunk_in_ring * (num_waves * chunk * park_bytes) + (seg >> shift) * group_stride + frame * frame_stride
+//            + (seg & (G - 1)) * seg_stride
+//   G = 1          segment-major [segment][frame]: the frames a wave steps in ONE launch are contiguous;
+//   G = 16         the 16 segments ONE expansion wave reads of a frame are contiguous (24 KiB), a frame-kernel wave's
+//                  frames lie 24 KiB apart inside the group's 768 KiB;
+//   G >= num_waves frame-major [frame][segment]: batches launched one frame at a time.  There a launch writes one
+//                  short run of records per segment, and segment-major puts consecutive segments 48 KiB apart: 16 200
+//                  scattered partial lines per 1080p frame cost the one-frame kernel 2.6 of its 14.7 us, and its
+//                  expansion 10 of 64 us per chunk.
 __host__ __device__ __forceinline__ size_t park_offset(uint32_t slot, uint32_t seg, uint32_t chunk, uint32_t num_waves,
-                                                       uint32_t park_bytes, uint32_t seg_stride, uint32_t frame_stride) {
+                                                       uint32_t park_bytes, const ParkLayout &l) {
     const uint32_t cir = slot / chunk, fi = slot - cir * chunk;
-    return (size_t)cir * num_waves * chunk * park_bytes + (size_t)seg * seg_stride + (size_t)fi * frame_stride;
+    const uint32_t group = seg >> l.group_shift, r = seg - (group << l.group_shift);
+    return (size_t)cir * num_waves * chunk * park_bytes + (size_t)group * l.group_stride + (size_t)fi * l.frame_stride +
+           (size_t)r * l.seg_stride;
 }
 
 // what the host reads after a batch (adder_publish_kernel), in page-locked host memory
@@ -203,8 +213,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
     a.sc.running_t = b->ftab[f].running_t;
     a.sc.running_t_u32 = f32_as_u32(a.sc.running_t);
     a.sc.cth = b->ftab[f].cth;
-    a.park = b->park_ring + park_offset(slot, 0u, b->chunk, a.num_waves, b->park_bytes, b->park_seg_stride,
-                                         b->park_frame_stride);  // segment s: + s * park_seg_stride
+    a.park = b->park_ring + park_offset(slot, 0u, b->chunk, a.num_waves, b->park_bytes, b->park_layout);  // segment 0
     a.wtot = b->wtot_ring + (size_t)slot * a.num_waves;
     a.wpref = b->wpref_ring + (size_t)slot * a.num_waves;
     a.ftot = b->ftot_ring + slot;

@@ -60,6 +60,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, uint32_t lan
     return x;
 }
 
+// the batch's ring layout in SGPRs
+__device__ __forceinline__ ParkLayout park_layout_u(const BatchArgs *__restrict__ b) {
+    ParkLayout l;
+    l.group_shift = __builtin_amdgcn_readfirstlane(b->park_layout.group_shift);
+    l.group_stride = __builtin_amdgcn_readfirstlane(b->park_layout.group_stride);
+    l.frame_stride = __builtin_amdgcn_readfirstlane(b->park_layout.frame_stride);
+    l.seg_stride = __builtin_amdgcn_readfirstlane(b->park_layout.seg_stride);
+    return l;
+}
+
 // levels k >= 1 of one unit, straight from / to the deep planes (index k - 1)
 struct DeepGlobal {
     float *integ, *dt, *bdt;
@@ -246,10 +256,9 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     // uniform pointers advanced by adds (the ring wraps at `slots`)
     // (a launch never crosses a chunk boundary, so the segment's frames are contiguous: park_offset)
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
-    const uint32_t seg_stride_u = __builtin_amdgcn_readfirstlane(b->park_seg_stride);
-    const uint32_t frame_stride_u = __builtin_amdgcn_readfirstlane(b->park_frame_stride);
-    uint8_t *seg = uniform_ptr(b->park_ring) +
-                   park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, seg_stride_u, frame_stride_u);
+    const ParkLayout lay = park_layout_u(b);
+    const uint32_t frame_stride_u = lay.frame_stride;
+    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
     // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
     // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
     // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
@@ -514,11 +523,13 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
     const uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % b->slots);
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
     const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
-    const uint32_t seg_stride_u = __builtin_amdgcn_readfirstlane(b->park_seg_stride);
+    const ParkLayout lay = park_layout_u(b);  // (a pair never straddles a group: gw0 is even, groups hold 2^k >= 2 ... or 1)
+    const uint32_t seg_stride_u = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(park_offset(slot, gw0 + 1u, chunk_u, a.num_waves, park_bytes_u, lay) -
+                   park_offset(slot, gw0, chunk_u, a.num_waves, park_bytes_u, lay)));
     uint8_t *const seg = uniform_ptr(b->park_ring) +
                          park_offset(slot, __builtin_amdgcn_readfirstlane(gw0), chunk_u,
-                                     __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u, seg_stride_u,
-                                     __builtin_amdgcn_readfirstlane(b->park_frame_stride));
+                                     __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u, lay);
     uint32_t off = (upper ? seg_stride_u : 0u) + pos * kLeanRecBytes;  // (the upper half is segment gw0 + 1)
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
@@ -728,8 +739,7 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
         uint2 *const seg = reinterpret_cast<uint2 *>(
             park_ring_u + park_offset(slot, sgw, __builtin_amdgcn_readfirstlane(b->chunk), num_waves_u, park_bytes_u,
-                                      __builtin_amdgcn_readfirstlane(b->park_seg_stride),
-                                      __builtin_amdgcn_readfirstlane(b->park_frame_stride)));  // uniform
+                                      park_layout_u(b)));  // uniform
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u) {
@@ -856,7 +866,7 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
     const uint32_t u0 = gw * kWaveUnits + lane * N;
     for (uint32_t i = 0; i < nb; ++i) {
         const FrameArgs a = frame_args(b, f0 + i);
-        uint8_t *const seg = a.park + (size_t)gw * b->park_seg_stride;
+        uint8_t *const seg = b->park_ring + park_offset((f0 + i) % b->slots, gw, b->chunk, a.num_waves, b->park_bytes, b->park_layout);
         uint32_t lane_cnt = 0;
         bool bad = false;
 #pragma unroll
@@ -1080,10 +1090,13 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint32_t park_bytes = __builtin_amdgcn_readfirstlane(b->park_bytes);
     // wave-uniform bases (SGPRs); the lanes add 32-bit byte offsets
     const uint32_t chunk_frames = __builtin_amdgcn_readfirstlane(b->chunk);
-    const uint32_t seg_stride = __builtin_amdgcn_readfirstlane(b->park_seg_stride);  // between consecutive segments of one frame
-    const uint8_t *park = uniform_ptr(b->park_ring) +
-                          park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, seg_stride,
-                                      __builtin_amdgcn_readfirstlane(b->park_frame_stride));
+    // (the wave's kExpandSegs segments lie in one group -- seg0 is a multiple of kExpandSegs, a group holds 1 or a
+    // multiple of kExpandSegs segments -- so consecutive ones are a constant stride apart)
+    const ParkLayout lay = park_layout_u(b);
+    const uint32_t seg_stride = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
+                   park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay)));
+    const uint8_t *park = uniform_ptr(b->park_ring) + park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay);
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
     UnitCoord uc;
