@@ -1001,7 +1001,10 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
 // event its place; generic batches park one 8-byte record per event with its final offset.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
-constexpr uint32_t kXbufEvents = 640;                 // staging capacity of one wave, in events
+#ifndef ADDER_XBUF_EVENTS
+#define ADDER_XBUF_EVENTS 640
+#endif
+constexpr uint32_t kXbufEvents = ADDER_XBUF_EVENTS;   // staging capacity of one wave, in events (>= 192)
 constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
 
 struct UnitCoord {  // (row, offset in row) of a segment's first unit + the plane geometry (uniform)
