@@ -1108,3 +1108,30 @@ def test_sparse_steps_of_event_camera_sources(multi_mode, time_mode):
     fp = A.HipVideo(16, 16, 1)
     with pytest.raises(A.AdderHipError, match="Continuous"):
         fp.integrate_sparse(_sparse_steps(rng, 16, 16, 1, 5))
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_one_frame_per_launch_wide_kernel_ragged_planes(time_mode):
+    """adder_lean1w_kernel (4 units per lane, a wave covers a pair of segments, frame-major parking): frame by
+    frame through the per-frame call, on planes whose unit count is not a multiple of 4 / 128 / 256 (the input dword
+    of the lane that straddles the band's end, padding units, a band of exactly 4 units; 3 units falls back to the
+    2-unit kernel), gray and RGB, both time modes, with the oracle's chunk offsets."""
+    for (W, H, Cn), kind in (((37, 23, 1), "noise"), ((61, 17, 3), "jitter"), ((130, 9, 1), "steps"),
+                             ((259, 3, 1), "noise"), ((2, 2, 1), "noise"), ((1, 3, 1), "noise"),
+                             ((640, 7, 1), "runs")):
+        clip = clips.make_clip(kind, 14, H, W, Cn, seed=W * 131 + H)
+        n = run_pair(clip, time_mode=time_mode, multi_mode=O.COLLAPSE, dtm=255, crf=CRFS[0])
+        assert n > 0, (W, H, Cn)
+    # ... and as one device batch stepped one frame per launch (graph replay + frame-major ring), a band of a plane
+    A = _hip()
+    clip = clips.make_clip("noise", 40, 45, 77, 1, seed=5)
+    tm = A.TIME_DELTA_T if time_mode == O.DELTA_T else A.TIME_ABSOLUTE_T
+    base, offs = _events_device(A, clip, time_mode=tm, multi_mode=A.MULTI_COLLAPSE, dtm=255, row_band=(3, 41))
+    one, offs1 = _events_device(A, clip, time_mode=tm, multi_mode=A.MULTI_COLLAPSE, dtm=255, row_band=(3, 41),
+                                frames_per_launch=1)
+    assert np.array_equal(offs, offs1) and np.array_equal(base, one)
+    ov = O.Video(77, 38, 1, row_begin=3, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    want = np.concatenate([ov.integrate_matrix(clip[k, 3:41]) for k in range(40)])
+    assert np.array_equal(one, want)
