@@ -19,6 +19,9 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef ADDER_LEAN1_WIDE
 #define ADDER_LEAN1_WIDE 1  // one frame per launch: the 4-units-per-lane kernel (16-byte accesses)
 #endif
+#ifndef ADDER_SCAN_THREADS
+#define ADDER_SCAN_THREADS 512
+#endif
 #ifndef ADDER_LEAN_WAVES_PER_SIMD
 #define ADDER_LEAN_WAVES_PER_SIMD 8
 #endif

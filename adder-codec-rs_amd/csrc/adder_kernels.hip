@@ -902,11 +902,33 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
 // Scan: exclusive prefix of the per-segment event counts of one frame per block
 // (blockIdx.x = frame inside the chunk) and the frame's total.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kScanThreads = 1024;
+// 512 threads: in the pipelined graph this kernel starts beside the resident frame kernel of the next chunk (5
+// waves per SIMD), and a 1024-thread block needs 4 free wave slots on EVERY SIMD of one CU: it queued for 32 us
+// where it runs 8.  A thread owns `per` consecutive uint4 groups; up to kScanRegGroups of them are fetched in one
+// go and kept in registers for both passes.
+constexpr uint32_t kScanThreads = ADDER_SCAN_THREADS;
+#ifndef ADDER_SCAN_REG_GROUPS
+#define ADDER_SCAN_REG_GROUPS 8
+#endif
+constexpr uint32_t kScanRegGroups = ADDER_SCAN_REG_GROUPS;
+__device__ __forceinline__ uint32_t scan_lo4(const uint4 &v) {
+    return (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+}
+__device__ __forceinline__ uint32_t scan_hi4(const uint4 &v) { return (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16); }
+__device__ __forceinline__ uint4 scan_prefix4(const uint4 &v, uint32_t &run) {
+    uint4 o;
+    o.x = run;
+    o.y = o.x + (v.x & 0xffffu);
+    o.z = o.y + (v.y & 0xffffu);
+    o.w = o.z + (v.z & 0xffffu);
+    run = o.w + (v.w & 0xffffu);
+    return o;
+}
 __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
     const FrameArgs a = frame_args(b, f0 + blockIdx.x);
     timeline_mark(b, 1u, f0, false);
     __shared__ uint32_t s_part[kScanThreads / kWave];
+    __shared__ uint32_t s_recs[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wid = tid / kWave;
@@ -917,14 +939,25 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     const uint32_t g1 = min(g0 + per, groups);
     const uint4 *src = reinterpret_cast<const uint4 *>(a.wtot);
     uint4 *dst = reinterpret_cast<uint4 *>(a.wpref);
+    const bool in_regs = per <= kScanRegGroups;  // uniform
+    uint4 v[kScanRegGroups];
     uint32_t sum = 0, recs = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
-        const uint4 v = src[g];
-        sum += (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
-        recs += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanRegGroups; ++k) v[k] = g0 + k < g1 ? src[g0 + k] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanRegGroups; ++k) {
+            sum += scan_lo4(v[k]);
+            recs += scan_hi4(v[k]);
+        }
+    } else {
+        for (uint32_t g = g0; g < g1; ++g) {
+            const uint4 w = src[g];
+            sum += scan_lo4(w);
+            recs += scan_hi4(w);
+        }
     }
     // parked records of the frame (diagnostics: bench.py's byte accounting); the offsets kernel adds the frames up
-    __shared__ uint32_t s_recs[kScanThreads / kWave];
 #pragma unroll
     for (uint32_t o = kWave / 2; o > 0; o >>= 1) recs += __shfl_down(recs, o, kWave);
     if (lane == 0) s_recs[wid] = recs;
@@ -940,15 +973,14 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
         rec_total += s_recs[w];
     }
     uint32_t run = base + incl - sum;
-    for (uint32_t g = g0; g < g1; ++g) {
-        const uint4 v = src[g];
-        uint4 o;
-        o.x = run;
-        o.y = o.x + (v.x & 0xffffu);
-        o.z = o.y + (v.y & 0xffffu);
-        o.w = o.z + (v.z & 0xffffu);
-        run = o.w + (v.w & 0xffffu);
-        dst[g] = o;
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanRegGroups; ++k) {
+            const uint4 o = scan_prefix4(v[k], run);
+            if (g0 + k < g1) dst[g0 + k] = o;
+        }
+    } else {
+        for (uint32_t g = g0; g < g1; ++g) dst[g] = scan_prefix4(src[g], run);
     }
     if (tid == 0) {
         *a.ftot = total;
@@ -960,20 +992,38 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
 // frame_offsets[f+1] = frame_offsets[f] + events(f) for the frames of the chunk, in order.
 // The batch's first chunk also starts the chain (frame_offsets[0] = 0) and the record count, so the host queues no
 // memset in front of a batch.
-__global__ void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t nf) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One wave: lane i fetches frame f0 + i's totals (one memory round trip for the whole chunk instead of a serial
+// chain of nf of them: 8 -> 3 us per chunk), a wave prefix sum chains them.  nf <= kMaxChunk <= 64.
+__global__ __launch_bounds__(kWave) void adder_offsets_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t nf) {
+    if (blockIdx.x != 0) return;
     timeline_mark(b, 2u, f0, false);
+    const uint32_t lane = threadIdx.x;
     uint64_t *offs = b->base.frame_offsets;
+    const uint32_t slots = b->slots;
     uint64_t run = f0 == 0u ? 0ull : offs[f0];
     uint64_t recs = (f0 == 0u || !b->rec_total) ? 0ull : *b->rec_total;
-    if (f0 == 0u) offs[0] = 0ull;
-    for (uint32_t i = 0; i < nf; ++i) {
-        const uint32_t slot = (f0 + i) % b->slots;
-        run += b->ftot_ring[slot];
-        recs += b->ftot_ring[b->slots + slot];
-        offs[f0 + i + 1] = run;
+    if (lane == 0u && f0 == 0u) offs[0] = 0ull;
+    for (uint32_t i0 = 0; i0 < nf; i0 += kWave) {  // (one trip: a chunk holds <= kMaxChunk <= 64 frames)
+        const uint32_t i = i0 + lane;
+        uint64_t ev = 0ull, rc = 0ull;
+        if (i < nf) {
+            const uint32_t slot = (f0 + i) % slots;
+            ev = b->ftot_ring[slot];
+            rc = b->ftot_ring[slots + slot];
+        }
+#pragma unroll
+        for (uint32_t o = 1; o < kWave; o <<= 1) {  // inclusive prefix sums over the lanes
+            const uint64_t e = __shfl_up(ev, o, kWave), r = __shfl_up(rc, o, kWave);
+            if (lane >= o) {
+                ev += e;
+                rc += r;
+            }
+        }
+        if (i < nf) offs[f0 + i + 1u] = run + ev;
+        run += __shfl(ev, kWave - 1, kWave);
+        recs += __shfl(rc, kWave - 1, kWave);
     }
-    if (b->rec_total) *b->rec_total = recs;
+    if (b->rec_total && lane == 0u) *b->rec_total = recs;
     timeline_mark(b, 2u, f0, true);
 }
 
