@@ -86,12 +86,16 @@ struct AdderHipCtx {
     // it is scanned and expanded)
     uint8_t *park_ring = nullptr;    // [slots][num_waves][park_bytes]
     uint32_t park_group_shift = 0;   // ring layout of temporally blocked batches (park_offset)
+    // graph instances no longer wanted (tuning losers, evicted batch lengths): destroyed with the context.  This HIP
+    // runtime (ROCm 7.0) crashed in hip::Graph::UpdateStreams at a later hipGraphLaunch of ANOTHER instance once a
+    // few dozen instances had been destroyed mid-life (rocgdb backtrace; tests: 22 batch lengths on one context).
+    std::vector<hipGraphExec_t> retired_execs;
     uint32_t park_bytes = 0;         // scratch of one segment of one frame
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
     uint32_t chunk = 1, slots = 2, ring_chunks = 3;
-    uint32_t lean_blocks_per_cu = 5, expand_blocks_per_cu = 3;
+    uint32_t lean_blocks_per_cu = 4, expand_blocks_per_cu = 3;  // (4 x 32 KB of input staging + one expansion block fit a CU's LDS)
     uint32_t gen_blocks_per_cu = 0, gen_expand_blocks_per_cu = 0;  // generic variants: 0 = full grids
     uint32_t frames_per_launch = kMaxFramesPerLaunch;  // temporal blocking depth of the frame kernels
     uint32_t num_waves = 0;
@@ -282,6 +286,7 @@ static void free_ctx(AdderHipCtx *c) {
     for (auto &kv : c->graphs)
         for (hipGraphExec_t e : kv.second.cand)
             if (e) (void)hipGraphExecDestroy(e);
+    for (hipGraphExec_t e : c->retired_execs) (void)hipGraphExecDestroy(e);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->h_result) (void)hipHostFree(c->h_result);
@@ -556,7 +561,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         {
             // workgroups per CU of the lean frame kernel and of the expansion when they share the chip (0: full grids)
             const char *lb = getenv("ADDER_HIP_LEAN_BLOCKS_PER_CU"), *eb = getenv("ADDER_HIP_EXPAND_BLOCKS_PER_CU");
-            c->lean_blocks_per_cu = lb ? (uint32_t)atoi(lb) : 5u;
+            c->lean_blocks_per_cu = lb ? (uint32_t)atoi(lb) : 4u;
             c->expand_blocks_per_cu = eb ? (uint32_t)atoi(eb) : 3u;
         }
         if (const char *e = getenv("ADDER_HIP_GEN_BLOCKS_PER_CU")) c->gen_blocks_per_cu = (uint32_t)atoi(e);
@@ -766,7 +771,7 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     if (c->park_bytes >= bytes && c->park_ring) return ADDER_OK;
     for (auto &kv : c->graphs)  // they bake the chunking
         for (hipGraphExec_t e : kv.second.cand)
-            if (e) (void)hipGraphExecDestroy(e);
+            if (e) c->retired_execs.push_back(e);
     c->graphs.clear();
     c->tune_pending = false;
     void *old[] = {c->park_ring, c->wtot_ring, c->wpref_ring, c->ftot_ring};
@@ -943,7 +948,7 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     if (it == c->graphs.end()) {
         if (c->graphs.size() >= 8) {  // keep the cache small
             for (hipGraphExec_t e : c->graphs.begin()->second.cand)
-                if (e) (void)hipGraphExecDestroy(e);
+                if (e) c->retired_execs.push_back(e);
             c->graphs.erase(c->graphs.begin());
         }
         it = c->graphs.emplace(key, AdderHipCtx::GraphTune{}).first;
@@ -993,7 +998,7 @@ static void graph_tune_report(AdderHipCtx *c, float ms) {
             if (g.ms[k] < g.ms[best]) best = k;
         for (int k = 0; k < (int)g.cand.size(); ++k)
             if (k != best) {
-                (void)hipGraphExecDestroy(g.cand[k]);
+                c->retired_execs.push_back(g.cand[k]);
                 g.cand[k] = nullptr;
             }
         g.chosen = best;
@@ -1144,7 +1149,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         // (the captured graphs hold the description's address)
         for (auto &kv : c->graphs)
             for (hipGraphExec_t e : kv.second.cand)
-                if (e) (void)hipGraphExecDestroy(e);
+                if (e) c->retired_execs.push_back(e);
         c->graphs.clear();
         c->tune_pending = false;
         int rc_ = alloc_batch_desc(c, std::max<size_t>(num_frames, 2 * c->ftab_cap));

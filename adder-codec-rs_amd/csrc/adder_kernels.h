@@ -30,7 +30,7 @@ constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // units per 
 constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // units per K1 block
 constexpr uint32_t kLeanWavesPerSimd = ADDER_LEAN_WAVES_PER_SIMD;  // register budget of the lean K1
 #ifndef ADDER_MAX_FRAMES_PER_LAUNCH
-#define ADDER_MAX_FRAMES_PER_LAUNCH 32
+#define ADDER_MAX_FRAMES_PER_LAUNCH 64
 #endif
 constexpr uint32_t kMaxFramesPerLaunch = ADDER_MAX_FRAMES_PER_LAUNCH;  // temporal blocking depth of K1 (<= 64)
 constexpr uint32_t kMaxChunk = kMaxFramesPerLaunch;                // frames per scan/expand launch

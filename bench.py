@@ -232,7 +232,7 @@ def main():
         hv.set_frames_per_launch(1)
         step("none")
         k1_one_pair_us = hv.last_launch_avg_us()
-        # ... and with ONE event pair around each chunk's run of 32 launches (no event packets between the
+        # ... and with ONE event pair around each chunk's run of launches (no event packets between the
         # kernels: what is left on top of the kernel time is the gap between two dependent launches)
         hv.set_launch_timing(2)
         step("none")
@@ -344,7 +344,7 @@ def main():
             "launch_avg_us_event_pair_per_launch": round(k1_one_pair_us, 3),
             "note": "the frame kernel alone with the state streamed from HBM every frame (per-frame consume contract): "
                     "bytes it really moves = 1 input + 16 state in + 16 state out + 12 per parked record.  launch_avg_us "
-                    "= one HIP-event pair around each chunk's run of 32 back-to-back launches / 32 (kernel + the gap "
+                    "= one HIP-event pair around each chunk's run of 64 back-to-back launches / 64 (kernel + the gap "
                     "to the next dependent launch); with a pair around EVERY launch the event packets themselves add "
                     "~2 us (launch_avg_us_event_pair_per_launch).  rocprofv3's kernel duration of the same command is "
                     "in profiles/ (kernel stats, adder_lean1w_kernel)",

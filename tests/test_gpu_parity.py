@@ -655,8 +655,8 @@ def test_lake_golden_bytes_pipelined_stream(golden_dir):
 
 
 def test_batch_lengths_around_chunk_and_lag_boundaries():
-    """The scratch ring holds two chunks of 32 frames and a launch steps up to 32 frames: batch lengths on
-    both sides of every boundary, several submission forms, consecutive batches on one context -- always
+    """The scratch ring holds three chunks of 64 frames and a launch steps up to 64 frames: batch lengths on
+    both sides of every boundary (launch depth, chunk, ring wrap-around at 192), several submission forms, consecutive batches on one context -- always
     the oracle's stream and frame offsets."""
     import subprocess, sys
     code = r'''
@@ -667,7 +667,7 @@ import adder_amd as A
 from oracle import oracle as O
 import clips
 W, H = 70, 23
-lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 5]
+lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 257, 5]
 clip = clips.make_clip("runs", sum(lens), H, W, 1, seed=4)
 ov = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
 ov.set_crf_parameters(0, 10); ov.reset_c_thresh(0)
@@ -1032,7 +1032,7 @@ def test_graph_instances_are_interchangeable_and_the_plan_settles():
     stream, the choice must be made after twelve of them, and reset / finish without host copies must keep working."""
     import torch
     A = _hip()
-    W, H, T = 640, 360, 100  # 4 chunks of 32 frames
+    W, H, T = 640, 360, 200  # 4 chunks (3 of 64 frames + one of 8)
     st = torch.cuda.current_stream().cuda_stream
     d_frames = torch.empty((T, W * H), dtype=torch.uint8, device="cuda")
     A.synth_clip_device(d_frames, A.CONTENT_SCENE, W, H, 1, num_frames=T, stream=st)
