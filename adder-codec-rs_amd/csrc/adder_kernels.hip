@@ -145,6 +145,48 @@ __device__ __forceinline__ void gstore(void *base, uint32_t byte_off, V v) {
     __builtin_memcpy(&r, &v, sizeof(V));
     *reinterpret_cast<ADDER_GLOBAL R *>((ADDER_GLOBAL char *)base + byte_off) = r;
 }
+// The same with the non-temporal hint (`nt`: the line is marked for early eviction): for bytes that are
+// touched once -- the event stream on its way out, parked records on their way back in.
+template <class V>
+__device__ __forceinline__ V gload_nt(const void *base, uint32_t byte_off) {
+    using R = typename RawOf<sizeof(V)>::type;
+    const R r = __builtin_nontemporal_load(reinterpret_cast<const ADDER_GLOBAL R *>((const ADDER_GLOBAL char *)base + byte_off));
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+}
+template <class V>
+__device__ __forceinline__ void gstore_nt(void *base, uint32_t byte_off, V v) {
+    using R = typename RawOf<sizeof(V)>::type;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<ADDER_GLOBAL R *>((ADDER_GLOBAL char *)base + byte_off));
+}
+#ifndef ADDER_NT_EVENTS
+#define ADDER_NT_EVENTS 1
+#endif
+#ifndef ADDER_NT_RECLOAD
+#define ADDER_NT_RECLOAD 1
+#endif
+#ifndef ADDER_NT_INPUT
+#define ADDER_NT_INPUT 1
+#endif
+#ifndef ADDER_NT_STATE
+#define ADDER_NT_STATE 1
+#endif
+#ifndef ADDER_NT_RECSTORE
+#define ADDER_NT_RECSTORE 0
+#endif
+template <class V>
+__device__ __forceinline__ void gstore_ev(void *base, uint32_t byte_off, V v) {
+    if (ADDER_NT_EVENTS) gstore_nt<V>(base, byte_off, v);
+    else gstore<V>(base, byte_off, v);
+}
+template <class V>
+__device__ __forceinline__ V gload_rec(const void *base, uint32_t byte_off) {
+    if (ADDER_NT_RECLOAD) return gload_nt<V>(base, byte_off);
+    return gload<V>(base, byte_off);
+}
 // a pointer that is the same in every lane, forced into SGPRs
 template <class T>
 __device__ __forceinline__ T *uniform_ptr(T *p) {
@@ -154,25 +196,27 @@ __device__ __forceinline__ T *uniform_ptr(T *p) {
                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x));
 }
 
-template <class T>
+template <bool NT = false, class T>
 __device__ __forceinline__ void load_vec(const T *plane, uint32_t u0, T (&v)[kUnitsPerLane]) {
     using V = typename VecOf<T, kUnitsPerLane>::type;
-    const V x = gload<V>(plane, u0 * (uint32_t)sizeof(T));
+    const V x = NT ? gload_nt<V>(plane, u0 * (uint32_t)sizeof(T)) : gload<V>(plane, u0 * (uint32_t)sizeof(T));
     __builtin_memcpy(v, &x, sizeof(V));
 }
-template <class T>
+template <bool NT = false, class T>
 __device__ __forceinline__ void store_vec(T *plane, uint32_t u0, const T (&v)[kUnitsPerLane]) {
     using V = typename VecOf<T, kUnitsPerLane>::type;
     V x;
     __builtin_memcpy(&x, v, sizeof(V));
-    gstore<V>(plane, u0 * (uint32_t)sizeof(T), x);
+    if (NT) gstore_nt<V>(plane, u0 * (uint32_t)sizeof(T), x);
+    else gstore<V>(plane, u0 * (uint32_t)sizeof(T), x);
 }
 
 // the lane's kUnitsPerLane input bytes of one frame, packed little-endian
 __device__ __forceinline__ uint32_t load_input(const uint8_t *frame, uint32_t u0, uint32_t n_units) {
     uint32_t w = 0u;
     if (u0 + kUnitsPerLane <= n_units) {
-        w = gload<typename VecOf<uint8_t, kUnitsPerLane>::type>(frame, u0);
+        using InV = typename VecOf<uint8_t, kUnitsPerLane>::type;
+        w = ADDER_NT_INPUT ? gload_nt<InV>(frame, u0) : gload<InV>(frame, u0);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < kUnitsPerLane; ++j)
@@ -206,16 +250,16 @@ struct LeanRaw {  // a segment's state as loaded (one memory round trip, nothing
     uint32_t vin_w;
 };
 
-template <bool ABS_T>
+template <bool ABS_T, bool NT = false>
 __device__ __forceinline__ void lean_load(const FrameArgs &a, uint32_t u0, bool full, LeanRaw &r) {
-    load_vec(a.hdr, u0, r.hdrv);
+    load_vec<NT>(a.hdr, u0, r.hdrv);
     r.vin_w = load_input(a.frame, u0, full ? 0xffffffffu : a.n_units);
     // level 0 is fetched whether or not the unit has one (m == 0 leaves it unread by the step)
-    load_vec(a.integ0, u0, r.iv);
-    load_vec(a.dt0, u0, r.dv);
-    load_vec(a.bdt0, u0, r.bv);
+    load_vec<NT>(a.integ0, u0, r.iv);
+    load_vec<NT>(a.dt0, u0, r.dv);
+    load_vec<NT>(a.bdt0, u0, r.bv);
     if (ABS_T) {
-        load_vec(a.lastf, u0, r.lfv);
+        load_vec<NT>(a.lastf, u0, r.lfv);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < kUnitsPerLane; ++j) r.lfv[j] = 0.0f;
@@ -319,7 +363,10 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
-            if (has) gstore(seg, pos * kLeanRecBytes, rec[j]);
+            if (has) {
+                if (ADDER_NT_RECSTORE != 0 && NB_MAX > 1u) gstore_nt(seg, pos * kLeanRecBytes, rec[j]);
+                else gstore(seg, pos * kLeanRecBytes, rec[j]);
+            }
             pos += has ? 1u : 0u;
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
@@ -346,11 +393,12 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
             bv[j] = px[j].bdt;
             lfv[j] = px[j].lastf;
         }
-        store_vec(a.hdr, u0, hdrv);
-        store_vec(a.integ0, u0, iv);
-        store_vec(a.dt0, u0, dv);
-        store_vec(a.bdt0, u0, bv);
-        if (ABS_T) store_vec(a.lastf, u0, lfv);
+        constexpr bool NTS = ADDER_NT_STATE != 0 && NB_MAX > 1u;  // blocked launches: the state comes back a chunk later
+        store_vec<NTS>(a.hdr, u0, hdrv);
+        store_vec<NTS>(a.integ0, u0, iv);
+        store_vec<NTS>(a.dt0, u0, dv);
+        store_vec<NTS>(a.bdt0, u0, bv);
+        if (ABS_T) store_vec<NTS>(a.lastf, u0, lfv);
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)
@@ -392,7 +440,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
         LeanRaw raw;
-        lean_load<ABS_T>(a, u0, full, raw);
+        lean_load<ABS_T, ADDER_NT_STATE != 0>(a, u0, full, raw);
         lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
     }
     timeline_mark(b, 0u, f, true);
@@ -465,7 +513,7 @@ __device__ __forceinline__ void wide_load_state(const Lean1wArgs &st, uint32_t u
 }
 __device__ __forceinline__ void wide_load_input(const uint8_t *frame, uint32_t n_units, uint32_t u0, WideRaw &r) {
     const uint32_t ua = min(u0, n_units - kWideUnits);
-    r.vin = gload<uint32_t>(frame, ua) >> (8u * min(u0 - ua, 3u));
+    r.vin = (ADDER_NT_INPUT ? gload_nt<uint32_t>(frame, ua) : gload<uint32_t>(frame, ua)) >> (8u * min(u0 - ua, 3u));
 }
 
 template <bool ABS_T, bool FULL>
@@ -1091,15 +1139,15 @@ __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, u
     uint32_t head = (4u - phase) & 3u;
     head = head < nd ? head : nd;
     uint32_t *const dst = out_dw + gd0;  // uniform 64-bit base; the lanes add 32-bit offsets
-    if (lane < head) gstore<uint32_t>(dst, lane * 4u, xb[phase + lane]);
+    if (lane < head) gstore_ev<uint32_t>(dst, lane * 4u, xb[phase + lane]);
     const uint32_t body = (nd - head) >> 2;  // whole 16-byte blocks
     const uint32_t b0 = phase + head;        // a multiple of 4
     for (uint32_t k = lane; k < body; k += kWave) {
         const uint4 v = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
-        gstore<uint4>(dst, (head + 4u * k) * 4u, v);
+        gstore_ev<uint4>(dst, (head + 4u * k) * 4u, v);
     }
     const uint32_t tail = (nd - head) & 3u;
-    if (lane < tail) gstore<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
+    if (lane < tail) gstore_ev<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
 }
 
 // Stages the <= 3 events of one decoded lean record at dword w of the buffer.
@@ -1178,7 +1226,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             first[p] = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                const LeanRec r = gload<LeanRec>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * kLeanRecBytes);
+                const LeanRec r = gload_rec<LeanRec>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * kLeanRecBytes);
                 first[p] = make_uint4(r.ta, r.tc, r.w, 0u);
             }
         }
@@ -1188,7 +1236,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
             first[q] = make_uint4(0u, 0u, 0u, 0u);
             if (lane < parked) {
-                const uint2 v = gload<uint2>(park + (size_t)q * seg_stride, lane * kGenRecBytes);
+                const uint2 v = gload_rec<uint2>(park + (size_t)q * seg_stride, lane * kGenRecBytes);
                 first[q] = make_uint4(v.x, v.y, 0u, 0u);
             }
         }
@@ -1257,7 +1305,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
-                            const LeanRec r = gload<LeanRec>(seg_park, (i0 + lane) * kLeanRecBytes);
+                            const LeanRec r = gload_rec<LeanRec>(seg_park, (i0 + lane) * kLeanRecBytes);
                             rw = make_uint4(r.ta, r.tc, r.w, 0u);
                         }
                         lean_round(rw, 0u);
@@ -1321,7 +1369,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     if (i0 == 0u)
                         sl = make_uint2(first[q].x, first[q].y);
                     else
-                        sl = gload<uint2>(seg_park, i * kGenRecBytes);
+                        sl = gload_rec<uint2>(seg_park, i * kGenRecBytes);
                     const uint32_t pos = sl.y >> 16;  // final offset inside the segment
                     if (pos < e0 || pos >= e0 + piece) continue;
                     uint32_t c;
