@@ -171,6 +171,9 @@ __device__ __forceinline__ void gstore_nt(void *base, uint32_t byte_off, V v) {
 #ifndef ADDER_NT_INPUT
 #define ADDER_NT_INPUT 1
 #endif
+#ifndef ADDER_LDS_DIRECT_INPUT
+#define ADDER_LDS_DIRECT_INPUT 1
+#endif
 #ifndef ADDER_NT_STATE
 #define ADDER_NT_STATE 1
 #endif
@@ -310,17 +313,45 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     // loop only ever issues stores to memory.
     using InT = typename VecOf<uint8_t, N>::type;
     InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame][lane]
-    {
-        // (no control flow between the loads: frames past the launch's last one re-read that one)
+    if constexpr (NB_MAX > 1u) {
+        // (frames past the launch's last one re-read that one: no control flow between the loads)
         const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-        uint32_t vin_all[NB_MAX];
+#if ADDER_LDS_DIRECT_INPUT
+        // Straight into LDS (global_load_lds_dwordx4: no staging registers -- 63 of them held the kernel at 111
+        // VGPRs): lane i fetches 16 bytes of frame 8 g + i / 8, and the instruction parks lane i's bytes at
+        // M0 + 16 i, which is exactly the [frame][128 bytes] layout the loop reads.  Needs whole, 16-byte aligned
+        // segments; anything else takes the register path eight frames at a time.
+        static_assert(kWaveUnits == 128u && NB_MAX % 8u == 0u, "eight frames of one segment per instruction");
+        const bool direct = FULL && __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+        if (direct) {
+            const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
 #pragma unroll
-        for (uint32_t k = 1; k < NB_MAX; ++k) {  // (row 0 is raw.vin_w, in a register already)
-            const uint32_t kk = k < nb ? k : nb - 1u;  // uniform
-            vin_all[k] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+            for (uint32_t g = 0; g < NB_MAX / 8u; ++g) {
+                uint32_t k = g * 8u + (lane >> 3);
+                k = k < nb ? k : nb - 1u;
+                __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
+                                                 (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                                 ADDER_NT_INPUT ? 2 : 0);
+            }
+        } else
+#endif
+        {
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < NB_MAX; k0 += 8u) {
+                uint32_t vin8[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) {
+                    const uint32_t k = k0 + q;
+                    const uint32_t kk = k < nb ? k : nb - 1u;  // uniform
+                    vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(k0 + q) * kWave] = (InT)vin8[q];
+            }
         }
-#pragma unroll
-        for (uint32_t k = 1; k < NB_MAX; ++k) in_lds[k * kWave] = (InT)vin_all[k];
+        // vmcnt(0): everything requested so far has landed -- the LDS writes of the direct loads, the frame table --
+        // so that nothing inside the frame loop ever waits on memory (a wait there would also wait for the record stores)
+        __builtin_amdgcn_s_waitcnt(0x0f70);
     }
     uint32_t vin_w = raw.vin_w;
     uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
@@ -424,6 +455,9 @@ __device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b
 template <bool ABS_T>
 #ifdef ADDER_LEAN_MAX_WAVES
 __attribute__((amdgpu_waves_per_eu(1, ADDER_LEAN_MAX_WAVES)))
+#endif
+#ifdef ADDER_LEAN_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(ADDER_LEAN_NUM_VGPR)))
 #endif
 __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
