@@ -870,13 +870,6 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
                 a.cctr_px[u0 + j] = cctrv[j];
             }
         }
-        if (perpx) {
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                a.cth_px[u0 + j] = cthv[j];
-                a.cctr_px[u0 + j] = cctrv[j];
-            }
-        }
         if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j)

@@ -275,7 +275,7 @@ def test_synth_clip_matches_oracle_generator():
 
 
 def _events_device(A, clip_np, *, time_mode, multi_mode, dtm, frames_per_launch=None, env=None, row_band=None,
-                   H_total=None):
+                   H_total=None, misalign=0):
     """Runs a clip resident in HBM through the device-pointer entry point; returns (events, offsets)."""
     import torch
     T, H, W, Cn = clip_np.shape
@@ -285,7 +285,14 @@ def _events_device(A, clip_np, *, time_mode, multi_mode, dtm, frames_per_launch=
     hv.set_crf_parameters(0, 10)
     if frames_per_launch is not None:
         hv.set_frames_per_launch(frames_per_launch)
-    d_frames = torch.from_numpy(np.ascontiguousarray(clip_np[:, y0:y1]).reshape(T, -1)).cuda()
+    h_frames = torch.from_numpy(np.ascontiguousarray(clip_np[:, y0:y1]).reshape(T, -1))
+    if misalign:  # the frames start `misalign` bytes into an allocation (a caller's pointer need not be aligned)
+        flat = torch.empty(h_frames.numel() + 64, dtype=torch.uint8, device="cuda")
+        d_frames = flat[misalign:misalign + h_frames.numel()].view(T, -1)
+        d_frames.copy_(h_frames)
+        assert d_frames.data_ptr() % 16 == misalign % 16
+    else:
+        d_frames = h_frames.cuda()
     d_ev = torch.empty((int(d_frames.numel() * 1.3) + 1024, 3), dtype=torch.int32, device="cuda")
     d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
     hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
@@ -1135,3 +1142,30 @@ def test_one_frame_per_launch_wide_kernel_ragged_planes(time_mode):
     ov.reset_c_thresh(0)
     want = np.concatenate([ov.integrate_matrix(clip[k, 3:41]) for k in range(40)])
     assert np.array_equal(one, want)
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_blocked_kernel_input_paths_direct_to_lds_and_register_fallback(time_mode):
+    """adder_lean_kernel parks the launch's input bytes in LDS either with global_load_lds_dwordx4 (whole, 16-byte
+    aligned segments) or through registers eight frames at a time (anything else).  Both against the oracle, 70 frames
+    (a launch of 64 and one of 6): an aligned plane of whole segments (direct), the same bytes 1 and 4 bytes into an
+    allocation (fallback for every segment), a plane whose frames are 5250 bytes apart (misaligned from frame 1 on,
+    last segment not whole), and a band of a plane (row_begin != 0)."""
+    A = _hip()
+    tm = A.TIME_DELTA_T if time_mode == O.DELTA_T else A.TIME_ABSOLUTE_T
+    T = 70
+    for (W, H), band, kind in (((256, 20), None, "noise"), ((250, 21), None, "jitter"), ((256, 40), (8, 24), "steps")):
+        clip = clips.make_clip(kind, T, H, W, 1, seed=W + H)
+        y0, y1 = (0, H) if band is None else band
+        ov = O.Video(W, y1 - y0, 1, row_begin=y0, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255,
+                     delta_t_max=255)
+        ov.set_crf_parameters(0, 10)
+        ov.reset_c_thresh(0)
+        per_frame = [ov.integrate_matrix(clip[k, y0:y1]) for k in range(T)]
+        want = np.concatenate(per_frame)
+        want_offs = np.concatenate([[0], np.cumsum([len(e) for e in per_frame])])
+        for mis in (0, 1, 4):
+            got, offs = _events_device(A, clip, time_mode=tm, multi_mode=A.MULTI_COLLAPSE, dtm=255, row_band=band,
+                                       misalign=mis)
+            assert np.array_equal(offs.astype(np.int64), want_offs), (W, H, mis)
+            assert np.array_equal(got, want), (W, H, mis)
