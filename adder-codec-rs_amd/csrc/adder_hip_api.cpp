@@ -1180,11 +1180,18 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
-        b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes};
+        b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes, 31u, 0xffffffffu};
     } else {
         uint32_t sh = c->park_group_shift;
         while (sh && ((c->num_waves & ((1u << sh) - 1u)) || ((uint64_t)c->chunk * c->park_bytes << sh) > 0xffffffffull)) --sh;
-        b.park_layout = ParkLayout{sh, (c->chunk * c->park_bytes) << sh, c->park_bytes << sh, c->park_bytes};
+        b.park_layout = ParkLayout{sh, (c->chunk * c->park_bytes) << sh, c->park_bytes << sh, c->park_bytes, 31u, 0xffffffffu};
+        // segment-major: rotate the frame slots by the segment's group of 16 (needs a power-of-two chunk)
+        static const bool rot_on = [] { const char *e = getenv("ADDER_HIP_PARK_ROT"); return !e || atoi(e) != 0; }();
+        if (rot_on && sh == 0u && c->chunk >= 2u && (c->chunk & (c->chunk - 1u)) == 0u &&
+            (uint64_t)c->chunk * c->park_bytes <= 0xffffffffull) {
+            b.park_layout.rot_shift = 4u;
+            b.park_layout.rot_mask = c->chunk - 1u;
+        }
     }
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;

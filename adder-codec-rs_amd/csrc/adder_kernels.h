@@ -108,6 +108,13 @@ struct ParkLayout {
     uint32_t group_stride;  // bytes between consecutive groups
     uint32_t frame_stride;  // bytes between consecutive frame slots of one segment
     uint32_t seg_stride;    // bytes between consecutive segments inside a group
+    // Rotation of the frame slots (segment-major blocked layout only): segment s keeps frame slot fi at
+    // (fi + (s >> rot_shift)) & rot_mask.  Without it every wave of the chip is, at any moment, writing (frame kernel)
+    // or reading (expansion: all waves work on the same frame) addresses that agree in their low 17 bits -- which
+    // memory channels that hits is then left to how the hardware hashes the upper bits of wherever the ring happened
+    // to be mapped.  rot_shift >= 4 keeps the 16 segments of one expansion wave a constant stride apart.
+    // Off: rot_shift = 31, rot_mask = 0xffffffff.
+    uint32_t rot_shift, rot_mask;
 };
 
 // What adder_lean1w_kernel takes as kernel arguments (by value): the level-0 planes and the band's size.
@@ -153,7 +160,8 @@ constexpr uint32_t kTimelineChunks = 64;
 //                  expansion 10 of 64 us per chunk.
 __host__ __device__ __forceinline__ size_t park_offset(uint32_t slot, uint32_t seg, uint32_t chunk, uint32_t num_waves,
                                                        uint32_t park_bytes, const ParkLayout &l) {
-    const uint32_t cir = slot / chunk, fi = slot - cir * chunk;
+    const uint32_t cir = slot / chunk;
+    const uint32_t fi = (slot - cir * chunk + (seg >> l.rot_shift)) & l.rot_mask;
     const uint32_t group = seg >> l.group_shift, r = seg - (group << l.group_shift);
     return (size_t)cir * num_waves * chunk * park_bytes + (size_t)group * l.group_stride + (size_t)fi * l.frame_stride +
            (size_t)r * l.seg_stride;

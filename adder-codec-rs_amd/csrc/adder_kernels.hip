@@ -67,6 +67,8 @@ __device__ __forceinline__ ParkLayout park_layout_u(const BatchArgs *__restrict_
     l.group_stride = __builtin_amdgcn_readfirstlane(b->park_layout.group_stride);
     l.frame_stride = __builtin_amdgcn_readfirstlane(b->park_layout.frame_stride);
     l.seg_stride = __builtin_amdgcn_readfirstlane(b->park_layout.seg_stride);
+    l.rot_shift = __builtin_amdgcn_readfirstlane(b->park_layout.rot_shift);
+    l.rot_mask = __builtin_amdgcn_readfirstlane(b->park_layout.rot_mask);
     return l;
 }
 
@@ -306,6 +308,9 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     const ParkLayout lay = park_layout_u(b);
     const uint32_t frame_stride_u = lay.frame_stride;
     uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
+    // the segment's frame slots may be rotated (ParkLayout): the walk wraps where the chunk's slots end
+    uint32_t ridx = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
+    const uint32_t wrap_bytes = chunk_u * frame_stride_u;
     // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
     // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
     // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
@@ -403,6 +408,10 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
         wt = lane == i ? (nev | (nrec << 16)) : wt;
         vin_w = next_w;
         seg += frame_stride_u;
+        if (++ridx == chunk_u) {  // uniform; never taken without rotation (a launch stays inside its chunk)
+            ridx = 0u;
+            seg -= wrap_bytes;
+        }
     }
 
     // ---------------- per-frame segment totals ----------------
