@@ -791,7 +791,7 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
     if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
         const int sh = atoi(e);
         c->park_group_shift = sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
-        static_assert(ADDER_EXPAND_SEGS == 16, "a group must hold whole expansion waves");
+        static_assert(16 % ADDER_EXPAND_SEGS == 0, "a group (and a rotation group of 16 segments) must hold whole expansion waves");
     }
     const size_t ch = budget / (c->ring_chunks * per_frame);
     c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
