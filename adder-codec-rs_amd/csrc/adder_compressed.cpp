@@ -126,9 +126,13 @@ struct BitWriter {
 struct BitReader {
     const uint8_t *data;
     size_t size, pos = 0;  // pos in bits
+    size_t over = 0;       // bits asked for past the end (the coder's tail legitimately reads a few dozen)
     bool bit() {           // Option<bool>: past the end reads as 0
         const size_t byte = pos >> 3;
-        if (byte >= size) return false;
+        if (byte >= size) {
+            ++over;
+            return false;
+        }
         const bool b = (data[byte] >> (7 - (pos & 7))) & 1;
         ++pos;
         return b;
@@ -179,6 +183,8 @@ struct ArithEncoder {
 struct ArithDecoder {
     uint64_t low = 0, high = 1ull << kPrecision, x = 0;
     bool init = false;
+    bool bad = false;  // the EOF symbol was decoded, or the input ran out long ago: the caller stops (the reference's
+                       // decoder returns an error at EOF; a corrupt ADU must not keep producing events)
     BitReader *in;
     size_t decode(Weights &w) {  // decoder.rs:120-141, 236-296; returns the fenwick index (0 = EOF)
         if (!init) {
@@ -211,6 +217,7 @@ struct ArithDecoder {
             if (in->bit()) x += 1;
         }
         if (w.total < kMaxDenominator) w.add(index, 1);
+        if (index == 0 || in->over > 2 * kPrecision + 64) bad = true;
         return index;
     }
     uint8_t byte(Weights &w) { return (uint8_t)(decode(w) - 1); }
@@ -674,6 +681,8 @@ extern "C" int adder_compressed_decode(const uint8_t *data, size_t size, int has
         return cfail(nullptr, ADDER_E_BAD_PARAMS, "bad stream parameters");
     const uint32_t by = (p.height + kBlock - 1) / kBlock, bx = (p.width + kBlock - 1) / kBlock;
     const uint32_t npix = p.channels * kBlock * kBlock;
+    // (parameters from a header or from the caller: one event list per pixel-channel is allocated below)
+    if ((uint64_t)by * bx * npix > (1ull << 28)) return cfail(nullptr, ADDER_E_BAD_PARAMS, "plane too large to decode");
     uint32_t start_t = 0;
     bool first_run = true;
     size_t total = 0;
@@ -691,6 +700,10 @@ extern "C" int adder_compressed_decode(const uint8_t *data, size_t size, int has
         ArithDecoder dec;
         dec.in = &br;
         for (int i = 0; i < 4; ++i) (void)dec.byte(m.t);  // the ADU's start_t: read, not used (event_adu.rs:131-137)
+        // An adaptive model can spend far less than a bit per event, so the bytes of an ADU do not bound its events
+        // tightly; this cap only guarantees termination (and bounded memory) on corrupt input.
+        const size_t adu_event_cap = std::max<size_t>((size_t)1 << 22, (size_t)nbytes * 4096);
+        size_t adu_events = 0;
         std::vector<uint8_t> skipped((size_t)by * bx, 0);
         for (size_t cb = 0; cb < px.size(); ++cb) {  // decompress_intra (event_cube.rs:518-599)
             px[cb].assign(npix, {});
@@ -727,7 +740,10 @@ extern "C" int adder_compressed_decode(const uint8_t *data, size_t size, int has
                 init.d = (uint32_t)((int)init.d + d_residual) & 0xffu;
                 init.t = (uint32_t)((int64_t)init.t + t_residual);
                 px[cb][q].push_back(Ev{d, init.t});
+                ++adu_events;
+                if (dec.bad) return cfail(nullptr, ADDER_E_BAD_PARAMS, "corrupt or truncated ADU (end of the coded data inside a cube)");
             }
+            if (dec.bad) return cfail(nullptr, ADDER_E_BAD_PARAMS, "corrupt or truncated ADU (end of the coded data inside a cube)");
         }
         for (size_t cb = 0; cb < px.size(); ++cb) {  // decompress_inter (:601-680)
             if (skipped[cb]) continue;
@@ -757,7 +773,10 @@ extern "C" int adder_compressed_decode(const uint8_t *data, size_t size, int has
                     const uint32_t t = std::max((uint32_t)((int64_t)t_pred + t_residual), prev.t);
                     last_delta_t = t - prev.t;
                     list.push_back(Ev{d, t});
+                    if (dec.bad || ++adu_events > adu_event_cap)
+                        return cfail(nullptr, ADDER_E_BAD_PARAMS, "corrupt or truncated ADU (no end marker for a pixel's events)");
                 }
+                if (dec.bad) return cfail(nullptr, ADDER_E_BAD_PARAMS, "corrupt or truncated ADU (end of the coded data inside a cube)");
             }
         }
         // digest order (event_adu.rs:195-217, event_cube.rs:165-210): cubes row-major; c, y, x; list order

@@ -603,11 +603,19 @@ extern "C" int adder_hip_set_crf_parameters(AdderHipCtx *c, uint8_t c_thresh_max
 
 extern "C" int adder_hip_reset_c_thresh(AdderHipCtx *c, uint8_t baseline) {
     if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending || c->f_submitted != c->f_collected || c->submitted != c->collected)
+        return fail(c, ADDER_E_BAD_PARAMS, "work is in flight on this context (finish / collect it first)");
     // every pixel: c_thresh = baseline, c_increase_counter = 0 (video.rs:1247-1250,1283-1286); the pair
     // is uniform across the plane, so it lives in the context
     c->c_thresh = baseline;
     c->c_counter = 0;
     c->perpx = false;  // uniform again; the next frame of a feature / ROI batch re-creates the planes from the pair
+    if (c->sparse_mode && c->cth_px) {  // sparse contexts keep the pair per unit: every unit gets (baseline, 0)
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMemsetAsync(c->cth_px, baseline, c->n_pad, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cctr_px, 0, c->n_pad, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return ADDER_OK;
 }
 
@@ -1412,6 +1420,8 @@ extern "C" int adder_hip_set_frames_per_launch(AdderHipCtx *c, uint32_t frames) 
 extern "C" int adder_hip_reset(AdderHipCtx *c) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending (call adder_hip_finish)");
+    if (c->f_submitted != c->f_collected || c->submitted != c->collected)
+        return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight (collect them first)");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = init_state(c);
     if (rc != ADDER_OK) return rc;
@@ -1941,8 +1951,16 @@ extern "C" int adder_hip_integrate_sparse(AdderHipCtx *c, const AdderSparseStep 
     if (!c) return ADDER_E_BAD_PARAMS;
     if (n_out) *n_out = 0;
     if (!steps && n) return fail(c, ADDER_E_BAD_PARAMS, "steps is null");
+    if (!out && out_cap) return fail(c, ADDER_E_BAD_PARAMS, "out is null");
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending || c->f_submitted != c->f_collected || c->submitted != c->collected)
+        return fail(c, ADDER_E_BAD_PARAMS, "work is in flight on this context");
     if (n == 0) return ADDER_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->reset_pending) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->reset_e, 0));
+        c->reset_pending = false;
+    }
     int rc = sparse_prepare(c, n, c->stream);
     if (rc != ADDER_OK) return rc;
     void *vp = c->d_events;
@@ -1954,7 +1972,7 @@ extern "C" int adder_hip_integrate_sparse(AdderHipCtx *c, const AdderSparseStep 
                                            &total, c->stream);
     if (n_out) *n_out = total;
     if (rc != ADDER_OK) return rc;
-    if (total) HIPCHK(c, hipMemcpy(out, c->d_events, total * sizeof(AdderEvent), hipMemcpyDeviceToHost));
+    if (total && out) HIPCHK(c, hipMemcpy(out, c->d_events, total * sizeof(AdderEvent), hipMemcpyDeviceToHost));
     return ADDER_OK;
 }
 

@@ -599,6 +599,249 @@ ADDER_HD void gen_pop(PxState &s, const GenPlan &p, Deep &deep) {
 }
 
 // ---------------------------------------------------------------------------------------
+// BOUNDED COLLAPSE STEP ("cb"): PixelMultiMode::Collapse with delta_t_max > time_spanned -- the reference's
+// DEFAULT configuration (Collapse, delta_t_max 7650 = 30 frames; lib.rs:207-213, video.rs:173-182) and BASELINE
+// config 5.  What is special about it:
+//   * until the root has accumulated delta_t_max (pop_top, :394-396) every frame adds at most one level to the
+//     arena, and in steady state the levels behave like a binary counter: depth <= ~log2(delta_t_max / time) + 1;
+//   * once popped, ONLY the root integrates (:360-362), a firing root truncates the arena to itself (:342-356) and a
+//     flush emits the first node's event plus the D_EMPTY filler (:249-265): levels >= 1 can never matter again, so
+//     pop_top here keeps at most the new root (m <= 1 while popped).
+// PREFIX COORDINATES.  While the walk visits a level it sees the same intensity and time as the root
+// (FramePerfect hands a child nothing, :468-469), and levels 0 .. k-1 all accumulate in any frame in which level
+// k is reached.  So for k >= 1:  integration_k = S - P_k,  delta_t_k = dt0 - Q_k  with (S, dt0) the ROOT's
+// integration and delta_t and (P_k, Q_k) constants fixed when the level was created.  All of these are integers
+// below 2^24 here (8-bit intensities, integer time_spanned, at most delta_t_max / time + 1 frames before the pop:
+// the host checks the bounds and falls back to the generic step otherwise), so the f32 subtractions are exact and
+// equal the reference's running sums bit for bit.  A level that is visited without firing therefore needs NO
+// update; "level k fires" is `S_new >= F_k` with the fire-at value F_k = P_k + 2^d_k, and only the one level that
+// fires in a frame is rewritten.  A stored level is {F, Q, best_delta_t, best_d}.
+// The zero-intensity quirk (a node firing at d = 128 keeps its integration and delta_t, :449) moves Q instead.
+// tests/cpu_sim runs exactly these functions (and the accessor below) against the literal oracle.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kCbFastLevels = 4;  // levels 1..4 of a unit sit side by side (one 16-byte read finds the one that fires)
+
+struct CbLevel {
+    float F;      // fire-at: the level fires in the first frame whose root integration reaches F
+    float Q;      // root delta_t minus the level's delta_t
+    float bdt;    // best_event.delta_t
+    uint32_t bd;  // best_event.d
+};
+
+// Levels k >= 1 of ONE unit.  Levels 1..kCbFastLevels: four consecutive floats per plane (F4, Q4, B4) and four
+// packed bytes (bd4) -- the wave's LDS slice on the device, plain arrays in the CPU harness.  Deeper levels
+// (delta_t_max beyond ~30 frames, or adversarial input) go to the context's deep planes, level k at [k - 1][u],
+// which hold {F, Q, best_delta_t, best_d} instead of {integration, delta_t, ..} for the duration of a launch.
+struct CbLevels {
+    float *F4, *Q4, *B4;
+    uint32_t *bd4;
+    float *gF, *gQ, *gB;
+    uint8_t *gbd;
+    size_t stride, u;
+    ADDER_HD CbLevel load(uint32_t k) const {
+        CbLevel l;
+        if (k <= kCbFastLevels) {
+            l.F = F4[k - 1u];
+            l.Q = Q4[k - 1u];
+            l.bdt = B4[k - 1u];
+            l.bd = (*bd4 >> (8u * (k - 1u))) & 0xffu;
+        } else {
+            const size_t i = (size_t)(k - 1u) * stride + u;
+            l.F = gF[i];
+            l.Q = gQ[i];
+            l.bdt = gB[i];
+            l.bd = gbd[i];
+        }
+        return l;
+    }
+    ADDER_HD void store(uint32_t k, const CbLevel &l) const {
+        if (k <= kCbFastLevels) {
+            F4[k - 1u] = l.F;
+            Q4[k - 1u] = l.Q;
+            B4[k - 1u] = l.bdt;
+            const uint32_t sh = 8u * (k - 1u);
+            *bd4 = (*bd4 & ~(0xffu << sh)) | ((l.bd & 0xffu) << sh);
+        } else {
+            const size_t i = (size_t)(k - 1u) * stride + u;
+            gF[i] = l.F;
+            gQ[i] = l.Q;
+            gB[i] = l.bdt;
+            gbd[i] = (uint8_t)l.bd;
+        }
+    }
+    // The shallowest level in [1, m) whose fire-at value S has reached, or m (then the pristine tail fires).
+    // Slots of levels >= m hold stale values; whatever they say, min(., m) is right.
+    ADDER_HD uint32_t first_firing(float S, uint32_t m) const {
+        uint32_t kf = kCbFastLevels + 1u;
+        kf = S >= F4[3] ? 4u : kf;
+        kf = S >= F4[2] ? 3u : kf;
+        kf = S >= F4[1] ? 2u : kf;
+        kf = S >= F4[0] ? 1u : kf;
+        if (kf > kCbFastLevels)
+            for (; kf < m; ++kf)
+                if (S >= gF[(size_t)(kf - 1u) * stride + u]) break;
+        return kf < m ? kf : m;
+    }
+};
+
+struct CbPx {
+    float S, dt0, bdt0;  // the root's integration, delta_t, best_event.delta_t   (meaningful iff m > 0)
+    float thr0;          // 2^d of the root (0 for d = 128)
+    uint32_t base, m;    // base_val; fired levels (arena length - 1)
+    bool popped;         // popped_dtm
+    float lastf;         // last_fired_t (AbsoluteT)
+};
+ADDER_HD CbPx cb_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
+    CbPx s;
+    s.S = integ;
+    s.dt0 = dt;
+    s.bdt0 = bdt;
+    s.thr0 = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
+    s.base = hdr & 0xffu;
+    s.m = hdr_m(hdr);
+    s.popped = (hdr & kHdrPopped) != 0u;
+    s.lastf = lastf;
+    return s;
+}
+ADDER_HD uint32_t cb_hdr(const CbPx &s) { return hdr_make(s.base, lean_bd_from_thr(f32_to_bits(s.thr0)), s.m, s.popped); }
+
+// Levels 1 .. m-1 between their resident form {integration, delta_t, best_delta_t, best_d} (the state planes, shared
+// with the generic step) and prefix coordinates.  A popped arena keeps only its root (header comment).
+ADDER_HD CbLevel cb_level_from_node(const CbPx &s, const Node &n) {
+    CbLevel l;
+    l.F = fadd(fsub(s.S, n.integ), lean_thr_from_bd(n.bd));
+    l.Q = fsub(s.dt0, n.dt);
+    l.bdt = n.bdt;
+    l.bd = n.bd;
+    return l;
+}
+ADDER_HD Node cb_node_from_level(const CbPx &s, const CbLevel &l) {
+    Node n;
+    n.integ = fsub(s.S, fsub(l.F, lean_thr_from_bd(l.bd)));
+    n.dt = fsub(s.dt0, l.Q);
+    n.bdt = l.bdt;
+    n.bd = l.bd;
+    return n;
+}
+
+struct CbPlan {
+    bool flush;       // pop_best_events ran this frame
+    bool collapsed;   // ... on a popped arena: root event + D_EMPTY filler (:249-265)
+    bool need_pop;    // pop_top_event follows the integrate
+    bool depth_error; // the unit needed more than sc.max_depth stored levels
+    uint32_t m_old;   // fired levels before the step
+    float old_thr0, old_bdt0;  // the old root's best event (valid iff m_old > 0)
+    uint32_t count;   // events of this unit this frame
+};
+
+// pop_best_events' bookkeeping + integrate (:317-413) of one unit.  The unit's OLD levels 1 .. m_old-1 are still in
+// place afterwards when plan.flush is set (a flushed arena restarts from the tail at index 0, which touches no level).
+template <class Lv>
+ADDER_HD void cb_step(CbPx &s, const Lv &lv, uint32_t v, float T, const StepConsts &sc, CbPlan &p) {
+    const float I = (float)v;
+    p.m_old = s.m;
+    p.old_thr0 = s.thr0;
+    p.old_bdt0 = s.bdt0;
+    p.flush = contrast_exceeded(v, s.base, sc.cth);
+    p.collapsed = p.flush && s.popped && s.m != 0u;
+    p.depth_error = false;
+    const uint32_t flushed = p.flush ? (p.collapsed ? 2u : s.m) : 0u;
+    const uint32_t m = p.flush ? 0u : s.m;
+    const bool popped = s.popped && !p.flush;
+    s.base = p.flush ? v : s.base;
+    const float S_old = m ? s.S : 0.0f, dt_old = m ? s.dt0 : 0.0f;
+    const float S_new = fadd(S_old, I);
+    // arena index 0: the root, or the pristine tail (which always fires)
+    const bool root_fires = m == 0u || S_new >= s.thr0;
+    if (root_fires) {
+        const bool zero = S_new == 0.0f;  // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
+        const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);  // 2^get_d(sum)
+        const bool unit_prop = zero || (m != 0u && s.thr0 == 0.0f);       // :432-437 (a pristine tail with d = 128 has I = 0)
+        const float q = fdiv_small(fsub(p2, S_old), I);
+        const float prop = unit_prop ? 1.0f : q;
+        s.bdt0 = fadd(dt_old, fmul(T, prop));
+        s.S = S_new;
+        s.dt0 = zero ? dt_old : fadd(dt_old, T);
+        s.thr0 = fadd(p2, p2);
+        s.m = 1u;
+    } else {
+        s.S = S_new;  // the root accumulates (:474-478)
+        s.dt0 = fadd(dt_old, T);
+        s.m = m;
+        if (!popped) {  // Collapse: once popped only the root integrates (:360-362)
+            const uint32_t k = lv.first_firing(S_new, m);
+            if (k >= sc.max_depth) {
+                p.depth_error = true;
+            } else {
+                CbLevel l;
+                float P = S_old, Qk = dt_old;  // the pristine tail at index k == m: integration 0, delta_t 0
+                bool d128 = I < 1.0f;          // ... and d = get_d(I) (:332-335)
+                if (k < m) {
+                    l = lv.load(k);
+                    P = fsub(l.F, lean_thr_from_bd(l.bd));
+                    Qk = l.Q;
+                    d128 = l.bd == kDZero;
+                }
+                const float integ_old = fsub(S_old, P), dtk_old = fsub(dt_old, Qk);
+                const float sum = fadd(integ_old, I);
+                const bool zero = sum == 0.0f;
+                const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);
+                const float q = fdiv_small(fsub(p2, integ_old), I);
+                const float prop = (zero || d128) ? 1.0f : q;
+                l.bdt = fadd(dtk_old, fmul(T, prop));
+                l.bd = lean_bd_from_thr(f32_to_bits(fadd(p2, p2)));
+                l.F = fadd(P, fadd(p2, p2));
+                l.Q = zero ? fadd(Qk, T) : Qk;  // a d = 128 firing does not advance the level's delta_t; the root's did
+                lv.store(k, l);
+                s.m = k + 1u;
+            }
+        }
+    }
+    s.popped = popped;
+    p.need_pop = s.dt0 >= sc.dtm_f && !popped;  // :394-396 (d == D_MAX cannot happen with 8-bit input)
+    p.count = flushed + (p.need_pop ? 1u : 0u);
+}
+
+// The unit's events of this frame, in emission order.  After cb_step, before cb_pop.
+template <bool ABS_T, class Lv, class Emit>
+ADDER_HD void cb_emit(CbPx &s, const CbPlan &p, const StepConsts &sc, const Lv &lv, Emit &emit) {
+    if (p.flush && p.m_old > 0u) {
+        const uint32_t bd = lean_bd_from_thr(f32_to_bits(p.old_thr0));
+        if (p.collapsed) {
+            emit(bd, f32_as_u32(ABS_T ? fadd(p.old_bdt0, s.lastf) : p.old_bdt0));
+            s.lastf = sc.running_t;  // :257
+            emit(kDEmpty, f32_as_u32(sc.running_t));
+        } else {
+            emit(bd, event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
+            for (uint32_t k = 1; k < p.m_old; ++k) {
+                const CbLevel l = lv.load(k);
+                emit(l.bd, event_time<ABS_T>(l.bdt, s.lastf, sc));
+            }
+        }
+    }
+    if (p.need_pop) emit(lean_bd_from_thr(f32_to_bits(s.thr0)), event_time<ABS_T>(s.bdt0, s.lastf, sc));
+}
+
+// pop_top_event's arena shift (:199-207): level 1, if there is one, becomes the root; deeper levels are dropped
+// (popped + Collapse: they would never be visited, emitted or kept again).
+template <class Lv>
+ADDER_HD void cb_pop(CbPx &s, const CbPlan &p, const Lv &lv) {
+    if (!p.need_pop) return;
+    if (s.m >= 2u) {
+        const CbLevel l = lv.load(1);
+        const float thr = lean_thr_from_bd(l.bd);
+        s.S = fsub(s.S, fsub(l.F, thr));
+        s.dt0 = fsub(s.dt0, l.Q);
+        s.bdt0 = l.bdt;
+        s.thr0 = thr;
+        s.m = 1u;
+    } else {
+        s.m = 0u;
+    }
+    s.popped = true;
+}
+
+// ---------------------------------------------------------------------------------------
 // GENERAL ARENA STEP -- Mode::Continuous (the mode of the event-camera sources,
 // prophesee.rs:65, davis.rs:116-117, and of Video::integrate_matrix when they feed it frames).
 // There a firing node hands the REST of the intensity and time to its child, which keeps integrating it

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void adder_sparse_run_kernel(const SparseStep 
     for (uint32_t j = i; j < n && keys[j] == u; ++j) {
         const uint32_t k = idx[j];
         const SparseStep st = steps[k];
-        s.base = 0u;  // `let mut base_val = 0;` in front of every call (prophesee.rs:204,242,343)
+        // (the `let mut base_val = 0` in front of every call, prophesee.rs:206,244,334, is an OUT parameter:
+        // integrate_for_px overwrites it with px.base_val before the contrast test, video.rs:1336 -- the test sees
+        // the pixel's persisted base_val)
         sc.time_spanned = st.time;
         sc.running_t = rt;
         sc.running_t_u32 = f32_as_u32(rt);
@@ -106,7 +108,9 @@ __global__ __launch_bounds__(256) void adder_sparse_run_kernel(const SparseStep 
         count[k] = em.n < em.cap ? em.n : em.cap;
         rt += st.time;  // `self.running_t += time` (event_pixel_tree.rs:336)
         c_thresh_advance(cth, cctr, (uint8_t)a.c_max, (uint8_t)a.c_vel, st.time, sc.ref_time);
-        if (a.running) {  // side plane after EVERY step (prophesee.rs:259-283): the root's best event, if it has one
+        // side plane (prophesee.rs:259-283): sampled once per CAMERA event, after its last integrate_for_px call --
+        // a step flagged ADDER_SPARSE_NO_SIDE (the first of a camera event's two, or an end_events step) is not sampled
+        if (a.running && !(st.pad & 1u)) {
             const ANode r = acc.load(0);
             if (r.has_best) {
                 side = frame_value_u8(r.bd, f32_as_u32(r.bdt), (double)sc.ref_time);

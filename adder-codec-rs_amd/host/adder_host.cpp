@@ -620,8 +620,9 @@ std::vector<std::vector<Event>> Prophesee::consume() {
             mid_clamp_u8(last_val, last_ln_val);
             const uint32_t time_spanned = (t - last_t - 1) * ref_time;
             const double intensity_to_integrate = last_val * (double)(t - last_t - 1);
-            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, f64_as_u8(last_val), 0, (float)intensity_to_integrate,
-                                            (float)time_spanned});
+            // (t > last_t + 1 implies the second step below: the side plane is sampled after that one, :259-283)
+            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, f64_as_u8(last_val), ADDER_SPARSE_NO_SIDE,
+                                            (float)intensity_to_integrate, (float)time_spanned});
         }
         if (e.p > 1) throw SourceError(SourceError::BadParams, "Invalid polarity");
         double new_ln_val = e.p == 0 ? last_ln_val - camera_theta_ : last_ln_val + camera_theta_;
@@ -653,7 +654,7 @@ void Prophesee::end_events() {  // :332-372: every pixel's last intensity up to 
                 throw SourceError(SourceError::Codec, "assert!(running_t - dvs_last_timestamps > 0)");
             const uint32_t time_spanned = (running_t_ - dvs_last_timestamps_[px]) * ref_time;
             const double intensity_to_integrate = last_val * (double)time_spanned;
-            steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, f64_as_u8(last_val), 0,
+            steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, f64_as_u8(last_val), ADDER_SPARSE_NO_SIDE,
                                             (float)intensity_to_integrate, (float)time_spanned});
         }
     last_end_events_ = video_.integrate_sparse(steps);

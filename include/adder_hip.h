@@ -187,11 +187,16 @@ uint32_t adder_hip_frames_in_flight(const AdderHipCtx *ctx);
  * and running_t advance per call, so after the first sparse call they differ between pixels: dense frames are then
  * refused until adder_hip_reset (the dense start-up frames of Prophesee::consume, :117-131, come first).  A buffer
  * of n * (max_depth + 3) events cannot overflow; an overflow poisons the context (no rollback on this route). */
+/* The running-intensities side plane is sampled once per CAMERA event, after the last of its (one or two)
+ * integrate_for_px calls (prophesee.rs:259-283): flag the first step of a two-step camera event, and the steps of
+ * end_events (:330-372, which never sample it). */
+#define ADDER_SPARSE_NO_SIDE 1u
 typedef struct AdderSparseStep {
     uint16_t x, y;      /* plane coordinates */
     uint8_t c;          /* channel, ADDER_C_NONE on a 1-channel plane */
-    uint8_t frame_val;  /* compared with c_thresh (base_val is 0 for every call) */
-    uint16_t pad;
+    uint8_t frame_val;  /* compared with the pixel's base_val +- c_thresh (video.rs:1336-1340; the sources' `&mut 0` is an
+                         * out parameter that integrate_for_px overwrites with px.base_val) */
+    uint16_t pad;       /* flags: ADDER_SPARSE_NO_SIDE, else 0 */
     float intensity;    /* intensity to integrate */
     float time;         /* over this many ticks */
 } AdderSparseStep;

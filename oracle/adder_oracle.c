@@ -685,10 +685,14 @@ int oracle_video_integrate_sparse(OracleVideo *v, const OracleSparseStep *steps,
             return -1;
         }
         PixelArena *px = &v->px[((size_t)(steps[i].y - v->row_begin) * v->width + steps[i].x) * v->channels + c];
-        px->base_val = 0; /* `let mut base_val = 0;` right before every call (prophesee.rs:204,242,343) */
+        /* `let mut base_val = 0;` right before every call (prophesee.rs:206,244,334) is an OUT parameter:
+         * integrate_for_px sets `*base_val = px.base_val` (video.rs:1336) before the contrast test, which therefore
+         * uses the pixel's persisted base_val */
         integrate_for_px(px, steps[i].frame_val, steps[i].intensity, steps[i].time, &ev, &v->sp);
-        /* the side plane (prophesee.rs:259-283): the root's best event, if it has one */
-        if (px->arena[0].has_best)
+        /* the side plane (prophesee.rs:259-283): once per camera event, after its last integrate_for_px call, the
+         * root's best event if it has one; pad bit 0 marks a step that is not followed by that sampling (the first
+         * of a camera event's two steps; end_events' steps, :330-372) */
+        if (!(steps[i].pad & 1u) && px->arena[0].has_best)
             v->running_intensities[((size_t)(steps[i].y - v->row_begin) * v->width + steps[i].x) * v->channels + c] =
                 frame_value_u8(px->arena[0].best_event.d, f32_as_u32(px->arena[0].best_event.delta_t), (double)v->sp.ref_time);
     }

@@ -44,7 +44,9 @@ struct Sim {
     int continuous;      // Mode::Continuous: the general arena step (cont_step), its own state planes
     std::vector<uint32_t> c_hdr, c_meta;           // [unit], [node][unit]
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
-    uint64_t fast_steps, generic_steps, lean_steps;
+    uint64_t fast_steps, generic_steps, lean_steps, cb_steps;
+    int use_cb;          // Collapse with delta_t_max > time: the bounded step (cb_step) instead of the generic one
+    int frac_time_seen;  // a non-integer time_spanned has been integrated since the last reset (cb needs exact sums)
     // feature-driven rate control (the kernel-side flow of adder_feature_kernel, serially)
     int feat_detect, feat_adjust, roi_on, perpx;
     uint32_t baseline, radius, chunk_rows, roi[4];
@@ -138,7 +140,9 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->use_fast = 1;
     s->generic_sticky = 0;
     s->continuous = 0;
-    s->fast_steps = s->generic_steps = s->lean_steps = 0;
+    s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = 0;
+    s->use_cb = 1;
+    s->frac_time_seen = 0;
     s->feat_detect = s->feat_adjust = s->roi_on = s->perpx = 0;
     s->baseline = 2; s->radius = 0; s->chunk_rows = 1;
     s->running.assign(s->N, 0);
@@ -189,6 +193,8 @@ void sim_set_use_fast(Sim *s, int on) { s->use_fast = on; }
 uint64_t sim_fast_steps(const Sim *s) { return s->fast_steps; }
 uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
 uint64_t sim_lean_steps(const Sim *s) { return s->lean_steps; }
+uint64_t sim_cb_steps(const Sim *s) { return s->cb_steps; }
+void sim_set_use_cb(Sim *s, int on) { s->use_cb = on; }
 
 // integrate_for_px(px, &mut 0, frame_val, intensity, time) per step, in order (the flow of adder_sparse_run_kernel,
 // serially): Continuous contexts; c_thresh, its counter and running_t are per unit from the first call on
@@ -222,7 +228,6 @@ int sim_integrate_sparse(Sim *s, const SimSparseStep *steps, size_t n, SimEvent 
         const size_t u = ((size_t)(steps[i].y - s->row_begin) * s->W + steps[i].x) * s->C + c;
         em.x = steps[i].x; em.y = steps[i].y; em.c = steps[i].c;
         APx p = apx_unpack(s->c_hdr[u], s->lastf[u]);
-        p.base = 0u;  // `let mut base_val = 0;` before every call (prophesee.rs:204,242,343)
         sc.time_spanned = steps[i].time;
         sc.running_t = s->rt_px[u];
         sc.running_t_u32 = f32_as_u32(sc.running_t);
@@ -238,6 +243,110 @@ int sim_integrate_sparse(Sim *s, const SimSparseStep *steps, size_t n, SimEvent 
     }
     *n_out = em.pos;
     if (em.pos > cap && rc == 0) rc = -4;
+    return rc;
+}
+
+// the product's choice (adder_hip_api.cpp cb_possible): Collapse, delta_t_max > time_spanned, uniform c_thresh, and
+// every sum the prefix coordinates form an exact integer below 2^24
+static bool sim_cb_possible(const Sim *s, float T) {
+    if (!s->use_cb || !s->collapse || s->perpx || s->continuous || s->frac_time_seen) return false;
+    if (!((float)s->dtm > T)) return false;
+    if (!(T >= 1.0f) || T != (float)(uint32_t)T || T > 65536.0f) return false;
+    if ((double)s->dtm + 2.0 * T >= 8388608.0) return false;
+    if (((double)s->dtm / T + 3.0) * 255.0 >= 8388608.0) return false;
+    return true;
+}
+
+// One temporally blocked launch of the bounded Collapse step, as adder_cb_kernel runs it: per unit the levels are
+// brought into prefix coordinates once, nb frames are stepped, and the state goes back in its resident form.
+// frames = [nb][N]; the events come out frame-major like the product's stream.  returns 0 ok, -4 capacity, -5 depth
+int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!sim_cb_possible(s, T)) return -7;
+    s->generic_sticky = 1;
+    StepConsts sc;
+    sc.time_spanned = T;
+    sc.dtm_f = (float)s->dtm;
+    sc.ref_time = s->ref_time;
+    sc.collapse = 1;
+    sc.abs_t = s->abs_t;
+    sc.max_depth = s->max_depth;
+    sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
+    std::vector<float> rts(nb);
+    std::vector<uint8_t> cths(nb);
+    {
+        float rt = s->running_t;
+        uint8_t cth = s->c_thresh, cctr = s->c_counter;
+        for (uint32_t i = 0; i < nb; ++i) {
+            rts[i] = rt;
+            cths[i] = cth;
+            rt += T;
+            c_thresh_advance(cth, cctr, (uint8_t)s->c_max, (uint8_t)s->velocity, T, s->ref_time);
+        }
+        s->running_t = rt;
+        s->c_thresh = cth;
+        s->c_counter = cctr;
+    }
+    std::vector<std::vector<SimEvent>> per_frame(nb);
+    int rc = 0;
+    size_t u = 0;
+    for (uint32_t y = 0; y < s->H; y++)
+        for (uint32_t x = 0; x < s->W; x++)
+            for (uint32_t c = 0; c < s->C; c++, u++) {
+                const uint32_t hdr = s->hdr[u];
+                const uint32_t m0 = hdr_m(hdr);
+                CbPx p = cb_unpack(hdr, m0 ? s->integ0[u] : -12345.0f, m0 ? s->dt0[u] : -777.0f, m0 ? s->bdt0[u] : -999.0f,
+                                   s->abs_t ? s->lastf[u] : -1.0f);
+                if (p.popped && p.m > 1u) p.m = 1u;  // a popped arena keeps only its root
+                // garbage on purpose: slots of levels >= m must never decide anything
+                float F4[4] = {-3.0f, 1e30f, 0.0f, -1e30f}, Q4[4] = {7.0f, 7.0f, 7.0f, 7.0f}, B4[4] = {9.0f, 9.0f, 9.0f, 9.0f};
+                uint32_t bd4 = 0xdeadbeefu;
+                CbLevels lv{F4, Q4, B4, &bd4, s->lv_integ.data(), s->lv_dt.data(), s->lv_bdt.data(), s->lv_bd.data(), s->N, u};
+                DeepAcc deep{s, u};
+                for (uint32_t k = 1; k < p.m; ++k) {
+                    Node n;
+                    deep.load(k, n);
+                    lv.store(k, cb_level_from_node(p, n));
+                }
+                for (uint32_t i = 0; i < nb; ++i) {
+                    sc.running_t = rts[i];
+                    sc.running_t_u32 = f32_as_u32(rts[i]);
+                    sc.cth = cths[i];
+                    struct VecEmit {
+                        std::vector<SimEvent> *v;
+                        uint16_t x, y;
+                        uint8_t c;
+                        uint32_t n;
+                        void operator()(uint32_t d, uint32_t t) {
+                            SimEvent e;
+                            e.x = x; e.y = y; e.c = c; e.d = (uint8_t)d; e.pad = 0; e.t = t;
+                            v->push_back(e);
+                            ++n;
+                        }
+                    } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
+                    CbPlan plan;
+                    cb_step(p, lv, frames[(size_t)i * s->N + u], T, sc, plan);
+                    if (plan.depth_error) rc = -5;
+                    if (s->abs_t) cb_emit<true>(p, plan, sc, lv, em); else cb_emit<false>(p, plan, sc, lv, em);
+                    if (em.n != plan.count) s->plan_mismatch++;
+                    cb_pop(p, plan, lv);
+                    if (p.m > s->max_m) s->max_m = p.m;
+                    s->cb_steps++;
+                }
+                for (uint32_t k = 1; k < p.m; ++k) deep.store(k, cb_node_from_level(p, lv.load(k)));
+                s->hdr[u] = cb_hdr(p);
+                if (p.m > 0) { s->integ0[u] = p.S; s->dt0[u] = p.dt0; s->bdt0[u] = p.bdt0; }
+                if (s->abs_t) s->lastf[u] = p.lastf;
+                if (p.m != 0u)
+                    s->running[u] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(p.thr0)), f32_as_u32(p.bdt0), (double)s->ref_time);
+            }
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i)
+        for (const SimEvent &e : per_frame[i]) {
+            if (pos < cap) out[pos] = e;
+            ++pos;
+        }
+    *n_out = pos;
+    if (pos > cap && rc == 0) rc = -4;
     return rc;
 }
 
@@ -265,6 +374,9 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
         s->perpx = 1;
     }
     const bool lean = s->collapse && (float)s->dtm <= time_spanned && !s->generic_sticky && s->use_fast && !s->perpx;
+    if (!lean && !s->continuous && !s->feat_detect && !s->roi_on && sim_cb_possible(s, time_spanned))
+        return sim_integrate_cb_block(s, frame, 1u, time_spanned, out, cap, n_out);
+    if (!(time_spanned >= 1.0f) || time_spanned != (float)(uint32_t)time_spanned) s->frac_time_seen = 1;
     if (!lean) s->generic_sticky = 1;
     int rc = 0;
     Emitter em;

@@ -55,6 +55,11 @@ def lib():
     L.sim_generic_steps.argtypes = [vp]
     L.sim_lean_steps.restype = C.c_uint64
     L.sim_lean_steps.argtypes = [vp]
+    L.sim_cb_steps.restype = C.c_uint64
+    L.sim_cb_steps.argtypes = [vp]
+    L.sim_set_use_cb.argtypes = [vp, i32]
+    L.sim_integrate_cb_block.restype = i32
+    L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate.restype = i32
     L.sim_integrate.argtypes = [vp, vp, f32, vp, sz, C.POINTER(sz)]
     L.sim_framer_run.restype = C.c_int64
@@ -163,6 +168,24 @@ class Sim:
     @property
     def lean_steps(self):
         return self.L.sim_lean_steps(self.h)
+
+    def set_use_cb(self, on):
+        self.L.sim_set_use_cb(self.h, int(on))
+
+    @property
+    def cb_steps(self):
+        return self.L.sim_cb_steps(self.h)
+
+    def integrate_cb_block(self, frames, time_spanned):
+        """nb frames as ONE temporally blocked launch of the bounded Collapse step; (rc, events frame-major)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), -1)
+        assert frames.shape[1] == self.n
+        cap = self._cap * len(frames)
+        out = np.zeros(cap, EVENT_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.sim_integrate_cb_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
+                                           C.byref(n))
+        return rc, out[: n.value].copy()
 
     @property
     def plan_mismatches(self):

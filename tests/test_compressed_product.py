@@ -147,3 +147,45 @@ def test_errors():
     enc.destroy()
     with pytest.raises(A.AdderHipError):
         A.compressed_decode(b"adder" + bytes(40))
+
+
+def test_decode_of_corrupt_or_truncated_adus_terminates():
+    """A truncated or corrupt ADU must end in an error (or a shorter, valid event list) in bounded time and memory: the
+    reference's decoder returns an error at the end of its input (arithmetic-coding-adder-dep/src/decoder.rs), it
+    never keeps producing events.  Reads past the coded data and the EOF symbol are errors here."""
+    import struct
+    import time
+    rng = np.random.default_rng(3)
+    n = 3000
+    ev = np.zeros(n, A.EVENT_DTYPE)
+    ev["x"], ev["y"], ev["c"] = rng.integers(0, 33, n), rng.integers(0, 20, n), 0xFF
+    ev["d"] = rng.choice(np.array([0, 3, 7, 8, 128, 255], np.uint8), n)
+    ev["t"] = np.cumsum(rng.integers(0, 3, n))  # everything inside the first ADU's span
+    good = _product_stream(ev, 33, 20, 1, tps=7650, ref=255, dtm=255 * 40, adu=40, header=False)
+    n_adu = struct.unpack(">I", good[:4])[0]
+    assert 8 < n_adu <= len(good) - 4
+    cases = []
+    for keep in (0, 1, 2, 5, n_adu // 4, n_adu // 2, n_adu - 2):  # the first ADU cut short, its length prefix fixed up
+        cases.append(struct.pack(">I", keep) + good[4:4 + keep])
+    rng = np.random.default_rng(5)
+    for k in range(24):  # byte noise inside the first ADU
+        b = bytearray(good[:4 + n_adu])
+        for pos in rng.integers(4, 4 + n_adu, 1 + k % 5):
+            b[pos] = rng.integers(0, 256)
+        cases.append(bytes(b))
+    cases.append(struct.pack(">I", 64) + bytes(64))        # all zeros
+    cases.append(struct.pack(">I", 64) + bytes([255]) * 64)  # all ones
+    t0 = time.time()
+    errors = 0
+    for data in cases:
+        try:
+            dec, _ = A.compressed_decode(data, has_header=False, width=33, height=20, channels=1, ref_interval=255,
+                                         adu_interval=40)
+            assert len(dec) < 1 << 23
+        except A.AdderHipError:
+            errors += 1
+    assert errors >= 5          # the truncated ones at the very least
+    assert time.time() - t0 < 60.0
+    with pytest.raises(A.AdderHipError):  # a header (or caller) that asks for an absurd plane
+        A.compressed_decode(good, has_header=False, width=65535, height=65535, channels=3, ref_interval=255,
+                            adu_interval=40)

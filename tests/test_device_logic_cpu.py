@@ -207,7 +207,9 @@ def test_continuous_mode_general_arena_step(multi_mode, time_mode):
 
 def _sparse_steps(rng, W, H, Cn, n, *, hot=0.3):
     """Steps of an event-camera source: a few hot pixels fire again and again, long and short spans, values around
-    and far from the previous one (base_val restarts at 0 for every call, so frame_val > c_thresh flushes)."""
+    and far from the previous one.  The contrast test uses the pixel's PERSISTED base_val: the sources' `let mut
+    base_val = 0` is an out parameter that integrate_for_px overwrites (video.rs:1336).  pad bit 0 marks steps that
+    are not followed by a sampling of the running-intensities side plane (prophesee.rs:259-283)."""
     st = np.zeros(n, O.SPARSE_STEP_DTYPE)
     hotpx = rng.integers(0, W * H, max(2, int(W * H * 0.05)))
     pix = np.where(rng.random(n) < hot, hotpx[rng.integers(0, len(hotpx), n)], rng.integers(0, W * H, n))
@@ -216,6 +218,7 @@ def _sparse_steps(rng, W, H, Cn, n, *, hot=0.3):
     val = rng.choice(np.array([0, 1, 3, 9, 40, 128, 200, 255]), n)
     span = rng.choice(np.array([1, 1, 1, 2, 5, 40, 700]), n)
     st["frame_val"] = val
+    st["pad"] = rng.integers(0, 2, n)
     st["intensity"] = (val * span).astype(np.float32)
     st["time"] = (span * 20).astype(np.float32)
     return st
@@ -224,7 +227,7 @@ def _sparse_steps(rng, W, H, Cn, n, *, hot=0.3):
 @pytest.mark.parametrize("multi_mode", [O.NORMAL, O.COLLAPSE])
 @pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
 def test_sparse_steps_of_event_camera_sources(multi_mode, time_mode):
-    """SURVEY 8(f)3, the sparse half: integrate_for_px(px, &mut 0, frame_val, intensity, time) pixel by pixel in the
+    """SURVEY 8(f)3, the sparse half: integrate_for_px(px, &mut base_val, frame_val, intensity, time) pixel by pixel in the
     order of a camera's events (prophesee.rs:170-258), after the two dense start-up frames of Prophesee::consume
     (:117-131).  The device flow (cont_step with c_thresh, its counter and running_t per unit) on the host against
     the oracle: every step's events, in order."""
@@ -252,3 +255,155 @@ def test_sparse_steps_of_event_camera_sources(multi_mode, time_mode):
             assert len(a) == len(b) and np.array_equal(a, b), k
             total += len(a)
         assert total > 500
+
+
+def test_sparse_step_contrast_test_uses_the_pixels_persisted_base_val():
+    """Known answer read off the reference: integrate_for_px sets `*base_val = px.base_val` before the contrast test
+    (video.rs:1336), so the `let mut base_val = 0` of prophesee.rs:206,244,334 never reaches it.  Two consecutive
+    steps of one pixel with the same frame_val > c_thresh: the first flushes (base_val 128 -> 200), the second finds
+    frame_val == base_val and must NOT run pop_best_events again."""
+    W, H = 3, 2
+    for time_mode in (O.DELTA_T, O.ABSOLUTE_T):
+        ov = O.Video(W, H, 1, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=20, delta_t_max=4000)
+        ov.set_pixel_mode(1)
+        sv = Sim(W, H, 1, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=20, delta_t_max=4000, max_depth=24)
+        sv.set_continuous()
+        ov.ensure_capacity(30)
+        start = np.full((H, W, 1), 128, np.uint8)
+        for v in (ov, sv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        for _ in range(2):
+            a = ov.integrate_matrix(start, time_spanned=20.0)
+            rc, b = sv.integrate(start, 20.0)
+            assert rc == 0 and np.array_equal(a, b)
+        st = np.zeros(1, O.SPARSE_STEP_DTYPE)
+        st["x"], st["y"], st["c"], st["frame_val"], st["intensity"], st["time"] = 1, 1, 0xFF, 200, 200.0, 20.0
+        first = ov.integrate_sparse(st)
+        rc, b = sv.integrate_sparse(st)
+        assert rc == 0 and np.array_equal(first, b)
+        assert len(first) >= 1  # 200 is outside 128 +- 0: the arena is flushed
+        second = ov.integrate_sparse(st)
+        rc, b = sv.integrate_sparse(st)
+        assert rc == 0 and np.array_equal(second, b)
+        # base_val is now 200: no pop_best_events.  With the d = 7 root of the flush holding 200 < 256, the second
+        # step fires the root once (200 + 200 >= 256) and FramePerfect-free Continuous hands the rest to a child:
+        # nothing is emitted at all (delta_t_max 4000 is far away).
+        assert len(second) == 0
+
+
+# ---- the bounded Collapse step (cb_step / cb_emit / cb_pop: Collapse with delta_t_max > time_spanned) ----
+def _cb_pair(W, H, Cn, tm, dtm, ref_time=255, max_depth=20, crf=None):
+    ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+    sv = Sim(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm, max_depth=max_depth)
+    ov.ensure_capacity(max_depth + 2)
+    if crf is not None:
+        base, cmax, vel = crf
+        for v in (ov, sv):
+            v.set_crf_parameters(cmax, vel)
+            v.reset_c_thresh(base)
+    return ov, sv
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("crf", [0, 3, 9])
+def test_cb_blocked_launches_match_the_oracle(time_mode, crf):
+    """The reference's default mode (Collapse, delta_t_max = 30 frames) through the bounded step, in temporally
+    blocked launches of every length that meets a pop (frame 30), a flush or a chunk edge differently: the levels
+    stay in prefix coordinates for the whole launch and go back to their resident form at its end."""
+    rng = np.random.default_rng(17 + crf + time_mode)
+    for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
+        frames = 150
+        clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, 7, 12, 1, seed=crf * 7 + len(kind)))
+        ov, sv = _cb_pair(12, 7, 1, time_mode, 7650, crf=CRFS[crf])
+        k, total = 0, 0
+        while k < frames:
+            nb = int(rng.choice([1, 2, 3, 7, 29, 30, 31, 64]))
+            nb = min(nb, frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            assert rc == 0, (kind, k, rc)
+            assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
+            total += len(got)
+            k += nb
+        assert sv.plan_mismatches == 0 and sv.cb_steps == frames * 12 * 7
+        assert total > 0
+
+
+def test_cb_and_generic_steps_are_interchangeable_mid_stream():
+    """Both steps keep the same resident state (level 0 planes + deep planes): alternating them frame by frame -- as
+    a context does when a mode switch makes the bounded step ineligible -- must not change a single event."""
+    clip = clips.make_clip("runs", 200, 6, 8, 3, seed=77)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _cb_pair(8, 6, 3, tm, 7650, crf=CRFS[3])
+        rng = np.random.default_rng(3)
+        for k in range(len(clip)):
+            sv.set_use_cb(bool(rng.integers(0, 2)))
+            a = ov.integrate_matrix(clip[k])
+            rc, b = sv.integrate(clip[k], 255.0)
+            assert rc == 0 and np.array_equal(a, b), k
+        assert sv.cb_steps > 0 and sv.generic_steps + sv.fast_steps > 0
+
+
+def test_cb_deep_levels_beyond_the_fast_four():
+    """delta_t_max of 500 frames: a static pixel's arena reaches seven levels before the pop, so levels 5+ live in the
+    deep planes in prefix form during a launch; a flush then drains all of them, and a too small max_depth is
+    reported, not overrun."""
+    frames = 560
+    clip = clips.make_clip("static", frames, 3, 5, 1, seed=4)
+    clip[300:] = 255 - clip[300:]      # one flush of a deep arena
+    clip[520:] = clip[0]               # ... and one after the second run's pop
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _cb_pair(5, 3, 1, tm, 255 * 500, crf=CRFS[0])
+        k = 0
+        while k < frames:
+            nb = min(64, frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            assert rc == 0 and np.array_equal(want, got), k
+            k += nb
+        assert sv.max_m >= 6  # root + levels 1..5 at least: past the four fast slots
+    sv = Sim(5, 3, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255 * 500, max_depth=3)
+    sv.set_crf_parameters(0, 10)
+    sv.reset_c_thresh(0)
+    rcs = [sv.integrate(clip[k], 255.0)[0] for k in range(40)]
+    assert -5 in rcs
+
+
+def test_cb_zero_intensity_quirk_inside_levels():
+    """A node that fires at d = 128 (zero intensity) keeps its integration and delta_t (event_pixel_tree.rs:449): with
+    crf > 0 zeros arrive INSIDE a run (base_val 3, c_thresh 7), at the root and at deeper levels."""
+    rng = np.random.default_rng(9)
+    frames = 400
+    clip = rng.choice(np.array([0, 0, 0, 1, 2, 3, 5, 7], np.uint8), size=(frames, 4, 6, 1))
+    clip[::37] = 200  # a flush now and then
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        for dtm in (510, 2040, 7650):
+            ov, sv = _cb_pair(6, 4, 1, tm, dtm, crf=(7, 7, 7))
+            k = 0
+            while k < frames:
+                nb = min(int(rng.integers(1, 40)), frames - k)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+                rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+                assert rc == 0 and np.array_equal(want, got), (dtm, k)
+                k += nb
+
+
+def test_cb_other_tick_rates_and_quality_change():
+    clip = clips.make_clip("runs", 160, 4, 6, 1, seed=31)
+    for ref_time, dtm in ((5000, 240000), (1000, 2000), (20, 10000), (255, 6120)):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            ov, sv = _cb_pair(6, 4, 1, tm, dtm, ref_time=ref_time, crf=CRFS[3])
+            for k in range(0, 160, 16):
+                if k == 80:  # update_quality_manual mid-stream: thresholds restart, delta_t_max changes
+                    for v in (ov, sv):
+                        v.set_crf_parameters(13, 4)
+                        v.reset_c_thresh(7)
+                        v.set_delta_t_max(dtm * 2)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=float(ref_time)) for i in range(16)])
+                rc, got = sv.integrate_cb_block(clip[k:k + 16], float(ref_time))
+                assert rc == 0 and np.array_equal(want, got), (ref_time, k)
+    # a fractional time_spanned is not exact in prefix coordinates: the bounded step must refuse it
+    sv = Sim(6, 4, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=7650)
+    assert sv.integrate_cb_block(clip[:2], 254.5)[0] == -7

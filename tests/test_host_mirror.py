@@ -202,8 +202,9 @@ def _prophesee_restatement(dvs, W, H, ref_time):
     def as_u8(x):
         return 0 if not x > 0.0 else (255 if x >= 255.0 else int(x))
 
-    def step(x, y, val, intensity, time):
-        return (x, y, 0xFF, as_u8(val), 0, np.float32(intensity), np.float32(time))
+    def step(x, y, val, intensity, time, no_side=0):
+        # pad bit 0 (ADDER_SPARSE_NO_SIDE): the side plane is sampled once per camera event, after its LAST step
+        return (x, y, 0xFF, as_u8(val), no_side, np.float32(intensity), np.float32(time))
 
     while True:
         if running_t == 0:
@@ -230,7 +231,7 @@ def _prophesee_restatement(dvs, W, H, ref_time):
                     val = (math.exp(last_ln[p]) - 1.0) * 255.0
                     assert running_t - last_t[p] > 0
                     span = (running_t - int(last_t[p])) * ref_time
-                    steps.append(step(x, y, val, val * float(span), span))
+                    steps.append(step(x, y, val, val * float(span), span, 1))
             out.append(v.integrate_sparse(np.array(steps, O.SPARSE_STEP_DTYPE)))
             break
         steps = []
@@ -245,7 +246,7 @@ def _prophesee_restatement(dvs, W, H, ref_time):
                 if val < 0.0 or val > 255.0:
                     val, ln = 128.0, math.log1p(128.0 / 255.0)
                 gap = t - int(last_t[p]) - 1
-                steps.append(step(x, y, val, val * float(gap), gap * ref_time))
+                steps.append(step(x, y, val, val * float(gap), gap * ref_time, 1))
             new_ln = ln - theta if int(e["p"]) == 0 else ln + theta
             last_ln[p] = new_ln
             was = int(last_t[p])
