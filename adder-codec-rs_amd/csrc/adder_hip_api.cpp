@@ -90,7 +90,18 @@ struct AdderHipCtx {
     // runtime (ROCm 7.0) crashed in hip::Graph::UpdateStreams at a later hipGraphLaunch of ANOTHER instance once a
     // few dozen instances had been destroyed mid-life (rocgdb backtrace; tests: 22 batch lengths on one context).
     std::vector<hipGraphExec_t> retired_execs;
-    uint32_t park_bytes = 0;         // scratch of one segment of one frame
+    uint32_t park_bytes = 0;         // scratch of one segment of one frame (fixed-slot kinds)
+    // what the scratch ring is laid out for: fixed slots per segment and frame (lean records, Continuous staging), or
+    // one record log per segment and chunk (per-event records of the generic / bounded Collapse kernels: log_capacity)
+    enum ScratchKind { kScratchNone, kScratchLean, kScratchCont, kScratchLog2, kScratchLog3 };
+    ScratchKind scratch_kind = kScratchNone;
+    uint32_t log_cap = 0;            // records per (segment, chunk) region (log kinds)
+    uint32_t *wofs_ring = nullptr;   // [slots][num_waves] log kinds: where a segment's run of a frame starts
+    uint32_t *wcur = nullptr;        // [ring_chunks][num_waves] log cursors between the launches of a chunk
+    // the bounded Collapse step needs exact integer sums (adder_pixel.hpp): a fractional time_spanned or a huge
+    // delta_t_max since the last reset rules it out
+    bool frac_time_seen = false;
+    uint32_t dtm_max_seen = 0;
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
@@ -253,7 +264,8 @@ static void free_ctx(AdderHipCtx *c) {
                     c->snap.running};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring})
+    for (void *p : {(void *)c->park_ring, (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring,
+                    (void *)c->wofs_ring, (void *)c->wcur})
         if (p) (void)hipFree(p);
     for (auto &sl : c->slot) {
         if (sl.d_wire) (void)hipFree(sl.d_wire);
@@ -394,6 +406,8 @@ static int init_state(AdderHipCtx *c) {
     c->c_thresh = p.c_thresh_start;
     c->c_counter = p.c_counter_start;
     c->generic_sticky = false;
+    c->frac_time_seen = false;
+    c->dtm_max_seen = p.delta_t_max;
     c->perpx = false;
     c->sparse_mode = false;
     if (c->fset) HIPCHK(c, hipMemsetAsync(c->fset, 0, (size_t)c->rows * p.width, c->stream));
@@ -407,7 +421,7 @@ static int init_state(AdderHipCtx *c) {
 // (launch_frame_loop makes the step of chunk k wait for the expansion of chunk k-2).
 
 
-static int alloc_scratch(AdderHipCtx *c, uint32_t bytes_per_segment);
+static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind);
 
 // BatchArgs followed (256-byte aligned) by the frame table, on the device and in page-locked host memory
 constexpr size_t kBatchDescBytes = (sizeof(BatchArgs) + 255) & ~(size_t)255;
@@ -536,8 +550,7 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             HIPCHK(c, dalloc(&c->cn_bdt, cnt));
             HIPCHK(c, dalloc(&c->cn_meta, cnt));
         }
-        { int rc_ = alloc_scratch(c, c->continuous ? kWaveUnits + kWaveUnits * (c->max_depth + 3u) * kGenRecBytes
-                                                   : kLeanParkBytes); if (rc_ != ADDER_OK) return rc_; }
+        { int rc_ = alloc_scratch(c, c->continuous ? AdderHipCtx::kScratchCont : AdderHipCtx::kScratchLean); if (rc_ != ADDER_OK) return rc_; }
         { int rc_ = alloc_batch_desc(c, 1024); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_result), sizeof(BatchResult), hipHostMallocDefault));
         memset(c->h_result, 0, sizeof(BatchResult));
@@ -733,6 +746,7 @@ extern "C" int adder_hip_set_delta_t_max(AdderHipCtx *c, uint32_t dtm) {
     if (dtm < c->p.ref_time || dtm % c->p.ref_time != 0)
         return fail(c, ADDER_E_BAD_PARAMS, "delta_t_max must be a multiple of ref_time and >= ref_time");
     c->p.delta_t_max = dtm;
+    c->dtm_max_seen = std::max(c->dtm_max_seen, dtm);
     return ADDER_OK;
 }
 
@@ -753,6 +767,21 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
     return !c->generic_sticky && !c->perpx && !feature_needs_perpx(c) && c->p.multi_mode == ADDER_MULTI_COLLAPSE &&
            (float)c->p.delta_t_max <= time_spanned;
 }
+// The bounded Collapse step (adder_pixel.hpp cb_step): Collapse with delta_t_max > time_spanned, a uniform c_thresh, and
+// every sum its prefix coordinates form an exact integer below 2^24 -- integer time_spanned, at most delta_t_max /
+// time + 1 frames of 8-bit intensities before the pop.  Anything else takes the generic step.
+static bool cb_possible(const AdderHipCtx *c, float T) {
+    if (c->continuous || c->p.multi_mode != ADDER_MULTI_COLLAPSE || c->perpx || feature_needs_perpx(c)) return false;
+    if (c->frac_time_seen) return false;
+    static const bool off = [] { const char *e = getenv("ADDER_HIP_NO_CB"); return e && atoi(e) != 0; }();
+    if (off) return false;
+    const double dtm = (double)std::max(c->p.delta_t_max, c->dtm_max_seen);
+    if (!((float)c->p.delta_t_max > T)) return false;
+    if (!(T >= 1.0f) || T != (float)(uint32_t)T || T > 65536.0f) return false;
+    if (dtm + 2.0 * T >= 8388608.0) return false;
+    if ((dtm / T + 3.0) * 255.0 >= 8388608.0) return false;
+    return true;
+}
 static size_t worst_case_events_per_frame(const AdderHipCtx *c, float time_spanned) {
     if (c->continuous) return (size_t)c->n_units * (c->max_depth + 3u);
     return (size_t)c->n_units * (lean_possible(c, time_spanned) ? 3u : c->max_depth + 1u);
@@ -769,31 +798,47 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
     if (st & kStatusWire)
         return fail(c, ADDER_E_BAD_PARAMS, "wire serialisation: an event without a channel on a multi-channel plane");
     if (st & kStatusSparse) return fail(c, ADDER_E_BAD_PARAMS, "a sparse step names a pixel outside the plane / row band");
+    if (st & kStatusScratch) return fail(c, ADDER_E_HIP, "internal error: a segment's record log exceeded its bound");
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 
-// (Re)allocates the compaction scratch ring for `bytes` of parked records per segment and frame.
-// The lean step parks at most one 12-byte record per unit (kLeanParkBytes per segment); a generic
-// batch can park up to max_depth + 2 8-byte records per unit.  Chunk = frames per scan launch: as many
-// as the budget allows (kFuseLagChunks + 1 chunks are in flight), at most kMaxChunk.  The budget is a
-// quarter of what the device has free, at most 12 GiB.
-static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
-    if (c->park_bytes >= bytes && c->park_ring) return ADDER_OK;
+// (Re)allocates the compaction scratch ring for one kind of record.  Fixed-slot kinds: the lean step parks at most
+// one 12-byte record per unit and frame (kLeanParkBytes per segment), a Continuous context stages max_depth + 3 events
+// per unit.  Log kinds (per-event records): one region per segment and CHUNK holding the hard bound of what the
+// segment can emit over the chunk (log_capacity: 2 or 3 events per unit and frame + one arena), instead of a slot per
+// frame that would have to hold a whole arena per unit -- 18 instead of 144 bytes per unit and frame at 64 frames.
+// Chunk = frames per scan launch: as many as the budget allows (ring_chunks chunks are in flight), at most kMaxChunk.
+// The budget is a quarter of what the device has free, at most 16 GiB.
+static size_t scratch_bytes_per_chunk(const AdderHipCtx *c, AdderHipCtx::ScratchKind kind, uint32_t chunk) {
+    switch (kind) {
+        case AdderHipCtx::kScratchLean: return (size_t)c->num_waves * chunk * kLeanParkBytes;
+        case AdderHipCtx::kScratchCont:
+            return (size_t)c->num_waves * chunk * (kWaveUnits + kWaveUnits * (c->max_depth + 3u) * kGenRecBytes);
+        case AdderHipCtx::kScratchLog2: return (size_t)c->num_waves * log_capacity(chunk, c->max_depth, true) * kGenRecBytes;
+        case AdderHipCtx::kScratchLog3: return (size_t)c->num_waves * log_capacity(chunk, c->max_depth, false) * kGenRecBytes;
+        default: return 0;
+    }
+}
+static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
+    // (a Collapse context that has the general log can run the bounded step on it: no thrash between the two)
+    if (c->park_ring && (c->scratch_kind == kind || (c->scratch_kind == AdderHipCtx::kScratchLog3 && kind == AdderHipCtx::kScratchLog2)))
+        return ADDER_OK;
     for (auto &kv : c->graphs)  // they bake the chunking
         for (hipGraphExec_t e : kv.second.cand)
             if (e) c->retired_execs.push_back(e);
     c->graphs.clear();
     c->tune_pending = false;
-    void *old[] = {c->park_ring, c->wtot_ring, c->wpref_ring, c->ftot_ring};
+    void *old[] = {c->park_ring, c->wtot_ring, c->wpref_ring, c->ftot_ring, c->wofs_ring, c->wcur};
     c->park_ring = nullptr;
-    c->wtot_ring = c->wpref_ring = c->ftot_ring = nullptr;
+    c->wtot_ring = c->wpref_ring = c->ftot_ring = c->wofs_ring = c->wcur = nullptr;
     c->park_bytes = 0;
+    c->log_cap = 0;
+    c->scratch_kind = AdderHipCtx::kScratchNone;
     for (void *p : old)
         if (p) HIPCHK(c, hipFree(p));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::min<size_t>((size_t)12 << 30, free_b / 4);
-    const size_t per_frame = (size_t)c->num_waves * ((size_t)bytes + 2 * sizeof(uint32_t));
+    const size_t budget = std::min<size_t>((size_t)16 << 30, free_b / 4);
     c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
     if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
     if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
@@ -801,18 +846,26 @@ static int alloc_scratch(AdderHipCtx *c, uint32_t bytes) {
         c->park_group_shift = sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
         static_assert(16 % ADDER_EXPAND_SEGS == 0, "a group (and a rotation group of 16 segments) must hold whole expansion waves");
     }
-    const size_t ch = budget / (c->ring_chunks * per_frame);
-    c->chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(ch, kMaxChunk));
+    uint32_t ch = kMaxChunk;
+    while (ch > 1u && c->ring_chunks * (scratch_bytes_per_chunk(c, kind, ch) + (size_t)c->num_waves * ch * 12u) > budget) --ch;
+    c->chunk = ch;
     if (const char *e = getenv("ADDER_HIP_CHUNK")) c->chunk = std::max(1, std::min<int>(atoi(e), kMaxChunk));
     c->slots = c->ring_chunks * c->chunk;
-    HIPCHK(c, dalloc(&c->park_ring, (size_t)c->slots * c->num_waves * bytes));
+    HIPCHK(c, dalloc(&c->park_ring, (size_t)c->ring_chunks * scratch_bytes_per_chunk(c, kind, c->chunk)));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->ftot_ring, 2 * (size_t)c->slots));  // events, then parked records per frame
-    c->park_bytes = bytes;
+    if (kind == AdderHipCtx::kScratchLog2 || kind == AdderHipCtx::kScratchLog3) {
+        HIPCHK(c, dalloc(&c->wofs_ring, (size_t)c->slots * c->num_waves));
+        HIPCHK(c, dalloc(&c->wcur, (size_t)c->ring_chunks * c->num_waves));
+        c->log_cap = log_capacity(c->chunk, c->max_depth, kind == AdderHipCtx::kScratchLog2);
+    } else {
+        c->park_bytes = (uint32_t)(scratch_bytes_per_chunk(c, kind, 1u) / c->num_waves);
+    }
+    c->scratch_kind = kind;
     if (getenv("ADDER_HIP_DEBUG_ADDRS"))
-        fprintf(stderr, "[adder_hip] slab %p park %p wtot %p wpref %p ftot %p\n", (void *)c->state_slab, (void *)c->park_ring,
-                (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring);
+        fprintf(stderr, "[adder_hip] slab %p park %p wtot %p wpref %p ftot %p chunk %u\n", (void *)c->state_slab, (void *)c->park_ring,
+                (void *)c->wtot_ring, (void *)c->wpref_ring, (void *)c->ftot_ring, c->chunk);
     return ADDER_OK;
 }
 
@@ -1123,15 +1176,23 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         int rc_ = prepare_feature_set(c, stream);
         if (rc_ != ADDER_OK) return rc_;
     }
+    const bool cb = generic && cb_possible(c, time_spanned);  // the bounded Collapse step instead of the generic one
+    if (!(time_spanned >= 1.0f) || time_spanned != (float)(uint32_t)time_spanned) c->frac_time_seen = true;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
-                             (c->n_units >= 4u ? 16u : 0u);  // 16: the 4-units-per-lane one-frame kernel may run
+                             (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
+                             (cb ? 32u : 0u);
     if (generic) {
-        // generic batches can park up to max_depth + 2 events per unit: grow the scratch on first use
-        int rc_ = alloc_scratch(c, kWaveUnits * (c->max_depth + 2) * kGenRecBytes);
+        // per-event records go to a log per segment and chunk, sized by the hard bound of what a segment can emit
+        // (pop_top and a flush exclude each other in one frame when delta_t_max >= 2 * time: 2 instead of 3 per frame)
+        const bool two = collapse && (double)c->p.delta_t_max >= 2.0 * (double)time_spanned;
+        int rc_ = alloc_scratch(c, two ? AdderHipCtx::kScratchLog2 : AdderHipCtx::kScratchLog3);
         if (rc_ == ADDER_OK) rc_ = alloc_deep_planes(c);
         if (rc_ != ADDER_OK) return rc_;
         c->generic_sticky = true;
+    } else if (!c->continuous) {
+        int rc_ = alloc_scratch(c, AdderHipCtx::kScratchLean);
+        if (rc_ != ADDER_OK) return rc_;
     }
     // an event buffer below the batch's worst case can overflow: keep an undo copy of the state so that the
     // overflow is recoverable (adder_hip_finish rolls back and reports the size needed)
@@ -1185,9 +1246,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
     b.park_bytes = c->park_bytes;
+    b.log_cap = c->log_cap;
+    b.wofs_ring = c->wofs_ring;
+    b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
-    if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
+    if (c->log_cap) {
+        b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};  // (unused: the records are appended to logs)
+    } else if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
         b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes, 31u, 0xffffffffu};
     } else {
         uint32_t sh = c->park_group_shift;

@@ -44,6 +44,7 @@ constexpr uint32_t kStatusCapacity = 1u;  // an event did not fit into the outpu
 constexpr uint32_t kStatusWire = 4u;      // wire serialisation met c = None on a multi-channel plane
 constexpr uint32_t kStatusDepth = 2u;     // a pixel needed more than max_depth stored levels
 constexpr uint32_t kStatusSparse = 8u;    // a sparse step names a pixel outside the plane / band
+constexpr uint32_t kStatusScratch = 16u;  // a segment's record log did not hold its bound (an internal error)
 
 struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint16_t x, y;
@@ -138,6 +139,14 @@ struct BatchArgs {
     uint32_t *wtot_ring;      // [slots][num_waves]
     uint32_t *wpref_ring;     // [slots][num_waves]
     uint32_t *ftot_ring;      // [2][slots]: events per frame, then parked records per frame
+    // Per-event records (the generic and the bounded Collapse frame kernels) are APPENDED to one log per segment and
+    // chunk: region (chunk in ring, segment) holds log_cap 8-byte records at park_ring + ((cir * num_waves + seg) *
+    // log_cap) * 8, a frame's run of records starts at wofs[slot][seg] and the cursor survives from one launch of a
+    // chunk to the next in wcur.  log_cap is the hard bound of what a segment can emit over a chunk (log_capacity()),
+    // so nothing can overflow; a fixed slot per frame would have to hold the per-FRAME bound (a whole arena per unit).
+    uint32_t log_cap;         // records per region; 0: fixed slots (park_layout)
+    uint32_t *wofs_ring;      // [slots][num_waves] first record of the segment's run, relative to its region
+    uint32_t *wcur;           // [ring chunks][num_waves] records appended to the region so far
     uint32_t slots;
     uint32_t chunk;           // frames per chunk; slots = chunks in the ring * chunk
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
@@ -165,6 +174,15 @@ __host__ __device__ __forceinline__ size_t park_offset(uint32_t slot, uint32_t s
     const uint32_t group = seg >> l.group_shift, r = seg - (group << l.group_shift);
     return (size_t)cir * num_waves * chunk * park_bytes + (size_t)group * l.group_stride + (size_t)fi * l.frame_stride +
            (size_t)r * l.seg_stride;
+}
+
+// Records a segment can emit over `chunk` consecutive frames, per unit.  A flush emits at most (frames since the
+// previous flush + 1) events -- every frame adds at most one level to the arena, a Collapse flush of a popped arena
+// emits 2 and needs >= 2 frames -- and max_depth at most; pop_top adds one per frame at most, and none in a frame that
+// flushed when delta_t_max >= 2 * time.  Summed: 2 * chunk + max_depth + 2 (Collapse with delta_t_max > time), 3 *
+// chunk + max_depth + 2 in general.
+__host__ __device__ __forceinline__ uint32_t log_capacity(uint32_t chunk, uint32_t max_depth, bool pops_exclude_flushes) {
+    return kWaveUnits * ((pops_exclude_flushes ? 2u : 3u) * chunk + max_depth + 2u);
 }
 
 // what the host reads after a batch (adder_publish_kernel), in page-locked host memory
@@ -235,7 +253,7 @@ __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) 
 
 extern "C" {
 // variant = collapse | abs_t << 1 | generic << 2 | continuous << 3 (host copy of what BatchArgs holds) | the band
-// has >= 4 units << 4
+// has >= 4 units << 4 | bounded Collapse step << 5 (with generic: the per-event record format)
 // K1: frames [f, f + nb) in one launch (nb > 1 = temporal blocking).  grid_cap (0 = none) bounds the number of
 // workgroups of the lean kernel / of the expansion: the workgroups then walk their work items, which leaves room
 // for the other kernel to be resident on the same CUs

@@ -100,13 +100,10 @@ struct __attribute__((aligned(4))) EventWords {
 
 // gen_emit's events of one unit, parked in final order with their final in-segment offset
 struct EmitPark {
-    uint2 *dst;     // next free parked slot of this lane
+    uint2 *seg;     // the segment's run of this frame (wave-uniform)
     uint32_t tag;   // unit_in_wave << 8
     uint32_t off;   // final offset of the unit's next event inside the segment
-    __device__ __forceinline__ void operator()(uint32_t d, uint32_t t) {
-        *dst++ = make_uint2(t, d | tag | (off << 16));
-        ++off;
-    }
+    __device__ __forceinline__ void operator()(uint32_t d, uint32_t t);
 };
 
 // kUnitsPerLane consecutive values as one vector access
@@ -182,6 +179,10 @@ __device__ __forceinline__ void gstore_nt(void *base, uint32_t byte_off, V v) {
 #ifndef ADDER_NT_RECSTORE
 #define ADDER_NT_RECSTORE 0
 #endif
+__device__ __forceinline__ void EmitPark::operator()(uint32_t d, uint32_t t) {
+    gstore<uint2>(seg, off * 8u, make_uint2(t, d | tag | (off << 16)));  // (uniform base + the lane's 32-bit offset)
+    ++off;
+}
 template <class V>
 __device__ __forceinline__ void gstore_ev(void *base, uint32_t byte_off, V v) {
     if (ADDER_NT_EVENTS) gstore_nt<V>(base, byte_off, v);
@@ -737,6 +738,39 @@ struct DeepHybrid {
     }
 };
 
+// The record log of one segment for the frames of one launch (BatchArgs::log_cap): wave-uniform, in SGPRs.
+struct SegLog {
+    uint2 *region;      // the segment's region of the launch's chunk
+    uint32_t cur, cap;  // records appended so far / the region's capacity
+    uint32_t *wcur_p;   // where the cursor lives between the launches of a chunk
+    __device__ __forceinline__ void open(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t sgw, uint32_t num_waves_u) {
+        const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
+        const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+        cap = __builtin_amdgcn_readfirstlane(b->log_cap);
+        const uint32_t slot0 = f0 % slots_u;
+        const uint32_t cir = slot0 / chunk_u;  // (a launch never crosses a chunk boundary)
+        const size_t seg_idx = (size_t)cir * num_waves_u + sgw;
+        region = reinterpret_cast<uint2 *>(uniform_ptr(b->park_ring)) + seg_idx * cap;
+        wcur_p = uniform_ptr(b->wcur) + seg_idx;
+        cur = 0u;
+        if (slot0 != cir * chunk_u) cur = __builtin_amdgcn_readfirstlane(*wcur_p);  // not the chunk's first launch
+    }
+    // room for n records of the next frame: where they start, or null (the bound was violated: reported, nothing stored)
+    __device__ __forceinline__ uint2 *append(uint32_t n, uint32_t &start, uint32_t *status) {
+        start = cur;
+        if (cur + n > cap) {
+            raise(status, kStatusScratch);
+            return nullptr;
+        }
+        uint2 *p = region + cur;
+        cur += n;
+        return p;
+    }
+    __device__ __forceinline__ void close(uint32_t lane) {
+        if (lane == 0u) *wcur_p = cur;
+    }
+};
+
 template <bool COLLAPSE, bool ABS_T>
 __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                 uint32_t u0, uint32_t gw, uint32_t lane, uint4 *lds_levels) {
@@ -783,14 +817,15 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
     const uint8_t *const frames_u = uniform_ptr(b->frames);
     const FrameTab *const ftab_u = uniform_ptr(b->ftab);
-    uint8_t *const park_ring_u = uniform_ptr(b->park_ring);
     uint32_t *const wtot_ring_u = uniform_ptr(b->wtot_ring);
-    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
     const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
     const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
     const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
     uint32_t slot = __builtin_amdgcn_readfirstlane(a.frame_idx % slots_u);
     bool depth_error = false;
+    uint32_t *const wofs_ring_u = uniform_ptr(b->wofs_ring);
+    SegLog log;
+    log.open(b, __builtin_amdgcn_readfirstlane(a.frame_idx), sgw, num_waves_u);
 
     for (uint32_t i = 0; i < nb; ++i, slot = (slot + 1u == slots_u) ? 0u : slot + 1u) {
         const uint32_t f = a.frame_idx + i;
@@ -825,16 +860,19 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         // ---------------- wave-level ordered compaction into the frame's segment ----------------
         const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
         const size_t seg_idx = (size_t)slot * num_waves_u + sgw;  // uniform
-        // events of the segment (low half) = parked records (high half): one record per event, in final order
-        if (lane == kWave - 1) gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl | (incl << 16));
+        // events of the segment (low half) = parked records (high half): one record per event, in final order,
+        // appended to the segment's log of the chunk
+        uint32_t run_start;
+        uint2 *const seg = log.append(__builtin_amdgcn_readlane(incl, kWave - 1), run_start, a.status);  // uniform
+        if (lane == kWave - 1) {
+            gstore<uint32_t>(wtot_ring_u + seg_idx, 0u, incl | (incl << 16));
+            gstore<uint32_t>(wofs_ring_u + seg_idx, 0u, run_start);
+        }
         uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
-        uint2 *const seg = reinterpret_cast<uint2 *>(
-            park_ring_u + park_offset(slot, sgw, __builtin_amdgcn_readfirstlane(b->chunk), num_waves_u, park_bytes_u,
-                                      park_layout_u(b)));  // uniform
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            if (plan[j].count != 0u) {
-                EmitPark em{seg + off, (lane * N + j) << 8, off};
+            if (plan[j].count != 0u && seg) {
+                EmitPark em{seg, (lane * N + j) << 8, off};
                 gen_emit<ABS_T>(px[j], plan[j], sc, deep[j], em);
             }
             off += plan[j].count;
@@ -849,6 +887,7 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
         vin_w = next_w;
     }
     if (depth_error) raise(a.status, kStatusDepth);
+    log.close(lane);
 
     // ---------------- state back to HBM ----------------
     {
@@ -901,6 +940,220 @@ __global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const Bat
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         gen_run_segment<COLLAPSE, ABS_T>(b, a, nb, u0, gw, lane, s_levels[tid / kWave]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1, bounded Collapse step (Collapse with delta_t_max > time_spanned: the reference's DEFAULT mode and BASELINE
+// config 5) -- adder_pixel.hpp cb_step / cb_emit / cb_pop.  Temporally blocked like the lean kernel: the root of
+// every unit lives in registers and levels 1..4 in the wave's LDS slice for the whole launch, in PREFIX COORDINATES
+// (a level that is visited without firing needs no update, and "which level fires" is four compares on one
+// 16-byte LDS read); deeper levels -- delta_t_max far beyond 30 frames -- sit in the deep planes in the same form.
+// Events leave as 8-byte records with their final in-segment offset (the generic kernel's format), appended to the
+// segment's log of the chunk.  The input bytes come through LDS in groups of kCbInFrames frames.
+// ------------------------------------------------------------------------------------------
+#ifndef ADDER_CB_IN_FRAMES
+#define ADDER_CB_IN_FRAMES 16
+#endif
+#ifndef ADDER_CB_WAVES_PER_SIMD
+#define ADDER_CB_WAVES_PER_SIMD 4
+#endif
+constexpr uint32_t kCbInFrames = ADDER_CB_IN_FRAMES;
+#define ADDER_LDS __attribute__((address_space(3)))
+using CbLevelsDev = CbLevelsT<ADDER_LDS float *>;
+struct __attribute__((aligned(16))) CbWaveLds {
+    float F[kWaveUnits * kCbFastLevels];  // [unit slot][level - 1]
+    float Q[kWaveUnits * kCbFastLevels];
+    float B[kWaveUnits * kCbFastLevels];
+    float T[kWaveUnits * kCbFastLevels];  // the level's threshold 2^d
+    uint8_t in[kCbInFrames * kWaveUnits]; // [frame of the group][unit]
+};
+
+// the next group of input frames of one segment -> the wave's LDS slice (frames [k0, k0 + kCbInFrames) of the launch)
+template <bool FULL>
+__device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_units_u, uint32_t sgw, uint32_t u0,
+                                               uint32_t lane, uint32_t k0, uint32_t nb, uint8_t *lds_in, bool direct) {
+    constexpr uint32_t N = kUnitsPerLane;
+    using InT = typename VecOf<uint8_t, N>::type;
+    static_assert(kWaveUnits == 128u && kCbInFrames % 8u == 0u, "eight frames of one segment per instruction");
+    if (direct) {  // global_load_lds_dwordx4: lane i fetches 16 bytes of frame 8 g + i / 8, parked at M0 + 16 i
+        const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
+#pragma unroll
+        for (uint32_t g = 0; g < kCbInFrames / 8u; ++g) {
+            uint32_t k = k0 + g * 8u + (lane >> 3);
+            k = k < nb ? k : nb - 1u;
+            __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
+                                             (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                             ADDER_NT_INPUT ? 2 : 0);
+        }
+    } else {  // ragged or unaligned segments: through registers, a frame at a time (rare: not unrolled)
+        InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;
+#pragma unroll 1
+        for (uint32_t q = 0; q < kCbInFrames; ++q) {
+            const uint32_t k = k0 + q;
+            const uint32_t kk = k < nb ? k : nb - 1u;
+            in_lds[q * kWave] = (InT)load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed (and so have the records stored so far)
+}
+
+template <bool ABS_T, bool FULL>
+__device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
+                                               uint32_t u0, uint32_t gw, uint32_t lane, CbWaveLds &w) {
+    constexpr uint32_t N = kUnitsPerLane;
+    CbPx px[N];
+    {
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N], lfv[N];
+        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
+        load_vec<ADDER_NT_STATE != 0>(a.integ0, u0, iv);
+        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
+        load_vec<ADDER_NT_STATE != 0>(a.bdt0, u0, bv);
+        if (ABS_T) load_vec<ADDER_NT_STATE != 0>(a.lastf, u0, lfv);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            px[j] = cb_unpack(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
+            if (px[j].popped && px[j].m > 1u) px[j].m = 1u;  // a popped arena keeps only its root
+        }
+    }
+    StepConsts sc = a.sc;
+    const float T = sc.time_spanned;
+    // levels >= 1: resident form -> prefix coordinates, once per launch
+    CbLevelsDev lv[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t slot = j * kWave + lane;  // consecutive lanes -> consecutive 16-byte slots
+        lv[j] = CbLevelsDev{(ADDER_LDS float *)(w.F + slot * kCbFastLevels), (ADDER_LDS float *)(w.Q + slot * kCbFastLevels),
+                            (ADDER_LDS float *)(w.B + slot * kCbFastLevels), (ADDER_LDS float *)(w.T + slot * kCbFastLevels),
+                            a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
+        const DeepGlobal g{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
+        for (uint32_t k = 1; k < px[j].m; ++k) {
+            Node nk;
+            g.load(k, nk);
+            lv[j].store(k, cb_level_from_node(px[j], nk));
+        }
+    }
+
+    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
+    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    const uint32_t f0 = __builtin_amdgcn_readfirstlane(a.frame_idx);
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(f0 % slots_u);
+    // the launch's rows of the per-frame table: one vector load, a lane read per frame
+    uint32_t tab_cth = 0u, tab_rt = 0u;
+    if (lane < nb) {
+        const uint2 e = gload<uint2>(uniform_ptr(b->ftab), (f0 + lane) * (uint32_t)sizeof(FrameTab));
+        tab_rt = e.x;
+        tab_cth = e.y;
+    }
+    SegLog log;
+    log.open(b, f0, sgw, num_waves_u);
+    const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+    const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
+                        __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+    using InT = typename VecOf<uint8_t, N>::type;
+    const InT *const in_lds = reinterpret_cast<const InT *>(w.in) + lane;
+    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
+    bool depth_error = false;
+
+    for (uint32_t i = 0; i < nb; ++i) {
+        if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
+        const uint32_t vin_w = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
+        sc.cth = __builtin_amdgcn_readlane(tab_cth, i);
+        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
+        sc.running_t_u32 = f32_as_u32(sc.running_t);
+
+        // ---------------- the step of every unit + the event counts ----------------
+        CbPlan plan[N];
+        uint32_t lane_cnt = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+            cb_step(px[j], lv[j], v, T, sc, plan[j]);
+            depth_error = depth_error || plan[j].depth_error;
+            if (!(FULL || u0 + j < n_units_u)) {  // padding units: stepped freely, their events suppressed
+                plan[j].count = 0u;
+                plan[j].flush = false;
+                plan[j].need_pop = false;
+            }
+            lane_cnt += plan[j].count;
+        }
+        // ---------------- wave-level ordered compaction into the segment's log ----------------
+        const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        uint32_t run_start;
+        uint2 *const seg = log.append(total, run_start, a.status);  // uniform
+        wt = lane == i ? (total | (total << 16)) : wt;
+        wo = lane == i ? run_start : wo;
+        uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            if (plan[j].count != 0u && seg) {
+#ifndef ADDER_DBG_CB_NOEMIT
+                EmitPark em{seg, (lane * N + j) << 8, off};
+                cb_emit<ABS_T>(px[j], plan[j], sc, lv[j], em);
+#endif
+            }
+            off += plan[j].count;
+            cb_pop(px[j], plan[j], lv[j]);
+        }
+    }
+    if (depth_error) raise(a.status, kStatusDepth);
+    log.close(lane);
+    if (lane < nb) {
+        uint32_t s = slot0 + lane;
+        s = s >= slots_u ? s - slots_u : s;
+        gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
+        gstore<uint32_t>(uniform_ptr(b->wofs_ring), (s * num_waves_u + sgw) * 4u, wo);
+    }
+
+    // ---------------- state back to HBM: levels in their resident form ----------------
+    {
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N], lfv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const DeepGlobal g{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
+            for (uint32_t k = 1; k < px[j].m; ++k) g.store(k, cb_node_from_level(px[j], lv[j].load(k)));
+            hdrv[j] = cb_hdr(px[j]);
+            iv[j] = px[j].S;
+            dv[j] = px[j].dt0;
+            bv[j] = px[j].bdt0;
+            lfv[j] = px[j].lastf;
+        }
+        constexpr bool NTS = ADDER_NT_STATE != 0;
+        store_vec<NTS>(a.hdr, u0, hdrv);
+        store_vec<NTS>(a.integ0, u0, iv);
+        store_vec<NTS>(a.dt0, u0, dv);
+        store_vec<NTS>(a.bdt0, u0, bv);
+        if (ABS_T) store_vec<NTS>(a.lastf, u0, lfv);
+        if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j)
+                if (u0 + j < n_units_u && px[j].m != 0u)
+                    a.running[u0 + j] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(px[j].thr0)),
+                                                                f32_as_u32(px[j].bdt0), (double)sc.ref_time);
+        }
+    }
+}
+
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_cb_kernel(const BatchArgs *__restrict__ b,
+                                                                                         uint32_t f, uint32_t nb) {
+    __shared__ CbWaveLds s_w[kWavesPerBlock];
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    timeline_mark(b, 0u, f, false);
+    // (a capped grid walks the segments, like the lean kernel; the wave's LDS slice is its own, no barrier needed)
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
+        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        if (full) cb_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_w[tid / kWave]);
+        else cb_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_w[tid / kWave]);
+    }
+    timeline_mark(b, 0u, f, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1230,10 +1483,11 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // (the wave's kExpandSegs segments lie in one group -- seg0 is a multiple of kExpandSegs, a group holds 1 or a
     // multiple of kExpandSegs segments -- so consecutive ones are a constant stride apart)
     const ParkLayout lay = park_layout_u(b);
-    const uint32_t seg_stride = __builtin_amdgcn_readfirstlane(
+    const uint32_t seg_stride = FORMAT == 0 ? 0u : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
                    park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay)));
-    const uint8_t *park = uniform_ptr(b->park_ring) + park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay);
+    const uint8_t *park = uniform_ptr(b->park_ring) +
+                          (FORMAT == 0 ? (size_t)0 : park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay));
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
     UnitCoord uc;
@@ -1255,6 +1509,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // with a segment of more than 32 records takes the one-segment-at-a-time path below.
     const uint32_t half = lane >> 5, hl = lane & 31u;
     uint4 first[LEAN ? kExpandSegs / 2u : kExpandSegs];  // (lean: {ta, tc, w, -})
+    const uint8_t *log0 = nullptr;  // per-event records: the log region of segment seg0, the regions' stride, and
+    uint32_t log_stride = 0u;       // where each segment's run of this frame starts inside its region (bytes)
+    uint32_t log_run[FORMAT == 0 ? kExpandSegs : 1u];
     if (LEAN) {
 #pragma unroll
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
@@ -1267,12 +1524,20 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             }
         }
     } else if (FORMAT == 0) {
+        // per-event records: a segment's run of this frame starts at wofs inside the segment's log of the chunk
+        uint32_t my_ofs = 0u;
+        if (lane < kExpandSegs)
+            my_ofs = gload<uint32_t>(uniform_ptr(b->wofs_ring) + (size_t)slot * num_waves + seg0, lane * 4u);
+        const uint32_t log_cap = __builtin_amdgcn_readfirstlane(b->log_cap);
+        log0 = uniform_ptr(b->park_ring) + ((size_t)(slot / chunk_frames) * num_waves + seg0) * log_cap * kGenRecBytes;
+        log_stride = log_cap * kGenRecBytes;
 #pragma unroll
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
             const uint32_t parked = __builtin_amdgcn_readlane(my_tot, q) >> 16;
+            log_run[q] = __builtin_amdgcn_readlane(my_ofs, q) * kGenRecBytes;
             first[q] = make_uint4(0u, 0u, 0u, 0u);
             if (lane < parked) {
-                const uint2 v = gload_rec<uint2>(park + (size_t)q * seg_stride, lane * kGenRecBytes);
+                const uint2 v = gload_rec<uint2>(log0 + (size_t)q * log_stride, log_run[q] + lane * kGenRecBytes);
                 first[q] = make_uint4(v.x, v.y, 0u, 0u);
             }
         }
@@ -1391,7 +1656,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t q = 0; q < kExpandSegs; ++q) {
             const uint32_t tot = __builtin_amdgcn_readlane(my_tot, q);
             const uint32_t parked = tot >> 16;
-            const uint8_t *const seg_park = park + (size_t)q * seg_stride;
+            const uint8_t *const seg_park = log0 + (size_t)q * log_stride + log_run[FORMAT == 0 ? q : 0u];
             // every record carries its event's offset inside the segment; a segment's events are staged
             // in pieces of the buffer's size (the segment total is known: tot & 0xffff)
             const uint32_t seg_events = tot & 0xffffu;
@@ -1784,6 +2049,12 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     if (variant & 8u) {  // Mode::Continuous
         if (abs_t) hipLaunchKernelGGL((adder_cont_kernel<true>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
         else hipLaunchKernelGGL((adder_cont_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
+        return hipGetLastError();
+    }
+    if (variant & 32u) {  // bounded Collapse step
+        const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
+        if (abs_t) hipLaunchKernelGGL((adder_cb_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_cb_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
         return hipGetLastError();
     }
     if (generic) {

@@ -622,67 +622,75 @@ ADDER_HD void gen_pop(PxState &s, const GenPlan &p, Deep &deep) {
 constexpr uint32_t kCbFastLevels = 4;  // levels 1..4 of a unit sit side by side (one 16-byte read finds the one that fires)
 
 struct CbLevel {
-    float F;      // fire-at: the level fires in the first frame whose root integration reaches F
-    float Q;      // root delta_t minus the level's delta_t
-    float bdt;    // best_event.delta_t
-    uint32_t bd;  // best_event.d
+    float F;    // fire-at: the level fires in the first frame whose root integration reaches F
+    float Q;    // root delta_t minus the level's delta_t
+    float bdt;  // best_event.delta_t
+    float thr;  // 2^d of the level (0 for d = 128); best_event.d is its exponent minus one (lean_bd_from_thr)
 };
 
-// Levels k >= 1 of ONE unit.  Levels 1..kCbFastLevels: four consecutive floats per plane (F4, Q4, B4) and four
-// packed bytes (bd4) -- the wave's LDS slice on the device, plain arrays in the CPU harness.  Deeper levels
+// Levels k >= 1 of ONE unit.  Levels 1..kCbFastLevels: four consecutive floats per plane (F4, Q4, B4, T4) -- the
+// wave's LDS slice on the device (FP is then an LDS pointer), plain arrays in the CPU harness.  Deeper levels
 // (delta_t_max beyond ~30 frames, or adversarial input) go to the context's deep planes, level k at [k - 1][u],
 // which hold {F, Q, best_delta_t, best_d} instead of {integration, delta_t, ..} for the duration of a launch.
-struct CbLevels {
-    float *F4, *Q4, *B4;
-    uint32_t *bd4;
+template <class FP>
+struct CbLevelsT {
+    FP F4, Q4, B4, T4;
     float *gF, *gQ, *gB;
     uint8_t *gbd;
     size_t stride, u;
-    ADDER_HD CbLevel load(uint32_t k) const {
+    ADDER_HD CbLevel load_fast(uint32_t k) const {  // 1 <= k <= kCbFastLevels
         CbLevel l;
-        if (k <= kCbFastLevels) {
-            l.F = F4[k - 1u];
-            l.Q = Q4[k - 1u];
-            l.bdt = B4[k - 1u];
-            l.bd = (*bd4 >> (8u * (k - 1u))) & 0xffu;
-        } else {
-            const size_t i = (size_t)(k - 1u) * stride + u;
-            l.F = gF[i];
-            l.Q = gQ[i];
-            l.bdt = gB[i];
-            l.bd = gbd[i];
-        }
+        l.F = F4[k - 1u];
+        l.Q = Q4[k - 1u];
+        l.bdt = B4[k - 1u];
+        l.thr = T4[k - 1u];
         return l;
     }
-    ADDER_HD void store(uint32_t k, const CbLevel &l) const {
-        if (k <= kCbFastLevels) {
-            F4[k - 1u] = l.F;
-            Q4[k - 1u] = l.Q;
-            B4[k - 1u] = l.bdt;
-            const uint32_t sh = 8u * (k - 1u);
-            *bd4 = (*bd4 & ~(0xffu << sh)) | ((l.bd & 0xffu) << sh);
-        } else {
-            const size_t i = (size_t)(k - 1u) * stride + u;
-            gF[i] = l.F;
-            gQ[i] = l.Q;
-            gB[i] = l.bdt;
-            gbd[i] = (uint8_t)l.bd;
-        }
+    ADDER_HD void store_fast(uint32_t k, const CbLevel &l) const {
+        F4[k - 1u] = l.F;
+        Q4[k - 1u] = l.Q;
+        B4[k - 1u] = l.bdt;
+        T4[k - 1u] = l.thr;
     }
-    // The shallowest level in [1, m) whose fire-at value S has reached, or m (then the pristine tail fires).
-    // Slots of levels >= m hold stale values; whatever they say, min(., m) is right.
-    ADDER_HD uint32_t first_firing(float S, uint32_t m) const {
+    ADDER_HD CbLevel load_deep(uint32_t k) const {  // k > kCbFastLevels
+        const size_t i = (size_t)(k - 1u) * stride + u;
+        CbLevel l;
+        l.F = gF[i];
+        l.Q = gQ[i];
+        l.bdt = gB[i];
+        l.thr = lean_thr_from_bd(gbd[i]);
+        return l;
+    }
+    ADDER_HD void store_deep(uint32_t k, const CbLevel &l) const {
+        const size_t i = (size_t)(k - 1u) * stride + u;
+        gF[i] = l.F;
+        gQ[i] = l.Q;
+        gB[i] = l.bdt;
+        gbd[i] = (uint8_t)lean_bd_from_thr(f32_to_bits(l.thr));
+    }
+    ADDER_HD CbLevel load(uint32_t k) const { return k <= kCbFastLevels ? load_fast(k) : load_deep(k); }
+    ADDER_HD void store(uint32_t k, const CbLevel &l) const {
+        if (k <= kCbFastLevels) store_fast(k, l);
+        else store_deep(k, l);
+    }
+    // The shallowest of the four fast levels whose fire-at value S has reached, or kCbFastLevels + 1.  Slots of levels
+    // that do not exist hold stale values; the caller's min(., m) makes them harmless.
+    ADDER_HD uint32_t first_fast(float S) const {
         uint32_t kf = kCbFastLevels + 1u;
         kf = S >= F4[3] ? 4u : kf;
         kf = S >= F4[2] ? 3u : kf;
         kf = S >= F4[1] ? 2u : kf;
         kf = S >= F4[0] ? 1u : kf;
-        if (kf > kCbFastLevels)
-            for (; kf < m; ++kf)
-                if (S >= gF[(size_t)(kf - 1u) * stride + u]) break;
-        return kf < m ? kf : m;
+        return kf;
+    }
+    ADDER_HD uint32_t first_deep(float S, uint32_t m) const {  // levels kCbFastLevels + 1 .. m - 1, or m
+        uint32_t k = kCbFastLevels + 1u;
+        for (; k < m; ++k)
+            if (S >= gF[(size_t)(k - 1u) * stride + u]) break;
+        return k;
     }
 };
+using CbLevels = CbLevelsT<float *>;
 
 struct CbPx {
     float S, dt0, bdt0;  // the root's integration, delta_t, best_event.delta_t   (meaningful iff m > 0)
@@ -709,18 +717,18 @@ ADDER_HD uint32_t cb_hdr(const CbPx &s) { return hdr_make(s.base, lean_bd_from_t
 // with the generic step) and prefix coordinates.  A popped arena keeps only its root (header comment).
 ADDER_HD CbLevel cb_level_from_node(const CbPx &s, const Node &n) {
     CbLevel l;
-    l.F = fadd(fsub(s.S, n.integ), lean_thr_from_bd(n.bd));
+    l.thr = lean_thr_from_bd(n.bd);
+    l.F = fadd(fsub(s.S, n.integ), l.thr);
     l.Q = fsub(s.dt0, n.dt);
     l.bdt = n.bdt;
-    l.bd = n.bd;
     return l;
 }
 ADDER_HD Node cb_node_from_level(const CbPx &s, const CbLevel &l) {
     Node n;
-    n.integ = fsub(s.S, fsub(l.F, lean_thr_from_bd(l.bd)));
+    n.integ = fsub(s.S, fsub(l.F, l.thr));
     n.dt = fsub(s.dt0, l.Q);
     n.bdt = l.bdt;
-    n.bd = l.bd;
+    n.bd = lean_bd_from_thr(f32_to_bits(l.thr));
     return n;
 }
 
@@ -734,8 +742,12 @@ struct CbPlan {
     uint32_t count;   // events of this unit this frame
 };
 
-// pop_best_events' bookkeeping + integrate (:317-413) of one unit.  The unit's OLD levels 1 .. m_old-1 are still in
-// place afterwards when plan.flush is set (a flushed arena restarts from the tail at index 0, which touches no level).
+// pop_best_events' bookkeeping + integrate (:317-413) of one unit.  Exactly one node fires per frame while the arena
+// is not popped -- arena index 0 (the root, or the pristine tail of an empty arena), else the shallowest level whose
+// fire-at value the root's integration has reached, else the pristine tail behind the levels -- and none or the root
+// once it is (:360-362).  The firing arm of integrate_main (:427-473) is computed ONCE, on the node's (integration,
+// delta_t, threshold) gathered from wherever it lives.  The unit's OLD levels 1 .. m_old-1 are still in place
+// afterwards when plan.flush is set (a flushed arena restarts from the tail at index 0, which touches no level).
 template <class Lv>
 ADDER_HD void cb_step(CbPx &s, const Lv &lv, uint32_t v, float T, const StepConsts &sc, CbPlan &p) {
     const float I = (float)v;
@@ -749,53 +761,69 @@ ADDER_HD void cb_step(CbPx &s, const Lv &lv, uint32_t v, float T, const StepCons
     const uint32_t m = p.flush ? 0u : s.m;
     const bool popped = s.popped && !p.flush;
     s.base = p.flush ? v : s.base;
-    const float S_old = m ? s.S : 0.0f, dt_old = m ? s.dt0 : 0.0f;
+    const bool has0 = m != 0u;
+    const float S_old = has0 ? s.S : 0.0f, dt_old = has0 ? s.dt0 : 0.0f;
     const float S_new = fadd(S_old, I);
-    // arena index 0: the root, or the pristine tail (which always fires)
-    const bool root_fires = m == 0u || S_new >= s.thr0;
-    if (root_fires) {
-        const bool zero = S_new == 0.0f;  // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
-        const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);  // 2^get_d(sum)
-        const bool unit_prop = zero || (m != 0u && s.thr0 == 0.0f);       // :432-437 (a pristine tail with d = 128 has I = 0)
-        const float q = fdiv_small(fsub(p2, S_old), I);
-        const float prop = unit_prop ? 1.0f : q;
-        s.bdt0 = fadd(dt_old, fmul(T, prop));
-        s.S = S_new;
-        s.dt0 = zero ? dt_old : fadd(dt_old, T);
-        s.thr0 = fadd(p2, p2);
-        s.m = 1u;
-    } else {
-        s.S = S_new;  // the root accumulates (:474-478)
-        s.dt0 = fadd(dt_old, T);
-        s.m = m;
-        if (!popped) {  // Collapse: once popped only the root integrates (:360-362)
-            const uint32_t k = lv.first_firing(S_new, m);
+    const bool root_fires = !has0 || S_new >= s.thr0;  // (the pristine tail at index 0 always fires)
+    // ---- which node fires, and its (integration, delta_t, threshold) as offsets from the root's ----
+    uint32_t k = 0u;
+    bool fresh = !has0;  // the firing node is a pristine tail: integration 0, delta_t 0, d = get_d(I) (:332-335)
+    float P = 0.0f, Qk = 0.0f, thr_old = s.thr0;
+    const bool walk = !root_fires && !popped;
+    if (walk) {
+        const uint32_t kf = lv.first_fast(S_new);
+        k = kf < m ? kf : m;
+        if (kf > kCbFastLevels && m > kCbFastLevels) {  // rare: the arena is deeper than the fast slots
+            k = lv.first_deep(S_new, m);
             if (k >= sc.max_depth) {
                 p.depth_error = true;
-            } else {
-                CbLevel l;
-                float P = S_old, Qk = dt_old;  // the pristine tail at index k == m: integration 0, delta_t 0
-                bool d128 = I < 1.0f;          // ... and d = get_d(I) (:332-335)
-                if (k < m) {
-                    l = lv.load(k);
-                    P = fsub(l.F, lean_thr_from_bd(l.bd));
-                    Qk = l.Q;
-                    d128 = l.bd == kDZero;
-                }
-                const float integ_old = fsub(S_old, P), dtk_old = fsub(dt_old, Qk);
-                const float sum = fadd(integ_old, I);
-                const bool zero = sum == 0.0f;
-                const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);
-                const float q = fdiv_small(fsub(p2, integ_old), I);
-                const float prop = (zero || d128) ? 1.0f : q;
-                l.bdt = fadd(dtk_old, fmul(T, prop));
-                l.bd = lean_bd_from_thr(f32_to_bits(fadd(p2, p2)));
-                l.F = fadd(P, fadd(p2, p2));
-                l.Q = zero ? fadd(Qk, T) : Qk;  // a d = 128 firing does not advance the level's delta_t; the root's did
-                lv.store(k, l);
-                s.m = k + 1u;
+                k = sc.max_depth - 1u;  // (flagged; keep the accesses inside the planes)
             }
+            fresh = k >= m;
+            if (!fresh) {
+                const CbLevel l = lv.load(k);
+                P = fsub(l.F, l.thr);
+                Qk = l.Q;
+                thr_old = l.thr;
+            }
+        } else {
+            if (k >= sc.max_depth) {
+                p.depth_error = true;
+                k = sc.max_depth > 1u ? sc.max_depth - 1u : 1u;
+            }
+            fresh = k >= m;
+            const CbLevel l = lv.load_fast(k);  // (a stale slot when fresh: selected away)
+            P = fsub(l.F, l.thr);
+            Qk = l.Q;
+            thr_old = l.thr;
         }
+        P = fresh ? S_old : P;
+        Qk = fresh ? dt_old : Qk;
+    }
+    // ---- the firing arm, once (:427-473) ----
+    const float integ_old = fsub(S_old, P), dtk_old = fsub(dt_old, Qk);
+    const float sum = fadd(integ_old, I);
+    const bool zero = sum == 0.0f;      // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
+    const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);  // 2^get_d(sum)
+    const bool d128 = fresh ? I < 1.0f : thr_old == 0.0f;           // the node's d before it fires (:432-437)
+    const float q = fdiv_small(fsub(p2, integ_old), I);
+    const float prop = (zero || d128) ? 1.0f : q;
+    const float bdt = fadd(dtk_old, fmul(T, prop));
+    const float thr2 = fadd(p2, p2);
+    // ---- where the result goes ----
+    s.S = S_new;  // (a root that fires at d = 128 has S_new == S_old)
+    s.dt0 = (root_fires && zero) ? dt_old : fadd(dt_old, T);
+    s.bdt0 = root_fires ? bdt : s.bdt0;
+    s.thr0 = root_fires ? thr2 : s.thr0;
+    s.m = root_fires ? 1u : m;
+    if (walk) {
+        CbLevel l;
+        l.F = fadd(P, thr2);
+        l.Q = zero ? fadd(Qk, T) : Qk;  // a d = 128 firing does not advance the level's delta_t; the root's did
+        l.bdt = bdt;
+        l.thr = thr2;
+        lv.store(k, l);
+        s.m = k + 1u;
     }
     s.popped = popped;
     p.need_pop = s.dt0 >= sc.dtm_f && !popped;  // :394-396 (d == D_MAX cannot happen with 8-bit input)
@@ -813,9 +841,27 @@ ADDER_HD void cb_emit(CbPx &s, const CbPlan &p, const StepConsts &sc, const Lv &
             emit(kDEmpty, f32_as_u32(sc.running_t));
         } else {
             emit(bd, event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
-            for (uint32_t k = 1; k < p.m_old; ++k) {
-                const CbLevel l = lv.load(k);
-                emit(l.bd, event_time<ABS_T>(l.bdt, s.lastf, sc));
+            // levels 1 .. m_old-1 in order: the fast ones without a loop (each step narrows the active lanes), the
+            // rest -- rare -- from the deep planes
+            if (p.m_old > 1u) {
+                const CbLevel l1 = lv.load_fast(1);
+                emit(lean_bd_from_thr(f32_to_bits(l1.thr)), event_time<ABS_T>(l1.bdt, s.lastf, sc));
+                if (p.m_old > 2u) {
+                    const CbLevel l2 = lv.load_fast(2);
+                    emit(lean_bd_from_thr(f32_to_bits(l2.thr)), event_time<ABS_T>(l2.bdt, s.lastf, sc));
+                    if (p.m_old > 3u) {
+                        const CbLevel l3 = lv.load_fast(3);
+                        emit(lean_bd_from_thr(f32_to_bits(l3.thr)), event_time<ABS_T>(l3.bdt, s.lastf, sc));
+                        if (p.m_old > 4u) {
+                            const CbLevel l4 = lv.load_fast(4);
+                            emit(lean_bd_from_thr(f32_to_bits(l4.thr)), event_time<ABS_T>(l4.bdt, s.lastf, sc));
+                            for (uint32_t k = kCbFastLevels + 1u; k < p.m_old; ++k) {
+                                const CbLevel l = lv.load_deep(k);
+                                emit(lean_bd_from_thr(f32_to_bits(l.thr)), event_time<ABS_T>(l.bdt, s.lastf, sc));
+                            }
+                        }
+                    }
+                }
             }
         }
     }
@@ -828,12 +874,11 @@ template <class Lv>
 ADDER_HD void cb_pop(CbPx &s, const CbPlan &p, const Lv &lv) {
     if (!p.need_pop) return;
     if (s.m >= 2u) {
-        const CbLevel l = lv.load(1);
-        const float thr = lean_thr_from_bd(l.bd);
-        s.S = fsub(s.S, fsub(l.F, thr));
+        const CbLevel l = lv.load_fast(1);
+        s.S = fsub(s.S, fsub(l.F, l.thr));
         s.dt0 = fsub(s.dt0, l.Q);
         s.bdt0 = l.bdt;
-        s.thr0 = thr;
+        s.thr0 = l.thr;
         s.m = 1u;
     } else {
         s.m = 0u;

@@ -299,8 +299,8 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 if (p.popped && p.m > 1u) p.m = 1u;  // a popped arena keeps only its root
                 // garbage on purpose: slots of levels >= m must never decide anything
                 float F4[4] = {-3.0f, 1e30f, 0.0f, -1e30f}, Q4[4] = {7.0f, 7.0f, 7.0f, 7.0f}, B4[4] = {9.0f, 9.0f, 9.0f, 9.0f};
-                uint32_t bd4 = 0xdeadbeefu;
-                CbLevels lv{F4, Q4, B4, &bd4, s->lv_integ.data(), s->lv_dt.data(), s->lv_bdt.data(), s->lv_bd.data(), s->N, u};
+                float T4[4] = {3.0f, -1.0f, 1e20f, 0.0f};
+                CbLevels lv{F4, Q4, B4, T4, s->lv_integ.data(), s->lv_dt.data(), s->lv_bdt.data(), s->lv_bd.data(), s->N, u};
                 DeepAcc deep{s, u};
                 for (uint32_t k = 1; k < p.m; ++k) {
                     Node n;

@@ -280,7 +280,7 @@ def test_prophesee_source_dvs_events_to_adder(tmp_path):
     got, calls = Hst.prophesee(dvs, W, H, 20)
     want, want_calls = _prophesee_restatement(dvs, W, H, 20)
     assert calls == want_calls >= 10
-    assert len(got) == len(want) > n and np.array_equal(got, want)
+    assert len(got) == len(want) > n // 2 and np.array_equal(got, want)
 
 
 @pytest.mark.gpu
