@@ -183,6 +183,27 @@ __device__ __forceinline__ void EmitPark::operator()(uint32_t d, uint32_t t) {
     gstore<uint2>(seg, off * 8u, make_uint2(t, d | tag | (off << 16)));  // (uniform base + the lane's 32-bit offset)
     ++off;
 }
+// The bounded Collapse kernel's records: {t, code | unit << 9 | final offset << 16} with the 9-bit d code of
+// adder_pixel.hpp (cb_d_from_code): the top nine bits of the threshold word, so one v_alignbit builds the word.
+struct EmitCb {
+    uint2 *seg;       // the segment's run of this frame (wave-uniform)
+    uint32_t tagoff;  // unit_in_wave | offset << 7
+    uint32_t boff;    // offset * 8: where the next record goes
+#ifdef ADDER_DBG_CB_NOSTORE
+    uint32_t dbg_acc = 0u;
+#endif
+    __device__ __forceinline__ void put(uint32_t w1, uint32_t t) {
+#ifdef ADDER_DBG_CB_NOSTORE
+        dbg_acc ^= t ^ w1;
+#else
+        gstore<uint2>(seg, boff, make_uint2(t, w1));
+#endif
+        tagoff += 1u << 7;
+        boff += kGenRecBytes;
+    }
+    __device__ __forceinline__ void ev(uint32_t thr_bits, uint32_t t) { put(__builtin_amdgcn_alignbit(tagoff, thr_bits, 23), t); }
+    __device__ __forceinline__ void filler(uint32_t t) { put((tagoff << 9) | kCbCodeEmpty, t); }
+};
 template <class V>
 __device__ __forceinline__ void gstore_ev(void *base, uint32_t byte_off, V v) {
     if (ADDER_NT_EVENTS) gstore_nt<V>(base, byte_off, v);
@@ -957,14 +978,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void adder_frame_kernel(const Bat
 #ifndef ADDER_CB_WAVES_PER_SIMD
 #define ADDER_CB_WAVES_PER_SIMD 4
 #endif
+#ifndef ADDER_CB_WAVE_LANES
+#define ADDER_CB_WAVE_LANES 0
+#endif
 constexpr uint32_t kCbInFrames = ADDER_CB_IN_FRAMES;
 #define ADDER_LDS __attribute__((address_space(3)))
 using CbLevelsDev = CbLevelsT<ADDER_LDS float *>;
 struct __attribute__((aligned(16))) CbWaveLds {
     float F[kWaveUnits * kCbFastLevels];  // [unit slot][level - 1]
     float Q[kWaveUnits * kCbFastLevels];
-    float B[kWaveUnits * kCbFastLevels];
-    float T[kWaveUnits * kCbFastLevels];  // the level's threshold 2^d
+    float BT[kWaveUnits * kCbFastLevels * 2];  // {best_delta_t, threshold 2^d} pairs
     uint8_t in[kCbInFrames * kWaveUnits]; // [frame of the group][unit]
 };
 
@@ -1001,7 +1024,14 @@ template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                uint32_t u0, uint32_t gw, uint32_t lane, CbWaveLds &w) {
     constexpr uint32_t N = kUnitsPerLane;
-    CbPx px[N];
+    // (booleans as wave masks -- the lean kernel's trick -- measured SLOWER here: with two units' worth of masks live
+    // across the step the scalar registers spill into VGPR lanes, 258 instead of 238 VALU instructions per wave-frame)
+#if ADDER_CB_WAVE_LANES
+    using L = WaveLanes;
+#else
+    using L = ScalarLanes;
+#endif
+    CbPxT<L> px[N];
     {
         uint32_t hdrv[N];
         float iv[N], dv[N], bv[N], lfv[N];
@@ -1012,8 +1042,8 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         if (ABS_T) load_vec<ADDER_NT_STATE != 0>(a.lastf, u0, lfv);
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            px[j] = cb_unpack(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
-            if (px[j].popped && px[j].m > 1u) px[j].m = 1u;  // a popped arena keeps only its root
+            px[j] = cb_unpack<L>(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
+            if (L::lane(px[j].popped) && px[j].m > 1u) px[j].m = 1u;  // a popped arena keeps only its root
         }
     }
     StepConsts sc = a.sc;
@@ -1024,7 +1054,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     for (uint32_t j = 0; j < N; ++j) {
         const uint32_t slot = j * kWave + lane;  // consecutive lanes -> consecutive 16-byte slots
         lv[j] = CbLevelsDev{(ADDER_LDS float *)(w.F + slot * kCbFastLevels), (ADDER_LDS float *)(w.Q + slot * kCbFastLevels),
-                            (ADDER_LDS float *)(w.B + slot * kCbFastLevels), (ADDER_LDS float *)(w.T + slot * kCbFastLevels),
+                            (ADDER_LDS float *)(w.BT + slot * kCbFastLevels * 2u),
                             a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
         const DeepGlobal g{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j};
         for (uint32_t k = 1; k < px[j].m; ++k) {
@@ -1055,7 +1085,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     using InT = typename VecOf<uint8_t, N>::type;
     const InT *const in_lds = reinterpret_cast<const InT *>(w.in) + lane;
     uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
-    bool depth_error = false;
+    typename L::Mask depth_error = L::from(false);
 
     for (uint32_t i = 0; i < nb; ++i) {
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
@@ -1065,18 +1095,16 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         sc.running_t_u32 = f32_as_u32(sc.running_t);
 
         // ---------------- the step of every unit + the event counts ----------------
-        CbPlan plan[N];
+        CbPlanT<L> plan[N];
+        CbMidT<L> mid[N];
         uint32_t lane_cnt = 0u;
 #pragma unroll
+        for (uint32_t j = 0; j < N; ++j) cb_step_a<L>(px[j], lv[j], (vin_w >> (8 * j)) & 0xffu, sc, plan[j], mid[j]);
+#pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
-            cb_step(px[j], lv[j], v, T, sc, plan[j]);
-            depth_error = depth_error || plan[j].depth_error;
-            if (!(FULL || u0 + j < n_units_u)) {  // padding units: stepped freely, their events suppressed
-                plan[j].count = 0u;
-                plan[j].flush = false;
-                plan[j].need_pop = false;
-            }
+            cb_step_b<L>(px[j], lv[j], T, sc, plan[j], mid[j]);
+            depth_error = L::or_(depth_error, plan[j].depth_error);
+            if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;  // padding units: stepped freely, no events
             lane_cnt += plan[j].count;
         }
         // ---------------- wave-level ordered compaction into the segment's log ----------------
@@ -1091,15 +1119,18 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u && seg) {
 #ifndef ADDER_DBG_CB_NOEMIT
-                EmitPark em{seg, (lane * N + j) << 8, off};
-                cb_emit<ABS_T>(px[j], plan[j], sc, lv[j], em);
+                EmitCb em{seg, (lane * N + j) | (off << 7), off * kGenRecBytes};
+                cb_emit<ABS_T, L>(px[j], plan[j], sc, lv[j], em);
+#ifdef ADDER_DBG_CB_NOSTORE
+                wo ^= em.dbg_acc;
+#endif
 #endif
             }
             off += plan[j].count;
-            cb_pop(px[j], plan[j], lv[j]);
+            cb_pop<L>(px[j], plan[j], lv[j]);
         }
     }
-    if (depth_error) raise(a.status, kStatusDepth);
+    if (L::lane(depth_error)) raise(a.status, kStatusDepth);
     log.close(lane);
     if (lane < nb) {
         uint32_t s = slot0 + lane;
@@ -1674,10 +1705,13 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     const uint32_t pos = sl.y >> 16;  // final offset inside the segment
                     if (pos < e0 || pos >= e0 + piece) continue;
                     uint32_t c;
-                    const uint32_t xy = coord_xy_c(uc, (sl.y >> 8) & 0xffu, c);
+                    // (FORMAT 0 with ABS_T set: the bounded Collapse kernel's records, d as a 9-bit code -- EmitCb)
+                    const uint32_t unit = ABS_T ? (sl.y >> 9) & 0x7fu : (sl.y >> 8) & 0xffu;
+                    const uint32_t d = ABS_T ? cb_d_from_code(sl.y & 0x1ffu) : sl.y & 0xffu;
+                    const uint32_t xy = coord_xy_c(uc, unit, c);
                     const uint32_t w = phase + (fill + pos - e0) * 3u;
                     xb[w] = xy;
-                    xb[w + 1u] = c | ((sl.y & 0xffu) << 8);
+                    xb[w + 1u] = c | (d << 8);
                     xb[w + 2u] = sl.x;
                 }
                 fill += piece;
@@ -2123,6 +2157,7 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     const dim3 grid(total);
     const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u;
     if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else if (generic && (variant & 32u)) hipLaunchKernelGGL((adder_expand_kernel<0, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);

@@ -628,13 +628,13 @@ struct CbLevel {
     float thr;  // 2^d of the level (0 for d = 128); best_event.d is its exponent minus one (lean_bd_from_thr)
 };
 
-// Levels k >= 1 of ONE unit.  Levels 1..kCbFastLevels: four consecutive floats per plane (F4, Q4, B4, T4) -- the
+// Levels k >= 1 of ONE unit.  Levels 1..kCbFastLevels: four consecutive floats per plane (F4, Q4) and four pairs (BT) -- the
 // wave's LDS slice on the device (FP is then an LDS pointer), plain arrays in the CPU harness.  Deeper levels
 // (delta_t_max beyond ~30 frames, or adversarial input) go to the context's deep planes, level k at [k - 1][u],
 // which hold {F, Q, best_delta_t, best_d} instead of {integration, delta_t, ..} for the duration of a launch.
 template <class FP>
 struct CbLevelsT {
-    FP F4, Q4, B4, T4;
+    FP F4, Q4, BT;  // BT: {best_delta_t, threshold} pairs (one 8-byte read per emitted level)
     float *gF, *gQ, *gB;
     uint8_t *gbd;
     size_t stride, u;
@@ -642,15 +642,18 @@ struct CbLevelsT {
         CbLevel l;
         l.F = F4[k - 1u];
         l.Q = Q4[k - 1u];
-        l.bdt = B4[k - 1u];
-        l.thr = T4[k - 1u];
+        l.bdt = BT[2u * (k - 1u)];
+        l.thr = BT[2u * (k - 1u) + 1u];
         return l;
     }
     ADDER_HD void store_fast(uint32_t k, const CbLevel &l) const {
         F4[k - 1u] = l.F;
         Q4[k - 1u] = l.Q;
-        B4[k - 1u] = l.bdt;
-        T4[k - 1u] = l.thr;
+        BT[2u * (k - 1u)] = l.bdt;
+        BT[2u * (k - 1u) + 1u] = l.thr;
+    }
+    ADDER_HD void load_bt(float (&bt)[2u * kCbFastLevels]) const {  // the four fast {best_delta_t, threshold} pairs
+        for (uint32_t i = 0; i < 2u * kCbFastLevels; ++i) bt[i] = BT[i];
     }
     ADDER_HD CbLevel load_deep(uint32_t k) const {  // k > kCbFastLevels
         const size_t i = (size_t)(k - 1u) * stride + u;
@@ -692,30 +695,46 @@ struct CbLevelsT {
 };
 using CbLevels = CbLevelsT<float *>;
 
-struct CbPx {
+// The 9-bit d code of a bounded-step record: the exponent field of the node's threshold (with the sign bit above it,
+// always 0) -- 0: d = 128 (a zero threshold), e: d = e - 128 -- or kCbCodeEmpty for the Collapse filler.
+constexpr uint32_t kCbCodeEmpty = 255u;  // (the exponent of inf / nan: never a threshold's)
+ADDER_HD uint32_t cb_d_from_code(uint32_t code) {
+    return code == kCbCodeEmpty ? kDEmpty : lean_bd_from_exp(code & 0xffu);
+}
+
+// Like the lean step, the bounded step is written over a "lanes" policy L (ScalarLanes on the host; WaveLanes on the
+// device, where every boolean is a wave mask in scalar registers and the logic runs on the scalar ALU).
+template <class L>
+struct CbPxT {
     float S, dt0, bdt0;  // the root's integration, delta_t, best_event.delta_t   (meaningful iff m > 0)
     float thr0;          // 2^d of the root (0 for d = 128)
     uint32_t base, m;    // base_val; fired levels (arena length - 1)
-    bool popped;         // popped_dtm
+    typename L::Mask popped;  // popped_dtm
     float lastf;         // last_fired_t (AbsoluteT)
 };
-ADDER_HD CbPx cb_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
-    CbPx s;
+using CbPx = CbPxT<ScalarLanes>;
+template <class L>
+ADDER_HD CbPxT<L> cb_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf) {
+    CbPxT<L> s;
     s.S = integ;
     s.dt0 = dt;
     s.bdt0 = bdt;
     s.thr0 = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
     s.base = hdr & 0xffu;
     s.m = hdr_m(hdr);
-    s.popped = (hdr & kHdrPopped) != 0u;
+    s.popped = L::from((hdr & kHdrPopped) != 0u);
     s.lastf = lastf;
     return s;
 }
-ADDER_HD uint32_t cb_hdr(const CbPx &s) { return hdr_make(s.base, lean_bd_from_thr(f32_to_bits(s.thr0)), s.m, s.popped); }
+template <class L>
+ADDER_HD uint32_t cb_hdr(const CbPxT<L> &s) {
+    return hdr_make(s.base, lean_bd_from_thr(f32_to_bits(s.thr0)), s.m, L::lane(s.popped));
+}
 
 // Levels 1 .. m-1 between their resident form {integration, delta_t, best_delta_t, best_d} (the state planes, shared
 // with the generic step) and prefix coordinates.  A popped arena keeps only its root (header comment).
-ADDER_HD CbLevel cb_level_from_node(const CbPx &s, const Node &n) {
+template <class L>
+ADDER_HD CbLevel cb_level_from_node(const CbPxT<L> &s, const Node &n) {
     CbLevel l;
     l.thr = lean_thr_from_bd(n.bd);
     l.F = fadd(fsub(s.S, n.integ), l.thr);
@@ -723,7 +742,8 @@ ADDER_HD CbLevel cb_level_from_node(const CbPx &s, const Node &n) {
     l.bdt = n.bdt;
     return l;
 }
-ADDER_HD Node cb_node_from_level(const CbPx &s, const CbLevel &l) {
+template <class L>
+ADDER_HD Node cb_node_from_level(const CbPxT<L> &s, const CbLevel &l) {
     Node n;
     n.integ = fsub(s.S, fsub(l.F, l.thr));
     n.dt = fsub(s.dt0, l.Q);
@@ -732,132 +752,156 @@ ADDER_HD Node cb_node_from_level(const CbPx &s, const CbLevel &l) {
     return n;
 }
 
-struct CbPlan {
-    bool flush;       // pop_best_events ran this frame
-    bool collapsed;   // ... on a popped arena: root event + D_EMPTY filler (:249-265)
-    bool need_pop;    // pop_top_event follows the integrate
-    bool depth_error; // the unit needed more than sc.max_depth stored levels
+template <class L>
+struct CbPlanT {
+    typename L::Mask flush;      // pop_best_events ran this frame
+    typename L::Mask flushed;    // ... and the arena held a fired level: events leave
+    typename L::Mask collapsed;  // ... and was popped: root event + D_EMPTY filler (:249-265)
+    typename L::Mask need_pop;   // pop_top_event follows the integrate
+    typename L::Mask depth_error;  // the unit needed more than sc.max_depth stored levels
     uint32_t m_old;   // fired levels before the step
     float old_thr0, old_bdt0;  // the old root's best event (valid iff m_old > 0)
     uint32_t count;   // events of this unit this frame
 };
+using CbPlan = CbPlanT<ScalarLanes>;
 
 // pop_best_events' bookkeeping + integrate (:317-413) of one unit.  Exactly one node fires per frame while the arena
 // is not popped -- arena index 0 (the root, or the pristine tail of an empty arena), else the shallowest level whose
 // fire-at value the root's integration has reached, else the pristine tail behind the levels -- and none or the root
 // once it is (:360-362).  The firing arm of integrate_main (:427-473) is computed ONCE, on the node's (integration,
-// delta_t, threshold) gathered from wherever it lives.  The unit's OLD levels 1 .. m_old-1 are still in place
-// afterwards when plan.flush is set (a flushed arena restarts from the tail at index 0, which touches no level).
-template <class Lv>
-ADDER_HD void cb_step(CbPx &s, const Lv &lv, uint32_t v, float T, const StepConsts &sc, CbPlan &p) {
-    const float I = (float)v;
+// delta_t, threshold) gathered from wherever it lives.
+// Two halves, so that a lane can run the first half of all its units before the second of any: the first issues the
+// level reads (two dependent round trips to the wave's LDS slice) without any control flow, the second consumes them.
+// The unit's OLD levels 1 .. m_old-1 are still in place afterwards when plan.flush is set (a flushed arena restarts
+// from the tail at index 0, which touches no level).
+template <class L>
+struct CbMidT {
+    float I, S_old, dt_old, S_new;
+    uint32_t m, k, kf;    // fired levels after the flush; the level that fires if the walk gets that far; first_fast
+    typename L::Mask has0, popped, root_fires, walk;
+    CbLevel l;            // fast slot clamp(k, 1, kCbFastLevels) as read (stale when the firing node is a fresh tail)
+};
+
+template <class L, class Lv>
+ADDER_HD void cb_step_a(CbPxT<L> &s, const Lv &lv, uint32_t v, const StepConsts &sc, CbPlanT<L> &p, CbMidT<L> &x) {
+    using M = typename L::Mask;
+    x.I = (float)v;
     p.m_old = s.m;
     p.old_thr0 = s.thr0;
     p.old_bdt0 = s.bdt0;
-    p.flush = contrast_exceeded(v, s.base, sc.cth);
-    p.collapsed = p.flush && s.popped && s.m != 0u;
-    p.depth_error = false;
-    const uint32_t flushed = p.flush ? (p.collapsed ? 2u : s.m) : 0u;
-    const uint32_t m = p.flush ? 0u : s.m;
-    const bool popped = s.popped && !p.flush;
-    s.base = p.flush ? v : s.base;
-    const bool has0 = m != 0u;
-    const float S_old = has0 ? s.S : 0.0f, dt_old = has0 ? s.dt0 : 0.0f;
-    const float S_new = fadd(S_old, I);
-    const bool root_fires = !has0 || S_new >= s.thr0;  // (the pristine tail at index 0 always fires)
+    const M has_m = L::from(s.m != 0u);
+    p.flush = L::from(contrast_exceeded(v, s.base, sc.cth));
+    p.flushed = L::and_(p.flush, has_m);
+    p.collapsed = L::and_(p.flushed, s.popped);
+    p.depth_error = L::from(false);
+    p.count = L::lane(p.flush) ? (L::lane(p.collapsed) ? 2u : s.m) : 0u;  // (+ pop_top's event: cb_step_b)
+    x.m = L::lane(p.flush) ? 0u : s.m;
+    x.popped = L::andnot(s.popped, p.flush);
+    s.base = L::lane(p.flush) ? v : s.base;
+    x.has0 = L::andnot(has_m, p.flush);
+    x.S_old = L::lane(x.has0) ? s.S : 0.0f;
+    x.dt_old = L::lane(x.has0) ? s.dt0 : 0.0f;
+    x.S_new = fadd(x.S_old, x.I);
+    x.root_fires = L::or_(L::not_(x.has0), L::from(x.S_new >= s.thr0));  // (the pristine tail at index 0 always fires)
+    x.walk = L::andnot(L::not_(x.root_fires), x.popped);
+    // the level reads, whether or not this unit walks (some lane of the wave does): no branch, so the reads of a
+    // lane's units overlap
+    x.kf = lv.first_fast(x.S_new);
+    x.k = x.kf < x.m ? x.kf : x.m;
+    const uint32_t ks = x.k < 1u ? 1u : (x.k > kCbFastLevels ? kCbFastLevels : x.k);
+    x.l = lv.load_fast(ks);
+}
+
+template <class L, class Lv>
+ADDER_HD void cb_step_b(CbPxT<L> &s, const Lv &lv, float T, const StepConsts &sc, CbPlanT<L> &p, const CbMidT<L> &x) {
+    using M = typename L::Mask;
     // ---- which node fires, and its (integration, delta_t, threshold) as offsets from the root's ----
-    uint32_t k = 0u;
-    bool fresh = !has0;  // the firing node is a pristine tail: integration 0, delta_t 0, d = get_d(I) (:332-335)
-    float P = 0.0f, Qk = 0.0f, thr_old = s.thr0;
-    const bool walk = !root_fires && !popped;
-    if (walk) {
-        const uint32_t kf = lv.first_fast(S_new);
-        k = kf < m ? kf : m;
-        if (kf > kCbFastLevels && m > kCbFastLevels) {  // rare: the arena is deeper than the fast slots
-            k = lv.first_deep(S_new, m);
-            if (k >= sc.max_depth) {
-                p.depth_error = true;
-                k = sc.max_depth - 1u;  // (flagged; keep the accesses inside the planes)
-            }
-            fresh = k >= m;
-            if (!fresh) {
-                const CbLevel l = lv.load(k);
-                P = fsub(l.F, l.thr);
-                Qk = l.Q;
-                thr_old = l.thr;
-            }
-        } else {
-            if (k >= sc.max_depth) {
-                p.depth_error = true;
-                k = sc.max_depth > 1u ? sc.max_depth - 1u : 1u;
-            }
-            fresh = k >= m;
-            const CbLevel l = lv.load_fast(k);  // (a stale slot when fresh: selected away)
+    uint32_t k = x.k;
+    M fresh_lv = L::from(k >= x.m);  // the pristine tail behind the levels: integration 0, delta_t 0, d = get_d(I) (:332-335)
+    float P = fsub(x.l.F, x.l.thr), Qk = x.l.Q, thr_lv = x.l.thr;
+    const M deep = L::and_(x.walk, L::from(x.kf > kCbFastLevels && x.m > kCbFastLevels));
+    if (L::lane(deep)) {  // rare: the arena is deeper than the fast slots
+        k = lv.first_deep(x.S_new, x.m);
+        if (k < x.m && k < sc.max_depth) {
+            const CbLevel l = lv.load_deep(k);
             P = fsub(l.F, l.thr);
             Qk = l.Q;
-            thr_old = l.thr;
+            thr_lv = l.thr;
         }
-        P = fresh ? S_old : P;
-        Qk = fresh ? dt_old : Qk;
     }
+    fresh_lv = L::or_(L::andnot(fresh_lv, deep), L::and_(deep, L::from(k >= x.m)));  // (a mask: merged outside the branch)
+    const M over = L::and_(x.walk, L::from(k >= sc.max_depth));
+    p.depth_error = over;
+    k = L::lane(over) ? (sc.max_depth > 1u ? sc.max_depth - 1u : 1u) : k;  // (flagged; keep the store inside the planes)
+    const M fresh = L::or_(L::and_(x.walk, fresh_lv), L::andnot(L::not_(x.has0), x.walk));
+    const M use_lv = L::andnot(x.walk, fresh_lv);  // the firing node is a stored level
+    P = L::lane(use_lv) ? P : (L::lane(x.walk) ? x.S_old : 0.0f);
+    Qk = L::lane(use_lv) ? Qk : (L::lane(x.walk) ? x.dt_old : 0.0f);
+    const float thr_old = L::lane(x.walk) ? thr_lv : s.thr0;
     // ---- the firing arm, once (:427-473) ----
-    const float integ_old = fsub(S_old, P), dtk_old = fsub(dt_old, Qk);
-    const float sum = fadd(integ_old, I);
-    const bool zero = sum == 0.0f;      // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
+    const float integ_old = fsub(x.S_old, P), dtk_old = fsub(x.dt_old, Qk);
+    const float sum = fadd(integ_old, x.I);
+    const M zero = L::from(sum == 0.0f);  // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
     const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);  // 2^get_d(sum)
-    const bool d128 = fresh ? I < 1.0f : thr_old == 0.0f;           // the node's d before it fires (:432-437)
-    const float q = fdiv_small(fsub(p2, integ_old), I);
-    const float prop = (zero || d128) ? 1.0f : q;
+    // the node's d before it fires is 128 (:432-437): a fresh tail with I < 1, a stored node with a zero threshold
+    const M d128 = L::or_(L::and_(fresh, L::from(x.I < 1.0f)), L::andnot(L::from(thr_old == 0.0f), fresh));
+    const float q = fdiv_small(fsub(p2, integ_old), x.I);
+    const float prop = L::lane(L::or_(zero, d128)) ? 1.0f : q;
     const float bdt = fadd(dtk_old, fmul(T, prop));
     const float thr2 = fadd(p2, p2);
     // ---- where the result goes ----
-    s.S = S_new;  // (a root that fires at d = 128 has S_new == S_old)
-    s.dt0 = (root_fires && zero) ? dt_old : fadd(dt_old, T);
-    s.bdt0 = root_fires ? bdt : s.bdt0;
-    s.thr0 = root_fires ? thr2 : s.thr0;
-    s.m = root_fires ? 1u : m;
-    if (walk) {
+    s.S = x.S_new;  // (a root that fires at d = 128 has S_new == S_old)
+    s.dt0 = L::lane(L::and_(x.root_fires, zero)) ? x.dt_old : fadd(x.dt_old, T);
+    s.bdt0 = L::lane(x.root_fires) ? bdt : s.bdt0;
+    s.thr0 = L::lane(x.root_fires) ? thr2 : s.thr0;
+    s.m = L::lane(x.root_fires) ? 1u : (L::lane(x.walk) ? k + 1u : x.m);
+    if (L::lane(x.walk)) {
         CbLevel l;
         l.F = fadd(P, thr2);
-        l.Q = zero ? fadd(Qk, T) : Qk;  // a d = 128 firing does not advance the level's delta_t; the root's did
+        l.Q = L::lane(zero) ? fadd(Qk, T) : Qk;  // a d = 128 firing does not advance the level's delta_t; the root's did
         l.bdt = bdt;
         l.thr = thr2;
         lv.store(k, l);
-        s.m = k + 1u;
     }
-    s.popped = popped;
-    p.need_pop = s.dt0 >= sc.dtm_f && !popped;  // :394-396 (d == D_MAX cannot happen with 8-bit input)
-    p.count = flushed + (p.need_pop ? 1u : 0u);
+    s.popped = x.popped;
+    p.need_pop = L::andnot(L::from(s.dt0 >= sc.dtm_f), x.popped);  // :394-396 (d == D_MAX cannot happen with 8-bit input)
+    p.count += L::lane(p.need_pop) ? 1u : 0u;
 }
 
-// The unit's events of this frame, in emission order.  After cb_step, before cb_pop.
-template <bool ABS_T, class Lv, class Emit>
-ADDER_HD void cb_emit(CbPx &s, const CbPlan &p, const StepConsts &sc, const Lv &lv, Emit &emit) {
-    if (p.flush && p.m_old > 0u) {
-        const uint32_t bd = lean_bd_from_thr(f32_to_bits(p.old_thr0));
-        if (p.collapsed) {
-            emit(bd, f32_as_u32(ABS_T ? fadd(p.old_bdt0, s.lastf) : p.old_bdt0));
+template <class L, class Lv>
+ADDER_HD void cb_step(CbPxT<L> &s, const Lv &lv, uint32_t v, float T, const StepConsts &sc, CbPlanT<L> &p) {
+    CbMidT<L> x;
+    cb_step_a(s, lv, v, sc, p, x);
+    cb_step_b(s, lv, T, sc, p, x);
+}
+
+// The unit's events of this frame, in emission order.  After cb_step, before cb_pop.  An event leaves as (the bits of
+// the node's threshold, t): best_event.d is the threshold's exponent minus one (lean_bd_from_thr), which the consumer
+// of the records works out -- emit.ev(thr_bits, t); the Collapse filler {d: D_EMPTY} as emit.filler(t).
+template <bool ABS_T, class L, class Lv, class Emit>
+ADDER_HD void cb_emit(CbPxT<L> &s, const CbPlanT<L> &p, const StepConsts &sc, const Lv &lv, Emit &emit) {
+    if (L::lane(p.flushed)) {
+        if (L::lane(p.collapsed)) {
+            emit.ev(f32_to_bits(p.old_thr0), f32_as_u32(ABS_T ? fadd(p.old_bdt0, s.lastf) : p.old_bdt0));
             s.lastf = sc.running_t;  // :257
-            emit(kDEmpty, f32_as_u32(sc.running_t));
+            emit.filler(sc.running_t_u32);
         } else {
-            emit(bd, event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
-            // levels 1 .. m_old-1 in order: the fast ones without a loop (each step narrows the active lanes), the
-            // rest -- rare -- from the deep planes
+            emit.ev(f32_to_bits(p.old_thr0), event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
+            // levels 1 .. m_old-1 in order: the four fast ones are read in one go and leave without a loop (each step
+            // narrows the active lanes), the rest -- rare -- come from the deep planes
             if (p.m_old > 1u) {
-                const CbLevel l1 = lv.load_fast(1);
-                emit(lean_bd_from_thr(f32_to_bits(l1.thr)), event_time<ABS_T>(l1.bdt, s.lastf, sc));
+                float bt[2u * kCbFastLevels];
+                lv.load_bt(bt);
+                emit.ev(f32_to_bits(bt[1]), event_time<ABS_T>(bt[0], s.lastf, sc));
                 if (p.m_old > 2u) {
-                    const CbLevel l2 = lv.load_fast(2);
-                    emit(lean_bd_from_thr(f32_to_bits(l2.thr)), event_time<ABS_T>(l2.bdt, s.lastf, sc));
+                    emit.ev(f32_to_bits(bt[3]), event_time<ABS_T>(bt[2], s.lastf, sc));
                     if (p.m_old > 3u) {
-                        const CbLevel l3 = lv.load_fast(3);
-                        emit(lean_bd_from_thr(f32_to_bits(l3.thr)), event_time<ABS_T>(l3.bdt, s.lastf, sc));
+                        emit.ev(f32_to_bits(bt[5]), event_time<ABS_T>(bt[4], s.lastf, sc));
                         if (p.m_old > 4u) {
-                            const CbLevel l4 = lv.load_fast(4);
-                            emit(lean_bd_from_thr(f32_to_bits(l4.thr)), event_time<ABS_T>(l4.bdt, s.lastf, sc));
+                            emit.ev(f32_to_bits(bt[7]), event_time<ABS_T>(bt[6], s.lastf, sc));
                             for (uint32_t k = kCbFastLevels + 1u; k < p.m_old; ++k) {
                                 const CbLevel l = lv.load_deep(k);
-                                emit(lean_bd_from_thr(f32_to_bits(l.thr)), event_time<ABS_T>(l.bdt, s.lastf, sc));
+                                emit.ev(f32_to_bits(l.thr), event_time<ABS_T>(l.bdt, s.lastf, sc));
                             }
                         }
                     }
@@ -865,25 +909,26 @@ ADDER_HD void cb_emit(CbPx &s, const CbPlan &p, const StepConsts &sc, const Lv &
             }
         }
     }
-    if (p.need_pop) emit(lean_bd_from_thr(f32_to_bits(s.thr0)), event_time<ABS_T>(s.bdt0, s.lastf, sc));
+    if (L::lane(p.need_pop)) emit.ev(f32_to_bits(s.thr0), event_time<ABS_T>(s.bdt0, s.lastf, sc));
 }
 
 // pop_top_event's arena shift (:199-207): level 1, if there is one, becomes the root; deeper levels are dropped
 // (popped + Collapse: they would never be visited, emitted or kept again).
-template <class Lv>
-ADDER_HD void cb_pop(CbPx &s, const CbPlan &p, const Lv &lv) {
-    if (!p.need_pop) return;
-    if (s.m >= 2u) {
-        const CbLevel l = lv.load_fast(1);
-        s.S = fsub(s.S, fsub(l.F, l.thr));
-        s.dt0 = fsub(s.dt0, l.Q);
-        s.bdt0 = l.bdt;
-        s.thr0 = l.thr;
-        s.m = 1u;
-    } else {
-        s.m = 0u;
+template <class L, class Lv>
+ADDER_HD void cb_pop(CbPxT<L> &s, const CbPlanT<L> &p, const Lv &lv) {
+    if (L::lane(p.need_pop)) {
+        if (s.m >= 2u) {
+            const CbLevel l = lv.load_fast(1);
+            s.S = fsub(s.S, fsub(l.F, l.thr));
+            s.dt0 = fsub(s.dt0, l.Q);
+            s.bdt0 = l.bdt;
+            s.thr0 = l.thr;
+            s.m = 1u;
+        } else {
+            s.m = 0u;
+        }
     }
-    s.popped = true;
+    s.popped = L::or_(s.popped, p.need_pop);
 }
 
 // ---------------------------------------------------------------------------------------

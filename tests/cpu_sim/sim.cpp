@@ -294,13 +294,13 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
             for (uint32_t c = 0; c < s->C; c++, u++) {
                 const uint32_t hdr = s->hdr[u];
                 const uint32_t m0 = hdr_m(hdr);
-                CbPx p = cb_unpack(hdr, m0 ? s->integ0[u] : -12345.0f, m0 ? s->dt0[u] : -777.0f, m0 ? s->bdt0[u] : -999.0f,
+                CbPx p = cb_unpack<ScalarLanes>(hdr, m0 ? s->integ0[u] : -12345.0f, m0 ? s->dt0[u] : -777.0f, m0 ? s->bdt0[u] : -999.0f,
                                    s->abs_t ? s->lastf[u] : -1.0f);
                 if (p.popped && p.m > 1u) p.m = 1u;  // a popped arena keeps only its root
                 // garbage on purpose: slots of levels >= m must never decide anything
-                float F4[4] = {-3.0f, 1e30f, 0.0f, -1e30f}, Q4[4] = {7.0f, 7.0f, 7.0f, 7.0f}, B4[4] = {9.0f, 9.0f, 9.0f, 9.0f};
-                float T4[4] = {3.0f, -1.0f, 1e20f, 0.0f};
-                CbLevels lv{F4, Q4, B4, T4, s->lv_integ.data(), s->lv_dt.data(), s->lv_bdt.data(), s->lv_bd.data(), s->N, u};
+                float F4[4] = {-3.0f, 1e30f, 0.0f, -1e30f}, Q4[4] = {7.0f, 7.0f, 7.0f, 7.0f};
+                float BT[8] = {9.0f, 3.0f, 9.0f, -1.0f, 9.0f, 1e20f, 9.0f, 0.0f};
+                CbLevels lv{F4, Q4, BT, s->lv_integ.data(), s->lv_dt.data(), s->lv_bdt.data(), s->lv_bd.data(), s->N, u};
                 DeepAcc deep{s, u};
                 for (uint32_t k = 1; k < p.m; ++k) {
                     Node n;
@@ -316,12 +316,15 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                         uint16_t x, y;
                         uint8_t c;
                         uint32_t n;
-                        void operator()(uint32_t d, uint32_t t) {
+                        void put(uint32_t d, uint32_t t) {
                             SimEvent e;
                             e.x = x; e.y = y; e.c = c; e.d = (uint8_t)d; e.pad = 0; e.t = t;
                             v->push_back(e);
                             ++n;
                         }
+                        // the record's 9-bit code = the threshold's exponent field, decoded as the expansion kernel does
+                        void ev(uint32_t thr_bits, uint32_t t) { put(cb_d_from_code(thr_bits >> 23), t); }
+                        void filler(uint32_t t) { put(cb_d_from_code(kCbCodeEmpty), t); }
                     } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
                     CbPlan plan;
                     cb_step(p, lv, frames[(size_t)i * s->N + u], T, sc, plan);

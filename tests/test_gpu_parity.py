@@ -1169,3 +1169,85 @@ def test_blocked_kernel_input_paths_direct_to_lds_and_register_fallback(time_mod
                                        misalign=mis)
             assert np.array_equal(offs.astype(np.int64), want_offs), (W, H, mis)
             assert np.array_equal(got, want), (W, H, mis)
+
+
+# ---- the bounded Collapse kernel (adder_cb_kernel: Collapse with delta_t_max > time_spanned, the reference's defaults) ----
+def _cb_pair(W, H, Cn, tm, dtm, *, ref_time=255, crf=CRFS[0], max_depth=20):
+    A = _hip()
+    ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+    hv = A.HipVideo(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm, max_depth=max_depth)
+    ov.ensure_capacity(max_depth + 2)
+    base, cmax, vel = crf
+    for v in (ov, hv):
+        v.set_crf_parameters(cmax, vel)
+        v.reset_c_thresh(base)
+    return ov, hv
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("crf", [0, 3])
+def test_cb_kernel_batches_of_every_shape(time_mode, crf):
+    """The default mode in batches whose lengths meet the frame-30 pop, the flushes and the chunk edges differently:
+    blocked launches of 64 frames, short tails, single frames (the per-frame contract) -- the levels stay in LDS in
+    prefix coordinates inside a launch and return to the deep planes between launches."""
+    rng = np.random.default_rng(50 + crf + time_mode)
+    W, H, frames = 333, 41, 330  # ragged: 13 653 units, the last segment partly padding
+    for kind in ("scene", "runs", "jitter"):
+        clip = (O.synth_clip(O.CONTENT_SCENE, W, H, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, H, W, 1, seed=crf * 7 + len(kind)))
+        ov, hv = _cb_pair(W, H, 1, time_mode, 7650, crf=CRFS[crf])
+        k, total = 0, 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 2, 29, 31, 64, 65, 130])), frames - k)
+            want = [ov.integrate_matrix(clip[k + i]) for i in range(nb)]
+            got, offs = hv.integrate_batch(clip[k:k + nb])
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (kind, k, nb)
+            assert np.array_equal(got, np.concatenate(want)), (kind, k, nb)
+            total += len(got)
+            k += nb
+        assert total > 0
+        hv.close()
+
+
+def test_cb_kernel_deep_levels_spill_to_the_deep_planes_and_depth_is_reported():
+    """delta_t_max of 500 frames: static pixels reach seven levels before the pop, past the four LDS slots, so levels 5+
+    are stepped in the deep planes; flushes drain them.  With max_depth 3 the same clip must fail with
+    ADDER_E_ARENA_DEPTH instead of overrunning."""
+    A = _hip()
+    frames = 560
+    clip = clips.make_clip("static", frames, 9, 70, 1, seed=4)
+    clip[300:] = 255 - clip[300:]
+    clip[520:] = clip[0]
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, hv = _cb_pair(70, 9, 1, tm, 255 * 500)
+        for k in range(0, frames, 70):
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(70)])
+            got, _ = hv.integrate_batch(clip[k:k + 70])
+            assert np.array_equal(got, want), (tm, k)
+        hv.close()
+    _, hv = _cb_pair(70, 9, 1, O.DELTA_T, 255 * 500, max_depth=3)
+    with pytest.raises(A.AdderHipError, match="max_depth"):
+        hv.integrate_batch(clip[:40])
+    hv.close()
+
+
+def test_cb_kernel_rgb_bands_other_rates_and_fractional_time_fallback():
+    A = _hip()
+    clip = clips.make_clip("runs", 96, 24, 50, 3, seed=12)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        for ref_time, dtm in ((255, 7650), (5000, 240000), (20, 10000)):
+            ov, hv = _cb_pair(50, 24, 3, tm, dtm, ref_time=ref_time, crf=CRFS[3])
+            want = np.concatenate([ov.integrate_matrix(f, time_spanned=float(ref_time)) for f in clip])
+            got, _ = hv.integrate_batch(clip, time_spanned=float(ref_time))
+            assert np.array_equal(got, want), (tm, ref_time)
+            hv.close()
+    # a fractional time_spanned has no exact prefix sums: those batches (and every later one) take the generic kernel
+    ov, hv = _cb_pair(50, 24, 3, O.ABSOLUTE_T, 7650, crf=CRFS[3])
+    spans = [255.0] * 40 + [254.5] * 16 + [255.0] * 40
+    k = 0
+    for span, n in ((255.0, 40), (254.5, 16), (255.0, 40)):
+        want = np.concatenate([ov.integrate_matrix(f, time_spanned=span) for f in clip[k:k + n]])
+        got, _ = hv.integrate_batch(clip[k:k + n], time_spanned=span)
+        assert np.array_equal(got, want), (span, k)
+        k += n
+    hv.close()
