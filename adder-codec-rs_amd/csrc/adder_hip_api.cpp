@@ -93,7 +93,7 @@ struct AdderHipCtx {
     uint32_t park_bytes = 0;         // scratch of one segment of one frame (fixed-slot kinds)
     // what the scratch ring is laid out for: fixed slots per segment and frame (lean records, Continuous staging), or
     // one record log per segment and chunk (per-event records of the generic / bounded Collapse kernels: log_capacity)
-    enum ScratchKind { kScratchNone, kScratchLean, kScratchCont, kScratchLog2, kScratchLog3 };
+    enum ScratchKind { kScratchNone, kScratchLean, kScratchLean8, kScratchCont, kScratchLog2, kScratchLog3 };
     ScratchKind scratch_kind = kScratchNone;
     uint32_t log_cap = 0;            // records per (segment, chunk) region (log kinds)
     uint32_t *wofs_ring = nullptr;   // [slots][num_waves] log kinds: where a segment's run of a frame starts
@@ -550,7 +550,9 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             HIPCHK(c, dalloc(&c->cn_bdt, cnt));
             HIPCHK(c, dalloc(&c->cn_meta, cnt));
         }
-        { int rc_ = alloc_scratch(c, c->continuous ? AdderHipCtx::kScratchCont : AdderHipCtx::kScratchLean); if (rc_ != ADDER_OK) return rc_; }
+        { int rc_ = alloc_scratch(c, c->continuous ? AdderHipCtx::kScratchCont
+                                      : p.time_mode == ADDER_TIME_ABSOLUTE_T ? AdderHipCtx::kScratchLean : AdderHipCtx::kScratchLean8);
+          if (rc_ != ADDER_OK) return rc_; }
         { int rc_ = alloc_batch_desc(c, 1024); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_result), sizeof(BatchResult), hipHostMallocDefault));
         memset(c->h_result, 0, sizeof(BatchResult));
@@ -812,6 +814,7 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 static size_t scratch_bytes_per_chunk(const AdderHipCtx *c, AdderHipCtx::ScratchKind kind, uint32_t chunk) {
     switch (kind) {
         case AdderHipCtx::kScratchLean: return (size_t)c->num_waves * chunk * kLeanParkBytes;
+        case AdderHipCtx::kScratchLean8: return (size_t)c->num_waves * chunk * kLeanPark8Bytes;
         case AdderHipCtx::kScratchCont:
             return (size_t)c->num_waves * chunk * (kWaveUnits + kWaveUnits * (c->max_depth + 3u) * kGenRecBytes);
         case AdderHipCtx::kScratchLog2: return (size_t)c->num_waves * log_capacity(chunk, c->max_depth, true) * kGenRecBytes;
@@ -989,7 +992,12 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
 static int instantiate_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
-    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, c->cap_s2, false);
+    // per-event-record batches (generic / bounded Collapse kernels) are captured on ONE stream: their frame kernel is
+    // bound by instruction issue at full occupancy and leaves the expansion no room to run beside it -- two branches
+    // measured 10.5 us per 1080p frame against 10.0 in sequence (walking grids 11.6 - 14.2)
+    static const bool gen_two = [] { const char *e = getenv("ADDER_HIP_GEN_TWO_STREAMS"); return e && atoi(e) != 0; }();
+    hipStream_t s2 = ((variant & 4u) && !gen_two) ? nullptr : c->cap_s2;
+    int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, s2, false);
     hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
     if (rc != ADDER_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -1024,7 +1032,7 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     }
     // still choosing: the newest candidate until it has had its runs, then one more candidate
     // (a batch of a single chunk has no second branch to overlap: one candidate is all it needs)
-    const uint32_t want = num_frames > c->chunk ? std::max(1u, c->graph_candidates) : 1u;
+    const uint32_t want = (num_frames > c->chunk && !(variant & 4u)) ? std::max(1u, c->graph_candidates) : 1u;
     int use = (int)g.cand.size() - 1;
     if (use < 0 || g.runs[use] >= kTuneRunsPerCandidate) {
         if (g.cand.size() < want) {
@@ -1054,7 +1062,7 @@ static void graph_tune_report(AdderHipCtx *c, float ms) {
     if (g.last < 0 || g.chosen >= 0) return;
     g.runs[g.last] += 1;
     if (g.runs[g.last] > 1 || kTuneRunsPerCandidate == 1) g.ms[g.last] = std::min(g.ms[g.last], ms);
-    const uint32_t want = c->pending_frames > c->chunk ? std::max(1u, c->graph_candidates) : 1u;
+    const uint32_t want = (c->pending_frames > c->chunk && !((c->tune_key >> 32) & 4u)) ? std::max(1u, c->graph_candidates) : 1u;
     if (g.cand.size() >= want && g.runs.back() >= kTuneRunsPerCandidate) {
         int best = 0;
         for (int k = 1; k < (int)g.cand.size(); ++k)
@@ -1191,7 +1199,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         if (rc_ != ADDER_OK) return rc_;
         c->generic_sticky = true;
     } else if (!c->continuous) {
-        int rc_ = alloc_scratch(c, AdderHipCtx::kScratchLean);
+        // (12-byte records in AbsoluteT, 8-byte ones otherwise: adder_pixel.hpp lean_decode8)
+        int rc_ = alloc_scratch(c, c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? AdderHipCtx::kScratchLean : AdderHipCtx::kScratchLean8);
         if (rc_ != ADDER_OK) return rc_;
     }
     // an event buffer below the batch's worst case can overflow: keep an undo copy of the state so that the

@@ -35,8 +35,11 @@ constexpr uint32_t kLeanWavesPerSimd = ADDER_LEAN_WAVES_PER_SIMD;  // register b
 constexpr uint32_t kMaxFramesPerLaunch = ADDER_MAX_FRAMES_PER_LAUNCH;  // temporal blocking depth of K1 (<= 64)
 constexpr uint32_t kMaxChunk = kMaxFramesPerLaunch;                // frames per scan/expand launch
 // parked-record scratch of one segment of one frame, in BYTES
-constexpr uint32_t kLeanRecBytes = 12;                             // LeanRec: at most one per unit
+constexpr uint32_t kLeanRecBytes = 12;                             // LeanRec {ta, tc, w}: at most one per unit (AbsoluteT)
+constexpr uint32_t kLeanRec8Bytes = 8;                             // {ta, w8}: DeltaT batches (adder_pixel.hpp lean_decode8)
 constexpr uint32_t kLeanParkBytes = kWaveUnits * kLeanRecBytes;
+constexpr uint32_t kLeanPark8Bytes = kWaveUnits * kLeanRec8Bytes;
+__host__ __device__ constexpr uint32_t lean_rec_bytes(bool abs_t) { return abs_t ? kLeanRecBytes : kLeanRec8Bytes; }
 constexpr uint32_t kGenRecBytes = 8;                               // generic variants: one per EVENT
 
 // bits of the device status word

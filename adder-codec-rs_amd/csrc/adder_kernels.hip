@@ -293,6 +293,21 @@ __device__ __forceinline__ void lean_load(const FrameArgs &a, uint32_t u0, bool 
     }
 }
 
+// a unit's record into its scratch slot: 12 bytes {ta, tc, w} (AbsoluteT) or 8 bytes {ta, w8} (DeltaT)
+template <bool ABS_T, bool NT>
+__device__ __forceinline__ void lean_store_rec(void *seg, uint32_t byte_off, const LeanRec &r) {
+    struct R12 { uint32_t a, b, c; };
+    if (ABS_T) {
+        const R12 v{r.ta, r.tc, r.w};
+        if (NT) gstore_nt(seg, byte_off, v);
+        else gstore(seg, byte_off, v);
+    } else {
+        const uint2 v = make_uint2(r.ta, r.w8);
+        if (NT) gstore_nt(seg, byte_off, v);
+        else gstore(seg, byte_off, v);
+    }
+}
+
 // FULL: the whole wave lies inside the band (every wave but possibly the band's last ones): no
 // per-unit bounds handling inside the frame loop.
 template <bool ABS_T, bool FULL, uint32_t NB_MAX>
@@ -421,10 +436,7 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
-            if (has) {
-                if (ADDER_NT_RECSTORE != 0 && NB_MAX > 1u) gstore_nt(seg, pos * kLeanRecBytes, rec[j]);
-                else gstore(seg, pos * kLeanRecBytes, rec[j]);
-            }
+            if (has) lean_store_rec<ABS_T, ADDER_NT_RECSTORE != 0 && (NB_MAX > 1u)>(seg, pos * lean_rec_bytes(ABS_T), rec[j]);
             pos += has ? 1u : 0u;
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
@@ -643,14 +655,14 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
     uint8_t *const seg = uniform_ptr(b->park_ring) +
                          park_offset(slot, __builtin_amdgcn_readfirstlane(gw0), chunk_u,
                                      __builtin_amdgcn_readfirstlane(a.num_waves), park_bytes_u, lay);
-    uint32_t off = (upper ? seg_stride_u : 0u) + pos * kLeanRecBytes;  // (the upper half is segment gw0 + 1)
+    uint32_t off = (upper ? seg_stride_u : 0u) + pos * lean_rec_bytes(ABS_T);  // (the upper half is segment gw0 + 1)
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
         const bool has = L::lane(mrec[j]);
 #ifndef ADDER_DBG_NOREC
-        if (has) gstore(seg, off, rec[j]);
+        if (has) lean_store_rec<ABS_T, false>(seg, off, rec[j]);
 #endif
-        off += has ? kLeanRecBytes : 0u;
+        off += has ? lean_rec_bytes(ABS_T) : 0u;
     }
     if (lane == 0u)
         gstore<uint2>(uniform_ptr(a.wtot), __builtin_amdgcn_readfirstlane(gw0) * 4u,
@@ -1494,6 +1506,18 @@ __device__ __forceinline__ void stage_lean(uint32_t *xb, uint32_t w, const LeanE
 // One workgroup's share of a frame's expansion: 4 waves x kExpandSegs segments.
 // FORMAT of the parked records: 0 = generic (8 bytes per event with its final offset), 1 = lean (one 16-byte
 // LeanRec per unit), 2 = staged (Mode::Continuous: per-unit counts + 8-byte {t, d} records at fixed slots)
+// a parked lean record as {ta, tc, w, -} (AbsoluteT, 12 bytes) or {ta, w8, -, -} (DeltaT, 8 bytes)
+template <bool ABS_T>
+__device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_off) {
+    if (ABS_T) {
+        struct R12 { uint32_t a, b, c; };
+        const R12 r = gload_rec<R12>(base, byte_off);
+        return make_uint4(r.a, r.b, r.c, 0u);
+    }
+    const uint2 r = gload_rec<uint2>(base, byte_off);
+    return make_uint4(r.x, r.y, 0u, 0u);
+}
+
 template <int FORMAT, bool ABS_T>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
     constexpr bool LEAN = FORMAT == 1;
@@ -1528,6 +1552,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     uc.one_wrap = uc.rowlen >= 2u * kWaveUnits;  // a pair of segments crosses at most one row end
     const uint64_t out_cap = b->base.out_cap;
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
+    const float time_spanned_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
     // segments' counts first, then exactly the records they hold (a speculative fetch of 64 records per
@@ -1550,8 +1575,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             first[p] = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                const LeanRec r = gload_rec<LeanRec>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * kLeanRecBytes);
-                first[p] = make_uint4(r.ta, r.tc, r.w, 0u);
+                first[p] = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * lean_rec_bytes(ABS_T));
             }
         }
     } else if (FORMAT == 0) {
@@ -1600,13 +1624,16 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         r.ta = rw.x;
         r.tc = rw.y;
         r.w = rw.z;
-        const LeanEvents e = lean_decode(r, ABS_T, rt_u32);  // an all-zero record decodes to no events
+        r.w8 = rw.y;
+        // (an all-zero record decodes to no events)
+        const LeanEvents e = ABS_T ? lean_decode(r, true, rt_u32) : lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
         const uint32_t incl = wave_inclusive_scan_dpp(n);
         const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t xy = coord_xy_c(uc, ((r.w >> kLeanUnitShift) & 0x3ffu) + unit_shift, c);
+        const uint32_t unit = ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
+        const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
     // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
@@ -1637,8 +1664,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
-                            const LeanRec r = gload_rec<LeanRec>(seg_park, (i0 + lane) * kLeanRecBytes);
-                            rw = make_uint4(r.ta, r.tc, r.w, 0u);
+                            rw = lean_load_rec<ABS_T>(seg_park, (i0 + lane) * lean_rec_bytes(ABS_T));
                         }
                         lean_round(rw, 0u);
                     }

@@ -343,7 +343,19 @@ constexpr uint32_t kLeanExpAShift = 13;  // exponent byte of A's threshold (thr 
 constexpr uint32_t kLeanExpCShift = 21;  // exponent byte of C's threshold (thr bits >> 2)
 struct LeanRec {
     uint32_t ta, tc, w;
+    uint32_t w8;  // the 8-byte form's second word (DeltaT, see below); {ta, w8} is then the whole record
 };
+// DeltaT batches park 8 bytes per unit instead of 12: event C -- pop_top's event right after the root's first
+// accumulation -- is a function of the frame's INPUT BYTE alone.  The root that pops is either the pristine tail
+// that fired this frame (integration 0, delta_t 0: d = get_d(I), best_delta_t = T * (2^d / I)) or a root that has
+// only ever seen zeros (threshold 0: the same d, best_delta_t = T), so the record carries I and one bit instead of
+// C's time and exponent, and the expansion redoes the one division (lean_decode8):
+//   w8 = A | B << 1 | C << 2 | (C's prop forced to 1) << 3 | unit << 4 | exponent byte of A's threshold << 11 | I << 19
+// (AbsoluteT records keep both times: C's depends on last_fired_t, which the expansion does not have.)
+constexpr uint32_t kLean8CUnit = 8u;
+constexpr uint32_t kLean8UnitShift = 4;
+constexpr uint32_t kLean8ExpAShift = 11;
+constexpr uint32_t kLean8InShift = 19;
 
 ADDER_HD float lean_thr_from_bd(uint32_t bd) { return pow2_d(fired_d(bd)); }
 // best_d of a fired node from its threshold word: thr = 2^(bd+1), or 0 for bd = 128
@@ -397,6 +409,9 @@ ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float 
     }
     const uint32_t wa =
         (f32_to_bits(p.thr) >> 10) | tag | (L::lane(a_valid) ? kLeanA : 0u) | (L::lane(b_valid) ? kLeanB : 0u);
+    const uint32_t w8a = (f32_to_bits(p.thr) >> 12) | (tag << (kLean8UnitShift - kLeanUnitShift)) |
+                         (L::lane(a_valid) ? kLeanA : 0u) | (L::lane(b_valid) ? kLeanB : 0u);
+    const float thr_in = p.thr;  // the root's threshold as the frame found it
     const M has0 = L::andnot(p.has0, flush);
     const M popped = L::andnot(p.popped, flush);
     p.base = L::lane(flush) ? v : p.base;
@@ -434,6 +449,8 @@ ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float 
     rec.ta = ta;
     rec.tc = tc;
     rec.w = wa | (f32_to_bits(p.thr) >> 2) | (L::lane(need_pop) ? kLeanC : 0u);
+    rec.w8 = w8a | (L::lane(need_pop) ? kLeanC : 0u) | (L::lane(L::and_(has0, L::from(thr_in == 0.0f))) ? kLean8CUnit : 0u) |
+             (v << kLean8InShift);
     p.has0 = L::not_(need_pop);
     p.popped = L::or_(popped, need_pop);
     p.lastf = lastf;
@@ -462,6 +479,24 @@ ADDER_HD LeanEvents lean_decode(const LeanRec &r, bool abs_t, uint32_t running_t
     e.ta = abs_t ? r.ta : ca;
     e.tc = abs_t ? r.tc : cc;
     e.tb = running_t_u32;
+    return e;
+}
+
+// The 8-byte DeltaT record {ta, w8}: C is recomputed from the input byte exactly as lean_step computed it (same
+// operations on the same values: best_delta_t = 0 + T * prop, prop = 2^get_d(I) / I or 1).
+ADDER_HD LeanEvents lean_decode8(uint32_t ta, uint32_t w8, float T, uint32_t running_t_u32) {
+    LeanEvents e;
+    e.a = (w8 & kLeanA) != 0u;
+    e.b = (w8 & kLeanB) != 0u;
+    e.c = (w8 & kLeanC) != 0u;
+    e.da = lean_bd_from_exp((w8 >> kLean8ExpAShift) & 0xffu);
+    e.ta = f32_as_u32(bits_to_f32(ta));
+    e.tb = running_t_u32;
+    const float I = (float)((w8 >> kLean8InShift) & 0xffu);
+    const float p2 = bits_to_f32(f32_to_bits(I) & 0x7f800000u);  // 2^get_d(I)
+    const float prop = (w8 & kLean8CUnit) ? 1.0f : fdiv_small(fsub(p2, 0.0f), I);
+    e.dc = get_d(I);
+    e.tc = f32_as_u32(fadd(0.0f, fmul(T, prop)));
     return e;
 }
 

@@ -415,13 +415,16 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                 if (lean) {
                     LeanPx p = lean_unpack<ScalarLanes>(hdr, gi, gd, gb, glf);
                     LeanRec rec;
-                    const uint32_t tag = (uint32_t)(u & 255u) << kLeanUnitShift;
+                    const uint32_t tag = (uint32_t)(u & 127u) << kLeanUnitShift;  // unit inside its 128-unit segment
                     const LeanFlagsT<ScalarLanes> fl = s->abs_t ? lean_step<true>(p, v, sc.cth, time_spanned, sc, tag, rec)
                                                                  : lean_step<false>(p, v, sc.cth, time_spanned, sc, tag, rec);
                     if (fl.b && !fl.a) rc = -9;
                     if (fl.a || fl.c) {
-                        if (((rec.w >> kLeanUnitShift) & 255u) != (u & 255u)) rc = -9;  // the tag must survive
-                        const LeanEvents e = lean_decode(rec, s->abs_t != 0, sc.running_t_u32);
+                        if (((rec.w >> kLeanUnitShift) & 255u) != (u & 127u)) rc = -9;  // the tag must survive
+                        // (DeltaT batches park the 8-byte form, as the device kernels do)
+                        const LeanEvents e = s->abs_t ? lean_decode(rec, true, sc.running_t_u32)
+                                                      : lean_decode8(rec.ta, rec.w8, time_spanned, sc.running_t_u32);
+                        if (!s->abs_t && ((rec.w8 >> kLean8UnitShift) & 127u) != (u & 127u)) rc = -9;
                         if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
                         if (e.a) em(e.da, e.ta);
                         if (e.b) em(kDEmpty, e.tb);
