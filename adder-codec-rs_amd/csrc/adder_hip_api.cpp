@@ -810,7 +810,8 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 // segment can emit over the chunk (log_capacity: 2 or 3 events per unit and frame + one arena), instead of a slot per
 // frame that would have to hold a whole arena per unit -- 18 instead of 144 bytes per unit and frame at 64 frames.
 // Chunk = frames per scan launch: as many as the budget allows (ring_chunks chunks are in flight), at most kMaxChunk.
-// The budget is a quarter of what the device has free, at most 16 GiB.
+// The budget is a quarter of what the device has free, at most 64 GiB (a 1080p plane takes 3 - 5 GiB at 64-frame
+// chunks, a 4K RGB one -- 12 times the units -- would fall to 5-frame chunks under 16 GiB).
 static size_t scratch_bytes_per_chunk(const AdderHipCtx *c, AdderHipCtx::ScratchKind kind, uint32_t chunk) {
     switch (kind) {
         case AdderHipCtx::kScratchLean: return (size_t)c->num_waves * chunk * kLeanParkBytes;
@@ -841,7 +842,7 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
         if (p) HIPCHK(c, hipFree(p));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::min<size_t>((size_t)16 << 30, free_b / 4);
+    const size_t budget = std::min<size_t>((size_t)64 << 30, free_b / 4);
     c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
     if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
     if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)

@@ -42,13 +42,13 @@ W, H, C, FRAMES = 1920, 1080, 1, 300
 REF_TIME, DTM = 255, 255
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 STATE_BYTES = 16       # level 0 of a unit: hdr + integration + delta_t + best_delta_t
-REC_BYTES = 12         # one parked record per unit with events (lean variants)
+REC_BYTES = 12         # one parked record per unit with events (lean variants, AbsoluteT; 8 in DeltaT)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=64, help="timed steps (64 x 1.6 ms: a timed region of ~100 ms)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--content", default="scene", choices=["static", "noise", "scene"])
@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other SURVEY 8(d) configurations")
+    ap.add_argument("--secondary-ms", type=float, default=120.0, help="timed region of each secondary leg")
     ap.add_argument("--gather", default="torch", choices=["torch", "cabi", "layout"],
                     help="N>1: how the bands' streams become one inside the timed step: 'torch' = torch.distributed "
                          "(RCCL) transport + the HIP merge kernel; 'cabi' = libadder_rccl.so (adder_gather_events, the "
@@ -219,6 +221,7 @@ def main():
     # ---- roofline: one extra step with HIP event pairs around the launches ----
     k1_us = post_us = k1_one_us = k1_one_pair_us = 0.0
     k1_frames = 1.0
+    post_chunks = 1
     chunk_frames = hv.chunk_frames()
     records1 = records
     if not args.skip_roofline:
@@ -226,6 +229,7 @@ def main():
         step("none")
         k1_us, k1_frames = hv.last_launch_avg_us(), hv.last_launch_frames() or 1.0
         post_us = hv.last_post_avg_us()
+        post_chunks = hv.last_post_chunks()
         default_depth = int(k1_frames + 0.999)
         # the frame kernel alone with one frame per launch (the per-frame `consume` contract, state
         # streamed from HBM every frame): the HBM-bound regime of SURVEY 8(d)
@@ -258,18 +262,22 @@ def main():
     # B = 1 (input) + (S_in + S_out) / T_launch + 12 e bytes per pixel-channel-frame, with the state
     # this implementation really keeps (S = 16 B, +4 B last_fired_t in AbsoluteT) and T_launch = frames per launch.
     S = STATE_BYTES + (4 if abs_t else 0)
-    # kernels of one (full) chunk of frames: its frame-kernel launches + scan + offsets + expansion
-    chunk_us = k1_us * (chunk_frames / max(k1_frames, 1.0)) + post_us
+    # kernels of one (full) chunk of frames: its frame-kernel launches + scan + offsets + expansion.  Both averages
+    # include the clip's last, shorter chunk and are scaled to a full one.
+    post_frames = T / max(post_chunks, 1)
+    post_us_full = post_us * (chunk_frames / max(post_frames, 1.0))
+    chunk_us = k1_us * (chunk_frames / max(k1_frames, 1.0)) + post_us_full
     alg_b = 1 + 2 * S / max(k1_frames, 1.0) + 12 * e0
     achieved = alg_b * units * chunk_frames / (chunk_us * 1e-6) / 1e9 if chunk_us > 0 else 0.0
     # the frame kernel's own traffic (what it really moves): input + state + parked records
-    k1_b = 1 + 2 * S / max(k1_frames, 1.0) + REC_BYTES * r0
+    rec_bytes = REC_BYTES if abs_t or not lean else 8
+    k1_b = 1 + 2 * S / max(k1_frames, 1.0) + rec_bytes * r0
     k1_gbs = k1_b * units * k1_frames / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
     # the rest of the chunk: parked records in, 12-byte events out
-    post_b = REC_BYTES * r0 + 12 * e0
-    post_gbs = post_b * units * chunk_frames / (post_us * 1e-6) / 1e9 if post_us > 0 else 0.0
+    post_b = rec_bytes * r0 + 12 * e0
+    post_gbs = post_b * units * chunk_frames / (post_us_full * 1e-6) / 1e9 if post_us > 0 else 0.0
     r1 = records1 / float(units * T)
-    one_b = 1 + 2 * S + REC_BYTES * r1
+    one_b = 1 + 2 * S + rec_bytes * r1
     one_gbs = one_b * units / (k1_one_us * 1e-6) / 1e9 if k1_one_us > 0 else 0.0
 
     out = {
@@ -323,7 +331,7 @@ def main():
             "units_per_chunk": int(units * chunk_frames),
             "chunk_us": round(chunk_us, 3),
             "frame_kernel_launch_us": round(k1_us, 3),
-            "scan_offsets_expand_us": round(post_us, 3),
+            "scan_offsets_expand_us": round(post_us_full, 3),
             "frame_kernel_actual_GBs": round(k1_gbs, 1),
             "frame_kernel_actual_bytes_per_unit_frame": round(k1_b, 3),
             "expansion_actual_GBs": round(post_gbs, 1),
@@ -356,6 +364,9 @@ def main():
             "unit": "Mpixels/s",
             "note": "same step with only the per-frame counts all-gathered (the payload stays sharded in HBM)"}
 
+    if world == 1 and not args.no_secondary:
+        # the other configurations of SURVEY 8(d), each with its own context and clip (the headline's stay alive)
+        out["secondary"] = secondary_legs(args, torch, A)
     if world == 1 and not args.no_end_to_end:
         out["end_to_end"] = end_to_end(hv, d_frames, T, units, Wd, Ht, Cn)
     if world == 1 and not args.no_cpu_baseline:
@@ -367,6 +378,88 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+SECONDARY = [
+    # name, (W, H, C), (row_begin, row_end) or None, frames, content, multi, time mode, delta_t_max, crf numbers (baseline, max, velocity)
+    ("C3 1080p RGB x300 (Collapse, DeltaT, dtm 255)", (1920, 1080, 3), None, 300, "scene", "collapse", "delta_t", 255, (0, 0, 10)),
+    ("C4 one band 3840x270 of 2160 x1200 (Collapse, DeltaT, dtm 255)", (3840, 2160, 1), (0, 270), 1200, "scene", "collapse", "delta_t", 255, (0, 0, 10)),
+    ("C5 shape 3840x2160 RGB, crf-3 numbers, Collapse, AbsoluteT, dtm 7650", (3840, 2160, 3), None, 64, "scene", "collapse", "absolute_t", 7650, (2, 7, 7)),
+    ("1080p static (Collapse, DeltaT, dtm 255)", (1920, 1080, 1), None, 300, "static", "collapse", "delta_t", 255, (0, 0, 10)),
+    ("1080p noise (Collapse, DeltaT, dtm 255)", (1920, 1080, 1), None, 300, "noise", "collapse", "delta_t", 255, (0, 0, 10)),
+    ("1080p headline in AbsoluteT (Collapse, dtm 255)", (1920, 1080, 1), None, 300, "scene", "collapse", "absolute_t", 255, (0, 0, 10)),
+    ("1080p reference default mode: Collapse, AbsoluteT, dtm 7650 (crf-0 numbers)", (1920, 1080, 1), None, 300, "scene", "collapse", "absolute_t", 7650, (0, 0, 10)),
+    ("1080p reference default mode with its default quality: crf-3 numbers", (1920, 1080, 1), None, 300, "scene", "collapse", "absolute_t", 7650, (2, 7, 7)),
+    ("1080p Collapse, DeltaT, dtm 7650", (1920, 1080, 1), None, 300, "scene", "collapse", "delta_t", 7650, (0, 0, 10)),
+    ("1080p Normal, DeltaT, dtm 255", (1920, 1080, 1), None, 300, "scene", "normal", "delta_t", 255, (0, 0, 10)),
+    ("1080p Normal, AbsoluteT, dtm 7650", (1920, 1080, 1), None, 300, "scene", "normal", "absolute_t", 7650, (0, 0, 10)),
+]
+
+
+def secondary_legs(args, torch, A):
+    """The rest of SURVEY 8(d) as driver-visible numbers: every leg is a fresh context over its own clip resident in HBM,
+    stepped (reset + one batch of all its frames) until the timed region reaches --secondary-ms.  `frac` is the
+    leg's algorithmic bytes (1 + 2 S / frames per launch + 12 e per unit-frame) over its WALL time / 8 TB/s."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    legs = []
+    for name, (Wd, Ht, Cn), band, T, content, multi, tmode, dtm, crf in SECONDARY:
+        leg = {"workload": name, "frames_per_step": T}
+        hv = None
+        try:
+            y0, y1 = band if band else (0, Ht)
+            units = (y1 - y0) * Wd * Cn
+            d_frames = torch.empty((T, units), dtype=torch.uint8, device=dev)
+            A.synth_clip_device(d_frames, {"static": A.CONTENT_STATIC, "noise": A.CONTENT_NOISE, "scene": A.CONTENT_SCENE}[content],
+                                Wd, Ht, Cn, row_begin=y0, rows=y1 - y0, frame_begin=0, num_frames=T, stream=stream)
+            cap = int(units * T * (2.1 if content == "noise" else 0.6)) + 1024
+            d_events = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+            d_offsets = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+            abs_t = tmode == "absolute_t"
+            hv = A.HipVideo(Wd, Ht, Cn, row_begin=y0, row_end=y1, time_mode=A.TIME_ABSOLUTE_T if abs_t else A.TIME_DELTA_T,
+                            multi_mode=A.MULTI_COLLAPSE if multi == "collapse" else A.MULTI_NORMAL, ref_time=REF_TIME,
+                            delta_t_max=dtm, c_thresh_start=crf[0], c_counter_start=0)
+            hv.set_crf_parameters(crf[1], crf[2])
+
+            def step():
+                hv.reset()
+                hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
+                return hv.finish()
+            n = 0
+            for _ in range(14):  # set-up: allocations, graph capture and the choice between its instances
+                n = step()
+                if hv.launch_plan_settled():
+                    break
+            n = step()
+            torch.cuda.synchronize()
+            steps, t0 = 0, time.perf_counter()
+            while True:
+                n = step()
+                steps += 1
+                el = time.perf_counter() - t0
+                if el * 1e3 >= args.secondary_ms or steps >= 4096:
+                    break
+            e = n / float(units * T)
+            depth = min(hv.chunk_frames(), 64)
+            S = STATE_BYTES + (4 if abs_t else 0)
+            alg_b = 1 + 2 * S / depth + 12 * e
+            achieved = alg_b * units * T * steps / el / 1e9
+            leg.update({
+                "value": round(Wd * (y1 - y0) * T * steps / el / 1e6, 1), "unit": "Mpixels/s",
+                "mpixel_channels_per_s": round(units * T * steps / el / 1e6, 1),
+                "us_per_frame": round(el / (steps * T) * 1e6, 3), "steps": steps, "timed_ms": round(el * 1e3, 1),
+                "events_per_unit_frame": round(e, 5), "frames_per_chunk": hv.chunk_frames(),
+                "bytes_per_unit_frame": round(alg_b, 3), "achieved_GBs": round(achieved, 1),
+                "frac": round(achieved / HBM_PEAK_GBS, 4)})
+        except Exception as exc:  # a leg must not take the headline down
+            leg["error"] = str(exc)[:300]
+        finally:
+            if hv is not None:
+                hv.close()
+            d_frames = d_events = d_offsets = None
+            torch.cuda.empty_cache()
+        legs.append(leg)
+    return legs
 
 
 def end_to_end(hv, d_frames, T, units, Wd, Ht, Cn):
@@ -443,6 +536,14 @@ def end_to_end(hv, d_frames, T, units, Wd, Ht, Cn):
         for _ in range(3):  # every slot allocates its buffers on first use
             assert L.adder_hip_frame_submit(hv.h, pin[0].ctypes.data, Wd * Cn, float(REF_TIME)) == 0
         for _ in range(3):
+            collect()
+        # ... and the HIP runtime grows its own pools once, about 90 submits into a process (one call of 8 - 15 ms,
+        # tools/ring_probe.py): a warm ring is what a source that decodes thousands of frames sees
+        for k in range(120):
+            if L.adder_hip_frames_in_flight(hv.h) == 3:
+                collect()
+            assert L.adder_hip_frame_submit(hv.h, pin[k % (n_calls + 1)].ctypes.data, Wd * Cn, float(REF_TIME)) == 0
+        while L.adder_hip_frames_in_flight(hv.h):
             collect()
         hv.reset()
         assert L.adder_hip_frame_submit(hv.h, pin[0].ctypes.data, Wd * Cn, float(REF_TIME)) == 0
