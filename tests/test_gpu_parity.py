@@ -1292,3 +1292,28 @@ def test_frame_ring_warm_submits_return_quickly():
     assert np.median(sub) < 200.0
     assert per_frame < 1000.0  # (217 us measured: the PCIe transfer of 7.5 MB of events; generous for a shared box)
     hv.close()
+
+
+def test_model_fixtures_on_the_gpu(golden_dir):
+    """The HIP path against the 216 known answers of the independent second restatement
+    (tests/golden/make_model_fixtures.py): the lean, bounded Collapse and generic kernels in the modes no reference
+    artefact pins, per-frame calls for half of the cases and one batch for the others."""
+    import model_fixtures
+    A = _hip()
+    for k, cs in enumerate(model_fixtures.load(golden_dir)):
+        T, H, W, Cn = cs["frames"].shape
+        hv = A.HipVideo(W, H, Cn, time_mode=A.TIME_ABSOLUTE_T if cs["abs_t"] else A.TIME_DELTA_T,
+                        multi_mode=A.MULTI_COLLAPSE if cs["collapse"] else A.MULTI_NORMAL, ref_time=cs["ref"],
+                        delta_t_max=cs["dtm"], max_depth=24)
+        hv.set_crf_parameters(cs["c_max"], cs["vel"])
+        if (cs["c_start"], cs["ctr_start"]) != (10, 1):
+            hv.reset_c_thresh(cs["c_start"])
+        if k % 2:
+            got, offs = hv.integrate_batch(cs["frames"], time_spanned=float(cs["ref"]))
+            counts = [int(offs[i + 1] - offs[i]) for i in range(T)]
+        else:
+            per = [hv.integrate_matrix(f, time_spanned=float(cs["ref"])) for f in cs["frames"]]
+            counts, got = [len(p) for p in per], np.concatenate(per)
+        assert counts == list(cs["counts"]), k
+        assert np.array_equal(got, cs["events"]), k
+        hv.close()

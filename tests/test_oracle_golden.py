@@ -95,3 +95,28 @@ def test_second_opinion_vectors(golden_dir):
         have = np.stack([got["x"].astype(np.int64), got["y"].astype(np.int64), gc,
                          got["d"].astype(np.int64), got["t"].astype(np.int64)], axis=1)
         assert np.array_equal(have, want), case["name"]
+
+
+def test_model_fixtures_pin_the_unpinned_modes(golden_dir):
+    """216 randomised known answers from the independent second restatement (tests/golden/make_model_fixtures.py,
+    written from SURVEY Appendix A alone): Collapse with delta_t_max = ref_time, Collapse + AbsoluteT at 30 frames,
+    crf 3 / 6 / 9 numbers, RGB, construction-default pixels, other tick rates.  The C oracle must agree event for
+    event, frame for frame."""
+    import model_fixtures
+    cases = model_fixtures.load(golden_dir)
+    assert len(cases) >= 200
+    seen = set()
+    for k, cs in enumerate(cases):
+        T, H, W, Cn = cs["frames"].shape
+        v = O.Video(W, H, Cn, time_mode=O.ABSOLUTE_T if cs["abs_t"] else O.DELTA_T,
+                    multi_mode=O.COLLAPSE if cs["collapse"] else O.NORMAL, ref_time=cs["ref"], delta_t_max=cs["dtm"])
+        v.set_crf_parameters(cs["c_max"], cs["vel"])
+        if (cs["c_start"], cs["ctr_start"]) != (10, 1):  # (10, 1) = PixelArena::new's own values
+            assert cs["ctr_start"] == 0
+            v.reset_c_thresh(cs["c_start"])
+        v.ensure_capacity(24)
+        got = [v.integrate_matrix(f, time_spanned=float(cs["ref"])) for f in cs["frames"]]
+        assert [len(g) for g in got] == list(cs["counts"]), k
+        assert np.array_equal(np.concatenate(got), cs["events"]), k
+        seen.add((cs["collapse"], cs["abs_t"], cs["dtm"] // cs["ref"], cs["c_max"], Cn))
+    assert len(seen) >= 12
