@@ -157,6 +157,7 @@ SYMBOLS = {
     "adder_hip_synth_clip_device": (_i32, [_vp, _i32, _u64, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
     "adder_hip_merge_work_bytes": (_sz, [_u32, _u32]),
     "adder_hip_merge_streams_device": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp]),
+    "adder_hip_merge_streams_device_at": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _u64, _vp]),
     "adder_hip_check_status": (_i32, [_vp, _vp]),
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
     "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),

@@ -23,6 +23,7 @@ SYMBOLS = {
     "adder_gather_last_error": (C.c_char_p, [_vp]),
     "adder_gather_world": (_i32, [_vp]),
     "adder_gather_events": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _sz, _vp, C.POINTER(_sz), _vp]),
+    "adder_gather_events_at": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _sz, C.c_uint64, _vp, C.POINTER(_sz), _vp]),
     "adder_gather_layout": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
 }
 _lib = None
@@ -89,6 +90,20 @@ class HipGather:
             self.h, d_events.data_ptr(), d_offsets.data_ptr(), T, root,
             None if d_merged is None else d_merged.data_ptr(), cap,
             None if d_merged_offsets is None else d_merged_offsets.data_ptr(), C.byref(n),
+            C.c_void_p(stream) if stream else None)
+        self.last_required = n.value
+        self._check(rc)
+        return n.value
+
+    def gather_events_at(self, d_events, d_offsets, frame_begin, T, root, d_merged, merged_base, d_merged_offsets, stream=None):
+        """One chunk (frames [frame_begin, frame_begin + T) of this rank's stream) appended to the merged stream behind
+        merged_base events; returns the chunk's merged length.  d_offsets: the rank's int64 offsets of the whole clip."""
+        n = C.c_size_t(0)
+        cap = 0 if d_merged is None else d_merged.numel() * d_merged.element_size() // 12
+        rc = self.L.adder_gather_events_at(
+            self.h, d_events.data_ptr(), d_offsets.data_ptr() + 8 * frame_begin, T, root,
+            None if d_merged is None else d_merged.data_ptr(), cap, merged_base,
+            None if d_merged_offsets is None else d_merged_offsets.data_ptr() + 8 * frame_begin, C.byref(n),
             C.c_void_p(stream) if stream else None)
         self.last_required = n.value
         self._check(rc)

@@ -147,3 +147,115 @@ def gather_event_stream(events, offsets, dst=0, group=None, video=None):
         segs.append((stage[pos:pos + n_r], all_offs[r]))
         pos += n_r
     return merge_frame_major(segs)
+
+
+class ChunkPipelinedGather:
+    """The ordered gather, chunk by chunk behind the integration ("after each frame (or batch of T frames)").
+
+    The caller integrates its band one chunk of frames at a time and hands every finished chunk to push(); the chunk's
+    exchange (all-gather of its per-frame offsets, point-to-point payload to `dst`, merge into the growing merged
+    stream) is issued on a SIDE stream, so it runs while the next chunk is being integrated on the caller's stream.
+    result() waits for the last chunk and returns the merged (events, offsets) on dst.  Works on CUDA tensors (RCCL, or
+    gloo through host copies on single-GPU debug boxes) and on CPU tensors over gloo (tests)."""
+
+    def __init__(self, total_frames, merged_cap_events=0, dst=0, group=None, video=None, device=None):
+        self.group, self.dst, self.video = group, dst, video
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.T = total_frames
+        self.device = torch.device("cpu") if device is None else torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.frame_pos, self.merged_pos = 0, 0
+        self.merged = self.merged_offs = None
+        self._keep = []  # tensors the side stream still reads
+        if self.rank == dst:
+            self.merged = torch.empty((max(merged_cap_events, 1), 3), dtype=torch.int32, device=self.device)
+            self.merged_offs = torch.zeros(total_frames + 1, dtype=torch.int64, device=self.device)
+
+    def reset(self):
+        self.frame_pos, self.merged_pos = 0, 0
+        self._keep = []
+
+    def push(self, events, offsets):
+        """events: this rank's events of the chunk (int32 [n, 3]); offsets: int64 [Tc + 1] (any start value).  The
+        tensors must stay untouched until result() (the exchange reads them asynchronously)."""
+        Tc = offsets.numel() - 1
+        if self.world == 1:
+            n = int(offsets[-1] - offsets[0])
+            self.merged[self.merged_pos:self.merged_pos + n] = events[:n]
+            self.merged_offs[self.frame_pos:self.frame_pos + Tc + 1] = offsets - offsets[0] + self.merged_pos
+            self.merged_pos += n
+            self.frame_pos += Tc
+            return
+        via_host = self.cuda and dist.get_backend(self.group) == "gloo"
+        tdev = torch.device("cpu") if (via_host or not self.cuda) else self.device
+        ctx = torch.cuda.stream(self.side) if self.cuda else _NullCtx()
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream(self.device))  # the chunk's events are complete behind this
+        with ctx:
+            offs = (offsets - offsets[0]).contiguous().to(tdev)
+            all_offs = torch.empty((self.world, Tc + 1), dtype=torch.int64, device=tdev)
+            if tdev.type == "cuda":
+                dist.all_gather_into_tensor(all_offs, offs, group=self.group)
+            else:
+                dist.all_gather(list(all_offs.unbind(0)), offs, group=self.group)
+            totals = all_offs[:, -1].tolist()  # (waits for the all-gather only: the next chunk keeps integrating)
+            total = int(sum(totals))
+            ops, stage = [], None
+            if self.rank == self.dst:
+                stage = torch.empty((max(total, 1), 3), dtype=torch.int32, device=tdev)
+                pos = 0
+                for r in range(self.world):
+                    n_r = int(totals[r])
+                    if r == self.dst:
+                        stage[pos:pos + n_r] = events[:n_r].to(tdev)
+                    elif n_r:
+                        ops.append(dist.P2POp(dist.irecv, stage[pos:pos + n_r], r, self.group))
+                    pos += n_r
+            elif int(totals[self.rank]):
+                send = events[:int(totals[self.rank])].contiguous().to(tdev)
+                self._keep.append(send)
+                ops.append(dist.P2POp(dist.isend, send, self.dst, self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if self.rank == self.dst:
+                if self.merged_pos + total > self.merged.shape[0]:
+                    raise RuntimeError(f"merged buffer too small: need {self.merged_pos + total} events")
+                if self.cuda:
+                    if via_host:
+                        stage, all_offs = stage.to(self.device), all_offs.to(self.device)
+                    self._keep += [stage, all_offs]
+                    self.video.merge_streams_device(stage, all_offs, self.world, Tc, self.merged[self.merged_pos:],
+                                                    self.merged_offs[self.frame_pos:], stream=self.side.cuda_stream,
+                                                    merged_base=self.merged_pos)
+                else:
+                    pos, segs = 0, []
+                    for r in range(self.world):
+                        n_r = int(totals[r])
+                        segs.append((stage[pos:pos + n_r], all_offs[r]))
+                        pos += n_r
+                    ev, mo = merge_frame_major(segs)
+                    self.merged[self.merged_pos:self.merged_pos + total] = ev
+                    self.merged_offs[self.frame_pos:self.frame_pos + Tc + 1] = mo + self.merged_pos
+            self.merged_pos += total
+            self.frame_pos += Tc
+
+    def result(self):
+        if self.cuda:
+            self.side.synchronize()
+            if self.rank == self.dst and self.video is not None and self.world > 1:
+                self.video.check_status(self.side.cuda_stream)
+        self._keep = []
+        if self.rank != self.dst:
+            return None
+        return self.merged[:self.merged_pos], self.merged_offs
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -347,7 +347,8 @@ class HipVideo:
         """Back to the freshly constructed state (Video::new); parameters are kept."""
         N.check(self.h, self.L.adder_hip_reset(self.h))
 
-    def merge_streams_device(self, d_stage, d_rank_offsets, world, T, d_out, d_merged_offsets=None, stream=None):
+    def merge_streams_device(self, d_stage, d_rank_offsets, world, T, d_out, d_merged_offsets=None, stream=None,
+                             merged_base=0):
         """Multi-GPU merge (include/adder_hip.h): `world` frame-major streams laid back to back in d_stage
         (rank offsets: int64 CUDA tensor [world, T+1]) -> one frame-major stream in d_out, rank order inside
         every frame.  Asynchronous; check_status() reports a capacity overflow."""
@@ -356,9 +357,10 @@ class HipVideo:
         if getattr(self, "_merge_work", None) is None or self._merge_work.numel() < need:
             self._merge_work = torch.empty(max(need, 8), dtype=torch.uint8, device=d_out.device)
         cap = d_out.numel() * d_out.element_size() // 12
-        N.check(self.h, self.L.adder_hip_merge_streams_device(
+        # (merged_base: d_out / d_merged_offsets are where a CHUNK of a longer merged stream begins)
+        N.check(self.h, self.L.adder_hip_merge_streams_device_at(
             self.h, d_stage.data_ptr(), d_rank_offsets.data_ptr(), world, T, self._merge_work.data_ptr(),
-            d_out.data_ptr(), cap, None if d_merged_offsets is None else d_merged_offsets.data_ptr(),
+            d_out.data_ptr(), cap, None if d_merged_offsets is None else d_merged_offsets.data_ptr(), merged_base,
             C.c_void_p(stream) if stream else None))
 
     def check_status(self, stream=None):

@@ -28,6 +28,7 @@ struct AdderGather {
     AdderEvent *d_stage = nullptr;   // root: the ranks' streams back to back
     size_t stage_cap = 0;            // bytes
     std::vector<uint64_t> h_offs;    // host copy of d_all_offs
+    int *d_flag = nullptr;           // the ranks' agreement that nothing failed before the payload exchange
     std::string err;
 };
 
@@ -126,6 +127,7 @@ extern "C" void adder_gather_destroy(AdderGather *g) {
     if (g->d_all_offs) (void)hipFree(g->d_all_offs);
     if (g->d_work) (void)hipFree(g->d_work);
     if (g->d_stage) (void)hipFree(g->d_stage);
+    if (g->d_flag) (void)hipFree(g->d_flag);
     if (g->owns_comm && g->comm) (void)ncclCommDestroy(g->comm);
     delete g;
 }
@@ -168,9 +170,12 @@ extern "C" int adder_gather_layout(AdderGather *g, const uint64_t *d_frame_offse
     return ADDER_OK;
 }
 
-extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
-                                   uint32_t T, int root, AdderEvent *d_merged, size_t merged_cap,
-                                   uint64_t *d_merged_offsets, size_t *n_merged, void *stream) {
+// One chunk of the streams: frames [0, T) of what every rank passes, appended to the merged stream behind merged_base
+// events.  Every failure that only one rank can see (root's staging / scratch allocations) is agreed on with a one-word
+// all-reduce BEFORE the payload exchange, so that no rank is left waiting in a send.
+extern "C" int adder_gather_events_at(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                      uint32_t T, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
+                                      uint64_t *d_merged_offsets, size_t *n_merged, void *stream) {
     if (n_merged) *n_merged = 0;
     if (!g || !d_frame_offsets) return gfail(g, ADDER_E_BAD_PARAMS, "null argument");
     if (root < 0 || root >= g->world) return gfail(g, ADDER_E_BAD_PARAMS, "bad root %d", root);
@@ -180,19 +185,35 @@ extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, c
     const size_t per = (size_t)T + 1;
     std::vector<uint64_t> tot(g->world), base(g->world + 1, 0);
     for (int r = 0; r < g->world; ++r) {
-        tot[r] = g->h_offs[r * per + T];
+        tot[r] = g->h_offs[r * per + T] - g->h_offs[r * per];  // (offsets need not start at 0: a chunk of a stream)
         base[r + 1] = base[r] + tot[r];
     }
     const uint64_t total = base[g->world];
-    if (g->rank == root) {
-        if (total > merged_cap) {
-            if (n_merged) *n_merged = (size_t)total;
-            // still take part in the exchange below with a staging buffer, so that no rank hangs
-        }
+    const uint64_t first = g->h_offs[(size_t)g->rank * per];
+    // ---- everything that can fail locally, then one agreement ----
+    int local_rc = ADDER_OK;
+    if (tot[g->rank] != 0 && !d_events) local_rc = gfail(g, ADDER_E_BAD_PARAMS, "d_events is null but the chunk holds events");
+    if (g->rank == root && local_rc == ADDER_OK) {
         void *p = g->d_stage;
-        rc = grow(g, &p, &g->stage_cap, (size_t)total * sizeof(AdderEvent));
+        local_rc = grow(g, &p, &g->stage_cap, (size_t)total * sizeof(AdderEvent));
         g->d_stage = (AdderEvent *)p;
-        if (rc != ADDER_OK) return rc;
+        if (local_rc == ADDER_OK) {
+            p = g->d_work;
+            local_rc = grow(g, &p, &g->work_cap, adder_hip_merge_work_bytes((uint32_t)g->world, T));
+            g->d_work = p;
+        }
+    }
+    if (g->world > 1) {
+        if (!g->d_flag) GHIP(g, hipMalloc(reinterpret_cast<void **>(&g->d_flag), sizeof(int)));
+        const int bad = local_rc != ADDER_OK ? 1 : 0;
+        int any = 0;
+        GHIP(g, hipMemcpyAsync(g->d_flag, &bad, sizeof bad, hipMemcpyHostToDevice, s));
+        GNCCL(g, ncclAllReduce(g->d_flag, g->d_flag, 1, ncclInt32, ncclMax, g->comm, s));
+        GHIP(g, hipMemcpyAsync(&any, g->d_flag, sizeof any, hipMemcpyDeviceToHost, s));
+        GHIP(g, hipStreamSynchronize(s));
+        if (any) return local_rc != ADDER_OK ? local_rc : gfail(g, ADDER_E_HIP, "another rank failed before the exchange");
+    } else if (local_rc != ADDER_OK) {
+        return local_rc;
     }
     // payload: every rank -> root, back to back in rank order (ncclGroup of point-to-point transfers
     // over xGMI; root's own stream is a device copy)
@@ -203,7 +224,7 @@ extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, c
             GNCCL(g, ncclRecv(g->d_stage + base[r], (size_t)tot[r] * sizeof(AdderEvent), ncclUint8, r, g->comm, s));
         }
     } else if (tot[g->rank] != 0) {
-        GNCCL(g, ncclSend(d_events, (size_t)tot[g->rank] * sizeof(AdderEvent), ncclUint8, root, g->comm, s));
+        GNCCL(g, ncclSend(d_events + first, (size_t)tot[g->rank] * sizeof(AdderEvent), ncclUint8, root, g->comm, s));
     }
     GNCCL(g, ncclGroupEnd());
     if (g->rank != root) {
@@ -211,21 +232,26 @@ extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, c
         return ADDER_OK;
     }
     if (tot[root])
-        GHIP(g, hipMemcpyAsync(g->d_stage + base[root], d_events, (size_t)tot[root] * sizeof(AdderEvent),
+        GHIP(g, hipMemcpyAsync(g->d_stage + base[root], d_events + first, (size_t)tot[root] * sizeof(AdderEvent),
                                hipMemcpyDeviceToDevice, s));
     if (n_merged) *n_merged = (size_t)total;
-    if (total > merged_cap) {
+    if (merged_base > merged_cap || total > merged_cap - merged_base) {
         GHIP(g, hipStreamSynchronize(s));
-        return gfail(g, ADDER_E_OUT_CAPACITY, "merged buffer too small: need %llu events", (unsigned long long)total);
+        return gfail(g, ADDER_E_OUT_CAPACITY, "merged buffer too small: need %llu events",
+                     (unsigned long long)(merged_base + total));
     }
-    void *p = g->d_work;
-    rc = grow(g, &p, &g->work_cap, adder_hip_merge_work_bytes((uint32_t)g->world, T));
-    g->d_work = p;
-    if (rc != ADDER_OK) return rc;
-    rc = adder_hip_merge_streams_device(g->ctx, g->d_stage, g->d_all_offs, (uint32_t)g->world, T, g->d_work, d_merged,
-                                        merged_cap, d_merged_offsets, s);
+    rc = adder_hip_merge_streams_device_at(g->ctx, g->d_stage, g->d_all_offs, (uint32_t)g->world, T, g->d_work,
+                                           d_merged ? d_merged + merged_base : nullptr, merged_cap - merged_base,
+                                           d_merged_offsets, merged_base, s);
     if (rc != ADDER_OK) return gfail(g, rc, "merge: %s", adder_hip_last_error(g->ctx));
     rc = adder_hip_check_status(g->ctx, s);
     if (rc != ADDER_OK) return gfail(g, rc, "merge: %s", adder_hip_last_error(g->ctx));
     return ADDER_OK;
+}
+
+extern "C" int adder_gather_events(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                   uint32_t T, int root, AdderEvent *d_merged, size_t merged_cap,
+                                   uint64_t *d_merged_offsets, size_t *n_merged, void *stream) {
+    return adder_gather_events_at(g, d_events, d_frame_offsets, T, root, d_merged, merged_cap, 0ull, d_merged_offsets,
+                                  n_merged, stream);
 }

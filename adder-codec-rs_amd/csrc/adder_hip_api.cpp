@@ -2116,22 +2116,31 @@ extern "C" size_t adder_hip_merge_work_bytes(uint32_t world, uint32_t num_frames
     return ((size_t)num_frames + 1 + (size_t)world * num_frames) * sizeof(uint64_t);
 }
 
-extern "C" int adder_hip_merge_streams_device(AdderHipCtx *c, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
-                                              uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
-                                              size_t out_cap, uint64_t *d_merged_offsets, void *stream) {
+// merged_base: events of the merged stream that precede this batch (a chunk of a longer stream: d_out is then the place
+// of the chunk's first event, d_merged_offsets the entry of its first frame, and the offsets written continue from there)
+extern "C" int adder_hip_merge_streams_device_at(AdderHipCtx *c, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
+                                                 uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
+                                                 size_t out_cap, uint64_t *d_merged_offsets, uint64_t merged_base, void *stream) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (!d_rank_offsets || !d_work || world == 0 || (!d_out && out_cap))
         return fail(c, ADDER_E_BAD_PARAMS, "merge: null pointer or empty world");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (num_frames == 0) {
-        if (d_merged_offsets) HIPCHK(c, hipMemsetAsync(d_merged_offsets, 0, sizeof(uint64_t), s));
+        if (d_merged_offsets) HIPCHK(c, hipMemcpyAsync(d_merged_offsets, &merged_base, sizeof(uint64_t), hipMemcpyHostToDevice, s));
         return ADDER_OK;
     }
     HIPCHK(c, adder_launch_merge(reinterpret_cast<const AdderEventPod *>(d_stage), d_rank_offsets, world, num_frames,
                                  reinterpret_cast<uint64_t *>(d_work), reinterpret_cast<AdderEventPod *>(d_out), out_cap,
-                                 d_merged_offsets, c->status, s));
+                                 d_merged_offsets, merged_base, c->status, s));
     return ADDER_OK;
+}
+
+extern "C" int adder_hip_merge_streams_device(AdderHipCtx *c, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
+                                              uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
+                                              size_t out_cap, uint64_t *d_merged_offsets, void *stream) {
+    return adder_hip_merge_streams_device_at(c, d_stage, d_rank_offsets, world, num_frames, d_work, d_out, out_cap,
+                                             d_merged_offsets, 0ull, stream);
 }
 
 extern "C" int adder_hip_check_status(AdderHipCtx *c, void *stream) {

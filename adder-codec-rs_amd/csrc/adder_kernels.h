@@ -284,7 +284,7 @@ hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n
 // merge of `world` frame-major streams laid back to back in `stage` (offs = [world][T+1]); work = (T+1) + world*T uint64
 hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
                               uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap, uint64_t *merged_offsets,
-                              uint32_t *status, hipStream_t stream);
+                              uint64_t merged_base, uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_frame_out(const adder::AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
                                   adder::AdderEventPod *h_ev, adder::FrameResult *h_res, uint32_t *h_chunks,
                                   const uint32_t *status, const uint32_t *counters, uint32_t row_begin, uint32_t chunk_rows,

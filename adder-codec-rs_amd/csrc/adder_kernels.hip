@@ -1979,7 +1979,8 @@ __global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPo
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adder_merge_layout_kernel(const uint64_t *__restrict__ offs, uint32_t world,
                                                                  uint32_t T, uint64_t *__restrict__ work,
-                                                                 uint64_t *__restrict__ merged_offsets) {
+                                                                 uint64_t *__restrict__ merged_offsets,
+                                                                 uint64_t merged_base) {
     // frame totals -> exclusive prefix over frames (serial per 256-frame tile; T is a few hundred)
     __shared__ uint64_t s_tile[256];
     __shared__ uint64_t s_carry;
@@ -1987,7 +1988,7 @@ __global__ __launch_bounds__(256) void adder_merge_layout_kernel(const uint64_t 
     if (tid == 0) {
         s_carry = 0;
         work[0] = 0;
-        if (merged_offsets) merged_offsets[0] = 0;
+        if (merged_offsets) merged_offsets[0] = merged_base;  // (a chunk of a longer stream: the events before it)
     }
     __syncthreads();
     for (uint32_t f0 = 0; f0 < T; f0 += 256u) {
@@ -2015,7 +2016,7 @@ __global__ __launch_bounds__(256) void adder_merge_layout_kernel(const uint64_t 
                 before += offs[(size_t)r * (T + 1) + f + 1] - offs[(size_t)r * (T + 1) + f];
             }
             work[f + 1] = base + before;
-            if (merged_offsets) merged_offsets[f + 1] = base + before;
+            if (merged_offsets) merged_offsets[f + 1] = merged_base + base + before;
         }
         __syncthreads();
     }
@@ -2027,20 +2028,24 @@ __global__ __launch_bounds__(256) void adder_merge_copy_kernel(const uint32_t *_
                                                                uint32_t T, const uint64_t *__restrict__ work,
                                                                uint32_t *__restrict__ out, uint64_t out_cap,
                                                                uint32_t *status) {
-    const uint32_t r = blockIdx.y / T, f = blockIdx.y - r * T;
-    uint64_t stage_base = 0;
-    for (uint32_t k = 0; k < r; ++k) stage_base += offs[(size_t)k * (T + 1) + T];
-    const uint64_t a = offs[(size_t)r * (T + 1) + f], e = offs[(size_t)r * (T + 1) + f + 1];
-    const uint64_t dst = work[(T + 1) + (size_t)r * T + f];
-    uint64_t n = e - a;
-    if (dst + n > out_cap) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) raise(status, kStatusCapacity);
-        n = dst < out_cap ? out_cap - dst : 0;
+    // (rank, frame) pairs: blockIdx.y walks them (world * T may exceed the 65 535 rows a grid can have)
+    for (uint32_t rf = blockIdx.y; rf < world * T; rf += gridDim.y) {
+        const uint32_t r = rf / T, f = rf - r * T;
+        uint64_t stage_base = 0;
+        for (uint32_t k = 0; k < r; ++k) stage_base += offs[(size_t)k * (T + 1) + T] - offs[(size_t)k * (T + 1)];
+        const uint64_t first = offs[(size_t)r * (T + 1)];  // (a rank's offsets need not start at 0: a chunk of its stream)
+        const uint64_t a = offs[(size_t)r * (T + 1) + f] - first, e = offs[(size_t)r * (T + 1) + f + 1] - first;
+        const uint64_t dst = work[(T + 1) + (size_t)r * T + f];
+        uint64_t n = e - a;
+        if (dst + n > out_cap) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) raise(status, kStatusCapacity);
+            n = dst < out_cap ? out_cap - dst : 0;
+        }
+        const uint32_t *src = stage + (stage_base + a) * 3u;
+        uint32_t *d = out + dst * 3u;
+        const uint64_t nd = n * 3u;
+        for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nd; i += (uint64_t)gridDim.x * 256u) d[i] = src[i];
     }
-    const uint32_t *src = stage + (stage_base + a) * 3u;
-    uint32_t *d = out + dst * 3u;
-    const uint64_t nd = n * 3u;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nd; i += (uint64_t)gridDim.x * 256u) d[i] = src[i];
 }
 
 // ---- deterministic synthetic content ----
@@ -2236,10 +2241,12 @@ extern "C" hipError_t adder_launch_synth(uint8_t *dst, int content, uint64_t see
 
 extern "C" hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t *offs, uint32_t world, uint32_t T,
                                          uint64_t *work, adder::AdderEventPod *out, uint64_t out_cap,
-                                         uint64_t *merged_offsets, uint32_t *status, hipStream_t stream) {
+                                         uint64_t *merged_offsets, uint64_t merged_base, uint32_t *status, hipStream_t stream) {
     if (world == 0 || T == 0) return hipSuccess;
-    hipLaunchKernelGGL(adder_merge_layout_kernel, dim3(1), dim3(256), 0, stream, offs, world, T, work, merged_offsets);
-    hipLaunchKernelGGL(adder_merge_copy_kernel, dim3(64, world * T), dim3(256), 0, stream,
+    hipLaunchKernelGGL(adder_merge_layout_kernel, dim3(1), dim3(256), 0, stream, offs, world, T, work, merged_offsets,
+                       merged_base);
+    const uint64_t pairs = (uint64_t)world * T;
+    hipLaunchKernelGGL(adder_merge_copy_kernel, dim3(64, (uint32_t)(pairs < 65535u ? pairs : 65535u)), dim3(256), 0, stream,
                        reinterpret_cast<const uint32_t *>(stage), offs, world, T, work,
                        reinterpret_cast<uint32_t *>(out), out_cap, status);
     return hipGetLastError();

@@ -152,20 +152,51 @@ def main():
             d_merged = torch.empty((cap * world, 3), dtype=torch.int32, device=dev)
             d_merged_offs = torch.zeros(T + 1, dtype=torch.int64, device=dev)
 
+    # N > 1: the band is integrated one chunk of frames at a time, and every finished chunk is exchanged and merged on a
+    # SIDE stream while the next chunk integrates (sharding.ChunkPipelinedGather / adder_gather_events_at): the gather
+    # of SURVEY 8(e) "after each batch of T frames", not one funnel after the whole clip.
+    gchunk = int(os.environ.get("ADDER_BENCH_GATHER_CHUNK", "64"))
+    pg = None
+    d_chunk_offs = None
+    side = None
+    if world > 1 and gather_mode in ("torch", "cabi"):
+        d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
+        if gather_mode == "torch":
+            pg = sharding.ChunkPipelinedGather(T, merged_cap_events=cap * world if rank == 0 else 0, dst=0, video=hv, device=dev)
+        else:
+            side = torch.cuda.Stream(device=dev)
+
     def step(mode):
         hv.reset()
+        if mode in ("torch", "cabi"):
+            if pg is not None:
+                pg.reset()
+            pos, merged_pos = 0, 0
+            for k, f0 in enumerate(range(0, T, gchunk)):
+                nf = min(gchunk, T - f0)
+                offs_k = d_chunk_offs[k, :nf + 1]
+                hv.integrate_device(d_frames[f0:f0 + nf], d_events[pos:], offs_k, stream=stream)
+                n_k = hv.finish()
+                if mode == "torch":
+                    pg.push(d_events[pos:pos + n_k], offs_k)  # side stream: overlaps the next chunk's integration
+                else:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    d_offsets[f0:f0 + nf + 1] = offs_k + pos  # (the rank's own whole-clip offsets, for the record)
+                    merged_pos += hg.gather_events_at(d_events[pos:], offs_k, 0, nf, 0, d_merged, merged_pos,
+                                                      None if d_merged_offs is None else d_merged_offs[f0:],
+                                                      stream=side.cuda_stream)
+                pos += n_k
+            if mode == "torch":
+                out = pg.result()
+                merged_total = int(out[1][-1]) if rank == 0 else pos
+            else:
+                side.synchronize()
+                merged_total = merged_pos if rank == 0 else pos
+            return pos, merged_total
         hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
         n = hv.finish()
         merged_total = n
-        if mode == "torch":
-            # all-gather of the offsets + point-to-point payload to rank 0 (RCCL over xGMI) + HIP merge kernel
-            out = sharding.gather_event_stream(d_events[:n], d_offsets, dst=0, video=hv)
-            if rank == 0:
-                hv.check_status(stream)  # synchronises: the merged stream is complete
-                merged_total = int(out[1][-1])
-        elif mode == "cabi":
-            merged_total = hg.gather_events(d_events, d_offsets, T, 0, d_merged, d_merged_offs, stream=stream)
-        elif mode == "layout":
+        if mode == "layout":
             lay = sharding.exchange_stream_layout(d_offsets.cpu() if share else d_offsets)
             merged_total = int(lay[0][-1])
         return n, merged_total
@@ -302,7 +333,8 @@ def main():
             "frames_per_step": T,
             "sharding": ("single GPU" if world == 1 else
                          f"{world} row bands of the one plane; per step the bands' event streams are gathered to "
-                         f"rank 0 ({gather_mode}) inside the timed region"),
+                         f"rank 0 ({gather_mode}) inside the timed region, chunk by chunk ({gchunk} frames) on a side "
+                         f"stream while the next chunk integrates"),
             "world_size_seen": world,
             "backend": "none" if world == 1 else ("gloo (shared-device debug)" if share else "nccl (RCCL)"),
         },

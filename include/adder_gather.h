@@ -50,6 +50,17 @@ int adder_gather_events(AdderGather *g, const AdderEvent *d_events, const uint64
                         uint32_t num_frames, int root, AdderEvent *d_merged, size_t merged_cap,
                         uint64_t *d_merged_offsets, size_t *n_merged, void *stream);
 
+/* The same for ONE CHUNK of the streams, so that the exchange of chunk k runs (on its own stream) while chunk k+1 is
+ * integrated: d_frame_offsets is the entry of the chunk's first frame in the rank's offsets (uint64[T+1], values as
+ * adder_hip_integrate_device left them: they need not start at 0), d_events the rank's whole event buffer, and the
+ * chunk's merged events are appended to d_merged behind merged_base events; d_merged_offsets is the entry of the
+ * chunk's first frame in the merged offsets, which continue from merged_base.  *n_merged = the chunk's merged events.
+ * A failure only one rank can see (root's staging allocation) is agreed on before the payload moves: every rank
+ * returns an error, none hangs. */
+int adder_gather_events_at(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                           uint32_t num_frames, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
+                           uint64_t *d_merged_offsets, size_t *n_merged, void *stream);
+
 /* Layout-only exchange: all-gathers the per-frame offsets and returns, on every rank, the merged
  * stream's frame offsets (h_merged_offsets, host uint64[T+1]) and where this rank's segment of each
  * frame belongs in it (h_my_base, host uint64[T]).  The payload stays sharded: every rank can deliver

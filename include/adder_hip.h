@@ -342,6 +342,13 @@ size_t adder_hip_merge_work_bytes(uint32_t world, uint32_t num_frames);
 int adder_hip_merge_streams_device(AdderHipCtx *ctx, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
                                    uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
                                    size_t out_cap, uint64_t *d_merged_offsets, void *stream);
+/* The same for a CHUNK of a longer stream (the gather is pipelined chunk by chunk behind the integration): a rank's
+ * offsets may start anywhere (they are taken relative to their first entry), d_out is where the chunk's first merged
+ * event goes, d_merged_offsets the entry of the chunk's first frame, and the offsets written continue from merged_base
+ * = the events of the merged stream before this chunk. */
+int adder_hip_merge_streams_device_at(AdderHipCtx *ctx, const AdderEvent *d_stage, const uint64_t *d_rank_offsets,
+                                      uint32_t world, uint32_t num_frames, void *d_work, AdderEvent *d_out,
+                                      size_t out_cap, uint64_t *d_merged_offsets, uint64_t merged_base, void *stream);
 int adder_hip_check_status(AdderHipCtx *ctx, void *stream);
 
 #ifdef __cplusplus

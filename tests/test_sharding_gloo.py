@@ -113,3 +113,69 @@ def test_merge_frame_major_orders_by_frame_then_rank():
     b = (torch.tensor([[10, 0, 0], [20, 0, 0]], dtype=torch.int32), torch.tensor([0, 0, 2, 2]))
     ev, offs = sharding.merge_frame_major([a, b])
     assert ev[:, 0].tolist() == [1, 10, 20, 2, 3] and offs.tolist() == [0, 1, 3, 5]
+
+
+def _worker_pipelined(rank, world, port, chunk_frames, q):
+    for p in (ROOT, os.path.join(ROOT, "adder-codec-rs_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import oracle as O
+    import clips
+    from adder_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, T = 41, 23, 37
+        clip = clips.make_clip("runs", T, H, W, 1, seed=5)
+        y0, y1 = sharding.row_bands(H, world)[rank]
+        v = O.Video(W, y1 - y0, 1, row_begin=y0, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+        pg = sharding.ChunkPipelinedGather(T, merged_cap_events=4 * H * W * T, dst=0)
+        for rnd in range(2):  # a second clip through the same object after reset()
+            pg.reset()
+            if rnd:
+                v = O.Video(W, y1 - y0, 1, row_begin=y0, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+                v.set_crf_parameters(0, 10)
+                v.reset_c_thresh(0)
+            run = 0  # the rank's offsets keep counting across chunks, like one long stream
+            for f0 in range(0, T, chunk_frames):
+                per = [v.integrate_matrix(clip[k, y0:y1]) for k in range(f0, min(T, f0 + chunk_frames))]
+                offs = torch.tensor(run + np.concatenate([[0], np.cumsum([len(e) for e in per])]), dtype=torch.int64)
+                run = int(offs[-1])
+                ev = np.concatenate(per)
+                pg.push(torch.from_numpy(np.frombuffer(ev.tobytes(), dtype=np.int32).reshape(-1, 3).copy()), offs)
+            merged = pg.result()
+            if rank == 0:
+                full = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+                full.set_crf_parameters(0, 10)
+                full.reset_c_thresh(0)
+                want_per = [full.integrate_matrix(clip[k]) for k in range(T)]
+                want = np.concatenate(want_per)
+                got = np.frombuffer(merged[0].numpy().tobytes(), dtype=O.EVENT_DTYPE)
+                ok = len(got) == len(want) and np.array_equal(got, want)
+                ok = ok and merged[1].tolist() == np.concatenate([[0], np.cumsum([len(e) for e in want_per])]).tolist()
+                q.put(bool(ok))
+            else:
+                assert merged is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunk_frames", [(2, 8), (4, 16), (4, 64)])
+def test_chunk_pipelined_gather_matches_single_stream(world, chunk_frames):
+    """the collective runs "after each frame (or batch of T frames)" -- every chunk of frames is exchanged
+    and merged into the growing stream while the next is integrated; rank 0 must end up with the single-context
+    stream, offsets included, at world sizes 2 and 4 and with a last chunk that is short."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, chunk_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert [q.get(timeout=5) for _ in range(2)] == [True, True]
