@@ -565,6 +565,18 @@ def test_gather_cabi_single_rank_world():
     assert torch.equal(d_m[:n], d_ev[:n]) and torch.equal(d_mo, d_off) and int((d_m[n:] != -1).sum()) == 0
     merged, base = g.layout(d_off, T, stream=st)
     assert np.array_equal(merged.astype(np.int64), d_off.cpu().numpy()) and np.array_equal(base, merged[:-1])
+    # the chunk-range entry point (adder_gather_events_at): three chunks appended one after the other, the rank's
+    # offsets passed as they are (they do not start at 0 for the later chunks), on a side stream
+    d_m2 = torch.full((n + 3, 3), -1, dtype=torch.int32, device="cuda")
+    d_mo2 = torch.full((T + 1,), -7, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    pos = 0
+    for f0, nf in ((0, 8), (8, 8), (16, 4)):
+        pos += g.gather_events_at(d_ev, d_off, f0, nf, 0, d_m2, pos, d_mo2, stream=side.cuda_stream)
+    side.synchronize()
+    assert pos == n and torch.equal(d_m2[:n], d_ev[:n]) and torch.equal(d_mo2, d_off) and int((d_m2[n:] != -1).sum()) == 0
+    with pytest.raises(A.AdderHipError, match="too small"):
+        g.gather_events_at(d_ev, d_off, 0, T, 0, d_m2[: n - 1], 0, d_mo2, stream=side.cuda_stream)
     g.close()
 
 
