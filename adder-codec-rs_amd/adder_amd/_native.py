@@ -159,6 +159,11 @@ SYMBOLS = {
     "adder_hip_merge_streams_device": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _vp]),
     "adder_hip_merge_streams_device_at": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _sz, _vp, _u64, _vp]),
     "adder_hip_check_status": (_i32, [_vp, _vp]),
+    "adder_hip_feature_halo_bytes": (_sz, [_vp]),
+    "adder_hip_feature_halo_export": (_i32, [_vp, _vp, _vp, _vp]),
+    "adder_hip_feature_halo_import": (_i32, [_vp, _vp, _vp, _vp]),
+    "adder_hip_feature_detect": (_i32, [_vp, _vp, _u32, C.POINTER(_u32), _vp]),
+    "adder_hip_feature_apply": (_i32, [_vp, _vp, _u32, _vp]),
     "adder_raw_header": (_sz, [_vp, _u8, _u16, _u16, _u8, _u32, _u32, _u32, _u32, _u32, _u32]),
     "adder_raw_events": (_sz, [_vp, _vp, _sz, _u8]),
     "adder_raw_eof": (_sz, [_vp]),

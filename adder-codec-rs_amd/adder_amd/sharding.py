@@ -259,3 +259,48 @@ class _NullCtx:
 
     def __exit__(self, *a):
         return False
+
+
+class FeatureBands:
+    """Feature-driven rate control / ROI over row bands held by ONE process (several contexts on one device, or one per
+    device with peer access): drives the per-frame protocol of include/adder_hip.h -- integrate the frame on every
+    band, exchange the 3-row halos of the running intensities, run the feature step per band, hand every band the
+    other bands' new features.  A multi-process host does the same with RCCL send / recv between its ranks."""
+
+    def __init__(self, videos):
+        import torch
+        self.videos = list(videos)  # top to bottom
+        self.torch = torch
+        hb = self.videos[0].L.adder_hip_feature_halo_bytes(self.videos[0].h)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.top = [torch.zeros(hb, dtype=torch.uint8, device=dev) for _ in self.videos]
+        self.bottom = [torch.zeros(hb, dtype=torch.uint8, device=dev) for _ in self.videos]
+        self.lists = [torch.zeros(1 << 16, dtype=torch.int32, device=dev) for _ in self.videos]
+        self.new_features = 0
+
+    def integrate_matrix(self, frame, time_spanned=None):
+        """frame: the whole plane [H, W, C]; returns the merged events of the frame (bands in order = raster order)."""
+        import ctypes as C
+        import numpy as np
+        from . import _native as N
+        vs = self.videos
+        out = [v.integrate_matrix(frame[v.row_begin:v.row_end], time_spanned=time_spanned) for v in vs]
+        for k, v in enumerate(vs):
+            N.check(v.h, v.L.adder_hip_feature_halo_export(v.h, self.top[k].data_ptr(), self.bottom[k].data_ptr(), None))
+        self.torch.cuda.synchronize()
+        for k, v in enumerate(vs):
+            above = self.bottom[k - 1].data_ptr() if k > 0 else None
+            below = self.top[k + 1].data_ptr() if k + 1 < len(vs) else None
+            N.check(v.h, v.L.adder_hip_feature_halo_import(v.h, above, below, None))
+        counts = []
+        for k, v in enumerate(vs):
+            n = C.c_uint32(0)
+            N.check(v.h, v.L.adder_hip_feature_detect(v.h, self.lists[k].data_ptr(), self.lists[k].numel(), C.byref(n), None))
+            counts.append(n.value)
+        for k, v in enumerate(vs):
+            for j in range(len(vs)):
+                if j != k and counts[j]:
+                    N.check(v.h, v.L.adder_hip_feature_apply(v.h, self.lists[j].data_ptr(), counts[j], None))
+        self.torch.cuda.synchronize()
+        self.new_features = sum(counts)
+        return np.concatenate(out)

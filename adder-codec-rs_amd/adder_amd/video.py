@@ -48,6 +48,7 @@ class HipVideo:
             p.c_counter_start = c_counter_start
         self.params = p
         self.width, self.height, self.channels = width, height, channels
+        self.row_begin, self.row_end = int(p.row_begin), int(p.row_end)
         self.rows = p.row_end - p.row_begin
         self.n_units = self.rows * width * channels
         self.ref_time = ref_time

@@ -48,8 +48,12 @@ struct AdderHipCtx {
     uint8_t *state_slab = nullptr;  // hdr, lastf, status, integ0, dt0, bdt0 live in here
     size_t reset_bytes = 0;         // hdr .. status: one memset per reset
     size_t slab_bytes = 0;
-    uint8_t *running = nullptr;
+    uint8_t *running = nullptr;       // the context's own rows, inside running_base
+    uint8_t *running_base = nullptr;  // kFeatureHalo rows of the band above + the own rows (n_pad) + kFeatureHalo rows below
     bool running_enabled = false;
+    uint32_t *d_new_xy = nullptr;     // row-band feature mode: this frame's new features (x | plane y << 16)
+    uint32_t new_xy_cap = 0;
+    bool band_frame_pending = false;  // a frame's events await adder_hip_feature_detect
     // undo copy of the pixel state, taken before a batch whose event buffer is smaller than the batch's worst
     // case: an overflow then rolls the state back and the caller retries with the size reported
     struct Snapshot {
@@ -257,7 +261,7 @@ static void free_ctx(AdderHipCtx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->state_slab, c->dv_integ, c->dv_dt,
-                    c->dv_bdt,  c->dv_bd,   c->running,  c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
+                    c->dv_bdt,  c->dv_bd,   c->running_base, c->d_new_xy, c->cn_integ, c->cn_dt, c->cn_bdt, c->cn_meta,
                     c->snap.cn_integ, c->snap.cn_dt, c->snap.cn_bdt, c->snap.cn_meta,
                     c->d_offsets, c->d_frames, c->d_events, c->d_chunks, c->d_wire,
                     c->cth_px, c->cctr_px, c->fset, c->d_feat_counters, c->snap.cth_px, c->snap.cctr_px, c->snap.fset,
@@ -383,6 +387,16 @@ static void base_args(const AdderHipCtx *c, FrameArgs *a) {
     a->row_begin = c->p.row_begin;
 }
 
+static size_t halo_bytes(const AdderHipCtx *c) { return (size_t)kFeatureHalo * c->p.width * c->p.channels; }
+static int alloc_running(AdderHipCtx *c, hipStream_t s) {
+    if (c->running) return ADDER_OK;
+    const size_t bytes = c->n_pad + 2 * halo_bytes(c);
+    HIPCHK(c, dalloc(&c->running_base, bytes));
+    HIPCHK(c, hipMemsetAsync(c->running_base, 0, bytes, s));
+    c->running = c->running_base + halo_bytes(c);
+    return ADDER_OK;
+}
+
 // Video::new (video.rs:350-438): every pixel = PixelArena::new(1.0, coord): base_val 0,
 // c_thresh 10, counter 1, one pristine node (m = 0), last_fired_t 0, running_t 0.
 static int init_state(AdderHipCtx *c) {
@@ -402,7 +416,8 @@ static int init_state(AdderHipCtx *c) {
     } else {
         HIPCHK(c, hipMemsetAsync(c->state_slab, 0, c->reset_bytes, c->stream));  // hdr, last_fired_t, status
     }
-    if (c->running) HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+    if (c->running_base) HIPCHK(c, hipMemsetAsync(c->running_base, 0, c->n_pad + 2 * halo_bytes(c), c->stream));
+    c->band_frame_pending = false;
     c->c_thresh = p.c_thresh_start;
     c->c_counter = p.c_counter_start;
     c->generic_sticky = false;
@@ -648,20 +663,16 @@ static bool feature_path(const AdderHipCtx *c) { return c->feat_detect || c->roi
 static bool feature_needs_perpx(const AdderHipCtx *c) {
     return c->roi_on || (c->feat_detect && c->feat_adjust && c->feature_c_radius > 0);
 }
-static int whole_plane_only(AdderHipCtx *c, const char *what) {
-    if (c->continuous) return fail(c, ADDER_E_BAD_PARAMS, "%s: FramePerfect contexts only", what);
-    if (c->p.row_begin != 0 || c->p.row_end != c->p.height)
-        return fail(c, ADDER_E_BAD_PARAMS, "%s couples pixels across rows: the context must own the whole plane", what);
-    return ADDER_OK;
-}
+static bool is_band(const AdderHipCtx *c) { return c->p.row_begin != 0 || c->p.row_end != c->p.height; }
+// A row-band context (multi-GPU) in feature mode cannot finish a frame on its own: the corner test reads the three
+// rows beyond its band and the reset squares of its neighbours' new features reach into its rows.  It integrates ONE
+// frame per call and leaves the feature step to adder_hip_feature_detect, between the halo exchanges (include/adder_hip.h).
+static bool band_features(const AdderHipCtx *c) { return is_band(c) && (c->feat_detect || c->roi_on); }
 
 extern "C" int adder_hip_update_detect_features(AdderHipCtx *c, int detect_features, int feature_rate_adjustment) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
-    if (detect_features) {
-        int rc = whole_plane_only(c, "feature detection");
-        if (rc != ADDER_OK) return rc;
-    }
+    if (detect_features && c->continuous) return fail(c, ADDER_E_BAD_PARAMS, "feature detection: FramePerfect contexts only");
     c->feat_detect = detect_features != 0;
     c->feat_adjust = feature_rate_adjustment != 0;
     return ADDER_OK;
@@ -678,10 +689,7 @@ extern "C" int adder_hip_set_feature_parameters(AdderHipCtx *c, uint8_t c_thresh
 extern "C" int adder_hip_update_roi(AdderHipCtx *c, int enable, uint16_t x0, uint16_t y0, uint16_t x1, uint16_t y1) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
-    if (enable) {
-        int rc = whole_plane_only(c, "a region of interest");
-        if (rc != ADDER_OK) return rc;
-    }
+    if (enable && c->continuous) return fail(c, ADDER_E_BAD_PARAMS, "a region of interest: FramePerfect contexts only");
     c->roi_on = enable != 0;
     c->roi[0] = x0;
     c->roi[1] = y0;
@@ -740,6 +748,68 @@ static int prepare_per_unit_c_thresh(AdderHipCtx *c, hipStream_t s) {
         HIPCHK(c, hipMemsetAsync(c->cctr_px, c->c_counter, c->n_pad, s));
         c->perpx = true;
     }
+    return ADDER_OK;
+}
+
+static FeatureArgs feature_args(const AdderHipCtx *c);
+// ---- feature mode across row bands (SURVEY 8(f)4 "needs a halo exchange between row bands") ----
+extern "C" size_t adder_hip_feature_halo_bytes(const AdderHipCtx *c) { return c ? halo_bytes(c) : 0; }
+
+extern "C" int adder_hip_feature_halo_export(AdderHipCtx *c, uint8_t *d_top, uint8_t *d_bottom, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (!c->running) return fail(c, ADDER_E_BAD_PARAMS, "no running-intensities plane yet (integrate a frame in feature mode first)");
+    if (c->rows < kFeatureHalo) return fail(c, ADDER_E_BAD_PARAMS, "a band in feature mode needs at least %u rows", kFeatureHalo);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t hb = halo_bytes(c), rowlen = (size_t)c->p.width * c->p.channels;
+    if (d_top) HIPCHK(c, hipMemcpyAsync(d_top, c->running, hb, hipMemcpyDeviceToDevice, s));
+    if (d_bottom) HIPCHK(c, hipMemcpyAsync(d_bottom, c->running + (size_t)(c->rows - kFeatureHalo) * rowlen, hb, hipMemcpyDeviceToDevice, s));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_feature_halo_import(AdderHipCtx *c, const uint8_t *d_above, const uint8_t *d_below, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (!c->running) return fail(c, ADDER_E_BAD_PARAMS, "no running-intensities plane yet (integrate a frame in feature mode first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t hb = halo_bytes(c), rowlen = (size_t)c->p.width * c->p.channels;
+    if (d_above) HIPCHK(c, hipMemcpyAsync(c->running_base, d_above, hb, hipMemcpyDeviceToDevice, s));
+    if (d_below) HIPCHK(c, hipMemcpyAsync(c->running + (size_t)c->rows * rowlen, d_below, hb, hipMemcpyDeviceToDevice, s));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_feature_detect(AdderHipCtx *c, uint32_t *d_new_xy, uint32_t cap, uint32_t *n_new, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (n_new) *n_new = 0;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (!c->band_frame_pending) return fail(c, ADDER_E_BAD_PARAMS, "no frame awaits its feature step");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    FeatureArgs fa = feature_args(c);
+    fa.new_xy = d_new_xy;
+    fa.new_cap = d_new_xy ? cap : 0u;
+    HIPCHK(c, adder_launch_features(c->d_batch, 0u, &fa, s));
+    uint32_t cnt[2] = {0u, 0u};
+    HIPCHK(c, hipMemcpyAsync(cnt, c->d_feat_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->band_frame_pending = false;
+    c->last_new_features = cnt[0];
+    if (n_new) *n_new = cnt[0];
+    if (d_new_xy && cnt[0] > cap) return fail(c, ADDER_E_OUT_CAPACITY, "feature list too small: %u new features", cnt[0]);
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_feature_apply(AdderHipCtx *c, const uint32_t *d_xy, uint32_t n, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "a device batch is pending");
+    if (!d_xy && n) return fail(c, ADDER_E_BAD_PARAMS, "null feature list");
+    if (!c->perpx || n == 0) return ADDER_OK;  // no per-unit thresholds to reset (detection without rate adjustment)
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const FeatureArgs fa = feature_args(c);
+    HIPCHK(c, adder_launch_feature_apply(c->d_batch, &fa, d_xy, n, s));
     return ADDER_OK;
 }
 
@@ -901,8 +971,7 @@ static Lean1wArgs lean1w_args(const AdderHipCtx *c) {
 
 // Feature path: frame f+1's contrast thresholds depend on the features frame f's EVENTS reveal, so the whole
 // pipeline runs frame by frame: step, scan, offsets, expansion, features.
-static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s) {
-    const Lean1wArgs wide = lean1w_args(c);
+static FeatureArgs feature_args(const AdderHipCtx *c) {
     FeatureArgs fa{};
     fa.fset = c->fset;
     fa.counters = c->d_feat_counters;
@@ -915,12 +984,22 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
     fa.ry0 = c->roi[1];
     fa.rx1 = c->roi[2];
     fa.ry1 = c->roi[3];
+    fa.plane_h = c->p.height;
+    fa.new_xy = nullptr;
+    fa.new_cap = 0;
+    return fa;
+}
+
+static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s) {
+    const Lean1wArgs wide = lean1w_args(c);
+    const FeatureArgs fa = feature_args(c);
+    const bool band = band_features(c);  // the feature step waits for the halo exchange: adder_hip_feature_detect
     for (uint32_t f = 0; f < num_frames; ++f) {
         HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, s, &wide));
         HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, 0u, s));
-        HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
+        if (!band) HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
     }
     HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, s));
     return ADDER_OK;
@@ -1160,6 +1239,17 @@ static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
     return ADDER_OK;
 }
 
+// a row band in feature / ROI mode: refused before anything is queued (a caller's mistake, not a poisoned context)
+static int band_precheck(AdderHipCtx *c, uint32_t num_frames) {
+    if (!band_features(c)) return ADDER_OK;
+    if (num_frames > 1)
+        return fail(c, ADDER_E_BAD_PARAMS, "a row band in feature / ROI mode integrates one frame per call (the halo "
+                    "exchange and adder_hip_feature_detect come between the frames)");
+    if (c->band_frame_pending)
+        return fail(c, ADDER_E_BAD_PARAMS, "the previous frame's feature step is missing (adder_hip_feature_detect)");
+    return ADDER_OK;
+}
+
 // Queues `num_frames` frames on `stream`.
 static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
                           AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
@@ -1178,6 +1268,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const bool collapse = c->p.multi_mode == ADDER_MULTI_COLLAPSE;
     const bool sticky_before = c->generic_sticky;
     const bool fpath = feature_path(c);
+
     const bool generic = !c->continuous && (c->generic_sticky || c->perpx || feature_needs_perpx(c) ||
                                             !(collapse && (float)c->p.delta_t_max <= time_spanned));
     if (fpath) {  // the corner test reads the running intensities (video.rs:736-744)
@@ -1207,8 +1298,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // an event buffer below the batch's worst case can overflow: keep an undo copy of the state so that the
     // overflow is recoverable (adder_hip_finish rolls back and reports the size needed)
     if (c->running_enabled && !c->running) {
-        HIPCHK(c, dalloc(&c->running, c->n_pad));
-        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, c->stream));
+        int rc_ = alloc_running(c, c->stream);
+        if (rc_ != ADDER_OK) return rc_;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->snap.valid = false;
@@ -1345,6 +1436,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->c_thresh = cth;
     c->c_counter = cctr;
     c->frames_done += num_frames;
+    c->band_frame_pending = band_features(c);
     return ADDER_OK;
 }
 
@@ -1358,6 +1450,7 @@ extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frame
         return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight (call adder_hip_frame_collect)");
     if (!d_frames || !d_frame_offsets || (!d_out && out_cap)) return fail(c, ADDER_E_BAD_PARAMS, "null pointer");
     if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
+    { int rc_ = band_precheck(c, num_frames); if (rc_ != ADDER_OK) return rc_; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (num_frames == 0) {
@@ -1768,6 +1861,9 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
     if (c->f_submitted - c->f_collected >= c->f_slots)
         return fail(c, ADDER_E_BAD_PARAMS, "%u frames are in flight: call adder_hip_frame_collect first", c->f_slots);
+    if (band_features(c))
+        return fail(c, ADDER_E_BAD_PARAMS, "a row band in feature / ROI mode uses the blocking calls (its feature step "
+                    "needs the neighbours' halo between the frames)");
     const size_t rowlen = (size_t)c->p.width * c->p.channels;
     if (row_stride == 0) row_stride = rowlen;
     if (row_stride < rowlen) return fail(c, ADDER_E_BAD_PARAMS, "row_stride_bytes smaller than a row");
@@ -1872,7 +1968,7 @@ extern "C" int adder_hip_integrate(AdderHipCtx *c, const uint8_t *frame, size_t 
     // a buffer that holds the frame's worst case needs no rollback: submit + collect, the events sent straight
     // into `out` when the device can see it (adder_hip_alloc_pinned / hipHostRegister), else through a slot
     if (out && c->f_submitted == c->f_collected && !c->pending && c->submitted == c->collected && !c->poisoned &&
-        time_spanned >= 0.0f && out_cap >= worst_case_events_per_frame(c, time_spanned)) {
+        !band_features(c) && time_spanned >= 0.0f && out_cap >= worst_case_events_per_frame(c, time_spanned)) {
         void *dev = nullptr;
         const bool direct = device_visible_host(out, &dev);
         int rc = frame_submit_impl(c, frame, row_stride, time_spanned, direct ? (AdderEvent *)dev : nullptr, out_cap);
@@ -1999,8 +2095,8 @@ extern "C" int adder_hip_integrate_sparse_device(AdderHipCtx *c, const AdderSpar
     int rc = sparse_prepare(c, n, s);
     if (rc != ADDER_OK) return rc;
     if (c->running_enabled && !c->running) {
-        HIPCHK(c, dalloc(&c->running, c->n_pad));
-        HIPCHK(c, hipMemsetAsync(c->running, 0, c->n_pad, s));
+        int rc_ = alloc_running(c, s);
+        if (rc_ != ADDER_OK) return rc_;
     }
     const SparseArgs a = sparse_args(c);
     AdderHipCtx::SparseWork &w = c->sw;

@@ -235,7 +235,14 @@ struct FeatureArgs {
     uint32_t radius;      // feature_c_radius if feature_rate_adjustment, else 0
     uint32_t low;         // min(c_thresh_baseline, 2)
     uint32_t roi_on, rx0, ry0, rx1, ry1;  // Roi {start, end}, inclusive, plane coordinates
+    // row-band contexts (multi-GPU): the running-intensities plane carries kFeatureHalo rows of the neighbouring bands
+    // above and below the context's own rows (adder_hip_feature_halo_import), the corner test runs in PLANE coordinates,
+    // and the new features are also listed (x | plane y << 16) so that the neighbours can reset THEIR rows around them
+    uint32_t plane_h;     // PlaneSize height
+    uint32_t *new_xy;     // list of this frame's new features, or nullptr
+    uint32_t new_cap;     // its capacity; counters[1] counts the entries
 };
+constexpr uint32_t kFeatureHalo = 3;  // rows the FAST 9_16 ring reaches over (adder_pixel.hpp kFastBorder)
 
 __device__ __forceinline__ FrameArgs frame_args(const BatchArgs *b, uint32_t f) {
     FrameArgs a = b->base;
@@ -293,6 +300,9 @@ hipError_t adder_launch_frame_out(const adder::AdderEventPod *d_ev, const uint64
 // around the new ones, ROI (video.rs:865-1112)
 hipError_t adder_launch_features(const adder::BatchArgs *b, uint32_t f, const adder::FeatureArgs *fa,
                                  hipStream_t stream);
+// the c_thresh resets around features found by OTHER row bands (x | plane y << 16), clipped to this band's rows
+hipError_t adder_launch_feature_apply(const adder::BatchArgs *b, const adder::FeatureArgs *fa, const uint32_t *xy, uint32_t n,
+                                      hipStream_t stream);
 hipError_t adder_launch_synth(uint8_t *dst, int content, uint64_t seed, uint32_t W, uint32_t H, uint32_t C,
                               uint32_t y0, uint32_t rows, uint32_t k0, uint32_t nframes, hipStream_t stream);
 }

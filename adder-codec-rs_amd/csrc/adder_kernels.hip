@@ -1864,6 +1864,16 @@ __device__ __forceinline__ void feature_fill_rect(uint8_t *cth, uint32_t width, 
     }
 }
 
+// the clamped square of radius r around plane pixel (fx, fy), cut to the context's rows [row_begin, row_begin + rows)
+__device__ __forceinline__ void feature_reset_around(const FrameArgs &a, const FeatureArgs &fa, uint32_t rows, uint32_t fx,
+                                                     uint32_t fy, uint32_t lane) {
+    const uint32_t x0 = fx > fa.radius ? fx - fa.radius : 0u, x1 = min(fx + fa.radius, a.width - 1u);
+    const uint32_t gy0 = max(fy > fa.radius ? fy - fa.radius : 0u, a.row_begin);
+    const uint32_t gy1 = min(min(fy + fa.radius, fa.plane_h - 1u), a.row_begin + rows - 1u);
+    if (gy0 > gy1) return;
+    feature_fill_rect(a.cth_px, a.width, a.channels, x0, gy0 - a.row_begin, x1, gy1 - a.row_begin, fa.low, lane);
+}
+
 __global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const BatchArgs *__restrict__ b, uint32_t f,
                                                                       const FeatureArgs fa) {
     const FrameArgs &a = b->base;
@@ -1875,17 +1885,21 @@ __global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const Batc
         uint64_t end = a.frame_offsets[f + 1];
         if (end > a.out_cap) end = a.out_cap;  // the overflow is on record in the status word
         const AdderEventPod *const ev = a.out;
+        // the running intensities in PLANE coordinates: row y of the plane at img + y * rowlen.  A band context only
+        // holds rows [row_begin - 3, row_begin + rows + 3) of it (its own and the neighbours' halo); the corner test
+        // reads rows y - 3 .. y + 3 of a pixel that is not within 3 pixels of the PLANE's border (cv.rs:57).
+        const uint8_t *const img = a.running - (size_t)a.row_begin * a.rowlen;
         for (uint64_t base = begin + (uint64_t)wave * kWave; base < end; base += (uint64_t)nwaves * kWave) {
             const uint64_t i = base + lane;
             bool is_new = false;
-            uint32_t x = 0, y = 0;
+            uint32_t x = 0, gy = 0;
             if (i < end) {
                 x = ev[i].x;
-                y = ev[i].y - a.row_begin;
+                gy = ev[i].y;
                 const bool look = feature_looked_at(ev, begin, end, i, a.row_begin, fa.chunk_rows);
                 if (look) {
-                    uint8_t *member = fa.fset + (size_t)y * a.width + x;
-                    if (fast9_is_feature(a.running, a.width, rows, a.channels, x, y)) {
+                    uint8_t *member = fa.fset + (size_t)(gy - a.row_begin) * a.width + x;
+                    if (fast9_is_feature(img, a.width, fa.plane_h, a.channels, x, gy)) {
                         is_new = *member == 0u;
                         *member = 1u;
                     } else {
@@ -1894,15 +1908,23 @@ __global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const Batc
                 }
             }
             uint64_t m = __ballot(is_new);
-            if (m != 0ull && lane == 0) atomicAdd(fa.counters, (uint32_t)__popcll(m));
+            if (m != 0ull) {
+                uint32_t list_base = 0u;
+                if (lane == 0) {
+                    atomicAdd(fa.counters, (uint32_t)__popcll(m));
+                    if (fa.new_xy) list_base = atomicAdd(fa.counters + 1, (uint32_t)__popcll(m));
+                }
+                if (fa.new_xy) {
+                    list_base = __builtin_amdgcn_readfirstlane(list_base);
+                    const uint32_t slot = list_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (is_new && slot < fa.new_cap) fa.new_xy[slot] = x | (gy << 16);
+                }
+            }
             if (fa.radius != 0u) {
                 while (m != 0ull) {
                     const uint32_t src = (uint32_t)__builtin_ctzll(m);
                     m &= m - 1ull;
-                    const uint32_t fx = __builtin_amdgcn_readlane(x, src), fy = __builtin_amdgcn_readlane(y, src);
-                    const uint32_t x0 = fx > fa.radius ? fx - fa.radius : 0u, y0 = fy > fa.radius ? fy - fa.radius : 0u;
-                    const uint32_t x1 = min(fx + fa.radius, a.width - 1u), y1 = min(fy + fa.radius, rows - 1u);
-                    feature_fill_rect(a.cth_px, a.width, a.channels, x0, y0, x1, y1, fa.low, lane);
+                    feature_reset_around(a, fa, rows, __builtin_amdgcn_readlane(x, src), __builtin_amdgcn_readlane(gy, src), lane);
                 }
             }
         }
@@ -1913,6 +1935,20 @@ __global__ __launch_bounds__(kBlockThreads) void adder_feature_kernel(const Batc
         if (fa.rx0 <= x1)
             for (uint32_t y = y_lo + wave; y <= y_hi && y_lo <= y_hi; y += nwaves)
                 feature_fill_rect(a.cth_px, a.width, a.channels, fa.rx0, y - a.row_begin, x1, y - a.row_begin, fa.low, lane);
+    }
+}
+
+// features found by the other row bands this frame: their reset squares reach into this band's rows
+__global__ __launch_bounds__(kBlockThreads) void adder_feature_apply_kernel(const BatchArgs *__restrict__ b, const FeatureArgs fa,
+                                                                            const uint32_t *__restrict__ xy, uint32_t n) {
+    const FrameArgs &a = b->base;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave, nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t rows = a.n_units / a.rowlen;
+    if (fa.radius == 0u) return;
+    for (uint32_t i = wave; i < n; i += nwaves) {
+        const uint32_t w = xy[i];
+        feature_reset_around(a, fa, rows, w & 0xffffu, w >> 16, lane);
     }
 }
 
@@ -2223,6 +2259,13 @@ extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const ui
 
 extern "C" hipError_t adder_launch_features(const BatchArgs *b, uint32_t f, const FeatureArgs *fa, hipStream_t stream) {
     hipLaunchKernelGGL(adder_feature_kernel, dim3(512), dim3(kBlockThreads), 0, stream, b, f, *fa);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_feature_apply(const BatchArgs *b, const FeatureArgs *fa, const uint32_t *xy, uint32_t n,
+                                                 hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(adder_feature_apply_kernel, dim3(64), dim3(kBlockThreads), 0, stream, b, *fa, xy, n);
     return hipGetLastError();
 }
 

@@ -112,8 +112,9 @@ int adder_hip_reset_c_thresh(AdderHipCtx *ctx, uint8_t c_thresh_baseline);
  * and a radius > 0 -- every pixel within feature_c_radius of a NEW feature gets c_thresh = min(c_thresh_baseline,
  * 2) (:1089-1105); handle_roi (:866-882) does the same for the region of interest after every frame.  From then
  * on c_thresh differs between pixels, so the context switches (until adder_hip_reset / adder_hip_reset_c_thresh) to
- * the generic kernels with one (c_thresh, c_increase_counter) pair per pixel, and steps frame by frame.  The
- * context must own the whole plane (row_begin = 0, row_end = height).
+ * the generic kernels with one (c_thresh, c_increase_counter) pair per pixel, and steps frame by frame.  A context
+ * that owns the whole plane does all of it inside the integrate call; a ROW BAND (multi-GPU) follows the protocol of
+ * adder_hip_feature_detect below.
  * Video::update_detect_features (video.rs:825-837; show_features / feature_cluster only drive displays): */
 int adder_hip_update_detect_features(AdderHipCtx *ctx, int detect_features, int feature_rate_adjustment);
 /* CrfParameters::{c_thresh_baseline, feature_c_radius} (rate_controller.rs:40-53; update_quality_manual
@@ -122,6 +123,25 @@ int adder_hip_set_feature_parameters(AdderHipCtx *ctx, uint8_t c_thresh_baseline
 /* Video::update_roi (video.rs:1291-1293); Roi {start, end} inclusive, plane coordinates. */
 int adder_hip_update_roi(AdderHipCtx *ctx, int enable, uint16_t start_x, uint16_t start_y, uint16_t end_x,
                          uint16_t end_y);
+/* ---- Feature mode across row bands ("needs a halo exchange between row bands").  The corner test at a
+ * pixel reads 3 rows above and below it, and the reset square around a NEW feature (radius feature_c_radius) reaches
+ * into the neighbouring bands.  A band context in feature / ROI mode therefore integrates ONE frame per call and leaves
+ * the feature step of video.rs:744-778 to the caller's per-frame exchange:
+ *   1. adder_hip_integrate / _integrate_device (one frame) on every band: the frame's events; running intensities updated;
+ *   2. adder_hip_feature_halo_export on every band -> its first / last 3 rows (adder_hip_feature_halo_bytes each, device
+ *      memory); ship them to the band above / below (peer copy, RCCL send/recv) and hand them to
+ *      adder_hip_feature_halo_import (d_above = the upper neighbour's bottom rows, d_below = the lower neighbour's top);
+ *   3. adder_hip_feature_detect on every band: the corner tests at its own events' pixels in plane coordinates, its
+ *      part of VideoState::features, the resets inside its own rows, the ROI; the frame's new features come back as a
+ *      device list of x | plane_y << 16 (n_new of them);
+ *   4. adder_hip_feature_apply on every band with the OTHER bands' lists: their reset squares cut to this band's rows.
+ * The bands together then hold exactly the state of one whole-plane context (tests: two and three bands on one device
+ * against the whole plane and the oracle).  Every reset writes the same value, so the order of 3 and 4 across bands is free. */
+size_t adder_hip_feature_halo_bytes(const AdderHipCtx *ctx);
+int adder_hip_feature_halo_export(AdderHipCtx *ctx, uint8_t *d_top_rows, uint8_t *d_bottom_rows, void *stream);
+int adder_hip_feature_halo_import(AdderHipCtx *ctx, const uint8_t *d_above, const uint8_t *d_below, void *stream);
+int adder_hip_feature_detect(AdderHipCtx *ctx, uint32_t *d_new_xy, uint32_t cap, uint32_t *n_new, void *stream);
+int adder_hip_feature_apply(AdderHipCtx *ctx, const uint32_t *d_xy, uint32_t n, void *stream);
 /* VideoState::features as a membership plane: dst = [rows][width] bytes, 1 = the pixel is a feature. */
 int adder_hip_feature_set(AdderHipCtx *ctx, uint8_t *dst);
 /* every pixel's c_thresh as the NEXT frame will test it: dst = [rows][width][channels] bytes */

@@ -939,11 +939,15 @@ def test_features_at_1080p_default_radius():
 @pytest.mark.gpu
 def test_feature_path_errors_and_rollback():
     A = _hip()
+    # a row band takes the mode, but one frame per call and with the per-frame halo protocol
     band = A.HipVideo(64, 48, 1, row_begin=8, row_end=40)
-    with pytest.raises(A.AdderHipError):
-        band.update_detect_features(True, True)
-    with pytest.raises(A.AdderHipError):
-        band.update_roi((1, 1, 5, 5))
+    band.update_detect_features(True, True)
+    with pytest.raises(A.AdderHipError, match="one frame per call"):
+        band.integrate_batch(np.zeros((3, 32, 64), np.uint8))
+    band.integrate_matrix(np.zeros((32, 64), np.uint8))
+    with pytest.raises(A.AdderHipError, match="feature step is missing"):
+        band.integrate_matrix(np.zeros((32, 64), np.uint8))
+    band.close()
     cont = A.HipVideo(64, 48, 1, pixel_mode=1)
     with pytest.raises(A.AdderHipError):
         cont.update_detect_features(True, False)
@@ -1329,3 +1333,47 @@ def test_model_fixtures_on_the_gpu(golden_dir):
         assert counts == list(cs["counts"]), k
         assert np.array_equal(got, cs["events"]), k
         hv.close()
+
+
+@pytest.mark.parametrize("bands", [2, 3])
+@pytest.mark.parametrize("channels", [1, 3])
+def test_feature_mode_over_row_bands_matches_the_whole_plane(bands, channels):
+    """SURVEY 8(f)4, the multi-GPU half: band contexts exchange a 3-row halo of the running intensities and the list of
+    each frame's new features (whose reset squares reach into the neighbours' rows) -- sharding.FeatureBands drives
+    adder_hip_feature_halo_export / _import / _detect / _apply.  Two and three bands on one device must produce the
+    whole-plane context's events, feature set, per-pixel thresholds and new-feature counts, which equal the
+    oracle's; a radius larger than a band and an ROI that straddles the band edges are part of it."""
+    A = _hip()
+    from adder_amd import sharding
+    H, W = 61, 83
+    clip = clips.make_clip("corners", 30, H, W, channels, seed=31 + bands)
+    for radius, roi in ((3, None), (25, (5, 17, 70, 44))):
+        ov, whole = _feature_pair(A, W, H, channels, multi_mode=O.COLLAPSE, dtm=7650, radius=radius, roi=roi)
+        vids = []
+        for y0, y1 in sharding.row_bands(H, bands):
+            v = A.HipVideo(W, H, channels, row_begin=y0, row_end=y1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE,
+                           ref_time=255, delta_t_max=7650, max_depth=30)
+            v.set_crf_parameters(13, 4)
+            v.reset_c_thresh(6)
+            v.update_detect_features(True, True)
+            v.set_feature_parameters(6, radius)
+            v.update_roi(roi)
+            vids.append(v)
+        fb = sharding.FeatureBands(vids)
+        total_new = 0
+        for k in range(len(clip)):
+            want = ov.integrate_matrix(clip[k])
+            ref = whole.integrate_matrix(clip[k])
+            got = fb.integrate_matrix(clip[k])
+            assert np.array_equal(ref, want), k
+            assert len(got) == len(want) and np.array_equal(got, want), (bands, radius, k)
+            assert fb.new_features == len(ov.new_features()) == whole.last_new_features(), k
+            total_new += fb.new_features
+            if k % 5 == 4:
+                cth = np.concatenate([v.c_thresh_plane().reshape(-1) for v in vids])
+                assert np.array_equal(cth, ov.c_thresh_plane().reshape(-1)), k
+                fset = np.concatenate([v.feature_set().reshape(-1) for v in vids])
+                assert np.array_equal(fset, ov.feature_set().reshape(-1)), k
+        assert total_new > 10
+        for v in vids + [whole]:
+            v.close()
