@@ -1067,12 +1067,18 @@ ADDER_HD bool cont_integrate_main(ANode &n, float intensity, float time, float &
 
 // integrate_for_px (video.rs:1318-1380) with pixel_tree_mode = Continuous.  `max_nodes` = nodes the arena may
 // hold; returns false if it needed more.
+// `kind` selects the parts of the step a source runs (AdderSparseStep::pad): 0 = all of integrate_for_px; the DAVIS
+// source (davis.rs:331-395) integrates the OLD intensity over the gap first (kSparseIntegrateOnly) and then tests the
+// NEW value against base_val without integrating it (kSparseTestOnly); at the end of its input every pixel is flushed
+// (kSparseFlush: pop_best_events alone, davis.rs:654-661).
+constexpr uint32_t kSparseNoSide = 1u, kSparseIntegrateOnly = 2u, kSparseTestOnly = 4u, kSparseFlush = 8u;
 template <bool ABS_T, class Acc, class Emit>
 ADDER_HD bool cont_step(APx &s, Acc &acc, uint32_t v, float intensity, float time, const StepConsts &sc,
-                        uint32_t max_nodes, Emit &emit) {
+                        uint32_t max_nodes, Emit &emit, uint32_t kind = 0u) {
     bool ok = true;
+    const bool flush_only = (kind & kSparseFlush) != 0u;
     // ---- pop_best_events (:213-287) + set_d_for_continuous (:289-312) ----
-    if (contrast_exceeded(v, s.base, sc.cth)) {
+    if (flush_only || (!(kind & kSparseIntegrateOnly) && contrast_exceeded(v, s.base, sc.cth))) {
         const bool collapsed = s.popped && sc.collapse;
         uint32_t count = 0, first_d = 0, first_t = 0;
         for (uint32_t k = 0; k < s.length; ++k) {
@@ -1113,17 +1119,20 @@ ADDER_HD bool cont_step(APx &s, Acc &acc, uint32_t v, float intensity, float tim
         }
         s.length = 1u;
         s.popped = false;
-        s.base = v;
-        ANode r = acc.load(0);
-        const uint32_t next_d = get_d(intensity);
-        if (next_d < r.d && r.dt > 0.0f) {
-            emit(kDEmpty, cont_event_time<ABS_T>(r.dt, s.lastf));
-            r.dt = 0.0f;
-            r.integ = 0.0f;
+        if (!flush_only) {
+            s.base = v;
+            ANode r = acc.load(0);
+            const uint32_t next_d = get_d(intensity);
+            if (next_d < r.d && r.dt > 0.0f) {
+                emit(kDEmpty, cont_event_time<ABS_T>(r.dt, s.lastf));
+                r.dt = 0.0f;
+                r.integ = 0.0f;
+            }
+            r.d = next_d;
+            acc.store(0, r);
         }
-        r.d = next_d;
-        acc.store(0, r);
     }
+    if (kind & (kSparseTestOnly | kSparseFlush)) return ok;
     // ---- integrate (:317-413) ----
     {
         ANode tail = acc.load(s.length - 1u);

@@ -103,11 +103,13 @@ __global__ __launch_bounds__(256) void adder_sparse_run_kernel(const SparseStep 
         sc.running_t_u32 = f32_as_u32(rt);
         sc.cth = cth;
         SparseEmit em{stage + (size_t)k * a.stage_events, 0u, a.stage_events};
-        const bool ok = cont_step<ABS_T>(s, acc, st.frame_val, st.intensity, st.time, sc, a.max_nodes, em);
+        const bool ok = cont_step<ABS_T>(s, acc, st.frame_val, st.intensity, st.time, sc, a.max_nodes, em, st.pad);
         bad = bad || !ok || em.n > em.cap;
         count[k] = em.n < em.cap ? em.n : em.cap;
-        rt += st.time;  // `self.running_t += time` (event_pixel_tree.rs:336)
-        c_thresh_advance(cth, cctr, (uint8_t)a.c_max, (uint8_t)a.c_vel, st.time, sc.ref_time);
+        if (!(st.pad & (kSparseTestOnly | kSparseFlush))) {  // (both advance inside PixelArena::integrate)
+            rt += st.time;  // `self.running_t += time` (event_pixel_tree.rs:336)
+            c_thresh_advance(cth, cctr, (uint8_t)a.c_max, (uint8_t)a.c_vel, st.time, sc.ref_time);
+        }
         // side plane (prophesee.rs:259-283): sampled once per CAMERA event, after its last integrate_for_px call --
         // a step flagged ADDER_SPARSE_NO_SIDE (the first of a camera event's two, or an end_events step) is not sampled
         if (a.running && !(st.pad & 1u)) {

@@ -660,6 +660,189 @@ void Prophesee::end_events() {  // :332-372: every pixel's last intensity up to 
     last_end_events_ = video_.integrate_sparse(steps);
 }
 
+// ---------------------------------------------------------------- Davis
+static void clamp_u8(double &frame_val, double &last_val_ln) {  // utils/cv.rs:432-440
+    if (frame_val <= 0.0) {
+        frame_val = 0.0;
+        last_val_ln = std::log1p(0.0);
+    } else if (frame_val > 255.0) {
+        frame_val = 255.0;
+        last_val_ln = std::log1p(1.0);
+    }
+}
+
+Davis::Davis(uint16_t width, uint16_t height, TranscoderMode mode, std::function<bool(DavisPacket &)> next_packet, int device_id)
+    : next_packet_(std::move(next_packet)),
+      video_(PlaneSize(width, height, 1), nullptr, device_id, mode == TranscoderMode::Framed ? Mode::FramePerfect : Mode::Continuous),
+      mode_(mode) {
+    if (height % 4 != 0) throw SourceError(SourceError::BadParams, "Davis: the height must be a multiple of 4");
+    video_.chunk_rows(height / 4);
+    dvs_last_timestamps_.assign(video_.plane().volume(), 0);
+    dvs_last_ln_val_.assign(video_.plane().volume(), 0.0);
+}
+
+double Davis::get_running_input_bitrate() const {
+    const double volume = (double)video_.plane().volume();
+    if (mode_ == TranscoderMode::Framed)
+        return volume * 8.0 * ((double)video_.get_tps() / (ref_time_divisor_ * (double)video_.get_ref_time()));
+    const double time_mult = 1e6 / time_change_;
+    const double event_bits = (double)num_dvs_events_ * time_mult * 9.0 * 8.0;
+    return mode_ == TranscoderMode::RawDavis ? event_bits + time_mult * volume * 8.0 : event_bits;
+}
+
+// :233-466.  The events of the four row chunks are handled chunk after chunk, each in arrival order (:254-258, the
+// rayon map is collected in chunk order); per event that passes the checks: the pixel's OLD intensity over the time
+// since its last event (no contrast test), then the NEW value against base_val without integrating it.
+std::vector<Event> Davis::integrate_dvs_events(const std::vector<DavisDvsEvent> &ev, int64_t frame_timestamp, bool check2_after,
+                                               bool has_ts2, int64_t frame_timestamp_2) {
+    const size_t W = video_.plane().w(), H = video_.plane().h();
+    const size_t chunk_h = H / 4;
+    const float ticks_per_micro = (float)video_.get_tps() / 1e6f;
+    const float ref_time_f = (float)video_.get_ref_time();
+    std::vector<AdderSparseStep> steps;
+    steps.reserve(ev.size() * 2);
+    for (size_t chunk = 0; chunk < 4; ++chunk)
+        for (const DavisDvsEvent &e : ev) {
+            if (e.x >= W || e.y >= H) throw SourceError(SourceError::BadParams, "DVS event outside the plane");
+            if (e.y / chunk_h != chunk) continue;
+            // "Ignore events occuring during the deblurred frame's effective exposure time" (:287-294)
+            if (!(e.t < frame_timestamp)) continue;  // check_dvs_before
+            if (has_ts2 && !(check2_after ? e.t > frame_timestamp_2 : e.t < frame_timestamp_2)) continue;
+            const size_t px = (size_t)e.y * W + e.x;
+            double &last_val_ln = dvs_last_ln_val_[px];
+            const double last_val = (std::exp(last_val_ln) - 1.0) * 255.0;
+            const int64_t delta_t_micro = e.t - dvs_last_timestamps_[px];
+            if (delta_t_micro == e.t) continue;
+            const float delta_t_ticks = (float)delta_t_micro * ticks_per_micro;
+            if (delta_t_ticks < 0.0f) continue;
+            const float first_integration = std::max((float)last_val / ref_time_f * delta_t_ticks, 0.0f);
+            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, 0, ADDER_SPARSE_NO_SIDE | ADDER_SPARSE_INTEGRATE_ONLY,
+                                            first_integration, delta_t_ticks});
+            last_val_ln *= std::exp(e.on ? dvs_c_ : -dvs_c_);
+            double frame_val = (std::exp(last_val_ln) - 1.0) * 255.0;
+            clamp_u8(frame_val, last_val_ln);
+            steps.push_back(AdderSparseStep{e.x, e.y, ADDER_C_NONE, f64_as_u8(frame_val), ADDER_SPARSE_NO_SIDE | ADDER_SPARSE_TEST_ONLY,
+                                            (float)frame_val, 0.0f});
+            dvs_last_timestamps_[px] = e.t;
+        }
+    return video_.integrate_sparse(steps);
+}
+
+// :468-598 -- every pixel's last intensity over the time from its last event to the start of the frame
+std::vector<Event> Davis::integrate_frame_gaps() {
+    if (!have_start_) throw SourceError(SourceError::Codec, "UninitializedData");
+    const size_t W = video_.plane().w(), H = video_.plane().h();
+    const float ticks_per_micro = (float)video_.get_tps() / 1e6f;
+    std::vector<AdderSparseStep> steps;
+    steps.reserve(W * H);
+    for (size_t y = 0; y < H; ++y)
+        for (size_t x = 0; x < W; ++x) {
+            const size_t px = y * W + x;
+            double last_val = (std::exp(dvs_last_ln_val_[px]) - 1.0) * 255.0;
+            clamp_u8(last_val, dvs_last_ln_val_[px]);
+            const int64_t delta_t_micro = start_of_frame_timestamp_ - dvs_last_timestamps_[px];
+            if (delta_t_micro == start_of_frame_timestamp_) continue;
+            const float delta_t_ticks = (float)delta_t_micro * ticks_per_micro;
+            if (delta_t_ticks <= 0.0f) continue;
+            const double integration = std::max((last_val / (double)video_.get_ref_time()) * (double)delta_t_ticks, 0.0);
+            steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, f64_as_u8(last_val), 0, (float)integration,
+                                            delta_t_ticks});
+        }
+    return video_.integrate_sparse(steps);
+}
+
+std::vector<std::vector<Event>> Davis::consume() {
+    const bool with_events = mode_ != TranscoderMode::Framed;
+    const size_t W = video_.plane().w(), H = video_.plane().h(), n = W * H;
+    std::vector<std::vector<Event>> ret;
+    auto log = [&](const std::vector<Event> &v) { ingested_.insert(ingested_.end(), v.begin(), v.end()); };
+    if (have_cached_) {
+        have_cached_ = false;
+        if (cached_end_) {  // :641-667 "We've reached the end of the input. Forcibly pop the last event from each pixel."
+            if (mode_ != TranscoderMode::Framed) {
+                std::vector<AdderSparseStep> steps;
+                steps.reserve(n);
+                for (size_t y = 0; y < H; ++y)
+                    for (size_t x = 0; x < W; ++x)
+                        steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, 0,
+                                                        ADDER_SPARSE_NO_SIDE | ADDER_SPARSE_FLUSH, 0.0f, 0.0f});
+                log(video_.integrate_sparse(steps));
+            }
+            throw SourceError(SourceError::NoData, "End of input");
+        }
+        DavisPacket pk = std::move(cached_);
+        if (pk.frame.size() != n) throw SourceError(SourceError::BadParams, "Davis: a frame of the wrong size");
+        if (pk.has_events) {  // :668-699
+            time_change_ = (double)(pk.img_start_ts - (have_start_ ? start_of_frame_timestamp_ : 0));
+            num_dvs_events_ = pk.events_before.size() + pk.events_after.size();
+            start_of_frame_timestamp_ = pk.img_start_ts;
+            end_of_frame_timestamp_ = pk.img_end_ts;
+            have_start_ = have_end_ = true;
+            if (mode_ == TranscoderMode::RawDvs) end_of_frame_timestamp_ = pk.img_start_ts + 1;
+            dvs_c_ = pk.c;
+            events_before_ = std::move(pk.events_before);
+            events_after_ = std::move(pk.events_after);
+            ref_time_divisor_ = (double)(pk.img_end_ts - pk.img_start_ts) / (double)video_.get_ref_time();
+        }
+        const int64_t start_ts = have_start_ ? start_of_frame_timestamp_ : 0;
+        const int64_t end_ts = have_end_ ? end_of_frame_timestamp_ : (int64_t)video_.get_ref_time();
+        if (temp_first_frame_start_timestamp_ == 0) temp_first_frame_start_timestamp_ = start_ts;
+        if (with_events) {
+            // (VideoState::in_interval_count starts at 1 and only grows, video.rs:231,662: the "very beginning" arm of
+            // :722-728 is dead; the pixels' last timestamps are 0 until the first frame and every event before it is skipped)
+            if (have_last_after_ && have_end_of_last_)
+                log(integrate_dvs_events(events_last_after_, start_ts, true, mode_ != TranscoderMode::RawDvs,
+                                         end_of_last_frame_timestamp_));
+            log(integrate_dvs_events(events_before_, start_ts, false, false, 0));
+            log(integrate_frame_gaps());
+        }
+        // :775-838 -- convert_to(CV_8U, 255.0): saturate_cast<uchar>(cvRound(v * 255)), round half to even
+        Frame image_8u(n);
+        for (size_t i = 0; i < n; ++i) {
+            const double v = std::nearbyint(pk.frame[i] * 255.0);
+            image_8u[i] = (uint8_t)(v <= 0.0 ? 0.0 : (v >= 255.0 ? 255.0 : v));
+        }
+        float mat_integration_time = (float)video_.get_ref_time();
+        if (mode_ == TranscoderMode::RawDavis) mat_integration_time = (float)(end_ts - start_ts);
+        if (mode_ == TranscoderMode::RawDvs) {
+            dvs_c_ = 0.15;
+            std::fill(image_8u.begin(), image_8u.end(), 0);
+            mat_integration_time = 0.0f;
+        }
+        if (mode_ == TranscoderMode::Framed) {
+            ret = video_.integrate_matrix(image_8u, mat_integration_time);
+            for (auto &v : ret) log(v);
+        } else {
+            // the frame as one integrate_for_px per pixel in raster order (video.rs:697-731): a context that has taken
+            // sparse steps keeps c_thresh, its counter and running_t per pixel
+            std::vector<AdderSparseStep> steps;
+            steps.reserve(n);
+            for (size_t y = 0; y < H; ++y)
+                for (size_t x = 0; x < W; ++x)
+                    steps.push_back(AdderSparseStep{(uint16_t)x, (uint16_t)y, ADDER_C_NONE, image_8u[y * W + x], 0,
+                                                    (float)image_8u[y * W + x], mat_integration_time});
+            const std::vector<Event> ev = video_.integrate_sparse(steps);
+            log(ev);
+            const size_t chunk_rows = video_.get_chunk_rows();
+            ret.assign((H + chunk_rows - 1) / chunk_rows, {});
+            for (const Event &e : ev) ret[e.y / chunk_rows].push_back(e);
+        }
+        for (size_t i = 0; i < n; ++i)  // :840-864
+            dvs_last_ln_val_[i] = mode_ == TranscoderMode::RawDvs ? std::log1p(0.5) : std::log1p(pk.frame[i]);
+        if (with_events) {
+            events_last_after_ = events_after_;
+            have_last_after_ = true;
+            end_of_last_frame_timestamp_ = end_ts;
+            have_end_of_last_ = have_end_;
+            std::fill(dvs_last_timestamps_.begin(), dvs_last_timestamps_.end(), end_ts);
+        }
+    }
+    cached_ = DavisPacket();
+    cached_end_ = !next_packet_(cached_);  // (the reference fetches on a thread while it integrates)
+    have_cached_ = true;
+    return ret;
+}
+
 // ---------------------------------------------------------------- Framed
 Frame handle_color(const Frame &input, uint32_t width, uint32_t height, uint32_t channels, bool color) {
     if (color || channels == 1) return input;

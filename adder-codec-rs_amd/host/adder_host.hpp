@@ -348,6 +348,65 @@ class Prophesee : public Source {
     double camera_theta_ = 0.02;  // "A fixed assumption" (:107)
 };
 
+// ---------------------------------------------------------------- Davis (transcoder/source/davis.rs)
+// The DAVIS source interleaves deblurred APS frames with the DVS events between them.  Its input is what the EDI
+// reconstructor (the un-vendored davis-edi-rs crate: file parsing + deblurring, not part of this path) hands out per
+// `next()`: a frame of f64 intensities in [0, 1] and, in the raw modes, the DVS events before and after the frame's
+// exposure with its start / end timestamps (in microseconds) and the contrast threshold c.
+struct DavisDvsEvent {
+    int64_t t;
+    uint16_t x, y;
+    bool on;
+};
+struct DavisPacket {                       // davis-edi-rs IterVal
+    std::vector<double> frame;             // [h][w]
+    bool has_events = false;               // Some((c, events_before, events_after, img_start_ts, img_end_ts))
+    double c = 0.15;
+    std::vector<DavisDvsEvent> events_before, events_after;
+    int64_t img_start_ts = 0, img_end_ts = 0;
+};
+enum class TranscoderMode { Framed, RawDavis, RawDvs };  // davis.rs:41-50
+class Davis : public Source {
+  public:
+    // ::new :109-177 -- Video::new(plane, FramePerfect | Continuous, None).chunk_rows(h / 4); `next_packet` stands for
+    // reconstructor.next(with_events): false at the end of the input.  The plane's height must be a multiple of 4 (the
+    // reference indexes four event chunks by y / (h / 4), :254-258).
+    Davis(uint16_t width, uint16_t height, TranscoderMode mode, std::function<bool(DavisPacket &)> next_packet,
+          int device_id = -1);
+    // :601-897 -- the frame's events; the first call only fetches (the reference keeps one packet cached); throws
+    // SourceError::NoData after the last pixel flush at the end of the input
+    std::vector<std::vector<Event>> consume() override;
+    void crf(uint8_t crf) override { video_.update_crf(crf); }
+    Video &get_video_mut() override { return video_; }
+    const Video &get_video_ref() const override { return video_; }
+    const Frame *get_input() const override { return nullptr; }
+    double get_running_input_bitrate() const override;  // :917-941
+    // every event the source fed to the encoder, in order (DVS events, frame gaps, frames, the final flush): the
+    // reference returns only the frames' events from consume() and ingests the others itself
+    const std::vector<Event> &ingested() const { return ingested_; }
+
+  private:
+    std::vector<Event> integrate_dvs_events(const std::vector<DavisDvsEvent> &ev, int64_t frame_timestamp, bool check2_after,
+                                            bool has_ts2, int64_t frame_timestamp_2);  // :233-466
+    std::vector<Event> integrate_frame_gaps();                                          // :468-598
+    std::function<bool(DavisPacket &)> next_packet_;
+    Video video_;
+    TranscoderMode mode_;
+    bool have_cached_ = false, cached_end_ = false;
+    DavisPacket cached_;
+    double dvs_c_ = 0.15;
+    bool have_last_after_ = false;
+    std::vector<DavisDvsEvent> events_before_, events_after_, events_last_after_;
+    int64_t temp_first_frame_start_timestamp_ = 0, start_of_frame_timestamp_ = 0, end_of_frame_timestamp_ = 0,
+            end_of_last_frame_timestamp_ = 0;
+    bool have_start_ = false, have_end_ = false, have_end_of_last_ = false;
+    std::vector<int64_t> dvs_last_timestamps_;
+    std::vector<double> dvs_last_ln_val_;
+    double time_change_ = 0.0, ref_time_divisor_ = 1.0;
+    size_t num_dvs_events_ = 0;
+    std::vector<Event> ingested_;
+};
+
 // ---------------------------------------------------------------- framer (framer/driver.rs)
 enum class FramerMode { INSTANTANEOUS, INTEGRATION };  // driver.rs:20-28; stored, never read by the reference's ingest: both behave alike
 enum class SourceType { U8, U16, U32, U64 };           // what the Intensity view divides by (scale_intensity.rs:68-75); F32 / F64 panic there

@@ -163,6 +163,66 @@ long long adder_host_prophesee(const uint8_t *dvs, size_t n, uint16_t width, uin
     }
 }
 
+// Davis::new + consume() until the input runs out (davis.rs), over EDI reconstructor output handed over in memory:
+// frames = [P][h * w] f64; meta = [P] records {c f64, img_start_ts i64, img_end_ts i64, n_before u32, n_after u32};
+// dvs = the packets' before-events then after-events, one packet after the other, as {t i64, x u16, y u16, on u8, pad[3]}.
+// out receives every event the source ingests, in order; returned = their number; *n_returned = events consume() returned.
+long long adder_host_davis(const double *frames, const uint8_t *meta, const uint8_t *dvs, uint32_t packets, uint16_t width,
+                           uint16_t height, int mode, uint32_t tps, uint32_t ref_time, uint32_t delta_t_max, int time_mode,
+                           int crf /* <0: none */, AdderEvent *out, size_t cap, unsigned long long *n_returned) {
+    try {
+        uint32_t pos = 0;
+        size_t dvs_pos = 0;
+        const size_t n = (size_t)width * height;
+        auto read_events = [&](uint32_t count, std::vector<DavisDvsEvent> &dst) {
+            dst.resize(count);
+            for (uint32_t i = 0; i < count; ++i, ++dvs_pos) {
+                const uint8_t *r = dvs + dvs_pos * 16;
+                memcpy(&dst[i].t, r, 8);
+                memcpy(&dst[i].x, r + 8, 2);
+                memcpy(&dst[i].y, r + 10, 2);
+                dst[i].on = r[12] != 0;
+            }
+        };
+        auto next = [&](DavisPacket &pk) {
+            if (pos >= packets) return false;
+            pk.frame.assign(frames + (size_t)pos * n, frames + (size_t)(pos + 1) * n);
+            const uint8_t *m = meta + (size_t)pos * 32;
+            uint32_t nb, na;
+            memcpy(&pk.c, m, 8);
+            memcpy(&pk.img_start_ts, m + 8, 8);
+            memcpy(&pk.img_end_ts, m + 16, 8);
+            memcpy(&nb, m + 24, 4);
+            memcpy(&na, m + 28, 4);
+            pk.has_events = mode != 0;
+            read_events(nb, pk.events_before);
+            read_events(na, pk.events_after);
+            ++pos;
+            return true;
+        };
+        Davis source(width, height, mode == 0 ? TranscoderMode::Framed : mode == 1 ? TranscoderMode::RawDavis : TranscoderMode::RawDvs,
+                     next);
+        source.get_video_mut().time_parameters(tps, ref_time, delta_t_max, time_mode == 1 ? TimeMode::AbsoluteT : TimeMode::DeltaT);
+        if (crf >= 0) source.crf((uint8_t)crf);
+        unsigned long long returned = 0;
+        for (;;) {
+            try {
+                for (auto &v : source.consume()) returned += v.size();
+            } catch (const SourceError &err) {
+                if (err.kind != SourceError::NoData) throw;
+                break;
+            }
+        }
+        const std::vector<Event> &all = source.ingested();
+        for (size_t i = 0; i < all.size() && i < cap; ++i) out[i] = all[i];
+        if (n_returned) *n_returned = returned;
+        return (long long)all.size();
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 long long adder_host_transcode_raw(const uint8_t *frames, uint32_t num_frames, uint32_t width, uint32_t height,
                                    uint32_t channels_in, int color_input, float fps, int crf /* <0: none */,
                                    uint32_t ref_time, uint32_t delta_t_max, int time_mode, int multi_mode,

@@ -211,6 +211,14 @@ uint32_t adder_hip_frames_in_flight(const AdderHipCtx *ctx);
  * integrate_for_px calls (prophesee.rs:259-283): flag the first step of a two-step camera event, and the steps of
  * end_events (:330-372, which never sample it). */
 #define ADDER_SPARSE_NO_SIDE 1u
+/* The DAVIS source (davis.rs:331-395) splits the step: it integrates the pixel's OLD intensity over the time since its
+ * last event without a contrast test (ADDER_SPARSE_INTEGRATE_ONLY: pop_top if flagged, integrate, pop_top if flagged),
+ * then tests the NEW value against base_val +- c_thresh and, outside, flushes and restarts the arena for it WITHOUT
+ * integrating it (ADDER_SPARSE_TEST_ONLY: pop_best_events(intensity), base_val = frame_val, set_d_for_continuous).
+ * At the end of its input it pops every pixel's events (ADDER_SPARSE_FLUSH: pop_best_events(intensity) alone, :654-661). */
+#define ADDER_SPARSE_INTEGRATE_ONLY 2u
+#define ADDER_SPARSE_TEST_ONLY 4u
+#define ADDER_SPARSE_FLUSH 8u
 typedef struct AdderSparseStep {
     uint16_t x, y;      /* plane coordinates */
     uint8_t c;          /* channel, ADDER_C_NONE on a 1-channel plane */

@@ -688,7 +688,31 @@ int oracle_video_integrate_sparse(OracleVideo *v, const OracleSparseStep *steps,
         /* `let mut base_val = 0;` right before every call (prophesee.rs:206,244,334) is an OUT parameter:
          * integrate_for_px sets `*base_val = px.base_val` (video.rs:1336) before the contrast test, which therefore
          * uses the pixel's persisted base_val */
-        integrate_for_px(px, steps[i].frame_val, steps[i].intensity, steps[i].time, &ev, &v->sp);
+        const unsigned kind = steps[i].pad;
+        if (kind & 8u) {
+            /* end of a DAVIS input: "Forcibly pop the last event from each pixel" (davis.rs:654-661) */
+            pop_best_events(px, &ev, v->sp.pixel_tree_mode, v->sp.pixel_multi_mode, v->sp.ref_time, steps[i].intensity);
+        } else if (kind & 2u) {
+            /* davis.rs:331-360: the old intensity over the time since the pixel's last event, no contrast test */
+            if (px->need_to_pop_top) evec_push(&ev, pop_top_event(px, steps[i].intensity, v->sp.pixel_tree_mode, v->sp.ref_time));
+            arena_integrate(px, steps[i].intensity, steps[i].time, v->sp.pixel_tree_mode, v->sp.delta_t_max, v->sp.ref_time,
+                            v->sp.c_thresh_max, v->sp.c_increase_velocity, v->sp.pixel_multi_mode);
+            if (px->need_to_pop_top) evec_push(&ev, pop_top_event(px, steps[i].intensity, v->sp.pixel_tree_mode, v->sp.ref_time));
+        } else if (kind & 4u) {
+            /* davis.rs:371-395: the new value against base_val; a flush restarts the arena for it, nothing is integrated */
+            const uint8_t base_val = px->base_val, fv = steps[i].frame_val;
+            const uint8_t lo = (uint8_t)(base_val > px->c_thresh ? base_val - px->c_thresh : 0);
+            const unsigned hs = (unsigned)base_val + px->c_thresh;
+            const uint8_t hi = (uint8_t)(hs > 255 ? 255 : hs);
+            if (fv < lo || fv > hi) {
+                pop_best_events(px, &ev, v->sp.pixel_tree_mode, v->sp.pixel_multi_mode, v->sp.ref_time, steps[i].intensity);
+                px->base_val = fv;
+                OracleEvent e;
+                if (set_d_for_continuous(px, steps[i].intensity, v->sp.ref_time, &e)) evec_push(&ev, e);
+            }
+        } else {
+            integrate_for_px(px, steps[i].frame_val, steps[i].intensity, steps[i].time, &ev, &v->sp);
+        }
         /* the side plane (prophesee.rs:259-283): once per camera event, after its last integrate_for_px call, the
          * root's best event if it has one; pad bit 0 marks a step that is not followed by that sampling (the first
          * of a camera event's two steps; end_events' steps, :330-372) */

@@ -233,13 +233,16 @@ int sim_integrate_sparse(Sim *s, const SimSparseStep *steps, size_t n, SimEvent 
         sc.running_t_u32 = f32_as_u32(sc.running_t);
         sc.cth = s->cth_px[u];
         ContAcc acc{s, u};
-        const bool ok = s->abs_t ? cont_step<true>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em)
-                                 : cont_step<false>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em);
+        const uint32_t kind = steps[i].pad;
+        const bool ok = s->abs_t ? cont_step<true>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em, kind)
+                                 : cont_step<false>(p, acc, steps[i].frame_val, steps[i].intensity, steps[i].time, sc, s->max_depth + 1, em, kind);
         if (!ok) rc = -5;
         s->c_hdr[u] = apx_hdr(p);
         s->lastf[u] = p.lastf;
-        s->rt_px[u] += steps[i].time;
-        c_thresh_advance(s->cth_px[u], s->cctr_px[u], (uint8_t)s->c_max, (uint8_t)s->velocity, steps[i].time, s->ref_time);
+        if (!(kind & (kSparseTestOnly | kSparseFlush))) {  // (running_t and c_thresh advance inside PixelArena::integrate)
+            s->rt_px[u] += steps[i].time;
+            c_thresh_advance(s->cth_px[u], s->cctr_px[u], (uint8_t)s->c_max, (uint8_t)s->velocity, steps[i].time, s->ref_time);
+        }
     }
     *n_out = em.pos;
     if (em.pos > cap && rc == 0) rc = -4;

@@ -142,6 +142,37 @@ def prophesee(dvs, width, height, ref_time):
     return out[:n].copy(), calls.value
 
 
+DAVIS_DVS_DTYPE = np.dtype([("t", "<i8"), ("x", "<u2"), ("y", "<u2"), ("on", "u1"), ("pad", "u1", (3,))])
+DAVIS_META_DTYPE = np.dtype([("c", "<f8"), ("start", "<i8"), ("end", "<i8"), ("n_before", "<u4"), ("n_after", "<u4")])
+
+
+def davis(packets, width, height, mode, *, tps, ref_time, delta_t_max, time_mode=1, crf=-1):
+    """Davis source of the C++ mirror over in-memory EDI output.  packets: list of dicts {frame [h, w] f64, c, start, end,
+    before, after (arrays of DAVIS_DVS_DTYPE)} -> (every event the source ingested, in order; events consume() returned)."""
+    P = len(packets)
+    crf = -1 if crf is None else crf
+    frames = np.ascontiguousarray(np.stack([p["frame"] for p in packets]).astype(np.float64))
+    meta = np.zeros(P, DAVIS_META_DTYPE)
+    dvs = []
+    for k, p in enumerate(packets):
+        meta[k] = (p["c"], p["start"], p["end"], len(p["before"]), len(p["after"]))
+        dvs += [np.ascontiguousarray(p["before"], DAVIS_DVS_DTYPE), np.ascontiguousarray(p["after"], DAVIS_DVS_DTYPE)]
+    dvs = np.concatenate(dvs) if dvs else np.zeros(0, DAVIS_DVS_DTYPE)
+    cap = max(4096, (len(dvs) * 4 + (3 * P + 2) * width * height) * 6)
+    out = np.zeros(cap, adder_amd.EVENT_DTYPE)
+    ret = C.c_ulonglong(0)
+    fn = lib().adder_host_davis
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_int, C.c_uint32, C.c_uint32,
+                   C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+    n = fn(frames.ctypes.data, meta.ctypes.data, dvs.ctypes.data, P, width, height, mode, tps, ref_time, delta_t_max,
+           time_mode, crf, out.ctypes.data, cap, C.byref(ret))
+    if n < 0:
+        raise RuntimeError(err())
+    assert n <= cap
+    return out[:n].copy(), ret.value
+
+
 def frame_events(events, chunk_offsets, width, height, channels, *, tps, ref_interval, delta_t_max, codec_version,
                  time_mode, chunk_rows, output_fps=0.0, framer_mode=0, view_mode=0, source_type=0, practical_d_max=0.0,
                  flushes=0, cap=1 << 26):

@@ -218,7 +218,9 @@ def _sparse_steps(rng, W, H, Cn, n, *, hot=0.3):
     val = rng.choice(np.array([0, 1, 3, 9, 40, 128, 200, 255]), n)
     span = rng.choice(np.array([1, 1, 1, 2, 5, 40, 700]), n)
     st["frame_val"] = val
-    st["pad"] = rng.integers(0, 2, n)
+    # bit 0: no side-plane sample after the step; bits 1-3: the DAVIS source's partial steps (integrate only, contrast
+    # test only, flush only -- davis.rs:331-395, 654-661)
+    st["pad"] = rng.integers(0, 2, n) | rng.choice(np.array([0, 0, 0, 0, 2, 2, 4, 4, 8]), n)
     st["intensity"] = (val * span).astype(np.float32)
     st["time"] = (span * 20).astype(np.float32)
     return st

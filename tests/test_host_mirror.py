@@ -311,3 +311,152 @@ def test_framer_builder_views_and_integration_mode(view, source, dmax, mode):
     got = Hst.frame_events(ev, offs, W, H, 1, time_mode=1, chunk_rows=rows, framer_mode=mode, view_mode=view,
                            source_type=source, practical_d_max=dmax, flushes=3, **kw)
     assert len(want) > 20 * W * H and got == want
+
+
+def _davis_restatement(packets, W, H, mode, *, tps, ref_time, dtm, crf):
+    """Davis::consume until the input ends (davis.rs:233-897), restated over the oracle's Video and its sparse driver:
+    per packet the DVS events left over from after the previous frame, those before this frame, the frame gaps of every
+    pixel, then the deblurred frame itself; at the end every pixel's events are popped.  Returns every event in the
+    order the reference feeds them to its encoder."""
+    import math
+    from oracle import oracle as O
+    continuous = mode != 0
+    v = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm, chunk_rows=H // 4)
+    if continuous:
+        v.set_pixel_mode(1)
+    v.ensure_capacity(40)
+    if crf is not None:
+        base, cmax, vel = [(0, 0, 10), (0, 1, 9), (1, 3, 8), (2, 7, 7)][crf]
+        v.set_crf_parameters(cmax, vel)
+        v.reset_c_thresh(base)
+    else:
+        v.set_crf_parameters(7, 7)
+    f32 = np.float32
+    tpm = f32(tps) / f32(1e6)
+    last_ts = np.zeros(W * H, np.int64)
+    last_ln = np.zeros(W * H, np.float64)
+    out = []
+    state = {"c": 0.15, "start": None, "end": None, "last_after": None, "end_of_last": None}
+
+    def as_u8(x):
+        return 0 if not x > 0.0 else (255 if x >= 255.0 else int(x))
+
+    def clamp(val, p):
+        if val <= 0.0:
+            last_ln[p] = math.log1p(0.0)
+            return 0.0
+        if val > 255.0:
+            last_ln[p] = math.log1p(1.0)
+            return 255.0
+        return val
+
+    def run(steps):
+        if steps:
+            out.append(v.integrate_sparse(np.array(steps, O.SPARSE_STEP_DTYPE)))
+
+    def dvs_events(events, ts1, ts2, after2):
+        steps = []
+        for chunk in range(4):
+            for e in events:
+                x, y, t = int(e["x"]), int(e["y"]), int(e["t"])
+                if y // (H // 4) != chunk:
+                    continue
+                if not t < ts1:
+                    continue
+                if ts2 is not None and not (t > ts2 if after2 else t < ts2):
+                    continue
+                p = y * W + x
+                last_val = (math.exp(last_ln[p]) - 1.0) * 255.0
+                dmicro = t - int(last_ts[p])
+                if dmicro == t:
+                    continue
+                dticks = f32(dmicro) * tpm
+                if dticks < 0:
+                    continue
+                first = max(f32(f32(last_val) / f32(ref_time)) * dticks, f32(0.0))
+                steps.append((x, y, 0xFF, 0, 1 | 2, f32(first), f32(dticks)))
+                last_ln[p] *= math.exp(state["c"] if e["on"] else -state["c"])
+                fv = clamp((math.exp(last_ln[p]) - 1.0) * 255.0, p)
+                steps.append((x, y, 0xFF, as_u8(fv), 1 | 4, f32(fv), f32(0.0)))
+                last_ts[p] = t
+        run(steps)
+
+    for pk in packets:
+        if continuous:
+            state["start"], state["end"], state["c"] = int(pk["start"]), int(pk["end"]), float(pk["c"])
+            if mode == 2:
+                state["end"] = state["start"] + 1
+        start = state["start"] if state["start"] is not None else 0
+        end = state["end"] if state["end"] is not None else ref_time
+        if continuous:
+            if state["last_after"] is not None and state["end_of_last"] is not None:
+                dvs_events(state["last_after"], start, state["end_of_last"] if mode != 2 else None, True)
+            dvs_events(pk["before"], start, None, False)
+            steps = []
+            for y in range(H):
+                for x in range(W):
+                    p = y * W + x
+                    lv = clamp((math.exp(last_ln[p]) - 1.0) * 255.0, p)
+                    dmicro = start - int(last_ts[p])
+                    if dmicro == start:
+                        continue
+                    dticks = f32(dmicro) * tpm
+                    if dticks <= 0:
+                        continue
+                    integ = max((lv / float(ref_time)) * float(dticks), 0.0)
+                    steps.append((x, y, 0xFF, as_u8(lv), 0, f32(integ), f32(dticks)))
+            run(steps)
+        img = np.clip(np.rint(pk["frame"] * 255.0), 0, 255).astype(np.uint8)
+        span = f32(ref_time)
+        if mode == 1:
+            span = f32(end - start)
+        if mode == 2:
+            state["c"] = 0.15
+            img[...] = 0
+            span = f32(0.0)
+        if not continuous:
+            out.append(v.integrate_matrix(img.reshape(H, W, 1), time_spanned=float(span)))
+        else:
+            run([(x, y, 0xFF, int(img[y, x]), 0, f32(img[y, x]), span) for y in range(H) for x in range(W)])
+        last_ln[:] = math.log1p(0.5) if mode == 2 else np.log1p(pk["frame"].reshape(-1))
+        if continuous:
+            state["last_after"], state["end_of_last"] = pk["after"], end
+            last_ts[:] = end
+    if continuous:
+        run([(x, y, 0xFF, 0, 1 | 8, f32(0.0), f32(0.0)) for y in range(H) for x in range(W)])
+    return np.concatenate(out) if out else np.zeros(0, O.EVENT_DTYPE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_davis_source_frames_and_dvs_events_interleaved(mode):
+    """SURVEY 8(f)3, the DAVIS half (davis.rs:233-897) end to end through the C++ mirror: EDI output (deblurred frames
+    + the DVS events before / after each exposure; the reconstructor itself is an un-vendored file-parsing crate) ->
+    Davis::consume in Framed / RawDavis / RawDvs mode -> sparse steps in the reference's order on the device (the
+    split steps of ADDER_SPARSE_INTEGRATE_ONLY / _TEST_ONLY / _FLUSH) -> ADDER events.  Against a restatement of the
+    same driver over the oracle.  The driver has no reference vector: oracle parity."""
+    rng = np.random.default_rng(20 + mode)
+    W, H, P = 38, 28, 7
+    tps, ref_time, dtm = 1_000_000, 5000, 500_000
+    packets, t = [], 40_000
+    base = rng.random((H, W))
+    for k in range(P):
+        start, end = t, t + int(rng.integers(3000, 9000))
+        nxt = end + int(rng.integers(10_000, 30_000))
+
+        def events(lo, hi, n):
+            ev = np.zeros(n, Hst.DAVIS_DVS_DTYPE)
+            ev["t"] = np.sort(rng.integers(lo, hi, n))
+            hot = rng.integers(0, W * H, 25)
+            pix = np.where(rng.random(n) < 0.6, hot[rng.integers(0, 25, n)], rng.integers(0, W * H, n))
+            ev["x"], ev["y"], ev["on"] = pix % W, pix // W, rng.integers(0, 2, n)
+            return ev
+        frame = np.clip(base + rng.normal(0, 0.08, (H, W)) + (0.3 if k == 4 else 0.0), -0.05, 1.1)
+        # (events that fall inside an exposure or beyond the next frame's start are there on purpose: the checks drop them)
+        packets.append({"frame": frame, "c": 0.1 + 0.05 * rng.random(), "start": start, "end": end,
+                        "before": events(start - 25_000, start + 2000, 400), "after": events(end - 2000, nxt + 1000, 400)})
+        t = nxt
+    got, returned = Hst.davis(packets, W, H, mode, tps=tps, ref_time=ref_time, delta_t_max=dtm, crf=2 if mode else None)
+    want = _davis_restatement(packets, W, H, mode, tps=tps, ref_time=ref_time, dtm=dtm, crf=2 if mode else None)
+    assert len(got) == len(want) > 2 * W * H and np.array_equal(got, want)
+    assert 0 < returned <= len(got)
