@@ -34,5 +34,5 @@ def run(hv, n=12):
         hv.integrate_device(f, e, d_off, stream=st); hv.finish()
         ts.append(time.perf_counter() - t0)
     return round(float(np.median(ts[3:])) * 1e3, 3)
-for rnd in range(3):
+for rnd in range(int(os.environ.get("ROUNDS", 3))):
     print("round", rnd, [run(hv) for hv in ctxs], flush=True)
