@@ -915,10 +915,11 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
     const size_t budget = std::min<size_t>((size_t)64 << 30, free_b / 4);
     c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
     if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
-    // default: groups of 64 segments -- the 16 segments an expansion wave reads of one frame are contiguous, and eight
-    // contexts measured 1.515 - 1.525 ms per step against 1.55 / 1.62 (two modes) for the rotated segment-major layout
-    // (profiles/r03_ctx_spread.txt)
-    c->park_group_shift = 6u;
+    // default: groups of 16 segments -- the 16 segments an expansion wave reads of one frame are contiguous; contexts
+    // measured 1.515 - 1.525 ms per step (a few 1.57 - 1.58) against 1.55 / 1.62 (two modes) for the rotated
+    // segment-major layout (profiles/r03_ctx_spread.txt).  (A group must divide the segment count, which is padded to a
+    // multiple of 16: larger requests fall back to 16.)
+    c->park_group_shift = 4u;
     if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
         const int sh = atoi(e);
         c->park_group_shift = sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
