@@ -1110,11 +1110,22 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         CbPlanT<L> plan[N];
         CbMidT<L> mid[N];
         uint32_t lane_cnt = 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) cb_step_a<L>(px[j], lv[j], (vin_w >> (8 * j)) & 0xffu, sc, plan[j], mid[j]);
+        bool lane_walks = false;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            cb_step_b<L>(px[j], lv[j], T, sc, plan[j], mid[j]);
+            cb_step_a<L>(px[j], lv[j], (vin_w >> (8 * j)) & 0xffu, sc, plan[j], mid[j]);
+            lane_walks = lane_walks || L::lane(mid[j].walk);
+        }
+        // a wave whose arenas are all popped (static content; lossy content between its rare flushes) only steps roots
+        const bool wave_walks = __builtin_amdgcn_ballot_w64(lane_walks) != 0ull;  // uniform
+        if (wave_walks) {
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) cb_step_reads<L>(lv[j], mid[j]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            if (wave_walks) cb_step_b<L, CbLevelsDev, true>(px[j], lv[j], T, sc, plan[j], mid[j]);
+            else cb_step_b<L, CbLevelsDev, false>(px[j], lv[j], T, sc, plan[j], mid[j]);
             depth_error = L::or_(depth_error, plan[j].depth_error);
             if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;  // padding units: stepped freely, no events
             lane_cnt += plan[j].count;
@@ -1127,6 +1138,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         wt = lane == i ? (total | (total << 16)) : wt;
         wo = lane == i ? run_start : wo;
         uint32_t off = incl - lane_cnt;  // final offset of the lane's first event inside the segment
+        if (total != 0u)  // (uniform: most frames of static or lossy content leave a segment without a single event)
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u && seg) {

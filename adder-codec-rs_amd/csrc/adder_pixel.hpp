@@ -839,17 +839,28 @@ ADDER_HD void cb_step_a(CbPxT<L> &s, const Lv &lv, uint32_t v, const StepConsts 
     x.S_new = fadd(x.S_old, x.I);
     x.root_fires = L::or_(L::not_(x.has0), L::from(x.S_new >= s.thr0));  // (the pristine tail at index 0 always fires)
     x.walk = L::andnot(L::not_(x.root_fires), x.popped);
-    // the level reads, whether or not this unit walks (some lane of the wave does): no branch, so the reads of a
-    // lane's units overlap
+    x.kf = kCbFastLevels + 1u;
+    x.k = 0u;
+    x.l = CbLevel{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// The level reads of the walk, whether or not THIS unit walks (when some lane of the wave does): no branch, so the reads
+// of a lane's units overlap.  A wave none of whose units walks -- every arena popped, the steady state of static and of
+// lossy (crf > 0) content -- skips them and runs cb_step_b<.., false>.
+template <class L, class Lv>
+ADDER_HD void cb_step_reads(const Lv &lv, CbMidT<L> &x) {
     x.kf = lv.first_fast(x.S_new);
     x.k = x.kf < x.m ? x.kf : x.m;
     const uint32_t ks = x.k < 1u ? 1u : (x.k > kCbFastLevels ? kCbFastLevels : x.k);
     x.l = lv.load_fast(ks);
 }
 
-template <class L, class Lv>
-ADDER_HD void cb_step_b(CbPxT<L> &s, const Lv &lv, float T, const StepConsts &sc, CbPlanT<L> &p, const CbMidT<L> &x) {
+// MAY_WALK = false: the caller knows that x.walk is false (no level is read, fired or stored: only the root integrates)
+template <class L, class Lv, bool MAY_WALK = true>
+ADDER_HD void cb_step_b(CbPxT<L> &s, const Lv &lv, float T, const StepConsts &sc, CbPlanT<L> &p, const CbMidT<L> &x_in) {
     using M = typename L::Mask;
+    CbMidT<L> x = x_in;
+    if (!MAY_WALK) x.walk = L::from(false);
     // ---- which node fires, and its (integration, delta_t, threshold) as offsets from the root's ----
     uint32_t k = x.k;
     M fresh_lv = L::from(k >= x.m);  // the pristine tail behind the levels: integration 0, delta_t 0, d = get_d(I) (:332-335)
@@ -907,7 +918,12 @@ template <class L, class Lv>
 ADDER_HD void cb_step(CbPxT<L> &s, const Lv &lv, uint32_t v, float T, const StepConsts &sc, CbPlanT<L> &p) {
     CbMidT<L> x;
     cb_step_a(s, lv, v, sc, p, x);
-    cb_step_b(s, lv, T, sc, p, x);
+    if (L::lane(x.walk)) {
+        cb_step_reads(lv, x);
+        cb_step_b<L, Lv, true>(s, lv, T, sc, p, x);
+    } else {
+        cb_step_b<L, Lv, false>(s, lv, T, sc, p, x);
+    }
 }
 
 // The unit's events of this frame, in emission order.  After cb_step, before cb_pop.  An event leaves as (the bits of
