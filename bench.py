@@ -311,6 +311,29 @@ def main():
     one_b = 1 + 2 * S + rec_bytes * r1
     one_gbs = one_b * units / (k1_one_us * 1e-6) / 1e9 if k1_one_us > 0 else 0.0
 
+    # HBM bytes really moved by the chunk's kernels: PMC counters cannot be read inside this process (rocprofv3 collects
+    # them in separate passes), so the figure comes from the committed collection of the SAME command
+    # (tools/profile_round.sh -> profiles/<round>_traffic_default.json: 2 x FETCH_SIZE + WRITE_SIZE per launch, KiB,
+    # MI355X_MICROARCH.md HBM section) when this run is the default workload; null otherwise.
+    traffic, traffic_note = None, "no committed PMC collection for this workload (tools/profile_round.sh)"
+    try:
+        default_workload = (Wd, Ht, Cn, T, args.delta_t_max, args.content, args.multi_mode, args.time_mode) == \
+            (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic_default.json")
+        if default_workload and world == 1 and os.path.exists(tpath):
+            tk = json.load(open(tpath))["kernels"]
+            per_launch = {k: v["hbm_bytes_per_launch"] for k, v in tk.items()}
+            lean_b = sum(v for k, v in per_launch.items() if "lean_kernel" in k)
+            exp_b = sum(v for k, v in per_launch.items() if "expand_kernel" in k)
+            scan_b = sum(v for k, v in per_launch.items() if "scan_kernel" in k or "offsets_kernel" in k)
+            traffic = int(lean_b + exp_b + scan_b)
+            traffic_note = ("HBM bytes of one 64-frame chunk (frame kernel + scan + offsets + expansion launches) from "
+                            "profiles/r03_traffic_default.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                            "this command, 2 x FETCH_SIZE + WRITE_SIZE (KiB); algorithmic bytes of the same chunk: "
+                            f"{int(alg_b * units * chunk_frames)}")
+    except Exception as exc:
+        traffic_note = f"could not read the committed PMC collection: {exc}"
+
     out = {
         "metric": "Mpixels/s framed->ADDER transcode (1080p, delta_t_max=255)",
         "value": round(value, 1),
@@ -356,7 +379,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,  # PMC counters need separate rocprofv3 passes: see profiles/ (tools/profile_round.sh)
+            "traffic": traffic,
+            "traffic_note": traffic_note,
             "bytes_per_unit_frame": round(alg_b, 3),
             "frames_per_launch": k1_frames,
             "frames_per_chunk": chunk_frames,
@@ -669,6 +693,10 @@ def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, arg
                   f"OpenMP over row chunks (chunk_rows=1, OMP_PROC_BIND=close) + serial raw sink; events stay in "
                   f"per-chunk buffers like the reference's Vec<Vec<Event>>",
         "host_cores": max_threads,
+        "caveat": "a stated baseline, not a target: the port forks and joins an OpenMP team per frame over single-row "
+                  "chunks and runs the sink serially, like the reference's default chunk_rows = 1; it peaks at 8 threads of "
+                  "this box's cores and falls beyond (memory-bound AoS state, NUMA), which may undersell what rayon's "
+                  "work stealing does on the same machine -- the Rust original cannot be built here",
         "thread_sweep": sweep,
         "one_thread": next((s["value"] for s in sweep if s["threads"] == 1), None),
         "without_sink": round(mp_nosink, 2),

@@ -7,7 +7,7 @@
 #    temporal depth, and of a 96-frame run with ONE frame per launch (the adder_lean1_kernel rows),
 # then writes summaries under gpurun_out/profiles_<round>/ (copy them into profiles/).
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p "$OUT"
@@ -15,30 +15,30 @@ export TMPDIR=/tmp
 cd /tmp
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python "$REPO/bench.py" --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --steps 5 --warmup 2 --secondary-ms 30 > "$OUT/bench_under_rocprof.log" 2>&1
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_kernel_stats.csv" \;
 find "$OUT/stats" -name '*domain_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_domain_stats.csv" \;
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -o bench -- \
-    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary > "$OUT/bench_default_depth_under_rocprof.log" 2>&1
 find "$OUT/stats2" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_default_depth_kernel_stats.csv" \;
 
 # 2b. the same, eager on ONE stream (ADDER_HIP_NO_GRAPH=1): the kernels run one after the other at full grids, which is
 #     what bench.py's HIP-event pairs time for its `roofline` block (in the default run the frame kernel and the
 #     expansion share the chip, so their trace durations overlap and are longer)
 ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -o bench -- \
-    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end > "$OUT/bench_eager_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary > "$OUT/bench_eager_under_rocprof.log" 2>&1
 find "$OUT/stats3" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_bench_eager_serial_kernel_stats.csv" \;
 
 pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
     local tag=$1 envs=$2; shift; shift
-    local cmd="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --skip-roofline $*"
+    local cmd="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-secondary --skip-roofline $*"
     mkdir -p "$OUT/$tag"
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES" \
                "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
                "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
         local st=$(echo "$set" | tr ' ' '_' | cut -c1-40)
-        env $envs ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$tag/pmc_$st" -o pmc -- \
+        env $envs ADDER_HIP_NO_GRAPH=1 ADDER_BENCH_PLAN_STEPS=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$tag/pmc_$st" -o pmc -- \
             $cmd > "$OUT/$tag/pmc_$st.log" 2>&1
     done
     python "$REPO/tools/pmc_csv_summary.py" "$OUT/$tag" --traffic "$OUT/${ROUND}_traffic_$tag.json" > "$OUT/${ROUND}_pmc_$tag.csv"
@@ -46,6 +46,10 @@ pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
 }
 pmc_passes default "A=1" --frames 160
 pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96
-pmc_passes generic_dtm7650_abs "A=1" --frames 60 --delta-t-max 7650 --time-mode absolute_t
-rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3
+pmc_passes default_mode_dtm7650_abs "A=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
+# 4. the reference default mode (Collapse, AbsoluteT, delta_t_max 7650: adder_cb_kernel) eager on one stream: kernel stats
+ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o bench -- \
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary --delta-t-max 7650 --time-mode absolute_t > "$OUT/bench_default_mode_under_rocprof.log" 2>&1
+find "$OUT/stats4" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_default_mode_eager_kernel_stats.csv" \;
+rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3 "$OUT"/stats4
 ls -la "$OUT"
