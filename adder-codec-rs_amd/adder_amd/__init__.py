@@ -12,5 +12,5 @@ from ._native import (  # noqa: F401
     OK, E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED,
 )
 from .video import CRF, crf_feature_radius, HipVideo, raw_header, raw_events, raw_eof, synth_clip_device  # noqa: F401
-from .framer import HipFramer, contiguous_run_segments, FRAMED_U8, DVS  # noqa: F401
+from .framer import HipFramer, contiguous_run_segments, FRAMED_U8, DVS, FRAME_U8, FRAME_U16, FRAME_U32  # noqa: F401
 from .compressed import CompressedEncoder, compressed_decode  # noqa: F401

@@ -76,7 +76,8 @@ class AdderFramerParams(C.Structure):
         ("device_id", C.c_int32),
         ("view_mode", C.c_uint8),
         ("source_type", C.c_uint8),
-        ("reserved1", C.c_uint8 * 2),
+        ("value_type", C.c_uint8),
+        ("reserved1", C.c_uint8),
         ("practical_d_max", C.c_float),
     ]
 

@@ -1,7 +1,7 @@
-"""HipFramer -- ctypes plumbing over include/adder_framer.h (events -> u8 frames on the GPU).
+"""HipFramer -- ctypes plumbing over include/adder_framer.h (events -> u8 / u16 / u32 frames on the GPU).
 
-Mirrors FramerBuilder / FrameSequence<u8> (adder-codec-rs/src/framer/driver.rs:55-138, 261-981) for
-FramerMode::INSTANTANEOUS + FramedViewMode::Intensity.
+Mirrors FramerBuilder / FrameSequence<T> (adder-codec-rs/src/framer/driver.rs:55-138, 261-981) for
+FramerMode::INSTANTANEOUS; T picked by value_type (scale_intensity.rs:16-209).
 """
 import ctypes as C
 
@@ -10,12 +10,14 @@ import numpy as np
 from . import _native as N
 
 FRAMED_U8, DVS = 0, 6  # SourceCamera (adder-codec-core/src/lib.rs:35-47)
+FRAME_U8, FRAME_U16, FRAME_U32 = 0, 1, 2  # the frame element type T of FrameSequence<T>
 
 
 class HipFramer:
     def __init__(self, width, height, channels=1, *, tps, ref_interval, delta_t_max, output_fps=None,
                  codec_version=1, time_mode=N.TIME_DELTA_T, source_camera=FRAMED_U8, row_begin=0, row_end=None,
-                 ring_frames=0, device_id=0, view_mode=0, source_type=0, practical_d_max=0.0):
+                 ring_frames=0, device_id=0, view_mode=0, source_type=0, practical_d_max=0.0,
+                 value_type=FRAME_U8):
         self.L = N.load()
         p = N.AdderFramerParams()
         self.L.adder_framer_default_params(C.byref(p), width, height, channels)
@@ -26,6 +28,7 @@ class HipFramer:
         p.source_camera, p.ring_frames, p.device_id = source_camera, ring_frames, device_id
         # FramedViewMode 0 Intensity / 1 D / 2 DeltaT / 3 SAE; SourceType 0 U8 .. 3 U64; practical_d_max for the D view
         p.view_mode, p.source_type, p.practical_d_max = view_mode, source_type, float(practical_d_max)
+        p.value_type = value_type  # popped frames hold big-endian elements of 1 << value_type bytes (bincode, driver.rs:279)
         h = C.c_void_p()
         rc = self.L.adder_framer_create(C.byref(p), C.byref(h))
         if rc != N.OK:
@@ -34,7 +37,7 @@ class HipFramer:
         self.h = h
         self.width, self.height, self.channels = width, height, channels
         self.rows = p.row_end - p.row_begin
-        self.frame_bytes = self.rows * width * channels
+        self.frame_bytes = (self.rows * width * channels) << value_type
 
     def close(self):
         if getattr(self, "h", None):

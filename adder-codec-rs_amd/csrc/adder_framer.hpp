@@ -46,12 +46,13 @@ struct FramerConsts {
     uint32_t source_type;    // SourceType of the intensities: 0 U8, 1 U16, 2 U32, 3 U64 (Intensity view)
     float practical_d_max;   // D view: log2_raw(255 * (delta_t_max / ref_interval)), computed by the caller (:1020-1021)
     uint32_t delta_t_max;    // DeltaT / SAE views
+    uint32_t value_type;     // the frame element type T of FrameSequence<T>: 0 u8, 1 u16, 2 u32 (scale_intensity.rs:54-209)
 };
 constexpr uint32_t kViewIntensity = 0, kViewD = 1, kViewDeltaT = 2, kViewSae = 3;
 
 ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
                                     uint32_t view_mode = 0, uint32_t source_type = 0, float practical_d_max = 0.0f,
-                                    uint32_t delta_t_max = 0) {
+                                    uint32_t delta_t_max = 0, uint32_t value_type = 0) {
     FramerConsts k;
     k.tpf = tpf;
     k.ref_interval = ref_interval;
@@ -63,6 +64,7 @@ ADDER_HD FramerConsts framer_consts(uint32_t tpf, uint32_t ref_interval, uint32_
     k.source_type = source_type;
     k.practical_d_max = practical_d_max;
     k.delta_t_max = delta_t_max;
+    k.value_type = value_type;
     return k;
 }
 
@@ -78,6 +80,36 @@ ADDER_HD uint32_t framer_value_u8(uint32_t d, uint32_t te, uint32_t clock, uint3
     if (k.source_type == 0u) return f64_as_u8(intensity * tpf);
     const double full = k.source_type == 1u ? 65535.0 : k.source_type == 2u ? 4294967295.0 : 18446744073709551616.0;
     return f64_as_u8(intensity / full * tpf * 255.0);
+}
+
+// Rust's `as u16` / `as u32` from a float: saturating, NaN -> 0
+ADDER_HD uint32_t f64_as_uint(double v, double max) {
+    if (!(v > 0.0)) return 0u;
+    if (v >= max) return (uint32_t)max;
+    return (uint32_t)v;
+}
+ADDER_HD uint32_t f32_as_uint(float v, double max) {
+    if (!(v > 0.0f)) return 0u;
+    if ((double)v >= max) return (uint32_t)max;
+    return (uint32_t)v;
+}
+// <u16 as FrameValue>::get_frame_value (scale_intensity.rs:111-160) and <u32 ..> (:162-209): the same expressions as u8's
+// with the target type's maximum (f32::from(u16::MAX) = 65535, u32::MAX as f32 = 2^32 after rounding).  Their SAE arm is
+// todo!() in the reference: the C-ABI refuses that combination at create.  FrameSequence<u64> cannot be instantiated in
+// the reference (its methods need T: Into<f64>).
+ADDER_HD uint32_t framer_value_wide(uint32_t d, uint32_t te, const FramerConsts &k) {
+    const double tmax = k.value_type == 1u ? 65535.0 : 4294967295.0;
+    const float tmax_f32 = k.value_type == 1u ? 65535.0f : 4294967296.0f;
+    if (k.view_mode == kViewD) return f32_as_uint((float)d / k.practical_d_max * tmax_f32, tmax);
+    if (k.view_mode == kViewDeltaT) return f32_as_uint((float)te / (float)k.delta_t_max * tmax_f32, tmax);
+    const double intensity = event_intensity_f64(d, te);
+    const double tpf = (double)k.ref_interval;
+    if (k.source_type == k.value_type) return f64_as_uint(intensity * tpf, tmax);
+    const double smax = k.source_type == 0u ? 255.0 : k.source_type == 1u ? 65535.0 : k.source_type == 2u ? 4294967295.0 : 18446744073709551616.0;
+    return f64_as_uint(intensity / smax * tpf * tmax, tmax);
+}
+ADDER_HD uint32_t framer_value(uint32_t d, uint32_t te, uint32_t clock, uint32_t prev_clock, const FramerConsts &k) {
+    return k.value_type == 0u ? framer_value_u8(d, te, clock, prev_clock, k) : framer_value_wide(d, te, k);
 }
 
 struct FramerPx {
@@ -116,7 +148,7 @@ ADDER_HD bool framer_step(FramerPx &p, uint32_t d, uint32_t t, const FramerConst
                 const uint32_t pr = (uint32_t)prev_ts;
                 te = t > pr ? t - pr : 0u;  // event.t.saturating_sub(prev_running_ts as u32)
             }
-            p.lasti = framer_value_u8(d, te, (uint32_t)p.ts, (uint32_t)prev_ts, k);
+            p.lasti = framer_value(d, te, (uint32_t)p.ts, (uint32_t)prev_ts, k);
         }
         fill_from = p.lastf;
         fill_to = (int32_t)q;

@@ -120,6 +120,11 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
     if (!p.ref_interval || !p.tps) return ffail(nullptr, ADDER_E_BAD_PARAMS, "tps and ref_interval must be non-zero");
     if (p.time_mode > ADDER_TIME_MIXED) return ffail(nullptr, ADDER_E_BAD_PARAMS, "bad time_mode");
     if (p.view_mode > ADDER_VIEW_SAE || p.source_type > 3) return ffail(nullptr, ADDER_E_BAD_PARAMS, "bad view_mode / source_type");
+    // FrameSequence<T>: T = u8 / u16 / u32.  (u64 cannot be instantiated in the reference -- its methods need T: Into<f64>
+    // -- and the SAE view of the wider types is todo!() there, scale_intensity.rs:154,203.)
+    if (p.value_type > ADDER_FRAME_U32) return ffail(nullptr, ADDER_E_BAD_PARAMS, "value_type must be ADDER_FRAME_U8 / _U16 / _U32");
+    if (p.value_type != ADDER_FRAME_U8 && p.view_mode == ADDER_VIEW_SAE)
+        return ffail(nullptr, ADDER_E_BAD_PARAMS, "the SAE view exists for u8 frames only (todo!() in the reference for u16 / u32)");
     // FrameSequence::new (driver.rs:357-361)
     uint32_t tpf = p.ref_interval;
     if (p.output_fps > 0.0f) {
@@ -157,7 +162,7 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
         FHIPCHK(fr, hipStreamCreateWithFlags(&fr->stream, hipStreamNonBlocking));
         FHIPCHK(fr, hipEventCreateWithFlags(&fr->ingested, hipEventDisableTiming));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->px), (size_t)fr->n_units * sizeof(FramerPx)));
-        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->ring), (size_t)fr->ring_frames * fr->n_units));
+        FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->ring), ((size_t)fr->ring_frames * fr->n_units) << p.value_type));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->status), sizeof(uint32_t)));
         FHIPCHK(fr, hipMalloc(reinterpret_cast<void **>(&fr->minmax), 2 * sizeof(int32_t)));
         // everything a batch of <= 64 frames needs exists from here on (longer ones grow the slice table once): an
@@ -170,7 +175,7 @@ extern "C" int adder_framer_create(const AdderFramerParams *pp, AdderFramer **ou
                                   hipHostMallocDefault));
         for (hipEvent_t &e : fr->h_offs_done) FHIPCHK(fr, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         FHIPCHK(fr, hipMemsetAsync(fr->status, 0, sizeof(uint32_t), fr->stream));
-        FHIPCHK(fr, hipMemsetAsync(fr->ring, 0, (size_t)fr->ring_frames * fr->n_units, fr->stream));
+        FHIPCHK(fr, hipMemsetAsync(fr->ring, 0, ((size_t)fr->ring_frames * fr->n_units) << p.value_type, fr->stream));
         FHIPCHK(fr, adder_framer_launch_init(fr->px, fr->n_units, fr->stream));
         FHIPCHK(fr, hipStreamSynchronize(fr->stream));
         return ADDER_OK;
@@ -219,7 +224,7 @@ static FramerArgs make_args(const AdderFramer *fr) {
     a.k = framer_consts(fr->tpf, fr->p.ref_interval,
                         (fr->p.codec_version >= 2 && fr->p.time_mode == ADDER_TIME_ABSOLUTE_T) ? 1u : 0u,
                         (fr->p.codec_version >= 1 && fr->p.source_camera <= 5u) ? 1u : 0u, fr->p.view_mode,
-                        fr->p.source_type, fr->p.practical_d_max, fr->p.delta_t_max);
+                        fr->p.source_type, fr->p.practical_d_max, fr->p.delta_t_max, fr->p.value_type);
     return a;
 }
 
@@ -286,6 +291,8 @@ extern "C" int adder_framer_ingest_frames_device(AdderFramer *fr, const AdderEve
         return ffail(fr, ADDER_E_BAD_PARAMS, "null argument");
     for (uint32_t s = 0; s < num_frames; ++s)
         if (frame_offsets[s + 1] < frame_offsets[s]) return ffail(fr, ADDER_E_BAD_PARAMS, "frame offsets must not decrease");
+    // u16 / u32 frames: the per-event kernel (the tile kernel's LDS window holds bytes)
+    if (fr->p.value_type != ADDER_FRAME_U8) return adder_framer_ingest_device(fr, d_events, frame_offsets, num_frames, stream);
     FHIPCHK(fr, hipSetDevice(fr->device));
     hipStream_t s = (hipStream_t)stream;
     {
@@ -330,6 +337,9 @@ extern "C" int adder_framer_ingest_frames_device_offsets(AdderFramer *fr, const 
     if (fr->flushed_pending) return ffail(fr, ADDER_E_BAD_PARAMS, "pop the flushed frame before ingesting more events");
     if (!num_frames) return ADDER_OK;
     if (!d_frame_offsets || !d_events) return ffail(fr, ADDER_E_BAD_PARAMS, "null argument");
+    if (fr->p.value_type != ADDER_FRAME_U8)
+        return ffail(fr, ADDER_E_BAD_PARAMS, "u16 / u32 frames take their segment offsets from host memory "
+                     "(adder_framer_ingest_frames_device / adder_framer_ingest_device)");
     FHIPCHK(fr, hipSetDevice(fr->device));
     hipStream_t s = (hipStream_t)stream;
     const int rc = after_last_op(fr, s);
@@ -429,7 +439,7 @@ extern "C" int adder_framer_pop_device(AdderFramer *fr, uint8_t *d_out, uint32_t
     const uint32_t n = std::min(ready, max_frames);
     if (!n) return ADDER_OK;
     FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->px, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, n,
-                                        0u, d_out, s));
+                                        0u, d_out, fr->p.value_type, s));
     {
         const int rc_ = mark_op(fr, s);
         if (rc_ != ADDER_OK) return rc_;
@@ -452,12 +462,12 @@ extern "C" int adder_framer_pop(AdderFramer *fr, uint8_t *out, uint32_t max_fram
     if (rc != ADDER_OK) return rc;
     const uint32_t want = std::min(ready, max_frames);
     if (!want) return ADDER_OK;
-    rc = fensure(fr, &fr->d_out, &fr->d_out_cap, (size_t)want * fr->n_units);
+    rc = fensure(fr, &fr->d_out, &fr->d_out_cap, ((size_t)want * fr->n_units) << fr->p.value_type);
     if (rc != ADDER_OK) return rc;
     uint32_t n = 0;
     rc = adder_framer_pop_device(fr, fr->d_out, want, &n, fr->stream);
     if (rc != ADDER_OK) return rc;
-    FHIPCHK(fr, hipMemcpyAsync(out, fr->d_out, (size_t)n * fr->n_units, hipMemcpyDeviceToHost, fr->stream));
+    FHIPCHK(fr, hipMemcpyAsync(out, fr->d_out, ((size_t)n * fr->n_units) << fr->p.value_type, hipMemcpyDeviceToHost, fr->stream));
     FHIPCHK(fr, hipStreamSynchronize(fr->stream));
     *n_popped = n;
     return ADDER_OK;
@@ -469,13 +479,13 @@ extern "C" int adder_framer_write_frame(AdderFramer *fr, uint8_t *out) {
     FHIPCHK(fr, hipSetDevice(fr->device));
     int rc = check_status(fr);
     if (rc != ADDER_OK) return rc;
-    rc = fensure(fr, &fr->d_out, &fr->d_out_cap, (size_t)fr->n_units);
+    rc = fensure(fr, &fr->d_out, &fr->d_out_cap, (size_t)fr->n_units << fr->p.value_type);
     if (rc != ADDER_OK) return rc;
     // frame 0 as it is: pixels that have no value yet read 0 (driver.rs:946-950); after a flush
     // every pixel has one
     FHIPCHK(fr, adder_framer_launch_pop(fr->ring, fr->px, fr->n_units, fr->ring_frames, (int32_t)fr->frames_written, 1u,
-                                        fr->flushed_pending ? 0u : 1u, fr->d_out, fr->stream));
-    FHIPCHK(fr, hipMemcpyAsync(out, fr->d_out, fr->n_units, hipMemcpyDeviceToHost, fr->stream));
+                                        fr->flushed_pending ? 0u : 1u, fr->d_out, fr->p.value_type, fr->stream));
+    FHIPCHK(fr, hipMemcpyAsync(out, fr->d_out, (size_t)fr->n_units << fr->p.value_type, hipMemcpyDeviceToHost, fr->stream));
     FHIPCHK(fr, hipStreamSynchronize(fr->stream));
     fr->frames_written += 1;
     fr->flushed_pending = false;
@@ -499,7 +509,7 @@ extern "C" int adder_framer_flush(AdderFramer *fr, int *frame0_ready) {
     // `any chunk.len() > 1` (driver.rs:635-639): some pixel has reached beyond frame 0
     if ((int64_t)mx > fr->frames_written) {
         FHIPCHK(fr, adder_framer_launch_flush(fr->ring, fr->px, fr->n_units, fr->ring_frames,
-                                              (int32_t)fr->frames_written, fr->stream));
+                                              (int32_t)fr->frames_written, fr->p.value_type, fr->stream));
         FHIPCHK(fr, hipStreamSynchronize(fr->stream));
         fr->flushed_pending = true;
         if (frame0_ready) *frame0_ready = 1;

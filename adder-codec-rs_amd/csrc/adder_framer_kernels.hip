@@ -19,6 +19,14 @@
 
 namespace adder {
 
+// an element of the frame ring: u8 / u16 / u32 by FramerConsts::value_type (host byte order; the pop kernel writes the
+// reference's big-endian bincode bytes)
+__device__ __forceinline__ void framer_ring_store(uint8_t *ring, size_t idx, uint32_t value_type, uint32_t v) {
+    if (value_type == 0u) ring[idx] = (uint8_t)v;
+    else if (value_type == 1u) reinterpret_cast<uint16_t *>(ring)[idx] = (uint16_t)v;
+    else reinterpret_cast<uint32_t *>(ring)[idx] = v;
+}
+
 __device__ __forceinline__ uint32_t unit_of(const FramerArgs &a, uint32_t xy, uint32_t cd, bool &ok) {
     const uint32_t x = xy & 0xffffu, y = xy >> 16;
     uint32_t c = cd & 0xffu;
@@ -71,7 +79,7 @@ __device__ __forceinline__ void framer_apply_run(const uint32_t *__restrict__ ev
                     flags |= kFramerStatusRing;
                     break;
                 }
-                a.ring[(size_t)((uint32_t)f % a.ring_frames) * a.n_units + u] = (uint8_t)p.lasti;
+                framer_ring_store(a.ring, (size_t)((uint32_t)f % a.ring_frames) * a.n_units + u, a.k.value_type, p.lasti);
             }
         }
     }
@@ -579,8 +587,24 @@ __global__ __launch_bounds__(256) void adder_framer_minmax_kernel(const FramerPx
 __global__ __launch_bounds__(256) void adder_framer_pop_kernel(const uint8_t *__restrict__ ring,
                                                                const FramerPx *__restrict__ px, uint32_t n_units,
                                                                uint32_t ring_frames, int32_t f0, uint32_t masked,
-                                                               uint8_t *__restrict__ out) {
+                                                               uint8_t *__restrict__ out, uint32_t value_type) {
     const uint32_t f = (uint32_t)f0 + blockIdx.y;
+    if (value_type != 0u) {  // u16 / u32 elements: big-endian bytes (bincode fixint BE, driver.rs:279,395-398)
+        const size_t base = (size_t)(f % ring_frames) * n_units;
+        uint8_t *dst = out + ((size_t)blockIdx.y * n_units << value_type);
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_units; i += gridDim.x * 256u) {
+            const bool has = !masked || px[i].lastf >= (int32_t)f;
+            if (value_type == 1u) {
+                const uint32_t v = has ? reinterpret_cast<const uint16_t *>(ring)[base + i] : 0u;
+                dst[2u * i] = (uint8_t)(v >> 8);
+                dst[2u * i + 1u] = (uint8_t)v;
+            } else {
+                const uint32_t v = has ? reinterpret_cast<const uint32_t *>(ring)[base + i] : 0u;
+                reinterpret_cast<uint32_t *>(dst)[i] = __builtin_bswap32(v);
+            }
+        }
+        return;
+    }
     const uint8_t *src = ring + (size_t)(f % ring_frames) * n_units;
     uint8_t *dst = out + (size_t)blockIdx.y * n_units;
     for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n_units; i += gridDim.x * 1024u) {
@@ -596,12 +620,12 @@ __global__ __launch_bounds__(256) void adder_framer_pop_kernel(const uint8_t *__
 // flush_frame_buffer (driver.rs:632-677): every pixel without a value in frame f0 gets its last
 // intensity there and its last_filled advances by ONE (as the reference does)
 __global__ __launch_bounds__(256) void adder_framer_flush_kernel(uint8_t *ring, FramerPx *px, uint32_t n_units,
-                                                                 uint32_t ring_frames, int32_t f0) {
+                                                                 uint32_t ring_frames, int32_t f0, uint32_t value_type) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_units) return;
     const int32_t lf = px[i].lastf;
     if (lf < f0) {
-        ring[(size_t)((uint32_t)f0 % ring_frames) * n_units + i] = (uint8_t)px[i].lasti;
+        framer_ring_store(ring, (size_t)((uint32_t)f0 % ring_frames) * n_units + i, value_type, px[i].lasti);
         px[i].lastf = lf + 1;
     }
 }
@@ -654,18 +678,18 @@ extern "C" hipError_t adder_framer_launch_minmax(const FramerPx *px, uint32_t n,
 }
 extern "C" hipError_t adder_framer_launch_pop(const uint8_t *ring, const FramerPx *px, uint32_t n_units,
                                               uint32_t ring_frames, int32_t f0, uint32_t nf, uint32_t masked,
-                                              uint8_t *out, hipStream_t s) {
+                                              uint8_t *out, uint32_t value_type, hipStream_t s) {
     if (!nf) return hipSuccess;
     uint32_t gx = (n_units + 1023u) / 1024u;
     gx = gx > 2048u ? 2048u : gx;
     hipLaunchKernelGGL(adder_framer_pop_kernel, dim3(gx, nf), dim3(256), 0, s, ring, px, n_units, ring_frames, f0,
-                       masked, out);
+                       masked, out, value_type);
     return hipGetLastError();
 }
 extern "C" hipError_t adder_framer_launch_flush(uint8_t *ring, FramerPx *px, uint32_t n_units, uint32_t ring_frames,
-                                                int32_t f0, hipStream_t s) {
+                                                int32_t f0, uint32_t value_type, hipStream_t s) {
     hipLaunchKernelGGL(adder_framer_flush_kernel, dim3((n_units + 255u) / 256u), dim3(256), 0, s, ring, px, n_units,
-                       ring_frames, f0);
+                       ring_frames, f0, value_type);
     return hipGetLastError();
 }
 extern "C" hipError_t adder_framer_launch_init(FramerPx *px, uint32_t n, hipStream_t s) {

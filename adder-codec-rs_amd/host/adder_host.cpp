@@ -905,9 +905,9 @@ double Framed::get_running_input_bitrate() const {
 // ================================================================ framer (framer/driver.rs)
 namespace adder_host {
 
-std::unique_ptr<FrameSequenceU8> FramerBuilder::finish() { return std::make_unique<FrameSequenceU8>(*this); }
+std::unique_ptr<FrameSequence> FramerBuilder::finish(FrameElement element) { return std::make_unique<FrameSequence>(*this, element); }
 
-FrameSequenceU8::FrameSequenceU8(const FramerBuilder &b) : chunk_rows(b.chunk_rows_) {
+FrameSequence::FrameSequence(const FramerBuilder &b, FrameElement element) : chunk_rows(b.chunk_rows_) {
     if (b.chunk_rows_ == 0) throw SourceError(SourceError::BadParams, "chunk_rows must be > 0");  // assert (:306)
     (void)b.mode_;  // driver.rs:270,383: stored and never read, INTEGRATION ingests like INSTANTANEOUS
     AdderFramerParams p;
@@ -923,38 +923,40 @@ FrameSequenceU8::FrameSequenceU8(const FramerBuilder &b) : chunk_rows(b.chunk_ro
     p.ring_frames = b.ring_frames_;
     p.view_mode = (uint8_t)b.view_mode_;
     p.source_type = (uint8_t)b.source_type_;
+    p.value_type = (uint8_t)element;
     p.practical_d_max = b.practical_d_max_ ? *b.practical_d_max_
                                            : std::log2f(255.0f * (float)(b.delta_t_max_ / (b.ref_interval_ ? b.ref_interval_ : 1u)));
     if (adder_framer_create(&p, &fr_) != ADDER_OK)
         throw SourceError(SourceError::BadParams, std::string("framer: ") + adder_framer_last_error(nullptr));
     num_chunks_ = (b.plane_.h() + b.chunk_rows_ - 1) / b.chunk_rows_;
-    frame_bytes_ = (size_t)b.plane_.w() * b.plane_.h() * b.plane_.c();
+    frame_units_ = (size_t)b.plane_.w() * b.plane_.h() * b.plane_.c();
+    frame_bytes_ = frame_units_ << (unsigned)element;
     width_ = b.plane_.w();
     height_ = b.plane_.h();
     channels_ = b.plane_.c();
 }
 
-FrameSequenceU8::~FrameSequenceU8() { adder_framer_destroy(fr_); }
-uint32_t FrameSequenceU8::tpf() const { return adder_framer_tpf(fr_); }
-int64_t FrameSequenceU8::frames_written() const { return adder_framer_frames_written(fr_); }
+FrameSequence::~FrameSequence() { adder_framer_destroy(fr_); }
+uint32_t FrameSequence::tpf() const { return adder_framer_tpf(fr_); }
+int64_t FrameSequence::frames_written() const { return adder_framer_frames_written(fr_); }
 
 static void framer_check(AdderFramer *fr, int rc) {
     if (rc != ADDER_OK) throw SourceError(SourceError::BadParams, std::string("framer: ") + adder_framer_last_error(fr));
 }
 
-bool FrameSequenceU8::is_frame_0_filled() {
+bool FrameSequence::is_frame_0_filled() {
     uint32_t n = 0;
     framer_check(fr_, adder_framer_frames_ready(fr_, &n));
     return n > 0;
 }
 
-bool FrameSequenceU8::ingest_event(Event &event) {
+bool FrameSequence::ingest_event(Event &event) {
     const uint64_t offs[2] = {0, 1};
     framer_check(fr_, adder_framer_ingest(fr_, &event, offs, 1));
     return is_frame_0_filled();
 }
 
-bool FrameSequenceU8::ingest_events_events(const std::vector<std::vector<Event>> &events) {
+bool FrameSequence::ingest_events_events(const std::vector<std::vector<Event>> &events) {
     // "Make sure that the chunk division is aligned between the source and the framer" (:566)
     if (events.size() != num_chunks_) throw SourceError(SourceError::BadParams, "events.len() != number of framer chunks");
     flat_.clear();
@@ -962,7 +964,7 @@ bool FrameSequenceU8::ingest_events_events(const std::vector<std::vector<Event>>
     // The device wants segments in which a pixel-channel's events are contiguous.  One source frame's events (what
     // SimulProcessor hands over) are one such segment; any other list is cut where a pixel comes back.
     seg_offs_.assign(1, 0);
-    seen_.assign(frame_bytes_, 0xffffffffu);
+    seen_.assign(frame_units_, 0xffffffffu);
     uint32_t seg = 0;
     size_t prev = SIZE_MAX;
     for (size_t i = 0; i < flat_.size(); ++i) {
@@ -982,19 +984,19 @@ bool FrameSequenceU8::ingest_events_events(const std::vector<std::vector<Event>>
     return is_frame_0_filled();
 }
 
-bool FrameSequenceU8::flush_frame_buffer() {
+bool FrameSequence::flush_frame_buffer() {
     int ready = 0;
     framer_check(fr_, adder_framer_flush(fr_, &ready));
     return ready != 0;
 }
 
-void FrameSequenceU8::write_frame_bytes(std::ostream &writer) {
+void FrameSequence::write_frame_bytes(std::ostream &writer) {
     out_.resize(frame_bytes_);
     framer_check(fr_, adder_framer_write_frame(fr_, out_.data()));
     writer.write(reinterpret_cast<const char *>(out_.data()), (std::streamsize)frame_bytes_);
 }
 
-int FrameSequenceU8::write_multi_frame_bytes(std::ostream &writer) {
+int FrameSequence::write_multi_frame_bytes(std::ostream &writer) {
     int frames = 0;
     for (;;) {
         out_.resize(frame_bytes_ * 64);

@@ -412,7 +412,10 @@ enum class FramerMode { INSTANTANEOUS, INTEGRATION };  // driver.rs:20-28; store
 enum class SourceType { U8, U16, U32, U64 };           // what the Intensity view divides by (scale_intensity.rs:68-75); F32 / F64 panic there
 enum class FramedViewMode { Intensity, D, DeltaT, SAE };  // video.rs:144-158
 
-class FrameSequenceU8;
+class FrameSequence;
+using FrameSequenceU8 = FrameSequence;
+// the T of FramerBuilder::finish::<T>() (driver.rs:126-138; T: FrameValue, scale_intensity.rs:54-209)
+enum class FrameElement : uint8_t { U8 = 0, U16 = 1, U32 = 2 };
 
 class FramerBuilder {  // driver.rs:36-147
   public:
@@ -433,10 +436,12 @@ class FramerBuilder {  // driver.rs:36-147
     FramerBuilder &device(int device_id) { device_id_ = device_id; return *this; }
     // frames the device ring holds (the reference's VecDeque grows without bound, :1066-1090); 0 = delta_t_max / tpf + 80
     FramerBuilder &ring_frames(uint32_t n) { ring_frames_ = n; return *this; }
-    std::unique_ptr<FrameSequenceU8> finish();  // :126-138, T = u8
+    // :126-138.  finish() is finish::<u8>(); u16 / u32 frames are written as the big-endian bincode elements of
+    // driver.rs:279,944.  (finish::<u64>() does not compile in the reference: FrameSequence<T> needs T: Into<f64>.)
+    std::unique_ptr<FrameSequence> finish(FrameElement element = FrameElement::U8);
 
   private:
-    friend class FrameSequenceU8;
+    friend class FrameSequence;
     PlaneSize plane_;
     size_t chunk_rows_;
     uint32_t tps_ = 150000, ref_interval_ = 5000, delta_t_max_ = 5000;  // FramerBuilder::new defaults (:60-65)
@@ -452,13 +457,13 @@ class FramerBuilder {  // driver.rs:36-147
     uint32_t ring_frames_ = 0;
 };
 
-// FrameSequence<u8> (driver.rs:261-981); the per-pixel work runs behind include/adder_framer.h
-class FrameSequenceU8 {
+// FrameSequence<T> (driver.rs:261-981), T = u8 / u16 / u32; the per-pixel work runs behind include/adder_framer.h
+class FrameSequence {
   public:
-    explicit FrameSequenceU8(const FramerBuilder &b);
-    ~FrameSequenceU8();
-    FrameSequenceU8(const FrameSequenceU8 &) = delete;
-    FrameSequenceU8 &operator=(const FrameSequenceU8 &) = delete;
+    explicit FrameSequence(const FramerBuilder &b, FrameElement element = FrameElement::U8);
+    ~FrameSequence();
+    FrameSequence(const FrameSequence &) = delete;
+    FrameSequence &operator=(const FrameSequence &) = delete;
     bool ingest_event(Event &event);                                          // :437-562 -> frame 0 filled?
     bool ingest_events_events(const std::vector<std::vector<Event>> &events); // :564-626
     bool flush_frame_buffer();                                                // :632-677
@@ -471,7 +476,7 @@ class FrameSequenceU8 {
 
   private:
     AdderFramer *fr_ = nullptr;
-    size_t num_chunks_ = 0, frame_bytes_ = 0;
+    size_t num_chunks_ = 0, frame_units_ = 0, frame_bytes_ = 0;
     size_t width_ = 0, height_ = 0, channels_ = 0;
     std::vector<Event> flat_;
     std::vector<uint64_t> seg_offs_;

@@ -281,7 +281,8 @@ long long adder_host_simulproc(const uint8_t *frames, uint32_t num_frames, uint3
 // FramerBuilder -> FrameSequence<u8> over events in memory: one ingest_events_events call (chunk_offsets has
 // n_chunks + 1 entries, the framer's chunk division), write_multi_frame_bytes, then `flushes` rounds of
 // flush_frame_buffer + write_frame_bytes.  params = {tps, ref_interval, delta_t_max, codec_version, time_mode,
-// framer mode, view mode, source type, chunk_rows}.  Returns the bytes written to out (needs <= cap), or -1.
+// framer mode, view mode, source type, chunk_rows, frame element type (0 u8 / 1 u16 / 2 u32)}.  Returns the bytes
+// written to out (needs <= cap), or -1.
 long long adder_host_frame_events(const AdderEvent *events, const uint64_t *chunk_offsets, uint32_t n_chunks,
                                   uint16_t width, uint16_t height, uint8_t channels, const uint32_t *params,
                                   float output_fps, float practical_d_max, uint32_t flushes, uint8_t *out, size_t cap) {
@@ -295,7 +296,7 @@ long long adder_host_frame_events(const AdderEvent *events, const uint64_t *chun
             .source((SourceType)params[7], SourceCamera::FramedU8)
             .ring_frames(1u << 14);
         if (practical_d_max > 0.0f) b.practical_d_max(practical_d_max);
-        auto fr = b.finish();
+        auto fr = b.finish((FrameElement)params[9]);
         std::vector<std::vector<Event>> chunks(n_chunks);
         for (uint32_t k = 0; k < n_chunks; ++k) chunks[k].assign(events + chunk_offsets[k], events + chunk_offsets[k + 1]);
         std::ostringstream os;

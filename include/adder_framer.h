@@ -1,6 +1,6 @@
-/* adder_framer.h -- C-ABI of the MI355X-native framer (ADDER events -> u8 frames).
+/* adder_framer.h -- C-ABI of the MI355X-native framer (ADDER events -> u8 / u16 / u32 frames).
  *
- * Replaces, for T = u8, the
+ * Replaces, for T = u8 / u16 / u32 (value_type), the
  * reference's FrameSequence<u8> (adder-codec-rs/src/framer/driver.rs):
  *   FramerBuilder::new / time_parameters / codec_version / source / finish   driver.rs:55-138
  *   Framer::ingest_event / ingest_events_events                               driver.rs:437-626 (+ :984-1133)
@@ -16,8 +16,10 @@
  * Views: every arm of <u8 as FrameValue>::get_frame_value (scale_intensity.rs:54-109) -- Intensity for U8 / U16 /
  * U32 / U64 sources, D, DeltaT, SAE -- through view_mode / source_type below.  FramerMode::INTEGRATION needs no
  * switch: the reference stores the mode (driver.rs:270, 383) and never reads it, both modes ingest alike.
- * Not built: u16/u32/u64/EventCoordless frame element types (the reference's own writers and tests use u8),
- * feature detection on frames, buffer_limit.
+ * Frame element types: u8, and u16 / u32 (<u16 / u32 as FrameValue>, scale_intensity.rs:111-209) whose frames are popped
+ * as the big-endian bincode bytes the reference's writers produce (driver.rs:279,395-398,944).  FrameSequence<u64> cannot
+ * be instantiated in the reference (its methods need T: Into<f64>).  Not built: EventCoordless frames, feature detection
+ * on frames, buffer_limit.
  */
 #ifndef ADDER_FRAMER_H
 #define ADDER_FRAMER_H
@@ -49,7 +51,9 @@ typedef struct AdderFramerParams {
     /* what a frame's byte shows: <u8 as FrameValue>::get_frame_value (framer/scale_intensity.rs:54-109) */
     uint8_t view_mode;      /* FramedViewMode (video.rs:144-158): 0 Intensity, 1 D, 2 DeltaT, 3 SAE */
     uint8_t source_type;    /* SourceType of the intensities (Intensity view): 0 U8, 1 U16, 2 U32, 3 U64 */
-    uint8_t reserved1[2];
+    uint8_t value_type;     /* the frame element type T: ADDER_FRAME_U8 (0, default) / _U16 / _U32; pops hand out
+                             * [n][rows][width][channels] elements of 1 / 2 / 4 bytes, big-endian */
+    uint8_t reserved1;
     float practical_d_max;  /* D view: fast_math::log2_raw(255.0 * (delta_t_max / ref_interval) as f32), computed by
                              * the caller (driver.rs:1020-1021; the approximation belongs to a third-party crate) */
 } AdderFramerParams;
@@ -58,6 +62,9 @@ typedef struct AdderFramerParams {
 #define ADDER_VIEW_D 1
 #define ADDER_VIEW_DELTA_T 2
 #define ADDER_VIEW_SAE 3
+#define ADDER_FRAME_U8 0
+#define ADDER_FRAME_U16 1
+#define ADDER_FRAME_U32 2
 
 typedef struct AdderFramer AdderFramer;
 

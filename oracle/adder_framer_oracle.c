@@ -35,8 +35,8 @@ typedef struct {
 } OracleEvent;
 
 typedef struct {
-    uint8_t *val;  /* Option<u8> payload */
-    uint8_t *some; /* Option<u8> discriminant */
+    uint32_t *val; /* Option<T> payload, T = u8 / u16 / u32 (value_type) */
+    uint8_t *some; /* Option<T> discriminant */
     size_t filled_count;
 } OFrame;
 
@@ -62,7 +62,7 @@ typedef struct {
     int64_t *frame_idx_offsets;
     uint64_t **pixel_ts;
     int64_t **last_filled;
-    uint8_t **last_intensity;
+    uint32_t **last_intensity;
     uint8_t *chunk_filled;
     int has_buffer_limit;
     uint32_t buffer_limit;
@@ -70,10 +70,13 @@ typedef struct {
      * (fast_math::log2_raw, a third-party approximation that is not restated here) */
     int view_mode, source_type;
     float practical_d_max;
+    /* the frame element type T of FrameSequence<T>: 0 u8, 1 u16, 2 u32 (scale_intensity.rs:54-211).  FrameSequence<u64>
+     * cannot be instantiated in the reference (its methods need T: Into<f64>, driver.rs:135,298,689,985, which u64 is not) */
+    int value_type;
 } OracleFramer;
 
 static void frame_init(OFrame *f, size_t px) {
-    f->val = (uint8_t *)calloc(px ? px : 1, 1);
+    f->val = (uint32_t *)calloc(px ? px : 1, sizeof(uint32_t));
     f->some = (uint8_t *)calloc(px ? px : 1, 1);
     f->filled_count = 0;
 }
@@ -107,7 +110,7 @@ OracleFramer *oracle_framer_new(uint16_t w, uint16_t h, uint8_t c, uint32_t chun
     f->frame_idx_offsets = (int64_t *)calloc(f->num_chunks, sizeof(int64_t));
     f->pixel_ts = (uint64_t **)calloc(f->num_chunks, sizeof(void *));
     f->last_filled = (int64_t **)calloc(f->num_chunks, sizeof(void *));
-    f->last_intensity = (uint8_t **)calloc(f->num_chunks, sizeof(void *));
+    f->last_intensity = (uint32_t **)calloc(f->num_chunks, sizeof(void *));
     f->chunk_filled = (uint8_t *)calloc(f->num_chunks, 1);
     for (size_t k = 0; k < f->num_chunks; ++k) {
         const size_t rows = k + 1 == f->num_chunks ? last_rows : chunk_rows;
@@ -117,7 +120,7 @@ OracleFramer *oracle_framer_new(uint16_t w, uint16_t h, uint8_t c, uint32_t chun
         f->pixel_ts[k] = (uint64_t *)calloc(px, sizeof(uint64_t));
         f->last_filled[k] = (int64_t *)malloc(px * sizeof(int64_t));
         for (size_t i = 0; i < px; ++i) f->last_filled[k][i] = -1; /* :351-355 */
-        f->last_intensity[k] = (uint8_t *)calloc(px, 1);
+        f->last_intensity[k] = (uint32_t *)calloc(px, sizeof(uint32_t));
     }
     /* :357-361: tpf = (tps as f32 / output_fps) as u32, or ref_interval */
     if (output_fps >= 0.0f) {
@@ -161,6 +164,11 @@ void oracle_framer_set_view(OracleFramer *f, int view_mode, int source_type, flo
     f->view_mode = view_mode;
     f->source_type = source_type;
     f->practical_d_max = practical_d_max;
+}
+int oracle_framer_set_value_type(OracleFramer *f, int value_type) {
+    if (value_type < 0 || value_type > 2) return -1;
+    f->value_type = value_type;
+    return 0;
 }
 uint32_t oracle_framer_tpf(const OracleFramer *f) { return f->tpf; }
 int64_t oracle_framer_frames_written(const OracleFramer *f) { return f->frames_written; }
@@ -225,12 +233,46 @@ static uint8_t get_frame_value_u8(uint8_t d, uint32_t t, int source, double tpf,
     }
 }
 
+/* Rust's `as u16` / `as u32` from a float: saturating, NaN -> 0 */
+static uint32_t f64_as_uint(double v, double max) {
+    if (!(v > 0.0)) return 0;
+    if (v >= max) return (uint32_t)max;
+    return (uint32_t)v;
+}
+static uint32_t f32_as_uint(float v, double max) {
+    if (!(v > 0.0f)) return 0;
+    if ((double)v >= max) return (uint32_t)max;
+    return (uint32_t)v;
+}
+/* <u16 as FrameValue>::get_frame_value (scale_intensity.rs:111-160) and <u32 ...> (:162-209); SAE is todo!() there.
+ * value_type 1: u16, 2: u32.  Returns -1 for the arms the reference does not implement. */
+static int get_frame_value_wide(int value_type, uint8_t d, uint32_t t, int source, double tpf, float practical_d_max,
+                                uint32_t delta_t_max, int view, uint32_t *out) {
+    const double tmax = value_type == 1 ? 65535.0 : 4294967295.0;
+    /* f32::from(u16::MAX) = 65535.0; u32::MAX as f32 = 4294967296.0 (rounded to the nearest f32) */
+    const float tmax_f32 = value_type == 1 ? 65535.0f : 4294967296.0f;
+    switch (view) {
+    case 1: *out = f32_as_uint(((float)d / practical_d_max) * tmax_f32, tmax); return 0;
+    case 2: *out = f32_as_uint(((float)t / (float)delta_t_max) * tmax_f32, tmax); return 0;
+    case 3: return -1; /* todo!() */
+    default: break;
+    }
+    const double intensity = event_to_intensity(d, t);
+    if (source == value_type) { /* the source's own type: (intensity * tpf) as T */
+        *out = f64_as_uint(intensity * tpf, tmax);
+        return 0;
+    }
+    const double smax = source == 0 ? 255.0 : source == 1 ? 65535.0 : source == 2 ? 4294967295.0 : 18446744073709551615.0;
+    *out = f64_as_uint(intensity / smax * tpf * tmax, tmax);
+    return 0;
+}
+
 static int is_framed_camera(uint32_t cam) { return cam <= 5u; } /* FramedU8..FramedF64 (lib.rs:35-47) */
 
 /* ingest_event_for_chunk (driver.rs:984-1133).  ev->y is already chunk-local.  Returns filled;
  * *grew_out as in the reference. */
 static int ingest_event_for_chunk(OracleFramer *f, OracleEvent *ev, ODeque *chunk, uint64_t *running_ts,
-                                  int64_t *frame_idx_offset, int64_t *last_filled, uint8_t *last_intensity,
+                                  int64_t *frame_idx_offset, int64_t *last_filled, uint32_t *last_intensity,
                                   int *grew_out) {
     const uint8_t channel = ev->c == 0xFF ? 0 : ev->c;
     int grew = 0;
@@ -255,7 +297,11 @@ static int ingest_event_for_chunk(OracleFramer *f, OracleEvent *ev, ODeque *chun
                 const uint32_t p = (uint32_t)prev_running_ts;
                 ev->t = ev->t > p ? ev->t - p : 0u; /* saturating_sub */
             }
-            if (f->view_mode == 0 && f->source_type == 0)
+            if (f->value_type != 0) {
+                if (get_frame_value_wide(f->value_type, ev->d, ev->t, f->source_type, (double)f->ref_interval,
+                                         f->practical_d_max, f->source_dtm, f->view_mode, last_intensity) != 0)
+                    abort(); /* todo!() in the reference */
+            } else if (f->view_mode == 0 && f->source_type == 0)
                 *last_intensity = frame_value_u8(ev->d, ev->t, (double)f->ref_interval);
             else
                 *last_intensity = get_frame_value_u8(ev->d, ev->t, f->source_type, (double)f->ref_interval,
@@ -402,7 +448,12 @@ size_t oracle_framer_write_frame_bytes(OracleFramer *f, uint8_t *out) {
     for (size_t k = 0; k < f->num_chunks; ++k) {
         OFrame fr;
         pop_next_frame_for_chunk(f, k, &fr);
-        for (size_t i = 0; i < f->frames[k].px; ++i) out[n++] = fr.some[i] ? fr.val[i] : 0;
+        for (size_t i = 0; i < f->frames[k].px; ++i) { /* bincode fixint, big-endian (driver.rs:279,395-398) */
+            const uint32_t v = fr.some[i] ? fr.val[i] : 0u;
+            if (f->value_type == 2) { out[n++] = (uint8_t)(v >> 24); out[n++] = (uint8_t)(v >> 16); }
+            if (f->value_type >= 1) out[n++] = (uint8_t)(v >> 8);
+            out[n++] = (uint8_t)v;
+        }
         frame_free(&fr);
     }
     f->frames_written += 1;
@@ -412,7 +463,7 @@ size_t oracle_framer_write_frame_bytes(OracleFramer *f, uint8_t *out) {
 /* write_multi_frame_bytes (driver.rs:970-981): frames written, or -1 if is_frame_filled errs or
  * the buffer is too small; *bytes_out = bytes appended. */
 int oracle_framer_write_multi_frame_bytes(OracleFramer *f, uint8_t *out, size_t cap, size_t *bytes_out) {
-    const size_t frame_bytes = (size_t)f->w * f->h * f->c;
+    const size_t frame_bytes = ((size_t)f->w * f->h * f->c) << f->value_type;
     int frames = 0;
     size_t n = 0;
     for (;;) {

@@ -365,6 +365,13 @@ class Framer:
         self.chunk_rows = chunk_rows
         self.num_chunks = self.L.oracle_framer_num_chunks(self.h)
 
+    def set_value_type(self, value_type):
+        """The frame element type T of FrameSequence<T>: 0 u8, 1 u16, 2 u32 (big-endian in the written bytes)."""
+        self.L.oracle_framer_set_value_type.argtypes = [C.c_void_p, C.c_int]
+        if self.L.oracle_framer_set_value_type(self.h, value_type) != 0:
+            raise ValueError("value_type must be 0, 1 or 2")
+        self.frame_bytes = (self.width * self.height * self.channels) << value_type
+
     def set_view(self, view_mode, source_type=0, practical_d_max=0.0):
         """FramerBuilder::view_mode / ::source: 0 Intensity, 1 D, 2 DeltaT, 3 SAE; source 0 U8 .. 3 U64."""
         self.L.oracle_framer_set_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]

@@ -520,7 +520,7 @@ extern "C" uint64_t sim_fast_div_check(uint32_t d, const uint32_t *n, size_t cou
     return bad;
 }
 
-static uint32_t g_view_mode = 0, g_source_type = 0, g_view_dtm = 0;
+static uint32_t g_view_mode = 0, g_source_type = 0, g_view_dtm = 0, g_value_type = 0;
 static float g_practical_d_max = 0.0f;
 // what the next sim_framer_run shows (FramedViewMode / SourceType; 0, 0 = the U8 Intensity view)
 extern "C" void sim_framer_set_view(uint32_t view_mode, uint32_t source_type, float practical_d_max, uint32_t delta_t_max) {
@@ -529,6 +529,8 @@ extern "C" void sim_framer_set_view(uint32_t view_mode, uint32_t source_type, fl
     g_practical_d_max = practical_d_max;
     g_view_dtm = delta_t_max;
 }
+// the frame element type T of the next sim_framer_run: 0 u8, 1 u16, 2 u32 (elements come out big-endian)
+extern "C" void sim_framer_set_value_type(uint32_t value_type) { g_value_type = value_type; }
 
 extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, uint32_t height, uint32_t channels,
                                   uint32_t tpf, uint32_t ref_interval, uint32_t abs_t, uint32_t round_up,
@@ -537,8 +539,10 @@ extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, 
     const size_t units = (size_t)width * height * channels;
     std::vector<FramerPx> px(units);
     for (auto &p : px) { p.ts = 0; p.lastf = -1; p.lasti = 0; }
-    std::vector<uint8_t> frames;
-    const FramerConsts k = framer_consts(tpf, ref_interval, abs_t, round_up, g_view_mode, g_source_type, g_practical_d_max, g_view_dtm);
+    std::vector<uint32_t> frames;
+    const FramerConsts k = framer_consts(tpf, ref_interval, abs_t, round_up, g_view_mode, g_source_type, g_practical_d_max, g_view_dtm,
+                                         g_value_type);
+    const size_t elem = (size_t)1 << g_value_type;
     for (size_t i = 0; i < n; ++i) {
         const uint32_t c = ev[i].c == 0xFF ? 0u : ev[i].c;
         if (ev[i].x >= width || ev[i].y >= height || c >= channels) return -1;
@@ -547,7 +551,7 @@ extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, 
         bool overflow = false;
         if (framer_step(px[u], ev[i].d, ev[i].t, k, from, to, overflow)) {
             if ((size_t)(to + 1) * units > frames.size()) frames.resize((size_t)(to + 1) * units, 0);
-            for (int32_t f = from + 1; f <= to; ++f) frames[(size_t)f * units + u] = (uint8_t)px[u].lasti;
+            for (int32_t f = from + 1; f <= to; ++f) frames[(size_t)f * units + u] = px[u].lasti;
         }
         if (overflow) return -2;
     }
@@ -555,6 +559,7 @@ extern "C" int64_t sim_framer_run(const SimEvent *ev, size_t n, uint32_t width, 
     for (auto &p : px) mn = p.lastf < mn ? p.lastf : mn;
     const int64_t complete = (int64_t)mn + 1;
     if (complete > (int64_t)out_cap_frames) return -3;
-    if (complete > 0) memcpy(out, frames.data(), (size_t)complete * units);
+    for (size_t i = 0; complete > 0 && i < (size_t)complete * units; ++i)
+        for (size_t b = 0; b < elem; ++b) out[i * elem + b] = (uint8_t)(frames[i] >> (8 * (elem - 1 - b)));
     return complete;
 }

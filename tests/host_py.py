@@ -175,12 +175,12 @@ def davis(packets, width, height, mode, *, tps, ref_time, delta_t_max, time_mode
 
 def frame_events(events, chunk_offsets, width, height, channels, *, tps, ref_interval, delta_t_max, codec_version,
                  time_mode, chunk_rows, output_fps=0.0, framer_mode=0, view_mode=0, source_type=0, practical_d_max=0.0,
-                 flushes=0, cap=1 << 26):
+                 flushes=0, cap=1 << 26, value_type=0):
     """FramerBuilder ... finish() -> ingest_events_events -> write_multi_frame_bytes (+ flushes) of the C++ mirror."""
     ev = np.ascontiguousarray(events, adder_amd.EVENT_DTYPE)
     offs = np.ascontiguousarray(chunk_offsets, np.uint64)
     params = np.array([tps, ref_interval, delta_t_max, codec_version, time_mode, framer_mode, view_mode, source_type,
-                       chunk_rows], np.uint32)
+                       chunk_rows, value_type], np.uint32)
     out = np.zeros(cap, np.uint8)
     n = lib().adder_host_frame_events(ev.ctypes.data, offs.ctypes.data, len(offs) - 1, width, height, channels,
                                       params.ctypes.data, output_fps, practical_d_max, flushes, out.ctypes.data, cap)

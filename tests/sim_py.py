@@ -79,17 +79,19 @@ def fast9_plane(img):
 
 
 def framer_run(events, width, height, channels, *, tpf, ref_interval, abs_t, round_up, max_frames=4096, view_mode=0,
-               source_type=0, practical_d_max=0.0, delta_t_max=0):
+               source_type=0, practical_d_max=0.0, delta_t_max=0, value_type=0):
     """All events through the device header's framer_step on the host -> bytes of the complete frames."""
     ev = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
     lib().sim_framer_set_view.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
     lib().sim_framer_set_view(view_mode, source_type, practical_d_max, delta_t_max)
-    out = np.zeros(max_frames * width * height * channels, np.uint8)
+    lib().sim_framer_set_value_type.argtypes = [C.c_uint32]
+    lib().sim_framer_set_value_type(value_type)
+    out = np.zeros((max_frames * width * height * channels) << value_type, np.uint8)
     n = lib().sim_framer_run(ev.ctypes.data, len(ev), width, height, channels, tpf, ref_interval, int(abs_t),
                              int(round_up), out.ctypes.data, max_frames)
     if n < 0:
         raise RuntimeError(f"sim_framer_run failed: {n}")
-    return out[: n * width * height * channels].tobytes()
+    return out[: (n * width * height * channels) << value_type].tobytes()
 
 
 class Sim:

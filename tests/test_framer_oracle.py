@@ -151,3 +151,55 @@ def test_view_modes_and_source_types_of_the_device_step_equal_the_oracle(abs_t, 
         fr0 = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
                        codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
         assert fr0.ingest_events(ev) != want
+
+
+@pytest.mark.parametrize("abs_t", [False, True])
+@pytest.mark.parametrize("value_type", [1, 2])
+@pytest.mark.parametrize("view,source,dmax", [(0, 0, 0.0), (0, 1, 0.0), (0, 2, 0.0), (0, 3, 0.0), (1, 0, 12.99), (2, 0, 0.0)])
+def test_u16_u32_frame_elements_of_the_device_step_equal_the_oracle(abs_t, value_type, view, source, dmax):
+    """<u16 / u32 as FrameValue>::get_frame_value (scale_intensity.rs:111-209): the device header's framer_value_wide
+    against the oracle's restatement; the frames are the big-endian bincode bytes FrameSequence<T> writes
+    (driver.rs:279,395-398).  No reference vector exists (its framer tests use u8 frames), so this is oracle parity --
+    and the Intensity arm is checked below against the formula itself."""
+    import sim_py
+    rng = np.random.default_rng(100 + view * 7 + source + 3 * abs_t + 31 * value_type)
+    W, H, T = 9, 7, 40
+    ev = _view_stream(rng, W, H, T, abs_t)
+    fr = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                  codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
+    fr.set_view(view, source, dmax)
+    fr.set_value_type(value_type)
+    want = fr.ingest_events(ev)
+    got = sim_py.framer_run(ev, W, H, 1, tpf=255, ref_interval=255, abs_t=abs_t, round_up=True, max_frames=1 << 14,
+                            view_mode=view, source_type=source, practical_d_max=dmax, delta_t_max=2550,
+                            value_type=value_type)
+    elem = 1 << value_type
+    assert len(want) > 10 * W * H * elem and len(want) % (W * H * elem) == 0 and got[: len(want)] == want
+    vals = np.frombuffer(want, ">u2" if value_type == 1 else ">u4")
+    assert len(np.unique(vals)) > 4 or source == 3  # not a degenerate image (a U64 source scales everything to 0)
+
+
+@pytest.mark.parametrize("value_type", [1, 2])
+@pytest.mark.parametrize("source", [0, 1, 2])
+def test_u16_u32_intensity_values_follow_the_reference_formula(value_type, source):
+    """One DeltaT event per pixel: frame 0 holds (2^d / delta_t [/ source max] * tpf [* T::MAX]) as T, the saturating
+    truncating cast of Rust (scale_intensity.rs:126-137,175-186), computed here in float64 numpy."""
+    W, H = 16, 8
+    rng = np.random.default_rng(value_type * 5 + source)
+    ev = np.zeros(W * H, O.EVENT_DTYPE)
+    ev["c"], ev["x"], ev["y"] = 0xFF, np.arange(W * H) % W, np.arange(W * H) // W
+    ev["d"] = rng.choice(np.array([0, 1, 3, 7, 8, 11, 16, 24, 31], np.uint8), W * H)
+    ev["t"] = rng.integers(255, 2000, W * H)
+    fr = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                  codec_version=3, time_mode=O.DELTA_T, source_camera=O.FRAMED_U8)
+    fr.set_view(0, source, 0.0)
+    fr.set_value_type(value_type)
+    out = fr.ingest_events(ev)
+    elem, tmax = 1 << value_type, float((1 << (8 << value_type)) - 1)
+    frame0 = np.frombuffer(out[: W * H * elem], ">u2" if value_type == 1 else ">u4").astype(np.float64)
+    inten = 2.0 ** ev["d"].astype(np.float64) / ev["t"].astype(np.float64)
+    smax = [255.0, 65535.0, 4294967295.0][source]
+    x = inten * 255.0 if source == value_type else inten / smax * 255.0 * tmax
+    want = np.clip(np.trunc(x), 0.0, tmax)
+    assert np.array_equal(frame0, want)
+    assert 0.0 < want.min() + want.max() and (want == tmax).any() == bool((x >= tmax).any())

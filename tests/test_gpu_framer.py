@@ -325,3 +325,62 @@ def test_view_modes_on_the_device(abs_t, view, source, dmax):
         (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
         got = fr.pop(max_frames=fr.frames_ready())
         assert len(want) > 0 and got[: len(want)] == want and len(got) >= len(want), (batch, len(got), len(want))
+
+
+@pytest.mark.parametrize("abs_t", [False, True])
+@pytest.mark.parametrize("value_type", [1, 2])
+@pytest.mark.parametrize("view,source,dmax", [(0, 0, 0.0), (0, 1, 0.0), (0, 2, 0.0), (1, 0, 12.99), (2, 0, 0.0)])
+def test_u16_u32_frames_on_the_device(abs_t, value_type, view, source, dmax):
+    """FrameSequence<u16> / <u32> (scale_intensity.rs:111-209; frames popped as big-endian bincode bytes,
+    driver.rs:279,395-398) through both host-offset ingest calls, pop / write_frame_bytes / flush, against the oracle."""
+    import torch
+    A = _hip()
+    rng = np.random.default_rng(211 + view + source + 5 * value_type)
+    W, H, T = 45, 31, 40
+    ev, offs = _synthetic_stream(rng, W, H, 1, T, abs_t=abs_t, density=0.7)
+    tm = A.TIME_ABSOLUTE_T if abs_t else A.TIME_DELTA_T
+    ofr = O.Framer(W, H, 1, chunk_rows=64, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0,
+                   codec_version=3, time_mode=O.ABSOLUTE_T if abs_t else O.DELTA_T, source_camera=O.FRAMED_U8)
+    ofr.set_view(view, source, dmax)
+    ofr.set_value_type(value_type)
+    want = ofr.ingest_events(ev.view(O.EVENT_DTYPE) if ev.dtype != O.EVENT_DTYPE else ev)
+    st = torch.cuda.current_stream().cuda_stream
+    d_ev = torch.from_numpy(ev.view(np.uint8).copy()).cuda()
+    fb = (W * H) << value_type
+    for batch in (True, False):
+        fr = A.HipFramer(W, H, 1, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3,
+                         time_mode=tm, source_camera=A.FRAMED_U8, ring_frames=1 << 14, view_mode=view,
+                         source_type=source, practical_d_max=dmax, value_type=value_type)
+        assert fr.frame_bytes == fb
+        (fr.ingest_frames_device if batch else fr.ingest_device)(d_ev, offs, stream=st)
+        ready = fr.frames_ready()
+        first = fr.write_frame_bytes() if batch else b""  # one frame through write_frame_bytes, the rest through pop
+        got = first + fr.pop(max_frames=ready)
+        assert len(want) > 0 and got[: len(want)] == want and len(got) >= len(want), (batch, len(got), len(want))
+        if not batch:  # the device-side pop hands out the same elements
+            fr2 = A.HipFramer(W, H, 1, tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3,
+                              time_mode=tm, source_camera=A.FRAMED_U8, ring_frames=1 << 14, view_mode=view,
+                              source_type=source, practical_d_max=dmax, value_type=value_type)
+            fr2.ingest_device(d_ev, offs, stream=st)
+            n = fr2.frames_ready()
+            d_out = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+            assert fr2.pop_device(d_out, n, stream=st) == n
+            torch.cuda.synchronize()
+            assert d_out.cpu().numpy().tobytes()[: len(want)] == want
+
+
+def test_u16_u32_frames_refusals():
+    """SAE is todo!() for the wide types in the reference (scale_intensity.rs:154,203); device-resident offsets feed
+    the u8 tile kernel only."""
+    import torch
+    A = _hip()
+    kw = dict(tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3)
+    with pytest.raises(A.AdderHipError):
+        A.HipFramer(8, 8, 1, view_mode=3, value_type=1, **kw)
+    with pytest.raises(A.AdderHipError):
+        A.HipFramer(8, 8, 1, value_type=3, **kw)
+    fr = A.HipFramer(8, 8, 1, value_type=2, **kw)
+    d_ev = torch.zeros(12 * 64, dtype=torch.uint8, device="cuda")
+    d_off = torch.tensor([0, 64], dtype=torch.int64, device="cuda")
+    with pytest.raises(A.AdderHipError):
+        fr.ingest_frames_device_offsets(d_ev, d_off, 1)

@@ -284,8 +284,9 @@ def test_prophesee_source_dvs_events_to_adder(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("view,source,dmax,mode", [(0, 0, 0.0, 1), (1, 0, 12.99, 0), (2, 0, 0.0, 0), (3, 0, 0.0, 1), (0, 1, 0.0, 0)])
-def test_framer_builder_views_and_integration_mode(view, source, dmax, mode):
+@pytest.mark.parametrize("view,source,dmax,mode,vt", [(0, 0, 0.0, 1, 0), (1, 0, 12.99, 0, 0), (2, 0, 0.0, 0, 0), (3, 0, 0.0, 1, 0),
+                                                      (0, 1, 0.0, 0, 0), (0, 0, 0.0, 0, 1), (0, 1, 0.0, 1, 2), (2, 0, 0.0, 0, 1)])
+def test_framer_builder_views_and_integration_mode(view, source, dmax, mode, vt):
     """FramerBuilder::mode / view_mode / source of the C++ mirror (driver.rs:98-115): FramerMode::INTEGRATION is stored
     and never read by the reference, so it must frame exactly like INSTANTANEOUS; the views go through
     get_frame_value (scale_intensity.rs:54-109).  ingest_events_events + write_multi_frame_bytes + 3 flushes against
@@ -304,13 +305,14 @@ def test_framer_builder_views_and_integration_mode(view, source, dmax, mode):
     kw = dict(tps=7650, ref_interval=255, delta_t_max=2550, output_fps=30.0, codec_version=3)
     ofr = O.Framer(W, H, 1, chunk_rows=rows, time_mode=O.ABSOLUTE_T, source_camera=O.FRAMED_U8, **kw)
     ofr.set_view(view, source, dmax)
+    ofr.set_value_type(vt)  # finish::<u8 / u16 / u32>()
     want = ofr.write_multi_frame_bytes() if ofr.ingest_events_events(ev, offs) else b""
     for _ in range(3):
         ofr.flush_frame_buffer()
         want += ofr.write_frame_bytes()
     got = Hst.frame_events(ev, offs, W, H, 1, time_mode=1, chunk_rows=rows, framer_mode=mode, view_mode=view,
-                           source_type=source, practical_d_max=dmax, flushes=3, **kw)
-    assert len(want) > 20 * W * H and got == want
+                           source_type=source, practical_d_max=dmax, flushes=3, value_type=vt, **kw)
+    assert len(want) > (20 * W * H) << vt and got == want
 
 
 def _davis_restatement(packets, W, H, mode, *, tps, ref_time, dtm, crf):
