@@ -842,6 +842,10 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
 // The bounded Collapse step (adder_pixel.hpp cb_step): Collapse with delta_t_max > time_spanned, a uniform c_thresh, and
 // every sum its prefix coordinates form an exact integer below 2^24 -- integer time_spanned, at most delta_t_max /
 // time + 1 frames of 8-bit intensities before the pop.  Anything else takes the generic step.
+// Lean batches stepped several frames per launch append their records to a log per segment and chunk (dense: no partial
+// lines, the expansion reads a frame's run at wofs); batches launched one frame at a time keep a slot per frame
+// (frame-major: their launches are independent of the frames before).  ADDER_HIP_LEAN_LOG=0: slots for both (A/B).
+static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames);
 static bool cb_possible(const AdderHipCtx *c, float T) {
     if (c->continuous || c->p.multi_mode != ADDER_MULTI_COLLAPSE || c->perpx || feature_needs_perpx(c)) return false;
     if (c->frac_time_seen) return false;
@@ -934,9 +938,11 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->ftot_ring, 2 * (size_t)c->slots));  // events, then parked records per frame
-    if (kind == AdderHipCtx::kScratchLog2 || kind == AdderHipCtx::kScratchLog3) {
+    if (kind != AdderHipCtx::kScratchCont) {  // (the lean records of blocked batches go to logs too: lean_log_cap)
         HIPCHK(c, dalloc(&c->wofs_ring, (size_t)c->slots * c->num_waves));
         HIPCHK(c, dalloc(&c->wcur, (size_t)c->ring_chunks * c->num_waves));
+    }
+    if (kind == AdderHipCtx::kScratchLog2 || kind == AdderHipCtx::kScratchLog3) {
         c->log_cap = log_capacity(c->chunk, c->max_depth, kind == AdderHipCtx::kScratchLog2);
     } else {
         c->park_bytes = (uint32_t)(scratch_bytes_per_chunk(c, kind, 1u) / c->num_waves);
@@ -969,6 +975,10 @@ static int alloc_deep_planes(AdderHipCtx *c) {
 // expansion inside K1's grid (round 1) no longer pays: with the lean step both kernels are bound by the
 // memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
+static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames) {
+    static const bool on = [] { const char *e = getenv("ADDER_HIP_LEAN_LOG"); return !e || atoi(e) != 0; }();
+    return on && !generic && !c->continuous && launch_depth(c) > 1u && num_frames > 1u;  // (one frame: the one-frame kernels)
+}
 
 static Lean1wArgs lean1w_args(const AdderHipCtx *c) {
     return Lean1wArgs{c->hdr, c->integ0, c->dt0, c->bdt0, c->lastf, c->n_units, c->num_waves};
@@ -1286,7 +1296,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
-                             (cb ? 32u : 0u);
+                             (cb ? 32u : 0u) |
+                             (lean_log_batch(c, generic, num_frames) ? 64u : 0u);  // 64: lean records in per-segment logs
     if (generic) {
         // per-event records go to a log per segment and chunk, sized by the hard bound of what a segment can emit
         // (pop_top and a flush exclude each other in one frame when delta_t_max >= 2 * time: 2 instead of 3 per frame)
@@ -1352,12 +1363,13 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
     b.park_bytes = c->park_bytes;
-    b.log_cap = c->log_cap;
+    // (a lean batch's region holds one record per unit and frame of the chunk: the same bytes as its fixed slots)
+    b.log_cap = (variant & 64u) ? kWaveUnits * c->chunk : c->log_cap;
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
-    if (c->log_cap) {
+    if (b.log_cap) {
         b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};  // (unused: the records are appended to logs)
     } else if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
         b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes, 31u, 0xffffffffu};

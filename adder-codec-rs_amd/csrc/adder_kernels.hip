@@ -310,7 +310,9 @@ __device__ __forceinline__ void lean_store_rec(void *seg, uint32_t byte_off, con
 
 // FULL: the whole wave lies inside the band (every wave but possibly the band's last ones): no
 // per-unit bounds handling inside the frame loop.
-template <bool ABS_T, bool FULL, uint32_t NB_MAX>
+// LOG: the records are appended to the segment's log of the chunk (BatchArgs::log_cap != 0: dense, frame after frame,
+// a frame's run found through wofs) instead of one fixed slot per frame (park_layout).
+template <bool ABS_T, bool FULL, uint32_t NB_MAX, bool LOG = false>
 __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                             uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
                                             uint8_t *lds_in) {
@@ -344,10 +346,22 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
     const ParkLayout lay = park_layout_u(b);
     const uint32_t frame_stride_u = lay.frame_stride;
-    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
+    uint8_t *seg = uniform_ptr(b->park_ring) + (LOG ? (size_t)0 : park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay));
     // the segment's frame slots may be rotated (ParkLayout): the walk wraps where the chunk's slots end
     uint32_t ridx = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
     const uint32_t wrap_bytes = chunk_u * frame_stride_u;
+    // LOG: the segment's region of the chunk holds log_cap = 128 * chunk records (at most one per unit and frame: it
+    // cannot overflow); the cursor survives from one launch of a chunk to the next in wcur
+    uint32_t log_cur0 = 0u;
+    uint32_t *wcur_p = nullptr;
+    if (LOG) {
+        const uint32_t cap = __builtin_amdgcn_readfirstlane(b->log_cap);
+        const uint32_t cir = slot0 / chunk_u;
+        const size_t seg_idx = (size_t)cir * num_waves_u + sgw;
+        wcur_p = uniform_ptr(b->wcur) + seg_idx;
+        if (slot0 != cir * chunk_u) log_cur0 = __builtin_amdgcn_readfirstlane(*wcur_p);  // not the chunk's first launch
+        seg += (seg_idx * cap + log_cur0) * lean_rec_bytes(ABS_T);
+    }
     // The input bytes of ALL the launch's frames are requested up front and parked in the wave's slice of
     // LDS: the record stores of the frame loop sit in divergent regions, so the compiler cannot count
     // them, and every global load waited for inside the loop would cost a full `s_waitcnt vmcnt(0)` --
@@ -441,18 +455,30 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
         vin_w = next_w;
-        seg += frame_stride_u;
-        if (++ridx == chunk_u) {  // uniform; never taken without rotation (a launch stays inside its chunk)
-            ridx = 0u;
-            seg -= wrap_bytes;
+        if (LOG) {
+            seg += nrec * lean_rec_bytes(ABS_T);  // the next frame's run follows this one's
+        } else {
+            seg += frame_stride_u;
+            if (++ridx == chunk_u) {  // uniform; never taken without rotation (a launch stays inside its chunk)
+                ridx = 0u;
+                seg -= wrap_bytes;
+            }
         }
     }
 
     // ---------------- per-frame segment totals ----------------
+    uint32_t wofs = 0u;
+    if (LOG) {  // where each frame's run starts inside the region: an exclusive scan of the record counts over the frames
+        const uint32_t nr = wt >> 16;
+        const uint32_t incl = wave_inclusive_scan_dpp(nr);
+        wofs = log_cur0 + incl - nr;
+        if (lane == kWave - 1u) *wcur_p = log_cur0 + incl;
+    }
     if (lane < nb) {
         uint32_t s = slot0 + lane;
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
+        if (LOG) gstore<uint32_t>(uniform_ptr(b->wofs_ring), (s * num_waves_u + sgw) * 4u, wofs);
     }
 
     // ---------------- state back to HBM ----------------
@@ -484,18 +510,18 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 }
 
 // NB_MAX: the most frames a launch of this kernel steps (1: no LDS is touched, lds_in may be null)
-template <bool ABS_T, uint32_t NB_MAX>
+template <bool ABS_T, uint32_t NB_MAX, bool LOG = false>
 __device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                  uint32_t u0, uint32_t gw, uint32_t lane, const LeanRaw &raw,
                                                  uint8_t *lds_in) {
     const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
     if (full)
-        lean_frames<ABS_T, true, NB_MAX>(b, a, nb, u0, gw, lane, raw, lds_in);
+        lean_frames<ABS_T, true, NB_MAX, LOG>(b, a, nb, u0, gw, lane, raw, lds_in);
     else
-        lean_frames<ABS_T, false, NB_MAX>(b, a, nb, u0, gw, lane, raw, lds_in);
+        lean_frames<ABS_T, false, NB_MAX, LOG>(b, a, nb, u0, gw, lane, raw, lds_in);
 }
 
-template <bool ABS_T>
+template <bool ABS_T, bool LOG>
 #ifdef ADDER_LEAN_MAX_WAVES
 __attribute__((amdgpu_waves_per_eu(1, ADDER_LEAN_MAX_WAVES)))
 #endif
@@ -518,7 +544,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
         LeanRaw raw;
         lean_load<ABS_T, ADDER_NT_STATE != 0>(a, u0, full, raw);
-        lean_run_segment<ABS_T, kMaxFramesPerLaunch>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
+        lean_run_segment<ABS_T, kMaxFramesPerLaunch, LOG>(b, a, nb, u0, gw, lane, raw, s_in[tid / kWave]);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -1446,6 +1472,9 @@ constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 #ifndef ADDER_XBUF_EVENTS
 #define ADDER_XBUF_EVENTS 640
 #endif
+#ifndef ADDER_XFLUSH_UNROLL
+#define ADDER_XFLUSH_UNROLL 1
+#endif
 constexpr uint32_t kXbufEvents = ADDER_XBUF_EVENTS;   // staging capacity of one wave, in events (>= 192)
 constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
 
@@ -1479,6 +1508,9 @@ __device__ __forceinline__ uint32_t coord_xy_c(const UnitCoord &uc, uint32_t uni
 // blocks of the destination).  Uniform arguments; returns nothing, the caller resets its fill.
 __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, uint32_t n, uint32_t *out_dw,
                                            uint64_t gd0, uint32_t lane) {
+#if defined(ADDER_DBG_X_NOSTORE)  // diagnostic A/B build: the expansion without its event stores
+    return;
+#endif
     const uint32_t nd = n * 3u;
     uint32_t head = (4u - phase) & 3u;
     head = head < nd ? head : nd;
@@ -1486,10 +1518,27 @@ __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, u
     if (lane < head) gstore_ev<uint32_t>(dst, lane * 4u, xb[phase + lane]);
     const uint32_t body = (nd - head) >> 2;  // whole 16-byte blocks
     const uint32_t b0 = phase + head;        // a multiple of 4
+#if ADDER_XFLUSH_UNROLL > 1
+    // (several LDS reads in flight before the first store: a flush is a chain of read -> wait -> store otherwise)
+    for (uint32_t k0 = 0; k0 < body; k0 += kWave * ADDER_XFLUSH_UNROLL) {  // uniform trip count
+        uint4 v[ADDER_XFLUSH_UNROLL];
+#pragma unroll
+        for (uint32_t q = 0; q < ADDER_XFLUSH_UNROLL; ++q) {
+            const uint32_t k = k0 + q * kWave + lane;
+            if (k < body) v[q] = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < ADDER_XFLUSH_UNROLL; ++q) {
+            const uint32_t k = k0 + q * kWave + lane;
+            if (k < body) gstore_ev<uint4>(dst, (head + 4u * k) * 4u, v[q]);
+        }
+    }
+#else
     for (uint32_t k = lane; k < body; k += kWave) {
         const uint4 v = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
         gstore_ev<uint4>(dst, (head + 4u * k) * 4u, v);
     }
+#endif
     const uint32_t tail = (nd - head) & 3u;
     if (lane < tail) gstore_ev<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
 }
@@ -1550,11 +1599,17 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // (the wave's kExpandSegs segments lie in one group -- seg0 is a multiple of kExpandSegs, a group holds 1 or a
     // multiple of kExpandSegs segments -- so consecutive ones are a constant stride apart)
     const ParkLayout lay = park_layout_u(b);
-    const uint32_t seg_stride = FORMAT == 0 ? 0u : __builtin_amdgcn_readfirstlane(
+    // lean records of blocked batches lie in per-segment logs like the per-event ones (log_cap records per segment and
+    // chunk, a frame's run at wofs); batches launched one frame at a time keep a fixed slot per frame
+    const uint32_t lean_log_cap = LEAN ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
+    const bool lean_log = lean_log_cap != 0u;
+    const uint32_t seg_stride = FORMAT == 0 ? 0u : lean_log ? lean_log_cap * lean_rec_bytes(ABS_T) : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
                    park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay)));
     const uint8_t *park = uniform_ptr(b->park_ring) +
-                          (FORMAT == 0 ? (size_t)0 : park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay));
+                          (FORMAT == 0 ? (size_t)0
+                           : lean_log  ? ((size_t)(slot / chunk_frames) * num_waves + seg0) * seg_stride
+                                       : park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay));
     const uint32_t *wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
     const uint32_t *wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
     UnitCoord uc;
@@ -1580,14 +1635,20 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint8_t *log0 = nullptr;  // per-event records: the log region of segment seg0, the regions' stride, and
     uint32_t log_stride = 0u;       // where each segment's run of this frame starts inside its region (bytes)
     uint32_t log_run[FORMAT == 0 ? kExpandSegs : 1u];
+    uint32_t lean_ofs = 0u;  // lean logs: lane q < kExpandSegs holds the byte offset of segment seg0 + q's run in its region
     if (LEAN) {
+        if (lean_log && lane < kExpandSegs)
+            lean_ofs = gload<uint32_t>(uniform_ptr(b->wofs_ring) + (size_t)slot * num_waves + seg0, lane * 4u) * lean_rec_bytes(ABS_T);
 #pragma unroll
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
+            // (slots: lean_ofs is 0 in every lane)
+            const uint32_t oa = __builtin_amdgcn_readlane(lean_ofs, 2 * p), ob = __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1);
             first[p] = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                first[p] = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride, half * seg_stride + hl * lean_rec_bytes(ABS_T));
+                first[p] = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride,
+                                                (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
             }
         }
     } else if (FORMAT == 0) {
@@ -1665,14 +1726,19 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             if (pa <= 32u && pb <= 32u) {
+#if defined(ADDER_DBG_X_NODECODE)  // diagnostic A/B build: no record loads, no decode, no staging -- only the stream's stores
+                if (fill + 3u * kWave > kXbufEvents) flush();
+                fill += (__builtin_amdgcn_readlane(my_tot, 2 * p) & 0xffffu) + (__builtin_amdgcn_readlane(my_tot, 2 * p + 1) & 0xffffu);
+#else
                 if (pa + pb != 0u) lean_round(first[p], half * kWaveUnits);
+#endif
                 next_segment();
                 next_segment();
             } else {
                 const uint32_t cnt[2] = {pa, pb};
 #pragma unroll
                 for (uint32_t h = 0; h < 2u; ++h) {
-                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride;
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride + __builtin_amdgcn_readlane(lean_ofs, 2 * p + h);
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
@@ -2183,7 +2249,8 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
 #if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
-    if (nb == 1u && num_waves % 2u == 0u && (variant & 16u) && wide) {
+    const bool lean_log = variant & 64u;  // blocked batches: records in per-segment logs (every launch, also a chunk's 1-frame tail)
+    if (nb == 1u && !lean_log && num_waves % 2u == 0u && (variant & 16u) && wide) {
         const uint32_t waves = (num_waves / 2u + kLean1wPairs - 1u) / kLean1wPairs;
         const uint32_t grid = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         if (abs_t) hipLaunchKernelGGL((adder_lean1w_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f, *wide);
@@ -2191,15 +2258,20 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
 #endif
-    if (nb == 1u && num_waves % kLean1Segs == 0u) {
+    if (nb == 1u && !lean_log && num_waves % kLean1Segs == 0u) {
         const uint32_t grid = (num_waves / kLean1Segs + kWavesPerBlock - 1) / kWavesPerBlock;
         if (abs_t) hipLaunchKernelGGL((adder_lean1_kernel<true>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         else hipLaunchKernelGGL((adder_lean1_kernel<false>), dim3(grid), dim3(kBlockThreads), 0, stream, b, f);
         return hipGetLastError();
     }
     const uint32_t SL = grid_cap && grid_cap < S ? grid_cap : S;  // (only the blocked lean kernel walks: see its comment)
-    if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
-    else hipLaunchKernelGGL((adder_lean_kernel<false>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+    if (lean_log) {
+        if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true, true>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_lean_kernel<false, true>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+    } else {
+        if (abs_t) hipLaunchKernelGGL((adder_lean_kernel<true, false>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_lean_kernel<false, false>), dim3(SL), dim3(kBlockThreads), 0, stream, b, f, nb);
+    }
     return hipGetLastError();
 }
 
