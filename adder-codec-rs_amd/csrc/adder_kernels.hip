@@ -1581,7 +1581,7 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
 
 template <int FORMAT, bool ABS_T>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1;
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3;  // (3: lean records in per-segment logs, variant bit 64)
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
     // only the frame-independent part of the arguments is needed here
@@ -1601,8 +1601,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const ParkLayout lay = park_layout_u(b);
     // lean records of blocked batches lie in per-segment logs like the per-event ones (log_cap records per segment and
     // chunk, a frame's run at wofs); batches launched one frame at a time keep a fixed slot per frame
-    const uint32_t lean_log_cap = LEAN ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
-    const bool lean_log = lean_log_cap != 0u;
+    constexpr bool lean_log = FORMAT == 3;
+    const uint32_t lean_log_cap = lean_log ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
     const uint32_t seg_stride = FORMAT == 0 ? 0u : lean_log ? lean_log_cap * lean_rec_bytes(ABS_T) : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
                    park_offset(slot, seg0, chunk_frames, num_waves, park_bytes, lay)));
@@ -1643,8 +1643,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
-            // (slots: lean_ofs is 0 in every lane)
-            const uint32_t oa = __builtin_amdgcn_readlane(lean_ofs, 2 * p), ob = __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1);
+            const uint32_t oa = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p) : 0u;
+            const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
             first[p] = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
                 first[p] = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride,
@@ -1738,7 +1738,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 const uint32_t cnt[2] = {pa, pb};
 #pragma unroll
                 for (uint32_t h = 0; h < 2u; ++h) {
-                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride + __builtin_amdgcn_readlane(lean_ofs, 2 * p + h);
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride +
+                                                    (lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + h) : 0u);
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
@@ -2310,6 +2311,10 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (generic && (variant & 32u)) hipLaunchKernelGGL((adder_expand_kernel<0, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else if (variant & 64u) {
+        if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<3, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+        else hipLaunchKernelGGL((adder_expand_kernel<3, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    }
     else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     return hipGetLastError();
