@@ -1058,6 +1058,9 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed (and so have the records stored so far)
 }
 
+#ifndef ADDER_CB_QUIET_PATH
+#define ADDER_CB_QUIET_PATH 1
+#endif
 template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                uint32_t u0, uint32_t gw, uint32_t lane, CbWaveLds &w) {
@@ -1125,13 +1128,46 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
     typename L::Mask depth_error = L::from(false);
 
+    // everything loaded so far (state, frame table, log cursor) has landed BEFORE the loop: otherwise the compiler must
+    // assume at the loop header that one of those registers is still in flight and waits vmcnt(0) in EVERY frame --
+    // i.e. for the acknowledgement of the previous frame's record stores
+#ifndef ADDER_DBG_CB_NO_PRELOOP_WAIT
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#endif
     for (uint32_t i = 0; i < nb; ++i) {
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
+        // (reading the next frame's bytes one frame ahead was measured: no difference)
         const uint32_t vin_w = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
         sc.cth = __builtin_amdgcn_readlane(tab_cth, i);
         sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
         sc.running_t_u32 = f32_as_u32(sc.running_t);
 
+#if ADDER_CB_QUIET_PATH
+        // ---------------- a quiet wave: every unit popped down to its root and inside its contrast band ----------------
+        // (static content, lossy content between its rare flushes: only the roots integrate, nothing leaves -- cb_quiet)
+        // (making the test only every few frames after it failed, or only when the wave's previous frame had no walker
+        // and no event, was measured: 13.7 / 13.4 instead of 13.1 us per frame on busy content -- a loop-carried uniform
+        // costs more than the test)
+        {
+            bool lane_quiet = true, lane_fires = false;
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) {
+                const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
+                lane_quiet = lane_quiet && cb_quiet<L>(px[j], v, sc.cth);
+                lane_fires = lane_fires || cb_quiet_fires<L>(px[j], v);
+            }
+            if (__builtin_amdgcn_ballot_w64(!lane_quiet) == 0ull) {  // uniform
+                if (__builtin_amdgcn_ballot_w64(lane_fires) != 0ull) {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, true>(px[j], (vin_w >> (8 * j)) & 0xffu, T);
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, false>(px[j], (vin_w >> (8 * j)) & 0xffu, T);
+                }
+                continue;  // (wt / wo of this frame stay 0: no events, no records)
+            }
+        }
+#endif
         // ---------------- the step of every unit + the event counts ----------------
         CbPlanT<L> plan[N];
         CbMidT<L> mid[N];

@@ -926,6 +926,47 @@ ADDER_HD void cb_step(CbPxT<L> &s, const Lv &lv, uint32_t v, float T, const Step
     }
 }
 
+// QUIET FRAMES.  A unit whose arena is popped down to its root (popped_dtm set, one fired level) and whose contrast test
+// passes takes none of the step's side roads: no flush, no walk, no pop_top (need_to_pop_top wants !popped_dtm, :396),
+// no event -- only the root integrates (:360-362), and fires now and then (its threshold doubles every time, :452).
+// That is the steady state of every pixel of static content and of lossy (crf > 0) content between its rare flushes:
+// a wave ALL of whose units are quiet runs cb_step_quiet instead of the step, the compaction and the emission.
+// cb_quiet is the predicate, cb_step_quiet what cb_step_a + cb_step_b<.., false> + cb_pop reduce to under it.
+// A BLACK pixel is quiet too although it never pops: its d = 128 root fires on every zero without accumulating delta_t
+// (:449), so delta_t never reaches delta_t_max -- the same root-only firing arm, no walk (the root fires), no pop.
+template <class L>
+ADDER_HD bool cb_quiet(const CbPxT<L> &s, uint32_t v, uint32_t cth) {
+    return s.m == 1u && !contrast_exceeded(v, s.base, cth) && (L::lane(s.popped) || (s.thr0 == 0.0f && v == 0u));
+}
+// MAY_FIRE = false: the caller knows that S + I stays below the root's threshold (for every unit of its wave)
+template <class L, bool MAY_FIRE = true>
+ADDER_HD void cb_step_quiet(CbPxT<L> &s, uint32_t v, float T) {
+    const float I = (float)v;
+    const float S_new = fadd(s.S, I);
+    if (!MAY_FIRE) {
+        s.S = S_new;
+        s.dt0 = fadd(s.dt0, T);
+        return;
+    }
+    using M = typename L::Mask;
+    const M fires = L::from(S_new >= s.thr0);
+    // the firing arm of integrate_main on the root (:427-473), as in cb_step_b with P = Q = 0
+    const M zero = L::from(S_new == 0.0f);
+    const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);
+    const M d128 = L::from(s.thr0 == 0.0f);
+    const float q = fdiv_small(fsub(p2, fsub(s.S, 0.0f)), I);
+    const float prop = L::lane(L::or_(zero, d128)) ? 1.0f : q;
+    const float bdt = fadd(fsub(s.dt0, 0.0f), fmul(T, prop));
+    const float thr2 = fadd(p2, p2);
+    const float dt_old = s.dt0;
+    s.S = S_new;
+    s.dt0 = L::lane(L::and_(fires, zero)) ? dt_old : fadd(dt_old, T);
+    s.bdt0 = L::lane(fires) ? bdt : s.bdt0;
+    s.thr0 = L::lane(fires) ? thr2 : s.thr0;
+}
+template <class L>
+ADDER_HD bool cb_quiet_fires(const CbPxT<L> &s, uint32_t v) { return fadd(s.S, (float)v) >= s.thr0; }
+
 // The unit's events of this frame, in emission order.  After cb_step, before cb_pop.  An event leaves as (the bits of
 // the node's threshold, t): best_event.d is the threshold's exponent minus one (lean_bd_from_thr), which the consumer
 // of the records works out -- emit.ev(thr_bits, t); the Collapse filler {d: D_EMPTY} as emit.filler(t).

@@ -44,7 +44,8 @@ struct Sim {
     int continuous;      // Mode::Continuous: the general arena step (cont_step), its own state planes
     std::vector<uint32_t> c_hdr, c_meta;           // [unit], [node][unit]
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
-    uint64_t fast_steps, generic_steps, lean_steps, cb_steps;
+    uint64_t fast_steps, generic_steps, lean_steps, cb_steps, cb_quiet_steps;
+    int cb_quiet_path;  // take the device's quiet-wave reduction wherever a unit qualifies (default on)
     int use_cb;          // Collapse with delta_t_max > time: the bounded step (cb_step) instead of the generic one
     int frac_time_seen;  // a non-integer time_spanned has been integrated since the last reset (cb needs exact sums)
     // feature-driven rate control (the kernel-side flow of adder_feature_kernel, serially)
@@ -140,7 +141,8 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->use_fast = 1;
     s->generic_sticky = 0;
     s->continuous = 0;
-    s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = 0;
+    s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = s->cb_quiet_steps = 0;
+    s->cb_quiet_path = 1;
     s->use_cb = 1;
     s->frac_time_seen = 0;
     s->feat_detect = s->feat_adjust = s->roi_on = s->perpx = 0;
@@ -194,6 +196,8 @@ uint64_t sim_fast_steps(const Sim *s) { return s->fast_steps; }
 uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
 uint64_t sim_lean_steps(const Sim *s) { return s->lean_steps; }
 uint64_t sim_cb_steps(const Sim *s) { return s->cb_steps; }
+uint64_t sim_cb_quiet_steps(const Sim *s) { return s->cb_quiet_steps; }
+void sim_set_cb_quiet_path(Sim *s, int on) { s->cb_quiet_path = on; }
 void sim_set_use_cb(Sim *s, int on) { s->use_cb = on; }
 
 // integrate_for_px(px, &mut 0, frame_val, intensity, time) per step, in order (the flow of adder_sparse_run_kernel,
@@ -330,7 +334,16 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                         void filler(uint32_t t) { put(cb_d_from_code(kCbCodeEmpty), t); }
                     } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
                     CbPlan plan;
-                    cb_step(p, lv, frames[(size_t)i * s->N + u], T, sc, plan);
+                    const uint32_t vq = frames[(size_t)i * s->N + u];
+                    if (s->cb_quiet_path && cb_quiet(p, vq, sc.cth)) {
+                        // the device's fast path (a wave all of whose units are quiet): must equal the step, no events
+                        if (cb_quiet_fires(p, vq) || (s->cb_steps & 1u)) cb_step_quiet<ScalarLanes, true>(p, vq, T);
+                        else cb_step_quiet<ScalarLanes, false>(p, vq, T);
+                        s->cb_quiet_steps++;
+                        s->cb_steps++;
+                        continue;
+                    }
+                    cb_step(p, lv, vq, T, sc, plan);
                     if (plan.depth_error) rc = -5;
                     if (s->abs_t) cb_emit<true>(p, plan, sc, lv, em); else cb_emit<false>(p, plan, sc, lv, em);
                     if (em.n != plan.count) s->plan_mismatch++;

@@ -333,6 +333,39 @@ def test_cb_blocked_launches_match_the_oracle(time_mode, crf):
         assert total > 0
 
 
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_cb_quiet_frames_reduce_to_the_root_update(time_mode):
+    """cb_quiet / cb_step_quiet (the device's fast path for waves whose units are all popped down to their root and pass
+    the contrast test): long static and lossy runs -- roots that fire at every power of two, black pixels whose d = 128
+    root "fires" every frame without advancing delta_t, jitter inside the threshold band, rare flushes -- with the
+    reduction on and off, both against the oracle, state included (a later flush emits what the quiet frames left)."""
+    frames = 420
+    rng = np.random.default_rng(5 + time_mode)
+    base = rng.integers(0, 256, (1, 9, 8, 1))
+    base[0, :2] = 0                                  # black rows: d = 128 roots
+    base[0, 2, :4] = 1
+    clip = np.repeat(base, frames, axis=0)
+    clip[:, 3:] = np.clip(clip[:, 3:] + rng.integers(-1, 2, (frames, 6, 8, 1)), 0, 255)   # jitter inside crf-3's band
+    clip[200:, 5] = 255 - clip[200:, 5]              # a flush of rows that were quiet for 170 frames
+    clip[390:] = rng.integers(0, 256, (30, 9, 8, 1))
+    clip = clip.astype(np.uint8)
+    for crf, quiet in ((3, True), (3, False), (0, True), (9, True)):
+        ov, sv = _cb_pair(8, 9, 1, time_mode, 7650, crf=CRFS[crf])
+        sv.set_cb_quiet_path(quiet)
+        k = 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 5, 30, 64])), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (crf, quiet, k, nb)
+            k += nb
+        assert sv.plan_mismatches == 0
+        if quiet and crf:
+            assert sv.cb_quiet_steps > 0.5 * sv.cb_steps, (sv.cb_quiet_steps, sv.cb_steps)   # most unit-frames took it
+        if not quiet:
+            assert sv.cb_quiet_steps == 0
+
+
 def test_cb_and_generic_steps_are_interchangeable_mid_stream():
     """Both steps keep the same resident state (level 0 planes + deep planes): alternating them frame by frame -- as
     a context does when a mode switch makes the bounded step ineligible -- must not change a single event."""

@@ -1,5 +1,6 @@
 """Timing helper (not a test): frame-loop time per frame for a mode, best of 4 batches.
-env: CONTENT (0 static,1 noise,2 scene), MULTI (0 normal,1 collapse), TMODE (0 delta,1 abs), DTM, W, H, C, T"""
+env: CONTENT (0 static,1 noise,2 scene), MULTI (0 normal,1 collapse), TMODE (0 delta,1 abs), DTM, W, H, C, T,
+CRF ("baseline,max,velocity", default 0,0,10)"""
 import json
 import os
 import sys
@@ -19,8 +20,9 @@ st = torch.cuda.current_stream().cuda_stream
 A.synth_clip_device(d_frames, content, W, H, Cn, num_frames=T, stream=st)
 d_ev = torch.empty((int(n_units * T * 1.3) + 1024, 3), dtype=torch.int32, device="cuda")
 d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
-hv = A.HipVideo(W, H, Cn, time_mode=tmode, multi_mode=multi, delta_t_max=dtm, c_thresh_start=0, c_counter_start=0, max_depth=20)
-hv.set_crf_parameters(0, 10)
+crf = [int(x) for x in E.get("CRF", "0,0,10").split(",")]
+hv = A.HipVideo(W, H, Cn, time_mode=tmode, multi_mode=multi, delta_t_max=dtm, c_thresh_start=crf[0], c_counter_start=0, max_depth=20)
+hv.set_crf_parameters(crf[1], crf[2])
 best, n = 1e9, -1
 for it in range(4):
     hv.reset()
