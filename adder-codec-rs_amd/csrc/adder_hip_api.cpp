@@ -1196,13 +1196,15 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
         HIPCHK(c, snap_copy(&n.cn_bdt, c->cn_bdt, cnt, s));
         HIPCHK(c, snap_copy(&n.cn_meta, c->cn_meta, cnt, s));
     }
+    // levels >= 1: the batch's first launch stores every unit's LIVE levels into the copy (BatchArgs::snap_dv_*);
+    // the buffers only have to exist
     n.deep = deep && c->dv_integ;
-    if (n.deep) {
+    if (n.deep && !n.dv_integ) {
         const size_t cnt = c->n_pad * (std::max<uint32_t>(c->max_depth, 2u) - 1u);
-        HIPCHK(c, snap_copy(&n.dv_integ, c->dv_integ, cnt, s));
-        HIPCHK(c, snap_copy(&n.dv_dt, c->dv_dt, cnt, s));
-        HIPCHK(c, snap_copy(&n.dv_bdt, c->dv_bdt, cnt, s));
-        HIPCHK(c, snap_copy(&n.dv_bd, c->dv_bd, cnt, s));
+        HIPCHK(c, dalloc(&n.dv_integ, cnt));
+        HIPCHK(c, dalloc(&n.dv_dt, cnt));
+        HIPCHK(c, dalloc(&n.dv_bdt, cnt));
+        HIPCHK(c, dalloc(&n.dv_bd, cnt));
     }
     n.perpx = c->perpx;
     if (c->perpx) {
@@ -1366,6 +1368,13 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.park_bytes = c->park_bytes;
     // (a lean batch's region holds one record per unit and frame of the chunk: the same bytes as its fixed slots)
     b.log_cap = (variant & 64u) ? kWaveUnits * c->chunk : c->log_cap;
+    {
+        const bool sd = c->snap.valid && c->snap.deep;  // this batch keeps an undo copy of the levels >= 1
+        b.snap_dv_integ = sd ? c->snap.dv_integ : nullptr;
+        b.snap_dv_dt = sd ? c->snap.dv_dt : nullptr;
+        b.snap_dv_bdt = sd ? c->snap.dv_bdt : nullptr;
+        b.snap_dv_bd = sd ? c->snap.dv_bd : nullptr;
+    }
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of

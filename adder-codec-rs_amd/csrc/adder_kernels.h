@@ -153,6 +153,12 @@ struct BatchArgs {
     uint32_t slots;
     uint32_t chunk;           // frames per chunk; slots = chunks in the ring * chunk
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
+    // Undo copy of the levels >= 1 (a batch whose event buffer is below its worst case keeps one: adder_hip_finish can
+    // roll back).  Not null: the batch's FIRST launch (frame 0) stores every unit's LIVE levels 1 .. m-1 here before
+    // anything overwrites them -- the generic / bounded Collapse kernels hold them in their hands anyway; a host-side
+    // copy of the whole planes moved (max_depth - 1) * 13 bytes per unit and batch, 6 GB for a 4K RGB plane.
+    float *snap_dv_integ, *snap_dv_dt, *snap_dv_bdt;
+    uint8_t *snap_dv_bd;
     // diagnostics (null in normal operation): first start / last end of every kernel of the batch on the 100 MHz
     // constant clock, [kernel kind 0 frame, 1 scan, 2 offsets, 3 expansion][chunk][2]  (tools/timeline_probe.py)
     unsigned long long *timeline;

@@ -94,6 +94,20 @@ struct DeepGlobal {
     }
 };
 
+// BatchArgs::snap_dv_*: the unit's live levels into the batch's undo copy (first launch of the batch only)
+__device__ __forceinline__ bool snap_deep_wanted(const BatchArgs *__restrict__ b, const FrameArgs &a) {
+    return __builtin_amdgcn_readfirstlane(a.frame_idx == 0u && b->snap_dv_integ != nullptr);
+}
+__device__ __forceinline__ void snap_deep_levels(const BatchArgs *__restrict__ b, const FrameArgs &a, size_t u, uint32_t m) {
+    const DeepGlobal src{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, u};
+    const DeepGlobal dst{b->snap_dv_integ, b->snap_dv_dt, b->snap_dv_bdt, b->snap_dv_bd, a.plane_stride, u};
+    for (uint32_t k = 1; k < m; ++k) {
+        Node n;
+        src.load(k, n);
+        dst.store(k, n);
+    }
+}
+
 struct __attribute__((aligned(4))) EventWords {
     uint32_t xy, cd, t;
 };
@@ -872,6 +886,10 @@ __device__ __forceinline__ void gen_run_segment(const BatchArgs *__restrict__ b,
             deep[j].store(k, nk);
         }
     }
+    if (snap_deep_wanted(b, a)) {
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) snap_deep_levels(b, a, (size_t)u0 + j, px[j].m);
+    }
 
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
     const uint8_t *const frames_u = uniform_ptr(b->frames);
@@ -1073,6 +1091,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     using L = ScalarLanes;
 #endif
     CbPxT<L> px[N];
+    uint32_t snap_m[N];  // fired levels as the header has them (the undo copy takes all of them)
     {
         uint32_t hdrv[N];
         float iv[N], dv[N], bv[N], lfv[N];
@@ -1084,6 +1103,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             px[j] = cb_unpack<L>(hdrv[j], iv[j], dv[j], bv[j], ABS_T ? lfv[j] : 0.0f);
+            snap_m[j] = px[j].m;
             if (L::lane(px[j].popped) && px[j].m > 1u) px[j].m = 1u;  // a popped arena keeps only its root
         }
     }
@@ -1103,6 +1123,10 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             g.load(k, nk);
             lv[j].store(k, cb_level_from_node(px[j], nk));
         }
+    }
+    if (snap_deep_wanted(b, a)) {  // (the levels as they are in the planes: also those a popped arena no longer needs)
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) snap_deep_levels(b, a, (size_t)u0 + j, snap_m[j]);
     }
 
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
