@@ -1158,7 +1158,46 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 #ifndef ADDER_DBG_CB_NO_PRELOOP_WAIT
     __builtin_amdgcn_s_waitcnt(0x0f70);
 #endif
-    for (uint32_t i = 0; i < nb; ++i) {
+    uint32_t i = 0u;
+#if ADDER_CB_QUIET_PATH
+    // ---------------- quiet frames first (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
+    // A wave ALL of whose units start the launch popped down to their root (or black: a d = 128 root) stays in this loop
+    // for as long as every unit also passes its contrast test: only the roots integrate, nothing leaves -- the steady state
+    // of static content and of lossy content away from what moves.  The first frame that is not quiet, and every frame
+    // after it, goes through the general loop below, which knows nothing of this one: a test inside the general loop,
+    // before the step or riding on its first half, cost the busy crf-0 scene 9-13 % of this kernel (and making it only
+    // after a calm frame, or with a back-off, cost more still).
+    {
+        bool lane_ok = true;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) lane_ok = lane_ok && px[j].m == 1u && (L::lane(px[j].popped) || px[j].thr0 == 0.0f);
+        if (__builtin_amdgcn_ballot_w64(!lane_ok) == 0ull) {  // uniform
+            for (; i < nb; ++i) {
+                if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
+                const uint32_t vin_q = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
+                const uint32_t cth_q = __builtin_amdgcn_readlane(tab_cth, i);
+                bool lane_quiet = true, lane_fires = false;
+#pragma unroll
+                for (uint32_t j = 0; j < N; ++j) {
+                    const uint32_t v = (vin_q >> (8 * j)) & 0xffu;
+                    lane_quiet = lane_quiet && cb_quiet<L>(px[j], v, cth_q);
+                    lane_fires = lane_fires || cb_quiet_fires<L>(px[j], v);
+                }
+                if (__builtin_amdgcn_ballot_w64(!lane_quiet) != 0ull) break;  // frame i: the general loop's (staged already)
+                if (__builtin_amdgcn_ballot_w64(lane_fires) != 0ull) {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, true>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, false>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
+                }
+                // (wt / wo of this frame stay 0: no events, no records)
+            }
+        }
+    }
+#endif
+    for (; i < nb; ++i) {
+        // (a frame handed over by the quiet loop mid-group finds its group staged)
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
         // (reading the next frame's bytes one frame ahead was measured: no difference)
         const uint32_t vin_w = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
@@ -1166,32 +1205,6 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
         sc.running_t_u32 = f32_as_u32(sc.running_t);
 
-#if ADDER_CB_QUIET_PATH
-        // ---------------- a quiet wave: every unit popped down to its root and inside its contrast band ----------------
-        // (static content, lossy content between its rare flushes: only the roots integrate, nothing leaves -- cb_quiet)
-        // (making the test only every few frames after it failed, or only when the wave's previous frame had no walker
-        // and no event, was measured: 13.7 / 13.4 instead of 13.1 us per frame on busy content -- a loop-carried uniform
-        // costs more than the test)
-        {
-            bool lane_quiet = true, lane_fires = false;
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                const uint32_t v = (vin_w >> (8 * j)) & 0xffu;
-                lane_quiet = lane_quiet && cb_quiet<L>(px[j], v, sc.cth);
-                lane_fires = lane_fires || cb_quiet_fires<L>(px[j], v);
-            }
-            if (__builtin_amdgcn_ballot_w64(!lane_quiet) == 0ull) {  // uniform
-                if (__builtin_amdgcn_ballot_w64(lane_fires) != 0ull) {
-#pragma unroll
-                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, true>(px[j], (vin_w >> (8 * j)) & 0xffu, T);
-                } else {
-#pragma unroll
-                    for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, false>(px[j], (vin_w >> (8 * j)) & 0xffu, T);
-                }
-                continue;  // (wt / wo of this frame stay 0: no events, no records)
-            }
-        }
-#endif
         // ---------------- the step of every unit + the event counts ----------------
         CbPlanT<L> plan[N];
         CbMidT<L> mid[N];
