@@ -1159,12 +1159,14 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     __builtin_amdgcn_s_waitcnt(0x0f70);
 #endif
     uint32_t i = 0u;
+    while (i < nb) {  // quiet frames, then general frames up to the next input group, then the same again
 #if ADDER_CB_QUIET_PATH
-    // ---------------- quiet frames first (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
+    // ---------------- quiet frames (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
     // A wave ALL of whose units start the launch popped down to their root (or black: a d = 128 root) stays in this loop
     // for as long as every unit also passes its contrast test: only the roots integrate, nothing leaves -- the steady state
-    // of static content and of lossy content away from what moves.  The first frame that is not quiet, and every frame
-    // after it, goes through the general loop below, which knows nothing of this one: a test inside the general loop,
+    // of static content and of lossy content away from what moves.  The first frame that is not quiet goes through the
+    // general loop below, which knows nothing of this one and hands back at the next input group (every 16 frames: a wave
+    // that calms down mid-launch -- a fresh clip pops everywhere at frame 30 -- is noticed there): a test inside the general loop,
     // before the step or riding on its first half, cost the busy crf-0 scene 9-13 % of this kernel (and making it only
     // after a calm frame, or with a back-off, cost more still).
     {
@@ -1252,6 +1254,13 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             off += plan[j].count;
             cb_pop<L>(px[j], plan[j], lv[j]);
         }
+#if ADDER_CB_QUIET_PATH
+        if (((i + 1u) % kCbInFrames) == 0u) {  // (uniform) the next frame starts an input group: back to the quiet test
+            ++i;
+            break;
+        }
+#endif
+    }
     }
     if (L::lane(depth_error)) raise(a.status, kStatusDepth);
     log.close(lane);
