@@ -443,6 +443,47 @@ def test_baseline_config_5_shape_4k_rgb_lossy():
     assert int((want["d"] == 255).sum()) > 0  # D_EMPTY fillers: collapsed flushes after the frame-30 pop happened
 
 
+@pytest.mark.parametrize("case", ["C3", "C4band", "C5"])
+def test_full_size_configs_across_chunk_boundaries(case):
+    """BASELINE configs 3, 4 (one band) and 5 at full size for long enough to cross the pipeline's chunk boundaries (64
+    frames; 48 for the 4K RGB plane, whose scratch is budget-limited) -- the scratch ring wraps, the state goes out and
+    comes back, in config 5 the arenas pop at frame 30 and the quiet-wave loop takes over -- every event and every frame
+    offset against the oracle."""
+    import torch
+    A = _hip()
+    if case == "C3":
+        W, H, Cn, T, band, tm, dtm, crf = 1920, 1080, 3, 70, None, O.DELTA_T, 255, (0, 0, 10)
+    elif case == "C4band":
+        W, H, Cn, T, band, tm, dtm, crf = 3840, 2160, 1, 135, (270, 540), O.DELTA_T, 255, (0, 0, 10)
+    else:
+        W, H, Cn, T, band, tm, dtm, crf = 3840, 2160, 3, 100, None, O.ABSOLUTE_T, 7650, (2, 7, 7)
+    y0, y1 = band if band else (0, H)
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, Cn, T, y0=y0, rows=y1 - y0)
+    hv = A.HipVideo(W, H, Cn, row_begin=y0, row_end=y1, time_mode=tm, multi_mode=A.MULTI_COLLAPSE, delta_t_max=dtm,
+                    c_thresh_start=crf[0], c_counter_start=0)
+    hv.set_crf_parameters(crf[1], crf[2])
+    d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_ev = torch.empty((int(d_frames.numel() * (0.1 if case == "C5" else 0.5)) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=torch.cuda.current_stream().cuda_stream)
+    n = hv.finish()
+    assert T > hv.chunk_frames()  # the clip really crosses a chunk boundary
+    got = np.frombuffer(d_ev[:n].cpu().numpy().tobytes(), dtype=A.EVENT_DTYPE)
+    del d_frames, d_ev
+    ov = O.Video(W, y1 - y0, Cn, row_begin=y0, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm,
+                 threads=min(O.max_threads(), 64))  # (the oracle's plane IS the band)
+    ov.ensure_capacity(8)
+    ov.set_crf_parameters(crf[1], crf[2])
+    ov.reset_c_thresh(crf[0])
+    pos, offs = 0, d_off.cpu().numpy()
+    for k in range(T):  # frame by frame: no second copy of the whole stream
+        w = ov.integrate_matrix(clip[k])
+        assert int(offs[k]) == pos and int(offs[k + 1]) == pos + len(w), (case, k)
+        assert np.array_equal(got[pos:pos + len(w)], w), (case, k)
+        pos += len(w)
+    assert pos == n and n > 0
+
+
 def test_full_plane_long_run_1080p_540_frames():
     """1920x1080, 540 frames, the lean kernel: a static plane (every pixel's run exceeds 514 frames, so the
     t of its flush is >= 2^17) with a noisy band and scattered late changes, bit-exact against the oracle
