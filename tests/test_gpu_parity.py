@@ -1266,6 +1266,37 @@ def test_cb_kernel_batches_of_every_shape(time_mode, crf):
         hv.close()
 
 
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("depth", [5, 16, 64])
+def test_cb_kernel_quiet_waves_hand_over_to_the_general_loop_and_back(time_mode, depth):
+    """The quiet-frame loop of adder_cb_kernel (cb_quiet / cb_step_quiet): whole segments popped down to their roots
+    for hundreds of frames, black rows (d = 128 roots that never pop), a flush inside ONE segment in the middle of a
+    launch (that wave leaves the loop, the others stay), jitter inside the contrast band, launches of 5 / 16 / 64 frames so
+    that the hand-over back at an input-group boundary happens at every phase -- against the oracle, state included (the
+    last frames flush everything the quiet frames accumulated)."""
+    W, H, frames = 256, 12, 260      # 3072 units = 24 whole segments: no padding keeps a wave out of the loop
+    rng = np.random.default_rng(9 + depth + time_mode)
+    base = rng.integers(0, 256, (1, H, W, 1))
+    base[0, :2] = 0                                        # four black segments
+    clip = np.repeat(base, frames, axis=0)
+    clip[:, 4:] = np.clip(clip[:, 4:] + rng.integers(-1, 2, (frames, H - 4, W, 1)), 0, 255)
+    clip[77:, 6, 10:40] = 255 - clip[77:, 6, 10:40]        # one segment flushes at frame 77 ...
+    clip[141:, 1, 200:210] = 9                             # ... a black one wakes up at 141 ...
+    clip[250:] = rng.integers(0, 256, (10, H, W, 1))       # ... and everything flushes at the end
+    clip = clip.astype(np.uint8)
+    for crf in (3, 0):
+        ov, hv = _cb_pair(W, H, 1, time_mode, 7650, crf=CRFS[crf])
+        hv.set_frames_per_launch(depth)
+        k = 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 37, 64, 100])), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            got, _ = hv.integrate_batch(clip[k:k + nb])
+            assert len(got) == len(want) and np.array_equal(got, want), (crf, k, nb)
+            k += nb
+        hv.close()
+
+
 def test_cb_kernel_deep_levels_spill_to_the_deep_planes_and_depth_is_reported():
     """delta_t_max of 500 frames: static pixels reach seven levels before the pop, past the four LDS slots, so levels 5+
     are stepped in the deep planes; flushes drain them.  With max_depth 3 the same clip must fail with
