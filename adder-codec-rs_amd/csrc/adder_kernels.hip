@@ -324,6 +324,9 @@ __device__ __forceinline__ void lean_store_rec(void *seg, uint32_t byte_off, con
 
 // FULL: the whole wave lies inside the band (every wave but possibly the band's last ones): no
 // per-unit bounds handling inside the frame loop.
+#ifndef ADDER_LEAN_QUIET_PATH
+#define ADDER_LEAN_QUIET_PATH 1
+#endif
 // LOG: the records are appended to the segment's log of the chunk (BatchArgs::log_cap != 0: dense, frame after frame,
 // a frame's run found through wofs) instead of one fixed slot per frame (park_layout).
 template <bool ABS_T, bool FULL, uint32_t NB_MAX, bool LOG = false>
@@ -429,7 +432,53 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
 
-    for (uint32_t i = 0; i < nb; ++i) {
+    uint32_t i = 0u;
+#if ADDER_LEAN_QUIET_PATH
+    // ---------------- quiet frames first (lean_quiet / lean_step_quiet, adder_pixel.hpp) ----------------
+    // A wave ALL of whose units hold their root and are popped (or black) stays in this loop for as long as every unit also
+    // passes its contrast test: the roots accumulate or fire, nothing leaves, no record is parked -- static content, lossy
+    // content away from what moves.  The first frame that is not quiet, and every later one of the launch, goes through the
+    // general loop below, which carries no test (adder_cb_kernel has the same loop; a test inside the general loop cost it
+    // 9-13 %).  Blocked launches only.
+    if constexpr (NB_MAX > 1u) {
+        uint64_t ok = ~0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) ok &= px[j].has0 & (px[j].popped | L::from(px[j].integ == 0.0f));
+        if (ok == ~0ull) {  // uniform
+            for (; i < nb; ++i) {
+                const uint32_t vin_q = (uint32_t)in_lds[i * kWave];
+                const uint32_t cth_q = __builtin_amdgcn_readlane(tab_cth, i);
+                uint64_t quiet = ~0ull, keeps = ~0ull;
+#pragma unroll
+                for (uint32_t j = 0; j < N; ++j) {
+                    const uint32_t v = (vin_q >> (8 * j)) & 0xffu;
+                    quiet &= lean_quiet<L>(px[j], v, cth_q);
+                    keeps &= lean_quiet_keeps<L>(px[j], v);
+                }
+                if (quiet != ~0ull) break;  // frame i is the general loop's
+                if (keeps == ~0ull) {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) lean_step_quiet<L, false>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) lean_step_quiet<L, true>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
+                }
+                // (wt of this frame stays 0: no events, no records; the slot walk below starts at frame i)
+            }
+            vin_w = i < nb ? (uint32_t)in_lds[i * kWave] : 0u;
+            if (!LOG) {
+                for (uint32_t k = 0; k < i; ++k) {  // uniform: the frames skipped above own their slots all the same
+                    seg += frame_stride_u;
+                    if (++ridx == chunk_u) {
+                        ridx = 0u;
+                        seg -= wrap_bytes;
+                    }
+                }
+            }
+        }
+    }
+#endif
+    for (; i < nb; ++i) {
         uint32_t next_w = 0u;
         if (NB_MAX > 1u && i + 1u < nb) next_w = (uint32_t)in_lds[(i + 1u) * kWave];  // one frame ahead
         const uint32_t cth = __builtin_amdgcn_readlane(tab_cth, i);

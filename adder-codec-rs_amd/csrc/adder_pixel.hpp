@@ -461,6 +461,46 @@ ADDER_HD LeanFlagsT<L> lean_step(LeanPxT<L> &p, uint32_t v, uint32_t cth, float 
     return fl;
 }
 
+// QUIET FRAMES of the lean step.  A unit with its root in place that is popped (or black: integration 0 and a zero
+// input, so get_d(sum) = 128 and need_to_pop_top stays clear, :394-396 / :449) and passes the contrast test leaves no
+// record: no flush, no pop -- the root accumulates, or fires and doubles its threshold.  What lean_step reduces to
+// under lean_quiet; the blocked kernel runs it for waves ALL of whose units are quiet (static content, lossy content
+// away from what moves).  has0, popped, base and last_fired_t stay as they are.
+template <class L>
+ADDER_HD typename L::Mask lean_quiet(const LeanPxT<L> &p, uint32_t v, uint32_t cth) {
+    using M = typename L::Mask;
+    const M calm = L::and_(p.has0, L::not_(L::from(contrast_exceeded(v, p.base, cth))));
+    return L::and_(calm, L::or_(p.popped, L::from(p.integ == 0.0f && v == 0u)));
+}
+// the root accumulates without firing (lean_step's `keep`)
+template <class L>
+ADDER_HD typename L::Mask lean_quiet_keeps(const LeanPxT<L> &p, uint32_t v) {
+    return L::from(!(fadd(p.integ, (float)v) >= p.thr));
+}
+// MAY_FIRE = false: the caller knows that every unit of its wave keeps
+template <class L, bool MAY_FIRE = true>
+ADDER_HD void lean_step_quiet(LeanPxT<L> &p, uint32_t v, float T) {
+    using M = typename L::Mask;
+    const float I = (float)v;
+    const float integ0 = p.integ;
+    const float sum = fadd(integ0, I);
+    const M zero = L::from(sum == 0.0f);
+    const float dt0 = p.dt;
+    const float dt_acc = fadd(dt0, T);
+    p.integ = sum;
+    p.dt = L::lane(zero) ? dt0 : dt_acc;
+    if (MAY_FIRE) {
+        const M keep = L::from(!(sum >= p.thr));
+        const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);
+        const M unit_prop = L::or_(zero, L::from(p.thr == 0.0f));
+        const float q = fdiv_small(fsub(p2, integ0), I);
+        const float prop = L::lane(unit_prop) ? 1.0f : q;
+        const float bdt_fire = fadd(dt0, fmul(T, prop));
+        p.thr = L::lane(keep) ? p.thr : fadd(p2, p2);
+        p.bdt = L::lane(keep) ? p.bdt : bdt_fire;
+    }
+}
+
 // Decoding of a record (expansion kernel, CPU harness): the events in emission order are A, B, C.
 struct LeanEvents {
     bool a, b, c;

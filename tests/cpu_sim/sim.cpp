@@ -44,7 +44,7 @@ struct Sim {
     int continuous;      // Mode::Continuous: the general arena step (cont_step), its own state planes
     std::vector<uint32_t> c_hdr, c_meta;           // [unit], [node][unit]
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
-    uint64_t fast_steps, generic_steps, lean_steps, cb_steps, cb_quiet_steps;
+    uint64_t fast_steps, generic_steps, lean_steps, cb_steps, cb_quiet_steps, lean_quiet_steps;
     int cb_quiet_path;  // take the device's quiet-wave reduction wherever a unit qualifies (default on)
     int use_cb;          // Collapse with delta_t_max > time: the bounded step (cb_step) instead of the generic one
     int frac_time_seen;  // a non-integer time_spanned has been integrated since the last reset (cb needs exact sums)
@@ -141,7 +141,7 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->use_fast = 1;
     s->generic_sticky = 0;
     s->continuous = 0;
-    s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = s->cb_quiet_steps = 0;
+    s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = s->cb_quiet_steps = s->lean_quiet_steps = 0;
     s->cb_quiet_path = 1;
     s->use_cb = 1;
     s->frac_time_seen = 0;
@@ -197,6 +197,7 @@ uint64_t sim_generic_steps(const Sim *s) { return s->generic_steps; }
 uint64_t sim_lean_steps(const Sim *s) { return s->lean_steps; }
 uint64_t sim_cb_steps(const Sim *s) { return s->cb_steps; }
 uint64_t sim_cb_quiet_steps(const Sim *s) { return s->cb_quiet_steps; }
+uint64_t sim_lean_quiet_steps(const Sim *s) { return s->lean_quiet_steps; }
 void sim_set_cb_quiet_path(Sim *s, int on) { s->cb_quiet_path = on; }
 void sim_set_use_cb(Sim *s, int on) { s->use_cb = on; }
 
@@ -430,6 +431,19 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
                 }
                 if (lean) {
                     LeanPx p = lean_unpack<ScalarLanes>(hdr, gi, gd, gb, glf);
+                    if (s->cb_quiet_path && lean_quiet(p, v, sc.cth)) {
+                        // the blocked kernel's quiet-frame loop: must equal the step and leave no record
+                        if (!lean_quiet_keeps(p, v) || (s->lean_steps & 1u)) lean_step_quiet<ScalarLanes, true>(p, v, time_spanned);
+                        else lean_step_quiet<ScalarLanes, false>(p, v, time_spanned);
+                        s->lean_quiet_steps++;
+                        s->lean_steps++;
+                        s->hdr[u] = lean_hdr(p);
+                        s->integ0[u] = p.integ; s->dt0[u] = p.dt; s->bdt0[u] = p.bdt;
+                        if (s->abs_t) s->lastf[u] = p.lastf;
+                        s->running[u] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(p.thr)), f32_as_u32(p.bdt),
+                                                               (double)s->ref_time);
+                        continue;
+                    }
                     LeanRec rec;
                     const uint32_t tag = (uint32_t)(u & 127u) << kLeanUnitShift;  // unit inside its 128-unit segment
                     const LeanFlagsT<ScalarLanes> fl = s->abs_t ? lean_step<true>(p, v, sc.cth, time_spanned, sc, tag, rec)

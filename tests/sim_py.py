@@ -60,6 +60,8 @@ def lib():
     L.sim_cb_quiet_steps.restype = C.c_uint64
     L.sim_cb_quiet_steps.argtypes = [vp]
     L.sim_set_cb_quiet_path.argtypes = [vp, C.c_int]
+    L.sim_lean_quiet_steps.restype = C.c_uint64
+    L.sim_lean_quiet_steps.argtypes = [vp]
     L.sim_set_use_cb.argtypes = [vp, i32]
     L.sim_integrate_cb_block.restype = i32
     L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
@@ -184,6 +186,10 @@ class Sim:
     @property
     def cb_quiet_steps(self):
         return self.L.sim_cb_quiet_steps(self.h)
+
+    @property
+    def lean_quiet_steps(self):
+        return self.L.sim_lean_quiet_steps(self.h)
 
     def set_cb_quiet_path(self, on):
         self.L.sim_set_cb_quiet_path(self.h, int(on))

@@ -145,6 +145,10 @@ def test_lean_step_is_the_path_of_the_headline_mode(time_mode, crf):
         for k in range(len(clip)):
             _same(ov, sv, clip[k], 255.0)
         assert sv.lean_steps == 120 * 35 and sv.fast_steps == 0 and sv.generic_steps == 0
+        if kind == "static":  # lean_quiet / lean_step_quiet (the blocked kernel's quiet-frame loop) took most of them
+            assert sv.lean_quiet_steps > 0.8 * sv.lean_steps, (kind, sv.lean_quiet_steps)
+        if kind == "dark":
+            assert sv.lean_quiet_steps > 0
 
 
 def test_lean_step_time_spanned_above_delta_t_max_and_long_runs():
