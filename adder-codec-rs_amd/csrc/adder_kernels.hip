@@ -1757,6 +1757,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // segment moved 3.4x the bytes: a segment parks ~20 records of 16 bytes)
     uint32_t my_tot = 0u;
     if (lane < kExpandSegs) my_tot = gload<uint32_t>(wtot, lane * 4u);
+    // quiet content: most waves find sixteen empty segments -- they are done here, before the second load and the set-up
+    if (__builtin_amdgcn_ballot_w64((my_tot & 0xffffu) != 0u) == 0ull) return;
     const uint32_t pref0 = gload<uint32_t>(wpref, 0u);  // events of the frame before segment seg0
     // Lean: segments go in PAIRS, lanes 0-31 on the even one and lanes 32-63 on the odd one (a segment
     // parks ~20 records: one 64-lane round per segment would leave two thirds of the lanes idle); a pair
