@@ -220,6 +220,29 @@ struct EmitCb {
 };
 template <class V>
 __device__ __forceinline__ void gstore_ev(void *base, uint32_t byte_off, V v) {
+#if defined(ADDER_EV_POLICY_ID) && defined(__HIP_DEVICE_COMPILE__)  // A/B builds: the cache-policy bits of the event stream's 16-byte stores
+#if ADDER_EV_POLICY_ID == 1
+#define ADDER_EV_POLICY "sc1"
+#elif ADDER_EV_POLICY_ID == 2
+#define ADDER_EV_POLICY "sc0 sc1"
+#elif ADDER_EV_POLICY_ID == 3
+#define ADDER_EV_POLICY "nt sc1"
+#elif ADDER_EV_POLICY_ID == 4
+#define ADDER_EV_POLICY "sc0 sc1 nt"
+#elif ADDER_EV_POLICY_ID == 5
+#define ADDER_EV_POLICY "sc0"
+#else
+#define ADDER_EV_POLICY "sc0 nt"
+#endif
+    if constexpr (sizeof(V) == 16) {
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        u4v r;
+        __builtin_memcpy(&r, &v, 16);
+        ADDER_GLOBAL char *const a64 = (ADDER_GLOBAL char *)base + byte_off;
+        asm volatile("global_store_dwordx4 %0, %1, off " ADDER_EV_POLICY : : "v"(a64), "v"(r) : "memory");
+        return;
+    }
+#endif
     if (ADDER_NT_EVENTS) gstore_nt<V>(base, byte_off, v);
     else gstore<V>(base, byte_off, v);
 }
