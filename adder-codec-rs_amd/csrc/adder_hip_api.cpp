@@ -975,6 +975,12 @@ static int alloc_deep_planes(AdderHipCtx *c) {
 // K1, and the K1s of chunk k+2 wait for them (the scratch ring holds two chunks).  Running the
 // expansion inside K1's grid (round 1) no longer pays: with the lean step both kernels are bound by the
 // memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
+// ADDER_HIP_PARK_FRAME_MAJOR=1: blocked batches park frame-major too (A/B: the expansion then reads a frame's slots
+// linearly, the frame kernel's waves write 64 slots num_waves * park_bytes apart)
+static bool park_frame_major() {
+    static const bool on = [] { const char *e = getenv("ADDER_HIP_PARK_FRAME_MAJOR"); return e && atoi(e) != 0; }();
+    return on;
+}
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
 static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames) {
     static const bool on = [] { const char *e = getenv("ADDER_HIP_LEAN_LOG"); return e && atoi(e) != 0; }();
@@ -1381,7 +1387,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (b.log_cap) {
         b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};  // (unused: the records are appended to logs)
-    } else if (launch_depth(c) == 1u && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
+    } else if ((launch_depth(c) == 1u || park_frame_major()) && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
         b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes, 31u, 0xffffffffu};
     } else {
         uint32_t sh = c->park_group_shift;
