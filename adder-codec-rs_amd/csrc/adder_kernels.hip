@@ -1151,6 +1151,9 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
 #ifndef ADDER_CB_QUIET_PATH
 #define ADDER_CB_QUIET_PATH 1
 #endif
+#ifndef ADDER_CB_SEQUENTIAL
+#define ADDER_CB_SEQUENTIAL 1
+#endif
 template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
                                                uint32_t u0, uint32_t gw, uint32_t lane, CbWaveLds &w) {
@@ -1281,8 +1284,26 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 
         // ---------------- the step of every unit + the event counts ----------------
         CbPlanT<L> plan[N];
-        CbMidT<L> mid[N];
         uint32_t lane_cnt = 0u;
+#if ADDER_CB_SEQUENTIAL
+        // one unit after the other, each through its whole step: the step's booleans of one unit are dead before the next
+        // unit's are made (with the booleans as wave masks that halves the scalar registers the step holds at once)
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            CbMidT<L> mid1;
+            cb_step_a<L>(px[j], lv[j], (vin_w >> (8 * j)) & 0xffu, sc, plan[j], mid1);
+            if (__builtin_amdgcn_ballot_w64(L::lane(mid1.walk)) != 0ull) {  // uniform
+                cb_step_reads<L>(lv[j], mid1);
+                cb_step_b<L, CbLevelsDev, true>(px[j], lv[j], T, sc, plan[j], mid1);
+            } else {
+                cb_step_b<L, CbLevelsDev, false>(px[j], lv[j], T, sc, plan[j], mid1);
+            }
+            depth_error = L::or_(depth_error, plan[j].depth_error);
+            if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;
+            lane_cnt += plan[j].count;
+        }
+#else
+        CbMidT<L> mid[N];
         bool lane_walks = false;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
@@ -1303,6 +1324,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;  // padding units: stepped freely, no events
             lane_cnt += plan[j].count;
         }
+#endif
         // ---------------- wave-level ordered compaction into the segment's log ----------------
         const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
