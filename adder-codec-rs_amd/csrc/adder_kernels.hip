@@ -1234,6 +1234,9 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     __builtin_amdgcn_s_waitcnt(0x0f70);
 #endif
     uint32_t i = 0u;
+#ifdef ADDER_DBG_CB_SKIP_LOOP  // diagnostic A/B build: prologue + epilogue only (what a launch costs before its first frame)
+    i = nb;
+#endif
     while (i < nb) {  // quiet frames, then general frames up to the next input group, then the same again
 #if ADDER_CB_QUIET_PATH
     // ---------------- quiet frames (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
@@ -1249,19 +1252,26 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) lane_ok = lane_ok && px[j].m == 1u && (L::lane(px[j].popped) || px[j].thr0 == 0.0f);
         if (__builtin_amdgcn_ballot_w64(!lane_ok) == 0ull) {  // uniform
+            // cb_quiet as wave masks: what does not change while the wave stays in this loop (m == 1; popped; a black
+            // root's zero threshold) is a scalar-register pair per unit, a frame adds two compares per unit
+            uint64_t unpopped[N];
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) unpopped[j] = __builtin_amdgcn_ballot_w64(!L::lane(px[j].popped));
             for (; i < nb; ++i) {
                 if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
                 const uint32_t vin_q = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
                 const uint32_t cth_q = __builtin_amdgcn_readlane(tab_cth, i);
-                bool lane_quiet = true, lane_fires = false;
+                uint64_t not_quiet = 0ull, fires = 0ull;
 #pragma unroll
                 for (uint32_t j = 0; j < N; ++j) {
                     const uint32_t v = (vin_q >> (8 * j)) & 0xffu;
-                    lane_quiet = lane_quiet && cb_quiet<L>(px[j], v, cth_q);
-                    lane_fires = lane_fires || cb_quiet_fires<L>(px[j], v);
+                    // (an unpopped unit is in here as a black one: it stays quiet only on a zero)
+                    not_quiet |= __builtin_amdgcn_ballot_w64(contrast_exceeded(v, px[j].base, cth_q)) |
+                                 (unpopped[j] & __builtin_amdgcn_ballot_w64(v != 0u));
+                    fires |= __builtin_amdgcn_ballot_w64(cb_quiet_fires<L>(px[j], v));
                 }
-                if (__builtin_amdgcn_ballot_w64(!lane_quiet) != 0ull) break;  // frame i: the general loop's (staged already)
-                if (__builtin_amdgcn_ballot_w64(lane_fires) != 0ull) {
+                if (not_quiet != 0ull) break;  // frame i: the general loop's (staged already)
+                if (fires != 0ull) {
 #pragma unroll
                     for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, true>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
                 } else {

@@ -3,7 +3,7 @@
 # 1080p default mode at crf 0 / crf 3 / static content / a 900-frame crf-3 run (steady state), C5's shape (4K RGB).
 cd /root/repo
 python -m pytest tests/test_gpu_parity.py -x -q -k "cb_ or crf0 or lossy or config_5 or model_fixtures or static" > gpurun_out/t.txt 2>&1; grep -v "RCCL\|HIP ver\|ROCm ver\|Hostname\|Librccl" gpurun_out/t.txt | tail -3
-for lib in "" /root/repo/build/variants/libadder_hip_nodbl.so; do
+for lib in "" /root/repo/build/variants/libadder_hip_prev.so; do
 echo "== lib=${lib##*/}"
 ADDER_HIP_LIB=$lib python - <<'PY'
 import os,sys,json
