@@ -1860,7 +1860,11 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     }
     uint32_t *const out_dw = reinterpret_cast<uint32_t *>(uniform_ptr(b->base.out));
     // the wave's events occupy [gpos, gpos + sum of its segments' event counts) of the stream
-    uint64_t gpos = b->base.frame_offsets[f] + __builtin_amdgcn_readfirstlane(pref0);
+    // (frame_offsets is written by the offsets kernel: a vector load; its value goes to scalar registers by hand, or all
+    // of the flush arithmetic below -- capacity check, phase, destination -- runs on the vector ALU in every lane)
+    const uint64_t fo = b->base.frame_offsets[f];
+    uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32)) << 32) |
+                     __builtin_amdgcn_readfirstlane((uint32_t)fo)) + __builtin_amdgcn_readfirstlane(pref0);
     uint32_t fill = 0u;                        // events staged (uniform)
     uint32_t phase = (uint32_t)(gpos * 3u) & 3u;  // dword phase of the staging buffer's first event
     bool dropped = false;
