@@ -103,6 +103,18 @@ __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters) {
         if (KIND == 27)
             asm volatile(REP8("v_readlane_b32 s20, %0, 3\n v_writelane_b32 %1, s20, 5\n v_readfirstlane_b32 s21, %2\n v_mov_b32 %3, s21\n")
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "s20", "s21");
+        if (KIND == 28)
+            asm volatile(REP8("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %0\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (KIND == 29)
+            asm volatile(REP8("v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %1, %1, %2\n v_mul_hi_u32 %2, %2, %3\n v_mul_hi_u32 %3, %3, %0\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (KIND == 30)
+            asm volatile(REP8("v_mul_u32_u24 %0, %0, %1\n v_mad_u32_u24 %1, %1, %2, %3\n v_mul_u32_u24 %2, %2, %3\n v_mad_u32_u24 %3, %3, %0, %1\n")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (KIND == 31)
+            asm volatile(REP8("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n")
+                         : "+v"(*(uint64_t *)&fa), "+v"(*(uint64_t *)&fc), "+v"(c), "+v"(d) : : "vcc");
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint32_t r = a + b + c + d + (uint32_t)fa + (uint32_t)fb + (uint32_t)fc + (uint32_t)fd + s0 + s1 + s2 + s3;
@@ -115,11 +127,11 @@ __global__ __launch_bounds__(256) void ub(uint64_t *out, int iters) {
 typedef void (*Fn)(uint64_t *, int);
 static const char *names[] = {"v_add_u32", "v_fma_f32", "v_cndmask", "v_cmp->sgpr", "v_rcp_f32", "s_add_u32 only",
                               "32 valu + 32 salu", "32 valu + 16 salu", "cvt_ubyte/sad/bfe/mbcnt", "v_pk f32",
-                              "v_add dpp", "s mask logic only", "v_cvt u32<->f32", "cmp->s_and->cndmask->add chain", "v_cndmask e64 sgpr mask", "v_cmp vcc + v_cndmask vcc pairs", "v_cmp sgpr + v_cndmask e64 pairs", "1 v_cmp vcc + 32 v_cndmask vcc", "v_addc_co vcc chain", "bfe/and_or/lshl_or/or3", "v_cvt_f32_ubyteN", "v_sad_u32", "v_mbcnt lo/hi", "and/or/shl/xor", "v_cmp f32 -> sgpr", "add/mul/sub f32", "v_cndmask 0,v,vcc", "readlane/writelane/readfirstlane/mov"};
-static const int instr_per_iter[] = {32, 32, 32, 32, 32, 32, 64, 48, 32, 32, 32, 32, 32, 32, 32, 32, 32, 33, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
+                              "v_add dpp", "s mask logic only", "v_cvt u32<->f32", "cmp->s_and->cndmask->add chain", "v_cndmask e64 sgpr mask", "v_cmp vcc + v_cndmask vcc pairs", "v_cmp sgpr + v_cndmask e64 pairs", "1 v_cmp vcc + 32 v_cndmask vcc", "v_addc_co vcc chain", "bfe/and_or/lshl_or/or3", "v_cvt_f32_ubyteN", "v_sad_u32", "v_mbcnt lo/hi", "and/or/shl/xor", "v_cmp f32 -> sgpr", "add/mul/sub f32", "v_cndmask 0,v,vcc", "readlane/writelane/readfirstlane/mov", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24 / v_mad_u32_u24", "v_mad_u64_u32"};
+static const int instr_per_iter[] = {32, 32, 32, 32, 32, 32, 64, 48, 32, 32, 32, 32, 32, 32, 32, 32, 32, 33, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
 
 int main() {
-    Fn fns[] = {ub<0>, ub<1>, ub<2>, ub<3>, ub<4>, ub<5>, ub<6>, ub<7>, ub<8>, ub<9>, ub<10>, ub<11>, ub<12>, ub<13>, ub<14>, ub<15>, ub<16>, ub<17>, ub<18>, ub<19>, ub<20>, ub<21>, ub<22>, ub<23>, ub<24>, ub<25>, ub<26>, ub<27>};
+    Fn fns[] = {ub<0>, ub<1>, ub<2>, ub<3>, ub<4>, ub<5>, ub<6>, ub<7>, ub<8>, ub<9>, ub<10>, ub<11>, ub<12>, ub<13>, ub<14>, ub<15>, ub<16>, ub<17>, ub<18>, ub<19>, ub<20>, ub<21>, ub<22>, ub<23>, ub<24>, ub<25>, ub<26>, ub<27>, ub<28>, ub<29>, ub<30>, ub<31>};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
@@ -130,7 +142,7 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int k = 0; k < 28; ++k) {
+    for (int k = 0; k < 32; ++k) {
         for (int w : {4, 8}) {
             const int grid = cus * w;  // 256-thread blocks: one wave per SIMD each
             hipLaunchKernelGGL(fns[k], dim3(grid), dim3(256), 0, 0, d, 64);  // warm
