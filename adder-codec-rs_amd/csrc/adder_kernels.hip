@@ -1283,7 +1283,10 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         }
     }
 #endif
-    for (; i < nb; ++i) {
+    // (general frames up to the end of the input group -- the quiet test above then gets another look; the bound is the
+    // loop's own, the frames carry no test)
+    const uint32_t i_end = ADDER_CB_QUIET_PATH ? ((i / kCbInFrames + 1u) * kCbInFrames < nb ? (i / kCbInFrames + 1u) * kCbInFrames : nb) : nb;
+    for (; i < i_end; ++i) {
         // (a frame handed over by the quiet loop mid-group finds its group staged)
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
         // (reading the next frame's bytes one frame ahead was measured: no difference)
@@ -1358,12 +1361,6 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             off += plan[j].count;
             cb_pop<L>(px[j], plan[j], lv[j]);
         }
-#if ADDER_CB_QUIET_PATH
-        if (((i + 1u) % kCbInFrames) == 0u) {  // (uniform) the next frame starts an input group: back to the quiet test
-            ++i;
-            break;
-        }
-#endif
     }
     }
     if (L::lane(depth_error)) raise(a.status, kStatusDepth);
