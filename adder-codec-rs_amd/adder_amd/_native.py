@@ -82,6 +82,22 @@ class AdderFramerParams(C.Structure):
     ]
 
 
+class AdderBandRecords(C.Structure):
+    """include/adder_hip.h::AdderBandRecords (records over the wire)"""
+    _fields_ = [
+        ("num_frames", C.c_uint32),
+        ("num_segments", C.c_uint32),
+        ("record_bytes", C.c_uint32),
+        ("row_begin", C.c_uint32),
+        ("rows", C.c_uint32),
+        ("d_counts", C.c_void_p),
+        ("d_prefix", C.c_void_p),
+        ("d_runs", C.c_void_p),
+        ("d_records", C.c_void_p),
+        ("d_frame_offsets", C.c_void_p),
+    ]
+
+
 class AdderCompressedParams(C.Structure):
     """include/adder_compressed.h::AdderCompressedParams"""
     _fields_ = [
@@ -147,6 +163,10 @@ SYMBOLS = {
     "adder_hip_last_post_avg_us": (_f32, [_vp]),
     "adder_hip_last_post_chunks": (_u32, [_vp]),
     "adder_hip_chunk_frames": (_u32, [_vp]),
+    "adder_hip_band_segments": (_u32, [_vp]),
+    "adder_hip_integrate_records_device": (C.c_int, [_vp, _vp, _u32, C.c_float, _vp, _vp, _vp]),
+    "adder_hip_expand_records_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _u64, _vp, _vp]),
+    "adder_hip_expand_status": (C.c_int, [_vp, _vp]),
     "adder_hip_last_batch_records": (_u64, [_vp]),
     "adder_hip_set_frames_per_launch": (_i32, [_vp, _u32]),
     "adder_hip_reset": (_i32, [_vp]),

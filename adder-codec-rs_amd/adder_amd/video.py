@@ -307,6 +307,36 @@ class HipVideo:
             self.h, d_frames.data_ptr(), T, ts, d_events.data_ptr(), cap, d_offsets.data_ptr(),
             C.c_void_p(stream) if stream else None))
 
+    # ---- records over the wire (include/adder_hip.h): a band ships its parked records, root expands them ----
+    def band_segments(self):
+        return int(self.L.adder_hip_band_segments(self.h))
+
+    def integrate_records_device(self, d_frames, d_offsets, time_spanned=None, stream=None):
+        """Queues T <= chunk_frames() frames WITHOUT expanding them; returns the AdderBandRecords description (device
+        pointers into this context's scratch, valid until its next batch).  finish() then completes the batch;
+        last_batch_records() is the number of records behind d_records."""
+        T = d_frames.shape[0]
+        assert d_frames.is_contiguous() and d_frames.numel() == T * self.n_units
+        assert d_offsets.numel() >= T + 1 and d_offsets.element_size() == 8
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        rec = N.AdderBandRecords()
+        N.check(self.h, self.L.adder_hip_integrate_records_device(
+            self.h, d_frames.data_ptr(), T, ts, d_offsets.data_ptr(), C.c_void_p(stream) if stream else None, C.byref(rec)))
+        return rec
+
+    def expand_records_device(self, bands, d_merged, merged_base, d_merged_offsets, stream=None):
+        """On root, after its own integrate_records_device + finish of the same frames: bands = AdderBandRecords in raster
+        order (pointers in this device's memory).  Appends to d_merged at event index merged_base; d_merged_offsets
+        (int64 / uint64 CUDA tensor, >= T + 1 entries) receives the absolute frame offsets."""
+        arr = (N.AdderBandRecords * len(bands))(*bands)
+        cap = d_merged.numel() * d_merged.element_size() // 12
+        N.check(self.h, self.L.adder_hip_expand_records_device(
+            self.h, C.byref(arr), len(bands), d_merged.data_ptr(), cap, int(merged_base), d_merged_offsets.data_ptr(),
+            C.c_void_p(stream) if stream else None))
+
+    def expand_status(self, stream=None):
+        N.check(self.h, self.L.adder_hip_expand_status(self.h, C.c_void_p(stream) if stream else None))
+
     def finish(self):
         n = C.c_size_t(0)
         rc = self.L.adder_hip_finish(self.h, C.byref(n))

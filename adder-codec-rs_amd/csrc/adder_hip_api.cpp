@@ -147,6 +147,11 @@ struct AdderHipCtx {
     bool eager_two_streams = false;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
+    // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
+    bool records_only = false;        // the batch being queued stops after its scan
+    float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
+    uint8_t *d_band_desc = nullptr, *h_band_desc = nullptr;  // root: n_bands BatchArgs + pointer / destination tables
+    size_t band_desc_cap = 0;
     unsigned long long *d_timeline = nullptr;  // ADDER_HIP_TIMELINE diagnostics
     // sparse steps (adder_hip_integrate_sparse): running_t per unit, and the work buffers of a call
     bool sparse_mode = false;  // c_thresh / counter / running_t live per unit from the first sparse call on
@@ -294,6 +299,8 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
+    if (c->d_band_desc) (void)hipFree(c->d_band_desc);
+    if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
     if (c->d_timeline) (void)hipFree(c->d_timeline);
     for (void *p : {(void *)c->rt_px, (void *)c->sw.steps, (void *)c->sw.keys0, (void *)c->sw.keys1, (void *)c->sw.idx0,
                     (void *)c->sw.idx1, (void *)c->sw.count, (void *)c->sw.offs, (void *)c->sw.stage, c->sw.temp,
@@ -1079,7 +1086,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
+        if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));
             c->timed_posts += 1;
@@ -1306,7 +1313,10 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) |
-                             (lean_log_batch(c, generic, num_frames) ? 64u : 0u);  // 64: lean records in per-segment logs
+                             ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
+    if (c->records_only && (generic || c->continuous || fpath))
+        return fail(c, ADDER_E_BAD_PARAMS, "records can be handed out in the lean regime only (Collapse, delta_t_max <= "
+                    "time_spanned, no feature mode, no generic batch before): gather events instead");
     if (generic) {
         // per-event records go to a log per segment and chunk, sized by the hard bound of what a segment can emit
         // (pop_top and a flush exclude each other in one frame when delta_t_max >= 2 * time: 2 instead of 3 per frame)
@@ -1445,7 +1455,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->h_result->valid = 0u;
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     int rc = ADDER_OK;
-    if (fpath) {
+    if (c->records_only) {
+        rc = launch_frame_loop(c, num_frames, variant, stream, nullptr, false);  // (stops after scan + offsets)
+    } else if (fpath) {
         rc = launch_feature_loop(c, num_frames, variant, stream);
     } else if (c->use_graph && !timing) {
         hipGraphExec_t exec = nullptr;
@@ -1468,6 +1480,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->running_t = rt;
     c->c_thresh = cth;
     c->c_counter = cctr;
+    c->last_time_spanned = time_spanned;
     c->frames_done += num_frames;
     c->band_frame_pending = band_features(c);
     return ADDER_OK;
@@ -1501,6 +1514,149 @@ extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frame
     c->pending_frames = num_frames;
     c->pending_cap = out_cap;
     return ADDER_OK;
+}
+
+// ---- records over the wire (include/adder_hip.h) ----
+extern "C" uint32_t adder_hip_band_segments(const AdderHipCtx *c) { return c ? c->num_waves : 0u; }
+
+extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames,
+                                                  float time_spanned, uint64_t *d_frame_offsets, void *stream,
+                                                  AdderBandRecords *out) {
+    if (!c || !out) return ADDER_E_BAD_PARAMS;
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    if (c->pending) return fail(c, ADDER_E_BAD_PARAMS, "previous device batch not finished (call adder_hip_finish)");
+    if (c->f_submitted != c->f_collected || c->submitted != c->collected)
+        return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight (collect them first)");
+    if (!d_frames || !d_frame_offsets || num_frames == 0) return fail(c, ADDER_E_BAD_PARAMS, "null pointer / no frames");
+    if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // the scratch must exist before the chunk size is known
+    if (!c->continuous) {
+        int rc_ = alloc_scratch(c, c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? AdderHipCtx::kScratchLean : AdderHipCtx::kScratchLean8);
+        if (rc_ != ADDER_OK && !c->generic_sticky) return rc_;
+    }
+    if (c->ring_chunks < 2 || num_frames > c->chunk)
+        return fail(c, ADDER_E_BAD_PARAMS, "a records batch holds at most adder_hip_chunk_frames() = %u frames", c->chunk);
+    c->records_only = true;
+    const bool snap = c->no_snapshot;
+    c->no_snapshot = true;  // (nothing can overflow: no event buffer)
+    int rc = enqueue_frames(c, d_frames, num_frames, time_spanned, nullptr, (size_t)1 << 62, d_frame_offsets, s);
+    c->no_snapshot = snap;
+    c->records_only = false;
+    if (rc != ADDER_OK) {
+        c->poisoned = true;
+        return rc;
+    }
+    // the batch started at slot 0: the first num_frames rows of the rings are its tables, chunk 0 of the ring its logs;
+    // the logs' used prefixes are packed into chunk 1's (idle) region, the runs re-based onto the packed buffer
+    const uint32_t rb = lean_rec_bytes(c->p.time_mode == ADDER_TIME_ABSOLUTE_T);
+    const uint32_t cap = kWaveUnits * c->chunk;
+    const size_t chunk_bytes = (size_t)c->num_waves * cap * rb;
+    uint8_t *const packed = c->park_ring + chunk_bytes;
+    uint32_t *const pbase = c->wcur + c->num_waves;
+    uint64_t *const d_total = reinterpret_cast<uint64_t *>(c->wcur + 2 * (size_t)c->num_waves);
+    HIPCHK(c, adder_launch_log_pack(c->park_ring, cap, rb, c->wcur, pbase, c->num_waves, num_frames, c->wofs_ring, packed,
+                                    chunk_bytes, d_total, c->status, s));
+    HIPCHK(c, hipEventRecord(c->ev_stop, s));
+    out->num_frames = num_frames;
+    out->num_segments = c->num_waves;
+    out->record_bytes = rb;
+    out->row_begin = c->p.row_begin;
+    out->rows = c->rows;
+    out->d_counts = c->wtot_ring;
+    out->d_prefix = c->wpref_ring;
+    out->d_runs = c->wofs_ring;
+    out->d_records = packed;
+    out->d_frame_offsets = d_frame_offsets;
+    c->pending = true;
+    c->pending_stream = s;
+    c->pending_offsets = d_frame_offsets;
+    c->pending_frames = num_frames;
+    c->pending_cap = (size_t)1 << 62;
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRecords *bands, uint32_t n_bands,
+                                               AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
+                                               uint64_t *d_merged_offsets, void *stream) {
+    if (!c || !bands || n_bands == 0 || !d_merged_offsets || (!d_merged && merged_cap)) return ADDER_E_BAD_PARAMS;
+    if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
+    const uint32_t nf = bands[0].num_frames;
+    const bool abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T;
+    if (nf == 0 || nf > kMaxChunk || nf > c->ftab_cap) return fail(c, ADDER_E_BAD_PARAMS, "bad num_frames (root integrates the same frames first)");
+    for (uint32_t r = 0; r < n_bands; ++r)
+        if (bands[r].num_frames != nf || bands[r].record_bytes != lean_rec_bytes(abs_t) || !bands[r].d_counts ||
+            !bands[r].d_prefix || !bands[r].d_runs || !bands[r].d_records || !bands[r].d_frame_offsets ||
+            bands[r].num_segments % (uint32_t)ADDER_EXPAND_SEGS != 0u || bands[r].rows == 0)
+            return fail(c, ADDER_E_BAD_PARAMS, "band %u: bad description", r);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // device block: n_bands BatchArgs, then the bands' offsets pointers, then the destination table [n_bands][nf]
+    const size_t ptrs_at = (size_t)n_bands * kBatchDescBytes;
+    const size_t dest_at = ptrs_at + (((size_t)n_bands * sizeof(uint64_t *) + 255) & ~(size_t)255);
+    const size_t bytes = dest_at + (size_t)n_bands * nf * sizeof(uint64_t);
+    if (c->band_desc_cap < bytes) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->d_band_desc) HIPCHK(c, hipFree(c->d_band_desc));
+        if (c->h_band_desc) HIPCHK(c, hipHostFree(c->h_band_desc));
+        c->d_band_desc = c->h_band_desc = nullptr;
+        c->band_desc_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_band_desc), bytes));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_band_desc), bytes, hipHostMallocDefault));
+        c->band_desc_cap = bytes;
+    } else {
+        HIPCHK(c, hipStreamSynchronize(s));  // (the host block is reused: the previous call's upload has to be through)
+    }
+    uint64_t *const d_dest = reinterpret_cast<uint64_t *>(c->d_band_desc + dest_at);
+    const uint64_t **h_ptrs = reinterpret_cast<const uint64_t **>(c->h_band_desc + ptrs_at);
+    for (uint32_t r = 0; r < n_bands; ++r) {
+        BatchArgs &b = *reinterpret_cast<BatchArgs *>(c->h_band_desc + (size_t)r * kBatchDescBytes);
+        memset(&b, 0, sizeof b);
+        base_args(c, &b.base);
+        b.base.n_units = bands[r].rows * c->p.width * c->p.channels;
+        b.base.num_waves = bands[r].num_segments;
+        b.base.row_begin = bands[r].row_begin;
+        b.base.out = reinterpret_cast<AdderEventPod *>(d_merged);
+        b.base.out_cap = merged_cap;
+        b.base.frame_offsets = d_dest + (size_t)r * nf;  // (the expansion reads [f] only: where the band's frame starts)
+        b.base.lean = 1u;
+        b.base.abs_t = abs_t ? 1u : 0u;
+        b.base.sc = make_consts(c, c->last_time_spanned);
+        b.ftab = c->d_ftab;  // root's own batch of the same frames
+        b.park_ring = const_cast<uint8_t *>(bands[r].d_records);
+        b.park_bytes = 0;
+        b.log_cap = 0;  // (expansion format 3 with a zero region stride: the runs index ONE packed buffer)
+        b.wofs_ring = const_cast<uint32_t *>(bands[r].d_runs);
+        b.wtot_ring = const_cast<uint32_t *>(bands[r].d_counts);
+        b.wpref_ring = const_cast<uint32_t *>(bands[r].d_prefix);
+        b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};
+        b.slots = kMaxChunk;  // slot of frame f = f: the tables' rows
+        b.chunk = kMaxChunk;
+        h_ptrs[r] = bands[r].d_frame_offsets;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_band_desc, c->h_band_desc, dest_at, hipMemcpyHostToDevice, s));
+    HIPCHK(c, adder_launch_band_layout(reinterpret_cast<const uint64_t *const *>(c->d_band_desc + ptrs_at), n_bands, nf,
+                                       merged_base, d_merged_offsets, d_dest, s));
+    const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u;
+    for (uint32_t r = 0; r < n_bands; ++r)
+        HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(c->d_band_desc + (size_t)r * kBatchDescBytes), 0u, nf,
+                                      bands[r].num_segments, variant, 0u, s));
+    return ADDER_OK;
+}
+
+extern "C" int adder_hip_expand_status(AdderHipCtx *c, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    uint32_t st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (st & kStatusCapacity) {
+        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), s));
+        return fail(c, ADDER_E_OUT_CAPACITY, "the merged event buffer was too small: events were dropped");
+    }
+    return status_to_code(c, st);
 }
 
 extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {

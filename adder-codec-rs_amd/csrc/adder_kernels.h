@@ -291,6 +291,12 @@ hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
                                uint32_t variant, uint32_t grid_cap, hipStream_t stream);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
+// records over the wire (adder_kernels.hip: adder_log_pack_kernel, adder_band_layout_kernel)
+hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t rec_bytes, const uint32_t *wcur,
+                                 uint32_t *pbase, uint32_t num_waves, uint32_t nf, uint32_t *wofs_rows, uint8_t *packed,
+                                 uint64_t packed_cap_bytes, uint64_t *d_total, uint32_t *status, hipStream_t stream);
+hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
+                                    uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,
                                       uint32_t chunk_rows, uint32_t num_chunks, uint32_t *offsets,
                                       hipStream_t stream);

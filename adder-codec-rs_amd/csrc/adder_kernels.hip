@@ -2509,6 +2509,104 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Records over the wire (multi-GPU gather): a band ships its PARKED RECORDS (0.35x the bytes of its events) and root
+// expands them.  adder_log_pack_*: the lean record logs of one batch of <= chunk frames (it starts at slot 0) -> one
+// packed buffer, every segment's used prefix behind the one before it; wofs rows then index the packed buffer.
+// adder_band_layout_kernel (root): where each band's events of each frame go in the merged stream.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void adder_log_bases_kernel(const uint32_t *__restrict__ wcur, uint32_t num_waves,
+                                                              uint32_t *__restrict__ pbase, uint64_t *__restrict__ total) {
+    __shared__ uint32_t s_part[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    uint32_t run = 0u;
+    for (uint32_t s0 = 0; s0 < num_waves; s0 += 1024u) {  // uniform trips
+        const uint32_t sgm = s0 + tid;
+        const uint32_t v = sgm < num_waves ? wcur[sgm] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v, lane);
+        if (lane == 63u) s_part[wid] = incl;
+        __syncthreads();
+        uint32_t base = run, tot = 0u;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t t = s_part[w];
+            if (w < wid) base += t;
+            tot += t;
+        }
+        if (sgm < num_waves) pbase[sgm] = base + incl - v;
+        run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *total = run;
+}
+// one wave per segment: its used log prefix -> packed + pbase[seg]; its column of the wofs rows += pbase[seg]
+__global__ __launch_bounds__(kBlockThreads) void adder_log_pack_kernel(const uint8_t *__restrict__ logs, uint32_t log_cap,
+                                                                      uint32_t rec_bytes, const uint32_t *__restrict__ wcur,
+                                                                      const uint32_t *__restrict__ pbase, uint32_t num_waves,
+                                                                      uint32_t nf, uint32_t *__restrict__ wofs_rows,
+                                                                      uint8_t *__restrict__ packed, uint64_t packed_cap_bytes,
+                                                                      uint32_t *status) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t sgm = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    if (sgm >= num_waves) return;
+    const uint32_t n = wcur[sgm], base = pbase[sgm];
+    const uint32_t dwords = n * (rec_bytes / 4u);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(logs + (size_t)sgm * log_cap * rec_bytes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(packed + (size_t)base * rec_bytes);
+    if ((uint64_t)(base + n) * rec_bytes > packed_cap_bytes) {
+        if (lane == 0u) raise(status, kStatusScratch);
+    } else {
+        for (uint32_t k = lane; k < dwords; k += kWave) dst[k] = src[k];
+    }
+    for (uint32_t f = lane; f < nf; f += kWave) wofs_rows[(size_t)f * num_waves + sgm] += base;
+}
+// One block.  offs[r] = band r's local frame offsets (nf + 1 entries, starting anywhere); merged_offsets[0 .. nf] (the
+// caller's, [0] = merged_base on entry... written here) and dest[r * nf + f] = where band r's events of frame f start.
+__global__ __launch_bounds__(kWave) void adder_band_layout_kernel(const uint64_t *const *__restrict__ offs, uint32_t n_bands,
+                                                                 uint32_t nf, uint64_t merged_base,
+                                                                 uint64_t *__restrict__ merged_offsets,
+                                                                 uint64_t *__restrict__ dest) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t run = merged_base;
+    for (uint32_t f0 = 0; f0 < nf; f0 += kWave) {  // (one trip: nf <= 64)
+        const uint32_t f = f0 + lane;
+        uint64_t tot = 0ull;
+        if (f < nf)
+            for (uint32_t r = 0; r < n_bands; ++r) tot += offs[r][f + 1u] - offs[r][f];
+        uint64_t incl = tot;
+#pragma unroll
+        for (uint32_t o = 1; o < kWave; o <<= 1) {
+            const uint64_t e = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += e;
+        }
+        if (f < nf) {
+            uint64_t pos = run + incl - tot;
+            if (f == 0u) merged_offsets[0] = pos;
+            for (uint32_t r = 0; r < n_bands; ++r) {
+                dest[(size_t)r * nf + f] = pos;
+                pos += offs[r][f + 1u] - offs[r][f];
+            }
+            merged_offsets[f + 1u] = run + incl;
+        }
+        run += __shfl(incl, kWave - 1, kWave);
+    }
+}
+extern "C" hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t rec_bytes, const uint32_t *wcur,
+                                            uint32_t *pbase, uint32_t num_waves, uint32_t nf, uint32_t *wofs_rows,
+                                            uint8_t *packed, uint64_t packed_cap_bytes, uint64_t *d_total, uint32_t *status,
+                                            hipStream_t stream) {
+    hipLaunchKernelGGL(adder_log_bases_kernel, dim3(1), dim3(1024), 0, stream, wcur, num_waves, pbase, d_total);
+    const uint32_t grid = (num_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(adder_log_pack_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, logs, log_cap, rec_bytes, wcur, pbase,
+                       num_waves, nf, wofs_rows, packed, packed_cap_bytes, status);
+    return hipGetLastError();
+}
+extern "C" hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
+                                               uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_band_layout_kernel, dim3(1), dim3(kWave), 0, stream, offs, n_bands, nf, merged_base,
+                       merged_offsets, dest);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream) {
     const uint32_t bs = 256;
     hipLaunchKernelGGL(adder_fill_u32_kernel, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, stream, p, n, v);

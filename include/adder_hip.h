@@ -289,6 +289,43 @@ uint32_t adder_hip_last_post_chunks(AdderHipCtx *ctx);
 uint32_t adder_hip_chunk_frames(const AdderHipCtx *ctx);
 /* Parked records of the last device batch (diagnostics: the bytes the frame kernel really moved). */
 uint64_t adder_hip_last_batch_records(AdderHipCtx *ctx);
+/* ---- records over the wire (multi-GPU gather of SURVEY 8(e); protocol in include/adder_gather.h / INTEGRATION.md) ----
+ * The ordered gather to one device moves every event over ONE xGMI link per peer.  The frame kernel's parked records
+ * carry the same information in 0.35x the bytes (8 bytes per unit with events instead of 12 per event), so a band can
+ * ship those and let root expand them: adder_hip_integrate_records_device runs a batch of at most
+ * adder_hip_chunk_frames() frames up to its scan (no expansion: nothing is written to an event buffer) and describes
+ * what root needs; adder_hip_expand_records_device, on root, expands the bands' records -- its own included -- into the
+ * merged frame-major stream, band after band inside every frame = raster order (video.rs:677-734).  Contexts in the lean
+ * regime only (Collapse, delta_t_max <= time_spanned, no feature mode): others fail with ADDER_E_BAD_PARAMS and the
+ * caller gathers events (adder_gather_events).  The tables and the records live in the band context's scratch until its
+ * next batch; a peer's copies of them (received over RCCL) are described by the same struct with root's pointers. */
+typedef struct AdderBandRecords {
+    uint32_t num_frames;        /* rows of the three tables */
+    uint32_t num_segments;      /* columns: the band's 128-unit segments, padded (adder_hip_band_segments) */
+    uint32_t record_bytes;      /* 8 (DeltaT) or 12 (AbsoluteT) */
+    uint32_t row_begin, rows;   /* the band */
+    const uint32_t *d_counts;   /* [num_frames][num_segments] events | records << 16 of the segment in the frame */
+    const uint32_t *d_prefix;   /* [num_frames][num_segments] events of the frame before the segment, inside the band */
+    const uint32_t *d_runs;     /* [num_frames][num_segments] first record of the segment's run in d_records */
+    const uint8_t *d_records;   /* the batch's records, adder_hip_last_batch_records() of them after adder_hip_finish */
+    const uint64_t *d_frame_offsets; /* [num_frames + 1] the band's own event offsets of the batch */
+} AdderBandRecords;
+uint32_t adder_hip_band_segments(const AdderHipCtx *ctx);
+/* Like adder_hip_integrate_device, without an event buffer: d_frame_offsets ([num_frames + 1], device) receives the
+ * band's event offsets, *out the description (device pointers into the context's scratch, valid until its next batch).
+ * adder_hip_finish completes the batch as usual (its count is the events the batch WOULD emit). */
+int adder_hip_integrate_records_device(AdderHipCtx *ctx, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
+                                       uint64_t *d_frame_offsets, void *stream, AdderBandRecords *out);
+/* On root, after its own adder_hip_integrate_records_device of the SAME frames (root's frame table gives the frames'
+ * running_t): bands[0 .. n_bands) in raster order, every pointer in root's memory.  Appends the frames' events to
+ * d_merged at event index merged_base and writes d_merged_offsets[0 .. num_frames] (absolute: [0] = merged_base).
+ * Queues on `stream`; a d_merged too small is reported by the context's status at the next adder_hip_finish /
+ * adder_hip_expand_status (events past merged_cap are dropped). */
+int adder_hip_expand_records_device(AdderHipCtx *root, const AdderBandRecords *bands, uint32_t n_bands, AdderEvent *d_merged,
+                                    size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets, void *stream);
+/* Waits for `stream` and returns ADDER_OK or the failure the expansions since the last call ran into (capacity). */
+int adder_hip_expand_status(AdderHipCtx *root, void *stream);
+
 /* Mean number of frames one timed frame-kernel launch stepped (see frames_per_launch). */
 float adder_hip_last_launch_frames(AdderHipCtx *ctx);
 
