@@ -95,6 +95,7 @@ class AdderBandRecords(C.Structure):
         ("d_runs", C.c_void_p),
         ("d_records", C.c_void_p),
         ("d_frame_offsets", C.c_void_p),
+        ("d_frame_table", C.c_void_p),
     ]
 
 
@@ -167,6 +168,10 @@ SYMBOLS = {
     "adder_hip_integrate_records_device": (C.c_int, [_vp, _vp, _u32, C.c_float, _vp, _vp, _vp]),
     "adder_hip_expand_records_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _u64, _vp, _vp]),
     "adder_hip_expand_status": (C.c_int, [_vp, _vp]),
+    "adder_hip_records_wire_bytes": (_sz, [_u32, _u32, _u32, _u64]),
+    "adder_hip_records_wire_sections": (None, [_u32, _u32, _u32, _vp]),
+    "adder_hip_records_to_wire": (C.c_int, [_vp, _vp, _u64, _vp, _sz, _vp]),
+    "adder_hip_last_batch_stream": (_vp, [_vp]),
     "adder_hip_last_batch_records": (_u64, [_vp]),
     "adder_hip_set_frames_per_launch": (_i32, [_vp, _u32]),
     "adder_hip_reset": (_i32, [_vp]),

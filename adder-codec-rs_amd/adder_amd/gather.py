@@ -25,6 +25,7 @@ SYMBOLS = {
     "adder_gather_events": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _sz, _vp, C.POINTER(_sz), _vp]),
     "adder_gather_events_at": (_i32, [_vp, _vp, _vp, _u32, _i32, _vp, _sz, C.c_uint64, _vp, C.POINTER(_sz), _vp]),
     "adder_gather_layout": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "adder_gather_records_at": (_i32, [_vp, _vp, C.c_uint64, C.c_uint64, _i32, _vp, _sz, C.c_uint64, _vp, C.POINTER(_sz), _vp]),
 }
 _lib = None
 
@@ -104,6 +105,21 @@ class HipGather:
             self.h, d_events.data_ptr(), d_offsets.data_ptr() + 8 * frame_begin, T, root,
             None if d_merged is None else d_merged.data_ptr(), cap, merged_base,
             None if d_merged_offsets is None else d_merged_offsets.data_ptr() + 8 * frame_begin, C.byref(n),
+            C.c_void_p(stream) if stream else None)
+        self.last_required = n.value
+        self._check(rc)
+        return n.value
+
+    def gather_records_at(self, rec, n_records, n_events, root, d_merged, merged_base, d_merged_offsets, stream=None):
+        """Records over the wire (adder_gather_records_at): rec = HipVideo.integrate_records_device's description of the
+        chunk just finished; the chunk's merged events are appended behind merged_base, d_merged_offsets is the (already
+        advanced) view of the merged offsets at the chunk's first frame.  Returns the chunk's merged length on root."""
+        n = C.c_size_t(0)
+        cap = 0 if d_merged is None else d_merged.numel() * d_merged.element_size() // 12
+        rc = self.L.adder_gather_records_at(
+            self.h, C.byref(rec), int(n_records), int(n_events), root,
+            None if d_merged is None else d_merged.data_ptr(), cap, int(merged_base),
+            None if d_merged_offsets is None else d_merged_offsets.data_ptr(), C.byref(n),
             C.c_void_p(stream) if stream else None)
         self.last_required = n.value
         self._check(rc)

@@ -334,6 +334,12 @@ class HipVideo:
             self.h, C.byref(arr), len(bands), d_merged.data_ptr(), cap, int(merged_base), d_merged_offsets.data_ptr(),
             C.c_void_p(stream) if stream else None))
 
+    def records_to_wire(self, rec, n_records, d_dst, stream=None):
+        """One contiguous image of the batch `rec` describes (adder_hip_records_to_wire) into the uint8 CUDA tensor d_dst."""
+        N.check(self.h, self.L.adder_hip_records_to_wire(self.h, C.byref(rec), int(n_records), d_dst.data_ptr(),
+                                                         d_dst.numel() * d_dst.element_size(),
+                                                         C.c_void_p(stream) if stream else None))
+
     def expand_status(self, stream=None):
         N.check(self.h, self.L.adder_hip_expand_status(self.h, C.c_void_p(stream) if stream else None))
 

@@ -150,8 +150,13 @@ struct AdderHipCtx {
     // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
     bool records_only = false;        // the batch being queued stops after its scan
     float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
-    uint8_t *d_band_desc = nullptr, *h_band_desc = nullptr;  // root: n_bands BatchArgs + pointer / destination tables
-    size_t band_desc_cap = 0;
+    // root: n_bands BatchArgs + pointer / destination tables per call, kBandDescSlots calls' worth in turn (a slot's
+    // host block is reused once the upload queued from it has gone through: no wait for the stream's other work)
+    static constexpr uint32_t kBandDescSlots = 4;
+    uint8_t *d_band_desc = nullptr, *h_band_desc = nullptr;
+    size_t band_desc_cap = 0;  // bytes of ONE slot
+    uint32_t band_desc_next = 0;
+    hipEvent_t band_desc_e[kBandDescSlots] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long long *d_timeline = nullptr;  // ADDER_HIP_TIMELINE diagnostics
     // sparse steps (adder_hip_integrate_sparse): running_t per unit, and the work buffers of a call
     bool sparse_mode = false;  // c_thresh / counter / running_t live per unit from the first sparse call on
@@ -301,6 +306,8 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
+    for (hipEvent_t e : c->band_desc_e)
+        if (e) (void)hipEventDestroy(e);
     if (c->d_timeline) (void)hipFree(c->d_timeline);
     for (void *p : {(void *)c->rt_px, (void *)c->sw.steps, (void *)c->sw.keys0, (void *)c->sw.keys1, (void *)c->sw.idx0,
                     (void *)c->sw.idx1, (void *)c->sw.count, (void *)c->sw.offs, (void *)c->sw.stage, c->sw.temp,
@@ -1569,6 +1576,7 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
     out->d_runs = c->wofs_ring;
     out->d_records = packed;
     out->d_frame_offsets = d_frame_offsets;
+    out->d_frame_table = c->d_ftab;
     c->pending = true;
     c->pending_stream = s;
     c->pending_offsets = d_frame_offsets;
@@ -1596,22 +1604,31 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
     const size_t ptrs_at = (size_t)n_bands * kBatchDescBytes;
     const size_t dest_at = ptrs_at + (((size_t)n_bands * sizeof(uint64_t *) + 255) & ~(size_t)255);
     const size_t bytes = dest_at + (size_t)n_bands * nf * sizeof(uint64_t);
+    constexpr uint32_t kSlots = AdderHipCtx::kBandDescSlots;
     if (c->band_desc_cap < bytes) {
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipStreamSynchronize(s));  // (the kernels queued from the old block have to be through: rare, it only grows)
         if (c->d_band_desc) HIPCHK(c, hipFree(c->d_band_desc));
         if (c->h_band_desc) HIPCHK(c, hipHostFree(c->h_band_desc));
         c->d_band_desc = c->h_band_desc = nullptr;
         c->band_desc_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_band_desc), bytes));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_band_desc), bytes, hipHostMallocDefault));
-        c->band_desc_cap = bytes;
-    } else {
-        HIPCHK(c, hipStreamSynchronize(s));  // (the host block is reused: the previous call's upload has to be through)
+        const size_t slot_bytes = (bytes + 4095) & ~(size_t)4095;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_band_desc), slot_bytes * kSlots));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_band_desc), slot_bytes * kSlots, hipHostMallocDefault));
+        c->band_desc_cap = slot_bytes;
+        for (hipEvent_t &e : c->band_desc_e) {
+            if (e) HIPCHK(c, hipEventDestroy(e));
+            e = nullptr;
+        }
     }
-    uint64_t *const d_dest = reinterpret_cast<uint64_t *>(c->d_band_desc + dest_at);
-    const uint64_t **h_ptrs = reinterpret_cast<const uint64_t **>(c->h_band_desc + ptrs_at);
+    const uint32_t slot = c->band_desc_next++ % kSlots;
+    if (c->band_desc_e[slot]) HIPCHK(c, hipEventSynchronize(c->band_desc_e[slot]));  // the call four calls ago is through
+    else HIPCHK(c, hipEventCreateWithFlags(&c->band_desc_e[slot], hipEventDisableTiming));
+    uint8_t *const d_blk = c->d_band_desc + (size_t)slot * c->band_desc_cap;
+    uint8_t *const h_blk = c->h_band_desc + (size_t)slot * c->band_desc_cap;
+    uint64_t *const d_dest = reinterpret_cast<uint64_t *>(d_blk + dest_at);
+    const uint64_t **h_ptrs = reinterpret_cast<const uint64_t **>(h_blk + ptrs_at);
     for (uint32_t r = 0; r < n_bands; ++r) {
-        BatchArgs &b = *reinterpret_cast<BatchArgs *>(c->h_band_desc + (size_t)r * kBatchDescBytes);
+        BatchArgs &b = *reinterpret_cast<BatchArgs *>(h_blk + (size_t)r * kBatchDescBytes);
         memset(&b, 0, sizeof b);
         base_args(c, &b.base);
         b.base.n_units = bands[r].rows * c->p.width * c->p.channels;
@@ -1623,7 +1640,8 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
         b.base.lean = 1u;
         b.base.abs_t = abs_t ? 1u : 0u;
         b.base.sc = make_consts(c, c->last_time_spanned);
-        b.ftab = c->d_ftab;  // root's own batch of the same frames
+        // the frames' running_t (D_EMPTY fillers): root's own batch of the same frames, or the copy the caller kept of it
+        b.ftab = bands[r].d_frame_table ? const_cast<FrameTab *>(reinterpret_cast<const FrameTab *>(bands[r].d_frame_table)) : c->d_ftab;
         b.park_ring = const_cast<uint8_t *>(bands[r].d_records);
         b.park_bytes = 0;
         b.log_cap = 0;  // (expansion format 3 with a zero region stride: the runs index ONE packed buffer)
@@ -1635,14 +1653,58 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
         b.chunk = kMaxChunk;
         h_ptrs[r] = bands[r].d_frame_offsets;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_band_desc, c->h_band_desc, dest_at, hipMemcpyHostToDevice, s));
-    HIPCHK(c, adder_launch_band_layout(reinterpret_cast<const uint64_t *const *>(c->d_band_desc + ptrs_at), n_bands, nf,
+    HIPCHK(c, hipMemcpyAsync(d_blk, h_blk, dest_at, hipMemcpyHostToDevice, s));
+    HIPCHK(c, adder_launch_band_layout(reinterpret_cast<const uint64_t *const *>(d_blk + ptrs_at), n_bands, nf,
                                        merged_base, d_merged_offsets, d_dest, s));
     const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u;
     for (uint32_t r = 0; r < n_bands; ++r)
-        HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(c->d_band_desc + (size_t)r * kBatchDescBytes), 0u, nf,
+        HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(d_blk + (size_t)r * kBatchDescBytes), 0u, nf,
                                       bands[r].num_segments, variant, 0u, s));
+    HIPCHK(c, hipEventRecord(c->band_desc_e[slot], s));  // (the device block is read by the kernels: free after them)
     return ADDER_OK;
+}
+
+static size_t wire_align(size_t x) { return (x + 255) & ~(size_t)255; }
+extern "C" void adder_hip_records_wire_sections(uint32_t nf, uint32_t nseg, uint32_t rb, size_t sec[6]) {
+    (void)rb;
+    const size_t tab = wire_align((size_t)nf * nseg * sizeof(uint32_t));
+    sec[0] = 0;                                                    // frame offsets
+    sec[1] = sec[0] + wire_align(((size_t)nf + 1) * sizeof(uint64_t));  // frame table
+    sec[2] = sec[1] + wire_align((size_t)nf * sizeof(FrameTab));   // counts
+    sec[3] = sec[2] + tab;                                         // prefix
+    sec[4] = sec[3] + tab;                                         // runs
+    sec[5] = sec[4] + tab;                                         // records
+}
+extern "C" size_t adder_hip_records_wire_bytes(uint32_t nf, uint32_t nseg, uint32_t rb, uint64_t n_records) {
+    size_t sec[6];
+    adder_hip_records_wire_sections(nf, nseg, rb, sec);
+    return sec[5] + wire_align((size_t)n_records * rb);
+}
+extern "C" int adder_hip_records_to_wire(AdderHipCtx *c, const AdderBandRecords *rec, uint64_t n_records, void *d_dst,
+                                         size_t dst_bytes, void *stream) {
+    if (!c || !rec || !d_dst) return ADDER_E_BAD_PARAMS;
+    static_assert(sizeof(FrameTab) == 8, "the wire image's frame table rows");
+    const uint32_t nf = rec->num_frames, nseg = rec->num_segments, rb = rec->record_bytes;
+    if (adder_hip_records_wire_bytes(nf, nseg, rb, n_records) > dst_bytes) return fail(c, ADDER_E_BAD_PARAMS, "wire buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    // (null: the stream the context's last batch ran on -- the copies are then ordered before its next batch)
+    hipStream_t s = stream ? (hipStream_t)stream : (c->pending_stream ? c->pending_stream : c->stream);
+    size_t sec[6];
+    adder_hip_records_wire_sections(nf, nseg, rb, sec);
+    uint8_t *dst = static_cast<uint8_t *>(d_dst);
+    const size_t tab = (size_t)nf * nseg * sizeof(uint32_t);
+    HIPCHK(c, hipMemcpyAsync(dst + sec[0], rec->d_frame_offsets, ((size_t)nf + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dst + sec[1], rec->d_frame_table ? rec->d_frame_table : c->d_ftab, (size_t)nf * sizeof(FrameTab),
+                             hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dst + sec[2], rec->d_counts, tab, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dst + sec[3], rec->d_prefix, tab, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dst + sec[4], rec->d_runs, tab, hipMemcpyDeviceToDevice, s));
+    if (n_records) HIPCHK(c, hipMemcpyAsync(dst + sec[5], rec->d_records, (size_t)n_records * rb, hipMemcpyDeviceToDevice, s));
+    return ADDER_OK;
+}
+
+extern "C" void *adder_hip_last_batch_stream(AdderHipCtx *c) {
+    return c ? (void *)(c->pending_stream ? c->pending_stream : c->stream) : nullptr;
 }
 
 extern "C" int adder_hip_expand_status(AdderHipCtx *c, void *stream) {

@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other SURVEY 8(d) configurations")
     ap.add_argument("--secondary-ms", type=float, default=120.0, help="timed region of each secondary leg")
-    ap.add_argument("--gather", default="torch", choices=["torch", "cabi", "layout"],
+    ap.add_argument("--gather", default="torch", choices=["torch", "cabi", "layout", "records"],
                     help="N>1: how the bands' streams become one inside the timed step: 'torch' = torch.distributed "
                          "(RCCL) transport + the HIP merge kernel; 'cabi' = libadder_rccl.so (adder_gather_events, the "
                          "call a Rust host makes); 'layout' = all-gather of the per-frame counts only")
@@ -159,6 +159,12 @@ def main():
     pg = None
     d_chunk_offs = None
     side = None
+    rg = None
+    if world > 1 and gather_mode == "records":
+        # records over the wire: the ranks ship their parked records (0.35x the events' bytes), root expands every band
+        from adder_amd.records import RecordsPipelinedGather
+        d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
+        rg = RecordsPipelinedGather(T, hv, merged_cap_events=cap * world if rank == 0 else 0, dst=0, device=dev)
     if world > 1 and gather_mode in ("torch", "cabi"):
         d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
         if gather_mode == "torch":
@@ -166,8 +172,22 @@ def main():
         else:
             side = torch.cuda.Stream(device=dev)
 
+    wire = {"bytes": 0}
+
     def step(mode):
         hv.reset()
+        if mode == "records":
+            rg.reset()
+            pos, sent = 0, 0
+            for k, f0 in enumerate(range(0, T, gchunk)):
+                nf = min(gchunk, T - f0)
+                rec = hv.integrate_records_device(d_frames[f0:f0 + nf], d_chunk_offs[k, :nf + 1], stream=stream)
+                n_k = hv.finish()
+                sent += rg.push(rec, hv.last_batch_records(), n_k)  # side stream: overlaps the next chunk's integration
+                pos += n_k
+            out = rg.result()
+            wire["bytes"] = sent
+            return pos, (int(out[1][T]) if rank == 0 else pos)
         if mode in ("torch", "cabi"):
             if pg is not None:
                 pg.reset()
@@ -241,9 +261,10 @@ def main():
     layout_elapsed, layout_steps = None, max(2, args.steps // 2)
     if world > 1:
         cdev = torch.device("cpu") if share else dev
-        te = torch.tensor([n_events], dtype=torch.int64, device=cdev)
+        te = torch.tensor([n_events, wire["bytes"]], dtype=torch.int64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.SUM)
-        total_events = int(te.item())
+        total_events = int(te[0].item())
+        wire["bytes"] = int(te[1].item())
         if rank == 0 and gather_mode != "layout":
             assert merged_total == total_events, (merged_total, total_events)
         if gather_mode != "layout":  # the cheaper exchange, as an extra key
@@ -414,6 +435,11 @@ def main():
                     "in profiles/ (kernel stats, adder_lean1w_kernel)",
         },
     }
+    if gather_mode == "records":
+        out["records_over_the_wire"] = {
+            "bytes_per_step_all_peers": wire["bytes"], "events_bytes_per_step_all_peers": 12 * (total_events - n_events),
+            "note": "the peers ship their parked records + three per-segment tables instead of their events; root expands "
+                    "every band (adder_hip_expand_records_device)"}
     if layout_elapsed is not None:
         out["layout_only_exchange"] = {
             "value": round(pixels_per_step / (layout_elapsed / layout_steps) / 1e6, 1),

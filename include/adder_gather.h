@@ -61,6 +61,20 @@ int adder_gather_events_at(AdderGather *g, const AdderEvent *d_events, const uin
                            uint32_t num_frames, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
                            uint64_t *d_merged_offsets, size_t *n_merged, void *stream);
 
+/* RECORDS over the wire (include/adder_hip.h: AdderBandRecords).  The events of a band cross ONE xGMI link on their way to
+ * root; its parked records are 0.35x the bytes.  Every rank integrates a chunk of at most adder_hip_chunk_frames() frames
+ * with adder_hip_integrate_records_device + adder_hip_finish and passes the description here with
+ * adder_hip_last_batch_records() and the finish count: the ranks exchange the sizes, every peer sends one contiguous image
+ * of its chunk (adder_hip_records_to_wire), root expands every band's records -- its own included -- into d_merged behind
+ * merged_base events (adder_hip_expand_records_device) and writes the chunk's merged offsets (absolute: [0] =
+ * merged_base).  The image is this object's (two chunks' worth in turn): on return the caller's context is free for its
+ * next chunk while the transfers and root's expansion are still queued on `stream`; a merged buffer found too small by
+ * the expansion itself is reported by adder_hip_expand_status(ctx, stream).  Lean regime only (the records call refuses
+ * the others: gather events then).  replaces the same lines of video.rs:677-734 / SURVEY 8(e) as adder_gather_events_at. */
+int adder_gather_records_at(AdderGather *g, const AdderBandRecords *rec, uint64_t n_records, uint64_t n_events, int root,
+                            AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets,
+                            size_t *n_merged, void *stream);
+
 /* Layout-only exchange: all-gathers the per-frame offsets and returns, on every rank, the merged
  * stream's frame offsets (h_merged_offsets, host uint64[T+1]) and where this rank's segment of each
  * frame belongs in it (h_my_base, host uint64[T]).  The payload stays sharded: every rank can deliver

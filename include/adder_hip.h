@@ -309,6 +309,8 @@ typedef struct AdderBandRecords {
     const uint32_t *d_runs;     /* [num_frames][num_segments] first record of the segment's run in d_records */
     const uint8_t *d_records;   /* the batch's records, adder_hip_last_batch_records() of them after adder_hip_finish */
     const uint64_t *d_frame_offsets; /* [num_frames + 1] the band's own event offsets of the batch */
+    const void *d_frame_table;  /* root only, may be null: [num_frames] x 8 bytes, the frames' {running_t, c_thresh} as
+                                 * root's own batch had them (null: root's current table -- valid until ITS next batch) */
 } AdderBandRecords;
 uint32_t adder_hip_band_segments(const AdderHipCtx *ctx);
 /* Like adder_hip_integrate_device, without an event buffer: d_frame_offsets ([num_frames + 1], device) receives the
@@ -323,6 +325,20 @@ int adder_hip_integrate_records_device(AdderHipCtx *ctx, const uint8_t *d_frames
  * adder_hip_expand_status (events past merged_cap are dropped). */
 int adder_hip_expand_records_device(AdderHipCtx *root, const AdderBandRecords *bands, uint32_t n_bands, AdderEvent *d_merged,
                                     size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets, void *stream);
+/* One contiguous image of a band's batch, for the transport: sections at 256-byte multiples,
+ *   frame offsets (num_frames + 1) x 8 | frame table num_frames x 8 | counts | prefix | runs (num_frames x num_segments x 4
+ *   each) | n_records x record_bytes.
+ * adder_hip_records_wire_bytes gives its size, adder_hip_records_wire_sections the byte offset of each of the six sections
+ * (so that the receiver rebuilds an AdderBandRecords from a received image + the five numbers), and
+ * adder_hip_records_to_wire queues the device-to-device copies of `rec` (this context's last records batch) into d_dst on
+ * `stream` -- after it the context may run its next batch while the image travels. */
+size_t adder_hip_records_wire_bytes(uint32_t num_frames, uint32_t num_segments, uint32_t record_bytes, uint64_t n_records);
+void adder_hip_records_wire_sections(uint32_t num_frames, uint32_t num_segments, uint32_t record_bytes, size_t sections[6]);
+int adder_hip_records_to_wire(AdderHipCtx *ctx, const AdderBandRecords *rec, uint64_t n_records, void *d_dst, size_t dst_bytes,
+                              void *stream);
+/* The stream the context's last device batch was queued on (what a null `stream` of adder_hip_records_to_wire means: the
+ * copies are then ordered before the context's next batch, whatever stream the transport uses). */
+void *adder_hip_last_batch_stream(AdderHipCtx *ctx);
 /* Waits for `stream` and returns ADDER_OK or the failure the expansions since the last call ran into (capacity). */
 int adder_hip_expand_status(AdderHipCtx *root, void *stream);
 

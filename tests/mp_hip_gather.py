@@ -38,6 +38,20 @@ def main():
     ev, off = run(hv, clip[:, y0:y1], T)
     out = sharding.gather_event_stream(ev, off, dst=0, video=hv)
     lay = sharding.exchange_stream_layout(off.cpu())
+    # the same clip again with RECORDS on the wire (adder_amd.records): chunks of 16 frames, the last one short
+    from adder_amd.records import RecordsPipelinedGather
+    hv.reset()
+    st = torch.cuda.current_stream().cuda_stream
+    d_band = torch.from_numpy(np.ascontiguousarray(clip[:, y0:y1]).reshape(T, -1)).cuda()
+    d_boff = torch.zeros(17, dtype=torch.int64, device="cuda")
+    rg = RecordsPipelinedGather(T, hv, merged_cap_events=H * W * T * 3 if rank == 0 else 0, dst=0)
+    sent = 0
+    for f0 in range(0, T, 16):
+        nf = min(16, T - f0)
+        rec = hv.integrate_records_device(d_band[f0:f0 + nf], d_boff, stream=st)
+        n = hv.finish()
+        sent += rg.push(rec, hv.last_batch_records(), n)
+    rout = rg.result()
     if rank == 0:
         hv.check_status()
         whole = A.HipVideo(W, H, 1, **kw)
@@ -45,7 +59,10 @@ def main():
         wev, woff = run(whole, clip, T)
         assert torch.equal(out[1].cpu(), woff.cpu()) and torch.equal(out[0].cpu(), wev.cpu())
         assert torch.equal(lay[0], woff.cpu())
+        assert torch.equal(rout[1].cpu(), woff.cpu()) and torch.equal(rout[0].cpu(), wev.cpu())  # records == events
         print("rank0 ok", flush=True)
+    else:
+        assert 0 < sent < 12 * int(ev.shape[0])  # fewer bytes than the band's events would have been
     dist.barrier()
     dist.destroy_process_group()
 

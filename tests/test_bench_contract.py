@@ -36,7 +36,7 @@ def test_bench_single_gpu_line_has_roofline_secondary_and_cpu_baseline():
     assert len(d["secondary"]) >= 8 and all("error" not in leg for leg in d["secondary"]), d["secondary"]
 
 
-@pytest.mark.parametrize("gather", ["torch", "layout"])
+@pytest.mark.parametrize("gather", ["torch", "layout", "records"])
 def test_bench_two_ranks_share_the_device_and_gather_chunk_by_chunk(gather):
     d = _run(["--gpus", "2", "--frames", "150", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end",
               "--no-secondary", "--skip-roofline", "--gather", gather],
@@ -45,3 +45,6 @@ def test_bench_two_ranks_share_the_device_and_gather_chunk_by_chunk(gather):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 540 and d["events_per_pixel_frame"] > 0.2
+    if gather == "records":  # the peers' records + tables are well under half of their events' bytes
+        w = d["records_over_the_wire"]
+        assert 0 < w["bytes_per_step_all_peers"] < 0.5 * w["events_bytes_per_step_all_peers"]

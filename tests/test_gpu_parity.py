@@ -618,6 +618,26 @@ def test_gather_cabi_single_rank_world():
     assert pos == n and torch.equal(d_m2[:n], d_ev[:n]) and torch.equal(d_mo2, d_off) and int((d_m2[n:] != -1).sum()) == 0
     with pytest.raises(A.AdderHipError, match="too small"):
         g.gather_events_at(d_ev, d_off, 0, T, 0, d_m2[: n - 1], 0, d_mo2, stream=side.cuda_stream)
+    # records over the wire through the same communicator (adder_gather_records_at): three chunks, the image round trip,
+    # root's expansion on the side stream while the context integrates the next chunk
+    hv.reset()
+    d_m3 = torch.full((n + 3, 3), -1, dtype=torch.int32, device="cuda")
+    d_mo3 = torch.full((T + 1,), -7, dtype=torch.int64, device="cuda")
+    d_boff = torch.zeros(9, dtype=torch.int64, device="cuda")
+    pos = 0
+    for f0, nf in ((0, 8), (8, 8), (16, 4)):
+        rec = hv.integrate_records_device(d_frames[f0:f0 + nf], d_boff, stream=st)
+        n_k = hv.finish()
+        side.wait_stream(torch.cuda.current_stream())
+        pos += g.gather_records_at(rec, hv.last_batch_records(), n_k, 0, d_m3, pos, d_mo3[f0:], stream=side.cuda_stream)
+    side.synchronize()
+    hv.expand_status(side.cuda_stream)
+    assert pos == n and torch.equal(d_m3[:n], d_ev[:n]) and torch.equal(d_mo3, d_off) and int((d_m3[n:] != -1).sum()) == 0
+    with pytest.raises(A.AdderHipError, match="too small"):
+        hv.reset()
+        rec = hv.integrate_records_device(d_frames[:8], d_boff, stream=st)
+        n_k = hv.finish()
+        g.gather_records_at(rec, hv.last_batch_records(), n_k, 0, d_m3[: n_k - 1], 0, d_mo3, stream=st)
     g.close()
 
 

@@ -112,3 +112,38 @@ def test_records_are_refused_outside_the_lean_regime_and_capacity_is_reported():
     with pytest.raises(A.AdderHipError) as ei:
         hv.expand_status()
     assert ei.value.code == A.E_OUT_CAPACITY
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_records_pipelined_gather_single_rank_through_the_wire_image(time_mode):
+    """RecordsPipelinedGather with one rank: every chunk goes through adder_hip_records_to_wire and back
+    (records_from_wire) before root expands it on the side stream -- the transport's code path without a transport."""
+    import torch
+    A = _hip()
+    from adder_amd.records import RecordsPipelinedGather
+    W, H, T = 320, 48, 200
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, 1, T)
+    st = torch.cuda.current_stream().cuda_stream
+    kw = dict(time_mode=time_mode, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
+    d_all = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    whole = A.HipVideo(W, H, 1, **kw)
+    whole.set_crf_parameters(0, 10)
+    d_ev = torch.empty((int(d_all.numel() * 1.3) + 1024, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    whole.integrate_device(d_all, d_ev, d_off, stream=st)
+    n_want = whole.finish()
+    hv = A.HipVideo(W, H, 1, **kw)
+    hv.set_crf_parameters(0, 10)
+    rg = RecordsPipelinedGather(T, hv, merged_cap_events=n_want + 8)
+    d_boff = torch.zeros(65, dtype=torch.int64, device="cuda")
+    for rep in range(2):  # a second clip through the same objects (reset)
+        hv.reset()
+        rg.reset()
+        for f0 in range(0, T, 64):
+            nf = min(64, T - f0)
+            rec = hv.integrate_records_device(d_all[f0:f0 + nf], d_boff, stream=st)
+            n = hv.finish()
+            rg.push(rec, hv.last_batch_records(), n)
+        merged, moff = rg.result()
+        assert merged.shape[0] == n_want and torch.equal(moff, d_off)
+        assert merged.cpu().numpy().tobytes() == d_ev[:n_want].cpu().numpy().tobytes()
