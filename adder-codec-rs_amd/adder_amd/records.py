@@ -48,7 +48,10 @@ class RecordsPipelinedGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.T = total_frames
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device)
+        # two side streams in turn: chunk k + 1's images arrive while chunk k is being expanded (one in-order stream
+        # would put every transfer behind the expansion before it)
+        self.sides = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        self.chunk_no = 0
         self.frame_pos, self.merged_pos = 0, 0
         self.merged = self.merged_offs = None
         self._keep = []
@@ -58,6 +61,7 @@ class RecordsPipelinedGather:
 
     def reset(self):
         self.frame_pos, self.merged_pos = 0, 0
+        self.chunk_no = 0
         self._keep = []
 
     def push(self, rec, n_records, n_events):
@@ -71,8 +75,10 @@ class RecordsPipelinedGather:
         v.records_to_wire(rec, n_records, img, stream=cur.cuda_stream)  # on the caller's stream: the scratch is free after it
         self._keep.append(img)
         sent = 0
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
+        side = self.sides[self.chunk_no % 2]
+        self.chunk_no += 1
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
             meta = torch.tensor([nf, nseg, rb, int(n_records), int(rec.row_begin), int(rec.rows), int(n_events)], dtype=torch.int64)
             if self.world > 1:
                 via_host = dist.get_backend(self.group) == "gloo"
@@ -117,15 +123,16 @@ class RecordsPipelinedGather:
                 bands = [records_from_wire(imgs[r], int(metas[r][0]), int(metas[r][1]), int(metas[r][2]), int(metas[r][4]),
                                            int(metas[r][5]), d_frame_table=ftab) for r in range(self.world)]
                 v.expand_records_device(bands, self.merged, self.merged_pos, self.merged_offs[self.frame_pos:],
-                                        stream=self.side.cuda_stream)
+                                        stream=side.cuda_stream)
             self.merged_pos += total
             self.frame_pos += nf
         return sent
 
     def result(self):
-        self.side.synchronize()
+        for sd in self.sides:
+            sd.synchronize()
         if self.rank == self.dst:
-            self.video.expand_status(self.side.cuda_stream)
+            self.video.expand_status(self.sides[0].cuda_stream)
         self._keep = []
         if self.rank != self.dst:
             return None

@@ -9,8 +9,9 @@ reset transcoder so every step does identical work.
 
 --gpus N (N > 1): the SAME 1080p clip is split into N contiguous row bands
 (adder_amd.sharding.row_bands; the reference's own split is video.rs:677-691), one rank per
-GPU, no collective while integrating; inside the timed step the bands' event streams are then
-gathered to rank 0 over RCCL/xGMI and merged into the single ordered stream (strong scaling:
+GPU, no collective while integrating; inside the timed step the bands are then gathered to rank 0
+over RCCL/xGMI into the single ordered stream -- by default as parked RECORDS (0.35x the events'
+bytes) that rank 0 expands, chunk by chunk behind the integration (--gather; strong scaling:
 `value` = the clip's pixels / wall time).  Started without a launcher, bench.py re-executes
 itself under torch.distributed.run.
 
@@ -63,10 +64,12 @@ def parse_args():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other SURVEY 8(d) configurations")
     ap.add_argument("--secondary-ms", type=float, default=120.0, help="timed region of each secondary leg")
-    ap.add_argument("--gather", default="torch", choices=["torch", "cabi", "layout", "records"],
+    ap.add_argument("--gather", default="records", choices=["torch", "cabi", "layout", "records"],
                     help="N>1: how the bands' streams become one inside the timed step: 'torch' = torch.distributed "
                          "(RCCL) transport + the HIP merge kernel; 'cabi' = libadder_rccl.so (adder_gather_events, the "
-                         "call a Rust host makes); 'layout' = all-gather of the per-frame counts only")
+                         "call a Rust host makes); 'layout' = all-gather of the per-frame counts only; 'records' "
+                         "(default) = the bands ship their parked records, 0.35x the events' bytes, and rank 0 expands "
+                         "every band (adder_amd.records; lean regime only, other modes fall back to 'torch')")
     ap.add_argument("--skip-roofline", action="store_true",
                     help="no per-launch timing passes (used under rocprofv3 so that only default launches are seen)")
     return ap.parse_args()
@@ -139,6 +142,8 @@ def main():
     hv.set_crf_parameters(0, 10)
 
     gather_mode = args.gather if world > 1 else "none"
+    if gather_mode == "records" and not (args.multi_mode == "collapse" and args.delta_t_max <= REF_TIME):
+        gather_mode = "torch"  # records exist in the lean regime only (adder_hip_integrate_records_device): events then
     if share and gather_mode == "cabi":
         gather_mode = "torch"  # RCCL cannot put two ranks on one device
     hg = None
@@ -178,15 +183,17 @@ def main():
         hv.reset()
         if mode == "records":
             rg.reset()
-            pos, sent = 0, 0
+            pos, sent, nrec = 0, 0, 0
             for k, f0 in enumerate(range(0, T, gchunk)):
                 nf = min(gchunk, T - f0)
                 rec = hv.integrate_records_device(d_frames[f0:f0 + nf], d_chunk_offs[k, :nf + 1], stream=stream)
                 n_k = hv.finish()
-                sent += rg.push(rec, hv.last_batch_records(), n_k)  # side stream: overlaps the next chunk's integration
+                nrec_k = hv.last_batch_records()
+                sent += rg.push(rec, nrec_k, n_k)  # side streams: overlap the next chunk's integration
                 pos += n_k
+                nrec += nrec_k
             out = rg.result()
-            wire["bytes"] = sent
+            wire["bytes"], wire["records"] = sent, nrec
             return pos, (int(out[1][T]) if rank == 0 else pos)
         if mode in ("torch", "cabi"):
             if pg is not None:
@@ -255,7 +262,7 @@ def main():
 
     elapsed, (n_events, merged_total) = timed(gather_mode, args.steps, args.warmup)
     kernel_ms = hv.last_batch_ms()  # HIP events around the last step's frame loop
-    records = hv.last_batch_records()
+    records = wire.get("records") if gather_mode == "records" else hv.last_batch_records()
 
     total_events = n_events
     layout_elapsed, layout_steps = None, max(2, args.steps // 2)
@@ -376,9 +383,11 @@ def main():
             "rows_per_gpu": rows,
             "frames_per_step": T,
             "sharding": ("single GPU" if world == 1 else
-                         f"{world} row bands of the one plane; per step the bands' event streams are gathered to "
-                         f"rank 0 ({gather_mode}) inside the timed region, chunk by chunk ({gchunk} frames) on a side "
-                         f"stream while the next chunk integrates"),
+                         f"{world} row bands of the one plane; per step the bands' " +
+                         ("parked RECORDS are shipped to rank 0, which expands every band into the one ordered stream"
+                          if gather_mode == "records" else "event streams are gathered to rank 0") +
+                         f" ({gather_mode}) inside the timed region, chunk by chunk ({gchunk} frames) on side "
+                         f"streams while the next chunk integrates"),
             "world_size_seen": world,
             "backend": "none" if world == 1 else ("gloo (shared-device debug)" if share else "nccl (RCCL)"),
         },
