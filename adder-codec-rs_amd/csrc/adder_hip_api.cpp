@@ -1656,10 +1656,16 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
     HIPCHK(c, hipMemcpyAsync(d_blk, h_blk, dest_at, hipMemcpyHostToDevice, s));
     HIPCHK(c, adder_launch_band_layout(reinterpret_cast<const uint64_t *const *>(d_blk + ptrs_at), n_bands, nf,
                                        merged_base, d_merged_offsets, d_dest, s));
-    const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u;
-    for (uint32_t r = 0; r < n_bands; ++r)
-        HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(d_blk + (size_t)r * kBatchDescBytes), 0u, nf,
-                                      bands[r].num_segments, variant, 0u, s));
+    if (n_bands <= kMaxBands) {  // every band in ONE launch, frame-major across the bands
+        uint32_t nw[kMaxBands];
+        for (uint32_t r = 0; r < n_bands; ++r) nw[r] = bands[r].num_segments;
+        HIPCHK(c, adder_launch_expand_bands(d_blk, (uint32_t)kBatchDescBytes, n_bands, nw, nf, abs_t ? 1u : 0u, s));
+    } else {
+        const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u;
+        for (uint32_t r = 0; r < n_bands; ++r)
+            HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(d_blk + (size_t)r * kBatchDescBytes), 0u, nf,
+                                          bands[r].num_segments, variant, 0u, s));
+    }
     HIPCHK(c, hipEventRecord(c->band_desc_e[slot], s));  // (the device block is read by the kernels: free after them)
     return ADDER_OK;
 }

@@ -164,6 +164,7 @@ struct BatchArgs {
     unsigned long long *timeline;
 };
 constexpr uint32_t kTimelineChunks = 64;
+constexpr uint32_t kMaxBands = 16;  // bands one adder_expand_bands_kernel launch takes (more: one launch per band)
 
 // Where (frame slot, segment) parks its records, in bytes from park_ring.  Within one chunk of the ring, segments
 // come in groups of G = 2^group_shift; a group holds [frame][segment of the group][park_bytes]:
@@ -295,6 +296,8 @@ hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t 
 hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t rec_bytes, const uint32_t *wcur,
                                  uint32_t *pbase, uint32_t num_waves, uint32_t nf, uint32_t *wofs_rows, uint8_t *packed,
                                  uint64_t packed_cap_bytes, uint64_t *d_total, uint32_t *status, hipStream_t stream);
+hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t stride, uint32_t n_bands, const uint32_t *num_waves,
+                                     uint32_t nf, uint32_t abs_t, hipStream_t stream);
 hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
                                     uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

@@ -2026,6 +2026,40 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const Batch
     timeline_mark(b, 3u, f0, true);
 }
 
+// Records over the wire, root: ALL bands of a chunk in one launch (adder_hip_expand_records_device).  Work items are
+// (frame, band, block of the band) frame-major, so the merged stream is written front to back as by the whole-plane
+// expansion; the bands' BatchArgs lie `stride` bytes apart (eight launches of an eighth of the plane each took 337 us per
+// chunk where the whole plane takes 150).
+struct BandBlocks {
+    uint32_t n_bands;
+    uint32_t cum[kMaxBands + 1];  // blocks of the bands before band r (cum[n_bands] = all of them)
+};
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads) void adder_expand_bands_kernel(const uint8_t *__restrict__ descs, uint32_t stride,
+                                                                          BandBlocks bb, uint32_t nf) {
+    const uint32_t per_frame = bb.cum[bb.n_bands];
+    const uint32_t w = blockIdx.x;
+    if (w >= per_frame * nf) return;
+    const uint32_t f = w / per_frame, rem = w - f * per_frame;
+    uint32_t r = 0;
+    while (r + 1u < bb.n_bands && rem >= bb.cum[r + 1u]) ++r;  // uniform
+    expand_block<3, ABS_T>(reinterpret_cast<const BatchArgs *>(descs + (size_t)r * stride), f, rem - bb.cum[r]);
+}
+extern "C" hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t stride, uint32_t n_bands,
+                                                const uint32_t *num_waves, uint32_t nf, uint32_t abs_t, hipStream_t stream) {
+    if (n_bands == 0 || n_bands > kMaxBands) return hipErrorInvalidValue;
+    BandBlocks bb;
+    bb.n_bands = n_bands;
+    bb.cum[0] = 0;
+    const uint32_t per_block = kWavesPerBlock * kExpandSegs;
+    for (uint32_t r = 0; r < n_bands; ++r) bb.cum[r + 1] = bb.cum[r] + (num_waves[r] + per_block - 1) / per_block;
+    for (uint32_t r = n_bands + 1; r <= kMaxBands; ++r) bb.cum[r] = bb.cum[n_bands];
+    const dim3 grid(bb.cum[n_bands] * nf);
+    if (abs_t) hipLaunchKernelGGL((adder_expand_bands_kernel<true>), grid, dim3(kBlockThreads), 0, stream, descs, stride, bb, nf);
+    else hipLaunchKernelGGL((adder_expand_bands_kernel<false>), grid, dim3(kBlockThreads), 0, stream, descs, stride, bb, nf);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // K3: the raw sink's event serialisation (RawOutput::ingest_event, raw/stream.rs:101-120 =
 // bincode fixint big-endian) on the device: 12-byte AdderEvents -> 9-byte `EventSingle`
