@@ -172,6 +172,7 @@ SYMBOLS = {
     "adder_hip_records_wire_sections": (None, [_u32, _u32, _u32, _vp]),
     "adder_hip_records_to_wire": (C.c_int, [_vp, _vp, _u64, _vp, _sz, _vp]),
     "adder_hip_last_batch_stream": (_vp, [_vp]),
+    "adder_hip_sync_last_batch_stream": (C.c_int, [_vp]),
     "adder_hip_last_batch_records": (_u64, [_vp]),
     "adder_hip_set_frames_per_launch": (_i32, [_vp, _u32]),
     "adder_hip_reset": (_i32, [_vp]),

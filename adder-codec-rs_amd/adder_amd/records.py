@@ -72,7 +72,11 @@ class RecordsPipelinedGather:
         nbytes = wire_bytes(nf, nseg, rb, n_records)
         img = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         cur = torch.cuda.current_stream(self.device)
-        v.records_to_wire(rec, n_records, img, stream=cur.cuda_stream)  # on the caller's stream: the scratch is free after it
+        # the image is copied on the stream the BATCH ran on (which may be the context's own, not a torch stream: the
+        # handle of torch's default stream is 0 = "the context's"), and waited for here: a copy of this band's records and
+        # tables, tens of microseconds -- after it the scratch is free for the next chunk and the side stream may send
+        v.records_to_wire(rec, n_records, img, stream=None)
+        v.sync_last_batch_stream()
         self._keep.append(img)
         sent = 0
         side = self.sides[self.chunk_no % 2]

@@ -340,6 +340,9 @@ class HipVideo:
                                                          d_dst.numel() * d_dst.element_size(),
                                                          C.c_void_p(stream) if stream else None))
 
+    def sync_last_batch_stream(self):
+        N.check(self.h, self.L.adder_hip_sync_last_batch_stream(self.h))
+
     def expand_status(self, stream=None):
         N.check(self.h, self.L.adder_hip_expand_status(self.h, C.c_void_p(stream) if stream else None))
 

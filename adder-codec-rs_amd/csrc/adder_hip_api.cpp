@@ -1712,6 +1712,12 @@ extern "C" int adder_hip_records_to_wire(AdderHipCtx *c, const AdderBandRecords 
 extern "C" void *adder_hip_last_batch_stream(AdderHipCtx *c) {
     return c ? (void *)(c->pending_stream ? c->pending_stream : c->stream) : nullptr;
 }
+extern "C" int adder_hip_sync_last_batch_stream(AdderHipCtx *c) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->pending_stream ? c->pending_stream : c->stream));
+    return ADDER_OK;
+}
 
 extern "C" int adder_hip_expand_status(AdderHipCtx *c, void *stream) {
     if (!c) return ADDER_E_BAD_PARAMS;

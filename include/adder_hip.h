@@ -339,6 +339,9 @@ int adder_hip_records_to_wire(AdderHipCtx *ctx, const AdderBandRecords *rec, uin
 /* The stream the context's last device batch was queued on (what a null `stream` of adder_hip_records_to_wire means: the
  * copies are then ordered before the context's next batch, whatever stream the transport uses). */
 void *adder_hip_last_batch_stream(AdderHipCtx *ctx);
+/* Waits for it (a transport that cannot order its own stream behind that one -- e.g. one that only knows torch streams
+ * while the batch ran on the context's own -- calls this after adder_hip_records_to_wire and before it sends). */
+int adder_hip_sync_last_batch_stream(AdderHipCtx *ctx);
 /* Waits for `stream` and returns ADDER_OK or the failure the expansions since the last call ran into (capacity). */
 int adder_hip_expand_status(AdderHipCtx *root, void *stream);
 
