@@ -62,3 +62,21 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f in ("adder_pixel.hpp",), (dirpath, f)
+
+
+def test_records_wire_layout_is_consistent():
+    """adder_hip_records_wire_bytes / _sections (host arithmetic only): six sections at 256-byte multiples, in order, each
+    large enough for what adder_hip_records_to_wire copies into it."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
+    from adder_amd import _native as N
+    L = N.load()
+    for nf, nseg, rb, nrec in ((1, 16, 8, 0), (64, 2032, 8, 123457), (37, 16208, 12, 5_000_001), (64, 48, 12, 1)):
+        sec = (C.c_size_t * 6)()
+        L.adder_hip_records_wire_sections(nf, nseg, rb, sec)
+        sec = [int(x) for x in sec]
+        total = int(L.adder_hip_records_wire_bytes(nf, nseg, rb, nrec))
+        need = [(nf + 1) * 8, nf * 8, nf * nseg * 4, nf * nseg * 4, nf * nseg * 4, nrec * rb]
+        ends = sec[1:] + [total]
+        assert sec[0] == 0 and all(s % 256 == 0 for s in sec) and total % 256 == 0
+        assert all(e - s >= n for s, e, n in zip(sec, ends, need)), (sec, total, need)
