@@ -4,6 +4,7 @@ raw sink reproduces the reference's container known answers."""
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
