@@ -28,6 +28,38 @@ def row_bands(height, world, chunk_rows=1):
     return bands
 
 
+def gather_peer_share(world, *, link_GBs=120.0, wire_bytes_per_unit_frame=1.45, root_chunk_us_per_plane=(160.0, 170.0),
+                      units=1920 * 1080, chunk=64):
+    """Fraction of the rows every PEER should own when the bands' records are gathered to rank 0 over one xGMI link per
+    peer (adder_amd.records): the peers' transfers (share * wire bytes / link) and root's own work (its band's frame kernel
+    + the expansion of the whole plane) take equally long.  Defaults: what was measured on one MI355X for the 1080p headline
+    (0.159 records * 8 B + 3 tables * 4 B / 128 units per unit-frame; 160 us of frame kernel and 170 us of expansion per
+    64-frame chunk of the whole plane) and a conservative link rate.  Never more than an even split."""
+    if world <= 1:
+        return 1.0
+    wire_us = units * chunk * wire_bytes_per_unit_frame / (link_GBs * 1e3)  # a whole plane's chunk over one link
+    lean_us, expand_us = root_chunk_us_per_plane
+    # share * wire_us == (1 - (world - 1) * share) * lean_us + expand_us
+    share = (lean_us + expand_us) / (wire_us + (world - 1) * lean_us)
+    return min(share, 1.0 / world)
+
+
+def row_bands_root_heavy(height, world, peer_share, chunk_rows=1):
+    """Contiguous bands with rank 0 (the gather's root) on top taking what the peers leave: every peer owns
+    round(peer_share * height) rows (a multiple of chunk_rows, at least one chunk)."""
+    if world == 1:
+        return [(0, height)]
+    chunks = (height + chunk_rows - 1) // chunk_rows
+    per = max(1, min(int(round(peer_share * chunks)), chunks // world))
+    root = chunks - per * (world - 1)
+    bands, c0 = [], 0
+    for r in range(world):
+        c1 = c0 + (root if r == 0 else per)
+        bands.append((min(c0 * chunk_rows, height), min(c1 * chunk_rows, height)))
+        c0 = c1
+    return bands
+
+
 def merge_frame_major(segments):
     """segments[r] = (events int32 [n_r, 3], offsets int64 [T+1]) of rank r, each frame-major.
     Returns (events [sum n_r, 3], offsets [T+1]) with, per frame, rank 0's events first, then

@@ -118,7 +118,18 @@ def main():
     from adder_amd import sharding
 
     T, Cn, Wd, Ht = args.frames, args.channels, args.width, args.height
-    y0, y1 = sharding.row_bands(Ht, world)[rank]  # strong scaling: the one plane, split by rows
+    # strong scaling: the one plane, split by rows.  With records on the wire (the default gather) rank 0 -- which expands
+    # every band and receives over ONE link per peer -- takes more rows than the peers, so that the peers' transfers and
+    # root's work take equally long (sharding.gather_peer_share); the other gathers split evenly
+    gather_mode = args.gather if world > 1 else "none"
+    if gather_mode == "records" and not (args.multi_mode == "collapse" and args.delta_t_max <= REF_TIME):
+        gather_mode = "torch"  # records exist in the lean regime only (adder_hip_integrate_records_device): events then
+    if gather_mode == "records":
+        peer_share = sharding.gather_peer_share(world, units=Wd * Ht * Cn)
+        bands = sharding.row_bands_root_heavy(Ht, world, peer_share)
+    else:
+        bands = sharding.row_bands(Ht, world)
+    y0, y1 = bands[rank]
     rows = y1 - y0
     units = rows * Wd * Cn
     content = {"static": A.CONTENT_STATIC, "noise": A.CONTENT_NOISE, "scene": A.CONTENT_SCENE}[args.content]
@@ -141,9 +152,6 @@ def main():
     # state `.crf(0)` leaves them in (video.rs:1247-1250), so reset() restores exactly that
     hv.set_crf_parameters(0, 10)
 
-    gather_mode = args.gather if world > 1 else "none"
-    if gather_mode == "records" and not (args.multi_mode == "collapse" and args.delta_t_max <= REF_TIME):
-        gather_mode = "torch"  # records exist in the lean regime only (adder_hip_integrate_records_device): events then
     if share and gather_mode == "cabi":
         gather_mode = "torch"  # RCCL cannot put two ranks on one device
     hg = None
@@ -381,6 +389,7 @@ def main():
                         f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, raw events to HBM",
             "plane": [Wd, Ht, Cn],
             "rows_per_gpu": rows,
+            "row_bands": [list(b) for b in bands],
             "frames_per_step": T,
             "sharding": ("single GPU" if world == 1 else
                          f"{world} row bands of the one plane; per step the bands' " +

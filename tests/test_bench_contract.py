@@ -44,7 +44,11 @@ def test_bench_two_ranks_share_the_device_and_gather_chunk_by_chunk(gather):
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["config"]["rows_per_gpu"] == 540 and d["events_per_pixel_frame"] > 0.2
+    assert d["events_per_pixel_frame"] > 0.2
+    if gather == "records":  # root (rank 0) takes more rows than its peer: sharding.gather_peer_share
+        assert 540 < d["config"]["rows_per_gpu"] < 1080 and d["config"]["row_bands"][1][1] == 1080
+    else:
+        assert d["config"]["rows_per_gpu"] == 540
     if gather == "records":  # the peers' records + tables are well under half of their events' bytes
         w = d["records_over_the_wire"]
         assert 0 < w["bytes_per_step_all_peers"] < 0.5 * w["events_bytes_per_step_all_peers"]

@@ -179,3 +179,25 @@ def test_chunk_pipelined_gather_matches_single_stream(world, chunk_frames):
         p.join(180)
         assert p.exitcode == 0
     assert [q.get(timeout=5) for _ in range(2)] == [True, True]
+
+
+def test_root_heavy_bands_tile_the_plane_and_balance_the_gather():
+    """sharding.gather_peer_share / row_bands_root_heavy (records gathered to rank 0 over one link per peer): the bands tile
+    the plane in rank order, the peers own equal bands no larger than an even split, root takes the rest, and the
+    balance the share was derived from holds."""
+    from adder_amd import sharding as S
+    for H in (1080, 2160, 48, 7):
+        for world in (1, 2, 3, 4, 8):
+            p = S.gather_peer_share(world, units=1920 * H)
+            assert 0.0 < p <= 1.0 / world + 1e-12
+            bands = S.row_bands_root_heavy(H, world, p)
+            assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == H
+            assert all(bands[r][1] == bands[r + 1][0] for r in range(world - 1))
+            rows = [b[1] - b[0] for b in bands]
+            if world > 1 and H >= world:
+                assert len(set(rows[1:])) == 1 and rows[0] >= rows[1] >= 1
+    # the balance: a peer's transfer takes as long as root's frame kernel on its band + the expansion of the plane
+    for world in (2, 4):
+        p = S.gather_peer_share(world, link_GBs=120.0)
+        wire_us = 1920 * 1080 * 64 * 1.45 / 120e3
+        assert abs(p * wire_us - ((1 - (world - 1) * p) * 160.0 + 170.0)) < 1e-6
