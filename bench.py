@@ -176,7 +176,7 @@ def main():
     if world > 1 and gather_mode == "records":
         # records over the wire: the ranks ship their parked records (0.35x the events' bytes), root expands every band
         from adder_amd.records import RecordsPipelinedGather
-        d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
+        d_chunk_offs = torch.zeros(T, gchunk + 1, dtype=torch.int64, device=dev)  # (rows for any chunk length)
         rg = RecordsPipelinedGather(T, hv, merged_cap_events=cap * world if rank == 0 else 0, dst=0, device=dev)
     if world > 1 and gather_mode in ("torch", "cabi"):
         d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
@@ -192,8 +192,9 @@ def main():
         if mode == "records":
             rg.reset()
             pos, sent, nrec = 0, 0, 0
-            for k, f0 in enumerate(range(0, T, gchunk)):
-                nf = min(gchunk, T - f0)
+            gc = wire.get("chunk", gchunk)  # (a records batch holds at most one chunk of the scratch ring: agreed below)
+            for k, f0 in enumerate(range(0, T, gc)):
+                nf = min(gc, T - f0)
                 rec = hv.integrate_records_device(d_frames[f0:f0 + nf], d_chunk_offs[k, :nf + 1], stream=stream)
                 n_k = hv.finish()
                 nrec_k = hv.last_batch_records()
@@ -267,6 +268,11 @@ def main():
         step("none")
         plan_steps += 1
     plan_settled = hv.launch_plan_settled()
+    if gather_mode == "records":  # every rank cuts the clip into the same chunks: the smallest scratch ring decides
+        cdev0 = torch.device("cpu") if share else dev
+        tc = torch.tensor([min(gchunk, hv.chunk_frames() or gchunk)], dtype=torch.int64, device=cdev0)
+        dist.all_reduce(tc, op=dist.ReduceOp.MIN)
+        wire["chunk"] = int(tc.item())
 
     elapsed, (n_events, merged_total) = timed(gather_mode, args.steps, args.warmup)
     kernel_ms = hv.last_batch_ms()  # HIP events around the last step's frame loop
