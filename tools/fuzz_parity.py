@@ -61,11 +61,61 @@ def one(rng):
     hv.close()
     return W * H * C * T
 
+def one_records(rng):
+    """Records over the wire on one GPU: a random plane in 1..18 bands (contexts), random chunk lengths; every band
+    hands out its records, band 0 expands them all -- against one context over the whole plane."""
+    import torch
+    from adder_amd import sharding
+    W, H = int(rng.choice([5, 33, 64, 130, 256])), int(rng.integers(2, 40))
+    C = int(rng.choice([1, 1, 3])); T = int(rng.integers(5, 150))
+    tm = int(rng.choice([O.DELTA_T, O.ABSOLUTE_T])); crf = int(rng.choice([0, 0, 3, 9]))
+    nb = int(min(H, rng.choice([1, 2, 3, 5, 8, 16, 17, 18])))
+    clip = make_clip(rng, T, H, W, C)
+    base, cmax, vel = CRF[crf]
+    kw = dict(time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, c_thresh_start=base, c_counter_start=0)
+    st = torch.cuda.current_stream().cuda_stream
+    whole = A.HipVideo(W, H, C, **kw); whole.set_crf_parameters(cmax, vel)
+    d_all = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_ev = torch.empty((d_all.numel() * 3 + 64, 3), dtype=torch.int32, device="cuda")
+    d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    whole.integrate_device(d_all, d_ev, d_off, stream=st)
+    n_want = whole.finish()
+    if rng.random() < 0.5:
+        bands = sharding.row_bands(H, nb)
+    else:
+        bands = sharding.row_bands_root_heavy(H, nb, float(rng.uniform(0.02, 1.0 / nb)))
+    bands = [b for b in bands if b[1] > b[0]]
+    ctxs, fr = [], []
+    for (y0, y1) in bands:
+        hv = A.HipVideo(W, H, C, row_begin=y0, row_end=y1, **kw); hv.set_crf_parameters(cmax, vel); ctxs.append(hv)
+        fr.append(torch.from_numpy(np.ascontiguousarray(clip[:, y0:y1]).reshape(T, -1)).cuda())
+    d_m = torch.full((n_want + 8, 3), -1, dtype=torch.int32, device="cuda")
+    d_mo = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    boffs = [torch.zeros(65, dtype=torch.int64, device="cuda") for _ in bands]
+    f0, base_ev = 0, 0
+    while f0 < T:
+        nf = min(int(rng.choice([1, 3, 16, 37, 64])), T - f0)
+        recs = []
+        for r, hv in enumerate(ctxs):
+            recs.append(hv.integrate_records_device(fr[r][f0:f0 + nf], boffs[r], stream=st)); hv.finish()
+        ctxs[0].expand_records_device(recs, d_m, base_ev, d_mo[f0:], stream=st)
+        ctxs[0].expand_status(st)
+        base_ev = int(d_mo[f0 + nf].item())
+        f0 += nf
+    ok = base_ev == n_want and torch.equal(d_mo, d_off) and torch.equal(d_m[:n_want], d_ev[:n_want]) and int((d_m[n_want:] != -1).sum()) == 0
+    if not ok:
+        raise SystemExit(f"RECORDS MISMATCH W{W} H{H} C{C} T{T} tm{tm} crf{crf} bands{bands}")
+    for hv in ctxs + [whole]:
+        hv.close()
+    return W * H * C * T
+
+
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     rng = np.random.default_rng(seed)
     t0, n, units = time.time(), 0, 0
+    records = os.environ.get("FUZZ_RECORDS") == "1"
     while time.time() - t0 < secs:
-        units += one(rng); n += 1
+        units += one_records(rng) if records else one(rng); n += 1
     print(f"fuzz_parity: {n} clips, {units} unit-frames, seed {seed}: all bit-exact")
