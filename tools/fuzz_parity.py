@@ -52,9 +52,21 @@ def one(rng):
                 raise SystemExit("overflow not reported")
             except A.AdderHipError as e:
                 assert e.code == A.E_OUT_CAPACITY and hv.last_required == len(want), (e.code, hv.last_required, len(want))
-            got, _ = hv.integrate_batch(clip[k:k + nb], out_cap=len(want))
+            try:
+                got, _ = hv.integrate_batch(clip[k:k + nb], out_cap=len(want))
+            except A.AdderHipError as e:
+                raise SystemExit(f"RETRY FAILED ({e}) want {len(want)} required {hv.last_required}: W{W} H{H} C{C} T{T} tm{tm} mm{mm} "
+                                 f"dtm{dtm} crf{crf} depth{depth} at frame {k}+{nb}")
         else:
-            got, _ = hv.integrate_batch(clip[k:k + nb])
+            try:
+                got, _ = hv.integrate_batch(clip[k:k + nb])
+            except A.AdderHipError as e:
+                # the plumbing's default buffer (4 events per unit and frame) can be too small for a Normal-mode scene cut
+                # that flushes deep arenas: reported with the size needed, state rolled back -- retry like a caller would
+                if e.code != A.E_OUT_CAPACITY or hv.last_required != len(want):
+                    raise SystemExit(f"DEFAULT-CAPACITY BATCH FAILED ({e}) want {len(want)}: W{W} H{H} C{C} T{T} tm{tm} mm{mm} "
+                                     f"dtm{dtm} crf{crf} depth{depth} at frame {k}+{nb}")
+                got, _ = hv.integrate_batch(clip[k:k + nb], out_cap=hv.last_required)
         if len(got) != len(want) or not np.array_equal(got, want):
             raise SystemExit(f"MISMATCH W{W} H{H} C{C} T{T} tm{tm} mm{mm} dtm{dtm} crf{crf} depth{depth} at frame {k}+{nb}")
         k += nb
