@@ -34,10 +34,15 @@ def one(rng):
     tm = int(rng.choice([O.DELTA_T, O.ABSOLUTE_T])); mm = int(rng.choice([O.COLLAPSE, O.COLLAPSE, O.COLLAPSE, O.NORMAL]))
     dtm = int(rng.choice([255, 7650, 7650, 1020])); crf = int(rng.choice([0, 3, 3, 6, 9]))
     depth = int(rng.choice([1, 3, 16, 64, 64]))
+    cont = os.environ.get("FUZZ_CONTINUOUS") == "1" or (os.environ.get("FUZZ_CONTINUOUS") is None and rng.random() < 0.12)
     clip = make_clip(rng, T, H, W, C)
     ov = O.Video(W, H, C, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm)
-    hv = A.HipVideo(W, H, C, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, max_depth=24)
-    ov.ensure_capacity(26)
+    if cont:  # Mode::Continuous (the event-camera sources' mode, fed frames): the general arena step
+        ov.set_pixel_mode(1)
+        hv = A.HipVideo(W, H, C, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, max_depth=24, pixel_mode=1)
+    else:
+        hv = A.HipVideo(W, H, C, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm, max_depth=24)
+    ov.ensure_capacity(30)
     base, cmax, vel = CRF[crf]
     for v in (ov, hv):
         v.set_crf_parameters(cmax, vel); v.reset_c_thresh(base)
