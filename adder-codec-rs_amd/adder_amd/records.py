@@ -83,11 +83,15 @@ class RecordsPipelinedGather:
         self.chunk_no += 1
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            meta = torch.tensor([nf, nseg, rb, int(n_records), int(rec.row_begin), int(rec.rows), int(n_events)], dtype=torch.int64)
+            # (the last word: the room left in the rank's merged buffer -- dst's is the one that counts; a chunk that does
+            # not fit is refused by EVERY rank before any point-to-point operation is posted, see ChunkPipelinedGather)
+            room = (self.merged.shape[0] - self.merged_pos) if self.rank == self.dst else -1
+            meta = torch.tensor([nf, nseg, rb, int(n_records), int(rec.row_begin), int(rec.rows), int(n_events), room],
+                                dtype=torch.int64)
             if self.world > 1:
                 via_host = dist.get_backend(self.group) == "gloo"
                 tdev = torch.device("cpu") if via_host else self.device
-                all_meta = torch.empty((self.world, 7), dtype=torch.int64, device=tdev)
+                all_meta = torch.empty((self.world, 8), dtype=torch.int64, device=tdev)
                 m = meta.to(tdev)
                 if tdev.type == "cuda":
                     dist.all_gather_into_tensor(all_meta, m, group=self.group)
@@ -98,6 +102,10 @@ class RecordsPipelinedGather:
                 via_host, tdev, metas = False, self.device, [meta.tolist()]
             if any(int(mm[0]) != nf for mm in metas):
                 raise RuntimeError("the ranks pushed chunks of different lengths")
+            total = int(sum(int(mm[6]) for mm in metas))
+            if total > int(metas[self.dst][7]):
+                raise RuntimeError(f"merged buffer too small: need {total} more events, room for {int(metas[self.dst][7])} "
+                                   f"(every rank refuses the chunk; nothing was sent)")
             ops, imgs = [], [None] * self.world
             if self.rank == self.dst:
                 for r in range(self.world):
@@ -115,10 +123,7 @@ class RecordsPipelinedGather:
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            total = int(sum(int(mm[6]) for mm in metas))
             if self.rank == self.dst:
-                if self.merged_pos + total > self.merged.shape[0]:
-                    raise RuntimeError(f"merged buffer too small: need {self.merged_pos + total} events")
                 if via_host:
                     imgs = [im if im.device.type == "cuda" else im.to(self.device) for im in imgs]
                 self._keep += imgs

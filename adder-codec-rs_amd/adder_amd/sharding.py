@@ -226,14 +226,24 @@ class ChunkPipelinedGather:
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream(self.device))  # the chunk's events are complete behind this
         with ctx:
-            offs = (offsets - offsets[0]).contiguous().to(tdev)
-            all_offs = torch.empty((self.world, Tc + 1), dtype=torch.int64, device=tdev)
+            # every row carries one more word: the room left in the rank's merged buffer (dst's is the one that counts).
+            # A chunk that does not fit is then refused by EVERY rank, before any point-to-point operation is posted --
+            # an error raised on dst alone would leave the peers in the next chunk's all-gather (adder_gather_events_at
+            # agrees on such failures with an all-reduce in front of the payload for the same reason)
+            room = (self.merged.shape[0] - self.merged_pos) if self.rank == self.dst else -1
+            row = torch.cat([(offsets - offsets[0]).to(tdev), torch.tensor([room], dtype=torch.int64, device=tdev)]).contiguous()
+            all_rows = torch.empty((self.world, Tc + 2), dtype=torch.int64, device=tdev)
             if tdev.type == "cuda":
-                dist.all_gather_into_tensor(all_offs, offs, group=self.group)
+                dist.all_gather_into_tensor(all_rows, row, group=self.group)
             else:
-                dist.all_gather(list(all_offs.unbind(0)), offs, group=self.group)
+                dist.all_gather(list(all_rows.unbind(0)), row, group=self.group)
+            all_offs = all_rows[:, :Tc + 1].contiguous()
             totals = all_offs[:, -1].tolist()  # (waits for the all-gather only: the next chunk keeps integrating)
             total = int(sum(totals))
+            dst_room = int(all_rows[self.dst, Tc + 1])
+            if total > dst_room:
+                raise RuntimeError(f"merged buffer too small: need {total} more events, room for {dst_room} "
+                                   f"(every rank refuses the chunk; nothing was sent)")
             ops, stage = [], None
             if self.rank == self.dst:
                 stage = torch.empty((max(total, 1), 3), dtype=torch.int32, device=tdev)
@@ -253,8 +263,6 @@ class ChunkPipelinedGather:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
             if self.rank == self.dst:
-                if self.merged_pos + total > self.merged.shape[0]:
-                    raise RuntimeError(f"merged buffer too small: need {self.merged_pos + total} events")
                 if self.cuda:
                     if via_host:
                         stage, all_offs = stage.to(self.device), all_offs.to(self.device)

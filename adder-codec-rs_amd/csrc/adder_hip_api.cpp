@@ -145,8 +145,19 @@ struct AdderHipCtx {
     uint32_t graph_candidates = 6;
     bool use_graph = true;
     bool eager_two_streams = false;
+    // ADDER_HIP_CU_SPLIT=n (0 < n < CUs): spatial partitioning instead of time sharing -- the frame kernel of chunk k+1
+    // on a stream masked to n CUs (the same share of every XCD), scan / offsets / expansion of chunk k on a stream masked
+    // to the others; a batch's first frame-kernel run and last expansion have no partner and take the unmasked stream.
+    hipStream_t split_a = nullptr, split_b = nullptr;
+    hipEvent_t split_el[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t cu_split = 0;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
+    // [0]: adder_log_pack_kernel's total (written, never read back); [1] (as u32): the status word of
+    // adder_hip_expand_records_device's kernels -- they run on a side stream beside root's own batches, so they must not
+    // share the batches' word (a capacity flag of theirs would be charged to an unrelated batch, and clearing theirs
+    // could erase a flag a batch in flight raised)
+    uint64_t *d_side_words = nullptr;
     // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
     bool records_only = false;        // the batch being queued stops after its scan
     float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
@@ -304,6 +315,7 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
+    if (c->d_side_words) (void)hipFree(c->d_side_words);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
     for (hipEvent_t e : c->band_desc_e)
@@ -325,6 +337,10 @@ static void free_ctx(AdderHipCtx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
     if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
+    if (c->split_a) (void)hipStreamDestroy(c->split_a);
+    if (c->split_b) (void)hipStreamDestroy(c->split_b);
+    for (hipEvent_t e : c->split_el)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -602,6 +618,21 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
         }
+        if (const char *cs = getenv("ADDER_HIP_CU_SPLIT")) {
+            // CU-mask bit i is CU i / XCDs of XCD i % XCDs (the driver deals the bits round-robin over the XCDs, then over
+            // the shader engines), so bits [0, n) take n / 8 CUs of EVERY XCD: both partitions keep all eight L2s
+            const int n = atoi(cs);
+            if (n > 0 && (uint32_t)n < c->num_cus) {
+                uint32_t ma[16] = {0}, mb[16] = {0};
+                const uint32_t words = (c->num_cus + 31u) / 32u;
+                for (uint32_t i = 0; i < c->num_cus && i < 512u; ++i) ((int)i < n ? ma : mb)[i >> 5] |= 1u << (i & 31u);
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->split_a, words, ma));
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->split_b, words, mb));
+                for (hipEvent_t &e : c->split_el) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->cu_split = (uint32_t)n;
+                c->use_graph = false;  // (a captured kernel node does not carry its stream's CU mask)
+            }
+        }
         {
             // workgroups per CU of the lean frame kernel and of the expansion when they share the chip (0: full grids)
             const char *lb = getenv("ADDER_HIP_LEAN_BLOCKS_PER_CU"), *eb = getenv("ADDER_HIP_EXPAND_BLOCKS_PER_CU");
@@ -616,6 +647,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->d_rec_total, 1));
+        HIPCHK(c, dalloc(&c->d_side_words, 2));
+        HIPCHK(c, hipMemsetAsync(c->d_side_words, 0, 2 * sizeof(uint64_t), c->stream));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1105,6 +1138,43 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     return ADDER_OK;
 }
 
+// ADDER_HIP_CU_SPLIT: the same launch sequence on CU-masked streams.  `full` (unmasked) takes what has no partner: the
+// first chunk's frame kernels and the last chunk's scan / offsets / expansion; in between chunk k+1's frame kernels run
+// on split_a's CUs while chunk k's expansion runs on split_b's.  Every dependency is an event (the streams differ from
+// chunk to chunk): frame kernels after the previous chunk's (the pixel state) and after the expansion that last used
+// their scratch; scan after its chunk's frame kernels and after the previous chunk's offsets (the offsets chain).
+static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t full) {
+    const uint32_t depth = launch_depth(c);
+    const Lean1wArgs wide = lean1w_args(c);
+    const uint32_t n_chunks = (num_frames + c->chunk - 1u) / c->chunk;
+    hipStream_t prev_l = nullptr, prev_p = nullptr;
+    uint32_t k = 0;
+    for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
+        const uint32_t nf = std::min(c->chunk, num_frames - f0);
+        hipStream_t ls = (k == 0u || n_chunks == 1u) ? full : c->split_a;
+        hipStream_t ps = (k + 1u == n_chunks) ? full : c->split_b;
+        if (k && ls != prev_l) HIPCHK(c, hipStreamWaitEvent(ls, c->split_el[(k - 1u) % 5u], 0));
+        if (k >= c->ring_chunks) HIPCHK(c, hipStreamWaitEvent(ls, c->cap_e2[(k - c->ring_chunks) % 5u], 0));
+        for (uint32_t f = f0; f < f0 + nf; f += depth) {
+            const uint32_t nb = std::min(depth, f0 + nf - f);
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, 0u, ls, &wide));
+        }
+        HIPCHK(c, hipEventRecord(c->split_el[k % 5u], ls));
+        if (ps != ls) HIPCHK(c, hipStreamWaitEvent(ps, c->split_el[k % 5u], 0));
+        if (k && ps != prev_p) HIPCHK(c, hipStreamWaitEvent(ps, c->cap_e2[(k - 1u) % 5u], 0));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, ps));
+        HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, ps));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps));
+        HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], ps));
+        prev_l = ls;
+        prev_p = ps;
+    }
+    // (the last chunk's expansion is on `full`, in order behind everything `full` was given; its frame kernels and the
+    // earlier expansions are ordered before it by the events above)
+    HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, full));
+    return ADDER_OK;
+}
+
 static int instantiate_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
@@ -1470,6 +1540,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         hipGraphExec_t exec = nullptr;
         rc = get_graph(c, num_frames, variant, &exec);
         if (rc == ADDER_OK) HIPCHK(c, hipGraphLaunch(exec, stream));
+    } else if (c->cu_split && !timing && !(variant & 4u) && !c->continuous && num_frames > c->chunk) {
+        HIPCHK(c, hipEventRecord(c->cap_e1, stream));
+        HIPCHK(c, hipStreamWaitEvent(c->cap_s, c->cap_e1, 0));
+        rc = launch_frame_loop_split(c, num_frames, variant, c->cap_s);
+        if (rc == ADDER_OK) {
+            HIPCHK(c, hipEventRecord(c->cap_e1, c->cap_s));
+            HIPCHK(c, hipStreamWaitEvent(stream, c->cap_e1, 0));
+        }
     } else if (c->eager_two_streams && !timing) {
         // the graph's two-stream structure, submitted eagerly (diagnostics)
         HIPCHK(c, hipEventRecord(c->cap_e1, stream));
@@ -1536,12 +1614,18 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
         return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight (collect them first)");
     if (!d_frames || !d_frame_offsets || num_frames == 0) return fail(c, ADDER_E_BAD_PARAMS, "null pointer / no frames");
     if (!(time_spanned >= 0.0f)) return fail(c, ADDER_E_BAD_PARAMS, "time_spanned must be >= 0");
+    // The lean regime is a precondition the CALLER can miss (include/adder_gather.h: "gather events instead"): it is
+    // checked before anything is touched -- no scratch re-laid out, no graph retired, no poisoned context.
+    if (c->generic_sticky || c->perpx || c->continuous || c->sparse_mode || feature_path(c) || feature_needs_perpx(c) ||
+        !(c->p.multi_mode == ADDER_MULTI_COLLAPSE && (float)c->p.delta_t_max <= time_spanned))
+        return fail(c, ADDER_E_BAD_PARAMS, "records can be handed out in the lean regime only (Collapse, delta_t_max <= "
+                    "time_spanned, no feature mode, no generic batch before): gather events instead");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     // the scratch must exist before the chunk size is known
-    if (!c->continuous) {
+    {
         int rc_ = alloc_scratch(c, c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? AdderHipCtx::kScratchLean : AdderHipCtx::kScratchLean8);
-        if (rc_ != ADDER_OK && !c->generic_sticky) return rc_;
+        if (rc_ != ADDER_OK) return rc_;
     }
     if (c->ring_chunks < 2 || num_frames > c->chunk)
         return fail(c, ADDER_E_BAD_PARAMS, "a records batch holds at most adder_hip_chunk_frames() = %u frames", c->chunk);
@@ -1562,7 +1646,7 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
     const size_t chunk_bytes = (size_t)c->num_waves * cap * rb;
     uint8_t *const packed = c->park_ring + chunk_bytes;
     uint32_t *const pbase = c->wcur + c->num_waves;
-    uint64_t *const d_total = reinterpret_cast<uint64_t *>(c->wcur + 2 * (size_t)c->num_waves);
+    uint64_t *const d_total = c->d_side_words;  // (its own word: wcur holds ring_chunks >= 2 rows and two are in use)
     HIPCHK(c, adder_launch_log_pack(c->park_ring, cap, rb, c->wcur, pbase, c->num_waves, num_frames, c->wofs_ring, packed,
                                     chunk_bytes, d_total, c->status, s));
     HIPCHK(c, hipEventRecord(c->ev_stop, s));
@@ -1631,6 +1715,7 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
         BatchArgs &b = *reinterpret_cast<BatchArgs *>(h_blk + (size_t)r * kBatchDescBytes);
         memset(&b, 0, sizeof b);
         base_args(c, &b.base);
+        b.base.status = reinterpret_cast<uint32_t *>(c->d_side_words + 1);  // (the expansions' own word: d_side_words)
         b.base.n_units = bands[r].rows * c->p.width * c->p.channels;
         b.base.num_waves = bands[r].num_segments;
         b.base.row_begin = bands[r].row_begin;
@@ -1724,12 +1809,12 @@ extern "C" int adder_hip_expand_status(AdderHipCtx *c, void *stream) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     uint32_t st = 0;
-    HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, s));
+    uint32_t *const word = reinterpret_cast<uint32_t *>(c->d_side_words + 1);
+    HIPCHK(c, hipMemcpyAsync(&st, word, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (st & kStatusCapacity) {
-        HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), s));
+    if (st) HIPCHK(c, hipMemsetAsync(word, 0, sizeof(uint32_t), s));
+    if (st & kStatusCapacity)
         return fail(c, ADDER_E_OUT_CAPACITY, "the merged event buffer was too small: events were dropped");
-    }
     return status_to_code(c, st);
 }
 
@@ -1798,6 +1883,7 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
     if (st == kStatusCapacity && c->snap.valid) {
         // the event buffer was too small: nothing else went wrong, and the state before the batch is at hand
         int rc = restore_snapshot(c, c->pending_stream);
+        c->band_frame_pending = false;  // (the frame is gone with the rollback: the retry is a fresh integrate call)
         if (rc != ADDER_OK) {
             c->poisoned = true;
             return rc;
@@ -1806,7 +1892,9 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
                     "retry with a larger buffer)", (unsigned long long)total);
     }
     c->snap.valid = false;
-    return status_to_code(c, st);
+    const int rc_st = status_to_code(c, st);
+    if (rc_st != ADDER_OK) c->band_frame_pending = false;  // (no feature step follows a failed frame)
+    return rc_st;
 }
 
 extern "C" float adder_hip_last_batch_ms(AdderHipCtx *c) { return c ? c->last_ms : 0.0f; }

@@ -1469,3 +1469,48 @@ def test_feature_mode_over_row_bands_matches_the_whole_plane(bands, channels):
         assert total_new > 10
         for v in vids + [whole]:
             v.close()
+
+
+def test_band_in_feature_mode_survives_a_too_small_event_buffer():
+    """a row band in feature / ROI mode whose event buffer is too small is rolled back (ADDER_E_OUT_CAPACITY)
+    and the documented retry -- the same frame with a larger buffer -- must be accepted: the pending-feature-step flag
+    goes with the rollback.  The retried stream equals the whole-plane context's and the oracle's."""
+    import torch
+    A = _hip()
+    from adder_amd import sharding
+    from adder_amd import _native as N
+    import ctypes as C
+    H, W, channels, radius = 61, 83, 1, 3
+    clip = clips.make_clip("corners", 12, H, W, channels, seed=77)
+    ov, whole = _feature_pair(A, W, H, channels, multi_mode=O.COLLAPSE, dtm=7650, radius=radius, roi=None)
+    vids = []
+    for y0, y1 in sharding.row_bands(H, 2):
+        v = A.HipVideo(W, H, channels, row_begin=y0, row_end=y1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE,
+                       ref_time=255, delta_t_max=7650, max_depth=30)
+        v.set_crf_parameters(13, 4)
+        v.reset_c_thresh(6)
+        v.update_detect_features(True, True)
+        v.set_feature_parameters(6, radius)
+        vids.append(v)
+    fb = sharding.FeatureBands(vids)
+    st = torch.cuda.current_stream().cuda_stream
+    retried = 0
+    for k in range(len(clip)):
+        want = ov.integrate_matrix(clip[k])
+        n_band0 = int(np.count_nonzero(want["y"] < vids[0].row_end))
+        if n_band0 > 2 and retried < 2 and k >= 2:  # band 0: a device call with room for 2 events, then the retry
+            v = vids[0]
+            d_fr = torch.from_numpy(np.ascontiguousarray(clip[k, v.row_begin:v.row_end]).reshape(1, -1)).cuda()
+            d_off = torch.zeros(2, dtype=torch.int64, device="cuda")
+            tiny = torch.empty((2, 3), dtype=torch.int32, device="cuda")
+            v.integrate_device(d_fr, tiny, d_off, stream=st)
+            with pytest.raises(A.AdderHipError) as ei:
+                v.finish()
+            assert ei.value.code == A.E_OUT_CAPACITY
+            retried += 1
+        got = fb.integrate_matrix(clip[k])  # (band 0's frame k again: must not be refused by band_precheck)
+        assert len(got) == len(want) and np.array_equal(got, want), k
+        assert fb.new_features == len(ov.new_features()), k
+    assert retried == 2
+    for v in vids + [whole]:
+        v.close()

@@ -95,8 +95,19 @@ def test_records_are_refused_outside_the_lean_regime_and_capacity_is_reported():
     d = torch.from_numpy(clip.reshape(T, -1)).cuda()
     d_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
     hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=7650)  # the default mode: not lean
-    with pytest.raises(A.AdderHipError):
+    d_ev = torch.empty((4 * W * H * T, 3), dtype=torch.int32, device="cuda")
+    hv.integrate_device(d[:7], d_ev, d_off[:8])
+    n7 = hv.finish()
+    with pytest.raises(A.AdderHipError) as ei:
         hv.integrate_records_device(d, d_off)
+    assert ei.value.code == A.E_BAD_PARAMS
+    #  the refusal is the caller's cue to gather events instead: the context is NOT poisoned and its pixel
+    # state is untouched -- the next frames continue the stream exactly as if the refused call had not happened
+    hv.integrate_device(d[7:], d_ev[n7:], d_off[7:])
+    n_rest = hv.finish()
+    ov = O.Video(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+    want = np.concatenate([ov.integrate_matrix(f) for f in clip])
+    assert n7 + n_rest == len(want) and d_ev[:n7 + n_rest].cpu().numpy().tobytes() == want.tobytes()
     hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
     hv.set_crf_parameters(0, 10)
     with pytest.raises(A.AdderHipError):  # more frames than a chunk

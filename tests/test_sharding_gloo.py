@@ -181,6 +181,51 @@ def test_chunk_pipelined_gather_matches_single_stream(world, chunk_frames):
     assert [q.get(timeout=5) for _ in range(2)] == [True, True]
 
 
+def _worker_too_small(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "adder-codec-rs_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from adder_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pg = sharding.ChunkPipelinedGather(8, merged_cap_events=10, dst=0)  # room for 10 events on rank 0
+        ev = torch.arange(12 * 3, dtype=torch.int32).reshape(12, 3) + 100 * rank
+        offs = torch.tensor([0, 4, 4, 7, 12], dtype=torch.int64)
+        raised = False
+        try:
+            pg.push(ev, offs)  # 24 events over the two ranks: does not fit
+        except RuntimeError as e:
+            raised = "too small" in str(e)
+        untouched = (pg.frame_pos, pg.merged_pos) == (0, 0)
+        # nothing was posted: the ranks are still in step, and a chunk that fits goes through afterwards
+        small = torch.tensor([0, 2, 2, 3, 4], dtype=torch.int64)
+        pg.push(ev[:4].contiguous(), small)
+        out = pg.result()
+        ok = raised and untouched and (out is None or (out[0].shape[0] == 8 and out[1][:5].tolist() == [0, 4, 4, 6, 8]))
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunk_that_does_not_fit_is_refused_by_every_rank():
+    """`merged buffer too small` used to be raised on dst alone, after the peers' sends had completed -- the
+    peers then ran on into the next chunk's all-gather.  dst's remaining room travels with the offsets now, every rank
+    raises before any point-to-point operation, and the gather object stays usable."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_too_small, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [q.get(timeout=5) for _ in range(2)] == [True, True]
+
+
 def test_root_heavy_bands_tile_the_plane_and_balance_the_gather():
     """sharding.gather_peer_share / row_bands_root_heavy (records gathered to rank 0 over one link per peer): the bands tile
     the plane in rank order, the peers own equal bands no larger than an even split, root takes the rest, and the
