@@ -177,6 +177,8 @@ SYMBOLS = {
     "adder_hip_set_frames_per_launch": (_i32, [_vp, _u32]),
     "adder_hip_reset": (_i32, [_vp]),
     "adder_hip_wire_events_device": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
+    "adder_hip_sink_layout_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "adder_hip_wire_scatter_device": (_i32, [_vp, _vp, _vp, _u32, _vp, _vp, C.c_uint64, C.c_uint64, _vp]),
     "adder_hip_integrate_batch_raw": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp]),
     "adder_hip_stream_submit": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _sz]),
     "adder_hip_stream_collect": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_vp)]),

@@ -2046,6 +2046,31 @@ extern "C" int adder_hip_wire_events_device(AdderHipCtx *c, const AdderEvent *d_
     return ADDER_OK;
 }
 
+// ---- sink per rank (include/adder_hip.h; SURVEY 8(e): every GPU delivers its own segments) ----
+extern "C" int adder_hip_sink_layout_device(AdderHipCtx *c, const uint64_t *d_all_offsets, uint32_t world, uint32_t rank,
+                                            uint32_t num_frames, uint64_t *d_file_pos, uint64_t *d_dest,
+                                            uint64_t *d_merged_offsets, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (!d_all_offsets || !d_file_pos || !d_dest || world == 0 || rank >= world || num_frames == 0)
+        return fail(c, ADDER_E_BAD_PARAMS, "sink layout: null pointer / bad rank / no frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, adder_launch_sink_layout(d_all_offsets, world, rank, num_frames, d_file_pos, d_dest, d_merged_offsets,
+                                       (hipStream_t)stream));
+    return ADDER_OK;
+}
+extern "C" int adder_hip_wire_scatter_device(AdderHipCtx *c, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                             uint32_t num_frames, const uint64_t *d_dest, uint8_t *out, uint64_t out_cap_bytes,
+                                             uint64_t header_bytes, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (!d_events || !d_frame_offsets || !d_dest || !out) return fail(c, ADDER_E_BAD_PARAMS, "wire scatter: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    // (the events per frame are known on the device only: a fixed grid of workgroups walks every frame's blocks)
+    HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(d_events), d_frame_offsets, num_frames, d_dest,
+                                        wire_record_bytes(c), out, out_cap_bytes, header_bytes,
+                                        reinterpret_cast<uint32_t *>(c->d_side_words + 1), c->num_cus * 4u, (hipStream_t)stream));
+    return ADDER_OK;
+}
+
 extern "C" int adder_hip_integrate_batch_raw(AdderHipCtx *c, const uint8_t *frames, uint32_t num_frames,
                                              size_t frame_stride, size_t row_stride, float time_spanned,
                                              uint8_t *out_bytes, size_t out_cap_bytes, size_t *n_bytes,

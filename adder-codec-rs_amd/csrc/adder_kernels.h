@@ -298,6 +298,11 @@ hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t
                                  uint64_t packed_cap_bytes, uint64_t *d_total, uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t stride, uint32_t n_bands, const uint32_t *num_waves,
                                      uint32_t nf, uint32_t abs_t, hipStream_t stream);
+hipError_t adder_launch_sink_layout(const uint64_t *all_offs, uint32_t world, uint32_t rank, uint32_t nf, uint64_t *file_pos,
+                                    uint64_t *dest, uint64_t *merged_offs, hipStream_t stream);
+hipError_t adder_launch_wire_scatter(const adder::AdderEventPod *ev, const uint64_t *offs, uint32_t nf, const uint64_t *dest,
+                                     uint32_t rec, uint8_t *out, uint64_t out_cap, uint64_t header, uint32_t *status,
+                                     uint32_t grid, hipStream_t stream);
 hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
                                     uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

@@ -2122,6 +2122,105 @@ __global__ __launch_bounds__(256) void adder_wire_kernel(const uint32_t *__restr
     if (bad) raise(status, kStatusWire);
 }
 
+// ------------------------------------------------------------------------------------------
+// Sink per rank (the alternative to the funnel: "each GPU D2H's its own segment and the host
+// concatenates -- 8 PCIe links vs one"; consumer: video.rs:736-740 -> encoder.rs:233-273, raw/stream.rs:101-120).
+// Every rank serialises ITS band's events of a chunk of frames to wire records and stores them straight to their final
+// byte positions of the one .adder image, which lives in host memory every rank has mapped (a POSIX shm file = the
+// file itself): no gather over xGMI, no staging copy, no host round trip per chunk.
+//   adder_sink_layout_kernel   from the ranks' all-gathered frame offsets of the chunk: where this rank's segment of
+//                              every frame starts in the file (event index), and the file position after the chunk.
+//   adder_wire_scatter_kernel  12-byte AdderEvents -> 9 / 11-byte records (adder_wire_kernel's repack) at
+//                              header + dest[f] * rec; a frame's segment starts at any byte phase, so every workgroup
+//                              writes leading / trailing bytes singly and the dwords in between whole.
+// ------------------------------------------------------------------------------------------
+__global__ void adder_sink_layout_kernel(const uint64_t *__restrict__ all_offs, uint32_t world, uint32_t rank, uint32_t nf,
+                                         uint64_t *file_pos, uint64_t *__restrict__ dest, uint64_t *__restrict__ merged_offs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const size_t per = (size_t)nf + 1;
+    uint64_t run = *file_pos;
+    if (merged_offs) merged_offs[0] = run;
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint64_t before = 0, tot = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint64_t c = all_offs[r * per + f + 1] - all_offs[r * per + f];
+            before += r < rank ? c : 0ull;
+            tot += c;
+        }
+        dest[f] = run + before;
+        run += tot;
+        if (merged_offs) merged_offs[f + 1] = run;
+    }
+    *file_pos = run;
+}
+
+__global__ __launch_bounds__(256) void adder_wire_scatter_kernel(const uint32_t *__restrict__ ev, const uint64_t *__restrict__ offs,
+                                                                 uint32_t nf, const uint64_t *__restrict__ dest, uint32_t rec,
+                                                                 uint8_t *__restrict__ out, uint64_t out_cap, uint64_t header,
+                                                                 uint32_t *status) {
+    __shared__ uint32_t s_w[kWireEvents * 3];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t magic = rec == 9u ? 0x38e38e39u : 0xba2e8ba3u;  // floor(B / rec) = mulhi(B, magic) >> (1 | 3)
+    const uint32_t sh = rec == 9u ? 1u : 3u;
+    bool bad = false, over = false;
+    for (uint32_t f = 0; f < nf; ++f) {
+        const uint64_t fb = offs[f];
+        const uint64_t fcnt = offs[f + 1] - fb;
+        const uint64_t nblocks = (fcnt + kWireEvents - 1) / kWireEvents;
+        for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {  // uniform per workgroup
+            const uint64_t e0 = blk * kWireEvents;
+            const uint32_t cnt = (uint32_t)min((uint64_t)kWireEvents, fcnt - e0);
+            const uint32_t *src = ev + (fb + e0) * 3u;
+            __syncthreads();  // (the previous block's reads of s_w)
+            for (uint32_t i = tid; i < cnt * 3u; i += 256u) s_w[i] = src[i];
+            __syncthreads();
+            for (uint32_t e = tid; e < cnt; e += 256u) {
+                const uint32_t xy = s_w[3 * e], cd = s_w[3 * e + 1], t = s_w[3 * e + 2];
+                const uint32_t x = xy & 0xffffu, y = xy >> 16, c = cd & 0xffu, d = (cd >> 8) & 0xffu;
+                const uint32_t w0 = (x >> 8) | ((x & 0xffu) << 8) | ((y >> 8) << 16) | ((y & 0xffu) << 24);
+                uint32_t w1, w2;
+                if (rec == 9u) {
+                    w1 = d | ((t >> 24) << 8) | (((t >> 16) & 0xffu) << 16) | (((t >> 8) & 0xffu) << 24);
+                    w2 = t & 0xffu;
+                } else {
+                    bad |= c == 0xffu;
+                    w1 = 1u | (c << 8) | (d << 16) | ((t >> 24) << 24);
+                    w2 = ((t >> 16) & 0xffu) | (((t >> 8) & 0xffu) << 8) | ((t & 0xffu) << 16);
+                }
+                s_w[3 * e] = w0;
+                s_w[3 * e + 1] = w1;
+                s_w[3 * e + 2] = w2;
+            }
+            __syncthreads();
+            const uint32_t bytes = cnt * rec;
+            const uint64_t a0 = header + (dest[f] + e0) * rec;  // the block's first byte in the image
+            if (a0 + bytes > out_cap) {
+                over = true;
+                continue;
+            }
+            uint8_t *const dst = out + a0;
+            auto seg_byte = [&](uint32_t B) -> uint32_t {
+                const uint32_t e = __umulhi(B, magic) >> sh;
+                const uint32_t r = B - e * rec;
+                return (s_w[3u * e + (r >> 2)] >> (8u * (r & 3u))) & 0xffu;
+            };
+            uint32_t head = (uint32_t)((4u - (a0 & 3u)) & 3u);
+            head = head < bytes ? head : bytes;
+            if (tid < head) dst[tid] = (uint8_t)seg_byte(tid);
+            const uint32_t nd = (bytes - head) >> 2;
+            uint32_t *const dst_dw = reinterpret_cast<uint32_t *>(dst + head);
+            for (uint32_t k = tid; k < nd; k += 256u) {
+                const uint32_t B = head + 4u * k;
+                dst_dw[k] = seg_byte(B) | (seg_byte(B + 1u) << 8) | (seg_byte(B + 2u) << 16) | (seg_byte(B + 3u) << 24);
+            }
+            const uint32_t tail = (bytes - head) & 3u;
+            if (tid < tail) dst[head + 4u * nd + tid] = (uint8_t)seg_byte(head + 4u * nd + tid);
+        }
+    }
+    if (bad) raise(status, kStatusWire);
+    if (over) raise(status, kStatusCapacity);
+}
+
 __global__ void adder_fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -2505,6 +2604,21 @@ extern "C" hipError_t adder_launch_wire(const AdderEventPod *ev, uint64_t n, uin
     const uint64_t grid = (n + kWireEvents - 1) / kWireEvents;
     hipLaunchKernelGGL(adder_wire_kernel, dim3((uint32_t)grid), dim3(256), 0, stream,
                        reinterpret_cast<const uint32_t *>(ev), n, rec, out, status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t adder_launch_sink_layout(const uint64_t *all_offs, uint32_t world, uint32_t rank, uint32_t nf,
+                                               uint64_t *file_pos, uint64_t *dest, uint64_t *merged_offs, hipStream_t stream) {
+    hipLaunchKernelGGL(adder_sink_layout_kernel, dim3(1), dim3(64), 0, stream, all_offs, world, rank, nf, file_pos, dest,
+                       merged_offs);
+    return hipGetLastError();
+}
+extern "C" hipError_t adder_launch_wire_scatter(const AdderEventPod *ev, const uint64_t *offs, uint32_t nf, const uint64_t *dest,
+                                                uint32_t rec, uint8_t *out, uint64_t out_cap, uint64_t header, uint32_t *status,
+                                                uint32_t grid, hipStream_t stream) {
+    if (nf == 0) return hipSuccess;
+    hipLaunchKernelGGL(adder_wire_scatter_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(ev), offs, nf, dest, rec, out, out_cap, header, status);
     return hipGetLastError();
 }
 

@@ -36,6 +36,35 @@ int adder_gather_create(AdderHipCtx *ctx, void *nccl_comm, int rank, int world, 
 /* Creates (and owns) a communicator from a unique id: ncclCommInitRank(world, id, rank). */
 int adder_gather_create_from_id(AdderHipCtx *ctx, const uint8_t id[ADDER_GATHER_UNIQUE_ID_BYTES], int rank,
                                 int world, AdderGather **out);
+
+/* The transport under the gather: what it needs from a communicator, as a table of functions.  RCCL is one
+ * implementation (the two constructors above); a host with another communicator (MPI, its own xGMI / shared-memory
+ * code) supplies its own.  All buffers are device memory, all sizes bytes; operations are ordered by `stream` like RCCL's
+ * and may block.  send / recv are only called between group_start and group_end, and group_end(stream) posts them all.
+ * Every function returns ADDER_OK or a negative AdderStatus; `error` (may be null) describes the last failure. */
+typedef struct AdderTransport {
+    void *self;
+    int (*all_gather)(void *self, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+    int (*all_reduce_max)(void *self, int32_t *d_word, void *stream); /* one int32, in place */
+    int (*group_start)(void *self);
+    int (*send)(void *self, const void *buf, size_t bytes, int peer, void *stream);
+    int (*recv)(void *self, void *buf, size_t bytes, int peer, void *stream);
+    int (*group_end)(void *self, void *stream);
+    const char *(*error)(void *self);
+} AdderTransport;
+/* The table is copied; `self` must outlive the gather object. */
+int adder_gather_create_with_transport(AdderHipCtx *ctx, const AdderTransport *transport, int rank, int world,
+                                       AdderGather **out);
+
+/* An in-process transport: the ranks are THREADS of one process, one context each (any devices, also all on one --
+ * where RCCL refuses two ranks per GPU).  Every operation is a blocking rendezvous with synchronous device copies: slow,
+ * but the protocol above it is the production one (tests/test_gpu_gather_local.py).  A rank that does not turn up within
+ * 30 s fails the operation on every rank (ADDER_E_TIMEOUT) instead of hanging the process. */
+typedef struct AdderLocalGroup AdderLocalGroup;
+int adder_gather_local_group_create(int world, AdderLocalGroup **out);
+void adder_gather_local_group_destroy(AdderLocalGroup *group); /* after every gather object made from it */
+int adder_gather_create_local(AdderHipCtx *ctx, AdderLocalGroup *group, int rank, AdderGather **out);
+
 void adder_gather_destroy(AdderGather *g);
 const char *adder_gather_last_error(const AdderGather *g);
 int adder_gather_world(const AdderGather *g);
@@ -61,7 +90,8 @@ int adder_gather_events_at(AdderGather *g, const AdderEvent *d_events, const uin
                            uint32_t num_frames, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
                            uint64_t *d_merged_offsets, size_t *n_merged, void *stream);
 
-/* RECORDS over the wire (include/adder_hip.h: AdderBandRecords).  The events of a band cross ONE xGMI link on their way to
+/* RECORDS over the wire, one chunk per call, complete when the call returns (two host waits per chunk: the sizes, the
+ * agreement; the streamed form below has none) (include/adder_hip.h: AdderBandRecords).  The events of a band cross ONE xGMI link on their way to
  * root; its parked records are 0.35x the bytes.  Every rank integrates a chunk of at most adder_hip_chunk_frames() frames
  * with adder_hip_integrate_records_device + adder_hip_finish and passes the description here with
  * adder_hip_last_batch_records() and the finish count: the ranks exchange the sizes, every peer sends one contiguous image
@@ -74,6 +104,49 @@ int adder_gather_events_at(AdderGather *g, const AdderEvent *d_events, const uin
 int adder_gather_records_at(AdderGather *g, const AdderBandRecords *rec, uint64_t n_records, uint64_t n_events, int root,
                             AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets,
                             size_t *n_merged, void *stream);
+
+/* The same, STREAMED: the host is out of the per-chunk loop.  begin() names the destination of a whole clip (root: the
+ * merged buffer, where the clip starts in it, the clip's merged offsets [T + 1]; the others pass nulls) and the stream
+ * every exchange is queued on; push() takes one chunk exactly like adder_gather_records_at, but only copies the chunk's
+ * image, queues the all-gather of ITS sizes (device -> pinned host memory, an event behind them) and then posts the
+ * PAYLOAD OF THE CHUNK BEFORE, whose sizes arrived a chunk ago -- it waits for nothing that is not long done; end() posts
+ * the last chunk's payload, waits for the stream and reports (root: the clip's merged events, a merged buffer that was too
+ * small -- the expansion drops what does not fit --; the others: the bytes they sent).  No agreement round per chunk: the
+ * image buffers hold a chunk's worst case (one record per unit and frame) from the object's first push on -- that push
+ * alone agrees on the allocations with a blocking all-reduce --, a rank's local failure travels in its own row of the
+ * sizes, and rows that do not fit together are seen by every rank alike, so every rank takes the same way out and none
+ * is left in a send.  One clip at a time per object; adder_gather_records_at must not be mixed into an open stream. */
+int adder_gather_records_begin(AdderGather *g, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
+                               uint64_t *d_merged_offsets, void *stream);
+int adder_gather_records_push(AdderGather *g, const AdderBandRecords *rec, uint64_t n_records, uint64_t n_events);
+int adder_gather_records_end(AdderGather *g, size_t *n_merged, uint64_t *bytes_sent);
+/* Host time spent inside adder_gather_records_push since the last begin, microseconds (diagnostics). */
+double adder_gather_records_host_us(const AdderGather *g);
+
+/* SINK PER RANK ("each GPU D2H's its own segment and the host concatenates -- 8 PCIe links vs one"; the
+ * consumer is the raw sink, video.rs:736-740 -> encoder.rs:233-273 -> raw/stream.rs:101-120).  Nothing is funnelled into
+ * one GPU: `image` is the .adder file itself, mapped into every rank's process and registered with HIP (a POSIX
+ * shared-memory file, hipHostRegister(.., hipHostRegisterMapped): pass the DEVICE pointer), header_bytes of it reserved
+ * for the header the host writes.  Per chunk every rank passes what adder_hip_integrate_device left it (events, frame
+ * offsets -- any start value); the ranks all-gather the chunk's offsets, a kernel derives where this rank's segment of
+ * every frame belongs, and a second one serialises the segments to 9 / 11-byte wire records and stores them straight to
+ * their final bytes -- over the rank's OWN PCIe link.  Everything is queued on `stream`; the file position lives on the
+ * device, the host waits for nothing until close(), which returns the events the image holds (the host then appends
+ * the EOF record and truncates the file).  Bytes past image_bytes are dropped and reported by close(). */
+int adder_gather_host_sink_open(AdderGather *g, void *image, uint64_t image_bytes, uint64_t header_bytes, void *stream);
+int adder_gather_host_sink_chunk(AdderGather *g, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                 uint32_t num_frames, void *stream);
+int adder_gather_host_sink_close(AdderGather *g, uint64_t *total_events, void *stream);
+
+/* The image for the sinks: a POSIX shared-memory file (shm_open(name): /dev/shm/<name> IS the .adder file) of `bytes`
+ * bytes, mapped into this process and registered with HIP so that kernels store into it.  create != 0: the rank that
+ * makes the file (the others open it after that rank says so, by any means).  close(): final_bytes >= 0 truncates the
+ * file to its real length; unlink_file removes it (benchmarks). */
+typedef struct AdderHostImage AdderHostImage;
+int adder_host_image_open(const char *name, uint64_t bytes, int create, AdderHostImage **out);
+void *adder_host_image_host_ptr(const AdderHostImage *image);
+void *adder_host_image_device_ptr(const AdderHostImage *image);
+int adder_host_image_close(AdderHostImage *image, int64_t final_bytes, int unlink_file);
 
 /* Layout-only exchange: all-gathers the per-frame offsets and returns, on every rank, the merged
  * stream's frame offsets (h_merged_offsets, host uint64[T+1]) and where this rank's segment of each

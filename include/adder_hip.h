@@ -345,6 +345,26 @@ int adder_hip_sync_last_batch_stream(AdderHipCtx *ctx);
 /* Waits for `stream` and returns ADDER_OK or the failure the expansions since the last call ran into (capacity). */
 int adder_hip_expand_status(AdderHipCtx *root, void *stream);
 
+/* ---- sink per rank ("each GPU D2H's its own segment and the host concatenates -- 8 PCIe links vs one";
+ * consumer: video.rs:736-740 -> encoder.rs:233-273 -> raw/stream.rs:101-120).  The building blocks
+ * adder_gather_host_sink_* (include/adder_gather.h) are made of; usable on their own with any means of exchanging the
+ * ranks' per-frame offsets.
+ * adder_hip_sink_layout_device: d_all_offsets = the ranks' frame offsets of ONE chunk, device uint64 [world][num_frames + 1]
+ * (values as adder_hip_integrate_device left them).  *d_file_pos (device) is the number of events the image holds before
+ * the chunk; the call writes d_dest[f] = the event index at which THIS rank's events of frame f start in the image, advances
+ * *d_file_pos by the chunk's total and, if d_merged_offsets is not null, writes the merged offsets [num_frames + 1].
+ * adder_hip_wire_scatter_device: this rank's events of the chunk (d_events indexed by d_frame_offsets' values) as 9 / 11-byte
+ * wire records at out + header_bytes + d_dest[f] * record_bytes.  `out` is anything the device can store to: HBM, or host
+ * memory mapped into the device (hipHostRegister / hipHostMalloc) -- then the stores cross this GPU's own PCIe link and
+ * the bytes land where the file has them.  Bytes past out_cap_bytes are dropped and reported by adder_hip_expand_status.
+ * Both queue on `stream`; nothing waits on the host. */
+int adder_hip_sink_layout_device(AdderHipCtx *ctx, const uint64_t *d_all_offsets, uint32_t world, uint32_t rank,
+                                 uint32_t num_frames, uint64_t *d_file_pos, uint64_t *d_dest, uint64_t *d_merged_offsets,
+                                 void *stream);
+int adder_hip_wire_scatter_device(AdderHipCtx *ctx, const AdderEvent *d_events, const uint64_t *d_frame_offsets,
+                                  uint32_t num_frames, const uint64_t *d_dest, uint8_t *out, uint64_t out_cap_bytes,
+                                  uint64_t header_bytes, void *stream);
+
 /* Mean number of frames one timed frame-kernel launch stepped (see frames_per_launch). */
 float adder_hip_last_launch_frames(AdderHipCtx *ctx);
 

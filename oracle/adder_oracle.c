@@ -608,18 +608,31 @@ OracleVideo *oracle_video_new(uint16_t width, uint16_t height, uint8_t channels,
     v->threads = threads > 0 ? threads : 1;
     size_t n = (size_t)width * height * channels;
     v->px = (PixelArena *)malloc(n * sizeof(PixelArena));
-    v->running_intensities = (uint8_t *)calloc(n, 1);
-    size_t i = 0;
-    for (uint32_t y = 0; y < height; y++)
-        for (uint32_t x = 0; x < width; x++)
-            for (uint32_t c = 0; c < channels; c++) {
-                arena_init(&v->px[i], 1.0f, (uint16_t)x, (uint16_t)(y + row_begin),
-                           channels == 1 ? 0xFF : (uint8_t)c);
-                v->px[i].time_mode = (uint8_t)time_mode;
-                i++;
-            }
+    v->running_intensities = (uint8_t *)malloc(n);
     v->num_chunks = (height + chunk_rows - 1) / chunk_rows;
     v->chunk_ev = (EventVec *)calloc(v->num_chunks, sizeof(EventVec));
+    /* The pixels are initialised chunk by chunk by the team that will step them, with the static schedule of
+     * oracle_video_integrate_clip: a thread first touches -- and so places on its own NUMA node -- the rows it owns for
+     * the life of the clip (what a rayon pool over `chunks` converges to; CPU-baseline timing only, same values). */
+    const long nchunks = (long)v->num_chunks;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(v->threads)
+#endif
+    for (long ch = 0; ch < nchunks; ch++) {
+        uint32_t y0 = (uint32_t)ch * chunk_rows, y1 = y0 + chunk_rows;
+        if (y1 > height) y1 = height;
+        for (uint32_t y = y0; y < y1; y++) {
+            size_t i = (size_t)y * width * channels;
+            memset(v->running_intensities + i, 0, (size_t)width * channels);
+            for (uint32_t x = 0; x < width; x++)
+                for (uint32_t c = 0; c < channels; c++) {
+                    arena_init(&v->px[i], 1.0f, (uint16_t)x, (uint16_t)(y + row_begin),
+                               channels == 1 ? 0xFF : (uint8_t)c);
+                    v->px[i].time_mode = (uint8_t)time_mode;
+                    i++;
+                }
+        }
+    }
     return v;
 }
 
@@ -902,37 +915,73 @@ void oracle_video_c_thresh_plane(const OracleVideo *v, uint8_t *out) {
  * NULL) gets num_chunks+1 prefix offsets so the caller can rebuild Vec<Vec<Event>>.
  * Returns the number of events, or (size_t)-1 if out_cap is too small (the
  * required size is then in *n_out and the pixel state HAS advanced). */
+/* one row chunk of one frame: the body of the rayon loop, video.rs:693-732 */
+static void integrate_chunk(OracleVideo *v, long ch, const uint8_t *frame, size_t row_stride, float time_spanned) {
+    const size_t rowlen = (size_t)v->width * v->channels;
+    const double tpf = (double)v->sp.ref_time;
+    EventVec *buf = &v->chunk_ev[ch];
+    buf->len = 0;
+    size_t y0 = (size_t)ch * v->chunk_rows;
+    size_t y1 = y0 + v->chunk_rows;
+    if (y1 > v->height) y1 = v->height;
+    for (size_t y = y0; y < y1; y++) {
+        const uint8_t *row = frame + y * row_stride;
+        PixelArena *prow = v->px + y * rowlen;
+        uint8_t *rrow = v->running_intensities + y * rowlen;
+        for (size_t i = 0; i < rowlen; i++) {
+            /* matrix.mapv(f32::from) ; `*input as u8` round-trips exactly */
+            float input = (float)row[i];
+            integrate_for_px(&prow[i], (uint8_t)input, input, time_spanned, buf, &v->sp);
+            if (prow[i].arena[0].has_best) {
+                /* Event32 -> Event: t = delta_t as u32 */
+                rrow[i] = frame_value_u8(prow[i].arena[0].best_event.d,
+                                         f32_as_u32(prow[i].arena[0].best_event.delta_t), tpf);
+            }
+        }
+    }
+}
+
+size_t oracle_video_chunks_raw_events(const OracleVideo *v, uint8_t *dst);
+/* CPU-baseline timing: `num_frames` frames through ONE parallel region (the team lives for the clip: a barrier per
+ * frame instead of a fork / join), chunks dealt statically -- a thread keeps the rows it first touched in
+ * oracle_video_new -- and, with `sink`, the serial raw-sink stage of video.rs:736-740 after every frame (one thread,
+ * the others wait: the reference's consume() does not return before it).  Feature detection / ROI are not run (off in
+ * every benchmark configuration).  The chunk buffers hold the LAST frame's events afterwards; returns the clip's events. */
+size_t oracle_video_integrate_clip(OracleVideo *v, const uint8_t *frames, size_t num_frames, size_t frame_stride,
+                                   size_t row_stride, float time_spanned, uint8_t *sink) {
+    const long nchunks = (long)v->num_chunks;
+    size_t total = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(v->threads)
+#endif
+    {
+        for (size_t f = 0; f < num_frames; f++) {
+            const uint8_t *frame = frames + f * frame_stride;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+            for (long ch = 0; ch < nchunks; ch++) integrate_chunk(v, ch, frame, row_stride, time_spanned);
+            /* (implicit barrier: the frame's events are complete) */
+#ifdef _OPENMP
+#pragma omp single
+#endif
+            {
+                for (long ch = 0; ch < nchunks; ch++) total += v->chunk_ev[ch].len;
+                if (sink) (void)oracle_video_chunks_raw_events(v, sink);
+            }
+        }
+    }
+    return total;
+}
+
 size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_t row_stride,
                                      float time_spanned, OracleEvent *out, size_t out_cap,
                                      size_t *n_out, uint32_t *chunk_offsets) {
-    const size_t rowlen = (size_t)v->width * v->channels;
-    const double tpf = (double)v->sp.ref_time;
     long nchunks = (long)v->num_chunks;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(v->threads)
 #endif
-    for (long ch = 0; ch < nchunks; ch++) {
-        EventVec *buf = &v->chunk_ev[ch];
-        buf->len = 0;
-        size_t y0 = (size_t)ch * v->chunk_rows;
-        size_t y1 = y0 + v->chunk_rows;
-        if (y1 > v->height) y1 = v->height;
-        for (size_t y = y0; y < y1; y++) {
-            const uint8_t *row = frame + y * row_stride;
-            PixelArena *prow = v->px + y * rowlen;
-            uint8_t *rrow = v->running_intensities + y * rowlen;
-            for (size_t i = 0; i < rowlen; i++) {
-                /* matrix.mapv(f32::from) ; `*input as u8` round-trips exactly */
-                float input = (float)row[i];
-                integrate_for_px(&prow[i], (uint8_t)input, input, time_spanned, buf, &v->sp);
-                if (prow[i].arena[0].has_best) {
-                    /* Event32 -> Event: t = delta_t as u32 */
-                    rrow[i] = frame_value_u8(prow[i].arena[0].best_event.d,
-                                             f32_as_u32(prow[i].arena[0].best_event.delta_t), tpf);
-                }
-            }
-        }
-    }
+    for (long ch = 0; ch < nchunks; ch++) integrate_chunk(v, ch, frame, row_stride, time_spanned);
     size_t total = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
         if (chunk_offsets) chunk_offsets[ch] = (uint32_t)total;
@@ -1096,6 +1145,42 @@ void oracle_synth_clip(uint8_t *dst, int content, uint64_t seed, uint32_t W, uin
     }
 }
 
+/* What this box's memory system gives a team of `threads` on the STREAM triad (a[i] = b[i] + s * c[i], three arrays of
+ * `n` floats first-touched by the threads that sweep them, best of `reps`): GB/s.  Printed next to the CPU baseline so
+ * that a plateau of the thread sweep can be read against the machine, not against the port. */
+double oracle_stream_triad(size_t n, int threads, int reps) {
+    float *a = (float *)malloc(n * sizeof(float)), *b = (float *)malloc(n * sizeof(float)), *c = (float *)malloc(n * sizeof(float));
+    if (!a || !b || !c) {
+        free(a); free(b); free(c);
+        return 0.0;
+    }
+    const long ln = (long)n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+    for (long i = 0; i < ln; i++) {
+        a[i] = 0.0f;
+        b[i] = 1.0f;
+        c[i] = 2.0f;
+    }
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+        double t0 = omp_get_wtime();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+        for (long i = 0; i < ln; i++) a[i] = b[i] + 3.0f * c[i];
+        double el = omp_get_wtime() - t0;
+        double gbs = 3.0 * (double)n * sizeof(float) / el / 1e9;
+        if (gbs > best) best = gbs;
+    }
+    volatile float sink = a[n / 2];
+    (void)sink;
+    free(a); free(b); free(c);
+    return best;
+}
+
+size_t oracle_sizeof_pixel_arena(void) { return sizeof(PixelArena); }
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

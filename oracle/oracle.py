@@ -101,6 +101,8 @@ def lib():
 
     L.oracle_video_integrate_matrix_chunks.restype = sz
     L.oracle_video_integrate_matrix_chunks.argtypes = [vp, vp, sz, f32]
+    L.oracle_video_integrate_clip.restype = sz
+    L.oracle_video_integrate_clip.argtypes = [vp, vp, sz, sz, sz, f32, vp]
     L.oracle_video_chunks_copy_out.restype = sz
     L.oracle_video_chunks_copy_out.argtypes = [vp, vp]
     L.oracle_video_chunks_raw_events.restype = sz
@@ -329,6 +331,11 @@ class Video:
     def integrate_matrix_chunks(self, frame_ptr, row_stride, time_spanned):
         return self.L.oracle_video_integrate_matrix_chunks(self.h, frame_ptr, row_stride, time_spanned)
 
+    def integrate_clip(self, frames_ptr, num_frames, frame_stride, row_stride, time_spanned, sink_ptr=None):
+        """CPU-baseline timing: the clip through one persistent OpenMP team (oracle_video_integrate_clip)."""
+        return self.L.oracle_video_integrate_clip(self.h, frames_ptr, num_frames, frame_stride, row_stride, time_spanned,
+                                                  sink_ptr)
+
     def chunks_copy_out(self, n):
         if n > self._cap:
             self._cap = n
@@ -465,3 +472,16 @@ def synth_clip(content, W, H, C_, frames, *, y0=0, rows=None, k0=0, seed=SEED):
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+def sizeof_pixel_arena():
+    L = lib()
+    L.oracle_sizeof_pixel_arena.restype = C.c_size_t
+    return int(L.oracle_sizeof_pixel_arena())
+
+
+def stream_triad_GBs(n_floats, threads, reps=3):
+    L = lib()
+    L.oracle_stream_triad.restype = C.c_double
+    L.oracle_stream_triad.argtypes = [C.c_size_t, C.c_int, C.c_int]
+    return float(L.oracle_stream_triad(int(n_floats), int(threads), int(reps)))

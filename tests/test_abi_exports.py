@@ -28,7 +28,7 @@ def test_gather_library_exports_every_declared_symbol():
     from adder_amd import gather
     hdr = open(os.path.join(ROOT, "include", "adder_gather.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(adder_gather_\w+)\s*\(", hdr))
+    names = set(re.findall(r"\b(adder_(?:gather|host_image)_\w+)\s*\(", hdr))
     assert len(names) >= 7 and names == set(gather.SYMBOLS)
     adder_amd.load()
     L = ctypes.CDLL(gather.LIB_PATH)
