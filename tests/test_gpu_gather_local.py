@@ -171,7 +171,8 @@ def test_streamed_records_gather_reports_a_merged_buffer_that_is_too_small_on_ro
             g.records_begin(0, dst if r == 0 else None, 0, d_moff if r == 0 else None, stream=side.cuda_stream)
             for f0 in range(0, T, 16):
                 rec = hv.integrate_records_device(d_fr[f0:f0 + 16], d_boff, stream=st.cuda_stream)
-                g.records_push(rec, hv.last_batch_records(), hv.finish())
+                n_k = hv.finish()  # (before last_batch_records(): finish is what reads the batch's record count)
+                g.records_push(rec, hv.last_batch_records(), n_k)
             if r == 0 and dst is d_small:
                 with pytest.raises(A.AdderHipError) as ei:
                     g.records_end()
