@@ -137,6 +137,8 @@ SYMBOLS = {
     "adder_hip_c_thresh_plane": (_i32, [_vp, _vp]),
     "adder_hip_last_new_features": (_u32, [_vp]),
     "adder_hip_frames_configure": (_i32, [_vp, _u32, _sz]),
+    "adder_hip_frames_set_format": (_i32, [_vp, _i32]),
+    "adder_hip_frame_collect_wire": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_vp)]),
     "adder_hip_frame_submit": (_i32, [_vp, _vp, _sz, _f32]),
     "adder_hip_frame_collect": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp)]),
     "adder_hip_frames_in_flight": (_u32, [_vp]),

@@ -231,6 +231,24 @@ class HipVideo:
             events, chunks = events.copy(), chunks.copy()
         return (events, chunks) if want_chunks else events
 
+    def frames_set_format(self, wire_records):
+        """The ring hands out 9 / 11-byte wire records (what RawOutput writes) instead of AdderEvents."""
+        N.check(self.h, self.L.adder_hip_frames_set_format(self.h, 1 if wire_records else 0))
+
+    def frame_collect_wire(self, want_chunks=False, copy=True):
+        """-> (wire bytes of the oldest frame in flight, its number of events[, chunk offsets in events])."""
+        by, nb, n, ch = C.c_void_p(), C.c_size_t(0), C.c_size_t(0), C.c_void_p()
+        rc = self.L.adder_hip_frame_collect_wire(self.h, C.byref(by), C.byref(nb), C.byref(n), C.byref(ch))
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
+        self.last_required = n.value
+        N.check(self.h, rc)
+        data = np.frombuffer((C.c_uint8 * nb.value).from_address(by.value), dtype=np.uint8) if nb.value else np.zeros(0, np.uint8)
+        chunks = np.frombuffer((C.c_uint32 * (self.num_chunks + 1)).from_address(ch.value), dtype=np.uint32)
+        if copy:
+            data, chunks = data.copy(), chunks.copy()
+        return (data, n.value, chunks) if want_chunks else (data, n.value)
+
     def frames_in_flight(self):
         return int(self.L.adder_hip_frames_in_flight(self.h))
 

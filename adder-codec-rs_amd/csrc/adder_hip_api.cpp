@@ -226,6 +226,7 @@ struct AdderHipCtx {
         size_t out_cap = 0;
     } fslot[4];
     uint32_t f_slots = 3;
+    bool f_wire = false;             // the ring hands out 9 / 11-byte wire records instead of AdderEvents (adder_hip_frames_set_format)
     size_t f_events_per_slot = 0;    // 0: the mode's worst case, at most 2 GiB of events
     uint64_t f_submitted = 0, f_collected = 0;
     hipEvent_t frame_e = nullptr;
@@ -647,8 +648,8 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
         if (const char *fl = getenv("ADDER_HIP_FRAMES_PER_LAUNCH"))
             c->frames_per_launch = (uint32_t)std::max(1, std::min<int>(atoi(fl), kMaxFramesPerLaunch));
         HIPCHK(c, dalloc(&c->d_rec_total, 1));
-        HIPCHK(c, dalloc(&c->d_side_words, 2));
-        HIPCHK(c, hipMemsetAsync(c->d_side_words, 0, 2 * sizeof(uint64_t), c->stream));
+        HIPCHK(c, dalloc(&c->d_side_words, 4));  // ([2]: a constant 0 -- the wire scatter's destination of a lone frame)
+        HIPCHK(c, hipMemsetAsync(c->d_side_words, 0, 4 * sizeof(uint64_t), c->stream));
         HIPCHK(c, dalloc(&c->d_chunks, c->num_chunks + 1));
         { int rc_ = init_state(c); if (rc_ != ADDER_OK) return rc_; }
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2285,8 +2286,13 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     fs.out_cap = need;
     HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
+    const bool wire = c->f_wire && !direct_out;
+    if (wire)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
+        HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
+                                            c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
+                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, 128u, c->out_s));
     HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
-                                     reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
+                                     wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
                                      feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s));
     HIPCHK(c, hipEventRecord(fs.done, c->out_s));
@@ -2331,6 +2337,25 @@ extern "C" int adder_hip_frame_collect(AdderHipCtx *c, const AdderEvent **events
                                        const uint32_t **chunk_offsets) {
     if (!c) return ADDER_E_BAD_PARAMS;
     return frame_collect_impl(c, events, n_events, chunk_offsets);
+}
+
+extern "C" int adder_hip_frames_set_format(AdderHipCtx *c, int wire_records) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (c->f_submitted != c->f_collected) return fail(c, ADDER_E_BAD_PARAMS, "frames are in flight");
+    c->f_wire = wire_records != 0;
+    return ADDER_OK;
+}
+extern "C" int adder_hip_frame_collect_wire(AdderHipCtx *c, const uint8_t **bytes, size_t *n_bytes, size_t *n_events,
+                                            const uint32_t **chunk_offsets) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    if (!c->f_wire) return fail(c, ADDER_E_BAD_PARAMS, "the ring hands out AdderEvents (adder_hip_frames_set_format)");
+    const AdderEvent *ev = nullptr;
+    size_t n = 0;
+    int rc = frame_collect_impl(c, &ev, &n, chunk_offsets);
+    if (bytes) *bytes = reinterpret_cast<const uint8_t *>(ev);
+    if (n_events) *n_events = n;
+    if (n_bytes) *n_bytes = n * wire_record_bytes(c);
+    return rc;
 }
 
 extern "C" uint32_t adder_hip_frames_in_flight(const AdderHipCtx *c) {

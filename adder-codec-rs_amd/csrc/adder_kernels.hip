@@ -2774,7 +2774,7 @@ extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const ui
                                              AdderEventPod *h_ev, FrameResult *h_res, uint32_t *h_chunks,
                                              const uint32_t *status, const uint32_t *counters, uint32_t row_begin,
                                              uint32_t chunk_rows, uint32_t num_chunks, hipStream_t stream) {
-    const uint32_t copy_blocks = 128;  // a slice of the chip keeps a x16 link busy
+    const uint32_t copy_blocks = h_ev ? 128 : 0;  // a slice of the chip keeps a x16 link busy (null: the wire scatter did the hand-over)
     const uint32_t chunk_blocks = (num_chunks + 1 + 255) / 256;
     hipLaunchKernelGGL(adder_frame_out_kernel, dim3(copy_blocks + chunk_blocks), dim3(256), 0, stream, d_ev, d_offsets,
                        cap, h_ev, h_res, h_chunks, status, counters, row_begin, chunk_rows, num_chunks, copy_blocks);

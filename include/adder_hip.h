@@ -198,6 +198,14 @@ int adder_hip_frame_submit(AdderHipCtx *ctx, const uint8_t *frame_hwc, size_t ro
 int adder_hip_frame_collect(AdderHipCtx *ctx, const AdderEvent **events, size_t *n_events,
                             const uint32_t **chunk_offsets);
 uint32_t adder_hip_frames_in_flight(const AdderHipCtx *ctx);
+/* The ring can hand out what the raw sink WRITES instead of AdderEvents (RawOutput::ingest_event, raw/stream.rs:101-120:
+ * 9-byte EventSingle records on a 1-channel plane, 11-byte Event records otherwise, bincode fixint big-endian): the
+ * hand-over kernel serialises on the device and stores the bytes into the slot -- 25 % fewer bytes over PCIe, and the
+ * caller's sink is a write().  adder_hip_frames_set_format(ctx, 1) while no frame is in flight; collect with
+ * adder_hip_frame_collect_wire (n_bytes = n_events x record size; chunk_offsets stay in events). */
+int adder_hip_frames_set_format(AdderHipCtx *ctx, int wire_records);
+int adder_hip_frame_collect_wire(AdderHipCtx *ctx, const uint8_t **bytes, size_t *n_bytes, size_t *n_events,
+                                 const uint32_t **chunk_offsets);
 
 /* --- sparse sources (event cameras; Mode::Continuous contexts) ------------------------------------------------
  * One step = one `integrate_for_px(px, &mut 0, frame_val, intensity, time, &mut events, ..)` call of the reference's

@@ -1077,6 +1077,51 @@ def test_frame_ring_submit_collect(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3])
+def test_frame_ring_hands_out_wire_records(channels):
+    """adder_hip_frames_set_format(ctx, 1): the hand-over kernel serialises on the device and the slots receive the
+    9 / 11-byte records RawOutput::ingest_event writes (raw/stream.rs:101-120) -- per frame they equal the oracle's
+    raw_events of that frame, the chunk offsets stay in events, and switching back mid-stream continues the stream."""
+    A = _hip()
+    W, H = 157, 61
+    clip = clips.make_clip("runs", 40, H, W, channels, seed=23)
+    ov = O.Video(W, H, channels, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, chunk_rows=5)
+    hv = A.HipVideo(W, H, channels, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, chunk_rows=5)
+    for v in (ov, hv):
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+    hv.frames_set_format(True)
+    rec = 9 if channels == 1 else 11
+    want = [ov.integrate_matrix(f, want_chunks=True) for f in clip[:30]]
+    pinned = [hv.pinned_frame() for _ in range(3)]
+    got = []
+    for k, f in enumerate(clip[:30]):
+        if hv.frames_in_flight() == 3:
+            got.append(hv.frame_collect_wire(want_chunks=True))
+        pinned[k % 3][...] = f.reshape(H, W * channels)
+        hv.frame_submit(pinned[k % 3])
+    with pytest.raises(A.AdderHipError):  # the format belongs to the frames in flight
+        hv.frames_set_format(False)
+    while hv.frames_in_flight():
+        got.append(hv.frame_collect_wire(want_chunks=True))
+    assert len(got) == 30 and sum(n for _, n, _ in got) > 1000
+    for k, ((ev, ch), (data, n, gch)) in enumerate(zip(want, got)):
+        assert n == len(ev) and len(data) == n * rec, k
+        assert data.tobytes() == O.raw_events(ev, channels), k
+        assert np.array_equal(ch, gch), k
+    hv.frames_set_format(False)
+    with pytest.raises(A.AdderHipError):
+        hv.frame_collect_wire()
+    for f in clip[30:]:  # back to AdderEvents, same stream: the ring, then the blocking call
+        pinned[0][...] = f.reshape(H, W * channels)
+        hv.frame_submit(pinned[0])
+        assert np.array_equal(hv.frame_collect(), ov.integrate_matrix(f))
+    extra = clips.make_clip("runs", 2, H, W, channels, seed=24)
+    for f in extra:
+        assert np.array_equal(hv.integrate_matrix(f), ov.integrate_matrix(f))
+
+
+@pytest.mark.gpu
 def test_frame_ring_rules_and_overflow():
     A = _hip()
     clip = clips.make_clip("noise", 6, 20, 33, 1, seed=1)
