@@ -1,12 +1,12 @@
 #!/bin/bash
-# Which kernel differs between a fast and a slow context?  tools/ctx_spread_probe.py under rocprofv3: kernel trace (or, with
+# Which kernel differs between a fast and a slow context?  tools/attic/ctx_spread_probe.py under rocprofv3: kernel trace (or, with
 # PMC="counter ...", one counter pass), mean per kernel and per context (contexts run one after the other: dispatch order).
 REPO=$(pwd); OUT=$REPO/gpurun_out/ctxab; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 K=${K:-8}
 if [ -n "$PMC" ]; then
-  K=$K ROUNDS=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/t -o k -- python $REPO/tools/ctx_spread_probe.py > $OUT/log.txt 2>&1
+  K=$K ROUNDS=1 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/t -o k -- python $REPO/tools/attic/ctx_spread_probe.py > $OUT/log.txt 2>&1
 else
-  K=$K ROUNDS=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o k -- python $REPO/tools/ctx_spread_probe.py > $OUT/log.txt 2>&1
+  K=$K ROUNDS=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o k -- python $REPO/tools/attic/ctx_spread_probe.py > $OUT/log.txt 2>&1
 fi
 grep "round" $OUT/log.txt | cut -c1-200
 python3 - "$OUT/t" "$K" <<'PY'

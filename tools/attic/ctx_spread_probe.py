@@ -3,7 +3,7 @@ prints each context's median step time next to the addresses of its scratch (ADD
 import os, sys, time
 os.environ.setdefault("ADDER_HIP_NO_GRAPH", "1")
 os.environ["ADDER_HIP_DEBUG_ADDRS"] = "1"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
 import numpy as np, torch
 import adder_amd as A

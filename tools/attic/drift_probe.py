@@ -1,6 +1,6 @@
 """Does the step time drift within ONE context (clocks / power) or only between contexts (placement)?"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
 import numpy as np, torch
 import adder_amd as A

@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the framer's ingest call spends its time: HIP-event time of the call vs the kernels' own durations
-# (rocprofv3 kernel trace of the same run).  tools/framer_gap.sh "T=64" "T=256 DTM=7650" ...
+# (rocprofv3 kernel trace of the same run).  tools/attic/framer_gap.sh "T=64" "T=256 DTM=7650" ...
 REPO=$(pwd); OUT=$REPO/gpurun_out/fgap; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for envs in "$@"; do
   echo "=== $envs"

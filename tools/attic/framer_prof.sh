@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel stats + PMC passes of tools/framer_bench.py on the GPU box: tools/framer_prof.sh <tag> ["ENV=.. ENV=.."]
+# Kernel stats + PMC passes of tools/framer_bench.py on the GPU box: tools/attic/framer_prof.sh <tag> ["ENV=.. ENV=.."]
 TAG=${1:-framer}; ENVS=${2:-A=1}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel time of the framer tiles kernel for a few env settings: tools/framer_quick.sh "ENV=.." "ENV=.." ...
+# kernel time of the framer tiles kernel for a few env settings: tools/attic/framer_quick.sh "ENV=.." "ENV=.." ...
 REPO=$(pwd); OUT=$REPO/gpurun_out/fq; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for envs in "$@"; do
   env $envs rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s -o b -- python $REPO/tools/framer_bench.py > $OUT/log.txt 2>&1

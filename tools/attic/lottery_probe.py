@@ -2,7 +2,7 @@
 chunk for a context's life)?  Round A: one context, the OUTPUT buffer reallocated each time.  Round B: one output buffer,
 the context (scratch ring, state) recreated each time.  Round C: both fixed (repeatability)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
 import numpy as np, torch
 import adder_amd as A

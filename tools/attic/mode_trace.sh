@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of several contexts in one process: which queues do the two branches use, and do they overlap?
 REPO=$(pwd); OUT=$REPO/gpurun_out/mode; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-env $1 REPS=${REPS:-6} rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o k -- python $REPO/tools/repeat_bench.py > $OUT/log.txt 2>&1
+env $1 REPS=${REPS:-6} rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o k -- python $REPO/tools/attic/repeat_bench.py > $OUT/log.txt 2>&1
 grep "\[(" $OUT/log.txt | cut -c1-400
 f=$(find $OUT/t -name '*kernel_trace.csv' | head -1)
 python3 - "$f" <<'PY'

@@ -1,6 +1,6 @@
 """Which buffer's placement decides the fast / slow mode?  K contexts x K event buffers x K clips held at once."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
 import numpy as np, torch
 import adder_amd as A

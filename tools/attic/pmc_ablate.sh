@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes of one tools/ablate.py configuration (eager, one stream): tools/pmc_ablate.sh <tag> "ENV=.. ENV=.." [sets]
+# PMC passes of one tools/ablate.py configuration (eager, one stream): tools/attic/pmc_ablate.sh <tag> "ENV=.. ENV=.." [sets]
 # One rocprofv3 --pmc pass per counter set (never combined with other trace domains); prints per-kernel averages.
 TAG=${1:-pmc}; ENVS=${2:-A=1}; MODE=${3:-inst}
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp

@@ -2,7 +2,7 @@
 import os, sys, time
 os.environ["ADDER_HIP_TIMELINE"] = "1"
 os.environ.setdefault("ADDER_HIP_GRAPH_CANDIDATES", "1")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
 import numpy as np, torch
 import adder_amd as A

@@ -7,7 +7,7 @@
 #    temporal depth, and of a 96-frame run with ONE frame per launch (the adder_lean1_kernel rows),
 # then writes summaries under gpurun_out/profiles_<round>/ (copy them into profiles/).
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p "$OUT"
@@ -51,5 +51,20 @@ pmc_passes default_mode_dtm7650_abs "A=1" --frames 128 --delta-t-max 7650 --time
 ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o bench -- \
     python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary --delta-t-max 7650 --time-mode absolute_t > "$OUT/bench_default_mode_under_rocprof.log" 2>&1
 find "$OUT/stats4" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_default_mode_eager_kernel_stats.csv" \;
+# 5. (round 4) the kernels VERDICT r3 found without evidence: adder_cb_kernel<false> (DeltaT default mode), adder_frame_kernel
+#    (Normal mode), and the one-frame-per-launch pipeline's scan / expansion -- PMC passes + eager kernel stats each
+pmc_passes default_mode_dtm7650_delta "A=1" --frames 128 --delta-t-max 7650
+pmc_passes normal_dtm255_delta "A=1" --frames 128 --multi-mode normal
+kstats() {  # $1 = tag, $2 = extra env, $3.. = bench args
+    local tag=$1 envs=$2; shift; shift
+    env $envs ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks_$tag" -o bench -- \
+        python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary $* > "$OUT/bench_${tag}_under_rocprof.log" 2>&1
+    find "$OUT/ks_$tag" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_${tag}_eager_kernel_stats.csv" \;
+    rm -rf "$OUT/ks_$tag"
+}
+kstats default_mode_delta "A=1" --delta-t-max 7650
+kstats normal_dtm255_delta "A=1" --multi-mode normal
+kstats normal_dtm7650_abs "A=1" --multi-mode normal --delta-t-max 7650 --time-mode absolute_t
+kstats one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 128
 rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3 "$OUT"/stats4
 ls -la "$OUT"
