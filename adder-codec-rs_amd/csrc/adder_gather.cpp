@@ -123,9 +123,13 @@ int local_all_gather(void *self, const void *send, void *recv, size_t bytes, voi
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return local_fail(t, "all_gather (stream)");
     { std::lock_guard<std::mutex> lk(g->m); g->ag_send[t->rank] = send; }
     if (!local_barrier(g)) return local_fail(t, "all_gather");
+    // (device-to-device hipMemcpy does not wait on the host: the copies go onto the RECEIVER's stream, which orders them
+    // before whatever it runs next, and that stream is drained before the senders may touch their buffers again)
     for (int r = 0; r < g->world; ++r)
-        if (hipMemcpy(static_cast<uint8_t *>(recv) + (size_t)r * bytes, g->ag_send[r], bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        if (hipMemcpyAsync(static_cast<uint8_t *>(recv) + (size_t)r * bytes, g->ag_send[r], bytes, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream) != hipSuccess)
             return local_fail(t, "all_gather (copy)");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return local_fail(t, "all_gather (copy)");
     if (!local_barrier(g)) return local_fail(t, "all_gather");
     return ADDER_OK;
 }
@@ -141,7 +145,9 @@ int local_all_reduce_max(void *self, int32_t *d_word, void *stream) {
     int32_t mx = g->words[0];
     for (int r = 1; r < g->world; ++r) mx = std::max(mx, g->words[r]);
     if (!local_barrier(g)) return local_fail(t, "all_reduce");
-    if (hipMemcpy(d_word, &mx, sizeof mx, hipMemcpyHostToDevice) != hipSuccess) return local_fail(t, "all_reduce (copy)");
+    if (hipMemcpyAsync(d_word, &mx, sizeof mx, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return local_fail(t, "all_reduce (copy)");
     return ADDER_OK;
 }
 int local_group_start(void *self) {
@@ -177,12 +183,13 @@ int local_group_end(void *self, void *stream) {
             rc = ADDER_E_BAD_PARAMS;
             break;
         }
-        if (hipMemcpy(rv.buf, ss[k].buf, rv.bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+        if (hipMemcpyAsync(rv.buf, ss[k].buf, rv.bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
             rc = local_fail(t, "group_end (copy)");
             break;
         }
         ++k;
     }
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && rc == ADDER_OK) rc = local_fail(t, "group_end (copy)");
     if (!local_barrier(g)) return local_fail(t, "group_end");
     return rc;
 }

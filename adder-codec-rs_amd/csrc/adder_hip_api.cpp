@@ -2290,7 +2290,7 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     if (wire)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
         HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
                                             c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
-                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, 128u, c->out_s));
+                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, c->num_cus * 4u, c->out_s));
     HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
                                      wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,

@@ -27,6 +27,7 @@
 // HBM/VALU-bound integer/f32 work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "adder_kernels.h"
 #include "adder_pixel.hpp"
@@ -2774,7 +2775,9 @@ extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const ui
                                              AdderEventPod *h_ev, FrameResult *h_res, uint32_t *h_chunks,
                                              const uint32_t *status, const uint32_t *counters, uint32_t row_begin,
                                              uint32_t chunk_rows, uint32_t num_chunks, hipStream_t stream) {
-    const uint32_t copy_blocks = h_ev ? 128 : 0;  // a slice of the chip keeps a x16 link busy (null: the wire scatter did the hand-over)
+    // a slice of the chip keeps a x16 link busy (null: the wire scatter did the hand-over); ADDER_HIP_OUT_BLOCKS for A/Bs
+    static const uint32_t want_blocks = [] { const char *e = getenv("ADDER_HIP_OUT_BLOCKS"); return e ? (uint32_t)atoi(e) : 128u; }();
+    const uint32_t copy_blocks = h_ev ? (want_blocks ? want_blocks : 128u) : 0;
     const uint32_t chunk_blocks = (num_chunks + 1 + 255) / 256;
     hipLaunchKernelGGL(adder_frame_out_kernel, dim3(copy_blocks + chunk_blocks), dim3(256), 0, stream, d_ev, d_offsets,
                        cap, h_ev, h_res, h_chunks, status, counters, row_begin, chunk_rows, num_chunks, copy_blocks);

@@ -569,6 +569,12 @@ def main():
         hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
         hv.finish()
         out["cpu_baseline"] = cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, args)
+    # (RCCL writes its version banner to the C stdout buffer: out with it first, so that the JSON is the LAST line)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -823,7 +829,11 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
         hv.set_crf_parameters(7, 7)
         hv.frames_set_format(True)
         L = hv.L
-        pin = [hv.pinned_frame() for _ in range(4)]
+        # (a live source decodes straight into page-locked memory: every frame of the clip gets its own pinned buffer,
+        # the loop below times the transcoder, not a numpy copy)
+        pin = [hv.pinned_frame() for _ in range(T)]
+        for k in range(T):
+            pin[k].reshape(-1)[...] = host[k]
         by_p, nb_p, n_p, ch_p = Ct.c_void_p(), Ct.c_size_t(0), Ct.c_size_t(0), Ct.c_void_p()
         total_b, total_e = 0, 0
 
@@ -838,8 +848,7 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
             for k in range(k0, k1):
                 if L.adder_hip_frames_in_flight(hv.h) == 3:
                     collect()
-                pin[k % 4].reshape(-1)[...] = host[k]  # (the source decodes into page-locked memory: part of the loop)
-                assert L.adder_hip_frame_submit(hv.h, pin[k % 4].ctypes.data, Wd, float(REF_TIME)) == 0
+                assert L.adder_hip_frame_submit(hv.h, pin[k].ctypes.data, Wd, float(REF_TIME)) == 0
             while L.adder_hip_frames_in_flight(hv.h):
                 collect()
         run(0, 32)  # warm: slots, pools; frames 0..31 also pass the start-up transient (everything pops at frame 30)
@@ -851,8 +860,8 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
         return {"value": round(Wd * Ht * n / el / 1e6, 1), "unit": "Mpixels/s", "us_per_frame_sustained": round(el / n * 1e6, 1),
                 "frames": n, "events_per_pixel_frame": round(total_e / float(Wd * Ht * n), 5), "wire_bytes": total_b,
                 "note": "1080p scene, the reference's default quality (crf 3) and mode (Collapse, AbsoluteT, delta_t_max 7650), "
-                        "frame by frame through adder_hip_frame_submit / _collect_wire: host frame in (copied into a "
-                        "page-locked buffer inside the loop), wire records out"}
+                        "frame by frame through adder_hip_frame_submit / _collect_wire: page-locked host frame in, wire "
+                        "records out"}
     except Exception as exc:
         return {"error": str(exc)[:300]}
     finally:
@@ -937,15 +946,16 @@ def end_to_end_host_image(torch, A, hv, d_frames, d_events, d_chunk, T, Wd, Ht, 
     events -> wire records stored by the device straight into the .adder image in shared memory, chunk by chunk beside
     the next chunk's integration.  What one GPU's PCIe link carries."""
     import numpy as np
-    from adder_amd.gather import HipGather, HostImage, unique_id
-    hg = image = None
+    from adder_amd.gather import HipGather, HostImage, LocalGroup
+    hg = image = grp = None
     try:
         dev = torch.device("cuda", torch.cuda.current_device())
         stream = torch.cuda.current_stream().cuda_stream
         side = torch.cuda.Stream(device=dev)
         rec_b = 9 if Cn == 1 else 11
         header = A.raw_header(3, Wd, Ht, Cn, REF_TIME * 30, REF_TIME, dtm, 0, tmode, 0)
-        hg = HipGather(hv, unique_id(), 0, 1)
+        grp = LocalGroup(1)  # (a one-rank group of the in-process transport: no RCCL communicator for one GPU)
+        hg = HipGather(hv, None, 0, 1, local=grp)
         img_bytes = len(header) + (n_events_expected + 4096) * rec_b
         image = HostImage(f"/adder_bench_e2e_{os.getpid()}", img_bytes, create=True)
         image.host_array()[:len(header)] = np.frombuffer(header, np.uint8)
@@ -980,6 +990,8 @@ def end_to_end_host_image(torch, A, hv, d_frames, d_events, d_chunk, T, Wd, Ht, 
     finally:
         if hg is not None:
             hg.close()
+        if grp is not None:
+            grp.close()
         if image is not None:
             image.close(unlink=True)
 

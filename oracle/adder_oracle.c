@@ -100,6 +100,12 @@ typedef struct {
     OracleEvent *data;
     size_t len, cap;
 } EventVec;
+/* a row chunk's buffer: one cache line each, so that buffers written by different threads do not share lines (a Vec's
+ * header lives in its owner's stack frame in the reference) */
+typedef struct {
+    EventVec v;
+    char pad_[64 - sizeof(EventVec)];
+} ChunkVec;
 
 static void evec_push(EventVec *v, OracleEvent e) {
     if (v->len == v->cap) {
@@ -569,7 +575,7 @@ typedef struct {
     uint32_t chunk_rows;
     PixelArena *px; /* [h][w][c] */
     uint8_t *running_intensities;
-    EventVec *chunk_ev; /* per row-chunk buffers */
+    ChunkVec *chunk_ev; /* per row-chunk buffers */
     size_t num_chunks;
     int threads;
     /* feature-driven rate control (video.rs:196-216, 865-1112): VideoState.feature_detection,
@@ -610,13 +616,13 @@ OracleVideo *oracle_video_new(uint16_t width, uint16_t height, uint8_t channels,
     v->px = (PixelArena *)malloc(n * sizeof(PixelArena));
     v->running_intensities = (uint8_t *)malloc(n);
     v->num_chunks = (height + chunk_rows - 1) / chunk_rows;
-    v->chunk_ev = (EventVec *)calloc(v->num_chunks, sizeof(EventVec));
+    v->chunk_ev = (ChunkVec *)calloc(v->num_chunks, sizeof(ChunkVec));
     /* The pixels are initialised chunk by chunk by the team that will step them, with the static schedule of
      * oracle_video_integrate_clip: a thread first touches -- and so places on its own NUMA node -- the rows it owns for
      * the life of the clip (what a rayon pool over `chunks` converges to; CPU-baseline timing only, same values). */
     const long nchunks = (long)v->num_chunks;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(v->threads)
+#pragma omp parallel for schedule(static, 1) num_threads(v->threads)
 #endif
     for (long ch = 0; ch < nchunks; ch++) {
         uint32_t y0 = (uint32_t)ch * chunk_rows, y1 = y0 + chunk_rows;
@@ -640,7 +646,7 @@ void oracle_video_free(OracleVideo *v) {
     if (!v) return;
     size_t n = (size_t)v->width * v->height * v->channels;
     for (size_t i = 0; i < n; i++) arena_free(&v->px[i]);
-    for (size_t i = 0; i < v->num_chunks; i++) free(v->chunk_ev[i].data);
+    for (size_t i = 0; i < v->num_chunks; i++) free(v->chunk_ev[i].v.data);
     free(v->chunk_ev);
     free(v->px);
     free(v->running_intensities);
@@ -841,7 +847,7 @@ static void handle_features(OracleVideo *v) {
     if (!v->feature_detection) return;
     v->n_new_features = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
-        const EventVec *ev = &v->chunk_ev[ch];
+        const EventVec *ev = &v->chunk_ev[ch].v;
         for (size_t i = 0; i < ev->len; i++) { /* circular_tuple_windows: (e[i], e[(i + 1) % len]) */
             const OracleEvent *e1 = &ev->data[i], *e2 = &ev->data[(i + 1) % ev->len];
             const int same = e1->x == e2->x && e1->y == e2->y && e1->c == e2->c;
@@ -919,7 +925,7 @@ void oracle_video_c_thresh_plane(const OracleVideo *v, uint8_t *out) {
 static void integrate_chunk(OracleVideo *v, long ch, const uint8_t *frame, size_t row_stride, float time_spanned) {
     const size_t rowlen = (size_t)v->width * v->channels;
     const double tpf = (double)v->sp.ref_time;
-    EventVec *buf = &v->chunk_ev[ch];
+    EventVec *buf = &v->chunk_ev[ch].v;
     buf->len = 0;
     size_t y0 = (size_t)ch * v->chunk_rows;
     size_t y1 = y0 + v->chunk_rows;
@@ -943,7 +949,7 @@ static void integrate_chunk(OracleVideo *v, long ch, const uint8_t *frame, size_
 
 size_t oracle_video_chunks_raw_events(const OracleVideo *v, uint8_t *dst);
 /* CPU-baseline timing: `num_frames` frames through ONE parallel region (the team lives for the clip: a barrier per
- * frame instead of a fork / join), chunks dealt statically -- a thread keeps the rows it first touched in
+ * frame instead of a fork / join), chunks dealt round-robin (static, 1: busy rows spread over the team) -- a thread keeps the chunks it first touched in
  * oracle_video_new -- and, with `sink`, the serial raw-sink stage of video.rs:736-740 after every frame (one thread,
  * the others wait: the reference's consume() does not return before it).  Feature detection / ROI are not run (off in
  * every benchmark configuration).  The chunk buffers hold the LAST frame's events afterwards; returns the clip's events. */
@@ -958,7 +964,7 @@ size_t oracle_video_integrate_clip(OracleVideo *v, const uint8_t *frames, size_t
         for (size_t f = 0; f < num_frames; f++) {
             const uint8_t *frame = frames + f * frame_stride;
 #ifdef _OPENMP
-#pragma omp for schedule(static)
+#pragma omp for schedule(static, 1)
 #endif
             for (long ch = 0; ch < nchunks; ch++) integrate_chunk(v, ch, frame, row_stride, time_spanned);
             /* (implicit barrier: the frame's events are complete) */
@@ -966,7 +972,7 @@ size_t oracle_video_integrate_clip(OracleVideo *v, const uint8_t *frames, size_t
 #pragma omp single
 #endif
             {
-                for (long ch = 0; ch < nchunks; ch++) total += v->chunk_ev[ch].len;
+                for (long ch = 0; ch < nchunks; ch++) total += v->chunk_ev[ch].v.len;
                 if (sink) (void)oracle_video_chunks_raw_events(v, sink);
             }
         }
@@ -985,7 +991,7 @@ size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_
     size_t total = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
         if (chunk_offsets) chunk_offsets[ch] = (uint32_t)total;
-        total += v->chunk_ev[ch].len;
+        total += v->chunk_ev[ch].v.len;
     }
     if (chunk_offsets) chunk_offsets[v->num_chunks] = (uint32_t)total;
     if (n_out) *n_out = total;
@@ -995,8 +1001,8 @@ size_t oracle_video_integrate_matrix(OracleVideo *v, const uint8_t *frame, size_
     if (total > out_cap) return (size_t)-1;
     size_t off = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
-        memcpy(out + off, v->chunk_ev[ch].data, v->chunk_ev[ch].len * sizeof(OracleEvent));
-        off += v->chunk_ev[ch].len;
+        memcpy(out + off, v->chunk_ev[ch].v.data, v->chunk_ev[ch].v.len * sizeof(OracleEvent));
+        off += v->chunk_ev[ch].v.len;
     }
     return total;
 }
@@ -1013,8 +1019,8 @@ size_t oracle_video_integrate_matrix_chunks(OracleVideo *v, const uint8_t *frame
 size_t oracle_video_chunks_copy_out(const OracleVideo *v, OracleEvent *out) {
     size_t off = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++) {
-        memcpy(out + off, v->chunk_ev[ch].data, v->chunk_ev[ch].len * sizeof(OracleEvent));
-        off += v->chunk_ev[ch].len;
+        memcpy(out + off, v->chunk_ev[ch].v.data, v->chunk_ev[ch].v.len * sizeof(OracleEvent));
+        off += v->chunk_ev[ch].v.len;
     }
     return off;
 }
@@ -1058,7 +1064,7 @@ size_t oracle_raw_events(uint8_t *dst, const OracleEvent *ev, size_t n, uint8_t 
 size_t oracle_video_chunks_raw_events(const OracleVideo *v, uint8_t *dst) {
     size_t off = 0;
     for (size_t ch = 0; ch < v->num_chunks; ch++)
-        off += oracle_raw_events(dst + off, v->chunk_ev[ch].data, v->chunk_ev[ch].len, v->channels);
+        off += oracle_raw_events(dst + off, v->chunk_ev[ch].v.data, v->chunk_ev[ch].v.len, v->channels);
     return off;
 }
 size_t oracle_raw_events(uint8_t *dst, const OracleEvent *ev, size_t n, uint8_t channels) {
