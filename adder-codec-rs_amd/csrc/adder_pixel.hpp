@@ -1064,6 +1064,381 @@ ADDER_HD void cb_pop(CbPxT<L> &s, const CbPlanT<L> &p, const Lv &lv) {
 }
 
 // ---------------------------------------------------------------------------------------
+// CONSTANT-RUN STEP: the bounded Collapse regime (above) while c_thresh is 0 in EVERY frame (crf 0: c_thresh_baseline =
+// c_thresh_max = 0, rate_controller.rs:9) and time_spanned is one integer constant.  Then the contrast test
+// (video.rs:1338-1340) is `frame_val != base_val`: any change of value flushes the arena, so between two flushes a pixel
+// integrates ONE intensity I, frame after frame -- and the whole arena is a function of (I, frames since the flush):
+//   * a node that has been visited r >= 1 times holds integration r I and delta_t r T (event_pixel_tree.rs:449-451: a
+//     firing accumulates like any other visit; I = 0 is the exception below), it fires at its first visit (a fresh
+//     node's d is floor(log2 I), :332-335, 503-512) and then whenever r I crosses a power of two (:427, :452: d becomes
+//     floor(log2 sum) + 1), so its LAST firing was at visit j = ceil(2^e / I), e = floor(log2(r I)), and its best event
+//     is the firing arm (:427-447) evaluated there: (2^e's exponent, (j-1) T + T (2^e - (j-1) I) / I);
+//   * a level exists since its parent's last firing (:342-356: the firing node gets a fresh child, deeper nodes are
+//     dropped) and has been visited in every frame since (a shallower node that fires drops it), so level k+1 has run
+//     r_{k+1} = r_k - j_k frames: the levels are the ROOT states of shorter and shorter runs, and the arena ends at the
+//     first r_k = 0 (the pristine tail).
+// So nothing but the root is stored or stepped: the levels' events are WORKED OUT when a flush wants them (one division
+// each, the same correctly rounded operations on the same exact integers as the stepped arm), pop_top's new root
+// (:199-207) is level 1 worked out the same way, and a launch writes the levels back in their resident form for whoever
+// runs next.  Per unit: the root {S, delta_t, best delta_t, threshold}, base_val, popped_dtm, and r1 = frames since the
+// root last fired (= level 1's run).  I = 0: a d = 128 node fires at every visit without accumulating (:449) -- no
+// level ever exists behind it, r1 stays 0.  tests/cpu_sim runs these functions against the literal oracle, launch by
+// launch, mixed with the bounded and the generic step.
+// ---------------------------------------------------------------------------------------
+template <class L>
+struct CrPxT {
+    float S, dt0, bdt0, thr0;  // the root (meaningful iff has)
+    uint32_t base;
+    uint32_t r1;               // frames since the root last fired: the run of level 1 (0: the root's child is the pristine tail)
+    typename L::Mask has;      // the arena holds a fired root (m != 0)
+    typename L::Mask popped;   // popped_dtm
+    float lastf;
+};
+using CrPx = CrPxT<ScalarLanes>;
+
+// A node that has been visited r >= 1 times at the constant intensity I >= 1: its best event and its last firing.
+struct CrNode {
+    float bdt, thr;   // best_event.delta_t; 2^d of the node (its exponent minus one is best_event.d)
+    uint32_t j;       // the visit at which it last fired (1 <= j <= r)
+};
+ADDER_HD CrNode cr_node(float I, uint32_t r, float T) {
+    const float rI = fmul((float)r, I);                           // exact: below 2^24 (cb_possible)
+    const float p2 = bits_to_f32(f32_to_bits(rI) & 0x7f800000u);  // 2^floor(log2(r I))
+    const float qj = fdiv_small(p2, I);                           // <= r: far from the next float, so ceil() is exact
+    uint32_t j = (uint32_t)qj;
+    j += (float)j < qj ? 1u : 0u;
+    const float jm1 = (float)(j - 1u);
+    const float q = fdiv_small(fsub(p2, fmul(jm1, I)), I);        // the firing arm at visit j (:431, :445)
+    CrNode n;
+    n.bdt = fadd(fmul(jm1, T), fmul(T, q));
+    n.thr = fadd(p2, p2);
+    n.j = j;
+    return n;
+}
+// fired levels of an unpopped arena whose root has run since its last firing for r1 frames (root included)
+ADDER_HD uint32_t cr_depth(float I, uint32_t r1, float T) {
+    uint32_t m = 1u;
+    for (uint32_t r = r1; r != 0u; ++m) r -= cr_node(I, r, T).j;
+    return m;
+}
+
+template <class L>
+ADDER_HD CrPxT<L> cr_unpack(uint32_t hdr, float integ, float dt, float bdt, float lastf, float T) {
+    CrPxT<L> s;
+    s.S = integ;
+    s.dt0 = dt;
+    s.bdt0 = bdt;
+    s.thr0 = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
+    s.base = hdr & 0xffu;
+    const bool has = hdr_m(hdr) != 0u, popped = (hdr & kHdrPopped) != 0u;
+    s.has = L::from(has);
+    s.popped = L::from(popped);
+    s.lastf = lastf;
+    // r1 from the root alone: it has run n = delta_t / T frames and last fired at ceil(2^(d-1) / I)
+    s.r1 = 0u;
+    if (has && !popped && s.base != 0u && hdr_m(hdr) > 1u) {
+        const float I = (float)s.base;
+        const float qj = fdiv_small(fmul(0.5f, s.thr0), I);
+        uint32_t j = (uint32_t)qj;
+        j += (float)j < qj ? 1u : 0u;
+        s.r1 = (uint32_t)fdiv(dt, T) - j;
+    }
+    return s;
+}
+template <class L>
+ADDER_HD uint32_t cr_hdr(const CrPxT<L> &s, float T) {
+    const uint32_t m = !L::lane(s.has) ? 0u : (L::lane(s.popped) ? 1u : cr_depth((float)s.base, s.r1, T));
+    return hdr_make(s.base, lean_bd_from_thr(f32_to_bits(s.thr0)), m, L::lane(s.popped));
+}
+
+constexpr uint32_t kCrKept = 4;  // levels whose events the step hands to the emission (deeper ones are worked out again)
+template <class L>
+struct CrPlanT {
+    typename L::Mask flushed;    // pop_best_events ran and the arena held a fired level: events leave
+    typename L::Mask collapsed;  // ... and was popped: root event + D_EMPTY filler (:249-265)
+    typename L::Mask need_pop;   // pop_top_event follows the integrate
+    float old_thr0, old_bdt0;    // the old root's best event (valid iff flushed)
+    uint32_t old_base;           // the flushed run's intensity
+    uint32_t n_lv;               // levels behind the flushed root (0 when collapsed)
+    float lv_bdt[kCrKept], lv_thr[kCrKept];  // levels 1 .. min(n_lv, kCrKept): best delta_t, threshold
+    uint32_t r_rest;             // the run of level kCrKept + 1 (0: there is none)
+    uint32_t count;              // events of this unit this frame
+};
+using CrPlan = CrPlanT<ScalarLanes>;
+
+// integrate_for_px (video.rs:1318-1380) of one unit under the conditions above: flush bookkeeping, the root's integrate
+// (the firing arm of cb_step_b with the node = the root), need_to_pop_top.  `count_levels`: the caller wants plan.count
+// to include the flushed levels (it costs the depth walk; the kernels need it for the ordered compaction).
+template <class L>
+ADDER_HD void cr_step(CrPxT<L> &s, uint32_t v, float T, const StepConsts &sc, CrPlanT<L> &p) {
+    using M = typename L::Mask;
+    const float I = (float)v;
+    const M flush = L::from(v != s.base);  // c_thresh == 0
+    p.flushed = L::and_(flush, s.has);
+    p.collapsed = L::and_(p.flushed, s.popped);
+    p.old_thr0 = s.thr0;
+    p.old_bdt0 = s.bdt0;
+    p.old_base = s.base;
+    p.n_lv = 0u;
+    p.r_rest = 0u;
+    p.count = 0u;
+    if (L::lane(p.flushed)) {
+        if (L::lane(p.collapsed)) {
+            p.count = 2u;
+        } else {  // the levels behind the root, worked out once: their number places the unit's events, the emission takes them
+            const float Io = (float)s.base;
+            uint32_t r = s.r1;
+            for (uint32_t k = 0; k < kCrKept; ++k) {  // (unrolled: the kept levels stay in registers)
+                if (r != 0u) {
+                    const CrNode n = cr_node(Io, r, T);
+                    p.lv_bdt[k] = n.bdt;
+                    p.lv_thr[k] = n.thr;
+                    r -= n.j;
+                    p.n_lv += 1u;
+                }
+            }
+            p.r_rest = r;
+            for (; r != 0u; p.n_lv += 1u) r -= cr_node(Io, r, T).j;  // deeper than kCrKept: rare (delta_t_max beyond ~30 frames)
+            p.count = 1u + p.n_lv;
+        }
+    }
+    const M has0 = L::andnot(s.has, flush);
+    const M popped = L::andnot(s.popped, flush);
+    s.base = L::lane(flush) ? v : s.base;
+    const float S_old = L::lane(has0) ? s.S : 0.0f;
+    const float dt_old = L::lane(has0) ? s.dt0 : 0.0f;
+    const float S_new = fadd(S_old, I);
+    const M fires = L::or_(L::not_(has0), L::from(S_new >= s.thr0));  // (the pristine tail at index 0 always fires)
+    // the firing arm (:427-473) on the root
+    const M zero = L::from(S_new == 0.0f);
+    const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);
+    const M d128 = L::or_(L::andnot(L::from(I < 1.0f), has0), L::and_(has0, L::from(s.thr0 == 0.0f)));
+    const float q = fdiv_small(fsub(p2, S_old), I);
+    const float prop = L::lane(L::or_(zero, d128)) ? 1.0f : q;
+    const float bdt = fadd(dt_old, fmul(T, prop));
+    s.S = S_new;
+    s.dt0 = L::lane(L::and_(fires, zero)) ? dt_old : fadd(dt_old, T);
+    s.bdt0 = L::lane(fires) ? bdt : s.bdt0;
+    s.thr0 = L::lane(fires) ? fadd(p2, p2) : s.thr0;
+    // level 1: reborn as the pristine tail when the root fires; visited (it, or a deeper node, fires or accumulates)
+    // otherwise -- unless the arena is popped, where only the root is visited (:360-362) and no level is kept
+    s.r1 = L::lane(L::or_(fires, popped)) ? 0u : s.r1 + 1u;
+    s.has = L::from(true);
+    s.popped = popped;
+    p.need_pop = L::andnot(L::from(s.dt0 >= sc.dtm_f), popped);  // :394-396
+    p.count += L::lane(p.need_pop) ? 1u : 0u;
+}
+
+// The unit's events of this frame, in emission order (after cr_step, before cr_pop): emit.ev(threshold bits, t) /
+// emit.filler(t) as for cb_emit.
+template <bool ABS_T, class L, class Emit>
+ADDER_HD void cr_emit(CrPxT<L> &s, const CrPlanT<L> &p, float T, const StepConsts &sc, Emit &emit) {
+    if (L::lane(p.flushed)) {
+        if (L::lane(p.collapsed)) {
+            emit.ev(f32_to_bits(p.old_thr0), f32_as_u32(ABS_T ? fadd(p.old_bdt0, s.lastf) : p.old_bdt0));
+            s.lastf = sc.running_t;  // :257
+            emit.filler(sc.running_t_u32);
+        } else {
+            emit.ev(f32_to_bits(p.old_thr0), event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
+            // levels 1, 2, ..: the root states of runs of r1, r2, .. frames (each step narrows the active lanes)
+            if (p.n_lv > 0u) {
+                emit.ev(f32_to_bits(p.lv_thr[0]), event_time<ABS_T>(p.lv_bdt[0], s.lastf, sc));
+                if (p.n_lv > 1u) {
+                    emit.ev(f32_to_bits(p.lv_thr[1]), event_time<ABS_T>(p.lv_bdt[1], s.lastf, sc));
+                    if (p.n_lv > 2u) {
+                        emit.ev(f32_to_bits(p.lv_thr[2]), event_time<ABS_T>(p.lv_bdt[2], s.lastf, sc));
+                        if (p.n_lv > 3u) {
+                            emit.ev(f32_to_bits(p.lv_thr[3]), event_time<ABS_T>(p.lv_bdt[3], s.lastf, sc));
+                            const float Io = (float)p.old_base;
+                            for (uint32_t r = p.r_rest; r != 0u;) {
+                                const CrNode n = cr_node(Io, r, T);
+                                emit.ev(f32_to_bits(n.thr), event_time<ABS_T>(n.bdt, s.lastf, sc));
+                                r -= n.j;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (L::lane(p.need_pop)) emit.ev(f32_to_bits(s.thr0), event_time<ABS_T>(s.bdt0, s.lastf, sc));
+}
+
+// pop_top_event's arena shift (:199-207): level 1, if there is one, becomes the root; deeper levels are dropped.
+template <class L>
+ADDER_HD void cr_pop(CrPxT<L> &s, const CrPlanT<L> &p, float T) {
+    // (masks are wave-wide under WaveLanes: they are combined outside of any per-lane branch)
+    const typename L::Mask promote = L::and_(p.need_pop, L::from(s.r1 != 0u));
+    if (L::lane(promote)) {
+        const float I = (float)s.base;
+        const CrNode n = cr_node(I, s.r1, T);
+        s.S = fmul((float)s.r1, I);
+        s.dt0 = fmul((float)s.r1, T);
+        s.bdt0 = n.bdt;
+        s.thr0 = n.thr;
+    }
+    s.has = L::andnot(s.has, L::andnot(p.need_pop, promote));  // a root popped off an arena without levels leaves the tail
+    s.r1 = L::lane(p.need_pop) ? 0u : s.r1;
+    s.popped = L::or_(s.popped, p.need_pop);
+}
+
+// ---- the same, arranged for a wave that emits COOPERATIVELY (adder_cr_kernel's dense path) ----
+// Per-lane emission walks nested, mostly idle regions: a sixth of the units flush in a busy frame, each 1-5 events.  The
+// dense path splits the work differently: the step only COUNTS (a table gives the levels behind a root), every unit with
+// events leaves a task {run, old root, new root}, and then one lane per EVENT works its event out from its unit's task
+// -- cr_event(task, k) below, the same closed forms.  kCrTabRows runs per intensity are tabulated: byte (I, r) =
+// levels of a node chain starting at run r << 5 | the last firing j of a node of run r (delta_t_max <= 32 frames: the
+// reference's default is 30; longer ones take the per-lane path).
+constexpr uint32_t kCrTabRows = 32;
+ADDER_HD void cr_build_tab(uint8_t *tab, float T) {  // tab[256 * kCrTabRows]
+    for (uint32_t I = 0; I < 256u; ++I) {
+        tab[I * kCrTabRows] = 0u;
+        for (uint32_t r = 1; r < kCrTabRows; ++r) {
+            if (I == 0u) {
+                tab[I * kCrTabRows + r] = 0u;
+                continue;
+            }
+            const uint32_t j = cr_node((float)I, r, T).j;
+            const uint32_t n = 1u + (tab[I * kCrTabRows + (r - j)] >> 5);
+            tab[I * kCrTabRows + r] = (uint8_t)(((n < 7u ? n : 7u) << 5) | (j & 31u));
+        }
+    }
+}
+
+struct CrTask {
+    uint32_t w0;  // old base_val | old r1 << 8 | flushed << 16 | collapsed << 17 | need_pop << 18 | events << 24
+    float thr_old, bdt_old;  // the flushed root's best event
+    float thr_new, bdt_new;  // the root after the integrate (pop_top's event)
+};
+constexpr uint32_t kCrTaskFlushed = 1u << 16, kCrTaskCollapsed = 1u << 17, kCrTaskPop = 1u << 18;
+
+// cr_step without the level events: plan.count from the table (tab(I, r) -> the byte), the task for the emission.
+template <class L, class Tab>
+ADDER_HD void cr_step_counted(CrPxT<L> &s, uint32_t v, float T, const StepConsts &sc, const Tab &tab, CrTask &t,
+                              uint32_t &count) {
+    using M = typename L::Mask;
+    const float I = (float)v;
+    const M flush = L::from(v != s.base);  // c_thresh == 0
+    const M flushed = L::and_(flush, s.has);
+    const M collapsed = L::and_(flushed, s.popped);
+    t.thr_old = s.thr0;
+    t.bdt_old = s.bdt0;
+    uint32_t w0 = s.base | (s.r1 << 8);
+    count = 0u;
+    if (L::lane(flushed)) count = L::lane(collapsed) ? 2u : 1u + (s.r1 != 0u ? (uint32_t)(tab(s.base, s.r1) >> 5) : 0u);
+    const M has0 = L::andnot(s.has, flush);
+    const M popped = L::andnot(s.popped, flush);
+    s.base = L::lane(flush) ? v : s.base;
+    const float S_old = L::lane(has0) ? s.S : 0.0f;
+    const float dt_old = L::lane(has0) ? s.dt0 : 0.0f;
+    const float S_new = fadd(S_old, I);
+    const M fires = L::or_(L::not_(has0), L::from(S_new >= s.thr0));
+    const M zero = L::from(S_new == 0.0f);
+    const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);
+    const M d128 = L::or_(L::andnot(L::from(I < 1.0f), has0), L::and_(has0, L::from(s.thr0 == 0.0f)));
+    const float q = fdiv_small(fsub(p2, S_old), I);
+    const float prop = L::lane(L::or_(zero, d128)) ? 1.0f : q;
+    const float bdt = fadd(dt_old, fmul(T, prop));
+    s.S = S_new;
+    s.dt0 = L::lane(L::and_(fires, zero)) ? dt_old : fadd(dt_old, T);
+    s.bdt0 = L::lane(fires) ? bdt : s.bdt0;
+    s.thr0 = L::lane(fires) ? fadd(p2, p2) : s.thr0;
+    s.r1 = L::lane(L::or_(fires, popped)) ? 0u : s.r1 + 1u;
+    s.has = L::from(true);
+    s.popped = popped;
+    const M need_pop = L::andnot(L::from(s.dt0 >= sc.dtm_f), popped);
+    count += L::lane(need_pop) ? 1u : 0u;
+    w0 |= (L::lane(flushed) ? kCrTaskFlushed : 0u) | (L::lane(collapsed) ? kCrTaskCollapsed : 0u) |
+          (L::lane(need_pop) ? kCrTaskPop : 0u) | (count << 24);
+    t.w0 = w0;
+    t.thr_new = s.thr0;
+    t.bdt_new = s.bdt0;
+    // pop_top's arena shift (cr_pop), masks outside of any per-lane branch
+    const M promote = L::and_(need_pop, L::from(s.r1 != 0u));
+    if (L::lane(promote)) {
+        const float Ib = (float)s.base;
+        const CrNode n = cr_node(Ib, s.r1, T);
+        s.S = fmul((float)s.r1, Ib);
+        s.dt0 = fmul((float)s.r1, T);
+        s.bdt0 = n.bdt;
+        s.thr0 = n.thr;
+    }
+    s.has = L::andnot(s.has, L::andnot(need_pop, promote));
+    s.r1 = L::lane(need_pop) ? 0u : s.r1;
+    s.popped = L::or_(s.popped, need_pop);
+}
+
+// Event k (0-based, emission order) of a unit's task: the threshold whose exponent carries d, the event's delta_t, and
+// how its time is made -- 0: delta_t_to_absolute_t (:113-137); 1: the collapsed root event, after which last_fired_t is
+// running_t whatever it was (:257); 2: the D_EMPTY filler, t = running_t (:259-263).
+struct CrEvent {
+    uint32_t thr_bits;
+    float bdt;
+    uint32_t kind;
+};
+template <class Tab>
+ADDER_HD CrEvent cr_event(const CrTask &t, uint32_t k, float T, const Tab &tab) {
+    const uint32_t n_flush = (t.w0 >> 24) - ((t.w0 & kCrTaskPop) ? 1u : 0u);
+    CrEvent e;
+    e.kind = 0u;
+    if (k >= n_flush) {  // pop_top's event: the integrated root
+        e.thr_bits = f32_to_bits(t.thr_new);
+        e.bdt = t.bdt_new;
+        return e;
+    }
+    if (k == 0u) {
+        e.thr_bits = f32_to_bits(t.thr_old);
+        e.bdt = t.bdt_old;
+        e.kind = (t.w0 & kCrTaskCollapsed) ? 1u : 0u;
+        return e;
+    }
+    if (t.w0 & kCrTaskCollapsed) {
+        e.thr_bits = 0u;
+        e.bdt = 0.0f;
+        e.kind = 2u;
+        return e;
+    }
+    const uint32_t Iu = t.w0 & 0xffu;
+    uint32_t r = (t.w0 >> 8) & 0xffu;
+    for (uint32_t q = 1; q < k; ++q) r -= (uint32_t)(tab(Iu, r) & 31u);  // level k has run r_k = r_{k-1} - its parent's last firing
+    const CrNode n = cr_node((float)Iu, r, T);
+    e.thr_bits = f32_to_bits(n.thr);
+    e.bdt = n.bdt;
+    return e;
+}
+template <bool ABS_T>
+ADDER_HD uint32_t cr_event_time(const CrEvent &e, float &lastf, const StepConsts &sc) {
+    if (e.kind == 2u) return sc.running_t_u32;
+    if (e.kind == 1u) {
+        const uint32_t t = f32_as_u32(ABS_T ? fadd(e.bdt, lastf) : e.bdt);
+        lastf = sc.running_t;
+        return t;
+    }
+    return event_time<ABS_T>(e.bdt, lastf, sc);
+}
+
+// The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
+// the planes the other steps read: store(k, Node).  Returns m.
+template <class L, class Store>
+ADDER_HD uint32_t cr_materialize(const CrPxT<L> &s, float T, Store &store) {
+    if (!L::lane(s.has)) return 0u;
+    uint32_t m = 1u;
+    if (L::lane(s.popped)) return m;
+    const float I = (float)s.base;
+    for (uint32_t r = s.r1; r != 0u; ++m) {
+        const CrNode n = cr_node(I, r, T);
+        Node nd;
+        nd.integ = fmul((float)r, I);
+        nd.dt = fmul((float)r, T);
+        nd.bdt = n.bdt;
+        nd.bd = lean_bd_from_thr(f32_to_bits(n.thr));
+        store(m, nd);
+        r -= n.j;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------
 // GENERAL ARENA STEP -- Mode::Continuous (the mode of the event-camera sources,
 // prophesee.rs:65, davis.rs:116-117, and of Video::integrate_matrix when they feed it frames).
 // There a firing node hands the REST of the intensity and time to its child, which keeps integrating it

@@ -370,6 +370,117 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
+// One temporally blocked launch of the CONSTANT-RUN step (cr_step / cr_emit / cr_pop / cr_materialize), as
+// adder_cr_kernel runs it: only the roots are loaded and stepped, the levels are written back in their resident form at
+// the end.  The caller vouches for the regime (c_thresh 0 in every frame since the reset, one integer time_spanned):
+// -7 if this launch is not in it.
+static int g_cr_dense = 0;  // 1: the cooperative arrangement (cr_step_counted + cr_event per event) instead of cr_step / cr_emit
+void sim_set_cr_dense(int on) { g_cr_dense = on; }
+int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!sim_cb_possible(s, T) || s->c_thresh != 0 || s->c_max != 0) return -7;
+    std::vector<uint8_t> tabv;
+    if (g_cr_dense) {
+        if (!((double)s->dtm <= (double)T * (kCrTabRows - 1u))) return -7;  // the table's runs
+        tabv.resize(256u * kCrTabRows);
+        cr_build_tab(tabv.data(), T);
+    }
+    const uint8_t *const tabp = tabv.data();
+    auto tab = [tabp](uint32_t I, uint32_t r) -> uint32_t { return tabp[I * kCrTabRows + r]; };
+    s->generic_sticky = 1;
+    StepConsts sc;
+    sc.time_spanned = T;
+    sc.dtm_f = (float)s->dtm;
+    sc.ref_time = s->ref_time;
+    sc.collapse = 1;
+    sc.abs_t = s->abs_t;
+    sc.max_depth = s->max_depth;
+    sc.cth = 0;
+    sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
+    std::vector<float> rts(nb);
+    {
+        float rt = s->running_t;
+        for (uint32_t i = 0; i < nb; ++i) {
+            rts[i] = rt;
+            rt += T;
+        }
+        s->running_t = rt;
+    }
+    std::vector<std::vector<SimEvent>> per_frame(nb);
+    int rc = 0;
+    size_t u = 0;
+    for (uint32_t y = 0; y < s->H; y++)
+        for (uint32_t x = 0; x < s->W; x++)
+            for (uint32_t c = 0; c < s->C; c++, u++) {
+                const uint32_t hdr = s->hdr[u];
+                const uint32_t m0 = hdr_m(hdr);
+                CrPx p = cr_unpack<ScalarLanes>(hdr, m0 ? s->integ0[u] : -12345.0f, m0 ? s->dt0[u] : -777.0f,
+                                                m0 ? s->bdt0[u] : -999.0f, s->abs_t ? s->lastf[u] : -1.0f, T);
+                for (uint32_t i = 0; i < nb; ++i) {
+                    sc.running_t = rts[i];
+                    sc.running_t_u32 = f32_as_u32(rts[i]);
+                    struct VecEmit {
+                        std::vector<SimEvent> *v;
+                        uint16_t x, y;
+                        uint8_t c;
+                        uint32_t n;
+                        void put(uint32_t d, uint32_t t) {
+                            SimEvent e;
+                            e.x = x; e.y = y; e.c = c; e.d = (uint8_t)d; e.pad = 0; e.t = t;
+                            v->push_back(e);
+                            ++n;
+                        }
+                        void ev(uint32_t thr_bits, uint32_t t) { put(cb_d_from_code(thr_bits >> 23), t); }
+                        void filler(uint32_t t) { put(cb_d_from_code(kCbCodeEmpty), t); }
+                    } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
+                    if (g_cr_dense) {
+                        CrTask task;
+                        uint32_t count;
+                        cr_step_counted(p, frames[(size_t)i * s->N + u], T, sc, tab, task, count);
+                        for (uint32_t k = 0; k < count; ++k) {  // one "lane" per event
+                            const CrEvent e = cr_event(task, k, T, tab);
+                            const uint32_t t = s->abs_t ? cr_event_time<true>(e, p.lastf, sc) : cr_event_time<false>(e, p.lastf, sc);
+                            if (e.kind == 2u) em.filler(t);
+                            else em.ev(e.thr_bits, t);
+                        }
+                        s->cb_steps++;
+                        continue;
+                    }
+                    CrPlan plan;
+                    cr_step(p, frames[(size_t)i * s->N + u], T, sc, plan);
+                    if (s->abs_t) cr_emit<true>(p, plan, T, sc, em); else cr_emit<false>(p, plan, T, sc, em);
+                    if (em.n != plan.count) s->plan_mismatch++;
+                    cr_pop(p, plan, T);
+                    s->cb_steps++;
+                }
+                DeepAcc deep{s, u};
+                struct Store {
+                    DeepAcc *d;
+                    uint32_t max_depth;
+                    int *rc;
+                    void operator()(uint32_t k, const Node &n) {
+                        if (k < max_depth) d->store(k, n);
+                        else *rc = -5;
+                    }
+                } st{&deep, s->max_depth, &rc};
+                const uint32_t m = cr_materialize(p, T, st);
+                if (m > s->max_m) s->max_m = m;
+                s->hdr[u] = cr_hdr(p, T);
+                if (m > 0) { s->integ0[u] = p.S; s->dt0[u] = p.dt0; s->bdt0[u] = p.bdt0; }
+                if (s->abs_t) s->lastf[u] = p.lastf;
+                if (m != 0u)
+                    s->running[u] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(p.thr0)), f32_as_u32(p.bdt0), (double)s->ref_time);
+            }
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i)
+        for (const SimEvent &e : per_frame[i]) {
+            if (pos < cap) out[pos] = e;
+            ++pos;
+        }
+    *n_out = pos;
+    if (pos > cap && rc == 0) rc = -4;
+    return rc;
+}
+
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
     StepConsts sc;

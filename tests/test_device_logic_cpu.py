@@ -446,3 +446,100 @@ def test_cb_other_tick_rates_and_quality_change():
     # a fractional time_spanned is not exact in prefix coordinates: the bounded step must refuse it
     sv = Sim(6, 4, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=7650)
     assert sv.integrate_cb_block(clip[:2], 254.5)[0] == -7
+
+
+# ---- the constant-run step (cr_step / cr_emit / cr_pop / cr_materialize: the bounded regime at c_thresh 0) ----
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_cr_blocked_launches_match_the_oracle(time_mode, dense):
+    """crf 0 (c_thresh_baseline = c_thresh_max = 0): every change of value flushes, a run integrates ONE intensity, and
+    the arena is a function of (intensity, frames since the flush).  cr_* keep only the root and work the levels out when
+    a flush or pop_top wants them; between launches the levels go back to the planes in their resident form.  Launches
+    of every length against the oracle, on every kind of content, black runs and runs past the pop included."""
+    rng = np.random.default_rng(41 + time_mode)
+    for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
+        frames = 170
+        clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, 7, 12, 1, seed=3 + len(kind)))
+        ov, sv = _cb_pair(12, 7, 1, time_mode, 7650, crf=CRFS[0])
+        k, total = 0, 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 2, 3, 7, 29, 30, 31, 64])), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=dense)
+            assert rc == 0, (kind, k, rc)
+            assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
+            total += len(got)
+            k += nb
+        assert sv.plan_mismatches == 0 and total > 0
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_cr_every_intensity_and_run_length(dense):
+    """The closed forms (last firing = ceil(2^e / I), level k+1's run = level k's run minus its last firing) against the
+    stepped oracle for EVERY intensity 0..255 and every run length 1..45 (delta_t_max = 30 and 40 frames: the pop falls
+    inside), flushed by a value change: a 256-pixel row per run length, both time modes, rgb interleaving too."""
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        for dtm_frames in ((30, 31, 3) if dense else (30, 40, 3)):
+            ov, sv = _cb_pair(256, 1, 1, tm, 255 * dtm_frames, crf=CRFS[0], max_depth=12)
+            frames = []
+            for run in range(1, 46):
+                frames += [np.arange(256, dtype=np.uint8).reshape(1, 256, 1)] * run
+                frames += [((np.arange(256) + 1 + run) % 256).astype(np.uint8).reshape(1, 256, 1)]  # the flush (a 1-frame run)
+            clip = np.stack(frames)
+            k = 0
+            while k < len(clip):
+                nb = min(37, len(clip) - k)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=dense)
+                assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (tm, dtm_frames, k)
+                k += nb
+            assert sv.plan_mismatches == 0
+
+
+def test_cr_cb_and_generic_steps_are_interchangeable_mid_stream():
+    """The constant-run step reads only the roots and writes the levels back in their resident form: a launch of any of
+    the three steps may follow a launch of any other (at crf 0) without a single event changing."""
+    clip = clips.make_clip("runs", 260, 6, 8, 3, seed=78)
+    rng = np.random.default_rng(8)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _cb_pair(8, 6, 3, tm, 7650, crf=CRFS[0])
+        k = 0
+        used = set()
+        while k < len(clip):
+            which = int(rng.integers(0, 3))
+            nb = min(int(rng.choice([1, 2, 5, 17, 33])), len(clip) - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            if which == 0:
+                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=bool(k & 1))
+            elif which == 1:
+                rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            else:
+                sv.set_use_cb(False)
+                parts = [sv.integrate(clip[k + i], 255.0) for i in range(nb)]
+                sv.set_use_cb(True)
+                rc, got = max(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+            used.add(which)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (tm, k, nb, which)
+            k += nb
+        assert used == {0, 1, 2}
+
+
+def test_cr_other_tick_rates_and_its_limits():
+    clip = clips.make_clip("runs", 200, 4, 6, 1, seed=32)
+    for ref_time, dtm in ((5000, 240000), (1000, 2000), (20, 10000), (255, 6120), (255, 255 * 200)):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            ov, sv = _cb_pair(6, 4, 1, tm, dtm, ref_time=ref_time, crf=CRFS[0], max_depth=14)
+            for k in range(0, 200, 25):
+                want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=float(ref_time)) for i in range(25)])
+                rc, got = sv.integrate_cr_block(clip[k:k + 25], float(ref_time))
+                assert rc == 0 and np.array_equal(want, got), (ref_time, dtm, k)
+    # outside the regime: c_thresh > 0, a fractional time_spanned
+    sv = Sim(6, 4, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=7650)
+    sv.set_crf_parameters(7, 7)
+    sv.reset_c_thresh(2)
+    assert sv.integrate_cr_block(clip[:2], 255.0)[0] == -7
+    sv = Sim(6, 4, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=7650)
+    sv.set_crf_parameters(0, 10)
+    sv.reset_c_thresh(0)
+    assert sv.integrate_cr_block(clip[:2], 254.5)[0] == -7
