@@ -110,8 +110,6 @@ struct AdderHipCtx {
     // time_spanned, so every arena is a function of (its run's intensity, the run's length) -- adder_pixel.hpp
     bool cr_valid = true;
     float cr_time = 0.0f;
-    uint8_t *d_cr_tab = nullptr;   // the run table of cr_time_tab (adder_pixel.hpp cr_build_tab), 256 x kCrTabRows bytes
-    float cr_tab_time = 0.0f;
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
@@ -323,7 +321,6 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_side_words) (void)hipFree(c->d_side_words);
-    if (c->d_cr_tab) (void)hipFree(c->d_cr_tab);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
     for (hipEvent_t e : c->band_desc_e)
@@ -1403,15 +1400,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         c->cr_valid = false;
     c->cr_time = time_spanned;
     static const bool cr_off = [] { const char *e = getenv("ADDER_HIP_NO_CR"); return e && atoi(e) != 0; }();
-    // ... then only the roots are stepped (adder_cr_kernel; its run table covers delta_t_max up to kCrTabRows - 1 frames)
-    const bool cr = cb && c->cr_valid && !cr_off && (double)c->p.delta_t_max <= (double)time_spanned * (kCrTabRows - 1u);
-    if (cr && (!c->d_cr_tab || c->cr_tab_time != time_spanned)) {
-        if (!c->d_cr_tab) HIPCHK(c, dalloc(&c->d_cr_tab, 256u * kCrTabRows));
-        std::vector<uint8_t> tab(256u * kCrTabRows);
-        cr_build_tab(tab.data(), time_spanned);
-        HIPCHK(c, hipMemcpy(c->d_cr_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));  // (once per time step: blocking)
-        c->cr_tab_time = time_spanned;
-    }
+    const bool cr = cb && c->cr_valid && !cr_off;  // ... then only the roots are stepped (adder_cr_kernel)
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
@@ -1496,7 +1485,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     }
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
-    b.cr_tab = c->d_cr_tab;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (b.log_cap) {

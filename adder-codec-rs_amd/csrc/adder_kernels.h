@@ -162,9 +162,6 @@ struct BatchArgs {
     // diagnostics (null in normal operation): first start / last end of every kernel of the batch on the 100 MHz
     // constant clock, [kernel kind 0 frame, 1 scan, 2 offsets, 3 expansion][chunk][2]  (tools/timeline_probe.py)
     unsigned long long *timeline;
-    // constant runs, the dense path (adder_cr_kernel): byte (I, r) = levels of a node chain of run r << 5 | last firing
-    // (adder_pixel.hpp cr_build_tab), 256 x kCrTabRows bytes; null: delta_t_max beyond the table's runs (per-lane path)
-    const uint8_t *cr_tab;
 };
 constexpr uint32_t kTimelineChunks = 64;
 constexpr uint32_t kMaxBands = 16;  // bands one adder_expand_bands_kernel launch takes (more: one launch per band)

@@ -1431,38 +1431,15 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_
 // expansion are the bounded Collapse kernel's (EmitCb / SegLog / expansion format 0 with the 9-bit d code).
 // ------------------------------------------------------------------------------------------
 #ifndef ADDER_CR_WAVES_PER_SIMD
-#define ADDER_CR_WAVES_PER_SIMD 4
+#define ADDER_CR_WAVES_PER_SIMD 5
 #endif
 #ifndef ADDER_CR_WAVE_LANES
 #define ADDER_CR_WAVE_LANES 1
 #endif
-#ifndef ADDER_CR_DENSE
-#define ADDER_CR_DENSE 1
-#endif
-// Cooperative emission: a busy frame has a sixth of the units flush, 1-5 events each -- per-lane emission walks nested,
-// mostly idle regions.  Instead every lane WITH events leaves a task in the wave's LDS slice, and one lane per EVENT
-// finds its unit (a marker per owner at its first event + a max-scan), reads the task and works its event out
-// (cr_event, adder_pixel.hpp); in AbsoluteT the events' times chain through last_fired_t per unit, so the owners walk
-// their few events once more over the staged delta_ts.  Up to kCrEvCap events per segment and frame; beyond (not seen
-// outside adversarial input: two events per unit on average) the per-lane loop takes the frame.
-constexpr uint32_t kCrEvCap = 256;
-constexpr uint32_t kCrTaskDwords = 13;  // (odd: the owners' slots fall on different banks)
-struct __attribute__((aligned(16))) CrWaveLds {
-    uint32_t task[kWave * kCrTaskDwords];  // [0..1] w0 of the lane's two units, [2..5] / [6..9] their roots, [10] first event, [11..12] last_fired_t
-    uint2 ev[kCrEvCap];                    // AbsoluteT: {delta_t bits -> t, code | unit << 9 | kind << 16}
-    uint32_t owner[kCrEvCap / 4];          // byte e: owner lane + 1 at the first event of a lane, else 0
-    uint8_t in[kCbInFrames * kWaveUnits];  // [frame of the group][unit]
-};
-struct CrTabLds {
-    const ADDER_LDS uint8_t *p;
-    __device__ __forceinline__ uint32_t operator()(uint32_t I, uint32_t r) const { return p[I * kCrTabRows + r]; }
-};
 template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void cr_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                               uint32_t u0, uint32_t gw, uint32_t lane, CrWaveLds &w,
-                                               const ADDER_LDS uint8_t *tab_lds) {
+                                               uint32_t u0, uint32_t gw, uint32_t lane, uint8_t *lds_in) {
     constexpr uint32_t N = kUnitsPerLane;
-    static_assert(N == 2u, "the task record holds two units per lane");
 #if ADDER_CR_WAVE_LANES
     using L = WaveLanes;
 #else
@@ -1470,7 +1447,6 @@ __device__ __forceinline__ void cr_run_segment(const BatchArgs *__restrict__ b, 
 #endif
     StepConsts sc = a.sc;
     const float T = sc.time_spanned;
-    const CrTabLds tab{tab_lds};
     CrPxT<L> px[N];
     uint32_t snap_m[N];
     {
@@ -1501,144 +1477,70 @@ __device__ __forceinline__ void cr_run_segment(const BatchArgs *__restrict__ b, 
     if (lane < nb) tab_rt = gload<uint2>(uniform_ptr(b->ftab), (f0 + lane) * (uint32_t)sizeof(FrameTab)).x;
     SegLog log;
     log.open(b, f0, sgw, num_waves_u);
-    const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-    const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
-                        __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+    // the launch's input bytes, all of them, into the wave's LDS slice (lean_frames has the reasons)
     using InT = typename VecOf<uint8_t, N>::type;
-    const InT *const in_lds = reinterpret_cast<const InT *>(w.in) + lane;
-    ADDER_LDS uint32_t *const task = (ADDER_LDS uint32_t *)w.task;
-    ADDER_LDS uint32_t *const evs = (ADDER_LDS uint32_t *)w.ev;  // [event]{delta_t bits -> t, code | unit << 9 | kind << 16}
-    ADDER_LDS uint8_t *const owner = (ADDER_LDS uint8_t *)w.owner;
-    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // everything loaded so far has landed before the loop (adder_cb_kernel has the reason)
-    for (uint32_t i = 0; i < nb; ++i) {
-        if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
-        const uint32_t vin_w = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
-        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
-        sc.running_t_u32 = f32_as_u32(sc.running_t);
-        // ---------------- the step of every unit: the roots, the counts, the tasks ----------------
-        CrTask tk[N];
-        uint32_t cnt[N];
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame][lane]
+    {
+        constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
+        const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+        static_assert(kWaveUnits == 128u && NB_MAX % 8u == 0u, "eight frames of one segment per instruction");
+        const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
+                            __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+        if (direct) {
+            const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
 #pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            cr_step_counted<L>(px[j], (vin_w >> (8 * j)) & 0xffu, T, sc, tab, tk[j], cnt[j]);
-            if (!FULL && !(u0 + j < n_units_u)) {  // padding units: stepped freely, no events
-                cnt[j] = 0u;
-                tk[j].w0 &= 0x00ffffffu;
+            for (uint32_t g = 0; g < NB_MAX / 8u; ++g) {
+                uint32_t k = g * 8u + (lane >> 3);
+                k = k < nb ? k : nb - 1u;
+                __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
+                                                 (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                                 ADDER_NT_INPUT ? 2 : 0);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < NB_MAX; k0 += 8u) {
+                uint32_t vin8[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) {
+                    const uint32_t k = k0 + q;
+                    const uint32_t kk = k < nb ? k : nb - 1u;
+                    vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(k0 + q) * kWave] = (InT)vin8[q];
             }
         }
-        const uint32_t lane_cnt = cnt[0] + cnt[1];
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing inside the frame loop waits on memory
+    }
+    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t vin_w = (uint32_t)in_lds[i * kWave];
+        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
+        sc.running_t_u32 = f32_as_u32(sc.running_t);
+        CrPlanT<L> plan[N];
+        uint32_t lane_cnt = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            cr_step<L>(px[j], (vin_w >> (8 * j)) & 0xffu, T, sc, plan[j]);
+            if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;  // padding units: stepped freely, no events
+            lane_cnt += plan[j].count;
+        }
         const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t run_start;
         uint2 *const seg = log.append(total, run_start, a.status);  // uniform
         wt = lane == i ? (total | (total << 16)) : wt;
         wo = lane == i ? run_start : wo;
-        const uint32_t excl = incl - lane_cnt;
-        if (total == 0u || !seg) continue;  // (uniform)
-        if (ADDER_CR_DENSE && total <= kCrEvCap) {
-            // ---- owners: a marker at the lane's first event, the task beside it ----
-            for (uint32_t q = lane; q * 4u < total; q += kWave) w.owner[q] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane_cnt != 0u) {
-                owner[excl] = (uint8_t)(lane + 1u);
-                ADDER_LDS uint32_t *const t = task + lane * kCrTaskDwords;
-                t[0] = tk[0].w0;
-                t[1] = tk[1].w0;
-                t[2] = f32_to_bits(tk[0].thr_old);
-                t[3] = f32_to_bits(tk[0].bdt_old);
-                t[4] = f32_to_bits(tk[0].thr_new);
-                t[5] = f32_to_bits(tk[0].bdt_new);
-                t[6] = f32_to_bits(tk[1].thr_old);
-                t[7] = f32_to_bits(tk[1].bdt_old);
-                t[8] = f32_to_bits(tk[1].thr_new);
-                t[9] = f32_to_bits(tk[1].bdt_new);
-                t[10] = excl;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- one lane per event ----
-            uint32_t carry = 0u;
-            for (uint32_t e0 = 0; e0 < total; e0 += kWave) {  // uniform
-                const uint32_t e = e0 + lane;
-                const bool valid = e < total;
-                uint32_t o = valid ? (uint32_t)owner[e] : 0u;
-                // inclusive max-scan: the owner of an event is the last marker at or before it
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x111, 0xf, 0xf, true));
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x112, 0xf, 0xf, true));
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x114, 0xf, 0xf, true));
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x118, 0xf, 0xf, true));
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x142, 0xa, 0xf, true));
-                o = max(o, (uint32_t)__builtin_amdgcn_update_dpp(0u, o, 0x143, 0xc, 0xf, true));
-                o = max(o, carry);
-                carry = __builtin_amdgcn_readlane(o, kWave - 1);
-                const uint32_t ol = (o != 0u ? o : 1u) - 1u;  // (lanes past `total` read lane 0's slot and store nothing)
-                const ADDER_LDS uint32_t *const t = task + ol * kCrTaskDwords;
-                const uint32_t w0a = t[0], w0b = t[1], first = t[10];
-                const uint32_t kl = e - first, c0 = w0a >> 24;
-                const bool second = kl >= c0;
-                const uint32_t k = second ? kl - c0 : kl;
-                CrTask me;
-                me.w0 = second ? w0b : w0a;
-                const uint32_t base4 = second ? 6u : 2u;
-                me.thr_old = bits_to_f32(t[base4]);
-                me.bdt_old = bits_to_f32(t[base4 + 1u]);
-                me.thr_new = bits_to_f32(t[base4 + 2u]);
-                me.bdt_new = bits_to_f32(t[base4 + 3u]);
-                const CrEvent ev = cr_event(me, valid ? k : 0u, T, tab);
-                const uint32_t unit = ol * N + (second ? 1u : 0u);
-                const uint32_t code = ev.kind == 2u ? kCbCodeEmpty : ev.thr_bits >> 23;
-                if (!ABS_T) {
-                    float nolf = 0.0f;
-                    const uint32_t tt = cr_event_time<false>(ev, nolf, sc);
-                    if (valid) gstore<uint2>(seg, e * kGenRecBytes, make_uint2(tt, code | (unit << 9) | (e << 16)));
-                } else if (valid) {
-                    evs[2u * e] = f32_to_bits(ev.bdt);
-                    evs[2u * e + 1u] = code | (unit << 9) | (ev.kind << 16);
-                }
-            }
-            if (ABS_T) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // ---- the owners chain their events' times through last_fired_t (:113-137), unit by unit ----
-                if (lane_cnt != 0u) {
-                    uint32_t pos = excl;
-#pragma unroll
-                    for (uint32_t j = 0; j < N; ++j) {
-                        float lf = px[j].lastf;
-                        for (uint32_t q = 0; q < cnt[j]; ++q, ++pos) {
-                            CrEvent ev;
-                            ev.thr_bits = 0u;
-                            ev.bdt = bits_to_f32(evs[2u * pos]);
-                            ev.kind = evs[2u * pos + 1u] >> 16;
-                            evs[2u * pos] = cr_event_time<true>(ev, lf, sc);
-                        }
-                        px[j].lastf = lf;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t e = lane; e < total; e += kWave) {
-                    gstore<uint2>(seg, e * kGenRecBytes, make_uint2(evs[2u * e], (evs[2u * e + 1u] & 0xffffu) | (e << 16)));
-                }
-            }
-        } else {
-            // ---- per lane, event after event (more than kCrEvCap events in one segment and frame) ----
-            uint32_t off = excl;
+        uint32_t off = incl - lane_cnt;
+        if (total != 0u) {  // (uniform)
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) {
-                EmitCb em{seg, (lane * N + j) | (off << 7), off * kGenRecBytes};
-                for (uint32_t k = 0; k < cnt[j]; ++k) {
-                    const CrEvent ev = cr_event(tk[j], k, T, tab);
-                    const uint32_t tt = cr_event_time<ABS_T>(ev, px[j].lastf, sc);
-                    if (ev.kind == 2u) em.filler(tt);
-                    else em.ev(ev.thr_bits, tt);
+                if (plan[j].count != 0u && seg) {
+                    EmitCb em{seg, (lane * N + j) | (off << 7), off * kGenRecBytes};
+                    cr_emit<ABS_T, L>(px[j], plan[j], T, sc, em);
                 }
-                off += cnt[j];
+                off += plan[j].count;
+                cr_pop<L>(px[j], plan[j], T);
             }
         }
     }
@@ -1694,25 +1596,16 @@ __device__ __forceinline__ void cr_run_segment(const BatchArgs *__restrict__ b, 
 template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_cr_kernel(const BatchArgs *__restrict__ b,
                                                                                          uint32_t f, uint32_t nb) {
-    __shared__ CrWaveLds s_w[kWavesPerBlock];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tab[256u * kCrTabRows];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     timeline_mark(b, 0u, f, false);
-    {   // the run table, once per workgroup (8 KB from L2)
-        const uint4 *const src = reinterpret_cast<const uint4 *>(uniform_ptr(b->cr_tab));
-        uint4 *const dst = reinterpret_cast<uint4 *>(s_tab);
-        static_assert(256u * kCrTabRows == kBlockThreads * 32u, "two 16-byte pieces per thread");
-        dst[tid * 2u] = src[tid * 2u];
-        dst[tid * 2u + 1u] = src[tid * 2u + 1u];
-        __syncthreads();
-    }
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) cr_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_w[tid / kWave], (const ADDER_LDS uint8_t *)s_tab);
-        else cr_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_w[tid / kWave], (const ADDER_LDS uint8_t *)s_tab);
+        if (full) cr_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+        else cr_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
     }
     timeline_mark(b, 0u, f, true);
 }

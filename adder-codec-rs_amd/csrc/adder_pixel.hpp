@@ -1282,141 +1282,6 @@ ADDER_HD void cr_pop(CrPxT<L> &s, const CrPlanT<L> &p, float T) {
     s.popped = L::or_(s.popped, p.need_pop);
 }
 
-// ---- the same, arranged for a wave that emits COOPERATIVELY (adder_cr_kernel's dense path) ----
-// Per-lane emission walks nested, mostly idle regions: a sixth of the units flush in a busy frame, each 1-5 events.  The
-// dense path splits the work differently: the step only COUNTS (a table gives the levels behind a root), every unit with
-// events leaves a task {run, old root, new root}, and then one lane per EVENT works its event out from its unit's task
-// -- cr_event(task, k) below, the same closed forms.  kCrTabRows runs per intensity are tabulated: byte (I, r) =
-// levels of a node chain starting at run r << 5 | the last firing j of a node of run r (delta_t_max <= 32 frames: the
-// reference's default is 30; longer ones take the per-lane path).
-constexpr uint32_t kCrTabRows = 32;
-ADDER_HD void cr_build_tab(uint8_t *tab, float T) {  // tab[256 * kCrTabRows]
-    for (uint32_t I = 0; I < 256u; ++I) {
-        tab[I * kCrTabRows] = 0u;
-        for (uint32_t r = 1; r < kCrTabRows; ++r) {
-            if (I == 0u) {
-                tab[I * kCrTabRows + r] = 0u;
-                continue;
-            }
-            const uint32_t j = cr_node((float)I, r, T).j;
-            const uint32_t n = 1u + (tab[I * kCrTabRows + (r - j)] >> 5);
-            tab[I * kCrTabRows + r] = (uint8_t)(((n < 7u ? n : 7u) << 5) | (j & 31u));
-        }
-    }
-}
-
-struct CrTask {
-    uint32_t w0;  // old base_val | old r1 << 8 | flushed << 16 | collapsed << 17 | need_pop << 18 | events << 24
-    float thr_old, bdt_old;  // the flushed root's best event
-    float thr_new, bdt_new;  // the root after the integrate (pop_top's event)
-};
-constexpr uint32_t kCrTaskFlushed = 1u << 16, kCrTaskCollapsed = 1u << 17, kCrTaskPop = 1u << 18;
-
-// cr_step without the level events: plan.count from the table (tab(I, r) -> the byte), the task for the emission.
-template <class L, class Tab>
-ADDER_HD void cr_step_counted(CrPxT<L> &s, uint32_t v, float T, const StepConsts &sc, const Tab &tab, CrTask &t,
-                              uint32_t &count) {
-    using M = typename L::Mask;
-    const float I = (float)v;
-    const M flush = L::from(v != s.base);  // c_thresh == 0
-    const M flushed = L::and_(flush, s.has);
-    const M collapsed = L::and_(flushed, s.popped);
-    t.thr_old = s.thr0;
-    t.bdt_old = s.bdt0;
-    uint32_t w0 = s.base | (s.r1 << 8);
-    count = 0u;
-    if (L::lane(flushed)) count = L::lane(collapsed) ? 2u : 1u + (s.r1 != 0u ? (uint32_t)(tab(s.base, s.r1) >> 5) : 0u);
-    const M has0 = L::andnot(s.has, flush);
-    const M popped = L::andnot(s.popped, flush);
-    s.base = L::lane(flush) ? v : s.base;
-    const float S_old = L::lane(has0) ? s.S : 0.0f;
-    const float dt_old = L::lane(has0) ? s.dt0 : 0.0f;
-    const float S_new = fadd(S_old, I);
-    const M fires = L::or_(L::not_(has0), L::from(S_new >= s.thr0));
-    const M zero = L::from(S_new == 0.0f);
-    const float p2 = bits_to_f32(f32_to_bits(S_new) & 0x7f800000u);
-    const M d128 = L::or_(L::andnot(L::from(I < 1.0f), has0), L::and_(has0, L::from(s.thr0 == 0.0f)));
-    const float q = fdiv_small(fsub(p2, S_old), I);
-    const float prop = L::lane(L::or_(zero, d128)) ? 1.0f : q;
-    const float bdt = fadd(dt_old, fmul(T, prop));
-    s.S = S_new;
-    s.dt0 = L::lane(L::and_(fires, zero)) ? dt_old : fadd(dt_old, T);
-    s.bdt0 = L::lane(fires) ? bdt : s.bdt0;
-    s.thr0 = L::lane(fires) ? fadd(p2, p2) : s.thr0;
-    s.r1 = L::lane(L::or_(fires, popped)) ? 0u : s.r1 + 1u;
-    s.has = L::from(true);
-    s.popped = popped;
-    const M need_pop = L::andnot(L::from(s.dt0 >= sc.dtm_f), popped);
-    count += L::lane(need_pop) ? 1u : 0u;
-    w0 |= (L::lane(flushed) ? kCrTaskFlushed : 0u) | (L::lane(collapsed) ? kCrTaskCollapsed : 0u) |
-          (L::lane(need_pop) ? kCrTaskPop : 0u) | (count << 24);
-    t.w0 = w0;
-    t.thr_new = s.thr0;
-    t.bdt_new = s.bdt0;
-    // pop_top's arena shift (cr_pop), masks outside of any per-lane branch
-    const M promote = L::and_(need_pop, L::from(s.r1 != 0u));
-    if (L::lane(promote)) {
-        const float Ib = (float)s.base;
-        const CrNode n = cr_node(Ib, s.r1, T);
-        s.S = fmul((float)s.r1, Ib);
-        s.dt0 = fmul((float)s.r1, T);
-        s.bdt0 = n.bdt;
-        s.thr0 = n.thr;
-    }
-    s.has = L::andnot(s.has, L::andnot(need_pop, promote));
-    s.r1 = L::lane(need_pop) ? 0u : s.r1;
-    s.popped = L::or_(s.popped, need_pop);
-}
-
-// Event k (0-based, emission order) of a unit's task: the threshold whose exponent carries d, the event's delta_t, and
-// how its time is made -- 0: delta_t_to_absolute_t (:113-137); 1: the collapsed root event, after which last_fired_t is
-// running_t whatever it was (:257); 2: the D_EMPTY filler, t = running_t (:259-263).
-struct CrEvent {
-    uint32_t thr_bits;
-    float bdt;
-    uint32_t kind;
-};
-template <class Tab>
-ADDER_HD CrEvent cr_event(const CrTask &t, uint32_t k, float T, const Tab &tab) {
-    const uint32_t n_flush = (t.w0 >> 24) - ((t.w0 & kCrTaskPop) ? 1u : 0u);
-    CrEvent e;
-    e.kind = 0u;
-    if (k >= n_flush) {  // pop_top's event: the integrated root
-        e.thr_bits = f32_to_bits(t.thr_new);
-        e.bdt = t.bdt_new;
-        return e;
-    }
-    if (k == 0u) {
-        e.thr_bits = f32_to_bits(t.thr_old);
-        e.bdt = t.bdt_old;
-        e.kind = (t.w0 & kCrTaskCollapsed) ? 1u : 0u;
-        return e;
-    }
-    if (t.w0 & kCrTaskCollapsed) {
-        e.thr_bits = 0u;
-        e.bdt = 0.0f;
-        e.kind = 2u;
-        return e;
-    }
-    const uint32_t Iu = t.w0 & 0xffu;
-    uint32_t r = (t.w0 >> 8) & 0xffu;
-    for (uint32_t q = 1; q < k; ++q) r -= (uint32_t)(tab(Iu, r) & 31u);  // level k has run r_k = r_{k-1} - its parent's last firing
-    const CrNode n = cr_node((float)Iu, r, T);
-    e.thr_bits = f32_to_bits(n.thr);
-    e.bdt = n.bdt;
-    return e;
-}
-template <bool ABS_T>
-ADDER_HD uint32_t cr_event_time(const CrEvent &e, float &lastf, const StepConsts &sc) {
-    if (e.kind == 2u) return sc.running_t_u32;
-    if (e.kind == 1u) {
-        const uint32_t t = f32_as_u32(ABS_T ? fadd(e.bdt, lastf) : e.bdt);
-        lastf = sc.running_t;
-        return t;
-    }
-    return event_time<ABS_T>(e.bdt, lastf, sc);
-}
-
 // The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
 // the planes the other steps read: store(k, Node).  Returns m.
 template <class L, class Store>

@@ -374,18 +374,8 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
 // adder_cr_kernel runs it: only the roots are loaded and stepped, the levels are written back in their resident form at
 // the end.  The caller vouches for the regime (c_thresh 0 in every frame since the reset, one integer time_spanned):
 // -7 if this launch is not in it.
-static int g_cr_dense = 0;  // 1: the cooperative arrangement (cr_step_counted + cr_event per event) instead of cr_step / cr_emit
-void sim_set_cr_dense(int on) { g_cr_dense = on; }
 int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
     if (!sim_cb_possible(s, T) || s->c_thresh != 0 || s->c_max != 0) return -7;
-    std::vector<uint8_t> tabv;
-    if (g_cr_dense) {
-        if (!((double)s->dtm <= (double)T * (kCrTabRows - 1u))) return -7;  // the table's runs
-        tabv.resize(256u * kCrTabRows);
-        cr_build_tab(tabv.data(), T);
-    }
-    const uint8_t *const tabp = tabv.data();
-    auto tab = [tabp](uint32_t I, uint32_t r) -> uint32_t { return tabp[I * kCrTabRows + r]; };
     s->generic_sticky = 1;
     StepConsts sc;
     sc.time_spanned = T;
@@ -432,19 +422,6 @@ int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                         void ev(uint32_t thr_bits, uint32_t t) { put(cb_d_from_code(thr_bits >> 23), t); }
                         void filler(uint32_t t) { put(cb_d_from_code(kCbCodeEmpty), t); }
                     } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
-                    if (g_cr_dense) {
-                        CrTask task;
-                        uint32_t count;
-                        cr_step_counted(p, frames[(size_t)i * s->N + u], T, sc, tab, task, count);
-                        for (uint32_t k = 0; k < count; ++k) {  // one "lane" per event
-                            const CrEvent e = cr_event(task, k, T, tab);
-                            const uint32_t t = s->abs_t ? cr_event_time<true>(e, p.lastf, sc) : cr_event_time<false>(e, p.lastf, sc);
-                            if (e.kind == 2u) em.filler(t);
-                            else em.ev(e.thr_bits, t);
-                        }
-                        s->cb_steps++;
-                        continue;
-                    }
                     CrPlan plan;
                     cr_step(p, frames[(size_t)i * s->N + u], T, sc, plan);
                     if (s->abs_t) cr_emit<true>(p, plan, T, sc, em); else cr_emit<false>(p, plan, T, sc, em);

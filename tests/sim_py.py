@@ -65,7 +65,6 @@ def lib():
     L.sim_set_use_cb.argtypes = [vp, i32]
     L.sim_integrate_cb_block.restype = i32
     L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
-    L.sim_set_cr_dense.argtypes = [i32]
     L.sim_integrate_cr_block.restype = i32
     L.sim_integrate_cr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate.restype = i32
@@ -208,10 +207,8 @@ class Sim:
                                            C.byref(n))
         return rc, out[: n.value].copy()
 
-    def integrate_cr_block(self, frames, time_spanned, dense=False):
-        """nb frames as ONE launch of the constant-run step (c_thresh 0 throughout); (rc, events frame-major).
-        dense: the cooperative arrangement (a count from the table, then one "lane" per event)."""
-        self.L.sim_set_cr_dense(int(dense))
+    def integrate_cr_block(self, frames, time_spanned):
+        """nb frames as ONE launch of the constant-run step (c_thresh 0 throughout); (rc, events frame-major)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), -1)
         assert frames.shape[1] == self.n
         cap = self._cap * len(frames)

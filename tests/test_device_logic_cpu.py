@@ -449,9 +449,8 @@ def test_cb_other_tick_rates_and_quality_change():
 
 
 # ---- the constant-run step (cr_step / cr_emit / cr_pop / cr_materialize: the bounded regime at c_thresh 0) ----
-@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
-def test_cr_blocked_launches_match_the_oracle(time_mode, dense):
+def test_cr_blocked_launches_match_the_oracle(time_mode):
     """crf 0 (c_thresh_baseline = c_thresh_max = 0): every change of value flushes, a run integrates ONE intensity, and
     the arena is a function of (intensity, frames since the flush).  cr_* keep only the root and work the levels out when
     a flush or pop_top wants them; between launches the levels go back to the planes in their resident form.  Launches
@@ -466,7 +465,7 @@ def test_cr_blocked_launches_match_the_oracle(time_mode, dense):
         while k < frames:
             nb = min(int(rng.choice([1, 2, 3, 7, 29, 30, 31, 64])), frames - k)
             want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
-            rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=dense)
+            rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0)
             assert rc == 0, (kind, k, rc)
             assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
             total += len(got)
@@ -474,13 +473,12 @@ def test_cr_blocked_launches_match_the_oracle(time_mode, dense):
         assert sv.plan_mismatches == 0 and total > 0
 
 
-@pytest.mark.parametrize("dense", [False, True])
-def test_cr_every_intensity_and_run_length(dense):
+def test_cr_every_intensity_and_run_length():
     """The closed forms (last firing = ceil(2^e / I), level k+1's run = level k's run minus its last firing) against the
     stepped oracle for EVERY intensity 0..255 and every run length 1..45 (delta_t_max = 30 and 40 frames: the pop falls
     inside), flushed by a value change: a 256-pixel row per run length, both time modes, rgb interleaving too."""
     for tm in (O.DELTA_T, O.ABSOLUTE_T):
-        for dtm_frames in ((30, 31, 3) if dense else (30, 40, 3)):
+        for dtm_frames in (30, 40, 3):
             ov, sv = _cb_pair(256, 1, 1, tm, 255 * dtm_frames, crf=CRFS[0], max_depth=12)
             frames = []
             for run in range(1, 46):
@@ -491,7 +489,7 @@ def test_cr_every_intensity_and_run_length(dense):
             while k < len(clip):
                 nb = min(37, len(clip) - k)
                 want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
-                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=dense)
+                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0)
                 assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (tm, dtm_frames, k)
                 k += nb
             assert sv.plan_mismatches == 0
@@ -511,7 +509,7 @@ def test_cr_cb_and_generic_steps_are_interchangeable_mid_stream():
             nb = min(int(rng.choice([1, 2, 5, 17, 33])), len(clip) - k)
             want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
             if which == 0:
-                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0, dense=bool(k & 1))
+                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0)
             elif which == 1:
                 rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
             else:

@@ -1087,6 +1087,7 @@ def test_frame_ring_hands_out_wire_records(channels):
     clip = clips.make_clip("runs", 40, H, W, channels, seed=23)
     ov = O.Video(W, H, channels, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, chunk_rows=5)
     hv = A.HipVideo(W, H, channels, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255, chunk_rows=5)
+    ov.ensure_capacity(4)
     for v in (ov, hv):
         v.set_crf_parameters(0, 10)
         v.reset_c_thresh(0)
