@@ -2243,6 +2243,13 @@ static int frame_slot_prepare(AdderHipCtx *c, AdderHipCtx::FrameSlot &fs, size_t
 }
 
 // direct_out: page-locked memory of the caller that takes the events instead of the slot's own (device view), or null
+// workgroups of the ring's wire hand-over: enough to keep the link busy, few enough to leave the next frame's kernels
+// their CUs (the stores are posted writes over PCIe: a workgroup spends most of its life waiting on them)
+static uint32_t wire_scatter_blocks(const AdderHipCtx *c) {
+    static const uint32_t env = [] { const char *e = getenv("ADDER_HIP_WIRE_BLOCKS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    return env ? env : c->num_cus;
+}
+
 static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
                              AdderEvent *direct_out, size_t direct_cap) {
     if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
@@ -2304,7 +2311,7 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     if (wire)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
         HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
                                             c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
-                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, c->num_cus * 4u, c->out_s));
+                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), c->out_s));
     HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
                                      wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,

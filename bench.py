@@ -1007,7 +1007,25 @@ def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, arg
     from oracle import oracle as O
 
     max_threads = O.max_threads()
-    sweep_threads = sorted({t for t in (1, 8, 16, 32, 64, 128, max_threads) if t <= max_threads})
+    # what this process may really use: its affinity mask and its cgroup's CPU quota (a pod of a shared node often has
+    # fewer CPUs than the node shows; a team larger than that spins against itself at every barrier)
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = max_threads
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except Exception:
+            quota = None
+    usable = int(min(max_threads, affinity, quota if quota else max_threads))
+    sweep_threads = sorted({t for t in (1, 8, 16, 32, 64, 128, usable) if t <= max(usable, 1)})
     n_points = len(sweep_threads) + 5
     budget = args.cpu_seconds / n_points
     max_frames = min(T, 64)
@@ -1066,7 +1084,7 @@ def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, arg
     mp_forkjoin, _, _, _ = run_per_frame(bt, 1, False)
     _, fr_chk, ev_chk, ok = run_per_frame(bt, 1, True)
     triad = {}
-    for th in sorted({1, bt, max_threads}):
+    for th in sorted({1, bt, usable}):
         triad[str(th)] = round(O.stream_triad_GBs(64 << 20, th), 1)  # 3 x 256 MB
     value = by_rows[best_rows]
     # the AoS state the port streams per frame (sizeof(PixelArena) in and out) + input + events: what `value` means in GB/s
@@ -1081,6 +1099,7 @@ def cpu_baseline(d_frames, d_events, d_offsets, T, Cn, Wd, Ht, multi, tmode, arg
                   f"{best_rows}, OMP_PLACES=cores, OMP_PROC_BIND=spread) + serial raw sink after every frame; events stay "
                   f"in per-chunk buffers like the reference's Vec<Vec<Event>>",
         "host_cores": max_threads,
+        "cpus_usable": {"omp_max_threads": max_threads, "affinity": affinity, "cgroup_quota_cpus": quota, "swept_up_to": usable},
         "caveat": "a stated baseline, not a target: a C restatement of the reference's rayon loop (the Rust original cannot "
                   "be built here).  Round 3 forked and joined a team per frame with a dynamic schedule and no placement "
                   "(fork_join_per_frame below, kept for comparison); this run keeps the team and the rows' placement for "
