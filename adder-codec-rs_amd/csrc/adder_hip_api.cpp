@@ -1207,7 +1207,7 @@ constexpr int kTuneRunsPerCandidate = 2;  // the first run of an exec also uploa
 
 static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     // everything the captured launch sequence depends on
-    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 40);
+    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 44);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         if (c->graphs.size() >= 8) {  // keep the cache small
@@ -1401,10 +1401,16 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->cr_time = time_spanned;
     static const bool cr_off = [] { const char *e = getenv("ADDER_HIP_NO_CR"); return e && atoi(e) != 0; }();
     const bool cr = cb && c->cr_valid && !cr_off;  // ... then only the roots are stepped (adder_cr_kernel)
+    // lean runs (adder_lr_kernel): the lean regime in DeltaT under the same property, in blocked batches of events, while
+    // rho * 255 and rho * time_spanned stay exact in binary32 (rho <= frames since the reset)
+    static const bool lr_off = [] { const char *e = getenv("ADDER_HIP_NO_LR"); return e && atoi(e) != 0; }();
+    const bool lr = !generic && !c->continuous && collapse && c->p.time_mode == ADDER_TIME_DELTA_T && c->cr_valid && !lr_off &&
+                    !c->records_only && !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
+                    (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
-                             (cb ? 32u : 0u) | (cr ? 128u : 0u) |
+                             (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) |
                              ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
     if (c->records_only && (generic || c->continuous || fpath))
         return fail(c, ADDER_E_BAD_PARAMS, "records can be handed out in the lean regime only (Collapse, delta_t_max <= "
@@ -1467,7 +1473,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.out = reinterpret_cast<AdderEventPod *>(d_out);
     b.base.out_cap = out_cap;
     b.base.frame_offsets = d_offsets;
-    b.base.lean = (generic || c->continuous) ? 0u : 1u;
+    b.base.lean = (generic || c->continuous) ? 0u : ((variant & 256u) ? 2u : 1u);  // 2: lean-runs records (lr_decode8)
     b.base.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
     b.base.sc = make_consts(c, time_spanned);
     b.frames = d_frames;

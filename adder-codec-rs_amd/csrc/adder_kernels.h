@@ -102,7 +102,7 @@ struct FrameArgs {
     uint32_t n_units;
     uint32_t num_waves;
     uint32_t width, channels, rowlen, row_begin;
-    uint32_t lean;        // 1: the batch runs the lean K1 (12-byte LeanRec records); 0: generic (8-byte per event)
+    uint32_t lean;        // 1: the batch runs the lean K1 (LeanRec records); 2: lean runs ({rho, base_val ..} records); 0: generic
     uint32_t abs_t;       // TimeMode::AbsoluteT (record decoding)
     StepConsts sc;        // running_t / cth are filled per frame from the table
 };

@@ -636,6 +636,152 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
     timeline_mark(b, 0u, f, true);
 }
 
+// ------------------------------------------------------------------------------------------
+// K1, lean runs -- `adder_lr_kernel`: the lean regime at crf 0 in DeltaT (the headline: BASELINE configs 2-4).  Under
+// the constant-run conditions (adder_pixel.hpp) a unit is {base_val, rho, popped}: the step is compares and a counter
+// (lr_step), the parked record carries (base_val, rho) of a flushed root and the expansion works event A out
+// (lr_decode8) -- the divisions moved from a sixth of the frame kernel's lanes to the expansion's dense ones.  Loads
+// the header and delta_t planes only (rho = delta_t / T), stores the four level-0 planes in their resident form
+// (lr_pack), so any other kernel may run next.  Same slots, scan and offsets as adder_lean_kernel.
+// ------------------------------------------------------------------------------------------
+#ifndef ADDER_LR_WAVES_PER_SIMD
+#define ADDER_LR_WAVES_PER_SIMD 5
+#endif
+template <bool FULL>
+__device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
+                                          uint32_t gw, uint32_t lane, uint8_t *lds_in) {
+    constexpr uint32_t N = kUnitsPerLane;
+    constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
+    using L = WaveLanes;
+    const float T = a.sc.time_spanned;
+    LrPxT<L> px[N];
+    {
+        uint32_t hdrv[N];
+        float dv[N];
+        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
+        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) px[j] = lr_unpack<L>(hdrv[j], dv[j], T);
+    }
+    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
+    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    const uint32_t f0 = __builtin_amdgcn_readfirstlane(a.frame_idx);
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(f0 % slots_u);
+    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
+    const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
+    const ParkLayout lay = park_layout_u(b);
+    const uint32_t frame_stride_u = lay.frame_stride;
+    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
+    uint32_t ridx = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
+    const uint32_t wrap_bytes = chunk_u * frame_stride_u;
+    // the launch's input bytes, all of them, into the wave's LDS slice (lean_frames has the reasons)
+    using InT = typename VecOf<uint8_t, N>::type;
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame][lane]
+    {
+        const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+        static_assert(kWaveUnits == 128u && NB_MAX % 8u == 0u, "eight frames of one segment per instruction");
+        const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
+                            __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+        if (direct) {
+            const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
+#pragma unroll
+            for (uint32_t g = 0; g < NB_MAX / 8u; ++g) {
+                uint32_t k = g * 8u + (lane >> 3);
+                k = k < nb ? k : nb - 1u;
+                __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
+                                                 (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                                 ADDER_NT_INPUT ? 2 : 0);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < NB_MAX; k0 += 8u) {
+                uint32_t vin8[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) {
+                    const uint32_t k = k0 + q;
+                    const uint32_t kk = k < nb ? k : nb - 1u;
+                    vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(k0 + q) * kWave] = (InT)vin8[q];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing inside the frame loop waits on memory
+    }
+    uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
+    uint64_t active[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
+    for (uint32_t i = 0; i < nb; ++i) {
+        const uint32_t vin_w = (uint32_t)in_lds[i * kWave];
+        uint32_t w0[N], w8[N];
+        uint64_t mrec[N];
+        uint32_t nev = 0u, nrec = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            LeanFlagsT<L> fl = lr_step<L>(px[j], (vin_w >> (8 * j)) & 0xffu, (lane * N + j) << kLean8UnitShift, w0[j], w8[j]);
+            if (!FULL) {  // padding units: stepped freely, no events
+                fl.a &= active[j];
+                fl.b &= active[j];
+                fl.c &= active[j];
+            }
+            mrec[j] = fl.a | fl.c;
+            nrec += (uint32_t)__popcll(mrec[j]);
+            nev += (uint32_t)__popcll(fl.a) + (uint32_t)__popcll(fl.b) + (uint32_t)__popcll(fl.c);
+        }
+        uint32_t pos = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j)
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mrec[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mrec[j], pos));
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const bool has = L::lane(mrec[j]);
+            if (has) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
+            pos += has ? 1u : 0u;
+        }
+        wt = lane == i ? (nev | (nrec << 16)) : wt;
+        seg += frame_stride_u;
+        if (++ridx == chunk_u) {
+            ridx = 0u;
+            seg -= wrap_bytes;
+        }
+    }
+    if (lane < nb) {
+        uint32_t s = slot0 + lane;
+        s = s >= slots_u ? s - slots_u : s;
+        gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
+    }
+    {   // state back to HBM in its resident form
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) hdrv[j] = lr_pack<L>(px[j], T, iv[j], dv[j], bv[j]);
+        constexpr bool NTS = ADDER_NT_STATE != 0;
+        store_vec<NTS>(a.hdr, u0, hdrv);
+        store_vec<NTS>(a.integ0, u0, iv);
+        store_vec<NTS>(a.dt0, u0, dv);
+        store_vec<NTS>(a.bdt0, u0, bv);
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_lr_kernel(const BatchArgs *__restrict__ b,
+                                                                                         uint32_t f, uint32_t nb) {
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
+    timeline_mark(b, 0u, f, false);
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
+        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        if (full) lr_frames<true>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+        else lr_frames<false>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+    }
+    timeline_mark(b, 0u, f, true);
+}
+
 // Lean K1 at temporal depth 1 (the per-frame `consume` contract; HBM-bound): a wave takes kLean1Segs
 // consecutive segments and issues the loads of all of them before it steps the first, so the later
 // segments' memory round trips hide under the first one's step (with one segment per wave all
@@ -1993,6 +2139,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint64_t out_cap = b->base.out_cap;
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
     const float time_spanned_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
+    const bool lean_runs = LEAN && !ABS_T && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u;
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
     // segments' counts first, then exactly the records they hold (a speculative fetch of 64 records per
@@ -2078,7 +2225,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         r.w = rw.z;
         r.w8 = rw.y;
         // (an all-zero record decodes to no events)
-        const LeanEvents e = ABS_T ? lean_decode(r, true, rt_u32) : lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
+        // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
+        const LeanEvents e = ABS_T ? lean_decode(r, true, rt_u32)
+                             : lean_runs ? lr_decode8(rw.x, rw.y, time_spanned_u, rt_u32)
+                                         : lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
         const uint32_t incl = wave_inclusive_scan_dpp(n);
         const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
@@ -2767,6 +2917,12 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
+    if (variant & 256u) {  // lean runs (DeltaT, constant runs): every launch of the batch, whatever its length
+        if (abs_t) return hipErrorInvalidValue;
+        const uint32_t SR = grid_cap && grid_cap < S ? grid_cap : S;
+        hipLaunchKernelGGL(adder_lr_kernel, dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
+        return hipGetLastError();
+    }
 #if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
     const bool lean_log = variant & 64u;  // blocked batches: records in per-segment logs (every launch, also a chunk's 1-frame tail)
     if (nb == 1u && !lean_log && num_waves % 2u == 0u && (variant & 16u) && wide) {

@@ -1282,6 +1282,95 @@ ADDER_HD void cr_pop(CrPxT<L> &s, const CrPlanT<L> &p, float T) {
     s.popped = L::or_(s.popped, p.need_pop);
 }
 
+// ---------------------------------------------------------------------------------------
+// LEAN RUNS: the lean regime (Collapse, delta_t_max <= time_spanned) under the constant-run conditions above (c_thresh
+// 0 throughout, one integer time_spanned), DeltaT.  There the arena holds the root or nothing, the root's whole state
+// is cr_node(base_val, rho) with rho = the frames it has accumulated -- so a unit is THREE SMALL INTEGERS {base_val, rho,
+// popped_dtm}, the step is compares and a counter, and the one event that needs arithmetic (A, the flushed root's best
+// event) is worked out by the EXPANSION from (base_val, rho), densely, like it already works event C out from the
+// input byte.  The parked 8-byte record is {rho of the flushed root, A | B << 1 | C << 2 | unit << 4 | flushed
+// base_val << 11 | input byte << 19}.  rho I and rho T stay below 2^24 (the host switches to lean_step before they would
+// not: 65 000 frames after a reset), so the closed form's operations are the stepped ones bit for bit.
+// ---------------------------------------------------------------------------------------
+template <class L>
+struct LrPxT {
+    uint32_t base, rho;       // rho: frames the root has accumulated; 0 = no root (the pristine tail alone)
+    typename L::Mask popped;  // popped_dtm
+};
+using LrPx = LrPxT<ScalarLanes>;
+constexpr uint32_t kLr8BaseShift = 11;  // the flushed root's intensity (where lean_decode8 has A's exponent byte)
+
+template <class L>
+ADDER_HD LrPxT<L> lr_unpack(uint32_t hdr, float dt, float T) {
+    LrPxT<L> p;
+    p.base = hdr & 0xffu;
+    p.popped = L::from((hdr & kHdrPopped) != 0u);
+    // a root of intensity I > 0 holds delta_t = rho T; a black one (it never accumulates, :449) counts as one frame
+    p.rho = hdr_m(hdr) == 0u ? 0u : (p.base != 0u ? (uint32_t)fdiv(dt, T) : 1u);
+    return p;
+}
+// integrate_for_px under the conditions above: which events leave, the record's two words, the new state
+template <class L>
+ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t tag8 /* unit << kLean8UnitShift */, uint32_t &w0,
+                               uint32_t &w8) {
+    using M = typename L::Mask;
+    const M flush = L::from(v != p.base);
+    const M has = L::from(p.rho != 0u);
+    LeanFlagsT<L> fl;
+    fl.a = L::and_(flush, has);
+    fl.b = L::and_(fl.a, p.popped);
+    w0 = p.rho;
+    const uint32_t old_base = p.base;
+    const M popped = L::andnot(p.popped, flush);
+    const M has1 = L::andnot(has, flush);
+    p.base = v;  // (unchanged without a flush)
+    const M zero = L::from(v == 0u);  // the root's sum stays 0 exactly when the run's intensity is 0 (:449)
+    fl.c = L::not_(L::or_(popped, zero));  // need_to_pop_top: the root has accumulated time_spanned >= delta_t_max
+    p.rho = L::lane(fl.c) ? 0u : (L::lane(L::andnot(has1, zero)) ? p.rho + 1u : 1u);
+    p.popped = L::or_(popped, fl.c);
+    w8 = tag8 | (old_base << kLr8BaseShift) | (v << kLean8InShift) | (L::lane(fl.a) ? kLeanA : 0u) |
+         (L::lane(fl.b) ? kLeanB : 0u) | (L::lane(fl.c) ? kLeanC : 0u);
+    return fl;
+}
+// The record back into events: A from the flushed root's run, C from the input byte (lean_decode8's arithmetic).
+ADDER_HD LeanEvents lr_decode8(uint32_t w0, uint32_t w8, float T, uint32_t running_t_u32) {
+    LeanEvents e;
+    e.a = (w8 & kLeanA) != 0u;
+    e.b = (w8 & kLeanB) != 0u;
+    e.c = (w8 & kLeanC) != 0u;
+    const uint32_t Io = (w8 >> kLr8BaseShift) & 0xffu;
+    // (a record without A still decodes: rho 0 is given a frame so that the divisions stay inside their domain)
+    const CrNode n = cr_node(Io != 0u ? (float)Io : 1.0f, w0 != 0u ? w0 : 1u, T);
+    e.da = Io != 0u ? lean_bd_from_thr(f32_to_bits(n.thr)) : kDZero;
+    e.ta = f32_as_u32(Io != 0u ? n.bdt : T);  // a black root's best event: (128, 0 + T * 1)
+    e.tb = running_t_u32;
+    const float I = (float)((w8 >> kLean8InShift) & 0xffu);
+    const float p2 = bits_to_f32(f32_to_bits(I) & 0x7f800000u);  // 2^get_d(I)
+    e.dc = get_d(I);
+    e.tc = f32_as_u32(fadd(0.0f, fmul(T, fdiv_small(fsub(p2, 0.0f), I))));  // (C exists only for I >= 1)
+    return e;
+}
+// back to the resident form {header, integration, delta_t, best delta_t}
+template <class L>
+ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, float &bdt) {
+    const float I = (float)p.base;
+    uint32_t bd = 0u;
+    integ = dt = bdt = 0.0f;
+    if (p.rho != 0u) {
+        if (p.base != 0u) {
+            const CrNode n = cr_node(I, p.rho, T);
+            integ = fmul((float)p.rho, I);
+            dt = fmul((float)p.rho, T);
+            bdt = n.bdt;
+            bd = lean_bd_from_thr(f32_to_bits(n.thr));
+        } else {
+            bdt = T;
+            bd = kDZero;
+        }
+    }
+    return hdr_make(p.base, bd, p.rho != 0u ? 1u : 0u, L::lane(p.popped));
+}
+
 // The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
 // the planes the other steps read: store(k, Node).  Returns m.
 template <class L, class Store>

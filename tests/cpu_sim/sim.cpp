@@ -458,6 +458,64 @@ int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
+// One temporally blocked launch of the LEAN-RUNS step (lr_step / lr_decode8 / lr_pack), as adder_lean_kernel's RUNS
+// instantiation and the expansion run it: a unit is {base_val, rho, popped}, event A is worked out from the record.
+// -7 outside its regime (Collapse, delta_t_max <= T, DeltaT, c_thresh 0 with c_thresh_max 0, integer T, no generic batch).
+int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!s->collapse || s->abs_t || !((float)s->dtm <= T) || s->generic_sticky || s->perpx || s->continuous ||
+        s->c_thresh != 0 || s->c_max != 0 || !(T >= 1.0f) || T != (float)(uint32_t)T || s->frac_time_seen)
+        return -7;
+    std::vector<float> rts(nb);
+    {
+        float rt = s->running_t;
+        for (uint32_t i = 0; i < nb; ++i) {
+            rts[i] = rt;
+            rt += T;
+        }
+        s->running_t = rt;
+    }
+    std::vector<std::vector<SimEvent>> per_frame(nb);
+    int rc = 0;
+    size_t u = 0;
+    for (uint32_t y = 0; y < s->H; y++)
+        for (uint32_t x = 0; x < s->W; x++)
+            for (uint32_t c = 0; c < s->C; c++, u++) {
+                const uint32_t m0 = hdr_m(s->hdr[u]);
+                LrPx p = lr_unpack<ScalarLanes>(s->hdr[u], m0 ? s->dt0[u] : -777.0f, T);
+                for (uint32_t i = 0; i < nb; ++i) {
+                    uint32_t w0, w8;
+                    const LeanFlagsT<ScalarLanes> fl = lr_step(p, frames[(size_t)i * s->N + u], (uint32_t)(u & 127u) << kLean8UnitShift, w0, w8);
+                    if (fl.b && !fl.a) rc = -9;
+                    if (!(fl.a || fl.c)) continue;  // (no record)
+                    if (((w8 >> kLean8UnitShift) & 127u) != (u & 127u)) rc = -9;
+                    const LeanEvents e = lr_decode8(w0, w8, T, f32_as_u32(rts[i]));
+                    if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
+                    SimEvent ev;
+                    ev.x = (uint16_t)x; ev.y = (uint16_t)(y + s->row_begin); ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)c; ev.pad = 0;
+                    if (e.a) { ev.d = (uint8_t)e.da; ev.t = e.ta; per_frame[i].push_back(ev); }
+                    if (e.b) { ev.d = (uint8_t)kDEmpty; ev.t = e.tb; per_frame[i].push_back(ev); }
+                    if (e.c) { ev.d = (uint8_t)e.dc; ev.t = e.tc; per_frame[i].push_back(ev); }
+                }
+                float integ, dt, bdt;
+                s->hdr[u] = lr_pack(p, T, integ, dt, bdt);
+                if (p.rho != 0u) {
+                    s->integ0[u] = integ; s->dt0[u] = dt; s->bdt0[u] = bdt;
+                    if (s->max_m < 1) s->max_m = 1;
+                    s->running[u] = (uint8_t)frame_value_u8((s->hdr[u] >> kHdrBdShift) & 0xffu, f32_as_u32(bdt), (double)s->ref_time);
+                }
+                s->lean_steps += nb;
+            }
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i)
+        for (const SimEvent &e : per_frame[i]) {
+            if (pos < cap) out[pos] = e;
+            ++pos;
+        }
+    *n_out = pos;
+    if (pos > cap && rc == 0) rc = -4;
+    return rc;
+}
+
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
     StepConsts sc;

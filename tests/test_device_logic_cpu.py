@@ -541,3 +541,72 @@ def test_cr_other_tick_rates_and_its_limits():
     sv.set_crf_parameters(0, 10)
     sv.reset_c_thresh(0)
     assert sv.integrate_cr_block(clip[:2], 254.5)[0] == -7
+
+
+# ---- lean runs (lr_step / lr_decode8 / lr_pack: the headline regime at crf 0, a unit = {base_val, rho, popped}) ----
+def _lean_pair(W, H, Cn, dtm=255, ref_time=255):
+    ov = O.Video(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+    sv = Sim(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+    ov.ensure_capacity(4)
+    for v in (ov, sv):
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+    return ov, sv
+
+
+def test_lr_blocked_launches_match_the_oracle_and_interleave_with_the_lean_step():
+    """BASELINE configs 2-4's mode at crf 0: launches of the lean-runs step of every length on every content, mixed at
+    random with frames of the ordinary lean step (both keep the same resident planes) -- every event equals the oracle's."""
+    rng = np.random.default_rng(61)
+    for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
+        frames = 260
+        clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, 7, 12, 1, seed=5 + len(kind)))
+        ov, sv = _lean_pair(12, 7, 1)
+        k, used = 0, set()
+        while k < frames:
+            nb = min(int(rng.choice([1, 2, 3, 7, 31, 64])), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            if rng.integers(0, 3):
+                rc, got = sv.integrate_lr_block(clip[k:k + nb], 255.0)
+                used.add("lr")
+            else:
+                parts = [sv.integrate(clip[k + i], 255.0) for i in range(nb)]
+                rc, got = max(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+                used.add("lean")
+            assert rc == 0, (kind, k, rc)
+            assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
+            k += nb
+        assert used == {"lr", "lean"}
+
+
+def test_lr_every_intensity_and_run_length_rgb_and_tick_rates():
+    """Event A worked out from (base_val, rho) for every intensity 0..255 and runs of 1..70 frames (and one of 700), the
+    time_spanned > delta_t_max case, other tick rates, three channels."""
+    for ref_time, dtm, T in ((255, 255, 255.0), (255, 255, 510.0), (1000, 1000, 1000.0), (20, 20, 20.0)):
+        ov, sv = _lean_pair(256, 1, 1, dtm=dtm, ref_time=ref_time)
+        frames = []
+        for run in list(range(1, 71, 3)) + [700]:
+            frames += [np.arange(256, dtype=np.uint8).reshape(1, 256, 1)] * run
+            frames += [((np.arange(256) + 1 + run) % 256).astype(np.uint8).reshape(1, 256, 1)]
+        clip = np.stack(frames)
+        k = 0
+        while k < len(clip):
+            nb = min(64, len(clip) - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=T) for i in range(nb)])
+            rc, got = sv.integrate_lr_block(clip[k:k + nb], T)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (ref_time, T, k)
+            k += nb
+    clip = clips.make_clip("runs", 120, 5, 6, 3, seed=9)
+    ov, sv = _lean_pair(6, 5, 3)
+    for k in range(0, 120, 40):
+        want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(40)])
+        rc, got = sv.integrate_lr_block(clip[k:k + 40], 255.0)
+        assert rc == 0 and np.array_equal(want, got), k
+    # outside the regime
+    sv = Sim(6, 5, 3, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, delta_t_max=255)
+    sv.set_crf_parameters(0, 10)
+    sv.reset_c_thresh(0)
+    assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7
+    sv = Sim(6, 5, 3, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255)
+    assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
