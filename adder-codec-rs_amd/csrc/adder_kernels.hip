@@ -645,8 +645,14 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 // (lr_pack), so any other kernel may run next.  Same slots, scan and offsets as adder_lean_kernel.
 // ------------------------------------------------------------------------------------------
 #ifndef ADDER_LR_WAVES_PER_SIMD
-#define ADDER_LR_WAVES_PER_SIMD 5
+#define ADDER_LR_WAVES_PER_SIMD 8
 #endif
+#ifndef ADDER_LR_IN_FRAMES
+#define ADDER_LR_IN_FRAMES 32
+#endif
+// input frames staged at a time: the step needs ~46 registers, so the wave's LDS slice decides the occupancy -- 32 frames
+// (4 KB per wave, 16 KB per workgroup) leave room for 8 waves per SIMD at the price of one more vmcnt(0) per launch
+constexpr uint32_t kLrInFrames = ADDER_LR_IN_FRAMES;
 template <bool FULL>
 __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
                                           uint32_t gw, uint32_t lane, uint8_t *lds_in) {
@@ -676,19 +682,19 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
     uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
     uint32_t ridx = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
     const uint32_t wrap_bytes = chunk_u * frame_stride_u;
-    // the launch's input bytes, all of them, into the wave's LDS slice (lean_frames has the reasons)
+    // the launch's input bytes into the wave's LDS slice, kLrInFrames frames at a time (lean_frames has the reasons)
     using InT = typename VecOf<uint8_t, N>::type;
-    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame][lane]
-    {
-        const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-        static_assert(kWaveUnits == 128u && NB_MAX % 8u == 0u, "eight frames of one segment per instruction");
-        const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
-                            __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame of the group][lane]
+    const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+    static_assert(kWaveUnits == 128u && kLrInFrames % 8u == 0u && NB_MAX % kLrInFrames == 0u, "eight frames of one segment per instruction");
+    const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
+                        __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+    auto stage = [&](uint32_t k0) {  // frames [k0, k0 + kLrInFrames) of the launch
         if (direct) {
             const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
 #pragma unroll
-            for (uint32_t g = 0; g < NB_MAX / 8u; ++g) {
-                uint32_t k = g * 8u + (lane >> 3);
+            for (uint32_t g = 0; g < kLrInFrames / 8u; ++g) {
+                uint32_t k = k0 + g * 8u + (lane >> 3);
                 k = k < nb ? k : nb - 1u;
                 __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
                                                  (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
@@ -696,26 +702,27 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
             }
         } else {
 #pragma unroll 1
-            for (uint32_t k0 = 0; k0 < NB_MAX; k0 += 8u) {
+            for (uint32_t q0 = 0; q0 < kLrInFrames; q0 += 8u) {
                 uint32_t vin8[8];
 #pragma unroll
                 for (uint32_t q = 0; q < 8u; ++q) {
-                    const uint32_t k = k0 + q;
+                    const uint32_t k = k0 + q0 + q;
                     const uint32_t kk = k < nb ? k : nb - 1u;
                     vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
                 }
 #pragma unroll
-                for (uint32_t q = 0; q < 8u; ++q) in_lds[(k0 + q) * kWave] = (InT)vin8[q];
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(q0 + q) * kWave] = (InT)vin8[q];
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing inside the frame loop waits on memory
-    }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing else inside the frame loop waits on memory
+    };
     uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
     uint64_t active[N];
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
     for (uint32_t i = 0; i < nb; ++i) {
-        const uint32_t vin_w = (uint32_t)in_lds[i * kWave];
+        if ((i % kLrInFrames) == 0u) stage(i);
+        const uint32_t vin_w = (uint32_t)in_lds[(i % kLrInFrames) * kWave];
         uint32_t w0[N], w8[N];
         uint64_t mrec[N];
         uint32_t nev = 0u, nrec = 0u;
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kMaxFramesPerLaunch * kWaveUnits];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kLrInFrames * kWaveUnits];
     timeline_mark(b, 0u, f, false);
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;

@@ -1,0 +1,6 @@
+#!/bin/bash
+# the lean-runs kernel: staging depth x occupancy variants (tools/build_variants.sh), headline ms per step + per-kernel us
+for lib in "" build/variants/libadder_hip_in64w5.so build/variants/libadder_hip_in16w8.so build/variants/libadder_hip_in32w6.so ""; do
+  ADDER_HIP_LIB=$lib python bench.py --steps 32 --warmup 3 --no-cpu-baseline --no-end-to-end --no-secondary 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('${lib:-default}', d['ms_per_step'], d['value'], r['frac'], r['frame_kernel_launch_us'], r['scan_offsets_expand_us'])"
+done
