@@ -432,16 +432,16 @@ def main():
     try:
         default_workload = (Wd, Ht, Cn, T, args.delta_t_max, args.content, args.multi_mode, args.time_mode) == \
             (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t")
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic_default.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic_default.json")
         if default_workload and world == 1 and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"]
             per_launch = {k: v["hbm_bytes_per_launch"] for k, v in tk.items()}
-            lean_b = sum(v for k, v in per_launch.items() if "lean_kernel" in k)
+            lean_b = sum(v for k, v in per_launch.items() if "lean_kernel" in k or "lr_kernel" in k)
             exp_b = sum(v for k, v in per_launch.items() if "expand_kernel" in k)
             scan_b = sum(v for k, v in per_launch.items() if "scan_kernel" in k or "offsets_kernel" in k)
             traffic = int(lean_b + exp_b + scan_b)
             traffic_note = ("HBM bytes of one 64-frame chunk (frame kernel + scan + offsets + expansion launches) from "
-                            "profiles/r03_traffic_default.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                            "profiles/r04_traffic_default.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                             "this command, 2 x FETCH_SIZE + WRITE_SIZE (KiB); algorithmic bytes of the same chunk: "
                             f"{int(alg_b * units * chunk_frames)}")
     except Exception as exc:
@@ -489,8 +489,8 @@ def main():
                                 "queues at instantiation; measured 1.86 vs 2.08 ms per step between instances)"},
         "roofline": {
             "bound": "hbm",
-            "kernel": ("one chunk of frames: adder_lean_kernel + adder_scan_kernel + adder_offsets_kernel + "
-                       "adder_expand_kernel") if lean else
+            "kernel": ("one chunk of frames: adder_lr_kernel (the lean step over constant runs: crf 0, DeltaT; adder_lean_kernel "
+                       "otherwise) + adder_scan_kernel + adder_offsets_kernel + adder_expand_kernel") if lean else
                       "one chunk of frames: adder_frame_kernel + adder_scan_kernel + adder_offsets_kernel + "
                       "adder_expand_kernel",
             "achieved": round(achieved, 1),
