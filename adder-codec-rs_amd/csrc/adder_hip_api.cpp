@@ -2253,7 +2253,7 @@ static int frame_slot_prepare(AdderHipCtx *c, AdderHipCtx::FrameSlot &fs, size_t
 // their CUs (the stores are posted writes over PCIe: a workgroup spends most of its life waiting on them)
 static uint32_t wire_scatter_blocks(const AdderHipCtx *c) {
     static const uint32_t env = [] { const char *e = getenv("ADDER_HIP_WIRE_BLOCKS"); return e ? (uint32_t)atoi(e) : 0u; }();
-    return env ? env : c->num_cus;
+    return env ? env : c->num_cus * 2u;  // (sweep, 1080p e = 0.3: 64-128: 203, 256: 197, 512: 185, 1024: 189 us per frame)
 }
 
 static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
