@@ -680,7 +680,9 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
     const ParkLayout lay = park_layout_u(b);
     const uint32_t frame_stride_u = lay.frame_stride;
     uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
-    uint32_t ridx = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
+    // rotated frame slots (ParkLayout) wrap once per chunk at most: the launch's frame index at which that happens
+    const uint32_t ridx0 = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
+    const uint32_t wrap_at = chunk_u - 1u - ridx0;  // (after this frame of the launch the walk returns to the chunk's first slot)
     const uint32_t wrap_bytes = chunk_u * frame_stride_u;
     // the launch's input bytes into the wave's LDS slice, kLrInFrames frames at a time (lean_frames has the reasons)
     using InT = typename VecOf<uint8_t, N>::type;
@@ -750,10 +752,7 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
         seg += frame_stride_u;
-        if (++ridx == chunk_u) {
-            ridx = 0u;
-            seg -= wrap_bytes;
-        }
+        if (__builtin_expect(i == wrap_at, 0)) seg -= wrap_bytes;  // (a branch, not selects: taken once per chunk at most)
     }
     if (lane < nb) {
         uint32_t s = slot0 + lane;

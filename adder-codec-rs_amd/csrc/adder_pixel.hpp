@@ -1326,7 +1326,9 @@ ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t tag8 /* unit <<
     p.base = v;  // (unchanged without a flush)
     const M zero = L::from(v == 0u);  // the root's sum stays 0 exactly when the run's intensity is 0 (:449)
     fl.c = L::not_(L::or_(popped, zero));  // need_to_pop_top: the root has accumulated time_spanned >= delta_t_max
-    p.rho = L::lane(fl.c) ? 0u : (L::lane(L::andnot(has1, zero)) ? p.rho + 1u : 1u);
+    // (two plain selects: rho + 1 where the root goes on accumulating, 1 where it starts, 0 where pop_top takes it)
+    const uint32_t grown = (L::lane(L::andnot(has1, zero)) ? p.rho : 0u) + 1u;
+    p.rho = L::lane(fl.c) ? 0u : grown;
     p.popped = L::or_(popped, fl.c);
     w8 = tag8 | (old_base << kLr8BaseShift) | (v << kLean8InShift) | (L::lane(fl.a) ? kLeanA : 0u) |
          (L::lane(fl.b) ? kLeanB : 0u) | (L::lane(fl.c) ? kLeanC : 0u);
