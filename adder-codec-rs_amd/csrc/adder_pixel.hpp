@@ -1373,6 +1373,152 @@ ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, f
     return hdr_make(p.base, bd, p.rho != 0u ? 1u : 0u, L::lane(p.popped));
 }
 
+// ---------------------------------------------------------------------------------------
+// RUN RECORDS: the bounded Collapse regime (delta_t_max > time_spanned) under the constant-run conditions, with the
+// whole step in integers -- what LEAN RUNS does for the lean regime.  A unit is {base_val, n, r1, popped_dtm} (n = the
+// frames the root has accumulated, r1 = frames since it last fired) and, in AbsoluteT, lq = last_fired_t / T.  The frame
+// kernel only decides WHAT happens -- a flush of (base_val, n), a collapsed flush, pop_top -- counts the events (a table
+// of chain lengths) and parks one 12-byte record per happening; the expansion works the events out, densely:
+// the flushed arena is the chain r_0 = n, r_{k+1} = r_k - j_k of cr_node(base_val, r_k).
+// AbsoluteT needs last_fired_t per unit, and it stays an integer too when time_spanned == ref_time >= 255 (every framed
+// source, framed.rs:101-109): last_fired_t is a multiple L T, an event's best delta_t lies in ((j-1) T, j T] with
+// T q >= T / 255 >= 1, so t = trunc(bdt + L T) lies in [L T + (j-1) T + 1, L T + j T] and delta_t_to_absolute_t's
+// round-up (:122-129) gives (L + j) T: every event advances L by its node's last firing j.  Over a flushed chain the j_k
+// telescope to n (the run's length), pop_top advances L by n - r1, a collapsed flush sets L to the frame's index (:257).
+// The expansion redoes the same chain to give event k its own L_k.  tests/cpu_sim checks every intensity, run length and
+// both time modes against the literal oracle.
+// record {n | r1 << 17, lq, kind | unit << 2 | base_val << 9 | events << 17}: kind 1 flush, 2 collapsed flush, 3 pop_top
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kRrFlush = 1u, kRrCollapsed = 2u, kRrPop = 3u;
+constexpr uint32_t kRrUnitShift = 2, kRrBaseShift = 9, kRrCountShift = 17, kRrR1Shift = 17;
+constexpr uint32_t kRrTabRows = 32;  // chain lengths tabulated for r1 < 32 (delta_t_max up to 32 frames; beyond: worked out)
+ADDER_HD void rr_build_tab(uint8_t *tab, float T) {  // tab[I * kRrTabRows + r] = levels of a chain that starts at run r
+    for (uint32_t I = 0; I < 256u; ++I)
+        for (uint32_t r = 0; r < kRrTabRows; ++r) tab[I * kRrTabRows + r] = (uint8_t)((I == 0u || r == 0u) ? 0u : cr_depth((float)I, r, T) - 1u);
+}
+template <class L>
+struct RrPxT {
+    uint32_t base, n, r1, lq;
+    typename L::Mask popped;
+};
+using RrPx = RrPxT<ScalarLanes>;
+
+template <class L>
+ADDER_HD RrPxT<L> rr_unpack(uint32_t hdr, float dt, float lastf, float T, bool abs_t) {
+    RrPxT<L> p;
+    p.base = hdr & 0xffu;
+    const bool popped = (hdr & kHdrPopped) != 0u;
+    p.popped = L::from(popped);
+    p.n = hdr_m(hdr) == 0u ? 0u : (p.base != 0u ? (uint32_t)fdiv(dt, T) : 1u);
+    p.r1 = 0u;
+    if (hdr_m(hdr) > 1u && !popped && p.base != 0u) {  // r1 = n - the root's last firing = ceil(2^(d-1) / I)
+        const float thr = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
+        const float qj = fdiv_small(fmul(0.5f, thr), (float)p.base);
+        uint32_t j = (uint32_t)qj;
+        j += (float)j < qj ? 1u : 0u;
+        p.r1 = p.n - j;
+    }
+    p.lq = abs_t ? (uint32_t)fdiv(lastf, T) : 0u;
+    return p;
+}
+// One frame of one unit: the record's three words (valid iff count != 0) and the number of events it stands for.
+// frame_idx = running_t / T before this frame; n_pop = ceil(delta_t_max / T) >= 2; levels(I, r1) = the chain's length.
+template <bool ABS_T, class L, class Levels>
+ADDER_HD void rr_step(RrPxT<L> &p, uint32_t v, uint32_t frame_idx, uint32_t n_pop, const Levels &levels, uint32_t tag,
+                      uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &count) {
+    using M = typename L::Mask;
+    const M flush = L::from(v != p.base);
+    const M has = L::from(p.n != 0u);
+    const M flushed = L::and_(flush, has);
+    const M collapsed = L::and_(flushed, p.popped);
+    count = 0u;
+    uint32_t kind = 0u, rn = p.n, rbase = p.base;
+    w1 = p.lq;
+    if (L::lane(flushed)) {
+        count = L::lane(collapsed) ? 2u : 1u + (p.r1 != 0u ? levels(p.base, p.r1) : 0u);
+        kind = L::lane(collapsed) ? kRrCollapsed : kRrFlush;
+        if (ABS_T) p.lq = L::lane(collapsed) ? frame_idx : p.lq + p.n;
+    }
+    const M popped1 = L::andnot(p.popped, flush);
+    const M has1 = L::andnot(has, flush);
+    const M zero = L::from(v == 0u);
+    p.base = v;
+    const uint32_t n1 = (L::lane(L::andnot(has1, zero)) ? p.n : 0u) + 1u;
+    const uint32_t P = n1 * v, Q = P - v;
+    const M fires = L::from((P ^ Q) > Q);  // n1 v crossed a power of two (or n1 == 1): the root fires this frame
+    const uint32_t r1n = L::lane(L::or_(L::or_(fires, popped1), zero)) ? 0u : p.r1 + 1u;
+    const M need_pop = L::andnot(L::andnot(L::from(n1 >= n_pop), popped1), zero);  // :394-396
+    if (L::lane(need_pop)) {  // (never in a frame that flushed: a new run starts at n = 1 < n_pop)
+        count = 1u;
+        kind = kRrPop;
+        rn = n1;
+        rbase = v;
+        w1 = p.lq;
+        if (ABS_T) p.lq += n1 - r1n;  // the popped root's last firing
+    }
+    p.n = L::lane(need_pop) ? r1n : n1;   // pop_top: level 1 (run r1) becomes the root, deeper levels are dropped
+    p.r1 = L::lane(need_pop) ? 0u : r1n;
+    p.popped = L::or_(popped1, need_pop);
+    w0 = rn;
+    w2 = kind | tag | (rbase << kRrBaseShift) | (count << kRrCountShift);
+}
+// Event k of a record, walking the chain: the caller keeps (r, lq) between calls, starting from (n, w1).
+struct RrEvent {
+    uint32_t d, t;
+};
+template <bool ABS_T>
+ADDER_HD RrEvent rr_event(uint32_t kind, uint32_t Iu, uint32_t k, uint32_t &r, uint32_t &lq, float T, uint32_t running_t_u32) {
+    RrEvent e;
+    if (kind == kRrCollapsed && k != 0u) {
+        e.d = kDEmpty;
+        e.t = running_t_u32;
+        return e;
+    }
+    float bdt = T;
+    uint32_t j = 1u;
+    e.d = kDZero;
+    if (Iu != 0u) {
+        const CrNode n = cr_node((float)Iu, r, T);
+        bdt = n.bdt;
+        j = n.j;
+        e.d = lean_bd_from_thr(f32_to_bits(n.thr));
+    }
+    e.t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)lq, T)) : bdt);
+    r -= j;
+    lq += j;
+    return e;
+}
+// back to the resident form: the root's planes; the levels through store(k, Node) (cr_materialize's contract); returns the header
+template <class L, class Store>
+ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, float &bdt, float &lastf, Store &store) {
+    CrPxT<L> c;
+    c.base = p.base;
+    c.r1 = p.r1;
+    c.has = L::from(p.n != 0u);
+    c.popped = p.popped;
+    c.S = c.dt0 = c.bdt0 = c.thr0 = 0.0f;
+    uint32_t bd = 0u;
+    if (p.n != 0u) {
+        if (p.base != 0u) {
+            const CrNode n = cr_node((float)p.base, p.n, T);
+            c.S = fmul((float)p.n, (float)p.base);
+            c.dt0 = fmul((float)p.n, T);
+            c.bdt0 = n.bdt;
+            c.thr0 = n.thr;
+            bd = lean_bd_from_thr(f32_to_bits(n.thr));
+        } else {
+            c.bdt0 = T;
+            bd = kDZero;
+        }
+    }
+    const uint32_t m = cr_materialize<L>(c, T, store);
+    integ = c.S;
+    dt = c.dt0;
+    bdt = c.bdt0;
+    lastf = fmul((float)p.lq, T);
+    return hdr_make(p.base, bd, m < kHdrMMask ? m : kHdrMMask, L::lane(p.popped));
+}
+
 // The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
 // the planes the other steps read: store(k, Node).  Returns m.
 template <class L, class Store>
