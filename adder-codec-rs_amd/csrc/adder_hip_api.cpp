@@ -162,6 +162,7 @@ struct AdderHipCtx {
     // share the batches' word (a capacity flag of theirs would be charged to an unrelated batch, and clearing theirs
     // could erase a flag a batch in flight raised)
     uint64_t *d_side_words = nullptr;
+    uint8_t *d_rr_tab = nullptr;  // [256][kRrTabRows] chain lengths of the run-records step (built at its first batch)
     // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
     bool records_only = false;        // the batch being queued stops after its scan
     float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
@@ -321,6 +322,7 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_side_words) (void)hipFree(c->d_side_words);
+    if (c->d_rr_tab) (void)hipFree(c->d_rr_tab);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
     for (hipEvent_t e : c->band_desc_e)
@@ -474,6 +476,10 @@ static int init_state(AdderHipCtx *c) {
 
 
 static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind);
+static bool env_flag(const char *name) {
+    const char *e = getenv(name);
+    return e && atoi(e) != 0;
+}
 
 // BatchArgs followed (256-byte aligned) by the frame table, on the device and in page-locked host memory
 constexpr size_t kBatchDescBytes = (sizeof(BatchArgs) + 255) & ~(size_t)255;
@@ -1399,19 +1405,31 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         (c->cr_time != 0.0f && c->cr_time != time_spanned))
         c->cr_valid = false;
     c->cr_time = time_spanned;
-    static const bool cr_off = [] { const char *e = getenv("ADDER_HIP_NO_CR"); return e && atoi(e) != 0; }();
+    const bool cr_off = env_flag("ADDER_HIP_NO_CR");  // (read per batch: the tests switch kernels inside one process)
     const bool cr = cb && c->cr_valid && !cr_off;  // ... then only the roots are stepped (adder_cr_kernel)
+    // run records (adder_rr_kernel): the same regime with integer state while n * 255 and n * time_spanned stay exact in
+    // binary32; AbsoluteT also wants last_fired_t on multiples of time_spanned (time_spanned == ref_time >= 255)
+    const bool rr_off = env_flag("ADDER_HIP_NO_RR");
+    const bool rr = cr && !rr_off &&
+                    (c->p.time_mode != ADDER_TIME_ABSOLUTE_T || (time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u)) &&
+                    (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     // lean runs (adder_lr_kernel): the lean regime in DeltaT under the same property, in blocked batches of events, while
     // rho * 255 and rho * time_spanned stay exact in binary32 (rho <= frames since the reset)
-    static const bool lr_off = [] { const char *e = getenv("ADDER_HIP_NO_LR"); return e && atoi(e) != 0; }();
+    const bool lr_off = env_flag("ADDER_HIP_NO_LR");
     const bool lr = !generic && !c->continuous && collapse && c->p.time_mode == ADDER_TIME_DELTA_T && c->cr_valid && !lr_off &&
                     !c->records_only && !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
-                             (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) |
+                             (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) |
                              ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
+    if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
+        std::vector<uint8_t> tab(256u * kRrTabRows);
+        rr_build_tab(tab.data(), 255.0f);
+        HIPCHK(c, dalloc(&c->d_rr_tab, tab.size()));
+        HIPCHK(c, hipMemcpy(c->d_rr_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    }
     if (c->records_only && (generic || c->continuous || fpath))
         return fail(c, ADDER_E_BAD_PARAMS, "records can be handed out in the lean regime only (Collapse, delta_t_max <= "
                     "time_spanned, no feature mode, no generic batch before): gather events instead");
@@ -1473,7 +1491,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.out = reinterpret_cast<AdderEventPod *>(d_out);
     b.base.out_cap = out_cap;
     b.base.frame_offsets = d_offsets;
-    b.base.lean = (generic || c->continuous) ? 0u : ((variant & 256u) ? 2u : 1u);  // 2: lean-runs records (lr_decode8)
+    b.base.lean = (variant & 512u) ? 3u : (generic || c->continuous) ? 0u : ((variant & 256u) ? 2u : 1u);  // 2: lean-runs records (lr_decode8), 3: run records (rr_event)
     b.base.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
     b.base.sc = make_consts(c, time_spanned);
     b.frames = d_frames;
@@ -1481,7 +1499,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.park_ring = c->park_ring;
     b.park_bytes = c->park_bytes;
     // (a lean batch's region holds one record per unit and frame of the chunk: the same bytes as its fixed slots)
-    b.log_cap = (variant & 64u) ? kWaveUnits * c->chunk : c->log_cap;
+    b.log_cap = (variant & (64u | 512u)) ? kWaveUnits * c->chunk : c->log_cap;  // (run records: <= 12 bytes each in a region of >= 2 * 128 * chunk * 8)
+    b.rr_tab = c->d_rr_tab;
     {
         const bool sd = c->snap.valid && c->snap.deep;  // this batch keeps an undo copy of the levels >= 1
         b.snap_dv_integ = sd ? c->snap.dv_integ : nullptr;

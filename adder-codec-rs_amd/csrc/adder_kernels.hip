@@ -1763,6 +1763,205 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, run records -- `adder_rr_kernel<ABS_T>`: the bounded Collapse regime under the constant-run conditions with the
+// whole step in integers (adder_pixel.hpp, RUN RECORDS): a unit is {base_val, n, r1, popped} and, in AbsoluteT,
+// last_fired_t / T.  The step is compares, counters and one multiply; a flush / collapsed flush / pop_top parks ONE record
+// of 8 (DeltaT) or 12 bytes, whatever the number of events it stands for (a byte table of chain lengths gives the count),
+// and the expansion works the events out.  Loads the header and delta_t (and last_fired_t) planes, stores the level-0
+// planes and the levels in their resident form.  Records go to the segment's log of the chunk (at most one per unit and
+// frame: a region of 128 * chunk records cannot overflow), the expansion is the lean one over logs (format 3).
+// ------------------------------------------------------------------------------------------
+#ifndef ADDER_RR_WAVES_PER_SIMD
+#define ADDER_RR_WAVES_PER_SIMD 6
+#endif
+constexpr uint32_t kRrInFrames = 32;
+template <bool ABS_T, bool FULL>
+__device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
+                                               uint32_t gw, uint32_t lane, uint8_t *lds_in, const uint8_t *lds_tab) {
+    constexpr uint32_t N = kUnitsPerLane;
+    constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
+    constexpr uint32_t REC = ABS_T ? 12u : 8u;
+    using L = WaveLanes;
+    const float T = a.sc.time_spanned;
+    RrPxT<L> px[N];
+    {
+        uint32_t hdrv[N];
+        float dv[N], lfv[N];
+        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
+        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
+        if (ABS_T) load_vec<ADDER_NT_STATE != 0>(a.lastf, u0, lfv);
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) px[j] = rr_unpack<L>(hdrv[j], dv[j], ABS_T ? lfv[j] : 0.0f, T, ABS_T);
+        if (snap_deep_wanted(b, a)) {  // the undo copy takes the levels as the planes have them
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) snap_deep_levels(b, a, (size_t)u0 + j, hdr_m(hdrv[j]));
+        }
+    }
+    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
+    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
+    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
+    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
+    const uint32_t f0 = __builtin_amdgcn_readfirstlane(a.frame_idx);
+    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(f0 % slots_u);
+    const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
+    // frames since the reset before this launch, and the frames after which the root is popped (:394-396)
+    const uint32_t frame0 = __builtin_amdgcn_readfirstlane((uint32_t)fdiv(a.sc.running_t, T));
+    const uint32_t Tu = __builtin_amdgcn_readfirstlane((uint32_t)T);
+    const uint32_t n_pop = __builtin_amdgcn_readfirstlane(((uint32_t)a.sc.dtm_f + Tu - 1u) / Tu);
+    // the segment's log of the chunk
+    const uint32_t cir = slot0 / chunk_u;  // (a launch never crosses a chunk boundary)
+    const size_t seg_idx = (size_t)cir * num_waves_u + sgw;
+    const uint32_t cap = __builtin_amdgcn_readfirstlane(b->log_cap);
+    uint8_t *const region = uniform_ptr(b->park_ring) + seg_idx * cap * REC;
+    uint32_t *const wcur_p = uniform_ptr(b->wcur) + seg_idx;
+    uint32_t cur = 0u;
+    if (slot0 != cir * chunk_u) cur = __builtin_amdgcn_readfirstlane(*wcur_p);  // not the chunk's first launch
+    // the launch's input bytes into the wave's LDS slice, kRrInFrames frames at a time (lr_frames has the reasons)
+    using InT = typename VecOf<uint8_t, N>::type;
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame of the group][lane]
+    const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
+    static_assert(kWaveUnits == 128u && kRrInFrames % 8u == 0u && NB_MAX % kRrInFrames == 0u, "eight frames of one segment per instruction");
+    const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
+                        __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
+    auto stage = [&](uint32_t k0) {  // frames [k0, k0 + kRrInFrames) of the launch
+        if (direct) {
+            const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
+#pragma unroll
+            for (uint32_t g = 0; g < kRrInFrames / 8u; ++g) {
+                uint32_t k = k0 + g * 8u + (lane >> 3);
+                k = k < nb ? k : nb - 1u;
+                __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
+                                                 (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                                 ADDER_NT_INPUT ? 2 : 0);
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t q0 = 0; q0 < kRrInFrames; q0 += 8u) {
+                uint32_t vin8[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) {
+                    const uint32_t k = k0 + q0 + q;
+                    const uint32_t kk = k < nb ? k : nb - 1u;
+                    vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(q0 + q) * kWave] = (InT)vin8[q];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing else inside the frame loop waits on memory
+    };
+    const auto levels = [&](uint32_t I, uint32_t r1) -> uint32_t {
+        if (r1 < kRrTabRows) return lds_tab[I * kRrTabRows + r1];
+        return cr_depth((float)I, r1, T) - 1u;  // (delta_t_max beyond 32 frames and a root that has not fired for that long)
+    };
+    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
+    bool active[N];
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) active[j] = FULL || u0 + j < n_units_u;
+    for (uint32_t i = 0; i < nb; ++i) {
+        if ((i % kRrInFrames) == 0u) stage(i);
+        const uint32_t vin_w = (uint32_t)in_lds[(i % kRrInFrames) * kWave];
+        uint32_t w0[N], w1[N], w2[N], cnt[N];
+        uint64_t mrec[N];
+        uint32_t lane_cnt = 0u, nrec = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            rr_step<ABS_T, L>(px[j], (vin_w >> (8 * j)) & 0xffu, frame0 + i, n_pop, levels, (lane * N + j) << kRrUnitShift,
+                              w0[j], w1[j], w2[j], cnt[j]);
+            if (!FULL) cnt[j] = active[j] ? cnt[j] : 0u;  // padding units: stepped freely, no events
+            mrec[j] = L::from(cnt[j] != 0u);
+            nrec += (uint32_t)__popcll(mrec[j]);
+            lane_cnt += cnt[j];
+        }
+        const uint32_t nev = __builtin_amdgcn_readlane(wave_inclusive_scan_dpp(lane_cnt), kWave - 1);
+        uint32_t pos = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j)
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mrec[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mrec[j], pos));
+        uint8_t *const seg = region + (size_t)cur * REC;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            const bool has = L::lane(mrec[j]);
+            if (has) {
+                if (ABS_T) {
+                    struct R12 { uint32_t a, b, c; };
+                    gstore(seg, pos * REC, R12{w0[j], w1[j], w2[j]});
+                } else {
+                    gstore(seg, pos * REC, make_uint2(w0[j], w2[j]));
+                }
+            }
+            pos += has ? 1u : 0u;
+        }
+        wt = lane == i ? (nev | (nrec << 16)) : wt;
+        wo = lane == i ? cur : wo;
+        cur += nrec;
+    }
+    if (lane == 0u) *wcur_p = cur;
+    if (lane < nb) {
+        uint32_t s = slot0 + lane;
+        s = s >= slots_u ? s - slots_u : s;
+        gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
+        gstore<uint32_t>(uniform_ptr(b->wofs_ring), (s * num_waves_u + sgw) * 4u, wo);
+    }
+    {   // state back to HBM in its resident form
+        uint32_t hdrv[N];
+        float iv[N], dv[N], bv[N], lfv[N];
+        bool too_deep = false;
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            struct Store {
+                DeepGlobal g;
+                uint32_t max_depth;
+                bool over;
+                __device__ __forceinline__ void operator()(uint32_t k, const Node &n) {
+                    if (k < max_depth) g.store(k, n);
+                    else over = true;
+                }
+            } st{DeepGlobal{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j}, a.sc.max_depth, false};
+            hdrv[j] = rr_pack<L>(px[j], T, iv[j], dv[j], bv[j], lfv[j], st);
+            too_deep = too_deep || (st.over && active[j]);
+        }
+        if (too_deep) raise(a.status, kStatusDepth);
+        constexpr bool NTS = ADDER_NT_STATE != 0;
+        store_vec<NTS>(a.hdr, u0, hdrv);
+        store_vec<NTS>(a.integ0, u0, iv);
+        store_vec<NTS>(a.dt0, u0, dv);
+        store_vec<NTS>(a.bdt0, u0, bv);
+        if (ABS_T) store_vec<NTS>(a.lastf, u0, lfv);
+        if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j)
+                if (u0 + j < n_units_u && hdr_m(hdrv[j]) != 0u)
+                    a.running[u0 + j] = (uint8_t)frame_value_u8((hdrv[j] >> kHdrBdShift) & 0xffu, f32_as_u32(bv[j]), (double)a.sc.ref_time);
+        }
+    }
+}
+
+template <bool ABS_T>
+__global__ __launch_bounds__(kBlockThreads, ADDER_RR_WAVES_PER_SIMD) void adder_rr_kernel(const BatchArgs *__restrict__ b,
+                                                                                         uint32_t f, uint32_t nb) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kRrInFrames * kWaveUnits];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tab[256 * kRrTabRows];
+    const FrameArgs a = frame_args(b, f);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    timeline_mark(b, 0u, f, false);
+    {   // the table of chain lengths (8 KB, the same for every launch: it comes out of L2)
+        const uint4 *const src = reinterpret_cast<const uint4 *>(b->rr_tab);
+        uint4 *const dst = reinterpret_cast<uint4 *>(s_tab);
+        for (uint32_t k = tid; k < 256u * kRrTabRows / 16u; k += kBlockThreads) dst[k] = src[k];
+        __syncthreads();
+    }
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
+        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
+        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
+        if (full) rr_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab);
+        else rr_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab);
+    }
+    timeline_mark(b, 0u, f, true);
+}
+
+// ------------------------------------------------------------------------------------------
 // K1, Mode::Continuous: the general arena step (adder_pixel.hpp cont_step), a unit's nodes
 // straight from / to the node planes.  A first, correct version -- the sources that use this mode are sparse
 // event cameras; nothing here is tuned.  A unit's events cannot be counted before they are produced, so they
@@ -2106,7 +2305,8 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
 
 template <int FORMAT, bool ABS_T>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3;  // (3: lean records in per-segment logs, variant bit 64)
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
+    constexpr bool RR = FORMAT == 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
     // only the frame-independent part of the arguments is needed here
@@ -2126,7 +2326,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const ParkLayout lay = park_layout_u(b);
     // lean records of blocked batches lie in per-segment logs like the per-event ones (log_cap records per segment and
     // chunk, a frame's run at wofs); batches launched one frame at a time keep a fixed slot per frame
-    constexpr bool lean_log = FORMAT == 3;
+    constexpr bool lean_log = FORMAT == 3 || FORMAT == 4;
     const uint32_t lean_log_cap = lean_log ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
     const uint32_t seg_stride = FORMAT == 0 ? 0u : lean_log ? lean_log_cap * lean_rec_bytes(ABS_T) : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
@@ -2145,7 +2345,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint64_t out_cap = b->base.out_cap;
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
     const float time_spanned_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
-    const bool lean_runs = LEAN && !ABS_T && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u;
+    const bool lean_runs = LEAN && !RR && !ABS_T && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u;
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
     // segments' counts first, then exactly the records they hold (a speculative fetch of 64 records per
@@ -2159,7 +2359,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // parks ~20 records: one 64-lane round per segment would leave two thirds of the lanes idle); a pair
     // with a segment of more than 32 records takes the one-segment-at-a-time path below.
     const uint32_t half = lane >> 5, hl = lane & 31u;
-    uint4 first[LEAN ? kExpandSegs / 2u : kExpandSegs];  // (lean: {ta, tc, w, -})
+    uint4 first[RR ? 1u : LEAN ? kExpandSegs / 2u : kExpandSegs];  // (lean: {ta, tc, w, -}; run records are fetched pair by pair)
     const uint8_t *log0 = nullptr;  // per-event records: the log region of segment seg0, the regions' stride, and
     uint32_t log_stride = 0u;       // where each segment's run of this frame starts inside its region (bytes)
     uint32_t log_run[FORMAT == 0 ? kExpandSegs : 1u];
@@ -2167,17 +2367,23 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     if (LEAN) {
         if (lean_log && lane < kExpandSegs)
             lean_ofs = gload<uint32_t>(uniform_ptr(b->wofs_ring) + (size_t)slot * num_waves + seg0, lane * 4u) * lean_rec_bytes(ABS_T);
-#pragma unroll
-        for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
+        auto fetch_pair = [&](uint32_t p) -> uint4 {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             const uint32_t oa = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p) : 0u;
             const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
-            first[p] = make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                first[p] = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride,
-                                                (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
+                v = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride,
+                                         (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
             }
+            return v;
+        };
+        if constexpr (RR) {
+            first[0] = fetch_pair(0u);
+        } else {
+#pragma unroll
+            for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) first[p] = fetch_pair(p);
         }
     } else if (FORMAT == 0) {
         // per-event records: a segment's run of this frame starts at wofs inside the segment's log of the chunk
@@ -2244,6 +2450,38 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
+    // 64 run records (or none) of ONE segment: every lane walks its record's chain (rr_event), the events of the round
+    // are placed by a scan of the records' counts
+    auto rr_round = [&](const uint4 &rw, uint32_t unit_shift) {
+        const uint32_t w2 = ABS_T ? rw.z : rw.y;
+        const uint32_t cnt = w2 >> kRrCountShift;  // (an all-zero record: no events)
+        const uint32_t incl = wave_inclusive_scan_dpp(cnt);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        const uint32_t first_ev = incl - cnt;
+        const uint32_t kind = w2 & 3u, Iu = (w2 >> kRrBaseShift) & 0xffu;
+        uint32_t c;
+        const uint32_t xy = coord_xy_c(uc, ((w2 >> kRrUnitShift) & 0x7fu) + unit_shift, c);
+        for (uint32_t e0 = 0; e0 < total; e0 += kXbufEvents) {  // (uniform; one pass unless the round outgrows the buffer)
+            const uint32_t piece = total - e0 < kXbufEvents ? total - e0 : kXbufEvents;
+            if (fill + piece > kXbufEvents) flush();
+            uint32_t r = rw.x, lq = rw.y;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const RrEvent e = rr_event<ABS_T>(kind, Iu, k, r, lq, time_spanned_u, rt_u32);
+                const uint32_t pos = first_ev + k;
+                if (pos >= e0 && pos < e0 + piece) {
+                    const uint32_t w = phase + (fill + pos - e0) * 3u;
+                    xb[w] = xy;
+                    xb[w + 1u] = c | (e.d << 8);
+                    xb[w + 2u] = e.t;
+                }
+            }
+            fill += piece;
+        }
+    };
+    auto record_round = [&](const uint4 &rw, uint32_t unit_shift) {
+        if constexpr (RR) rr_round(rw, unit_shift);  // adder_rr_kernel's records: 1 .. depth + 1 events each
+        else lean_round(rw, unit_shift);
+    };
     // (row, offset in row) of the first unit of segment seg0: ONE wave-uniform division; the
     // following segments advance it with scalar add/compare instead of dividing again
     uc.y0 = __builtin_amdgcn_readfirstlane((seg0 * kWaveUnits) / uc.rowlen);
@@ -2255,7 +2493,45 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             ++uc.y0;
         }
     };
-    if (LEAN) {
+    if constexpr (RR) {
+        // run records: a round is a loop over every lane's chain -- the pairs are not unrolled; the next pair's records are
+        // fetched before this pair's round
+        auto fetch_pair_rr = [&](uint32_t p) -> uint4 {
+            const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
+            const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
+            const uint32_t oa = __builtin_amdgcn_readlane(lean_ofs, 2 * p);
+            const uint32_t ob = __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (hl < (half ? pb : pa))
+                v = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
+            return v;
+        };
+        uint4 cur_rec = first[0];
+#pragma unroll 1
+        for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
+            const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
+            const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
+            uint4 next_rec = make_uint4(0u, 0u, 0u, 0u);
+            if (p + 1u < kExpandSegs / 2u) next_rec = fetch_pair_rr(p + 1u);
+            if (pa <= 32u && pb <= 32u) {
+                if (pa + pb != 0u) rr_round(cur_rec, half * kWaveUnits);
+                next_segment();
+                next_segment();
+            } else {
+                const uint32_t cnt2[2] = {pa, pb};
+                for (uint32_t h = 0; h < 2u; ++h) {
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride + __builtin_amdgcn_readlane(lean_ofs, 2 * p + h);
+                    for (uint32_t i0 = 0; i0 < cnt2[h]; i0 += kWave) {  // uniform trip count
+                        uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+                        if (i0 + lane < cnt2[h]) rw = lean_load_rec<ABS_T>(seg_park, (i0 + lane) * lean_rec_bytes(ABS_T));
+                        rr_round(rw, 0u);
+                    }
+                    next_segment();
+                }
+            }
+            cur_rec = next_rec;
+        }
+    } else if (LEAN) {
 #pragma unroll
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
@@ -2265,7 +2541,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 if (fill + 3u * kWave > kXbufEvents) flush();
                 fill += (__builtin_amdgcn_readlane(my_tot, 2 * p) & 0xffffu) + (__builtin_amdgcn_readlane(my_tot, 2 * p + 1) & 0xffffu);
 #else
-                if (pa + pb != 0u) lean_round(first[p], half * kWaveUnits);
+                if (pa + pb != 0u) record_round(first[p], half * kWaveUnits);
 #endif
                 next_segment();
                 next_segment();
@@ -2280,7 +2556,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                         if (i0 + lane < cnt[h]) {
                             rw = lean_load_rec<ABS_T>(seg_park, (i0 + lane) * lean_rec_bytes(ABS_T));
                         }
-                        lean_round(rw, 0u);
+                        record_round(rw, 0u);
                     }
                     next_segment();
                 }
@@ -2899,6 +3175,12 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         else hipLaunchKernelGGL((adder_cont_kernel<false>), dim3(S), dim3(kBlockThreads), 0, stream, b, f, nb);
         return hipGetLastError();
     }
+    if (variant & 512u) {  // run records (the bounded Collapse regime at c_thresh 0, integer state)
+        const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
+        if (abs_t) hipLaunchKernelGGL((adder_rr_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_rr_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+        return hipGetLastError();
+    }
     if (variant & 128u) {  // constant runs (the bounded Collapse regime at c_thresh 0)
         const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
         if (abs_t) hipLaunchKernelGGL((adder_cr_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
@@ -3004,6 +3286,10 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     const dim3 grid(total);
     const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u;
     if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    else if (variant & 512u) {  // run records in per-segment logs
+        if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<4, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+        else hipLaunchKernelGGL((adder_expand_kernel<4, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    }
     else if (generic && (variant & 32u)) hipLaunchKernelGGL((adder_expand_kernel<0, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
     else if (variant & 64u) {

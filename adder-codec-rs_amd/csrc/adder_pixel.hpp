@@ -1387,10 +1387,11 @@ ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, f
 // telescope to n (the run's length), pop_top advances L by n - r1, a collapsed flush sets L to the frame's index (:257).
 // The expansion redoes the same chain to give event k its own L_k.  tests/cpu_sim checks every intensity, run length and
 // both time modes against the literal oracle.
-// record {n | r1 << 17, lq, kind | unit << 2 | base_val << 9 | events << 17}: kind 1 flush, 2 collapsed flush, 3 pop_top
+// record {n, lq, kind | unit << 2 | base_val << 9 | events << 17} (DeltaT: {n, the third word}): kind 1 flush, 2 collapsed
+// flush, 3 pop_top
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kRrFlush = 1u, kRrCollapsed = 2u, kRrPop = 3u;
-constexpr uint32_t kRrUnitShift = 2, kRrBaseShift = 9, kRrCountShift = 17, kRrR1Shift = 17;
+constexpr uint32_t kRrUnitShift = 2, kRrBaseShift = 9, kRrCountShift = 17;
 constexpr uint32_t kRrTabRows = 32;  // chain lengths tabulated for r1 < 32 (delta_t_max up to 32 frames; beyond: worked out)
 ADDER_HD void rr_build_tab(uint8_t *tab, float T) {  // tab[I * kRrTabRows + r] = levels of a chain that starts at run r
     for (uint32_t I = 0; I < 256u; ++I)
@@ -1488,6 +1489,27 @@ ADDER_HD RrEvent rr_event(uint32_t kind, uint32_t Iu, uint32_t k, uint32_t &r, u
     lq += j;
     return e;
 }
+// The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
+// the planes the other steps read: store(k, Node).  Returns m.
+template <class L, class Store>
+ADDER_HD uint32_t cr_materialize(const CrPxT<L> &s, float T, Store &store) {
+    if (!L::lane(s.has)) return 0u;
+    uint32_t m = 1u;
+    if (L::lane(s.popped)) return m;
+    const float I = (float)s.base;
+    for (uint32_t r = s.r1; r != 0u; ++m) {
+        const CrNode n = cr_node(I, r, T);
+        Node nd;
+        nd.integ = fmul((float)r, I);
+        nd.dt = fmul((float)r, T);
+        nd.bdt = n.bdt;
+        nd.bd = lean_bd_from_thr(f32_to_bits(n.thr));
+        store(m, nd);
+        r -= n.j;
+    }
+    return m;
+}
+
 // back to the resident form: the root's planes; the levels through store(k, Node) (cr_materialize's contract); returns the header
 template <class L, class Store>
 ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, float &bdt, float &lastf, Store &store) {
@@ -1517,27 +1539,6 @@ ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, f
     bdt = c.bdt0;
     lastf = fmul((float)p.lq, T);
     return hdr_make(p.base, bd, m < kHdrMMask ? m : kHdrMMask, L::lane(p.popped));
-}
-
-// The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
-// the planes the other steps read: store(k, Node).  Returns m.
-template <class L, class Store>
-ADDER_HD uint32_t cr_materialize(const CrPxT<L> &s, float T, Store &store) {
-    if (!L::lane(s.has)) return 0u;
-    uint32_t m = 1u;
-    if (L::lane(s.popped)) return m;
-    const float I = (float)s.base;
-    for (uint32_t r = s.r1; r != 0u; ++m) {
-        const CrNode n = cr_node(I, r, T);
-        Node nd;
-        nd.integ = fmul((float)r, I);
-        nd.dt = fmul((float)r, T);
-        nd.bdt = n.bdt;
-        nd.bd = lean_bd_from_thr(f32_to_bits(n.thr));
-        store(m, nd);
-        r -= n.j;
-    }
-    return m;
 }
 
 // ---------------------------------------------------------------------------------------

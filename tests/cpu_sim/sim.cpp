@@ -458,6 +458,81 @@ int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
+// One temporally blocked launch of the RUN-RECORDS step (rr_step / rr_event / rr_pack): integer state, one record per
+// happening, the events worked out from the records as the expansion does.  -7 outside its regime (the constant-run
+// conditions; AbsoluteT also wants time_spanned == ref_time >= 255).
+int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!sim_cb_possible(s, T) || s->c_thresh != 0 || s->c_max != 0) return -7;
+    if (s->abs_t && (T != (float)s->ref_time || s->ref_time < 255u)) return -7;
+    s->generic_sticky = 1;
+    const uint32_t Tu = (uint32_t)T;
+    const uint32_t n_pop = (s->dtm + Tu - 1u) / Tu;
+    std::vector<uint8_t> tab(256 * kRrTabRows);
+    rr_build_tab(tab.data(), T);
+    auto levels = [&](uint32_t I, uint32_t r1) -> uint32_t {
+        return r1 < kRrTabRows ? tab[I * kRrTabRows + r1] : cr_depth((float)I, r1, T) - 1u;
+    };
+    const uint32_t frame0 = (uint32_t)(s->running_t / T);
+    std::vector<std::vector<SimEvent>> per_frame(nb);
+    int rc = 0;
+    size_t u = 0;
+    for (uint32_t y = 0; y < s->H; y++)
+        for (uint32_t x = 0; x < s->W; x++)
+            for (uint32_t c = 0; c < s->C; c++, u++) {
+                const uint32_t hdr = s->hdr[u];
+                const uint32_t m0 = hdr_m(hdr);
+                RrPx p = rr_unpack<ScalarLanes>(hdr, m0 ? s->dt0[u] : -777.0f, s->abs_t ? s->lastf[u] : -1.0f, T, s->abs_t != 0);
+                for (uint32_t i = 0; i < nb; ++i) {
+                    uint32_t w0, w1, w2, count;
+                    if (s->abs_t) rr_step<true>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, levels, 0u, w0, w1, w2, count);
+                    else rr_step<false>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, levels, 0u, w0, w1, w2, count);
+                    s->cb_steps++;
+                    if (count == 0u) continue;
+                    // the expansion's side: everything from the three words
+                    const uint32_t kind = w2 & 3u, Iu = (w2 >> kRrBaseShift) & 0xffu, cnt = w2 >> kRrCountShift;
+                    if (cnt != count) s->plan_mismatch++;
+                    uint32_t r = w0, lq = w1;
+                    const uint32_t rt_u32 = f32_as_u32(fmul((float)(frame0 + i), T));
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const RrEvent e = s->abs_t ? rr_event<true>(kind, Iu, k, r, lq, T, rt_u32) : rr_event<false>(kind, Iu, k, r, lq, T, rt_u32);
+                        SimEvent ev;
+                        ev.x = (uint16_t)x; ev.y = (uint16_t)(y + s->row_begin); ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)c;
+                        ev.d = (uint8_t)e.d; ev.pad = 0; ev.t = e.t;
+                        per_frame[i].push_back(ev);
+                    }
+                    if (kind == kRrFlush && r != 0u) s->plan_mismatch++;  // the chain must end exactly at the count
+                }
+                DeepAcc deep{s, u};
+                struct Store {
+                    DeepAcc *d;
+                    uint32_t max_depth;
+                    int *rc;
+                    void operator()(uint32_t k, const Node &n) {
+                        if (k < max_depth) d->store(k, n);
+                        else *rc = -5;
+                    }
+                } st{&deep, s->max_depth, &rc};
+                float integ, dt, bdt, lastf;
+                const uint32_t h2 = rr_pack(p, T, integ, dt, bdt, lastf, st);
+                const uint32_t m = hdr_m(h2);
+                if (m > s->max_m) s->max_m = m;
+                s->hdr[u] = h2;
+                if (m > 0) { s->integ0[u] = integ; s->dt0[u] = dt; s->bdt0[u] = bdt; }
+                if (s->abs_t) s->lastf[u] = lastf;
+                if (m != 0u) s->running[u] = (uint8_t)frame_value_u8((h2 >> kHdrBdShift) & 0xffu, f32_as_u32(bdt), (double)s->ref_time);
+            }
+    s->running_t = fmul((float)(frame0 + nb), T);
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i)
+        for (const SimEvent &e : per_frame[i]) {
+            if (pos < cap) out[pos] = e;
+            ++pos;
+        }
+    *n_out = pos;
+    if (pos > cap && rc == 0) rc = -4;
+    return rc;
+}
+
 // One temporally blocked launch of the LEAN-RUNS step (lr_step / lr_decode8 / lr_pack), as adder_lean_kernel's RUNS
 // instantiation and the expansion run it: a unit is {base_val, rho, popped}, event A is worked out from the record.
 // -7 outside its regime (Collapse, delta_t_max <= T, DeltaT, c_thresh 0 with c_thresh_max 0, integer T, no generic batch).

@@ -67,6 +67,8 @@ def lib():
     L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_lr_block.restype = i32
     L.sim_integrate_lr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
+    L.sim_integrate_rr_block.restype = i32
+    L.sim_integrate_rr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_cr_block.restype = i32
     L.sim_integrate_cr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate.restype = i32
@@ -228,6 +230,17 @@ class Sim:
         out = np.zeros(cap, EVENT_DTYPE)
         n = C.c_size_t(0)
         rc = self.L.sim_integrate_cr_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
+                                           C.byref(n))
+        return rc, out[: n.value].copy()
+
+    def integrate_rr_block(self, frames, time_spanned):
+        """nb frames as ONE launch of the run-records step (integer state; events worked out from the records)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), -1)
+        assert frames.shape[1] == self.n
+        cap = self._cap * len(frames)
+        out = np.zeros(cap, EVENT_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.sim_integrate_rr_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
                                            C.byref(n))
         return rc, out[: n.value].copy()
 

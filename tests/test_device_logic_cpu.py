@@ -543,6 +543,95 @@ def test_cr_other_tick_rates_and_its_limits():
     assert sv.integrate_cr_block(clip[:2], 254.5)[0] == -7
 
 
+# ---- run records (rr_step / rr_event / rr_pack: the bounded regime at crf 0 with integer state, both time modes) ----
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_rr_blocked_launches_match_the_oracle(time_mode):
+    """A unit is {base_val, n, r1, popped, last_fired_t / T}; the step parks one record per flush / collapsed flush /
+    pop_top and the events are worked out from the record alone (the chain of cr_node; in AbsoluteT each event advances
+    last_fired_t by its node's last firing).  Launches of every length, every content, against the oracle."""
+    rng = np.random.default_rng(43 + time_mode)
+    for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
+        frames = 170
+        clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, 7, 12, 1, seed=3 + len(kind)))
+        ov, sv = _cb_pair(12, 7, 1, time_mode, 7650, crf=CRFS[0])
+        k, total = 0, 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 2, 3, 7, 29, 30, 31, 64])), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_rr_block(clip[k:k + nb], 255.0)
+            assert rc == 0, (kind, k, rc)
+            assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
+            total += len(got)
+            k += nb
+        assert sv.plan_mismatches == 0 and total > 0
+
+
+def test_rr_every_intensity_and_run_length():
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        for dtm_frames in (30, 40, 3, 2):
+            ov, sv = _cb_pair(256, 1, 1, tm, 255 * dtm_frames, crf=CRFS[0], max_depth=12)
+            frames = []
+            for run in range(1, 46):
+                frames += [np.arange(256, dtype=np.uint8).reshape(1, 256, 1)] * run
+                frames += [((np.arange(256) + 1 + run) % 256).astype(np.uint8).reshape(1, 256, 1)]  # the flush (a 1-frame run)
+            clip = np.stack(frames)
+            k = 0
+            while k < len(clip):
+                nb = min(37, len(clip) - k)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+                rc, got = sv.integrate_rr_block(clip[k:k + nb], 255.0)
+                assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (tm, dtm_frames, k)
+                k += nb
+            assert sv.plan_mismatches == 0
+
+
+def test_rr_interchangeable_with_the_other_steps_mid_stream():
+    clip = clips.make_clip("runs", 260, 6, 8, 3, seed=79)
+    rng = np.random.default_rng(9)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, sv = _cb_pair(8, 6, 3, tm, 7650, crf=CRFS[0])
+        k = 0
+        used = set()
+        while k < len(clip):
+            which = int(rng.integers(0, 4))
+            nb = min(int(rng.choice([1, 2, 5, 17, 33])), len(clip) - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            if which == 0:
+                rc, got = sv.integrate_cr_block(clip[k:k + nb], 255.0)
+            elif which == 1:
+                rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            elif which == 2:
+                rc, got = sv.integrate_rr_block(clip[k:k + nb], 255.0)
+            else:
+                sv.set_use_cb(False)
+                parts = [sv.integrate(clip[k + i], 255.0) for i in range(nb)]
+                sv.set_use_cb(True)
+                rc, got = max(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+            used.add(which)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (tm, k, nb, which)
+            k += nb
+        assert used == {0, 1, 2, 3}
+
+
+def test_rr_other_tick_rates_and_its_limits():
+    clip = clips.make_clip("runs", 200, 4, 6, 1, seed=33)
+    for ref_time, dtm in ((5000, 240000), (1000, 2000), (20, 10000), (255, 6120), (255, 255 * 200), (255, 300)):
+        for tm in (O.DELTA_T, O.ABSOLUTE_T):
+            ov, sv = _cb_pair(6, 4, 1, tm, dtm, ref_time=ref_time, crf=CRFS[0], max_depth=14)
+            if tm == O.ABSOLUTE_T and ref_time < 255:  # T q >= 1 is what keeps last_fired_t on multiples of T
+                assert sv.integrate_rr_block(clip[:2], float(ref_time))[0] == -7
+                continue
+            for k in range(0, 200, 25):
+                want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=float(ref_time)) for i in range(25)])
+                rc, got = sv.integrate_rr_block(clip[k:k + 25], float(ref_time))
+                assert rc == 0 and np.array_equal(want, got), (ref_time, dtm, tm, k)
+    sv = Sim(6, 4, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=7650)
+    sv.set_crf_parameters(7, 7)
+    sv.reset_c_thresh(2)
+    assert sv.integrate_rr_block(clip[:2], 255.0)[0] == -7
+
+
 # ---- lean runs (lr_step / lr_decode8 / lr_pack: the headline regime at crf 0, a unit = {base_val, rho, popped}) ----
 def _lean_pair(W, H, Cn, dtm=255, ref_time=255):
     ov = O.Video(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)

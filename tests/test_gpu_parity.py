@@ -1407,6 +1407,100 @@ def test_cb_kernel_rgb_bands_other_rates_and_fractional_time_fallback():
     hv.close()
 
 
+# ---- the default mode at crf 0: three frame kernels for the same regime (run records, constant runs, bounded Collapse) ----
+_STEP_ENV = {"rr": {}, "cr": {"ADDER_HIP_NO_RR": "1"}, "cb": {"ADDER_HIP_NO_RR": "1", "ADDER_HIP_NO_CR": "1"}}
+
+
+def _use_step(monkeypatch, step):
+    for k in ("ADDER_HIP_NO_RR", "ADDER_HIP_NO_CR"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in _STEP_ENV[step].items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("step", ["rr", "cr", "cb"])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_default_mode_crf0_every_step_kernel(monkeypatch, step, time_mode):
+    """adder_rr_kernel (integer state, one record per flush / pop, the events worked out by the expansion), adder_cr_kernel
+    and adder_cb_kernel on the same ragged clips in batches of every shape: every event equals the oracle's."""
+    _use_step(monkeypatch, step)
+    rng = np.random.default_rng(70 + time_mode)
+    W, H, frames = 333, 41, 330
+    for kind in ("scene", "runs", "jitter", "dark", "noise"):
+        clip = (O.synth_clip(O.CONTENT_SCENE, W, H, 1, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, H, W, 1, seed=11 + len(kind)))
+        ov, hv = _cb_pair(W, H, 1, time_mode, 7650, crf=CRFS[0])
+        k, total = 0, 0
+        while k < frames:
+            nb = min(int(rng.choice([1, 2, 29, 31, 64, 65, 130])), frames - k)
+            want = [ov.integrate_matrix(clip[k + i]) for i in range(nb)]
+            got, offs = hv.integrate_batch(clip[k:k + nb])
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (kind, k, nb)
+            assert np.array_equal(got, np.concatenate(want)), (kind, k, nb)
+            total += len(got)
+            k += nb
+        assert total > 0
+        hv.close()
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_default_mode_crf0_step_kernels_interleave_in_one_stream(monkeypatch, time_mode):
+    """All three keep the planes in the same resident form: any of them may take the next batch of a stream (rgb, a band
+    of the plane, 1 .. 100 frames per batch)."""
+    rng = np.random.default_rng(5 + time_mode)
+    clip = clips.make_clip("runs", 300, 24, 50, 3, seed=13)
+    A = _hip()
+    ov = O.Video(50, 24, 3, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+    hv = A.HipVideo(50, 24, 3, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=7650)
+    ov.ensure_capacity(22)
+    for v in (ov, hv):
+        v.set_crf_parameters(CRFS[0][1], CRFS[0][2])
+        v.reset_c_thresh(CRFS[0][0])
+    k, used = 0, set()
+    while k < len(clip):
+        step = ("rr", "cr", "cb")[int(rng.integers(0, 3))]
+        _use_step(monkeypatch, step)
+        used.add(step)
+        nb = min(int(rng.choice([1, 3, 17, 64, 100])), len(clip) - k)
+        want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+        got, _ = hv.integrate_batch(clip[k:k + nb])
+        assert np.array_equal(got, want), (k, nb, step)
+        k += nb
+    assert used == {"rr", "cr", "cb"}
+    hv.close()
+
+
+def test_run_records_long_runs_deep_chains_other_rates_and_depth():
+    """delta_t_max of 500 frames: roots that have not fired for more than the table's 32 rows (the chain length is worked
+    out), records of eight and more events, rounds of the expansion that outgrow its staging buffer; other tick rates (in
+    AbsoluteT the step needs time_spanned == ref_time >= 255, else the constant-run kernel takes the batch); a max_depth
+    below the chain is reported."""
+    A = _hip()
+    frames = 560
+    clip = clips.make_clip("static", frames, 9, 70, 1, seed=4)
+    clip[300:] = 255 - clip[300:]
+    clip[520:] = clip[0]
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, hv = _cb_pair(70, 9, 1, tm, 255 * 500)
+        for k in range(0, frames, 70):
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(70)])
+            got, _ = hv.integrate_batch(clip[k:k + 70])
+            assert np.array_equal(got, want), (tm, k)
+        hv.close()
+    _, hv = _cb_pair(70, 9, 1, O.DELTA_T, 255 * 500, max_depth=3)
+    with pytest.raises(A.AdderHipError, match="max_depth"):
+        hv.integrate_batch(clip[:40])
+    hv.close()
+    clip = clips.make_clip("runs", 96, 24, 50, 3, seed=12)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        for ref_time, dtm in ((255, 7650), (5000, 240000), (20, 10000), (255, 510)):
+            ov, hv = _cb_pair(50, 24, 3, tm, dtm, ref_time=ref_time)
+            want = np.concatenate([ov.integrate_matrix(f, time_spanned=float(ref_time)) for f in clip])
+            got, _ = hv.integrate_batch(clip, time_spanned=float(ref_time))
+            assert np.array_equal(got, want), (tm, ref_time)
+            hv.close()
+
+
 def test_frame_ring_warm_submits_return_quickly():
     """framed.rs:127-157 calls integrate_matrix once per decoded frame: adder_hip_frame_submit only QUEUES a frame
     (upload, kernels, hand-over) and must come back at once.  The first submits of a process pay for the slots'
