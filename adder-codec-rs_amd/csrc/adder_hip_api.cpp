@@ -936,6 +936,8 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
         return fail(c, ADDER_E_BAD_PARAMS, "wire serialisation: an event without a channel on a multi-channel plane");
     if (st & kStatusSparse) return fail(c, ADDER_E_BAD_PARAMS, "a sparse step names a pixel outside the plane / row band");
     if (st & kStatusScratch) return fail(c, ADDER_E_HIP, "internal error: a segment's record log exceeded its bound");
+    if (st & kStatusLeanRuns)
+        return fail(c, ADDER_E_HIP, "internal error: the lean-runs kernel met state planes outside its regime (popped_dtm != (base_val != 0))");
     return fail(c, ADDER_E_OUT_CAPACITY, "event buffer too small");
 }
 

@@ -48,6 +48,7 @@ constexpr uint32_t kStatusWire = 4u;      // wire serialisation met c = None on 
 constexpr uint32_t kStatusDepth = 2u;     // a pixel needed more than max_depth stored levels
 constexpr uint32_t kStatusSparse = 8u;    // a sparse step names a pixel outside the plane / band
 constexpr uint32_t kStatusScratch = 16u;  // a segment's record log did not hold its bound (an internal error)
+constexpr uint32_t kStatusLeanRuns = 32u; // adder_lr_kernel met a unit whose popped_dtm is not (base_val != 0) (an internal error)
 
 struct AdderEventPod {  // same layout as AdderEvent (include/adder_hip.h)
     uint16_t x, y;

@@ -650,8 +650,9 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 #ifndef ADDER_LR_IN_FRAMES
 #define ADDER_LR_IN_FRAMES 32
 #endif
-// input frames staged at a time: the step needs ~46 registers, so the wave's LDS slice decides the occupancy -- 32 frames
-// (4 KB per wave, 16 KB per workgroup) leave room for 8 waves per SIMD at the price of one more vmcnt(0) per launch
+// input frames in the wave's LDS slice (two groups of half as many, one being stepped, one on its way): the step needs ~46
+// registers, so the slice decides the occupancy -- 32 frames (4 KB per wave, 16 KB per workgroup) leave room for 8 waves
+// per SIMD
 constexpr uint32_t kLrInFrames = ADDER_LR_IN_FRAMES;
 template <bool FULL>
 __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
@@ -661,14 +662,6 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
     using L = WaveLanes;
     const float T = a.sc.time_spanned;
     LrPxT<L> px[N];
-    {
-        uint32_t hdrv[N];
-        float dv[N];
-        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
-        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) px[j] = lr_unpack<L>(hdrv[j], dv[j], T);
-    }
     const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
     const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
     const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
@@ -684,27 +677,32 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
     const uint32_t ridx0 = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
     const uint32_t wrap_at = chunk_u - 1u - ridx0;  // (after this frame of the launch the walk returns to the chunk's first slot)
     const uint32_t wrap_bytes = chunk_u * frame_stride_u;
-    // the launch's input bytes into the wave's LDS slice, kLrInFrames frames at a time (lean_frames has the reasons)
+    // The launch's input bytes go through the wave's LDS slice in groups of kLrGroup frames, ONE GROUP AHEAD: the slice
+    // holds two groups, the loads of group g + 1 are issued when group g starts and waited for when it ends -- a wave never
+    // sits out a memory round trip inside the loop (the waves of a CU start together and met those waits together).  The
+    // first two groups are issued before the state's planes are even asked for.
     using InT = typename VecOf<uint8_t, N>::type;
-    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame of the group][lane]
+    InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame % kLrInFrames][lane]
     const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-    static_assert(kWaveUnits == 128u && kLrInFrames % 8u == 0u && NB_MAX % kLrInFrames == 0u, "eight frames of one segment per instruction");
+    constexpr uint32_t kLrGroup = kLrInFrames / 2u;
+    static_assert(kWaveUnits == 128u && kLrGroup % 8u == 0u && NB_MAX % kLrInFrames == 0u, "eight frames of one segment per instruction");
     const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
                         __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
-    auto stage = [&](uint32_t k0) {  // frames [k0, k0 + kLrInFrames) of the launch
+    auto stage_issue = [&](uint32_t k0) {  // frames [k0, k0 + kLrGroup) of the launch -> their half of the slice
+        const uint32_t half = (k0 / kLrGroup) & 1u;
         if (direct) {
             const uint8_t *const seg_in = fr0 + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u;
 #pragma unroll
-            for (uint32_t g = 0; g < kLrInFrames / 8u; ++g) {
+            for (uint32_t g = 0; g < kLrGroup / 8u; ++g) {
                 uint32_t k = k0 + g * 8u + (lane >> 3);
                 k = k < nb ? k : nb - 1u;
                 __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(seg_in + (size_t)k * n_units_u),
-                                                 (__attribute__((address_space(3))) void *)(lds_in + g * 1024u), 16, 0,
+                                                 (__attribute__((address_space(3))) void *)(lds_in + (half * (kLrGroup / 8u) + g) * 1024u), 16, 0,
                                                  ADDER_NT_INPUT ? 2 : 0);
             }
-        } else {
+        } else {  // (ragged or unaligned planes: through registers, waited for at once)
 #pragma unroll 1
-            for (uint32_t q0 = 0; q0 < kLrInFrames; q0 += 8u) {
+            for (uint32_t q0 = 0; q0 < kLrGroup; q0 += 8u) {
                 uint32_t vin8[8];
 #pragma unroll
                 for (uint32_t q = 0; q < 8u; ++q) {
@@ -713,33 +711,81 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
                     vin8[q] = load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
                 }
 #pragma unroll
-                for (uint32_t q = 0; q < 8u; ++q) in_lds[(q0 + q) * kWave] = (InT)vin8[q];
+                for (uint32_t q = 0; q < 8u; ++q) in_lds[(half * kLrGroup + q0 + q) * kWave] = (InT)vin8[q];
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing else inside the frame loop waits on memory
     };
-    uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
-    uint64_t active[N];
+    // group g starts: its bytes have landed (vmcnt(0): nothing else inside the frame loop waits on memory), group g + 1 leaves
+    auto stage = [&](uint32_t i) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (i != 0u && i + kLrGroup < nb) stage_issue(i + kLrGroup);
+    };
+    stage_issue(0u);
+    if (kLrGroup < nb) stage_issue(kLrGroup);
+    {
+        uint32_t hdrv[N];
+        float dv[N];
+        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
+        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
+        bool all_ok = true;
 #pragma unroll
-    for (uint32_t j = 0; j < N; ++j) active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
-    for (uint32_t i = 0; i < nb; ++i) {
-        if ((i % kLrInFrames) == 0u) stage(i);
+        for (uint32_t j = 0; j < N; ++j) {
+            bool ok;
+            px[j] = lr_unpack<L>(hdrv[j], dv[j], T, ok);
+            all_ok = all_ok && (ok || (!FULL && u0 + j >= n_units_u));
+        }
+        if (!all_ok) raise(a.status, kStatusLeanRuns);
+    }
+    // The loop is bound by instruction issue: a SIMD issues at most one vector and one scalar instruction per four
+    // cycles (from different waves), so a frame costs about max(vector, scalar instructions) x 4 cycles per wave and
+    // SIMD.  Four versions -- 62 scalar + 45 vector instructions per frame, 38 + 53, 54 + 31, 43 + 48 -- took 110, 107, 110
+    // and 103 us per 64 frames: whichever side was lightened, the other one bound.  So BOTH sides are kept short: the masks
+    // are scalar (WaveLanes) and popped_dtm is no mask of its own (LrPxT); the record word is one byte permute of the
+    // previous and the current input words plus the unit -- which events it stands for is worked out by the expansion
+    // (lr_decode8); frames go in pairs (the loop's own scalar work and the select into wt halve).
+    uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
+    uint64_t active[N], nz_old[N];
+    uint32_t prev_w = 0u;  // the units' base_vals as an input word
+    uint32_t sel[N];       // v_perm_b32 selectors in vector registers (as scalar constants they are set again per use)
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
+        nz_old[j] = L::from(px[j].base != 0u);
+        prev_w |= px[j].base << (8u * j);
+        // bytes {0, prev_w[j], vin_w[j], 0}: selectors 0-3 = bytes of the second operand, 4-7 of the first, 12 = 0
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sel[j]) : "s"(0x0c00000cu | (j << 8) | ((4u + j) << 16)));
+    }
+#ifndef ADDER_LR_COUNT_VALU
+#define ADDER_LR_COUNT_VALU 1  // events counted per lane (an add-with-carry per mask), summed over the wave once per pair of frames
+#endif
+    auto frame = [&](uint32_t i, uint32_t &k_lane) -> uint32_t {  // -> events | records << 16 of the segment's frame i (uniform)
         const uint32_t vin_w = (uint32_t)in_lds[(i % kLrInFrames) * kWave];
         uint32_t w0[N], w8[N];
         uint64_t mrec[N];
         uint32_t nev = 0u, nrec = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            LeanFlagsT<L> fl = lr_step<L>(px[j], (vin_w >> (8 * j)) & 0xffu, (lane * N + j) << kLean8UnitShift, w0[j], w8[j]);
+            const uint32_t pair = __builtin_amdgcn_perm(vin_w, prev_w, sel[j]);
+            LeanFlagsT<L> fl = lr_step<L>(px[j], (vin_w >> (8 * j)) & 0xffu, pair, lane * N + j, nz_old[j], w0[j], w8[j]);
             if (!FULL) {  // padding units: stepped freely, no events
                 fl.a &= active[j];
                 fl.b &= active[j];
                 fl.c &= active[j];
             }
             mrec[j] = fl.a | fl.c;
+#if ADDER_LR_COUNT_VALU
+            {   // k_lane += a + b + c (the carry-in of v_addc_co_u32 is a lane mask)
+                uint64_t co;
+                asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.a));
+                asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.b));
+                asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.c));
+            }
+#else
             nrec += (uint32_t)__popcll(mrec[j]);
             nev += (uint32_t)__popcll(fl.a) + (uint32_t)__popcll(fl.b) + (uint32_t)__popcll(fl.c);
+#endif
         }
+        prev_w = vin_w;
         uint32_t pos = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j)
@@ -747,12 +793,43 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
+#if !defined(ADDER_DBG_LR_NOSTORE)  // (diagnostic A/B build: everything but the record stores)
             if (has) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
+#else
+            if (has && w0[j] == 0xfffffff1u) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
+#endif
             pos += has ? 1u : 0u;
         }
-        wt = lane == i ? (nev | (nrec << 16)) : wt;
         seg += frame_stride_u;
         if (__builtin_expect(i == wrap_at, 0)) seg -= wrap_bytes;  // (a branch, not selects: taken once per chunk at most)
+#if ADDER_LR_COUNT_VALU
+        return (uint32_t)__builtin_amdgcn_readlane((int)pos, kWave - 1) << 16;  // (the records parked: the last lane's offset)
+#else
+        return nev | (nrec << 16);
+#endif
+    };
+    static_assert(kLrGroup % 2u == 0u && N <= 4u, "pairs of frames never straddle a staging group; an input word holds the units' bytes");
+    uint32_t i = 0u;
+    for (; i + 2u <= nb; i += 2u) {
+        if ((i % kLrGroup) == 0u) stage(i);
+        uint32_t k0 = 0u, k1 = 0u;
+        uint32_t t0 = frame(i, k0);
+        uint32_t t1 = frame(i + 1u, k1);
+#if ADDER_LR_COUNT_VALU
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0 | (k1 << 16)), kWave - 1);
+        t0 |= tot & 0xffffu;
+        t1 |= tot >> 16;
+#endif
+        wt = lane == i ? t0 : lane == i + 1u ? t1 : wt;
+    }
+    if (i < nb) {
+        if ((i % kLrGroup) == 0u) stage(i);
+        uint32_t k0 = 0u;
+        uint32_t t0 = frame(i, k0);
+#if ADDER_LR_COUNT_VALU
+        t0 |= (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0), kWave - 1);
+#endif
+        wt = lane == i ? t0 : wt;
     }
     if (lane < nb) {
         uint32_t s = slot0 + lane;
@@ -1764,12 +1841,12 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_
 
 // ------------------------------------------------------------------------------------------
 // K1, run records -- `adder_rr_kernel<ABS_T>`: the bounded Collapse regime under the constant-run conditions with the
-// whole step in integers (adder_pixel.hpp, RUN RECORDS): a unit is {base_val, n, r1, popped} and, in AbsoluteT,
-// last_fired_t / T.  The step is compares, counters and one multiply; a flush / collapsed flush / pop_top parks ONE record
+// whole step in integers (adder_pixel.hpp, RUN RECORDS): a unit is {base_val, n, popped} and, in AbsoluteT,
+// last_fired_t / T.  The step is a handful of compares and a counter; a flush / collapsed flush / pop_top parks ONE record
 // of 8 (DeltaT) or 12 bytes, whatever the number of events it stands for (a byte table of chain lengths gives the count),
 // and the expansion works the events out.  Loads the header and delta_t (and last_fired_t) planes, stores the level-0
 // planes and the levels in their resident form.  Records go to the segment's log of the chunk (at most one per unit and
-// frame: a region of 128 * chunk records cannot overflow), the expansion is the lean one over logs (format 3).
+// frame: a region of 128 * chunk records cannot overflow), the expansion is the lean one over logs (format 4).
 // ------------------------------------------------------------------------------------------
 #ifndef ADDER_RR_WAVES_PER_SIMD
 #define ADDER_RR_WAVES_PER_SIMD 6
@@ -1850,10 +1927,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing else inside the frame loop waits on memory
     };
-    const auto levels = [&](uint32_t I, uint32_t r1) -> uint32_t {
-        if (r1 < kRrTabRows) return lds_tab[I * kRrTabRows + r1];
-        return cr_depth((float)I, r1, T) - 1u;  // (delta_t_max beyond 32 frames and a root that has not fired for that long)
-    };
+    const auto chain_tab = [&](uint32_t I, uint32_t r) -> uint32_t { return lds_tab[I * kRrTabRows + r]; };
     uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
     bool active[N];
 #pragma unroll
@@ -1866,7 +1940,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
         uint32_t lane_cnt = 0u, nrec = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
-            rr_step<ABS_T, L>(px[j], (vin_w >> (8 * j)) & 0xffu, frame0 + i, n_pop, levels, (lane * N + j) << kRrUnitShift,
+            rr_step<ABS_T, L>(px[j], (vin_w >> (8 * j)) & 0xffu, frame0 + i, n_pop, T, chain_tab, (lane * N + j) << kRrUnitShift,
                               w0[j], w1[j], w2[j], cnt[j]);
             if (!FULL) cnt[j] = active[j] ? cnt[j] : 0u;  // padding units: stepped freely, no events
             mrec[j] = L::from(cnt[j] != 0u);
@@ -2201,6 +2275,7 @@ constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 #endif
 constexpr uint32_t kXbufEvents = ADDER_XBUF_EVENTS;   // staging capacity of one wave, in events (>= 192)
 constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
+constexpr uint32_t kRrOwnerWindow = 128;              // events of a run-record round placed at a time (<= kXbufEvents)
 
 struct UnitCoord {  // (row, offset in row) of a segment's first unit + the plane geometry (uniform)
     uint32_t y0, rem0, rowlen, channels, row_begin;
@@ -2308,6 +2383,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
     constexpr bool RR = FORMAT == 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
+    __shared__ uint16_t s_owner[RR ? kWavesPerBlock : 1u][RR ? kRrOwnerWindow : 1u];  // (run records: event -> record lane | index << 8)
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
     // only the frame-independent part of the arguments is needed here
     const uint32_t slots = __builtin_amdgcn_readfirstlane(b->slots);
@@ -2446,35 +2522,52 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t unit = ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
+        const uint32_t unit = ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : lean_runs ? rw.y & 0x7fu : (rw.y >> kLean8UnitShift) & 0x7fu;
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
-    // 64 run records (or none) of ONE segment: every lane walks its record's chain (rr_event), the events of the round
-    // are placed by a scan of the records' counts
+    // 64 run records (or none): a scan of the records' counts places the round's events; then ONE LANE PER EVENT -- an
+    // owner map in LDS (written by the record lanes, a short loop over their counts) tells event e its record and its
+    // index k in the record, the record's words come over ds_bpermute, and the lane works event k out (rr_event_at: k
+    // hops down the chain, then the node).  A loop over the records' chains instead cost every lane the round's longest
+    // chain at three divisions a step.
     auto rr_round = [&](const uint4 &rw, uint32_t unit_shift) {
         const uint32_t w2 = ABS_T ? rw.z : rw.y;
         const uint32_t cnt = w2 >> kRrCountShift;  // (an all-zero record: no events)
         const uint32_t incl = wave_inclusive_scan_dpp(cnt);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         const uint32_t first_ev = incl - cnt;
-        const uint32_t kind = w2 & 3u, Iu = (w2 >> kRrBaseShift) & 0xffu;
         uint32_t c;
         const uint32_t xy = coord_xy_c(uc, ((w2 >> kRrUnitShift) & 0x7fu) + unit_shift, c);
-        for (uint32_t e0 = 0; e0 < total; e0 += kXbufEvents) {  // (uniform; one pass unless the round outgrows the buffer)
-            const uint32_t piece = total - e0 < kXbufEvents ? total - e0 : kXbufEvents;
+        uint16_t *const owner = s_owner[wid];
+        for (uint32_t e0 = 0; e0 < total; e0 += kRrOwnerWindow) {  // (uniform; one window unless the round holds more events)
+            const uint32_t piece = total - e0 < kRrOwnerWindow ? total - e0 : kRrOwnerWindow;
             if (fill + piece > kXbufEvents) flush();
-            uint32_t r = rw.x, lq = rw.y;
             for (uint32_t k = 0; k < cnt; ++k) {
-                const RrEvent e = rr_event<ABS_T>(kind, Iu, k, r, lq, time_spanned_u, rt_u32);
-                const uint32_t pos = first_ev + k;
-                if (pos >= e0 && pos < e0 + piece) {
-                    const uint32_t w = phase + (fill + pos - e0) * 3u;
-                    xb[w] = xy;
-                    xb[w + 1u] = c | (e.d << 8);
-                    xb[w + 2u] = e.t;
+                const uint32_t pos = first_ev + k - e0;  // (wraps below the window: unsigned compare)
+                if (pos < piece) owner[pos] = (uint16_t)(lane | (k << 8));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t p0 = 0; p0 < piece; p0 += kWave) {  // uniform
+                const uint32_t e = p0 + lane;
+                const uint32_t o = e < piece ? owner[e] : 0u;
+                const int src = (int)((o & 0x3fu) << 2);
+                const uint32_t rn = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw.x);
+                const uint32_t rlq = ABS_T ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw.y) : 0u;
+                const uint32_t rw2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w2);
+                const uint32_t rxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)xy);
+                const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c);
+                if (e < piece) {
+                    const RrEvent ev = rr_event_at<ABS_T>(rw2 & 3u, (rw2 >> kRrBaseShift) & 0xffu, rn, rlq, o >> 8, time_spanned_u, rt_u32);
+                    const uint32_t w = phase + (fill + e) * 3u;
+                    xb[w] = rxy;
+                    xb[w + 1u] = rc | (ev.d << 8);
+                    xb[w + 2u] = ev.t;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             fill += piece;
         }
     };

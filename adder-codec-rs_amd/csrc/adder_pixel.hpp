@@ -1288,65 +1288,71 @@ ADDER_HD void cr_pop(CrPxT<L> &s, const CrPlanT<L> &p, float T) {
 // is cr_node(base_val, rho) with rho = the frames it has accumulated -- so a unit is THREE SMALL INTEGERS {base_val, rho,
 // popped_dtm}, the step is compares and a counter, and the one event that needs arithmetic (A, the flushed root's best
 // event) is worked out by the EXPANSION from (base_val, rho), densely, like it already works event C out from the
-// input byte.  The parked 8-byte record is {rho of the flushed root, A | B << 1 | C << 2 | unit << 4 | flushed
-// base_val << 11 | input byte << 19}.  rho I and rho T stay below 2^24 (the host switches to lean_step before they would
+// input byte.  The parked 8-byte record is {rho of the flushed root, unit | popped_dtm << 7 | flushed base_val << 8 |
+// input byte << 16}.  rho I and rho T stay below 2^24 (the host switches to lean_step before they would
 // not: 65 000 frames after a reset), so the closed form's operations are the stepped ones bit for bit.
 // ---------------------------------------------------------------------------------------
+// popped_dtm is no state of its own here: in this regime a root of non-zero intensity is popped in the very frame it
+// starts (it has accumulated time_spanned >= delta_t_max), a black one never is, a flush clears the flag and the same
+// frame's integrate sets it again -- after every frame popped_dtm == (base_val != 0).  (adder_lr_kernel checks the planes
+// it loads against this and reports a violation instead of stepping on.)
 template <class L>
 struct LrPxT {
-    uint32_t base, rho;       // rho: frames the root has accumulated; 0 = no root (the pristine tail alone)
-    typename L::Mask popped;  // popped_dtm
+    uint32_t base, rho;  // rho: frames the root has accumulated; 0 = no root (the pristine tail alone)
 };
 using LrPx = LrPxT<ScalarLanes>;
-constexpr uint32_t kLr8BaseShift = 11;  // the flushed root's intensity (where lean_decode8 has A's exponent byte)
+// record: w0 = rho of the flushed root, w8 = unit | flushed base_val << 8 | input << 16; which of the events A, B, C it
+// stands for follows from these (lr_decode8) -- the frame kernel assembles no flag bits, its event count comes from the
+// masks.  (An all-zero word decodes to no events.)
+constexpr uint32_t kLrBaseShift = 8, kLrInShift = 16;
 
 template <class L>
-ADDER_HD LrPxT<L> lr_unpack(uint32_t hdr, float dt, float T) {
+ADDER_HD LrPxT<L> lr_unpack(uint32_t hdr, float dt, float T, bool &consistent) {
     LrPxT<L> p;
     p.base = hdr & 0xffu;
-    p.popped = L::from((hdr & kHdrPopped) != 0u);
     // a root of intensity I > 0 holds delta_t = rho T; a black one (it never accumulates, :449) counts as one frame
     p.rho = hdr_m(hdr) == 0u ? 0u : (p.base != 0u ? (uint32_t)fdiv(dt, T) : 1u);
+    consistent = ((hdr & kHdrPopped) != 0u) == (p.base != 0u);
     return p;
 }
-// integrate_for_px under the conditions above: which events leave, the record's two words, the new state
+// integrate_for_px under the conditions above: which events leave, the record's two words, the new state.
+// pair = base_val << 8 | v << 16 (the kernel builds it with one byte permute of the previous and the current input
+// words); nz_old = the previous frame's (v != 0), i.e. popped_dtm before this frame
 template <class L>
-ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t tag8 /* unit << kLean8UnitShift */, uint32_t &w0,
+ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t pair, uint32_t unit, typename L::Mask &nz_old, uint32_t &w0,
                                uint32_t &w8) {
     using M = typename L::Mask;
     const M flush = L::from(v != p.base);
     const M has = L::from(p.rho != 0u);
-    LeanFlagsT<L> fl;
-    fl.a = L::and_(flush, has);
-    fl.b = L::and_(fl.a, p.popped);
-    w0 = p.rho;
-    const uint32_t old_base = p.base;
-    const M popped = L::andnot(p.popped, flush);
-    const M has1 = L::andnot(has, flush);
-    p.base = v;  // (unchanged without a flush)
     const M zero = L::from(v == 0u);  // the root's sum stays 0 exactly when the run's intensity is 0 (:449)
-    fl.c = L::not_(L::or_(popped, zero));  // need_to_pop_top: the root has accumulated time_spanned >= delta_t_max
-    // (two plain selects: rho + 1 where the root goes on accumulating, 1 where it starts, 0 where pop_top takes it)
-    const uint32_t grown = (L::lane(L::andnot(has1, zero)) ? p.rho : 0u) + 1u;
-    p.rho = L::lane(fl.c) ? 0u : grown;
-    p.popped = L::or_(popped, fl.c);
-    w8 = tag8 | (old_base << kLr8BaseShift) | (v << kLean8InShift) | (L::lane(fl.a) ? kLeanA : 0u) |
-         (L::lane(fl.b) ? kLeanB : 0u) | (L::lane(fl.c) ? kLeanC : 0u);
+    LeanFlagsT<L> fl;
+    fl.a = L::and_(flush, has);          // the flushed root's best event
+    fl.b = L::and_(fl.a, nz_old);        // ... and the D_EMPTY filler if it had been popped
+    fl.c = L::andnot(flush, zero);       // need_to_pop_top: a new root of non-zero intensity (an old one is popped already)
+    w0 = p.rho;
+    w8 = pair | unit;
+    p.base = v;  // (unchanged without a flush)
+    // rho: 0 where pop_top takes the new root, rho + 1 where a root goes on accumulating (or the tail starts one, 0 + 1),
+    // 1 for a black root
+    const uint32_t grown = L::lane(flush) ? 0u : p.rho + 1u;
+    p.rho = L::lane(zero) ? 1u : grown;
+    nz_old = L::not_(zero);
     return fl;
 }
 // The record back into events: A from the flushed root's run, C from the input byte (lean_decode8's arithmetic).
 ADDER_HD LeanEvents lr_decode8(uint32_t w0, uint32_t w8, float T, uint32_t running_t_u32) {
     LeanEvents e;
-    e.a = (w8 & kLeanA) != 0u;
-    e.b = (w8 & kLeanB) != 0u;
-    e.c = (w8 & kLeanC) != 0u;
-    const uint32_t Io = (w8 >> kLr8BaseShift) & 0xffu;
+    const uint32_t Io = (w8 >> kLrBaseShift) & 0xffu, Iv = (w8 >> kLrInShift) & 0xffu;
+    const bool flush = Io != Iv;
+    e.a = flush && w0 != 0u;
+    e.b = e.a && Io != 0u;
+    e.c = flush && Iv != 0u;
     // (a record without A still decodes: rho 0 is given a frame so that the divisions stay inside their domain)
     const CrNode n = cr_node(Io != 0u ? (float)Io : 1.0f, w0 != 0u ? w0 : 1u, T);
     e.da = Io != 0u ? lean_bd_from_thr(f32_to_bits(n.thr)) : kDZero;
     e.ta = f32_as_u32(Io != 0u ? n.bdt : T);  // a black root's best event: (128, 0 + T * 1)
     e.tb = running_t_u32;
-    const float I = (float)((w8 >> kLean8InShift) & 0xffu);
+    const float I = (float)Iv;
     const float p2 = bits_to_f32(f32_to_bits(I) & 0x7f800000u);  // 2^get_d(I)
     e.dc = get_d(I);
     e.tc = f32_as_u32(fadd(0.0f, fmul(T, fdiv_small(fsub(p2, 0.0f), I))));  // (C exists only for I >= 1)
@@ -1370,36 +1376,39 @@ ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, f
             bd = kDZero;
         }
     }
-    return hdr_make(p.base, bd, p.rho != 0u ? 1u : 0u, L::lane(p.popped));
+    return hdr_make(p.base, bd, p.rho != 0u ? 1u : 0u, p.base != 0u);  // (popped_dtm == (base_val != 0): see LrPxT)
 }
 
 // ---------------------------------------------------------------------------------------
 // RUN RECORDS: the bounded Collapse regime (delta_t_max > time_spanned) under the constant-run conditions, with the
-// whole step in integers -- what LEAN RUNS does for the lean regime.  A unit is {base_val, n, r1, popped_dtm} (n = the
-// frames the root has accumulated, r1 = frames since it last fired) and, in AbsoluteT, lq = last_fired_t / T.  The frame
-// kernel only decides WHAT happens -- a flush of (base_val, n), a collapsed flush, pop_top -- counts the events (a table
-// of chain lengths) and parks one 12-byte record per happening; the expansion works the events out, densely:
-// the flushed arena is the chain r_0 = n, r_{k+1} = r_k - j_k of cr_node(base_val, r_k).
+// whole step in integers -- what LEAN RUNS does for the lean regime.  A unit is {base_val, n, popped_dtm} (n = the frames
+// the root has accumulated) and, in AbsoluteT, lq = last_fired_t / T: nothing else is state -- an unpopped root of n frames
+// last fired at j = cr_node(base_val, n).j, so level 1 has run n - j frames, and so on down the chain.  The frame kernel
+// only decides WHAT happens -- a flush of (base_val, n), a collapsed flush, pop_top -- counts the events (a byte table of
+// chain lengths) and parks one record per happening; the expansion works the events out, densely: the flushed arena is
+// the chain r_0 = n, r_{k+1} = r_k - j_k of cr_node(base_val, r_k).
 // AbsoluteT needs last_fired_t per unit, and it stays an integer too when time_spanned == ref_time >= 255 (every framed
 // source, framed.rs:101-109): last_fired_t is a multiple L T, an event's best delta_t lies in ((j-1) T, j T] with
 // T q >= T / 255 >= 1, so t = trunc(bdt + L T) lies in [L T + (j-1) T + 1, L T + j T] and delta_t_to_absolute_t's
 // round-up (:122-129) gives (L + j) T: every event advances L by its node's last firing j.  Over a flushed chain the j_k
-// telescope to n (the run's length), pop_top advances L by n - r1, a collapsed flush sets L to the frame's index (:257).
-// The expansion redoes the same chain to give event k its own L_k.  tests/cpu_sim checks every intensity, run length and
-// both time modes against the literal oracle.
+// telescope to n (the run's length), pop_top advances L by the root's last firing, a collapsed flush sets L to the
+// frame's index (:257).  The expansion redoes the same chain to give event k its own L_k.  tests/cpu_sim checks every
+// intensity, run length and both time modes against the literal oracle.
 // record {n, lq, kind | unit << 2 | base_val << 9 | events << 17} (DeltaT: {n, the third word}): kind 1 flush, 2 collapsed
 // flush, 3 pop_top
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kRrFlush = 1u, kRrCollapsed = 2u, kRrPop = 3u;
 constexpr uint32_t kRrUnitShift = 2, kRrBaseShift = 9, kRrCountShift = 17;
-constexpr uint32_t kRrTabRows = 32;  // chain lengths tabulated for r1 < 32 (delta_t_max up to 32 frames; beyond: worked out)
-ADDER_HD void rr_build_tab(uint8_t *tab, float T) {  // tab[I * kRrTabRows + r] = levels of a chain that starts at run r
+constexpr uint32_t kRrTabRows = 32;  // chain lengths tabulated for runs below 32 frames (delta_t_max up to 32 frames; beyond: worked out)
+// events of an unpopped arena whose root has accumulated r frames of intensity I (0 for r == 0; a black root holds one)
+ADDER_HD uint32_t rr_chain(uint32_t I, uint32_t r, float T) { return r == 0u ? 0u : I == 0u ? 1u : cr_depth((float)I, r, T) - 1u; }
+ADDER_HD void rr_build_tab(uint8_t *tab, float T) {  // tab[I * kRrTabRows + r] (the time step does not enter: j = ceil(2^e / I))
     for (uint32_t I = 0; I < 256u; ++I)
-        for (uint32_t r = 0; r < kRrTabRows; ++r) tab[I * kRrTabRows + r] = (uint8_t)((I == 0u || r == 0u) ? 0u : cr_depth((float)I, r, T) - 1u);
+        for (uint32_t r = 0; r < kRrTabRows; ++r) tab[I * kRrTabRows + r] = (uint8_t)rr_chain(I, r, T);
 }
 template <class L>
 struct RrPxT {
-    uint32_t base, n, r1, lq;
+    uint32_t base, n, lq;
     typename L::Mask popped;
 };
 using RrPx = RrPxT<ScalarLanes>;
@@ -1408,85 +1417,74 @@ template <class L>
 ADDER_HD RrPxT<L> rr_unpack(uint32_t hdr, float dt, float lastf, float T, bool abs_t) {
     RrPxT<L> p;
     p.base = hdr & 0xffu;
-    const bool popped = (hdr & kHdrPopped) != 0u;
-    p.popped = L::from(popped);
+    p.popped = L::from((hdr & kHdrPopped) != 0u);
     p.n = hdr_m(hdr) == 0u ? 0u : (p.base != 0u ? (uint32_t)fdiv(dt, T) : 1u);
-    p.r1 = 0u;
-    if (hdr_m(hdr) > 1u && !popped && p.base != 0u) {  // r1 = n - the root's last firing = ceil(2^(d-1) / I)
-        const float thr = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
-        const float qj = fdiv_small(fmul(0.5f, thr), (float)p.base);
-        uint32_t j = (uint32_t)qj;
-        j += (float)j < qj ? 1u : 0u;
-        p.r1 = p.n - j;
-    }
     p.lq = abs_t ? (uint32_t)fdiv(lastf, T) : 0u;
     return p;
 }
 // One frame of one unit: the record's three words (valid iff count != 0) and the number of events it stands for.
-// frame_idx = running_t / T before this frame; n_pop = ceil(delta_t_max / T) >= 2; levels(I, r1) = the chain's length.
-template <bool ABS_T, class L, class Levels>
-ADDER_HD void rr_step(RrPxT<L> &p, uint32_t v, uint32_t frame_idx, uint32_t n_pop, const Levels &levels, uint32_t tag,
+// frame_idx = running_t / T before this frame; n_pop = ceil(delta_t_max / T) >= 2; tab(I, r) = rr_chain for r < kRrTabRows.
+template <bool ABS_T, class L, class Tab>
+ADDER_HD void rr_step(RrPxT<L> &p, uint32_t v, uint32_t frame_idx, uint32_t n_pop, float T, const Tab &tab, uint32_t tag,
                       uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &count) {
     using M = typename L::Mask;
     const M flush = L::from(v != p.base);
-    const M has = L::from(p.n != 0u);
-    const M flushed = L::and_(flush, has);
-    const M collapsed = L::and_(flushed, p.popped);
-    count = 0u;
-    uint32_t kind = 0u, rn = p.n, rbase = p.base;
+    const M collapsed = L::and_(L::and_(flush, p.popped), L::from(p.n != 0u));
+    // the flushed arena's events (pop_best_events, :210-286): the chain below an unpopped root, root + filler if popped
+    uint32_t chain = tab(p.base, p.n < kRrTabRows - 1u ? p.n : kRrTabRows - 1u);
+    if (L::lane(L::andnot(flush, p.popped)) && p.n >= kRrTabRows) chain = rr_chain(p.base, p.n, T);  // (delta_t_max beyond 32 frames)
+    count = L::lane(flush) ? (L::lane(collapsed) ? 2u : chain) : 0u;
+    uint32_t kind = L::lane(collapsed) ? kRrCollapsed : kRrFlush;
+    uint32_t rn = p.n, rbase = p.base;
     w1 = p.lq;
-    if (L::lane(flushed)) {
-        count = L::lane(collapsed) ? 2u : 1u + (p.r1 != 0u ? levels(p.base, p.r1) : 0u);
-        kind = L::lane(collapsed) ? kRrCollapsed : kRrFlush;
-        if (ABS_T) p.lq = L::lane(collapsed) ? frame_idx : p.lq + p.n;
+    if (ABS_T) {
+        const uint32_t lq_f = L::lane(collapsed) ? frame_idx : p.lq + p.n;  // (:257 / the chain's firings telescope to n)
+        p.lq = L::lane(flush) ? lq_f : p.lq;
     }
     const M popped1 = L::andnot(p.popped, flush);
-    const M has1 = L::andnot(has, flush);
     const M zero = L::from(v == 0u);
-    p.base = v;
-    const uint32_t n1 = (L::lane(L::andnot(has1, zero)) ? p.n : 0u) + 1u;
-    const uint32_t P = n1 * v, Q = P - v;
-    const M fires = L::from((P ^ Q) > Q);  // n1 v crossed a power of two (or n1 == 1): the root fires this frame
-    const uint32_t r1n = L::lane(L::or_(L::or_(fires, popped1), zero)) ? 0u : p.r1 + 1u;
+    const uint32_t n1 = L::lane(L::or_(flush, zero)) ? 1u : p.n + 1u;  // (a black root holds one frame, :427-473 with intensity 0)
     const M need_pop = L::andnot(L::andnot(L::from(n1 >= n_pop), popped1), zero);  // :394-396
-    if (L::lane(need_pop)) {  // (never in a frame that flushed: a new run starts at n = 1 < n_pop)
+    uint32_t nn = n1;
+    if (L::lane(need_pop)) {  // pop_top (:156-197): the root's event; level 1 becomes the root, deeper levels are dropped
+        const uint32_t j = cr_node((float)v, n1, T).j;  // (never in a frame that flushed: a new run starts at n = 1 < n_pop)
+        nn = n1 - j;
         count = 1u;
         kind = kRrPop;
         rn = n1;
         rbase = v;
-        w1 = p.lq;
-        if (ABS_T) p.lq += n1 - r1n;  // the popped root's last firing
+        if (ABS_T) p.lq += j;
     }
-    p.n = L::lane(need_pop) ? r1n : n1;   // pop_top: level 1 (run r1) becomes the root, deeper levels are dropped
-    p.r1 = L::lane(need_pop) ? 0u : r1n;
+    p.n = nn;
+    p.base = v;
     p.popped = L::or_(popped1, need_pop);
     w0 = rn;
     w2 = kind | tag | (rbase << kRrBaseShift) | (count << kRrCountShift);
 }
-// Event k of a record, walking the chain: the caller keeps (r, lq) between calls, starting from (n, w1).
+// Event k of a record (n, lq, kind, base_val), from the record alone: k hops down the chain (one division each), then
+// the node's event (two).  Event k's own last_fired_t is (lq + n - r_k) T: the firings above it telescope.
 struct RrEvent {
     uint32_t d, t;
 };
 template <bool ABS_T>
-ADDER_HD RrEvent rr_event(uint32_t kind, uint32_t Iu, uint32_t k, uint32_t &r, uint32_t &lq, float T, uint32_t running_t_u32) {
+ADDER_HD RrEvent rr_event_at(uint32_t kind, uint32_t Iu, uint32_t n, uint32_t lq, uint32_t k, float T, uint32_t running_t_u32) {
     RrEvent e;
-    if (kind == kRrCollapsed && k != 0u) {
+    if (kind == kRrCollapsed && k != 0u) {  // the D_EMPTY filler of a collapsed flush (:258-264)
         e.d = kDEmpty;
         e.t = running_t_u32;
         return e;
     }
-    float bdt = T;
-    uint32_t j = 1u;
+    float bdt = T;  // a black root: (D_ZERO, time_spanned)
+    uint32_t r = n;
     e.d = kDZero;
     if (Iu != 0u) {
-        const CrNode n = cr_node((float)Iu, r, T);
-        bdt = n.bdt;
-        j = n.j;
-        e.d = lean_bd_from_thr(f32_to_bits(n.thr));
+        const float I = (float)Iu;
+        for (uint32_t h = 0; h < k; ++h) r -= cr_node(I, r, T).j;
+        const CrNode nd = cr_node(I, r, T);
+        bdt = nd.bdt;
+        e.d = lean_bd_from_thr(f32_to_bits(nd.thr));
     }
-    e.t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)lq, T)) : bdt);
-    r -= j;
-    lq += j;
+    e.t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)(lq + (n - r)), T)) : bdt);
     return e;
 }
 // The levels 1 .. m-1 of an unpopped arena in their resident form {integration, delta_t, best_delta_t, best_d}, for
@@ -1515,7 +1513,7 @@ template <class L, class Store>
 ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, float &bdt, float &lastf, Store &store) {
     CrPxT<L> c;
     c.base = p.base;
-    c.r1 = p.r1;
+    c.r1 = 0u;
     c.has = L::from(p.n != 0u);
     c.popped = p.popped;
     c.S = c.dt0 = c.bdt0 = c.thr0 = 0.0f;
@@ -1527,6 +1525,7 @@ ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, f
             c.dt0 = fmul((float)p.n, T);
             c.bdt0 = n.bdt;
             c.thr0 = n.thr;
+            c.r1 = L::lane(p.popped) ? 0u : p.n - n.j;
             bd = lean_bd_from_thr(f32_to_bits(n.thr));
         } else {
             c.bdt0 = T;

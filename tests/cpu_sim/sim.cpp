@@ -469,9 +469,7 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     const uint32_t n_pop = (s->dtm + Tu - 1u) / Tu;
     std::vector<uint8_t> tab(256 * kRrTabRows);
     rr_build_tab(tab.data(), T);
-    auto levels = [&](uint32_t I, uint32_t r1) -> uint32_t {
-        return r1 < kRrTabRows ? tab[I * kRrTabRows + r1] : cr_depth((float)I, r1, T) - 1u;
-    };
+    auto levels = [&](uint32_t I, uint32_t r) -> uint32_t { return tab[I * kRrTabRows + r]; };
     const uint32_t frame0 = (uint32_t)(s->running_t / T);
     std::vector<std::vector<SimEvent>> per_frame(nb);
     int rc = 0;
@@ -484,23 +482,22 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 RrPx p = rr_unpack<ScalarLanes>(hdr, m0 ? s->dt0[u] : -777.0f, s->abs_t ? s->lastf[u] : -1.0f, T, s->abs_t != 0);
                 for (uint32_t i = 0; i < nb; ++i) {
                     uint32_t w0, w1, w2, count;
-                    if (s->abs_t) rr_step<true>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, levels, 0u, w0, w1, w2, count);
-                    else rr_step<false>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, levels, 0u, w0, w1, w2, count);
+                    if (s->abs_t) rr_step<true>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count);
+                    else rr_step<false>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count);
                     s->cb_steps++;
                     if (count == 0u) continue;
                     // the expansion's side: everything from the three words
                     const uint32_t kind = w2 & 3u, Iu = (w2 >> kRrBaseShift) & 0xffu, cnt = w2 >> kRrCountShift;
                     if (cnt != count) s->plan_mismatch++;
-                    uint32_t r = w0, lq = w1;
                     const uint32_t rt_u32 = f32_as_u32(fmul((float)(frame0 + i), T));
                     for (uint32_t k = 0; k < cnt; ++k) {
-                        const RrEvent e = s->abs_t ? rr_event<true>(kind, Iu, k, r, lq, T, rt_u32) : rr_event<false>(kind, Iu, k, r, lq, T, rt_u32);
+                        const RrEvent e = s->abs_t ? rr_event_at<true>(kind, Iu, w0, w1, k, T, rt_u32) : rr_event_at<false>(kind, Iu, w0, w1, k, T, rt_u32);
                         SimEvent ev;
                         ev.x = (uint16_t)x; ev.y = (uint16_t)(y + s->row_begin); ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)c;
                         ev.d = (uint8_t)e.d; ev.pad = 0; ev.t = e.t;
                         per_frame[i].push_back(ev);
                     }
-                    if (kind == kRrFlush && r != 0u) s->plan_mismatch++;  // the chain must end exactly at the count
+                    if (kind == kRrFlush && Iu != 0u && rr_chain(Iu, w0, T) != cnt) s->plan_mismatch++;  // the chain ends exactly at the count
                 }
                 DeepAcc deep{s, u};
                 struct Store {
@@ -556,13 +553,17 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
         for (uint32_t x = 0; x < s->W; x++)
             for (uint32_t c = 0; c < s->C; c++, u++) {
                 const uint32_t m0 = hdr_m(s->hdr[u]);
-                LrPx p = lr_unpack<ScalarLanes>(s->hdr[u], m0 ? s->dt0[u] : -777.0f, T);
+                bool consistent;
+                LrPx p = lr_unpack<ScalarLanes>(s->hdr[u], m0 ? s->dt0[u] : -777.0f, T, consistent);
+                if (!consistent) rc = -10;  // popped_dtm != (base_val != 0): the planes are not the lean regime's
+                bool nz_old = p.base != 0u;
                 for (uint32_t i = 0; i < nb; ++i) {
                     uint32_t w0, w8;
-                    const LeanFlagsT<ScalarLanes> fl = lr_step(p, frames[(size_t)i * s->N + u], (uint32_t)(u & 127u) << kLean8UnitShift, w0, w8);
+                    const uint32_t vin = frames[(size_t)i * s->N + u];
+                    const LeanFlagsT<ScalarLanes> fl = lr_step<ScalarLanes>(p, vin, (p.base << kLrBaseShift) | (vin << kLrInShift), (uint32_t)(u & 127u), nz_old, w0, w8);
                     if (fl.b && !fl.a) rc = -9;
                     if (!(fl.a || fl.c)) continue;  // (no record)
-                    if (((w8 >> kLean8UnitShift) & 127u) != (u & 127u)) rc = -9;
+                    if ((w8 & 127u) != (u & 127u)) rc = -9;
                     const LeanEvents e = lr_decode8(w0, w8, T, f32_as_u32(rts[i]));
                     if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
                     SimEvent ev;

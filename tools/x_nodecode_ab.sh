@@ -1,7 +1,4 @@
-#!/bin/bash
-# A/B on ONE box (boxes differ by +-4 %): the tree's library against variants under build/variants (tools/build_variants.sh;
-# libadder_hip_base.so = the last commit's sources), headline ms per step + per-kernel us, interleaved twice
-for lib in "" build/variants/libadder_hip_base.so "" build/variants/libadder_hip_base.so; do
+for lib in "" build/variants/libadder_hip_nodecode.so "" build/variants/libadder_hip_nodecode.so; do
   ADDER_HIP_LIB=$lib python bench.py --steps 32 --warmup 3 --no-cpu-baseline --no-end-to-end --no-secondary 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('${lib:-default}', d['ms_per_step'], d['value'], r['frac'], r['frame_kernel_launch_us'], r['scan_offsets_expand_us'])"
 done
