@@ -163,6 +163,8 @@ struct AdderHipCtx {
     // could erase a flag a batch in flight raised)
     uint64_t *d_side_words = nullptr;
     uint8_t *d_rr_tab = nullptr;  // [256][kRrTabRows] chain lengths of the run-records step (built at its first batch)
+    uint32_t *d_lr_tab = nullptr; // [kLrTabWords] the lean-runs expansion's events by (base_val, rho) / input, for lr_tab_time
+    float lr_tab_time = 0.0f;
     // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
     bool records_only = false;        // the batch being queued stops after its scan
     float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
@@ -323,6 +325,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_side_words) (void)hipFree(c->d_side_words);
     if (c->d_rr_tab) (void)hipFree(c->d_rr_tab);
+    if (c->d_lr_tab) (void)hipFree(c->d_lr_tab);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
     for (hipEvent_t e : c->band_desc_e)
@@ -1190,14 +1193,14 @@ static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t
     return ADDER_OK;
 }
 
-static int instantiate_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
+static int instantiate_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, bool one_stream, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
     // per-event-record batches (generic / bounded Collapse kernels) are captured on ONE stream: their frame kernel is
     // bound by instruction issue at full occupancy and leaves the expansion no room to run beside it -- two branches
     // measured 10.5 us per 1080p frame against 10.0 in sequence (walking grids 11.6 - 14.2)
     static const bool gen_two = [] { const char *e = getenv("ADDER_HIP_GEN_TWO_STREAMS"); return e && atoi(e) != 0; }();
-    hipStream_t s2 = ((variant & 4u) && !gen_two) ? nullptr : c->cap_s2;
+    hipStream_t s2 = (one_stream || ((variant & 4u) && !gen_two)) ? nullptr : c->cap_s2;
     int rc = launch_frame_loop(c, num_frames, variant, c->cap_s, s2, false);
     hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
     if (rc != ADDER_OK) {
@@ -1238,7 +1241,12 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     if (use < 0 || g.runs[use] >= kTuneRunsPerCandidate) {
         if (g.cand.size() < want) {
             hipGraphExec_t exec = nullptr;
-            int rc = instantiate_graph(c, num_frames, variant, &exec);
+            // the first candidate runs the chunks' kernels one after the other, the others on two branches (the frame
+            // kernel of chunk k + 1 beside the scan / expansion of chunk k): with both big kernels bound by instruction
+            // issue the branches only get in each other's way on a full 1080p plane (1.335 against 1.284 ms per step,
+            // medians of six processes each), on small or quiet planes they hide the short kernels' launch gaps -- the
+            // measured batch times decide
+            int rc = instantiate_graph(c, num_frames, variant, g.cand.empty(), &exec);
             if (rc != ADDER_OK) return rc;
             g.cand.push_back(exec);
             g.ms.push_back(1e30f);
@@ -1426,6 +1434,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) |
                              ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
+    if (lr && (!c->d_lr_tab || c->lr_tab_time != time_spanned)) {  // (cr_valid: one time step per reset, so once per stream)
+        std::vector<uint32_t> tab(kLrTabWords);
+        lr_build_tab(tab.data(), time_spanned);
+        if (!c->d_lr_tab) HIPCHK(c, dalloc(&c->d_lr_tab, tab.size()));
+        HIPCHK(c, hipStreamSynchronize(stream));  // (an expansion of the batch before may still read the old one)
+        HIPCHK(c, hipMemcpy(c->d_lr_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->lr_tab_time = time_spanned;
+    }
     if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
         std::vector<uint8_t> tab(256u * kRrTabRows);
         rr_build_tab(tab.data(), 255.0f);
@@ -1503,6 +1519,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // (a lean batch's region holds one record per unit and frame of the chunk: the same bytes as its fixed slots)
     b.log_cap = (variant & (64u | 512u)) ? kWaveUnits * c->chunk : c->log_cap;  // (run records: <= 12 bytes each in a region of >= 2 * 128 * chunk * 8)
     b.rr_tab = c->d_rr_tab;
+    b.lr_tab = c->d_lr_tab;
     {
         const bool sd = c->snap.valid && c->snap.deep;  // this batch keeps an undo copy of the levels >= 1
         b.snap_dv_integ = sd ? c->snap.dv_integ : nullptr;

@@ -154,6 +154,7 @@ struct BatchArgs {
     uint32_t slots;
     uint32_t chunk;           // frames per chunk; slots = chunks in the ring * chunk
     const uint8_t *rr_tab;    // [256][kRrTabRows] chain lengths (adder_pixel.hpp rr_build_tab); run-record batches only
+    const uint32_t *lr_tab;   // [kLrTabWords] events A and C by (base_val, rho) / input (lr_build_tab); lean-runs batches only
     uint64_t *rec_total;      // parked records of the batch so far (diagnostics; may be null)
     // Undo copy of the levels >= 1 (a batch whose event buffer is below its worst case keeps one: adder_hip_finish can
     // roll back).  Not null: the batch's FIRST launch (frame 0) stores every unit's LIVE levels 1 .. m-1 here before

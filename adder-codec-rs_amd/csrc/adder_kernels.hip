@@ -2268,7 +2268,7 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 #ifndef ADDER_XBUF_EVENTS
-#define ADDER_XBUF_EVENTS 640
+#define ADDER_XBUF_EVENTS 448
 #endif
 #ifndef ADDER_XFLUSH_UNROLL
 #define ADDER_XFLUSH_UNROLL 1
@@ -2384,6 +2384,13 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     constexpr bool RR = FORMAT == 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
     __shared__ uint16_t s_owner[RR ? kWavesPerBlock : 1u][RR ? kRrOwnerWindow : 1u];  // (run records: event -> record lane | index << 8)
+    // lean runs: event C by input byte (lr_build_tab), 1 KB per workgroup out of L2 -- a division less per record
+    constexpr bool LRC = FORMAT == 1 && !ABS_T;
+    __shared__ uint32_t s_tab_c[LRC ? 256u : 1u];
+    if (LRC && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u) {
+        s_tab_c[threadIdx.x] = uniform_ptr(b->lr_tab)[256u * kLrTabRuns + threadIdx.x];
+        __syncthreads();
+    }
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");
     // only the frame-independent part of the arguments is needed here
     const uint32_t slots = __builtin_amdgcn_readfirstlane(b->slots);
@@ -2428,9 +2435,15 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // segment moved 3.4x the bytes: a segment parks ~20 records of 16 bytes)
     uint32_t my_tot = 0u;
     if (lane < kExpandSegs) my_tot = gload<uint32_t>(wtot, lane * 4u);
-    // quiet content: most waves find sixteen empty segments -- they are done here, before the second load and the set-up
-    if (__builtin_amdgcn_ballot_w64((my_tot & 0xffffu) != 0u) == 0ull) return;
+    // (a wave's life is a chain of memory round trips -- counts, records, stores: everything that does not depend on the
+    // counts is asked for in the same trip as the counts)
     const uint32_t pref0 = gload<uint32_t>(wpref, 0u);  // events of the frame before segment seg0
+    const uint64_t fo = b->base.frame_offsets[f];
+    uint32_t lean_ofs = 0u;  // lean logs: lane q < kExpandSegs holds the byte offset of segment seg0 + q's run in its region
+    if (lean_log && lane < kExpandSegs)
+        lean_ofs = gload<uint32_t>(uniform_ptr(b->wofs_ring) + (size_t)slot * num_waves + seg0, lane * 4u) * lean_rec_bytes(ABS_T);
+    // quiet content: most waves find sixteen empty segments -- they are done here, before the records and the set-up
+    if (__builtin_amdgcn_ballot_w64((my_tot & 0xffffu) != 0u) == 0ull) return;
     // Lean: segments go in PAIRS, lanes 0-31 on the even one and lanes 32-63 on the odd one (a segment
     // parks ~20 records: one 64-lane round per segment would leave two thirds of the lanes idle); a pair
     // with a segment of more than 32 records takes the one-segment-at-a-time path below.
@@ -2439,10 +2452,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint8_t *log0 = nullptr;  // per-event records: the log region of segment seg0, the regions' stride, and
     uint32_t log_stride = 0u;       // where each segment's run of this frame starts inside its region (bytes)
     uint32_t log_run[FORMAT == 0 ? kExpandSegs : 1u];
-    uint32_t lean_ofs = 0u;  // lean logs: lane q < kExpandSegs holds the byte offset of segment seg0 + q's run in its region
     if (LEAN) {
-        if (lean_log && lane < kExpandSegs)
-            lean_ofs = gload<uint32_t>(uniform_ptr(b->wofs_ring) + (size_t)slot * num_waves + seg0, lane * 4u) * lean_rec_bytes(ABS_T);
         auto fetch_pair = [&](uint32_t p) -> uint4 {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
@@ -2484,7 +2494,6 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // the wave's events occupy [gpos, gpos + sum of its segments' event counts) of the stream
     // (frame_offsets is written by the offsets kernel: a vector load; its value goes to scalar registers by hand, or all
     // of the flush arithmetic below -- capacity check, phase, destination -- runs on the vector ALU in every lane)
-    const uint64_t fo = b->base.frame_offsets[f];
     uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32)) << 32) |
                      __builtin_amdgcn_readfirstlane((uint32_t)fo)) + __builtin_amdgcn_readfirstlane(pref0);
     uint32_t fill = 0u;                        // events staged (uniform)
@@ -2515,11 +2524,12 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         // (an all-zero record decodes to no events)
         // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
         const LeanEvents e = ABS_T ? lean_decode(r, true, rt_u32)
-                             : lean_runs ? lr_decode8(rw.x, rw.y, time_spanned_u, rt_u32)
+                             : lean_runs ? lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c)
                                          : lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
         const uint32_t incl = wave_inclusive_scan_dpp(n);
-        const uint32_t w = phase + (fill + incl - n) * 3u;  // the record's first dword in the buffer
+        const uint32_t ev0 = fill + incl - n;
+        const uint32_t w = phase + ev0 + (ev0 << 1);  // the record's first dword in the buffer (x3 without a 64-bit multiply-add)
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
         const uint32_t unit = ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : lean_runs ? rw.y & 0x7fu : (rw.y >> kLean8UnitShift) & 0x7fu;

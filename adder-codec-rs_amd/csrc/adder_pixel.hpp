@@ -1358,6 +1358,48 @@ ADDER_HD LeanEvents lr_decode8(uint32_t w0, uint32_t w8, float T, uint32_t runni
     e.tc = f32_as_u32(fadd(0.0f, fmul(T, fdiv_small(fsub(p2, 0.0f), I))));  // (C exists only for I >= 1)
     return e;
 }
+// The same through a table: the expansion is bound by vector instructions, and the two events' arithmetic (three
+// divisions, the reciprocals at a quarter of the rate) is most of a record's.  tab[I * kLrTabRuns + rho] = d << 24 | t of
+// event A for rho < kLrTabRuns (I = 0: the black root's (128, T)), tab[256 * kLrTabRuns + v] the same of event C; every t
+// fits 24 bits (rho T < 2^24 is the regime's own condition).  Longer runs are worked out (a branch no lane takes in most
+// rounds).  Built by lr_build_tab with the very functions above: equal bit for bit by construction, and tests/cpu_sim
+// decodes through it against the oracle.
+constexpr uint32_t kLrTabRuns = 32, kLrTabWords = 256u * kLrTabRuns + 256u;
+ADDER_HD void lr_build_tab(uint32_t *tab, float T) {
+    for (uint32_t I = 0; I < 256u; ++I) {
+        for (uint32_t rho = 0; rho < kLrTabRuns; ++rho) {
+            const LeanEvents e = lr_decode8(rho, (I << kLrBaseShift) | ((I ^ 1u) << kLrInShift), T, 0u);
+            tab[I * kLrTabRuns + rho] = (e.da << 24) | (e.ta & 0xffffffu);
+        }
+        const LeanEvents e = lr_decode8(0u, (0u << kLrBaseShift) | (I << kLrInShift), T, 0u);
+        tab[256u * kLrTabRuns + I] = I != 0u ? (e.dc << 24) | (e.tc & 0xffffffu) : 0u;
+    }
+}
+// tab_a: the event-A rows (may be null: then A is always worked out -- per-lane gathers from global memory cost the
+// expansion more than the divisions they replace, so the kernel keeps only the 256 event-C words, in LDS)
+ADDER_HD LeanEvents lr_decode8_tab(uint32_t w0, uint32_t w8, float T, uint32_t running_t_u32, const uint32_t *tab_a,
+                                   const uint32_t *tab_c) {
+    LeanEvents e;
+    const uint32_t Io = (w8 >> kLrBaseShift) & 0xffu, Iv = (w8 >> kLrInShift) & 0xffu;
+    const bool flush = Io != Iv;
+    e.a = flush && w0 != 0u;
+    e.b = e.a && Io != 0u;
+    e.c = flush && Iv != 0u;
+    const uint32_t xc = tab_c[Iv];
+    if (tab_a != nullptr && w0 < kLrTabRuns) {
+        const uint32_t xa = tab_a[Io * kLrTabRuns + w0];
+        e.da = xa >> 24;
+        e.ta = xa & 0xffffffu;
+    } else {
+        const CrNode n = cr_node(Io != 0u ? (float)Io : 1.0f, w0 != 0u ? w0 : 1u, T);
+        e.da = Io != 0u ? lean_bd_from_thr(f32_to_bits(n.thr)) : kDZero;
+        e.ta = f32_as_u32(Io != 0u ? n.bdt : T);
+    }
+    e.tb = running_t_u32;
+    e.dc = xc >> 24;
+    e.tc = xc & 0xffffffu;
+    return e;
+}
 // back to the resident form {header, integration, delta_t, best delta_t}
 template <class L>
 ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, float &bdt) {

@@ -547,6 +547,8 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
         s->running_t = rt;
     }
     std::vector<std::vector<SimEvent>> per_frame(nb);
+    std::vector<uint32_t> lr_tab(kLrTabWords);
+    lr_build_tab(lr_tab.data(), T);
     int rc = 0;
     size_t u = 0;
     for (uint32_t y = 0; y < s->H; y++)
@@ -564,7 +566,11 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                     if (fl.b && !fl.a) rc = -9;
                     if (!(fl.a || fl.c)) continue;  // (no record)
                     if ((w8 & 127u) != (u & 127u)) rc = -9;
-                    const LeanEvents e = lr_decode8(w0, w8, T, f32_as_u32(rts[i]));
+                    const LeanEvents e = lr_decode8_tab(w0, w8, T, f32_as_u32(rts[i]), (u & 1u) ? lr_tab.data() : nullptr, lr_tab.data() + 256u * kLrTabRuns);  // (as the expansion does; odd units through the A rows too)
+                    {
+                        const LeanEvents e2 = lr_decode8(w0, w8, T, f32_as_u32(rts[i]));
+                        if ((e.a && (e.da != e2.da || e.ta != e2.ta)) || (e.c && (e.dc != e2.dc || e.tc != e2.tc))) rc = -11;
+                    }
                     if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
                     SimEvent ev;
                     ev.x = (uint16_t)x; ev.y = (uint16_t)(y + s->row_begin); ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)c; ev.pad = 0;
