@@ -151,6 +151,7 @@ SYMBOLS = {
     "adder_hip_integrate": (_i32, [_vp, _vp, _sz, _f32, _vp, _sz, C.POINTER(_sz), _vp]),
     "adder_hip_integrate_batch": (_i32, [_vp, _vp, _u32, _sz, _sz, _f32, _vp, _sz, C.POINTER(_sz), _vp]),
     "adder_hip_integrate_device": (_i32, [_vp, _vp, _u32, _f32, _vp, _sz, _vp, _vp]),
+    "adder_hip_integrate_wire_device": (_i32, [_vp, _vp, _u32, _f32, _vp, _sz, _vp, _vp]),
     "adder_hip_finish": (_i32, [_vp, C.POINTER(_sz)]),
     "adder_hip_chunk_offsets_device": (_i32, [_vp, _vp, _sz, _vp, _vp]),
     "adder_hip_running_intensities": (_i32, [_vp, _vp]),

@@ -325,6 +325,17 @@ class HipVideo:
             self.h, d_frames.data_ptr(), T, ts, d_events.data_ptr(), cap, d_offsets.data_ptr(),
             C.c_void_p(stream) if stream else None))
 
+    def integrate_wire_device(self, d_frames, d_wire, d_offsets, time_spanned=None, stream=None):
+        """As integrate_device, but d_wire (uint8 CUDA tensor) receives the raw sink's 9 / 11-byte records back to back
+        (adder_hip_integrate_wire_device); d_offsets still counts events."""
+        T = d_frames.shape[0]
+        assert d_frames.is_contiguous() and d_frames.numel() == T * self.n_units
+        assert d_offsets.numel() >= T + 1 and d_offsets.element_size() == 8
+        ts = float(self.ref_time) if time_spanned is None else float(time_spanned)
+        N.check(self.h, self.L.adder_hip_integrate_wire_device(
+            self.h, d_frames.data_ptr(), T, ts, d_wire.data_ptr(), d_wire.numel() * d_wire.element_size(), d_offsets.data_ptr(),
+            C.c_void_p(stream) if stream else None))
+
     # ---- records over the wire (include/adder_hip.h): a band ships its parked records, root expands them ----
     def band_segments(self):
         return int(self.L.adder_hip_band_segments(self.h))

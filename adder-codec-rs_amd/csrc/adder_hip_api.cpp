@@ -162,6 +162,7 @@ struct AdderHipCtx {
     // share the batches' word (a capacity flag of theirs would be charged to an unrelated batch, and clearing theirs
     // could erase a flag a batch in flight raised)
     uint64_t *d_side_words = nullptr;
+    bool wire_batch = false;      // the batch being enqueued writes the raw sink's records instead of AdderEvents (adder_hip_integrate_wire_device)
     uint8_t *d_rr_tab = nullptr;  // [256][kRrTabRows] chain lengths of the run-records step (built at its first batch)
     uint32_t *d_lr_tab = nullptr; // [kLrTabWords] the lean-runs expansion's events by (base_val, rho) / input, for lr_tab_time
     float lr_tab_time = 0.0f;
@@ -1432,7 +1433,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
-                             (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) |
+                             (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |
                              ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
     if (lr && (!c->d_lr_tab || c->lr_tab_time != time_spanned)) {  // (cr_valid: one time step per reset, so once per stream)
         std::vector<uint32_t> tab(kLrTabWords);
@@ -1448,6 +1449,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         HIPCHK(c, dalloc(&c->d_rr_tab, tab.size()));
         HIPCHK(c, hipMemcpy(c->d_rr_tab, tab.data(), tab.size(), hipMemcpyHostToDevice));
     }
+    if (c->wire_batch && (c->continuous || fpath || c->records_only))
+        return fail(c, ADDER_E_BAD_PARAMS, "wire records straight from the expansion: dense FramePerfect batches without feature mode only "
+                    "(otherwise integrate events and serialise them with adder_hip_wire_events_device)");
     if (c->records_only && (generic || c->continuous || fpath))
         return fail(c, ADDER_E_BAD_PARAMS, "records can be handed out in the lean regime only (Collapse, delta_t_max <= "
                     "time_spanned, no feature mode, no generic batch before): gather events instead");
@@ -1511,6 +1515,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.base.frame_offsets = d_offsets;
     b.base.lean = (variant & 512u) ? 3u : (generic || c->continuous) ? 0u : ((variant & 256u) ? 2u : 1u);  // 2: lean-runs records (lr_decode8), 3: run records (rr_event)
     b.base.abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 1u : 0u;
+    b.base.wire_rec = c->wire_batch ? (c->p.channels == 1 ? 9u : 11u) : 0u;
     b.base.sc = make_consts(c, time_spanned);
     b.frames = d_frames;
     b.ftab = c->d_ftab;
@@ -1628,6 +1633,18 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->frames_done += num_frames;
     c->band_frame_pending = band_features(c);
     return ADDER_OK;
+}
+
+// The same batch with the raw sink's records as its output (include/adder_hip.h): out_cap in records.
+extern "C" int adder_hip_integrate_wire_device(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
+                                               uint8_t *d_wire, size_t wire_cap_bytes, uint64_t *d_frame_offsets, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    const size_t rec = c->p.channels == 1 ? 9u : 11u;
+    c->wire_batch = true;
+    const int rc = adder_hip_integrate_device(c, d_frames, num_frames, time_spanned, reinterpret_cast<AdderEvent *>(d_wire),
+                                              wire_cap_bytes / rec, d_frame_offsets, stream);
+    c->wire_batch = false;
+    return rc;
 }
 
 extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames,

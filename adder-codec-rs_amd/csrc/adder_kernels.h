@@ -105,6 +105,7 @@ struct FrameArgs {
     uint32_t width, channels, rowlen, row_begin;
     uint32_t lean;        // 1: the batch runs the lean K1 (LeanRec records); 2: lean runs ({rho, base_val ..} records); 0: generic
     uint32_t abs_t;       // TimeMode::AbsoluteT (record decoding)
+    uint32_t wire_rec;    // 0: `out` takes 12-byte AdderEvents; 9 / 11: the raw sink's records (bytes, back to back), out_cap in records
     StepConsts sc;        // running_t / cth are filled per frame from the table
 };
 

@@ -2305,12 +2305,18 @@ __device__ __forceinline__ uint32_t coord_xy_c(const UnitCoord &uc, uint32_t uni
 // The wave's staging buffer -> the stream.  xb[phase .. phase + 3 n) holds n events whose first dword
 // goes to dword `gd0` of the output (phase == gd0 & 3, so 16-byte blocks of the buffer are 16-byte
 // blocks of the destination).  Uniform arguments; returns nothing, the caller resets its fill.
+__device__ __forceinline__ void xbuf_flush_dwords(const uint32_t *xb, uint32_t phase, uint32_t nd, uint32_t *out_dw,
+                                                  uint64_t gd0, uint32_t lane);
 __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, uint32_t n, uint32_t *out_dw,
                                            uint64_t gd0, uint32_t lane) {
+    xbuf_flush_dwords(xb, phase, n * 3u, out_dw, gd0, lane);
+}
+// xb[phase .. phase + nd) -> dwords [gd0, gd0 + nd) of the output, phase == gd0 & 3
+__device__ __forceinline__ void xbuf_flush_dwords(const uint32_t *xb, uint32_t phase, uint32_t nd, uint32_t *out_dw,
+                                                  uint64_t gd0, uint32_t lane) {
 #if defined(ADDER_DBG_X_NOSTORE)  // diagnostic A/B build: the expansion without its event stores
     return;
 #endif
-    const uint32_t nd = n * 3u;
     uint32_t head = (4u - phase) & 3u;
     head = head < nd ? head : nd;
     uint32_t *const dst = out_dw + gd0;  // uniform 64-bit base; the lanes add 32-bit offsets
@@ -2340,6 +2346,109 @@ __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, u
 #endif
     const uint32_t tail = (nd - head) & 3u;
     if (lane < tail) gstore_ev<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
+}
+
+// The same straight into the raw sink's records (RawOutput::ingest_event, raw/stream.rs:101-120: bincode fixint big-endian;
+// 9 bytes {x u16, y u16, d u8, t u32} on a 1-channel plane, 11 bytes {x, y, 0x01, c, d, t} otherwise): the stream's
+// largest buffer shrinks by a quarter and no second pass serialises it.  Event k of the stream lies at byte k * rec, so
+// FOUR events are rec whole dwords: a lane takes four staged events whose stream index is a multiple of four (three
+// 16-byte LDS reads: the caller staged the events so that these are aligned), funnels their 36 / 44 record bytes into 9 /
+// 11 dwords and stores them; the <= 3 events before the first such group and after the last one share their dwords with
+// the neighbouring waves' events and go out byte by byte.
+struct WireWords {
+    uint32_t w0, w1, w2;  // the record's bytes, little-endian packed (w2: its last 1 / 3 bytes)
+};
+__device__ __forceinline__ WireWords wire_words(uint32_t xy, uint32_t cd, uint32_t t, uint32_t rec) {
+    WireWords r;
+    r.w0 = __builtin_amdgcn_perm(0u, xy, 0x02030001u);  // x_hi x_lo y_hi y_lo
+    const uint32_t tb = __builtin_amdgcn_perm(0u, t, 0x00010203u);  // t3 t2 t1 t0
+    const uint32_t d = (cd >> 8) & 0xffu;
+    if (rec == 9u) {
+        r.w1 = d | (tb << 8);
+        r.w2 = tb >> 24;
+    } else {
+        r.w1 = 1u | ((cd & 0xffffu) << 8) | (tb << 24);
+        r.w2 = tb >> 8;
+    }
+    return r;
+}
+__device__ __forceinline__ void xbuf_flush_wire(const uint32_t *xb, uint32_t pad, uint32_t n, uint8_t *out, uint64_t g0,
+                                                uint32_t rec, uint32_t lane) {
+    uint32_t head = (4u - ((uint32_t)g0 & 3u)) & 3u;
+    head = head < n ? head : n;
+    const uint32_t body = (n - head) >> 2, tail = (n - head) & 3u;
+    uint8_t *const dst = out + g0 * rec;  // uniform 64-bit base; the lanes add 32-bit offsets
+    if (lane < head + tail) {  // byte by byte: the events that share dwords with another wave's
+        const uint32_t k = lane < head ? lane : n - tail + (lane - head);
+        const WireWords r = wire_words(xb[pad + 3u * k], xb[pad + 3u * k + 1u], xb[pad + 3u * k + 2u], rec);
+        uint8_t *const p = dst + k * rec;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            p[j] = (uint8_t)(r.w0 >> (8u * j));
+            p[4u + j] = (uint8_t)(r.w1 >> (8u * j));
+        }
+        p[8] = (uint8_t)r.w2;
+        if (rec != 9u) {
+            p[9] = (uint8_t)(r.w2 >> 8);
+            p[10] = (uint8_t)(r.w2 >> 16);
+        }
+    }
+    if (body == 0u) return;
+    // the body: four events -> rec dwords, written back over the staged events (every lane has read its twelve dwords
+    // before any lane writes, and the compacted run stays below what later passes still have to read), at the 16-byte
+    // phase of the run's destination -- then the plain flush: 16-byte stores, a kilobyte per instruction
+    const uint32_t b0 = pad + 3u * head;  // a multiple of 4 (the caller's pad)
+    const uint64_t gd0 = (g0 + head) * rec >> 2;  // the run's first dword in the output
+    const uint32_t q0 = (uint32_t)gd0 & 3u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *const xw = const_cast<uint32_t *>(xb);
+    for (uint32_t m0 = 0; m0 < body; m0 += kWave) {  // uniform trip count
+        const uint32_t m = m0 + lane;
+        if (m < body) {
+            const uint4 q0v = *reinterpret_cast<const uint4 *>(xb + b0 + 12u * m);
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(xb + b0 + 12u * m + 4u);
+            const uint4 q2 = *reinterpret_cast<const uint4 *>(xb + b0 + 12u * m + 8u);
+            const WireWords r0 = wire_words(q0v.x, q0v.y, q0v.z, rec), r1 = wire_words(q0v.w, q1.x, q1.y, rec);
+            const WireWords r2 = wire_words(q1.z, q1.w, q2.x, rec), r3 = wire_words(q2.y, q2.z, q2.w, rec);
+            uint32_t *const o = xw + q0 + rec * m;  // rec dwords per group of four
+            if (rec == 9u) {
+                o[0] = r0.w0;
+                o[1] = r0.w1;
+                o[2] = (r0.w2 & 0xffu) | (r1.w0 << 8);
+                o[3] = (r1.w0 >> 24) | (r1.w1 << 8);
+                o[4] = (r1.w1 >> 24) | ((r1.w2 & 0xffu) << 8) | (r2.w0 << 16);
+                o[5] = (r2.w0 >> 16) | (r2.w1 << 16);
+                o[6] = (r2.w1 >> 16) | ((r2.w2 & 0xffu) << 16) | (r3.w0 << 24);
+                o[7] = (r3.w0 >> 8) | (r3.w1 << 24);
+                o[8] = (r3.w1 >> 8) | (r3.w2 << 24);
+            } else {
+                o[0] = r0.w0;
+                o[1] = r0.w1;
+                o[2] = (r0.w2 & 0xffffffu) | (r1.w0 << 24);
+                o[3] = (r1.w0 >> 8) | (r1.w1 << 24);
+                o[4] = (r1.w1 >> 8) | (r1.w2 << 24);
+                o[5] = ((r1.w2 >> 8) & 0xffffu) | (r2.w0 << 16);
+                o[6] = (r2.w0 >> 16) | (r2.w1 << 16);
+                o[7] = (r2.w1 >> 16) | (r2.w2 << 16);
+                o[8] = ((r2.w2 >> 16) & 0xffu) | (r3.w0 << 8);
+                o[9] = (r3.w0 >> 24) | (r3.w1 << 8);
+                o[10] = (r3.w1 >> 24) | (r3.w2 << 8);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next pass reads beyond what this one wrote; order the LDS traffic anyway)
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    xbuf_flush_dwords(xb, q0, body * rec, reinterpret_cast<uint32_t *>(out), gd0, lane);
+}
+// where the first staged event goes in the LDS buffer (dwords): events -> the 16-byte phase of its destination; wire
+// records -> so that the first event whose stream index is a multiple of four lies on a 16-byte boundary
+__device__ __forceinline__ uint32_t xbuf_phase(uint64_t gpos, uint32_t wire_rec) {
+    if (wire_rec == 0u) return (uint32_t)(gpos * 3u) & 3u;
+    const uint32_t head = (4u - ((uint32_t)gpos & 3u)) & 3u;
+    return (4u - ((3u * head) & 3u)) & 3u;
 }
 
 // Stages the <= 3 events of one decoded lean record at dword w of the buffer.
@@ -2378,16 +2487,18 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
     return make_uint4(r.x, r.y, 0u, 0u);
 }
 
-template <int FORMAT, bool ABS_T>
+template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
     constexpr bool RR = FORMAT == 4;
+    constexpr bool LR = FORMAT == 5;  // lean-runs records in fixed slots (adder_lr_kernel; DeltaT only): a format of its own, so that
+                                      // the decoders do not meet in one instantiation (their results would merge through registers)
+    static_assert(!LR || !ABS_T, "lean runs are a DeltaT format");
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
     __shared__ uint16_t s_owner[RR ? kWavesPerBlock : 1u][RR ? kRrOwnerWindow : 1u];  // (run records: event -> record lane | index << 8)
     // lean runs: event C by input byte (lr_build_tab), 1 KB per workgroup out of L2 -- a division less per record
-    constexpr bool LRC = FORMAT == 1 && !ABS_T;
-    __shared__ uint32_t s_tab_c[LRC ? 256u : 1u];
-    if (LRC && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u) {
+    __shared__ uint32_t s_tab_c[LR ? 256u : 1u];
+    if (LR) {
         s_tab_c[threadIdx.x] = uniform_ptr(b->lr_tab)[256u * kLrTabRuns + threadIdx.x];
         __syncthreads();
     }
@@ -2428,7 +2539,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint64_t out_cap = b->base.out_cap;
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
     const float time_spanned_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
-    const bool lean_runs = LEAN && !RR && !ABS_T && __builtin_amdgcn_readfirstlane(b->base.lean) == 2u;
+    constexpr bool lean_runs = LR;
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
     // segments' counts first, then exactly the records they hold (a speculative fetch of 64 records per
@@ -2497,7 +2608,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32)) << 32) |
                      __builtin_amdgcn_readfirstlane((uint32_t)fo)) + __builtin_amdgcn_readfirstlane(pref0);
     uint32_t fill = 0u;                        // events staged (uniform)
-    uint32_t phase = (uint32_t)(gpos * 3u) & 3u;  // dword phase of the staging buffer's first event
+    // WIRE: the raw sink's records instead of AdderEvents (an instantiation of its own: both flushes in one body cost
+    // the unrolled segment loop its registers)
+    const uint32_t wire_rec = WIRE ? __builtin_amdgcn_readfirstlane(b->base.wire_rec) : 0u;
+    uint32_t phase = xbuf_phase(gpos, wire_rec);  // where the staging buffer's first event goes (dwords)
     bool dropped = false;
     // staged events -> stream; events past the caller's capacity are dropped and reported
     auto flush = [&]() {
@@ -2506,11 +2620,14 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         dropped = dropped || n != fill;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (n) xbuf_flush(xb, phase, n, out_dw, gpos * 3u, lane);
+        if (n) {
+            if constexpr (WIRE) xbuf_flush_wire(xb, phase, n, reinterpret_cast<uint8_t *>(out_dw), gpos, wire_rec, lane);
+            else xbuf_flush(xb, phase, n, out_dw, gpos * 3u, lane);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         gpos += fill;
-        phase = (uint32_t)(gpos * 3u) & 3u;
+        phase = xbuf_phase(gpos, wire_rec);
         fill = 0u;
     };
     // 64 lean records (or none) of ONE segment whose first unit is at (uc.y0, uc.rem0 + unit_shift)
@@ -2523,9 +2640,10 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         r.w8 = rw.y;
         // (an all-zero record decodes to no events)
         // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
-        const LeanEvents e = ABS_T ? lean_decode(r, true, rt_u32)
-                             : lean_runs ? lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c)
-                                         : lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
+        LeanEvents e;
+        if constexpr (LR) e = lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
+        else if constexpr (ABS_T) e = lean_decode(r, true, rt_u32);
+        else e = lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
         const uint32_t incl = wave_inclusive_scan_dpp(n);
         const uint32_t ev0 = fill + incl - n;
@@ -2742,12 +2860,12 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     if (dropped) raise(b->base.status, kStatusCapacity);
 }
 
-template <int FORMAT, bool ABS_T>
+template <int FORMAT, bool ABS_T, bool WIRE = false>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0,
                                                                      uint32_t xblocks, uint32_t nf) {
     // (frame, group of segments) pairs, frame-major; a grid smaller than their number walks them (see the lean kernel)
     timeline_mark(b, 3u, f0, false);
-    for (uint32_t w = blockIdx.x; w < xblocks * nf; w += gridDim.x) expand_block<FORMAT, ABS_T>(b, f0 + w / xblocks, w % xblocks);
+    for (uint32_t w = blockIdx.x; w < xblocks * nf; w += gridDim.x) expand_block<FORMAT, ABS_T, WIRE>(b, f0 + w / xblocks, w % xblocks);
     timeline_mark(b, 3u, f0, true);
 }
 
@@ -3387,20 +3505,23 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     uint32_t total = xblocks * nf;
     if (grid_cap && grid_cap < total) total = grid_cap;
     const dim3 grid(total);
-    const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u;
-    if (continuous) hipLaunchKernelGGL((adder_expand_kernel<2, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+    const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u, wire = variant & 1024u;
+#define ADDER_X(F, A, W) hipLaunchKernelGGL((adder_expand_kernel<F, A, W>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf)
+#define ADDER_XW(F, A) do { if (wire) ADDER_X(F, A, true); else ADDER_X(F, A, false); } while (0)
+    if (continuous) ADDER_X(2, false, false);  // (its events are stored as they are decoded: no wire form)
     else if (variant & 512u) {  // run records in per-segment logs
-        if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<4, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-        else hipLaunchKernelGGL((adder_expand_kernel<4, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-    }
-    else if (generic && (variant & 32u)) hipLaunchKernelGGL((adder_expand_kernel<0, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-    else if (generic) hipLaunchKernelGGL((adder_expand_kernel<0, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+        if (abs_t) ADDER_XW(4, true);
+        else ADDER_XW(4, false);
+    } else if (generic && (variant & 32u)) ADDER_XW(0, true);
+    else if (generic) ADDER_XW(0, false);
     else if (variant & 64u) {
-        if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<3, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-        else hipLaunchKernelGGL((adder_expand_kernel<3, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-    }
-    else if (abs_t) hipLaunchKernelGGL((adder_expand_kernel<1, true>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
-    else hipLaunchKernelGGL((adder_expand_kernel<1, false>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf);
+        if (abs_t) ADDER_XW(3, true);
+        else ADDER_XW(3, false);
+    } else if (abs_t) ADDER_XW(1, true);
+    else if (variant & 256u) ADDER_XW(5, false);
+    else ADDER_XW(1, false);
+#undef ADDER_XW
+#undef ADDER_X
     return hipGetLastError();
 }
 

@@ -75,6 +75,11 @@ def parse_args():
                          "'host' = a sink per rank: every rank stores its own wire bytes into the one .adder image in "
                          "shared memory over its own PCIe link (adder_gather_host_sink_*); 'layout' = all-gather of the "
                          "per-frame counts only")
+    ap.add_argument("--output", default="events", choices=["events", "wire"],
+                    help="N=1: what the timed step leaves in HBM: 12-byte AdderEvents (adder_hip_integrate_device; the default, and "
+                         "N>1 always: the gathers move events or records) or the raw sink's 9 / 11-byte records written by the "
+                         "expansion itself (adder_hip_integrate_wire_device: the bytes of the .adder file between header and "
+                         "EOF).  The other form is timed in the same process as `output_check` either way")
     ap.add_argument("--skip-roofline", action="store_true",
                     help="no per-launch timing passes (used under rocprofv3 so that only default launches are seen)")
     return ap.parse_args()
@@ -287,13 +292,18 @@ def main():
                 side.synchronize()
                 merged_total = merged_pos if rank == 0 else pos
             return pos, merged_total
-        hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
+        if wire_out:
+            hv.integrate_wire_device(d_frames, d_events.view(torch.uint8).reshape(-1), d_offsets, stream=stream)
+        else:
+            hv.integrate_device(d_frames, d_events, d_offsets, stream=stream)
         n = hv.finish()
         merged_total = n
         if mode == "layout":
             lay = sharding.exchange_stream_layout(d_offsets.cpu() if share else d_offsets)
             merged_total = int(lay[0][-1])
         return n, merged_total
+
+    wire_out = world == 1 and args.output == "wire"
 
     def barrier():
         if world > 1:
@@ -335,6 +345,41 @@ def main():
     elapsed, (n_events, merged_total) = timed(gather_mode, args.steps, args.warmup)
     kernel_ms = hv.last_batch_ms()  # HIP events around the last step's frame loop
     records = wire.get("records") if gather_mode in ("records", "records-torch") else hv.last_batch_records()
+
+    output_check = None
+    if world == 1 and not args.skip_roofline:
+        # the same step with the OTHER output form, in this process (same context, same buffers), and the whole stream's
+        # bytes checked: the expansion's records == the events serialised by the separate pass (adder_hip_wire_events_device)
+        rec_b = 9 if Cn == 1 else 11
+        main_wire = wire_out
+        alt_steps = max(4, args.steps // 4)
+        wire_out = not main_wire
+        for _ in range(plan_steps):  # (another batch variant: its launch plan settles first, untimed like the headline's)
+            step("none")
+        alt_elapsed, _ = timed("none", alt_steps, 2)
+        wire_out = False
+        hv.reset()
+        step("none")
+        n_ev2 = int(d_offsets[-1].item())
+        offs_ev = d_offsets.clone()
+        d_wire_ref = torch.empty(n_ev2 * rec_b + 16, dtype=torch.uint8, device=dev)
+        hv.wire_events_device(d_events, n_ev2, d_wire_ref, stream=stream)
+        d_wire = torch.empty(n_ev2 * rec_b + 16, dtype=torch.uint8, device=dev)
+        hv.reset()
+        hv.integrate_wire_device(d_frames, d_wire, d_offsets, stream=stream)
+        n_w = hv.finish()
+        torch.cuda.synchronize()
+        output_check = {
+            ("events_output_ms_per_step" if main_wire else "wire_output_ms_per_step"): round(alt_elapsed / alt_steps * 1e3, 3),
+            "wire_bytes": int(n_w * rec_b),
+            "wire_equals_serialised_events_whole_stream": bool(n_w == n_ev2 and torch.equal(d_wire[:n_w * rec_b], d_wire_ref[:n_w * rec_b])
+                                                               and torch.equal(offs_ev, d_offsets)),
+            "note": "adder_hip_integrate_wire_device: the expansion serialises the events itself (25 % fewer bytes stored, no "
+                    "second pass); where the process's buffers landed decides which form is faster (DESIGN section 5)",
+        }
+        del d_wire, d_wire_ref
+        wire_out = main_wire
+        hv.reset()
 
     total_events = n_events
     layout_elapsed, layout_steps = None, max(2, args.steps // 2)
@@ -463,7 +508,9 @@ def main():
         "config": {
             "workload": f"{Wd}x{Ht}{'x3 RGB' if Cn == 3 else ' gray'} 8-bit, {T} frames, "
                         f"delta_t_max={args.delta_t_max}, ref_time={REF_TIME}, content={args.content}, crf0 "
-                        f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, raw events to HBM",
+                        f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, " +
+                        ("the raw sink's 9 / 11-byte records to HBM (serialised by the expansion)" if wire_out else "raw events to HBM"),
+            "output": "raw-sink records" if wire_out else "AdderEvents (12 B)",
             "plane": [Wd, Ht, Cn],
             "rows_per_gpu": rows,
             "row_bands": [list(b) for b in bands],
@@ -479,6 +526,7 @@ def main():
             "world_size_seen": world,
             "backend": "none" if world == 1 else ("gloo (shared-device debug)" if share else "nccl (RCCL)"),
         },
+        "output_check": output_check,
         "events_per_s": round(total_events / (elapsed / args.steps), 1),
         "events_per_pixel_frame": round(e_all, 5),
         "records_per_unit_frame": round(r0, 5),
@@ -500,6 +548,12 @@ def main():
             "traffic": traffic,
             "traffic_note": traffic_note,
             "bytes_per_unit_frame": round(alg_b, 3),
+            "bytes_per_unit_frame_note": "SURVEY 8(d)'s canonical figure: 1 input + state / T_launch + 12 per event (E = 12 B, "
+                                         "the device buffer's AdderEvent)" + (
+                "; this run's expansion writes the events as 9 / 11-byte records instead -- frac_at_record_bytes prices the "
+                "same time with E = the record's bytes" if wire_out else ""),
+            "frac_at_record_bytes": (round((alg_b - (12 - (9 if Cn == 1 else 11)) * e0) * units * chunk_frames / (chunk_us * 1e-6) / 1e9
+                                           / HBM_PEAK_GBS, 4) if wire_out and chunk_us > 0 else None),
             "frames_per_launch": k1_frames,
             "frames_per_chunk": chunk_frames,
             "units_per_chunk": int(units * chunk_frames),

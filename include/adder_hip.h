@@ -255,6 +255,16 @@ int adder_hip_integrate_batch(AdderHipCtx *ctx, const uint8_t *frames_hwc, uint3
 int adder_hip_integrate_device(AdderHipCtx *ctx, const uint8_t *d_frames, uint32_t num_frames,
                                float time_spanned, AdderEvent *d_out, size_t out_cap,
                                uint64_t *d_frame_offsets, void *stream);
+
+/* The same batch with the raw sink's RECORDS as its output: the expansion serialises every event as
+ * RawOutput::ingest_event does (raw/stream.rs:101-120: bincode fixint big-endian; 9 bytes {x u16, y u16, d u8, t u32} on
+ * a 1-channel plane, 11 bytes {x, y, 0x01, c, d, t} otherwise) and stores the records back to back -- the bytes between a
+ * raw .adder file's header and its EOF event, in HBM, without a second pass (and 25 % fewer bytes than AdderEvents).
+ * d_frame_offsets counts EVENTS as for adder_hip_integrate_device (frame f's records start at byte
+ * d_frame_offsets[f] * record_bytes); wire_cap_bytes / record_bytes is the capacity in events, with the same overflow
+ * semantics (adder_hip_finish reports the size needed and rolls back).  Dense FramePerfect batches without feature mode. */
+int adder_hip_integrate_wire_device(AdderHipCtx *ctx, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
+                                    uint8_t *d_wire, size_t wire_cap_bytes, uint64_t *d_frame_offsets, void *stream);
 /* Waits for the work queued by adder_hip_integrate_device and reports its status;
  * *n_out (may be NULL) = total events of the last device batch. */
 int adder_hip_finish(AdderHipCtx *ctx, size_t *n_out);

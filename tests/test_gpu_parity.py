@@ -712,6 +712,59 @@ def test_device_sink_equals_host_sink(channels):
         assert (got[nb:] == 0xAB).all()  # nothing written past the stream's end
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3])
+def test_expansion_writes_wire_records_directly(channels):
+    """adder_hip_integrate_wire_device: the expansion itself serialises (no AdderEvents in between).  Every expansion
+    format (lean runs, lean AbsoluteT / DeltaT, run records, constant runs, bounded Collapse, generic Normal), ragged
+    planes, batches that start at every stream index mod 4, a sentinel past the stream's end: the bytes equal the
+    oracle's raw sink byte for byte and the offsets still count events."""
+    import torch
+    A = _hip()
+    W, H = 157, 61
+    rec = 9 if channels == 1 else 11
+    st = torch.cuda.current_stream().cuda_stream
+    clip = clips.make_clip("runs", 72, H, W, channels, seed=31 + channels)
+    cases = [(O.DELTA_T, O.COLLAPSE, 255, 0), (O.ABSOLUTE_T, O.COLLAPSE, 255, 0), (O.DELTA_T, O.COLLAPSE, 255, 3),
+             (O.ABSOLUTE_T, O.COLLAPSE, 7650, 0), (O.DELTA_T, O.COLLAPSE, 7650, 0), (O.ABSOLUTE_T, O.COLLAPSE, 7650, 3),
+             (O.DELTA_T, O.NORMAL, 255, 0), (O.ABSOLUTE_T, O.NORMAL, 7650, 3)]
+    for tm, mm, dtm, crf in cases:
+        ov = O.Video(W, H, channels, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, channels, time_mode=tm, multi_mode=mm, ref_time=255, delta_t_max=dtm)
+        ov.ensure_capacity(24)
+        for v in (ov, hv):
+            v.set_crf_parameters(CRFS[crf][1], CRFS[crf][2])
+            v.reset_c_thresh(CRFS[crf][0])
+        k = 0
+        for nb in (1, 2, 3, 30, 34):
+            want = [ov.integrate_matrix(f) for f in clip[k:k + nb]]
+            n = sum(len(w) for w in want)
+            d_frames = torch.from_numpy(np.ascontiguousarray(clip[k:k + nb]).reshape(nb, -1)).cuda()
+            d_wire = torch.full((n * rec + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+            d_offs = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+            hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+            hv.finish()
+            offs = d_offs.cpu().numpy()
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (tm, mm, dtm, crf, k)
+            got = d_wire.cpu().numpy()
+            assert got[:n * rec].tobytes() == O.raw_events(np.concatenate(want), channels), (tm, mm, dtm, crf, k, nb)
+            assert (got[n * rec:] == 0xAB).all()
+            k += nb
+        # too small a buffer: reported with the size needed, rolled back, and the retry continues the stream
+        want = np.concatenate([ov.integrate_matrix(f) for f in clip[k:k + 2]])
+        d_frames = torch.from_numpy(np.ascontiguousarray(clip[k:k + 2]).reshape(2, -1)).cuda()
+        d_small = torch.zeros(max(rec, (len(want) // 2) * rec), dtype=torch.uint8, device="cuda")
+        d_offs = torch.zeros(3, dtype=torch.int64, device="cuda")
+        hv.integrate_wire_device(d_frames, d_small, d_offs, stream=st)
+        with pytest.raises(A.AdderHipError):
+            hv.finish()
+        d_wire = torch.zeros(len(want) * rec, dtype=torch.uint8, device="cuda")
+        hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+        hv.finish()
+        assert d_wire.cpu().numpy().tobytes() == O.raw_events(want, channels), (tm, mm, dtm, crf)
+        hv.close()
+
+
 def test_lake_golden_bytes_pipelined_stream(golden_dir):
     """Same golden through the pipelined submit/collect form (two batches in flight)."""
     A = _hip()
