@@ -1520,9 +1520,13 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.frames = d_frames;
     b.ftab = c->d_ftab;
     b.park_ring = c->park_ring;
-    b.park_bytes = c->park_bytes;
+    // run records: a fixed slot per (segment, frame) like the lean records' (at most one 8 / 12-byte record per unit and
+    // frame), laid out by park_offset inside the log ring (2 KB per segment and frame there: enough) -- the expansion
+    // reads the sixteen segments of a wave out of one contiguous stretch instead of sixteen logs 64 KB apart
+    const uint32_t pb = (variant & 512u) ? kWaveUnits * (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 12u : 8u) : c->park_bytes;
+    b.park_bytes = pb;
     // (a lean batch's region holds one record per unit and frame of the chunk: the same bytes as its fixed slots)
-    b.log_cap = (variant & (64u | 512u)) ? kWaveUnits * c->chunk : c->log_cap;  // (run records: <= 12 bytes each in a region of >= 2 * 128 * chunk * 8)
+    b.log_cap = (variant & 512u) ? 0u : (variant & 64u) ? kWaveUnits * c->chunk : c->log_cap;
     b.rr_tab = c->d_rr_tab;
     b.lr_tab = c->d_lr_tab;
     {
@@ -1538,16 +1542,16 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (b.log_cap) {
         b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};  // (unused: the records are appended to logs)
-    } else if ((launch_depth(c) == 1u || park_frame_major()) && (uint64_t)c->num_waves * c->park_bytes <= 0xffffffffull) {
-        b.park_layout = ParkLayout{31u, 0u, c->num_waves * c->park_bytes, c->park_bytes, 31u, 0xffffffffu};
+    } else if ((launch_depth(c) == 1u || park_frame_major()) && (uint64_t)c->num_waves * pb <= 0xffffffffull) {
+        b.park_layout = ParkLayout{31u, 0u, c->num_waves * pb, pb, 31u, 0xffffffffu};
     } else {
         uint32_t sh = c->park_group_shift;
-        while (sh && ((c->num_waves & ((1u << sh) - 1u)) || ((uint64_t)c->chunk * c->park_bytes << sh) > 0xffffffffull)) --sh;
-        b.park_layout = ParkLayout{sh, (c->chunk * c->park_bytes) << sh, c->park_bytes << sh, c->park_bytes, 31u, 0xffffffffu};
+        while (sh && ((c->num_waves & ((1u << sh) - 1u)) || ((uint64_t)c->chunk * pb << sh) > 0xffffffffull)) --sh;
+        b.park_layout = ParkLayout{sh, (c->chunk * pb) << sh, pb << sh, pb, 31u, 0xffffffffu};
         // segment-major: rotate the frame slots by the segment's group of 16 (needs a power-of-two chunk)
         static const bool rot_on = [] { const char *e = getenv("ADDER_HIP_PARK_ROT"); return !e || atoi(e) != 0; }();
         if (rot_on && sh == 0u && c->chunk >= 2u && (c->chunk & (c->chunk - 1u)) == 0u &&
-            (uint64_t)c->chunk * c->park_bytes <= 0xffffffffull) {
+            (uint64_t)c->chunk * pb <= 0xffffffffull) {
             b.park_layout.rot_shift = 4u;
             b.park_layout.rot_mask = c->chunk - 1u;
         }

@@ -1845,8 +1845,9 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_
 // last_fired_t / T.  The step is a handful of compares and a counter; a flush / collapsed flush / pop_top parks ONE record
 // of 8 (DeltaT) or 12 bytes, whatever the number of events it stands for (a byte table of chain lengths gives the count),
 // and the expansion works the events out.  Loads the header and delta_t (and last_fired_t) planes, stores the level-0
-// planes and the levels in their resident form.  Records go to the segment's log of the chunk (at most one per unit and
-// frame: a region of 128 * chunk records cannot overflow), the expansion is the lean one over logs (format 4).
+// planes and the levels in their resident form.  Records go to a fixed slot per (segment, frame) laid out like the lean
+// records' (at most one per unit and frame; groups of 16 segments contiguous per frame: what one expansion wave reads),
+// inside the generic log ring; the expansion is format 4.
 // ------------------------------------------------------------------------------------------
 #ifndef ADDER_RR_WAVES_PER_SIMD
 #define ADDER_RR_WAVES_PER_SIMD 6
@@ -1885,14 +1886,14 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
     const uint32_t frame0 = __builtin_amdgcn_readfirstlane((uint32_t)fdiv(a.sc.running_t, T));
     const uint32_t Tu = __builtin_amdgcn_readfirstlane((uint32_t)T);
     const uint32_t n_pop = __builtin_amdgcn_readfirstlane(((uint32_t)a.sc.dtm_f + Tu - 1u) / Tu);
-    // the segment's log of the chunk
-    const uint32_t cir = slot0 / chunk_u;  // (a launch never crosses a chunk boundary)
-    const size_t seg_idx = (size_t)cir * num_waves_u + sgw;
-    const uint32_t cap = __builtin_amdgcn_readfirstlane(b->log_cap);
-    uint8_t *const region = uniform_ptr(b->park_ring) + seg_idx * cap * REC;
-    uint32_t *const wcur_p = uniform_ptr(b->wcur) + seg_idx;
-    uint32_t cur = 0u;
-    if (slot0 != cir * chunk_u) cur = __builtin_amdgcn_readfirstlane(*wcur_p);  // not the chunk's first launch
+    // the segment's slot of the launch's first frame (lr_frames: the same ring layout and walk)
+    const uint32_t park_bytes_u = __builtin_amdgcn_readfirstlane(b->park_bytes);
+    const ParkLayout lay = park_layout_u(b);
+    const uint32_t frame_stride_u = lay.frame_stride;
+    uint8_t *seg = uniform_ptr(b->park_ring) + park_offset(slot0, sgw, chunk_u, num_waves_u, park_bytes_u, lay);
+    const uint32_t ridx0 = __builtin_amdgcn_readfirstlane((slot0 % chunk_u + (sgw >> lay.rot_shift)) & lay.rot_mask);
+    const uint32_t wrap_at = chunk_u - 1u - ridx0;  // (after this frame of the launch the walk returns to the chunk's first slot)
+    const uint32_t wrap_bytes = chunk_u * frame_stride_u;
     // the launch's input bytes into the wave's LDS slice, kRrInFrames frames at a time (lr_frames has the reasons)
     using InT = typename VecOf<uint8_t, N>::type;
     InT *const in_lds = reinterpret_cast<InT *>(lds_in) + lane;  // [frame of the group][lane]
@@ -1928,7 +1929,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): nothing else inside the frame loop waits on memory
     };
     const auto chain_tab = [&](uint32_t I, uint32_t r) -> uint32_t { return lds_tab[I * kRrTabRows + r]; };
-    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
+    uint32_t wt = 0u;  // lane i: {events | records << 16} of the launch's i-th frame
     bool active[N];
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) active[j] = FULL || u0 + j < n_units_u;
@@ -1952,7 +1953,6 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j)
             pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mrec[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mrec[j], pos));
-        uint8_t *const seg = region + (size_t)cur * REC;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
@@ -1967,15 +1967,13 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
             pos += has ? 1u : 0u;
         }
         wt = lane == i ? (nev | (nrec << 16)) : wt;
-        wo = lane == i ? cur : wo;
-        cur += nrec;
+        seg += frame_stride_u;
+        if (__builtin_expect(i == wrap_at, 0)) seg -= wrap_bytes;
     }
-    if (lane == 0u) *wcur_p = cur;
     if (lane < nb) {
         uint32_t s = slot0 + lane;
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
-        gstore<uint32_t>(uniform_ptr(b->wofs_ring), (s * num_waves_u + sgw) * 4u, wo);
     }
     {   // state back to HBM in its resident form
         uint32_t hdrv[N];
@@ -2275,7 +2273,6 @@ constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 #endif
 constexpr uint32_t kXbufEvents = ADDER_XBUF_EVENTS;   // staging capacity of one wave, in events (>= 192)
 constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
-constexpr uint32_t kRrOwnerWindow = 128;              // events of a run-record round placed at a time (<= kXbufEvents)
 
 struct UnitCoord {  // (row, offset in row) of a segment's first unit + the plane geometry (uniform)
     uint32_t y0, rem0, rowlen, channels, row_begin;
@@ -2494,8 +2491,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     constexpr bool LR = FORMAT == 5;  // lean-runs records in fixed slots (adder_lr_kernel; DeltaT only): a format of its own, so that
                                       // the decoders do not meet in one instantiation (their results would merge through registers)
     static_assert(!LR || !ABS_T, "lean runs are a DeltaT format");
-    __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][kXbufDwords];
-    __shared__ uint16_t s_owner[RR ? kWavesPerBlock : 1u][RR ? kRrOwnerWindow : 1u];  // (run records: event -> record lane | index << 8)
+    // staging capacity of one wave, in events: run-record rounds hold up to 64 x (depth + 1) events and like room
+    constexpr uint32_t XE = RR ? 640u : kXbufEvents;
+    __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][XE * 3u + 4u];
     // lean runs: event C by input byte (lr_build_tab), 1 KB per workgroup out of L2 -- a division less per record
     __shared__ uint32_t s_tab_c[LR ? 256u : 1u];
     if (LR) {
@@ -2520,7 +2518,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const ParkLayout lay = park_layout_u(b);
     // lean records of blocked batches lie in per-segment logs like the per-event ones (log_cap records per segment and
     // chunk, a frame's run at wofs); batches launched one frame at a time keep a fixed slot per frame
-    constexpr bool lean_log = FORMAT == 3 || FORMAT == 4;
+    constexpr bool lean_log = FORMAT == 3;
     const uint32_t lean_log_cap = lean_log ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
     const uint32_t seg_stride = FORMAT == 0 ? 0u : lean_log ? lean_log_cap * lean_rec_bytes(ABS_T) : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
@@ -2632,7 +2630,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     };
     // 64 lean records (or none) of ONE segment whose first unit is at (uc.y0, uc.rem0 + unit_shift)
     auto lean_round = [&](const uint4 &rw, uint32_t unit_shift) {
-        if (fill + 3u * kWave > kXbufEvents) flush();  // room for this round's worst case
+        if (fill + 3u * kWave > XE) flush();  // room for this round's worst case
         LeanRec r;
         r.ta = rw.x;
         r.tc = rw.y;
@@ -2654,48 +2652,49 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
-    // 64 run records (or none): a scan of the records' counts places the round's events; then ONE LANE PER EVENT -- an
-    // owner map in LDS (written by the record lanes, a short loop over their counts) tells event e its record and its
-    // index k in the record, the record's words come over ds_bpermute, and the lane works event k out (rr_event_at: k
-    // hops down the chain, then the node).  A loop over the records' chains instead cost every lane the round's longest
-    // chain at three divisions a step.
+    // 64 run records (or none) of ONE segment: a scan of the records' counts places the round's events, every lane
+    // walks its record's chain (one cr_node per event: the node's event, its last firing takes the walk to the next
+    // level).  One lane per EVENT instead (an owner map in LDS, the record's words over ds_bpermute, k hops + the node per
+    // lane) measured 204 us per 64-frame chunk against this loop's 186: the rounds hold ~58 events, so the second pass
+    // of 64 lanes runs nearly empty, and the LDS round trips sit in the wave's critical path.
     auto rr_round = [&](const uint4 &rw, uint32_t unit_shift) {
         const uint32_t w2 = ABS_T ? rw.z : rw.y;
         const uint32_t cnt = w2 >> kRrCountShift;  // (an all-zero record: no events)
         const uint32_t incl = wave_inclusive_scan_dpp(cnt);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         const uint32_t first_ev = incl - cnt;
+        const uint32_t kind = w2 & 3u, Iu = (w2 >> kRrBaseShift) & 0xffu;
+        const float I = (float)Iu;
         uint32_t c;
         const uint32_t xy = coord_xy_c(uc, ((w2 >> kRrUnitShift) & 0x7fu) + unit_shift, c);
-        uint16_t *const owner = s_owner[wid];
-        for (uint32_t e0 = 0; e0 < total; e0 += kRrOwnerWindow) {  // (uniform; one window unless the round holds more events)
-            const uint32_t piece = total - e0 < kRrOwnerWindow ? total - e0 : kRrOwnerWindow;
-            if (fill + piece > kXbufEvents) flush();
+        for (uint32_t e0 = 0; e0 < total; e0 += XE) {  // (uniform; one pass unless the round outgrows the buffer)
+            const uint32_t piece = total - e0 < XE ? total - e0 : XE;
+            if (fill + piece > XE) flush();
+            uint32_t r = rw.x;
             for (uint32_t k = 0; k < cnt; ++k) {
-                const uint32_t pos = first_ev + k - e0;  // (wraps below the window: unsigned compare)
-                if (pos < piece) owner[pos] = (uint16_t)(lane | (k << 8));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t p0 = 0; p0 < piece; p0 += kWave) {  // uniform
-                const uint32_t e = p0 + lane;
-                const uint32_t o = e < piece ? owner[e] : 0u;
-                const int src = (int)((o & 0x3fu) << 2);
-                const uint32_t rn = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw.x);
-                const uint32_t rlq = ABS_T ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)rw.y) : 0u;
-                const uint32_t rw2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w2);
-                const uint32_t rxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)xy);
-                const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c);
-                if (e < piece) {
-                    const RrEvent ev = rr_event_at<ABS_T>(rw2 & 3u, (rw2 >> kRrBaseShift) & 0xffu, rn, rlq, o >> 8, time_spanned_u, rt_u32);
-                    const uint32_t w = phase + (fill + e) * 3u;
-                    xb[w] = rxy;
-                    xb[w + 1u] = rc | (ev.d << 8);
-                    xb[w + 2u] = ev.t;
+                uint32_t d = kDEmpty, t = rt_u32;  // (the filler of a collapsed flush, :258-264)
+                if (!(kind == kRrCollapsed && k != 0u)) {
+                    float bdt = time_spanned_u;  // a black root: (D_ZERO, time_spanned)
+                    uint32_t j = 1u;
+                    d = kDZero;
+                    if (Iu != 0u) {
+                        const CrNode nd = cr_node(I, r, time_spanned_u);
+                        bdt = nd.bdt;
+                        j = nd.j;
+                        d = lean_bd_from_thr(f32_to_bits(nd.thr));
+                    }
+                    // event k's own last_fired_t: the firings above it telescope to n - r
+                    t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)(rw.y + (rw.x - r)), time_spanned_u)) : bdt);
+                    r -= j;
+                }
+                const uint32_t pos = first_ev + k;
+                if (pos >= e0 && pos < e0 + piece) {
+                    const uint32_t w = phase + (fill + pos - e0) * 3u;
+                    xb[w] = xy;
+                    xb[w + 1u] = c | (d << 8);
+                    xb[w + 2u] = t;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             fill += piece;
         }
     };
@@ -2720,11 +2719,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         auto fetch_pair_rr = [&](uint32_t p) -> uint4 {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
-            const uint32_t oa = __builtin_amdgcn_readlane(lean_ofs, 2 * p);
-            const uint32_t ob = __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1);
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa))
-                v = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
+                v = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride : 0u) + hl * lean_rec_bytes(ABS_T));
             return v;
         };
         uint4 cur_rec = first[0];
@@ -2741,7 +2738,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             } else {
                 const uint32_t cnt2[2] = {pa, pb};
                 for (uint32_t h = 0; h < 2u; ++h) {
-                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride + __builtin_amdgcn_readlane(lean_ofs, 2 * p + h);
+                    const uint8_t *const seg_park = park + (size_t)(2 * p + h) * seg_stride;
                     for (uint32_t i0 = 0; i0 < cnt2[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt2[h]) rw = lean_load_rec<ABS_T>(seg_park, (i0 + lane) * lean_rec_bytes(ABS_T));
@@ -2759,7 +2756,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
             if (pa <= 32u && pb <= 32u) {
 #if defined(ADDER_DBG_X_NODECODE)  // diagnostic A/B build: no record loads, no decode, no staging -- only the stream's stores
-                if (fill + 3u * kWave > kXbufEvents) flush();
+                if (fill + 3u * kWave > XE) flush();
                 fill += (__builtin_amdgcn_readlane(my_tot, 2 * p) & 0xffffu) + (__builtin_amdgcn_readlane(my_tot, 2 * p + 1) & 0xffffu);
 #else
                 if (pa + pb != 0u) record_round(first[p], half * kWaveUnits);
@@ -2828,9 +2825,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             // every record carries its event's offset inside the segment; a segment's events are staged
             // in pieces of the buffer's size (the segment total is known: tot & 0xffff)
             const uint32_t seg_events = tot & 0xffffu;
-            for (uint32_t e0 = 0; e0 < seg_events; e0 += kXbufEvents) {
-                const uint32_t piece = seg_events - e0 < kXbufEvents ? seg_events - e0 : kXbufEvents;
-                if (fill + piece > kXbufEvents) flush();
+            for (uint32_t e0 = 0; e0 < seg_events; e0 += XE) {
+                const uint32_t piece = seg_events - e0 < XE ? seg_events - e0 : XE;
+                if (fill + piece > XE) flush();
                 for (uint32_t i0 = 0; i0 < parked; i0 += kWave) {
                     const uint32_t i = i0 + lane;
                     if (i >= parked) continue;

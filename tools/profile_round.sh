@@ -62,12 +62,19 @@ kstats() {  # $1 = tag, $2 = extra env, $3.. = bench args
     find "$OUT/ks_$tag" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_${tag}_eager_kernel_stats.csv" \;
     rm -rf "$OUT/ks_$tag"
 }
-# (round 4: at crf 0 the default mode runs adder_cr_kernel; ADDER_HIP_NO_CR=1 gives the bounded Collapse kernel's rows)
-pmc_passes cb_dtm7650_delta "ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650
-pmc_passes cb_dtm7650_abs "ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
+# (round 4: at crf 0 the default mode runs adder_rr_kernel; ADDER_HIP_NO_RR=1 gives adder_cr_kernel's rows,
+#  ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1 the bounded Collapse kernel's)
+pmc_passes cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650
+pmc_passes cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
+pmc_passes cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650
+pmc_passes cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
 pmc_passes lean_step_no_runs "ADDER_HIP_NO_LR=1" --frames 160
-kstats cb_dtm7650_delta "ADDER_HIP_NO_CR=1" --delta-t-max 7650
-kstats cb_dtm7650_abs "ADDER_HIP_NO_CR=1" --delta-t-max 7650 --time-mode absolute_t
+pmc_passes wire_output "A=1" --frames 160 --output wire
+kstats cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --delta-t-max 7650
+kstats cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --time-mode absolute_t
+kstats cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650
+kstats cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650 --time-mode absolute_t
+kstats wire_output "A=1" --output wire
 kstats default_mode_delta "A=1" --delta-t-max 7650
 kstats normal_dtm255_delta "A=1" --multi-mode normal
 kstats normal_dtm7650_abs "A=1" --multi-mode normal --delta-t-max 7650 --time-mode absolute_t
