@@ -911,8 +911,14 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
 // frame.  Measured: frame kernel 164.6 -> 158.9 us per 64 frames, step time unchanged, and the expansion FETCHES more
 // (127 instead of 104 MiB per launch: a run of ~160 bytes at 8-byte alignment touches 2.25 128-byte lines, a slot 2).
 static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames);
+static bool rr_possible(const AdderHipCtx *c, float T);
 static bool cb_possible(const AdderHipCtx *c, float T) {
-    if (c->continuous || c->p.multi_mode != ADDER_MULTI_COLLAPSE || c->perpx || feature_needs_perpx(c)) return false;
+    if (c->p.multi_mode != ADDER_MULTI_COLLAPSE) return false;
+    return rr_possible(c, T);
+}
+// (the bounded regime's conditions without the mode)
+static bool rr_possible(const AdderHipCtx *c, float T) {
+    if (c->continuous || c->perpx || feature_needs_perpx(c)) return false;
     if (c->frac_time_seen) return false;
     static const bool off = [] { const char *e = getenv("ADDER_HIP_NO_CB"); return e && atoi(e) != 0; }();
     if (off) return false;
@@ -1421,7 +1427,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // run records (adder_rr_kernel): the same regime with integer state while n * 255 and n * time_spanned stay exact in
     // binary32; AbsoluteT also wants last_fired_t on multiples of time_spanned (time_spanned == ref_time >= 255)
     const bool rr_off = env_flag("ADDER_HIP_NO_RR");
-    const bool rr = cr && !rr_off &&
+    // (Mode Normal under the same conditions runs it too -- adder_pixel.hpp rr_step; the other two kernels are Collapse's)
+    const bool rr_regime = cr || (generic && !collapse && c->cr_valid && rr_possible(c, time_spanned));
+    const bool rr = rr_regime && !rr_off &&
                     (c->p.time_mode != ADDER_TIME_ABSOLUTE_T || (time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u)) &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     // lean runs (adder_lr_kernel): the lean regime in DeltaT under the same property, in blocked batches of events, while

@@ -1884,6 +1884,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
     const uint32_t chunk_u = __builtin_amdgcn_readfirstlane(b->chunk);
     // frames since the reset before this launch, and the frames after which the root is popped (:394-396)
     const uint32_t frame0 = __builtin_amdgcn_readfirstlane((uint32_t)fdiv(a.sc.running_t, T));
+    const bool collapse_u = __builtin_amdgcn_readfirstlane((uint32_t)a.sc.collapse) != 0u;  // (Mode Normal runs the same step: rr_step)
     const uint32_t Tu = __builtin_amdgcn_readfirstlane((uint32_t)T);
     const uint32_t n_pop = __builtin_amdgcn_readfirstlane(((uint32_t)a.sc.dtm_f + Tu - 1u) / Tu);
     // the segment's slot of the launch's first frame (lr_frames: the same ring layout and walk)
@@ -1942,7 +1943,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             rr_step<ABS_T, L>(px[j], (vin_w >> (8 * j)) & 0xffu, frame0 + i, n_pop, T, chain_tab, (lane * N + j) << kRrUnitShift,
-                              w0[j], w1[j], w2[j], cnt[j]);
+                              w0[j], w1[j], w2[j], cnt[j], collapse_u);
             if (!FULL) cnt[j] = active[j] ? cnt[j] : 0u;  // padding units: stepped freely, no events
             mrec[j] = L::from(cnt[j] != 0u);
             nrec += (uint32_t)__popcll(mrec[j]);
@@ -1990,7 +1991,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
                     else over = true;
                 }
             } st{DeepGlobal{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j}, a.sc.max_depth, false};
-            hdrv[j] = rr_pack<L>(px[j], T, iv[j], dv[j], bv[j], lfv[j], st);
+            hdrv[j] = rr_pack<L>(px[j], T, iv[j], dv[j], bv[j], lfv[j], st, collapse_u);
             too_deep = too_deep || (st.over && active[j]);
         }
         if (too_deep) raise(a.status, kStatusDepth);

@@ -1466,15 +1466,18 @@ ADDER_HD RrPxT<L> rr_unpack(uint32_t hdr, float dt, float lastf, float T, bool a
 }
 // One frame of one unit: the record's three words (valid iff count != 0) and the number of events it stands for.
 // frame_idx = running_t / T before this frame; n_pop = ceil(delta_t_max / T) >= 2; tab(I, r) = rr_chain for r < kRrTabRows.
+// Mode Normal (collapse = false) differs in two places only: a flush after the pop still emits the whole chain (no
+// root + filler), and the levels below a popped root go on being visited -- pop_top leaves [level 1, level 2, ..], which IS
+// the arena of a run of n - j frames, so the same {base_val, n} describes it.
 template <bool ABS_T, class L, class Tab>
 ADDER_HD void rr_step(RrPxT<L> &p, uint32_t v, uint32_t frame_idx, uint32_t n_pop, float T, const Tab &tab, uint32_t tag,
-                      uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &count) {
+                      uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &count, bool collapse = true) {
     using M = typename L::Mask;
     const M flush = L::from(v != p.base);
-    const M collapsed = L::and_(L::and_(flush, p.popped), L::from(p.n != 0u));
+    const M collapsed = L::and_(L::and_(L::and_(flush, p.popped), L::from(p.n != 0u)), L::from(collapse));
     // the flushed arena's events (pop_best_events, :210-286): the chain below an unpopped root, root + filler if popped
     uint32_t chain = tab(p.base, p.n < kRrTabRows - 1u ? p.n : kRrTabRows - 1u);
-    if (L::lane(L::andnot(flush, p.popped)) && p.n >= kRrTabRows) chain = rr_chain(p.base, p.n, T);  // (delta_t_max beyond 32 frames)
+    if (L::lane(L::andnot(flush, L::and_(p.popped, L::from(collapse)))) && p.n >= kRrTabRows) chain = rr_chain(p.base, p.n, T);  // (runs beyond the table)
     count = L::lane(flush) ? (L::lane(collapsed) ? 2u : chain) : 0u;
     uint32_t kind = L::lane(collapsed) ? kRrCollapsed : kRrFlush;
     uint32_t rn = p.n, rbase = p.base;
@@ -1552,12 +1555,13 @@ ADDER_HD uint32_t cr_materialize(const CrPxT<L> &s, float T, Store &store) {
 
 // back to the resident form: the root's planes; the levels through store(k, Node) (cr_materialize's contract); returns the header
 template <class L, class Store>
-ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, float &bdt, float &lastf, Store &store) {
+ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, float &bdt, float &lastf, Store &store,
+                          bool collapse = true) {
     CrPxT<L> c;
     c.base = p.base;
     c.r1 = 0u;
     c.has = L::from(p.n != 0u);
-    c.popped = p.popped;
+    c.popped = L::and_(p.popped, L::from(collapse));  // (Normal: the levels below a popped root are kept and stepped)
     c.S = c.dt0 = c.bdt0 = c.thr0 = 0.0f;
     uint32_t bd = 0u;
     if (p.n != 0u) {
@@ -1567,7 +1571,7 @@ ADDER_HD uint32_t rr_pack(const RrPxT<L> &p, float T, float &integ, float &dt, f
             c.dt0 = fmul((float)p.n, T);
             c.bdt0 = n.bdt;
             c.thr0 = n.thr;
-            c.r1 = L::lane(p.popped) ? 0u : p.n - n.j;
+            c.r1 = L::lane(c.popped) ? 0u : p.n - n.j;
             bd = lean_bd_from_thr(f32_to_bits(n.thr));
         } else {
             c.bdt0 = T;

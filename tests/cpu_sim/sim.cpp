@@ -462,7 +462,13 @@ int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
 // happening, the events worked out from the records as the expansion does.  -7 outside its regime (the constant-run
 // conditions; AbsoluteT also wants time_spanned == ref_time >= 255).
 int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
-    if (!sim_cb_possible(s, T) || s->c_thresh != 0 || s->c_max != 0) return -7;
+    {   // the bounded Collapse step's conditions without the mode: Normal runs it too
+        const bool was = s->collapse;
+        s->collapse = true;
+        const bool ok = sim_cb_possible(s, T);
+        s->collapse = was;
+        if (!ok || s->c_thresh != 0 || s->c_max != 0) return -7;
+    }
     if (s->abs_t && (T != (float)s->ref_time || s->ref_time < 255u)) return -7;
     s->generic_sticky = 1;
     const uint32_t Tu = (uint32_t)T;
@@ -482,8 +488,8 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 RrPx p = rr_unpack<ScalarLanes>(hdr, m0 ? s->dt0[u] : -777.0f, s->abs_t ? s->lastf[u] : -1.0f, T, s->abs_t != 0);
                 for (uint32_t i = 0; i < nb; ++i) {
                     uint32_t w0, w1, w2, count;
-                    if (s->abs_t) rr_step<true>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count);
-                    else rr_step<false>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count);
+                    if (s->abs_t) rr_step<true>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count, s->collapse);
+                    else rr_step<false>(p, frames[(size_t)i * s->N + u], frame0 + i, n_pop, T, levels, 0u, w0, w1, w2, count, s->collapse);
                     s->cb_steps++;
                     if (count == 0u) continue;
                     // the expansion's side: everything from the three words
@@ -510,7 +516,7 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                     }
                 } st{&deep, s->max_depth, &rc};
                 float integ, dt, bdt, lastf;
-                const uint32_t h2 = rr_pack(p, T, integ, dt, bdt, lastf, st);
+                const uint32_t h2 = rr_pack(p, T, integ, dt, bdt, lastf, st, s->collapse);
                 const uint32_t m = hdr_m(h2);
                 if (m > s->max_m) s->max_m = m;
                 s->hdr[u] = h2;

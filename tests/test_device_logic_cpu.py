@@ -632,6 +632,41 @@ def test_rr_other_tick_rates_and_its_limits():
     assert sv.integrate_rr_block(clip[:2], 255.0)[0] == -7
 
 
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_rr_in_mode_normal(time_mode):
+    """Mode Normal under the same conditions: pop_top leaves [level 1, level 2, ..] = the arena of a run of n - j frames
+    (the levels go on being visited), a flush after the pop emits the whole chain.  Every content, blocked launches, and
+    launches of the generic step in between (the same planes)."""
+    rng = np.random.default_rng(47 + time_mode)
+    for dtm in (7650, 255 * 3, 255 * 40):
+        for kind in ("scene", "runs", "jitter", "static", "dark", "noise"):
+            frames = 150
+            clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
+                    else clips.make_clip(kind, frames, 7, 12, 1, seed=3 + len(kind)))
+            ov = O.Video(12, 7, 1, time_mode=time_mode, multi_mode=O.NORMAL, ref_time=255, delta_t_max=dtm)
+            sv = Sim(12, 7, 1, time_mode=time_mode, multi_mode=O.NORMAL, ref_time=255, delta_t_max=dtm, max_depth=20)
+            ov.ensure_capacity(24)
+            for v in (ov, sv):
+                v.set_crf_parameters(0, 10)
+                v.reset_c_thresh(0)
+            k, total, used = 0, 0, set()
+            while k < frames:
+                nb = min(int(rng.choice([1, 2, 3, 7, 29, 31, 64])), frames - k)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+                if rng.integers(0, 4) == 0:
+                    parts = [sv.integrate(clip[k + i], 255.0) for i in range(nb)]
+                    rc, got = max(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+                    used.add("generic")
+                else:
+                    rc, got = sv.integrate_rr_block(clip[k:k + nb], 255.0)
+                    used.add("rr")
+                assert rc == 0, (dtm, kind, k, rc)
+                assert len(want) == len(got) and np.array_equal(want, got), (dtm, kind, k, nb)
+                total += len(got)
+                k += nb
+            assert sv.plan_mismatches == 0 and total > 0 and "rr" in used
+
+
 # ---- lean runs (lr_step / lr_decode8 / lr_pack: the headline regime at crf 0, a unit = {base_val, rho, popped}) ----
 def _lean_pair(W, H, Cn, dtm=255, ref_time=255):
     ov = O.Video(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)

@@ -1523,6 +1523,39 @@ def test_default_mode_crf0_step_kernels_interleave_in_one_stream(monkeypatch, ti
     hv.close()
 
 
+@pytest.mark.parametrize("step", ["rr", "generic"])
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_mode_normal_crf0_run_records_and_generic_kernel(monkeypatch, step, time_mode):
+    """Mode Normal at crf 0 with delta_t_max > time_spanned runs adder_rr_kernel too (a popped arena is the arena of a
+    shorter run; a flush after the pop emits the whole chain); ADDER_HIP_NO_RR=1 keeps adder_frame_kernel.  Ragged plane,
+    rgb, batches of every shape, and the two kernels taking turns on one stream."""
+    rng = np.random.default_rng(90 + time_mode)
+    A = _hip()
+    W, H, Cn, frames = 131, 23, 3, 200
+    for kind, dtm in (("runs", 7650), ("scene", 255 * 4), ("jitter", 7650)):
+        clip = (O.synth_clip(O.CONTENT_SCENE, W, H, Cn, frames) if kind == "scene"
+                else clips.make_clip(kind, frames, H, W, Cn, seed=17 + len(kind)))
+        ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=O.NORMAL, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, Cn, time_mode=time_mode, multi_mode=O.NORMAL, ref_time=255, delta_t_max=dtm, max_depth=24)
+        ov.ensure_capacity(26)
+        for v in (ov, hv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        k = 0
+        while k < frames:
+            if step == "rr" and rng.integers(0, 4) != 0:
+                monkeypatch.delenv("ADDER_HIP_NO_RR", raising=False)
+            else:
+                monkeypatch.setenv("ADDER_HIP_NO_RR", "1")
+            nb = min(int(rng.choice([1, 2, 29, 31, 64, 65])), frames - k)
+            want = [ov.integrate_matrix(clip[k + i]) for i in range(nb)]
+            got, offs = hv.integrate_batch(clip[k:k + nb])
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (kind, k, nb)
+            assert np.array_equal(got, np.concatenate(want)), (kind, k, nb)
+            k += nb
+        hv.close()
+
+
 def test_run_records_long_runs_deep_chains_other_rates_and_depth():
     """delta_t_max of 500 frames: roots that have not fired for more than the table's 32 rows (the chain length is worked
     out), records of eight and more events, rounds of the expansion that outgrow its staging buffer; other tick rates (in
