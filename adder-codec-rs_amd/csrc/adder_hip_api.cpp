@@ -1435,7 +1435,10 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // lean runs (adder_lr_kernel): the lean regime in DeltaT under the same property, in blocked batches of events, while
     // rho * 255 and rho * time_spanned stay exact in binary32 (rho <= frames since the reset)
     const bool lr_off = env_flag("ADDER_HIP_NO_LR");
-    const bool lr = !generic && !c->continuous && collapse && c->p.time_mode == ADDER_TIME_DELTA_T && c->cr_valid && !lr_off &&
+    // (AbsoluteT: last_fired_t / T rides along as an integer when time_spanned == ref_time >= 255, like the run records')
+    const bool lr_time = c->p.time_mode == ADDER_TIME_DELTA_T ||
+                         (c->p.time_mode == ADDER_TIME_ABSOLUTE_T && time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u);
+    const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
                     !c->records_only && !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |

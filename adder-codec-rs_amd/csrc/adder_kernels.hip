@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 // registers, so the slice decides the occupancy -- 32 frames (4 KB per wave, 16 KB per workgroup) leave room for 8 waves
 // per SIMD
 constexpr uint32_t kLrInFrames = ADDER_LR_IN_FRAMES;
-template <bool FULL>
+template <bool FULL, bool ABS_T>
 __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
                                           uint32_t gw, uint32_t lane, uint8_t *lds_in) {
     constexpr uint32_t N = kUnitsPerLane;
@@ -722,16 +722,21 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
     };
     stage_issue(0u);
     if (kLrGroup < nb) stage_issue(kLrGroup);
+    uint32_t lq[N];  // AbsoluteT: last_fired_t / T (lr_step_lq)
+    const uint32_t frame0 = ABS_T ? __builtin_amdgcn_readfirstlane((uint32_t)fdiv(a.sc.running_t, T)) : 0u;
+    constexpr uint32_t REC = ABS_T ? 12u : 8u;
     {
         uint32_t hdrv[N];
-        float dv[N];
+        float dv[N], lfv[N];
         load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
         load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
+        if (ABS_T) load_vec<ADDER_NT_STATE != 0>(a.lastf, u0, lfv);
         bool all_ok = true;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             bool ok;
             px[j] = lr_unpack<L>(hdrv[j], dv[j], T, ok);
+            lq[j] = ABS_T ? (uint32_t)fdiv(lfv[j], T) : 0u;
             all_ok = all_ok && (ok || (!FULL && u0 + j >= n_units_u));
         }
         if (!all_ok) raise(a.status, kStatusLeanRuns);
@@ -760,13 +765,15 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
 #endif
     auto frame = [&](uint32_t i, uint32_t &k_lane) -> uint32_t {  // -> events | records << 16 of the segment's frame i (uniform)
         const uint32_t vin_w = (uint32_t)in_lds[(i % kLrInFrames) * kWave];
-        uint32_t w0[N], w8[N];
+        uint32_t w0[N], w1[N], w8[N];
         uint64_t mrec[N];
         uint32_t nev = 0u, nrec = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const uint32_t pair = __builtin_amdgcn_perm(vin_w, prev_w, sel[j]);
             LeanFlagsT<L> fl = lr_step<L>(px[j], (vin_w >> (8 * j)) & 0xffu, pair, lane * N + j, nz_old[j], w0[j], w8[j]);
+            w1[j] = 0u;
+            if (ABS_T) lr_step_lq<L>(lq[j], fl, frame0 + i, w1[j]);
             if (!FULL) {  // padding units: stepped freely, no events
                 fl.a &= active[j];
                 fl.b &= active[j];
@@ -794,7 +801,14 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
 #if !defined(ADDER_DBG_LR_NOSTORE)  // (diagnostic A/B build: everything but the record stores)
-            if (has) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
+            if (has) {
+                if (ABS_T) {
+                    struct R12 { uint32_t a, b, c; };
+                    gstore(seg, pos * REC, R12{w0[j], w1[j], w8[j]});
+                } else {
+                    gstore(seg, pos * REC, make_uint2(w0[j], w8[j]));
+                }
+            }
 #else
             if (has && w0[j] == 0xfffffff1u) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
 #endif
@@ -846,9 +860,16 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         store_vec<NTS>(a.integ0, u0, iv);
         store_vec<NTS>(a.dt0, u0, dv);
         store_vec<NTS>(a.bdt0, u0, bv);
+        if (ABS_T) {
+            float lfv[N];
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) lfv[j] = fmul((float)lq[j], T);
+            store_vec<NTS>(a.lastf, u0, lfv);
+        }
     }
 }
 
+template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_lr_kernel(const BatchArgs *__restrict__ b,
                                                                                          uint32_t f, uint32_t nb) {
     const FrameArgs a = frame_args(b, f);
@@ -859,8 +880,8 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) lr_frames<true>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
-        else lr_frames<false>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+        if (full) lr_frames<true, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+        else lr_frames<false, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -2491,13 +2512,12 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     constexpr bool RR = FORMAT == 4;
     constexpr bool LR = FORMAT == 5;  // lean-runs records in fixed slots (adder_lr_kernel; DeltaT only): a format of its own, so that
                                       // the decoders do not meet in one instantiation (their results would merge through registers)
-    static_assert(!LR || !ABS_T, "lean runs are a DeltaT format");
     // staging capacity of one wave, in events: run-record rounds hold up to 64 x (depth + 1) events and like room
     constexpr uint32_t XE = RR ? 640u : kXbufEvents;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][XE * 3u + 4u];
     // lean runs: event C by input byte (lr_build_tab), 1 KB per workgroup out of L2 -- a division less per record
-    __shared__ uint32_t s_tab_c[LR ? 256u : 1u];
-    if (LR) {
+    __shared__ uint32_t s_tab_c[LR && !ABS_T ? 256u : 1u];
+    if (LR && !ABS_T) {
         s_tab_c[threadIdx.x] = uniform_ptr(b->lr_tab)[256u * kLrTabRuns + threadIdx.x];
         __syncthreads();
     }
@@ -2538,6 +2558,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const uint64_t out_cap = b->base.out_cap;
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY (lean)
     const float time_spanned_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
+    const uint32_t frame_idx_u = (LR && ABS_T) ? __builtin_amdgcn_readfirstlane((uint32_t)fdiv(b->ftab[f].running_t, time_spanned_u)) : 0u;  // (lr_decode12)
     constexpr bool lean_runs = LR;
 
     // num_waves is a multiple of kExpandSegs (n_pad is padded accordingly).  Two round trips: the
@@ -2640,7 +2661,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         // (an all-zero record decodes to no events)
         // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
         LeanEvents e;
-        if constexpr (LR) e = lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
+        if constexpr (LR && ABS_T) e = lr_decode12(rw.x, rw.y, rw.z, time_spanned_u, rt_u32, frame_idx_u);
+        else if constexpr (LR) e = lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
         else if constexpr (ABS_T) e = lean_decode(r, true, rt_u32);
         else e = lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
         const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
@@ -2649,7 +2671,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t w = phase + ev0 + (ev0 << 1);  // the record's first dword in the buffer (x3 without a 64-bit multiply-add)
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t unit = ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : lean_runs ? rw.y & 0x7fu : (rw.y >> kLean8UnitShift) & 0x7fu;
+        const uint32_t unit = lean_runs ? (ABS_T ? rw.z : rw.y) & 0x7fu : ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
@@ -3425,9 +3447,9 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
     if (variant & 256u) {  // lean runs (DeltaT, constant runs): every launch of the batch, whatever its length
-        if (abs_t) return hipErrorInvalidValue;
         const uint32_t SR = grid_cap && grid_cap < S ? grid_cap : S;
-        hipLaunchKernelGGL(adder_lr_kernel, dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
+        if (abs_t) hipLaunchKernelGGL((adder_lr_kernel<true>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
+        else hipLaunchKernelGGL((adder_lr_kernel<false>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
         return hipGetLastError();
     }
 #if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
@@ -3515,8 +3537,10 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     else if (variant & 64u) {
         if (abs_t) ADDER_XW(3, true);
         else ADDER_XW(3, false);
+    } else if (variant & 256u) {
+        if (abs_t) ADDER_XW(5, true);
+        else ADDER_XW(5, false);
     } else if (abs_t) ADDER_XW(1, true);
-    else if (variant & 256u) ADDER_XW(5, false);
     else ADDER_XW(1, false);
 #undef ADDER_XW
 #undef ADDER_X

@@ -1339,6 +1339,35 @@ ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t pair, uint32_t 
     nz_old = L::not_(zero);
     return fl;
 }
+// AbsoluteT (time_spanned == ref_time >= 255: the run records' condition and argument): lq = last_fired_t / T rides along
+// as an integer.  A's time stamp is (best delta_t + lq T); the filler B sets last_fired_t to the frame's running_t (:257),
+// a black root's one firing advances it by one frame; C (the new root popped at once, best delta_t in (T / 2, T]) by one
+// more.  The 12-byte record is {rho, lq before the frame, the DeltaT record's second word}.
+template <class L>
+ADDER_HD void lr_step_lq(uint32_t &lq, const LeanFlagsT<L> &fl, uint32_t frame_idx, uint32_t &w1) {
+    w1 = lq;
+    const uint32_t after_a = L::lane(fl.b) ? frame_idx : lq + 1u;
+    lq = L::lane(fl.a) ? after_a : lq;
+    lq += L::lane(fl.c) ? 1u : 0u;
+}
+ADDER_HD LeanEvents lr_decode12(uint32_t w0, uint32_t w1, uint32_t w8, float T, uint32_t running_t_u32, uint32_t frame_idx) {
+    LeanEvents e;
+    const uint32_t Io = (w8 >> kLrBaseShift) & 0xffu, Iv = (w8 >> kLrInShift) & 0xffu;
+    const bool flush = Io != Iv;
+    e.a = flush && w0 != 0u;
+    e.b = e.a && Io != 0u;
+    e.c = flush && Iv != 0u;
+    const CrNode n = cr_node(Io != 0u ? (float)Io : 1.0f, w0 != 0u ? w0 : 1u, T);
+    e.da = Io != 0u ? lean_bd_from_thr(f32_to_bits(n.thr)) : kDZero;
+    e.ta = f32_as_u32(fadd(Io != 0u ? n.bdt : T, fmul((float)w1, T)));
+    e.tb = running_t_u32;
+    const uint32_t lq_c = e.a ? (e.b ? frame_idx : w1 + 1u) : w1;
+    const float I = (float)Iv;
+    const float p2 = bits_to_f32(f32_to_bits(I) & 0x7f800000u);  // 2^get_d(I)
+    e.dc = get_d(I);
+    e.tc = f32_as_u32(fadd(fadd(0.0f, fmul(T, fdiv_small(fsub(p2, 0.0f), I))), fmul((float)lq_c, T)));  // (C exists only for I >= 1)
+    return e;
+}
 // The record back into events: A from the flushed root's run, C from the input byte (lean_decode8's arithmetic).
 ADDER_HD LeanEvents lr_decode8(uint32_t w0, uint32_t w8, float T, uint32_t running_t_u32) {
     LeanEvents e;

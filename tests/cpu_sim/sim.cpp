@@ -540,9 +540,11 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
 // instantiation and the expansion run it: a unit is {base_val, rho, popped}, event A is worked out from the record.
 // -7 outside its regime (Collapse, delta_t_max <= T, DeltaT, c_thresh 0 with c_thresh_max 0, integer T, no generic batch).
 int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
-    if (!s->collapse || s->abs_t || !((float)s->dtm <= T) || s->generic_sticky || s->perpx || s->continuous ||
+    if (!s->collapse || !((float)s->dtm <= T) || s->generic_sticky || s->perpx || s->continuous ||
         s->c_thresh != 0 || s->c_max != 0 || !(T >= 1.0f) || T != (float)(uint32_t)T || s->frac_time_seen)
         return -7;
+    if (s->abs_t && (T != (float)s->ref_time || s->ref_time < 255u)) return -7;  // (last_fired_t on multiples of T)
+    const uint32_t frame0 = (uint32_t)(s->running_t / T);
     std::vector<float> rts(nb);
     {
         float rt = s->running_t;
@@ -565,15 +567,18 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 LrPx p = lr_unpack<ScalarLanes>(s->hdr[u], m0 ? s->dt0[u] : -777.0f, T, consistent);
                 if (!consistent) rc = -10;  // popped_dtm != (base_val != 0): the planes are not the lean regime's
                 bool nz_old = p.base != 0u;
+                uint32_t lq = s->abs_t ? (uint32_t)(s->lastf[u] / T) : 0u;
                 for (uint32_t i = 0; i < nb; ++i) {
-                    uint32_t w0, w8;
+                    uint32_t w0, w8, w1 = 0u;
                     const uint32_t vin = frames[(size_t)i * s->N + u];
                     const LeanFlagsT<ScalarLanes> fl = lr_step<ScalarLanes>(p, vin, (p.base << kLrBaseShift) | (vin << kLrInShift), (uint32_t)(u & 127u), nz_old, w0, w8);
+                    if (s->abs_t) lr_step_lq<ScalarLanes>(lq, fl, frame0 + i, w1);
                     if (fl.b && !fl.a) rc = -9;
                     if (!(fl.a || fl.c)) continue;  // (no record)
                     if ((w8 & 127u) != (u & 127u)) rc = -9;
-                    const LeanEvents e = lr_decode8_tab(w0, w8, T, f32_as_u32(rts[i]), (u & 1u) ? lr_tab.data() : nullptr, lr_tab.data() + 256u * kLrTabRuns);  // (as the expansion does; odd units through the A rows too)
-                    {
+                    const LeanEvents e = s->abs_t ? lr_decode12(w0, w1, w8, T, f32_as_u32(rts[i]), frame0 + i)
+                                                  : lr_decode8_tab(w0, w8, T, f32_as_u32(rts[i]), (u & 1u) ? lr_tab.data() : nullptr, lr_tab.data() + 256u * kLrTabRuns);  // (as the expansion does; odd units through the A rows too)
+                    if (!s->abs_t) {
                         const LeanEvents e2 = lr_decode8(w0, w8, T, f32_as_u32(rts[i]));
                         if ((e.a && (e.da != e2.da || e.ta != e2.ta)) || (e.c && (e.dc != e2.dc || e.tc != e2.tc))) rc = -11;
                     }
@@ -586,6 +591,7 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 }
                 float integ, dt, bdt;
                 s->hdr[u] = lr_pack(p, T, integ, dt, bdt);
+                if (s->abs_t) s->lastf[u] = fmul((float)lq, T);
                 if (p.rho != 0u) {
                     s->integ0[u] = integ; s->dt0[u] = dt; s->bdt0[u] = bdt;
                     if (s->max_m < 1) s->max_m = 1;

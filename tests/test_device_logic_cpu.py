@@ -668,9 +668,9 @@ def test_rr_in_mode_normal(time_mode):
 
 
 # ---- lean runs (lr_step / lr_decode8 / lr_pack: the headline regime at crf 0, a unit = {base_val, rho, popped}) ----
-def _lean_pair(W, H, Cn, dtm=255, ref_time=255):
-    ov = O.Video(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
-    sv = Sim(W, H, Cn, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+def _lean_pair(W, H, Cn, dtm=255, ref_time=255, time_mode=O.DELTA_T):
+    ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
+    sv = Sim(W, H, Cn, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=ref_time, delta_t_max=dtm)
     ov.ensure_capacity(4)
     for v in (ov, sv):
         v.set_crf_parameters(0, 10)
@@ -678,15 +678,17 @@ def _lean_pair(W, H, Cn, dtm=255, ref_time=255):
     return ov, sv
 
 
-def test_lr_blocked_launches_match_the_oracle_and_interleave_with_the_lean_step():
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_lr_blocked_launches_match_the_oracle_and_interleave_with_the_lean_step(time_mode):
     """BASELINE configs 2-4's mode at crf 0: launches of the lean-runs step of every length on every content, mixed at
-    random with frames of the ordinary lean step (both keep the same resident planes) -- every event equals the oracle's."""
-    rng = np.random.default_rng(61)
+    random with frames of the ordinary lean step (both keep the same resident planes) -- every event equals the oracle's.
+    In AbsoluteT last_fired_t / T rides along as an integer (lr_step_lq / lr_decode12)."""
+    rng = np.random.default_rng(61 + time_mode)
     for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
         frames = 260
         clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"
                 else clips.make_clip(kind, frames, 7, 12, 1, seed=5 + len(kind)))
-        ov, sv = _lean_pair(12, 7, 1)
+        ov, sv = _lean_pair(12, 7, 1, time_mode=time_mode)
         k, used = 0, set()
         while k < frames:
             nb = min(int(rng.choice([1, 2, 3, 7, 31, 64])), frames - k)
@@ -727,10 +729,27 @@ def test_lr_every_intensity_and_run_length_rgb_and_tick_rates():
         want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(40)])
         rc, got = sv.integrate_lr_block(clip[k:k + 40], 255.0)
         assert rc == 0 and np.array_equal(want, got), k
-    # outside the regime
-    sv = Sim(6, 5, 3, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, delta_t_max=255)
+    # AbsoluteT: every intensity and run length too, three channels
+    ov, sv = _lean_pair(256, 1, 1, time_mode=O.ABSOLUTE_T)
+    frames = []
+    for run in list(range(1, 40, 2)) + [300]:
+        frames += [np.arange(256, dtype=np.uint8).reshape(1, 256, 1)] * run
+        frames += [((np.arange(256) + 1 + run) % 256).astype(np.uint8).reshape(1, 256, 1)]
+    clipa = np.stack(frames)
+    for k in range(0, len(clipa), 64):
+        nb = min(64, len(clipa) - k)
+        want = np.concatenate([ov.integrate_matrix(clipa[k + i]) for i in range(nb)])
+        rc, got = sv.integrate_lr_block(clipa[k:k + nb], 255.0)
+        assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), k
+    ov, sv = _lean_pair(6, 5, 3, time_mode=O.ABSOLUTE_T)
+    for k in range(0, 120, 40):
+        want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(40)])
+        rc, got = sv.integrate_lr_block(clip[k:k + 40], 255.0)
+        assert rc == 0 and np.array_equal(want, got), k
+    # outside the regime: AbsoluteT at a tick rate whose events need not advance last_fired_t by whole frames
+    sv = Sim(6, 5, 3, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=20, delta_t_max=20)
     sv.set_crf_parameters(0, 10)
     sv.reset_c_thresh(0)
-    assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7
+    assert sv.integrate_lr_block(clip[:2], 20.0)[0] == -7
     sv = Sim(6, 5, 3, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255)
     assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
