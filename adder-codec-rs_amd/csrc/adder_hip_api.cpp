@@ -238,6 +238,9 @@ struct AdderHipCtx {
     size_t f_events_per_slot = 0;    // 0: the mode's worst case, at most 2 GiB of events
     uint64_t f_submitted = 0, f_collected = 0;
     hipEvent_t frame_e = nullptr;
+    hipStream_t in_s = nullptr;      // the ring's upload stream (wire format: the next frame's H2D beside this frame's kernels)
+    uint64_t f_last_produced = 0;    // events of the frame collected last
+    hipEvent_t in_e = nullptr;
     bool no_snapshot = false;
     uint32_t *d_chunks = nullptr;
     // running state
@@ -318,6 +321,8 @@ static void free_ctx(AdderHipCtx *c) {
     }
     if (c->frame_e) (void)hipEventDestroy(c->frame_e);
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
+    if (c->in_s) (void)hipStreamDestroy(c->in_s);
+    if (c->in_e) (void)hipEventDestroy(c->in_e);
     for (void *p : {(void *)c->snap.slab, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
                     (void *)c->snap.dv_bd})
         if (p) (void)hipFree(p);
@@ -2349,10 +2354,32 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     if (rc != ADDER_OK) return rc;
     if (!c->out_s) HIPCHK(c, hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
     if (!c->frame_e) HIPCHK(c, hipEventCreateWithFlags(&c->frame_e, hipEventDisableTiming));
+    // The ring's uploads go on a stream of their own, so that the next frame's 2 MB cross the link beside this frame's
+    // kernels instead of behind them: 220 -> 84 us per 1080p frame at the default quality (sparse frames: real video).
+    // Frames dense with events are bound by their events' way to the host and lose 3 % to the contention (194 -> 200 us
+    // at crf 0).  Always, not by the frames' density: a context whose uploads change their HIP stream back and forth stays
+    // slow for life (194 -> 238-330 us per dense frame after four uploads on the other stream; `profiles/r04_ring_ab.txt`).
+    // ADDER_HIP_RING_DIRECT_WIRE=1 (wire format): the expansion itself stores the records into the slot's page-locked
+    // buffer (adder_hip_integrate_wire_device's path, no hand-over pass) -- measured no better for sparse frames and
+    // 5 % worse for dense ones (the byte stores at its waves' edges are single PCIe writes): off by default.
+    static const bool direct_wire_on = env_flag("ADDER_HIP_RING_DIRECT_WIRE");
+    static const bool own_upload_off = env_flag("ADDER_HIP_RING_ONE_STREAM");
+    const bool wire_direct = direct_wire_on && c->f_wire && !direct_out && !c->continuous && !feature_path(c);
+    const bool own_upload = !direct_out && !own_upload_off;
+    hipStream_t up = c->stream;
+    if (own_upload) {
+        if (!c->in_s) HIPCHK(c, hipStreamCreateWithFlags(&c->in_s, hipStreamNonBlocking));
+        if (!c->in_e) HIPCHK(c, hipEventCreateWithFlags(&c->in_e, hipEventDisableTiming));
+        up = c->in_s;
+    }
     if (row_stride == rowlen)
-        HIPCHK(c, hipMemcpyAsync(fs.d_frame, frame, c->n_units, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(fs.d_frame, frame, c->n_units, hipMemcpyHostToDevice, up));
     else
-        HIPCHK(c, hipMemcpy2DAsync(fs.d_frame, rowlen, frame, row_stride, rowlen, c->rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(fs.d_frame, rowlen, frame, row_stride, rowlen, c->rows, hipMemcpyHostToDevice, up));
+    if (own_upload) {
+        HIPCHK(c, hipEventRecord(c->in_e, c->in_s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->in_e, 0));
+    }
     // the slot's own batch description: the shared one may still be read by the copy engine for the frame before
     struct Swap {
         AdderHipCtx *c;
@@ -2374,24 +2401,27 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     c->ftab_cap = 64;
     c->use_graph = false;   // the captured graphs point at the shared description
     c->no_snapshot = true;  // frames behind this one are submitted before its outcome is known: no rollback
-    rc = enqueue_frames(c, fs.d_frame, 1, time_spanned, fs.d_events, need, fs.d_offsets, c->stream);
+    fs.out = direct_out ? direct_out : fs.h_events;
+    fs.out_cap = need;
+    c->wire_batch = wire_direct;
+    rc = enqueue_frames(c, fs.d_frame, 1, time_spanned, wire_direct ? fs.out : fs.d_events, need, fs.d_offsets, c->stream);
+    c->wire_batch = false;
     if (rc != ADDER_OK) {
         c->poisoned = true;
         return rc;
     }
-    fs.out = direct_out ? direct_out : fs.h_events;
-    fs.out_cap = need;
     HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
     const bool wire = c->f_wire && !direct_out;
-    if (wire)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
+    if (wire && !wire_direct)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
         HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
                                             c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
                                             (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), c->out_s));
-    HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, fs.out_cap,
+    HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(wire_direct ? fs.out : fs.d_events), fs.d_offsets, fs.out_cap,
                                      wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
-                                     feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s));
+                                     feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s,
+                                     wire_direct ? wire_record_bytes(c) : 0u));
     HIPCHK(c, hipEventRecord(fs.done, c->out_s));
     c->f_submitted += 1;
     return ADDER_OK;
@@ -2405,6 +2435,7 @@ static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t 
     c->f_collected += 1;
     const FrameResult *res = reinterpret_cast<const FrameResult *>(fs.h_hdr);
     c->last_new_features = res->new_features;
+    c->f_last_produced = res->produced;
     if (events) *events = fs.out;
     if (n_events) *n_events = (size_t)res->produced;
     if (chunk_offsets) *chunk_offsets = reinterpret_cast<const uint32_t *>(fs.h_hdr + sizeof(FrameResult));

@@ -319,7 +319,7 @@ hipError_t adder_launch_merge(const adder::AdderEventPod *stage, const uint64_t 
 hipError_t adder_launch_frame_out(const adder::AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
                                   adder::AdderEventPod *h_ev, adder::FrameResult *h_res, uint32_t *h_chunks,
                                   const uint32_t *status, const uint32_t *counters, uint32_t row_begin, uint32_t chunk_rows,
-                                  uint32_t num_chunks, hipStream_t stream);
+                                  uint32_t num_chunks, hipStream_t stream, uint32_t wire_rec = 0u);
 // after frame f's events are in place: FAST features at the events' pixels -> membership plane, c_thresh reset
 // around the new ones, ROI (video.rs:865-1112)
 hipError_t adder_launch_features(const adder::BatchArgs *b, uint32_t f, const adder::FeatureArgs *fa,

@@ -3230,7 +3230,9 @@ __global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPo
                                                               const uint32_t *__restrict__ status,
                                                               const uint32_t *__restrict__ counters, uint32_t row_begin,
                                                               uint32_t chunk_rows, uint32_t num_chunks,
-                                                              uint32_t copy_blocks) {
+                                                              uint32_t copy_blocks, uint32_t wire_rec) {
+    // wire_rec != 0: d_ev is the frame's run of 9 / 11-byte records (the expansion wrote them, possibly into page-locked
+    // host memory); the chunk search reads y out of the records
     const uint64_t begin = d_offsets[0];
     const uint64_t produced = d_offsets[1] - begin;
     const uint64_t n = produced < cap ? produced : cap;
@@ -3263,7 +3265,14 @@ __global__ __launch_bounds__(256) void adder_frame_out_kernel(const AdderEventPo
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (ev[mid].y < y0) lo = mid + 1;
+        uint32_t y;
+        if (wire_rec) {
+            const uint8_t *const p = reinterpret_cast<const uint8_t *>(d_ev) + (begin + mid) * wire_rec;
+            y = ((uint32_t)p[2] << 8) | p[3];
+        } else {
+            y = ev[mid].y;
+        }
+        if (y < y0) lo = mid + 1;
         else hi = mid;
     }
     h_chunks[c] = (uint32_t)lo;
@@ -3663,13 +3672,13 @@ extern "C" hipError_t adder_launch_chunk_offsets(const AdderEventPod *ev, uint32
 extern "C" hipError_t adder_launch_frame_out(const AdderEventPod *d_ev, const uint64_t *d_offsets, uint64_t cap,
                                              AdderEventPod *h_ev, FrameResult *h_res, uint32_t *h_chunks,
                                              const uint32_t *status, const uint32_t *counters, uint32_t row_begin,
-                                             uint32_t chunk_rows, uint32_t num_chunks, hipStream_t stream) {
+                                             uint32_t chunk_rows, uint32_t num_chunks, hipStream_t stream, uint32_t wire_rec) {
     // a slice of the chip keeps a x16 link busy (null: the wire scatter did the hand-over); ADDER_HIP_OUT_BLOCKS for A/Bs
     static const uint32_t want_blocks = [] { const char *e = getenv("ADDER_HIP_OUT_BLOCKS"); return e ? (uint32_t)atoi(e) : 128u; }();
     const uint32_t copy_blocks = h_ev ? (want_blocks ? want_blocks : 128u) : 0;
     const uint32_t chunk_blocks = (num_chunks + 1 + 255) / 256;
     hipLaunchKernelGGL(adder_frame_out_kernel, dim3(copy_blocks + chunk_blocks), dim3(256), 0, stream, d_ev, d_offsets,
-                       cap, h_ev, h_res, h_chunks, status, counters, row_begin, chunk_rows, num_chunks, copy_blocks);
+                       cap, h_ev, h_res, h_chunks, status, counters, row_begin, chunk_rows, num_chunks, copy_blocks, wire_rec);
     return hipGetLastError();
 }
 
