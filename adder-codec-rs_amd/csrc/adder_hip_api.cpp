@@ -916,19 +916,20 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
 // frame.  Measured: frame kernel 164.6 -> 158.9 us per 64 frames, step time unchanged, and the expansion FETCHES more
 // (127 instead of 104 MiB per launch: a run of ~160 bytes at 8-byte alignment touches 2.25 128-byte lines, a slot 2).
 static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames);
-static bool rr_possible(const AdderHipCtx *c, float T);
+static bool rr_possible(const AdderHipCtx *c, float T, bool pop_at_once_ok = false);
 static bool cb_possible(const AdderHipCtx *c, float T) {
     if (c->p.multi_mode != ADDER_MULTI_COLLAPSE) return false;
     return rr_possible(c, T);
 }
-// (the bounded regime's conditions without the mode)
-static bool rr_possible(const AdderHipCtx *c, float T) {
+// (the bounded regime's conditions without the mode; pop_at_once_ok: delta_t_max <= time_spanned is fine too -- Mode Normal,
+// where a new root is then popped in the frame it starts: adder_pixel.hpp kRrFlushPop)
+static bool rr_possible(const AdderHipCtx *c, float T, bool pop_at_once_ok) {
     if (c->continuous || c->perpx || feature_needs_perpx(c)) return false;
     if (c->frac_time_seen) return false;
     static const bool off = [] { const char *e = getenv("ADDER_HIP_NO_CB"); return e && atoi(e) != 0; }();
     if (off) return false;
     const double dtm = (double)std::max(c->p.delta_t_max, c->dtm_max_seen);
-    if (!((float)c->p.delta_t_max > T)) return false;
+    if (!((float)c->p.delta_t_max > T) && !pop_at_once_ok) return false;
     if (!(T >= 1.0f) || T != (float)(uint32_t)T || T > 65536.0f) return false;
     if (dtm + 2.0 * T >= 8388608.0) return false;
     if ((dtm / T + 3.0) * 255.0 >= 8388608.0) return false;
@@ -1433,7 +1434,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // binary32; AbsoluteT also wants last_fired_t on multiples of time_spanned (time_spanned == ref_time >= 255)
     const bool rr_off = env_flag("ADDER_HIP_NO_RR");
     // (Mode Normal under the same conditions runs it too -- adder_pixel.hpp rr_step; the other two kernels are Collapse's)
-    const bool rr_regime = cr || (generic && !collapse && c->cr_valid && rr_possible(c, time_spanned));
+    const bool rr_regime = cr || (generic && !collapse && c->cr_valid && rr_possible(c, time_spanned, true));
     const bool rr = rr_regime && !rr_off &&
                     (c->p.time_mode != ADDER_TIME_ABSOLUTE_T || (time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u)) &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;

@@ -2693,22 +2693,27 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t e0 = 0; e0 < total; e0 += XE) {  // (uniform; one pass unless the round outgrows the buffer)
             const uint32_t piece = total - e0 < XE ? total - e0 : XE;
             if (fill + piece > XE) flush();
-            uint32_t r = rw.x;
+            const uint32_t n_run = rw.x & kRrRunMask;
+            uint32_t r = n_run;
             for (uint32_t k = 0; k < cnt; ++k) {
                 uint32_t d = kDEmpty, t = rt_u32;  // (the filler of a collapsed flush, :258-264)
                 if (!(kind == kRrCollapsed && k != 0u)) {
+                    // (kRrFlushPop's last event: the new run's root (v, 1) -- the chain has ended at r = 0 by then)
+                    const bool popped_root = kind == kRrFlushPop && k + 1u == cnt;
+                    const float Ik = popped_root ? (float)(rw.x >> kRrPopInShift) : I;
+                    const uint32_t rk = popped_root ? 1u : r;
                     float bdt = time_spanned_u;  // a black root: (D_ZERO, time_spanned)
                     uint32_t j = 1u;
                     d = kDZero;
-                    if (Iu != 0u) {
-                        const CrNode nd = cr_node(I, r, time_spanned_u);
+                    if (Iu != 0u || popped_root) {
+                        const CrNode nd = cr_node(Ik, rk, time_spanned_u);
                         bdt = nd.bdt;
                         j = nd.j;
                         d = lean_bd_from_thr(f32_to_bits(nd.thr));
                     }
                     // event k's own last_fired_t: the firings above it telescope to n - r
-                    t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)(rw.y + (rw.x - r)), time_spanned_u)) : bdt);
-                    r -= j;
+                    t = f32_as_u32(ABS_T ? fadd(bdt, fmul((float)(rw.y + (n_run - r)), time_spanned_u)) : bdt);
+                    r -= popped_root ? 0u : j;
                 }
                 const uint32_t pos = first_ev + k;
                 if (pos >= e0 && pos < e0 + piece) {

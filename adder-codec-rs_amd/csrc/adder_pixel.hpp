@@ -1468,7 +1468,8 @@ ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, f
 // record {n, lq, kind | unit << 2 | base_val << 9 | events << 17} (DeltaT: {n, the third word}): kind 1 flush, 2 collapsed
 // flush, 3 pop_top
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kRrFlush = 1u, kRrCollapsed = 2u, kRrPop = 3u;
+constexpr uint32_t kRrFlush = 1u, kRrCollapsed = 2u, kRrPop = 3u, kRrFlushPop = 0u;  // (kind 0 with a count: a flush, then the new root's pop)
+constexpr uint32_t kRrPopInShift = 24, kRrRunMask = 0xffffffu;  // first word: n | the popped root's intensity << 24 (kRrFlushPop)
 constexpr uint32_t kRrUnitShift = 2, kRrBaseShift = 9, kRrCountShift = 17;
 constexpr uint32_t kRrTabRows = 32;  // chain lengths tabulated for runs below 32 frames (delta_t_max up to 32 frames; beyond: worked out)
 // events of an unpopped arena whose root has accumulated r frames of intensity I (0 for r == 0; a black root holds one)
@@ -1521,13 +1522,21 @@ ADDER_HD void rr_step(RrPxT<L> &p, uint32_t v, uint32_t frame_idx, uint32_t n_po
     const M need_pop = L::andnot(L::andnot(L::from(n1 >= n_pop), popped1), zero);  // :394-396
     uint32_t nn = n1;
     if (L::lane(need_pop)) {  // pop_top (:156-197): the root's event; level 1 becomes the root, deeper levels are dropped
-        const uint32_t j = cr_node((float)v, n1, T).j;  // (never in a frame that flushed: a new run starts at n = 1 < n_pop)
+        const uint32_t j = cr_node((float)v, n1, T).j;
         nn = n1 - j;
-        count = 1u;
-        kind = kRrPop;
-        rn = n1;
-        rbase = v;
         if (ABS_T) p.lq += j;
+        if (count != 0u) {
+            // a frame that flushed AND pops: only with delta_t_max <= time_spanned (n_pop = 1: Mode Normal's lean case), where
+            // the new run's root (v, 1) is popped at once.  One record for both: the flushed chain, then that root's event
+            count += 1u;
+            kind = kRrFlushPop;
+            rn |= v << kRrPopInShift;
+        } else {
+            count = 1u;
+            kind = kRrPop;
+            rn = n1;
+            rbase = v;
+        }
     }
     p.n = nn;
     p.base = v;
@@ -1541,11 +1550,20 @@ struct RrEvent {
     uint32_t d, t;
 };
 template <bool ABS_T>
-ADDER_HD RrEvent rr_event_at(uint32_t kind, uint32_t Iu, uint32_t n, uint32_t lq, uint32_t k, float T, uint32_t running_t_u32) {
+// (w0 = the record's first word, cnt its event count: kRrFlushPop's last event is the popped root's)
+ADDER_HD RrEvent rr_event_at(uint32_t kind, uint32_t Iu, uint32_t w0, uint32_t lq, uint32_t k, uint32_t cnt, float T,
+                             uint32_t running_t_u32) {
     RrEvent e;
+    const uint32_t n = w0 & kRrRunMask;
     if (kind == kRrCollapsed && k != 0u) {  // the D_EMPTY filler of a collapsed flush (:258-264)
         e.d = kDEmpty;
         e.t = running_t_u32;
+        return e;
+    }
+    if (kind == kRrFlushPop && k + 1u == cnt) {  // the new run's root (v, 1), popped in the frame it started
+        const CrNode nd = cr_node((float)(w0 >> kRrPopInShift), 1u, T);
+        e.d = lean_bd_from_thr(f32_to_bits(nd.thr));
+        e.t = f32_as_u32(ABS_T ? fadd(nd.bdt, fmul((float)(lq + n), T)) : nd.bdt);
         return e;
     }
     float bdt = T;  // a black root: (D_ZERO, time_spanned)

@@ -464,9 +464,12 @@ int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
 int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
     {   // the bounded Collapse step's conditions without the mode: Normal runs it too
         const bool was = s->collapse;
+        const uint32_t dtm_was = s->dtm;
         s->collapse = true;
+        if (!was && (float)s->dtm <= T) s->dtm = (uint32_t)T + 1u;  // (Normal also with delta_t_max <= time_spanned: kRrFlushPop)
         const bool ok = sim_cb_possible(s, T);
         s->collapse = was;
+        s->dtm = dtm_was;
         if (!ok || s->c_thresh != 0 || s->c_max != 0) return -7;
     }
     if (s->abs_t && (T != (float)s->ref_time || s->ref_time < 255u)) return -7;
@@ -497,13 +500,14 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                     if (cnt != count) s->plan_mismatch++;
                     const uint32_t rt_u32 = f32_as_u32(fmul((float)(frame0 + i), T));
                     for (uint32_t k = 0; k < cnt; ++k) {
-                        const RrEvent e = s->abs_t ? rr_event_at<true>(kind, Iu, w0, w1, k, T, rt_u32) : rr_event_at<false>(kind, Iu, w0, w1, k, T, rt_u32);
+                        const RrEvent e = s->abs_t ? rr_event_at<true>(kind, Iu, w0, w1, k, cnt, T, rt_u32) : rr_event_at<false>(kind, Iu, w0, w1, k, cnt, T, rt_u32);
                         SimEvent ev;
                         ev.x = (uint16_t)x; ev.y = (uint16_t)(y + s->row_begin); ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)c;
                         ev.d = (uint8_t)e.d; ev.pad = 0; ev.t = e.t;
                         per_frame[i].push_back(ev);
                     }
                     if (kind == kRrFlush && Iu != 0u && rr_chain(Iu, w0, T) != cnt) s->plan_mismatch++;  // the chain ends exactly at the count
+                    if (kind == kRrFlushPop && Iu != 0u && rr_chain(Iu, w0 & kRrRunMask, T) + 1u != cnt) s->plan_mismatch++;
                 }
                 DeepAcc deep{s, u};
                 struct Store {

@@ -638,7 +638,7 @@ def test_rr_in_mode_normal(time_mode):
     (the levels go on being visited), a flush after the pop emits the whole chain.  Every content, blocked launches, and
     launches of the generic step in between (the same planes)."""
     rng = np.random.default_rng(47 + time_mode)
-    for dtm in (7650, 255 * 3, 255 * 40):
+    for dtm in (7650, 255 * 3, 255 * 40, 255):  # (255 = time_spanned: a flush and the new root's pop in one frame, one record)
         for kind in ("scene", "runs", "jitter", "static", "dark", "noise"):
             frames = 150
             clip = (O.synth_clip(O.CONTENT_SCENE, 12, 7, 1, frames) if kind == "scene"

@@ -1532,7 +1532,7 @@ def test_mode_normal_crf0_run_records_and_generic_kernel(monkeypatch, step, time
     rng = np.random.default_rng(90 + time_mode)
     A = _hip()
     W, H, Cn, frames = 131, 23, 3, 200
-    for kind, dtm in (("runs", 7650), ("scene", 255 * 4), ("jitter", 7650)):
+    for kind, dtm in (("runs", 7650), ("scene", 255 * 4), ("jitter", 7650), ("runs", 255), ("scene", 255)):
         clip = (O.synth_clip(O.CONTENT_SCENE, W, H, Cn, frames) if kind == "scene"
                 else clips.make_clip(kind, frames, H, W, Cn, seed=17 + len(kind)))
         ov = O.Video(W, H, Cn, time_mode=time_mode, multi_mode=O.NORMAL, ref_time=255, delta_t_max=dtm)
