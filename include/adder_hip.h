@@ -285,7 +285,7 @@ float adder_hip_last_batch_ms(AdderHipCtx *ctx);
 /* Device batches of more than one chunk are replayed from a captured graph whose two branches (the frame kernel of
  * chunk k+1 beside scan / offsets / expansion of chunk k) the runtime binds to hardware queues when the graph is
  * instantiated -- well or badly, for the life of the instance.  The first batches of a given length therefore try
- * a few instances (2 batches each, 6 instances) and keep the fastest; this returns 1 once the last batch's length
+ * a few instances (2 batches each, 6 instances -- the first on one stream, measured twice more at the end) and keep the fastest; this returns 1 once the last batch's length
  * has settled (always 1 for single-chunk batches and with ADDER_HIP_NO_GRAPH). */
 int adder_hip_launch_plan_settled(const AdderHipCtx *ctx);
 /* Diagnostics (environment ADDER_HIP_TIMELINE=1): first start / last end of the kernels of the last batch, in 10 ns
