@@ -1106,6 +1106,16 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
     return ADDER_OK;
 }
 
+// The integer-state kernels (lean runs, run records) keep their whole state in the header, delta_t and last_fired_t
+// planes; the other level-0 planes and the levels are derived from it (divisions, and for run records a store per level).
+// A launch that is followed by another launch of the same batch leaves them stale (variant bit 2048): only the batch's last
+// launch brings the planes to the resident form every other kernel, a rollback or the next batch reads.  (Run records:
+// 30 us of a 160 us launch were this epilogue.)
+static uint32_t lazy_state_bit(const AdderHipCtx *c, uint32_t variant, bool more_launches) {
+    static const bool off = env_flag("ADDER_HIP_NO_LAZY_STATE");
+    return (more_launches && (variant & (256u | 512u)) && !c->running_enabled && !off) ? 2048u : 0u;
+}
+
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
                              bool timing) {
     // temporal blocking is off while the running-intensities side plane is wanted (per-frame
@@ -1131,7 +1141,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
             if (timing && !per_chunk) HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs], s));
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, lean_cap, s, &wide));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant | lazy_state_bit(c, variant, f + nb < num_frames), c->num_waves, lean_cap, s, &wide));
             if (timing) {  // the pair brackets the frame kernel (K1) only
                 if (!per_chunk) {
                     HIPCHK(c, hipEventRecord(c->launch_events[2 * c->timed_pairs + 1], s));
@@ -1189,7 +1199,7 @@ static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t
         if (k >= c->ring_chunks) HIPCHK(c, hipStreamWaitEvent(ls, c->cap_e2[(k - c->ring_chunks) % 5u], 0));
         for (uint32_t f = f0; f < f0 + nf; f += depth) {
             const uint32_t nb = std::min(depth, f0 + nf - f);
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant, c->num_waves, 0u, ls, &wide));
+            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant | lazy_state_bit(c, variant, f + nb < num_frames), c->num_waves, 0u, ls, &wide));
         }
         HIPCHK(c, hipEventRecord(c->split_el[k % 5u], ls));
         if (ps != ls) HIPCHK(c, hipStreamWaitEvent(ps, c->split_el[k % 5u], 0));

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 constexpr uint32_t kLrInFrames = ADDER_LR_IN_FRAMES;
 template <bool FULL, bool ABS_T>
 __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
-                                          uint32_t gw, uint32_t lane, uint8_t *lds_in) {
+                                          uint32_t gw, uint32_t lane, uint8_t *lds_in, bool lazy) {
     constexpr uint32_t N = kUnitsPerLane;
     constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
     using L = WaveLanes;
@@ -850,6 +850,21 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
     }
+    constexpr bool NTS_ = ADDER_NT_STATE != 0;
+    if (lazy) {  // another launch of this batch follows: only what lr_unpack reads (header, delta_t, last_fired_t)
+        uint32_t hdrv[N];
+        float dv[N], lfv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            hdrv[j] = hdr_make(px[j].base, 0u, px[j].rho != 0u ? 1u : 0u, px[j].base != 0u);
+            dv[j] = px[j].base != 0u ? fmul((float)px[j].rho, T) : 0.0f;
+            lfv[j] = ABS_T ? fmul((float)lq[j], T) : 0.0f;
+        }
+        store_vec<NTS_>(a.hdr, u0, hdrv);
+        store_vec<NTS_>(a.dt0, u0, dv);
+        if (ABS_T) store_vec<NTS_>(a.lastf, u0, lfv);
+        return;
+    }
     {   // state back to HBM in its resident form
         uint32_t hdrv[N];
         float iv[N], dv[N], bv[N];
@@ -871,7 +886,7 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
 
 template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_lr_kernel(const BatchArgs *__restrict__ b,
-                                                                                         uint32_t f, uint32_t nb) {
+                                                                                         uint32_t f, uint32_t nb, uint32_t lazy) {
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
@@ -880,8 +895,8 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) lr_frames<true, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
-        else lr_frames<false, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave]);
+        if (full) lr_frames<true, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], lazy != 0u);
+        else lr_frames<false, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], lazy != 0u);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -1876,7 +1891,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_
 constexpr uint32_t kRrInFrames = 32;
 template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
-                                               uint32_t gw, uint32_t lane, uint8_t *lds_in, const uint8_t *lds_tab) {
+                                               uint32_t gw, uint32_t lane, uint8_t *lds_in, const uint8_t *lds_tab, bool lazy) {
     constexpr uint32_t N = kUnitsPerLane;
     constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
     constexpr uint32_t REC = ABS_T ? 12u : 8u;
@@ -1997,6 +2012,21 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
     }
+    if (lazy) {  // another launch of this batch follows: only what rr_unpack reads (header, delta_t, last_fired_t)
+        uint32_t hdrv[N];
+        float dv[N], lfv[N];
+#pragma unroll
+        for (uint32_t j = 0; j < N; ++j) {
+            hdrv[j] = hdr_make(px[j].base, 0u, px[j].n != 0u ? 1u : 0u, L::lane(px[j].popped));
+            dv[j] = px[j].base != 0u ? fmul((float)px[j].n, T) : 0.0f;
+            lfv[j] = ABS_T ? fmul((float)px[j].lq, T) : 0.0f;
+        }
+        constexpr bool NTS_ = ADDER_NT_STATE != 0;
+        store_vec<NTS_>(a.hdr, u0, hdrv);
+        store_vec<NTS_>(a.dt0, u0, dv);
+        if (ABS_T) store_vec<NTS_>(a.lastf, u0, lfv);
+        return;
+    }
     {   // state back to HBM in its resident form
         uint32_t hdrv[N];
         float iv[N], dv[N], bv[N], lfv[N];
@@ -2033,7 +2063,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
 
 template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_RR_WAVES_PER_SIMD) void adder_rr_kernel(const BatchArgs *__restrict__ b,
-                                                                                         uint32_t f, uint32_t nb) {
+                                                                                         uint32_t f, uint32_t nb, uint32_t lazy) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kRrInFrames * kWaveUnits];
     __shared__ __attribute__((aligned(16))) uint8_t s_tab[256 * kRrTabRows];
     const FrameArgs a = frame_args(b, f);
@@ -2049,8 +2079,8 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_RR_WAVES_PER_SIMD) void adder_
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) rr_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab);
-        else rr_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab);
+        if (full) rr_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab, lazy != 0u);
+        else rr_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_tab, lazy != 0u);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -3432,8 +3462,9 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     }
     if (variant & 512u) {  // run records (the bounded Collapse regime at c_thresh 0, integer state)
         const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
-        if (abs_t) hipLaunchKernelGGL((adder_rr_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
-        else hipLaunchKernelGGL((adder_rr_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
+        const uint32_t lazy = (variant & 2048u) ? 1u : 0u;  // (more launches of this batch follow: adder_hip_api.cpp lazy_state_bit)
+        if (abs_t) hipLaunchKernelGGL((adder_rr_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
+        else hipLaunchKernelGGL((adder_rr_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
         return hipGetLastError();
     }
     if (variant & 128u) {  // constant runs (the bounded Collapse regime at c_thresh 0)
@@ -3462,8 +3493,9 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
     if (variant & 256u) {  // lean runs (DeltaT, constant runs): every launch of the batch, whatever its length
         const uint32_t SR = grid_cap && grid_cap < S ? grid_cap : S;
-        if (abs_t) hipLaunchKernelGGL((adder_lr_kernel<true>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
-        else hipLaunchKernelGGL((adder_lr_kernel<false>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb);
+        const uint32_t lazy = (variant & 2048u) ? 1u : 0u;  // (more launches of this batch follow: adder_hip_api.cpp lazy_state_bit)
+        if (abs_t) hipLaunchKernelGGL((adder_lr_kernel<true>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
+        else hipLaunchKernelGGL((adder_lr_kernel<false>), dim3(SR), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
         return hipGetLastError();
     }
 #if ADDER_UNITS_PER_LANE == 2 && ADDER_LEAN1_WIDE
