@@ -1166,8 +1166,8 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             t = s2;
         }
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t));
-        HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t, num_frames == 1u ? 1u : 0u));
+        if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
         if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));

@@ -2190,7 +2190,7 @@ __device__ __forceinline__ uint4 scan_prefix4(const uint4 &v, uint32_t &run) {
     run = o.w + (v.w & 0xffffu);
     return o;
 }
-__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t whole_batch) {
     const FrameArgs a = frame_args(b, f0 + blockIdx.x);
     timeline_mark(b, 1u, f0, false);
     __shared__ uint32_t s_part[kScanThreads / kWave];
@@ -2251,6 +2251,11 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     if (tid == 0) {
         *a.ftot = total;
         a.ftot[b->slots] = rec_total;  // second half of the ring: records per frame
+        if (whole_batch) {  // a batch of ONE frame (the per-frame calls and the ring): the offsets kernel's work, a launch less
+            b->base.frame_offsets[0] = 0ull;
+            b->base.frame_offsets[1] = total;
+            if (b->rec_total) *b->rec_total = rec_total;
+        }
     }
     timeline_mark(b, 1u, f0, true);
 }
@@ -3549,8 +3554,8 @@ extern "C" hipError_t adder_launch_wire_scatter(const AdderEventPod *ev, const u
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream) {
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf), dim3(kScanThreads), 0, stream, b, f0);
+extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream, uint32_t whole_batch) {
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u);
     return hipGetLastError();
 }
 
