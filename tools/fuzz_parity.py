@@ -2,7 +2,7 @@
 Small planes, contents that mix static stretches, jitter inside and outside the contrast band, black regions, scene cuts and
 noise; Collapse / Normal, DeltaT / AbsoluteT, delta_t_max 255 / 1020 / 7650, crf 0 / 3 / 6 / 9 numbers, gray / RGB, random batch
 lengths and launch depths, some batches with an event buffer that is too small (rollback + retry).
-usage: python tools/fuzz_parity.py [seconds] [seed]"""
+usage: python tools/fuzz_parity.py [seconds] [seed]   (FUZZ_CRF0=1: crf 0 only; FUZZ_CONTINUOUS=0/1)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
@@ -33,6 +33,8 @@ def one(rng):
     C = int(rng.choice([1, 1, 3])); T = int(rng.integers(20, 220))
     tm = int(rng.choice([O.DELTA_T, O.ABSOLUTE_T])); mm = int(rng.choice([O.COLLAPSE, O.COLLAPSE, O.COLLAPSE, O.NORMAL]))
     dtm = int(rng.choice([255, 7650, 7650, 1020])); crf = int(rng.choice([0, 3, 3, 6, 9]))
+    if os.environ.get("FUZZ_CRF0") == "1":  # the integer-state kernels (lean runs, run records): crf 0 only
+        crf = 0
     depth = int(rng.choice([1, 3, 16, 64, 64]))
     cont = os.environ.get("FUZZ_CONTINUOUS") == "1" or (os.environ.get("FUZZ_CONTINUOUS") is None and rng.random() < 0.12)
     clip = make_clip(rng, T, H, W, C)
