@@ -478,7 +478,7 @@ def main():
     try:
         default_workload = (Wd, Ht, Cn, T, args.delta_t_max, args.content, args.multi_mode, args.time_mode) == \
             (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t")
-        tname = "r04_traffic_wire_output.json" if wire_out else "r04_traffic_default.json"
+        tname = "r04_traffic_default.json" if wire_out else "r04_traffic_events_output.json"  # (profile_round.sh: the default command / --output events)
         tpath = os.path.join(ROOT, "profiles", tname)
         if default_workload and world == 1 and os.path.exists(tpath):
             tk = json.load(open(tpath))["kernels"]

@@ -45,16 +45,18 @@ pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
     rm -rf "$OUT/$tag"/pmc_*/
 }
 pmc_passes default "A=1" --frames 160
-pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96
-pmc_passes default_mode_dtm7650_abs "A=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
+pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96 --output events
+pmc_passes default_mode_dtm7650_abs "A=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
 # 4. the reference default mode (Collapse, AbsoluteT, delta_t_max 7650: adder_cb_kernel) eager on one stream: kernel stats
 ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o bench -- \
-    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary --delta-t-max 7650 --time-mode absolute_t > "$OUT/bench_default_mode_under_rocprof.log" 2>&1
+    python "$REPO/bench.py" --steps 5 --warmup 2 --skip-roofline --no-cpu-baseline --no-end-to-end --no-secondary --delta-t-max 7650 --time-mode absolute_t --output events > "$OUT/bench_default_mode_under_rocprof.log" 2>&1
 find "$OUT/stats4" -name '*kernel_stats.csv' -exec cp {} "$OUT/${ROUND}_default_mode_eager_kernel_stats.csv" \;
+# (every row below runs with --output events: AdderEvents as the step's output, as bench.py's secondary legs run these modes;
+#  the default command of 1.-3. writes the raw sink's records)
 # 5. (round 4) the kernels VERDICT r3 found without evidence: adder_cb_kernel<false> (DeltaT default mode), adder_frame_kernel
 #    (Normal mode), and the one-frame-per-launch pipeline's scan / expansion -- PMC passes + eager kernel stats each
-pmc_passes default_mode_dtm7650_delta "A=1" --frames 128 --delta-t-max 7650
-pmc_passes normal_dtm255_delta "A=1" --frames 128 --multi-mode normal
+pmc_passes default_mode_dtm7650_delta "A=1" --frames 128 --delta-t-max 7650 --output events
+pmc_passes normal_dtm255_delta "A=1" --frames 128 --multi-mode normal --output events
 kstats() {  # $1 = tag, $2 = extra env, $3.. = bench args
     local tag=$1 envs=$2; shift; shift
     env $envs ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks_$tag" -o bench -- \
@@ -64,20 +66,20 @@ kstats() {  # $1 = tag, $2 = extra env, $3.. = bench args
 }
 # (round 4: at crf 0 the default mode runs adder_rr_kernel; ADDER_HIP_NO_RR=1 gives adder_cr_kernel's rows,
 #  ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1 the bounded Collapse kernel's)
-pmc_passes cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650
-pmc_passes cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
-pmc_passes cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650
-pmc_passes cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t
-pmc_passes lean_step_no_runs "ADDER_HIP_NO_LR=1" --frames 160
-pmc_passes wire_output "A=1" --frames 160 --output wire
-kstats cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --delta-t-max 7650
-kstats cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --time-mode absolute_t
-kstats cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650
-kstats cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650 --time-mode absolute_t
-kstats wire_output "A=1" --output wire
-kstats default_mode_delta "A=1" --delta-t-max 7650
-kstats normal_dtm255_delta "A=1" --multi-mode normal
-kstats normal_dtm7650_abs "A=1" --multi-mode normal --delta-t-max 7650 --time-mode absolute_t
-kstats one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 128
+pmc_passes cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 --output events
+pmc_passes cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
+pmc_passes cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --output events
+pmc_passes cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
+pmc_passes lean_step_no_runs "ADDER_HIP_NO_LR=1" --frames 160 --output events
+pmc_passes events_output "A=1" --frames 160 --output events
+kstats cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --output events
+kstats cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --time-mode absolute_t --output events
+kstats cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650 --output events
+kstats cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650 --time-mode absolute_t --output events
+kstats events_output "A=1" --output events
+kstats default_mode_delta "A=1" --delta-t-max 7650 --output events
+kstats normal_dtm255_delta "A=1" --multi-mode normal --output events
+kstats normal_dtm7650_abs "A=1" --multi-mode normal --delta-t-max 7650 --time-mode absolute_t --output events
+kstats one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 128 --output events
 rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3 "$OUT"/stats4
 ls -la "$OUT"
