@@ -2436,14 +2436,15 @@ __device__ __forceinline__ void xbuf_flush_wire(const uint32_t *xb, uint32_t pad
         const uint32_t k = lane < head ? lane : n - tail + (lane - head);
         const WireWords r = wire_words(xb[pad + 3u * k], xb[pad + 3u * k + 1u], xb[pad + 3u * k + 2u], rec);
         uint8_t *const p = dst + k * rec;
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            p[j] = (uint8_t)(r.w0 >> (8u * j));
-            p[4u + j] = (uint8_t)(r.w1 >> (8u * j));
-        }
-        p[8] = (uint8_t)r.w2;
-        if (rec != 9u) {
-            p[9] = (uint8_t)(r.w2 >> 8);
+        // (global stores may sit at any byte address: two dwords and the rest, instead of nine to eleven byte stores --
+        // the stores of a flush are counted in instructions, not bytes)
+        __builtin_memcpy(p, &r.w0, 4);
+        __builtin_memcpy(p + 4, &r.w1, 4);
+        if (rec == 9u) {
+            p[8] = (uint8_t)r.w2;
+        } else {
+            const uint16_t lo = (uint16_t)r.w2;
+            __builtin_memcpy(p + 8, &lo, 2);
             p[10] = (uint8_t)(r.w2 >> 16);
         }
     }
