@@ -650,13 +650,19 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 #ifndef ADDER_LR_IN_FRAMES
 #define ADDER_LR_IN_FRAMES 32
 #endif
+#ifndef ADDER_LR_QUIET_GROUPS
+#define ADDER_LR_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
+#endif
+#ifndef ADDER_LR_QUIET_REENTER
+#define ADDER_LR_QUIET_REENTER 1  // (0: the group test only in front of a launch's first stepped frame)
+#endif
 // input frames in the wave's LDS slice (two groups of half as many, one being stepped, one on its way): the step needs ~46
 // registers, so the slice decides the occupancy -- 32 frames (4 KB per wave, 16 KB per workgroup) leave room for 8 waves
 // per SIMD
 constexpr uint32_t kLrInFrames = ADDER_LR_IN_FRAMES;
 template <bool FULL, bool ABS_T>
 __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t u0,
-                                          uint32_t gw, uint32_t lane, uint8_t *lds_in, bool lazy) {
+                                          uint32_t gw, uint32_t lane, uint8_t *lds_in, uint8_t *lds_base, bool lazy) {
     constexpr uint32_t N = kUnitsPerLane;
     constexpr uint32_t NB_MAX = kMaxFramesPerLaunch;
     using L = WaveLanes;
@@ -823,27 +829,71 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
 #endif
     };
     static_assert(kLrGroup % 2u == 0u && N <= 4u, "pairs of frames never straddle a staging group; an input word holds the units' bytes");
+    // QUIET GROUPS (lr_quiet_run): a staged group ALL of whose bytes equal the units' base_vals -- static content -- is decided
+    // at once: no flush, no event, no record, every run grows by the group.  The units' base_vals go to LDS as one more
+    // frame row and every lane compares its 16-byte pieces of the group's rows with its piece of that row (kLrGroup / 8 + 1
+    // LDS reads, an OR of XORs, one ballot -- against 16 x 80 instructions of stepping).  The test is made only where the
+    // frame before left no record in the segment (and at the launch's start), so waves of busy content never pay for it.
+    static_assert(kLrGroup == kQuietGroup, "the group the sim's lr block decides at once");
+    auto group_quiet = [&](uint32_t i) -> bool {  // uniform
+        const InT bw = (InT)prev_w;
+        __builtin_memcpy(lds_base + lane * (uint32_t)sizeof(InT), &bw, sizeof(InT));
+        const uint8_t *const g = lds_in + ((i / kLrGroup) & 1u) * (kLrGroup * kWaveUnits) + lane * 16u;
+        uint4 r;
+        __builtin_memcpy(&r, (const uint8_t *)__builtin_assume_aligned(lds_base + (lane & 7u) * 16u, 16), 16);
+        uint32_t diff = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < kLrGroup / 8u; ++q) {
+            uint4 x;
+            __builtin_memcpy(&x, (const uint8_t *)__builtin_assume_aligned(g + q * 1024u, 16), 16);
+            diff |= (x.x ^ r.x) | (x.y ^ r.y) | (x.z ^ r.z) | (x.w ^ r.w);
+        }
+        return __builtin_amdgcn_ballot_w64(diff != 0u) == 0ull;
+    };
+    // The frame loop below is bound by instruction issue and sensitive to what is live across it (a first version with the
+    // group test inside it cost the busy headline 18 %: 93 -> 110 us per 60 frames): the quiet groups are a loop of their own
+    // IN FRONT of it, and the frame loop runs one staged group per trip of the outer loop, so that a wave whose content
+    // calms down goes back to the group test at the next group (only after a frame that parked no record).
     uint32_t i = 0u;
-    for (; i + 2u <= nb; i += 2u) {
-        if ((i % kLrGroup) == 0u) stage(i);
-        uint32_t k0 = 0u, k1 = 0u;
-        uint32_t t0 = frame(i, k0);
-        uint32_t t1 = frame(i + 1u, k1);
+    uint32_t last_recs = 0u;  // records the segment parked in the last frame stepped (uniform)
+    while (i < nb) {
+        stage(i);  // (i is a multiple of kLrGroup here)
+        if (ADDER_LR_QUIET_GROUPS && last_recs == 0u && group_quiet(i)) {
+            const uint32_t gn = nb - i < kLrGroup ? nb - i : kLrGroup;  // (a short last group: its other rows repeat the last frame)
+#pragma unroll
+            for (uint32_t j = 0; j < N; ++j) lr_quiet_run<L>(px[j], gn);
+            seg += gn * frame_stride_u;
+            if (wrap_at - i < gn) seg -= wrap_bytes;  // (unsigned: wrap_at lies in [i, i + gn))
+            i += gn;  // (wt of these frames stays 0)
+            continue;
+        }
+        // (REENTER: one staged group per trip; otherwise the rest of the launch, staging as it goes)
+        const uint32_t i_first = i;
+        const uint32_t i_end = ADDER_LR_QUIET_REENTER ? (i + kLrGroup < nb ? i + kLrGroup : nb) : nb;
+#pragma clang loop unroll(disable)
+        for (; i + 2u <= i_end; i += 2u) {
+            if (!ADDER_LR_QUIET_REENTER && (i % kLrGroup) == 0u && i != i_first) stage(i);
+            uint32_t k0 = 0u, k1 = 0u;
+            uint32_t t0 = frame(i, k0);
+            uint32_t t1 = frame(i + 1u, k1);
+            if (ADDER_LR_QUIET_REENTER) last_recs = t1 >> 16;
 #if ADDER_LR_COUNT_VALU
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0 | (k1 << 16)), kWave - 1);
-        t0 |= tot & 0xffffu;
-        t1 |= tot >> 16;
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0 | (k1 << 16)), kWave - 1);
+            t0 |= tot & 0xffffu;
+            t1 |= tot >> 16;
 #endif
-        wt = lane == i ? t0 : lane == i + 1u ? t1 : wt;
-    }
-    if (i < nb) {
-        if ((i % kLrGroup) == 0u) stage(i);
-        uint32_t k0 = 0u;
-        uint32_t t0 = frame(i, k0);
+            wt = lane == i ? t0 : lane == i + 1u ? t1 : wt;
+        }
+        if (i < i_end) {  // (the launch's last frame, odd launches only)
+            if (!ADDER_LR_QUIET_REENTER && (i % kLrGroup) == 0u && i != i_first) stage(i);
+            uint32_t k0 = 0u;
+            uint32_t t0 = frame(i, k0);
 #if ADDER_LR_COUNT_VALU
-        t0 |= (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0), kWave - 1);
+            t0 |= (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0), kWave - 1);
 #endif
-        wt = lane == i ? t0 : wt;
+            wt = lane == i ? t0 : wt;
+            i += 1u;
+        }
     }
     if (lane < nb) {
         uint32_t s = slot0 + lane;
@@ -891,12 +941,13 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kLrInFrames * kWaveUnits];
+    __shared__ __attribute__((aligned(16))) uint8_t s_base[kWavesPerBlock][kWaveUnits];  // the units' base_vals as a frame row (quiet groups)
     timeline_mark(b, 0u, f, false);
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) lr_frames<true, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], lazy != 0u);
-        else lr_frames<false, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], lazy != 0u);
+        if (full) lr_frames<true, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_base[tid / kWave], lazy != 0u);
+        else lr_frames<false, ABS_T>(b, a, nb, u0, gw, lane, s_in[tid / kWave], s_base[tid / kWave], lazy != 0u);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -1385,9 +1436,10 @@ struct __attribute__((aligned(16))) CbWaveLds {
     uint8_t in[kCbInFrames * kWaveUnits]; // [frame of the group][unit]
 };
 
-// the next group of input frames of one segment -> the wave's LDS slice (frames [k0, k0 + kCbInFrames) of the launch)
+// the next group of input frames of one segment -> the wave's LDS slice (frames [k0, k0 + kCbInFrames) of the launch);
+// cb_stage_issue only asks for them (vmcnt(0) before the first read), cb_stage_input waits as well
 template <bool FULL>
-__device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_units_u, uint32_t sgw, uint32_t u0,
+__device__ __forceinline__ void cb_stage_issue(const uint8_t *fr0, uint32_t n_units_u, uint32_t sgw, uint32_t u0,
                                                uint32_t lane, uint32_t k0, uint32_t nb, uint8_t *lds_in, bool direct) {
     constexpr uint32_t N = kUnitsPerLane;
     using InT = typename VecOf<uint8_t, N>::type;
@@ -1411,11 +1463,58 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
             in_lds[q * kWave] = (InT)load_input(fr0 + (size_t)kk * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
         }
     }
+}
+template <bool FULL>
+__device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_units_u, uint32_t sgw, uint32_t u0,
+                                               uint32_t lane, uint32_t k0, uint32_t nb, uint8_t *lds_in, bool direct) {
+    cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, k0, nb, lds_in, direct);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed (and so have the records stored so far)
+}
+
+// packed 16-bit operations of the quiet groups' statistics (two units of a lane per instruction)
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // max(a - b, 0) per half
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c per half
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// min over each row of 16 lanes, left in the row's last lane (DPP row shifts; lanes without a source keep their own value)
+__device__ __forceinline__ uint32_t row16_min_to_last(uint32_t x) {
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false); x = y < x ? y : x;
+    return x;
 }
 
 #ifndef ADDER_CB_QUIET_PATH
 #define ADDER_CB_QUIET_PATH 1
+#endif
+#ifndef ADDER_CB_QUIET_GROUPS
+#define ADDER_CB_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
+#endif
+#ifndef ADDER_CB_QUIET_PREFETCH
+#define ADDER_CB_QUIET_PREFETCH 1  // (0: the quiet loop stages a group when it gets there, as the general loop does)
 #endif
 #ifndef ADDER_CB_SEQUENTIAL
 #define ADDER_CB_SEQUENTIAL 1
@@ -1490,6 +1589,8 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
                         __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)fr0) & 15u) == 0u);
     using InT = typename VecOf<uint8_t, N>::type;
     const InT *const in_lds = reinterpret_cast<const InT *>(w.in) + lane;
+    // the smallest c_thresh of every input group (lane 16 g + 15: group g; frames past the launch do not count)
+    const uint32_t tab_cmin = row16_min_to_last(lane < nb ? tab_cth : 0xffu);
     uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
     typename L::Mask depth_error = L::from(false);
 
@@ -1523,9 +1624,85 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             uint64_t unpopped[N];
 #pragma unroll
             for (uint32_t j = 0; j < N; ++j) unpopped[j] = __builtin_amdgcn_ballot_w64(!L::lane(px[j].popped));
-            for (; i < nb; ++i) {
-                if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
-                const uint32_t vin_q = (uint32_t)in_lds[(i % kCbInFrames) * kWave];
+            // Input staging of THIS loop is double-buffered: no unit of such a wave holds a level (m == 1 everywhere), so the
+            // wave's fast-level slots are idle and take the NEXT group's bytes while this group is worked on (the quiet groups
+            // below get through a group in a few hundred instructions: the wait for its bytes would be most of the time).
+            // The general loop knows nothing of it: whoever leaves this loop waits for what is in flight (nothing may land in
+            // the level slots once levels live there again) and puts the current group into w.in if it is not there.
+            static_assert(sizeof(w.F) >= sizeof(w.in), "the level slots hold a group of input frames");
+            uint8_t *const buf_b = reinterpret_cast<uint8_t *>(w.F);
+            bool pref = false;   // the next group's bytes are on their way into the other buffer (uniform)
+            uint32_t cur = 0u;   // where the current group is: 0 = w.in, 1 = the level slots (uniform)
+            const InT *cur_in = in_lds;
+            for (; i < nb;) {
+                if ((i % kCbInFrames) == 0u) {
+                    if (pref) cur ^= 1u;
+                    else {
+                        cur = 0u;
+                        cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed
+                    pref = ADDER_CB_QUIET_PREFETCH != 0 && i + kCbInFrames < nb;
+                    if (pref) cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i + kCbInFrames, nb, cur ? w.in : buf_b, direct);
+                    cur_in = reinterpret_cast<const InT *>(cur ? buf_b : w.in) + lane;
+#if ADDER_CB_QUIET_GROUPS
+                    // ---------------- the whole group at once (quiet_group_apply, adder_pixel.hpp) ----------------
+                    // min / max / sum of every unit's bytes over the group, the number of frames before the root fires and
+                    // what it has accumulated by then -- packed 16-bit operations, both units of a lane per instruction --
+                    // then ONE contrast test against the group's smallest c_thresh and ONE firing test per unit.  A group
+                    // in which some unit is not quiet is stepped frame by frame below, as before.
+                    static_assert(N == 2u && kCbInFrames == kQuietGroup, "two units per lane in one packed register");
+                    {
+                        const uint32_t gn = nb - i < kCbInFrames ? nb - i : kCbInFrames;  // (uniform; a launch's last group may be short)
+                        const uint32_t cth_min = __builtin_amdgcn_readlane(tab_cmin, i + kCbInFrames - 1u);
+                        const uint32_t need2 = quiet_group_need(px[0].S, px[0].thr0) | (quiet_group_need(px[1].S, px[1].thr0) << 16);
+                        uint32_t mn = 0x00ff00ffu, mx = 0u, P = 0u, cnt = 0u, pm = 0u;
+                        for (uint32_t k = 0; k < gn; ++k) {
+                            const uint32_t pk = __builtin_amdgcn_perm(0u, (uint32_t)cur_in[k * kWave], 0x0c010c00u);  // {v0, v1} as halves
+                            mn = pk_min_u16(mn, pk);
+                            mx = pk_max_u16(mx, pk);
+                            P = pk_add_u16(P, pk);
+                            const uint32_t below = pk_min_u16(pk_sub_sat_u16(need2, P), 0x00010001u);  // prefix sum < need
+                            cnt = pk_add_u16(cnt, below);
+                            pm = pk_mad_u16(pk, below, pm);
+                        }
+                        CbPxT<L> t[N];
+                        uint32_t verdict[N];
+                        bool any_no = false, any_slow = false;
+#pragma unroll
+                        for (uint32_t j = 0; j < N; ++j) {
+                            QuietGroupStats g;
+                            g.mn = (mn >> (16u * j)) & 0xffffu;
+                            g.mx = (mx >> (16u * j)) & 0xffffu;
+                            g.sum = (P >> (16u * j)) & 0xffffu;
+                            g.cnt = (cnt >> (16u * j)) & 0xffffu;
+                            g.pm = (pm >> (16u * j)) & 0xffffu;
+                            const uint32_t row = g.cnt < gn ? g.cnt : gn - 1u;
+                            g.vc = ((uint32_t)cur_in[row * kWave] >> (8u * j)) & 0xffu;
+                            t[j] = px[j];
+                            verdict[j] = cb_group_apply<L>(t[j], g, gn, cth_min, T);
+                            any_no = any_no || verdict[j] == kQuietNo;
+                            any_slow = any_slow || verdict[j] == kQuietSlow;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(any_no) == 0ull) {  // uniform: every unit of the wave is quiet in every frame
+#pragma unroll
+                            for (uint32_t j = 0; j < N; ++j)
+                                if (verdict[j] == kQuietDone) px[j] = t[j];
+                            if (__builtin_amdgcn_ballot_w64(any_slow) != 0ull) {  // (rare: second firings, black roots that wake up)
+                                for (uint32_t k = 0; k < gn; ++k) {
+                                    const uint32_t vin_s = (uint32_t)cur_in[k * kWave];
+#pragma unroll
+                                    for (uint32_t j = 0; j < N; ++j)
+                                        if (verdict[j] == kQuietSlow) cb_step_quiet<L, true>(px[j], (vin_s >> (8 * j)) & 0xffu, T);
+                                }
+                            }
+                            i += gn;  // (wt / wo of these frames stay 0: no events, no records)
+                            continue;
+                        }
+                    }
+#endif
+                }
+                const uint32_t vin_q = (uint32_t)cur_in[(i % kCbInFrames) * kWave];
                 const uint32_t cth_q = __builtin_amdgcn_readlane(tab_cth, i);
                 uint64_t not_quiet = 0ull, fires = 0ull;
 #pragma unroll
@@ -1536,7 +1713,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
                                  (unpopped[j] & __builtin_amdgcn_ballot_w64(v != 0u));
                     fires |= __builtin_amdgcn_ballot_w64(cb_quiet_fires<L>(px[j], v));
                 }
-                if (not_quiet != 0ull) break;  // frame i: the general loop's (staged already)
+                if (not_quiet != 0ull) break;  // frame i: the general loop's
                 if (fires != 0ull) {
 #pragma unroll
                     for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, true>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
@@ -1545,6 +1722,12 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
                     for (uint32_t j = 0; j < N; ++j) cb_step_quiet<L, false>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
                 }
                 // (wt / wo of this frame stay 0: no events, no records)
+                ++i;
+            }
+            if (i < nb) {  // frame i goes to the general loop, which stages into w.in at a group's first frame
+                if (pref) __builtin_amdgcn_s_waitcnt(0x0f70);  // (what was on its way into the level slots has landed: they may hold levels again)
+                if (cur != 0u && (i % kCbInFrames) != 0u)
+                    cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i - (i % kCbInFrames), nb, w.in, direct);
             }
         }
     }
@@ -2554,7 +2737,15 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     // lean runs: event C by input byte (lr_build_tab), 1 KB per workgroup out of L2 -- a division less per record
     __shared__ uint32_t s_tab_c[LR && !ABS_T ? 256u : 1u];
     if (LR && !ABS_T) {
-        s_tab_c[threadIdx.x] = uniform_ptr(b->lr_tab)[256u * kLrTabRuns + threadIdx.x];
+        // (the table's words are asked for first and parked after the test below: the two loads share one round trip -- a test
+        // in front of the table load cost busy content a round trip per workgroup, 165 -> 177 us per chunk)
+        const uint32_t tab_word = gload<uint32_t>(uniform_ptr(b->lr_tab), (256u * kLrTabRuns + threadIdx.x) * 4u);
+        // a frame without a single event -- static content -- has nothing to expand: the workgroup is done before the table,
+        // the barrier and the counts' round trip (the scan's frame total; the bands' descriptions of the records gather
+        // carry none)
+        const uint32_t *const ft = b->ftot_ring;
+        if (ft != nullptr && __builtin_amdgcn_readfirstlane(ft[f % b->slots]) == 0u) return;
+        s_tab_c[threadIdx.x] = tab_word;
         __syncthreads();
     }
     static_assert(kExpandSegs % 2u == 0u, "segments are expanded in pairs");

@@ -1007,6 +1007,93 @@ ADDER_HD void cb_step_quiet(CbPxT<L> &s, uint32_t v, float T) {
 template <class L>
 ADDER_HD bool cb_quiet_fires(const CbPxT<L> &s, uint32_t v) { return fadd(s.S, (float)v) >= s.thr0; }
 
+// QUIET GROUPS: n <= kQuietGroup consecutive frames of a quiet unit decided at once instead of stepped (the blocked
+// kernels stage their input in groups of that many frames).  A root that only integrates (popped, or black) does, per
+// frame, S += v, delta_t += T (:449-451) and fires when S reaches its threshold (:427), which then doubles (:452-461).  Over
+// a group whose bytes ALL pass the contrast test against the group's SMALLEST c_thresh (video.rs:1338-1340; the ramp of
+// :402-412 is the same for every pixel, so the kernel hands the group's minimum down) that is: S += sum of the bytes,
+// delta_t += n T, and at most one firing -- in the first frame whose prefix sum reaches (threshold - S) -- as long as the sum
+// stays below the DOUBLED threshold; the firing arm is evaluated on that frame's (S, delta_t, v) exactly as the stepped
+// form would.  Everything is an exact integer below 2^24 (checked here: larger sums are stepped), so the group's adds
+// equal the frame-by-frame ones bit for bit.  What the caller gathers per unit over the group's bytes v_0 .. v_{n-1}, with
+// P_i = v_0 + .. + v_i and need = quiet_group_need():
+struct QuietGroupStats {
+    uint32_t mn, mx;  // smallest / largest byte
+    uint32_t sum;     // P_{n-1}
+    uint32_t cnt;     // frames whose prefix sum P_i stays below need: the root fires in frame cnt (if cnt < n)
+    uint32_t pm;      // P_{cnt-1}: what the root has accumulated of the group when it fires
+    uint32_t vc;      // v_cnt (any value when cnt == n)
+};
+constexpr uint32_t kQuietGroup = 16;
+constexpr uint32_t kQuietNo = 0u;    // some frame of the group is not quiet for this unit: the caller steps frame by frame
+constexpr uint32_t kQuietDone = 1u;  // the group is applied
+constexpr uint32_t kQuietSlow = 2u;  // quiet in every frame, but not a closed form (a second firing, a black root that
+                                     // wakes up, sums beyond 2^24): the unit steps its n frames with *_step_quiet
+// what the root still needs to fire, as a 16-bit count (65535: not within a group's reach; 0 for a black root)
+ADDER_HD uint32_t quiet_group_need(float S, float thr) {
+    const uint32_t d = f32_as_u32(fsub(thr, S));
+    return d < 0xffffu ? d : 0xffffu;
+}
+// the reference computation of the statistics (the kernels gather them with packed 16-bit operations)
+ADDER_HD QuietGroupStats quiet_group_stats(const uint8_t *v, size_t stride, uint32_t n, uint32_t need) {
+    QuietGroupStats g{255u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t P = 0u;
+    bool below = true;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t x = v[i * stride];
+        g.mn = x < g.mn ? x : g.mn;
+        g.mx = x > g.mx ? x : g.mx;
+        P += x;
+        if (below && P >= need) {
+            below = false;
+            g.vc = x;
+        }
+        if (below) {
+            ++g.cnt;
+            g.pm = P;
+        }
+    }
+    g.sum = P;
+    return g;
+}
+// (S, dt, bdt, thr) = the root's integration, delta_t, best delta_t and threshold 2^d; precondition: the unit holds its
+// root alone and is popped or black (cb_quiet / lean_quiet without their per-frame part)
+ADDER_HD uint32_t quiet_group_apply(float &S, float &dt, float &bdt, float &thr, uint32_t base, bool popped,
+                                    const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T) {
+    const uint32_t dmx = g.mx > base ? g.mx - base : base - g.mx, dmn = g.mn > base ? g.mn - base : base - g.mn;
+    if ((dmx > dmn ? dmx : dmn) > cth_min) return kQuietNo;  // the extremes bound |v - base_val| of every frame
+    if (!popped && g.mx != 0u) return kQuietNo;              // an unpopped unit is in here as a black one: quiet on zeros only
+    if (thr == 0.0f) {
+        // a black root (integration 0, d = 128) fires on every zero without accumulating (:449): idempotent
+        if (g.sum != 0u) return kQuietSlow;
+        bdt = fadd(dt, fmul(T, 1.0f));
+        return kQuietDone;
+    }
+    const float S_new = fadd(S, (float)g.sum), dt_new = fadd(dt, fmul((float)n, T));
+    if (!(S_new < 16777216.0f && dt_new < 16777216.0f)) return kQuietSlow;
+    if (S_new >= thr) {  // the root fires in frame g.cnt: the firing arm of integrate_main (:427-473) on that frame
+        if (g.cnt >= n || g.vc == 0u) return kQuietSlow;  // (cannot happen while thr > S; never divide by zero)
+        const float S_old = fadd(S, (float)g.pm), I = (float)g.vc;
+        const float p2 = bits_to_f32(f32_to_bits(fadd(S_old, I)) & 0x7f800000u);
+        const float thr2 = fadd(p2, p2);
+        if (S_new >= thr2) return kQuietSlow;  // a second firing inside the group
+        bdt = fadd(fadd(dt, fmul((float)g.cnt, T)), fmul(T, fdiv_small(fsub(p2, S_old), I)));
+        thr = thr2;
+    }
+    S = S_new;
+    dt = dt_new;
+    return kQuietDone;
+}
+template <class L>
+ADDER_HD uint32_t cb_group_apply(CbPxT<L> &s, const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T) {
+    return quiet_group_apply(s.S, s.dt0, s.bdt0, s.thr0, s.base, L::lane(s.popped), g, n, cth_min, T);
+}
+// (the lean step's quiet root is the same root: lean_step_quiet == cb_step_quiet on {integ, dt, bdt, thr})
+template <class L>
+ADDER_HD uint32_t lean_group_apply(LeanPxT<L> &p, const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T) {
+    return quiet_group_apply(p.integ, p.dt, p.bdt, p.thr, p.base, L::lane(p.popped), g, n, cth_min, T);
+}
+
 // The unit's events of this frame, in emission order.  After cb_step, before cb_pop.  An event leaves as (the bits of
 // the node's threshold, t): best_event.d is the threshold's exponent minus one (lean_bd_from_thr), which the consumer
 // of the records works out -- emit.ev(thr_bits, t); the Collapse filler {d: D_EMPTY} as emit.filler(t).
@@ -1338,6 +1425,12 @@ ADDER_HD LeanFlagsT<L> lr_step(LrPxT<L> &p, uint32_t v, uint32_t pair, uint32_t 
     p.rho = L::lane(zero) ? 1u : grown;
     nz_old = L::not_(zero);
     return fl;
+}
+// k consecutive frames whose byte equals base_val, at once: no flush, no event (lr_step's three masks stay clear), the
+// root goes on accumulating -- or stays the one-frame black root.  (nz_old and last_fired_t / T do not move either.)
+template <class L>
+ADDER_HD void lr_quiet_run(LrPxT<L> &p, uint32_t k) {
+    p.rho = p.base != 0u ? p.rho + k : 1u;
 }
 // AbsoluteT (time_spanned == ref_time >= 255: the run records' condition and argument): lq = last_fired_t / T rides along
 // as an integer.  A's time stamp is (best delta_t + lq T); the filler B sets last_fired_t to the frame's running_t (:257),

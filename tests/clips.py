@@ -52,3 +52,27 @@ def make_clip(kind, frames, H, W, C, seed):
             out[k] = np.clip(img, 0, 255).astype(np.uint8)
         return out
     raise ValueError(kind)
+
+
+def quiet_group_clip(frames, H, W, rng, jitter, C=1):
+    """Content for the quiet-GROUP paths of the blocked kernels (16 frames of a quiet unit decided at once): static rows
+    of every kind -- black, dark (tiny sums: several firings per group), mid, bright -- with jitter inside the contrast
+    band, and ONE disturbance per 64-frame block that walks through every position of a 16-frame group.
+    Returns (clip [frames][H][W][C] u8, the frames at which a row changes)."""
+    base = rng.integers(0, 256, (1, H, W, C))
+    base[0, 0] = 0
+    base[0, 1, : W // 2] = 1
+    base[0, 1, W // 2:] = 3
+    base[0, 2] = rng.integers(2, 9, (W, C))
+    clip = np.repeat(base, frames, axis=0).astype(np.int64)
+    if jitter:
+        clip[:, 3:] += rng.integers(-jitter, jitter + 1, (frames, H - 3, W, C))
+        clip[:, 1] += rng.integers(0, 2, (frames, W, C))          # 0 / 1 flicker on near-black pixels: black roots that wake up
+    clip = np.clip(clip, 0, 255)
+    breaks = []
+    for blk in range(frames // 64):
+        pos = 64 * blk + 16 * (blk % 4) + (blk * 5 + 3) % 16      # every position of a group over 16 blocks
+        row = 3 + blk % (H - 3)
+        clip[pos:, row] = 255 - clip[pos:, row]                   # a flush: the row restarts (and pops again later)
+        breaks.append(pos)
+    return clip.astype(np.uint8), breaks

@@ -46,6 +46,8 @@ struct Sim {
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
     uint64_t fast_steps, generic_steps, lean_steps, cb_steps, cb_quiet_steps, lean_quiet_steps;
     int cb_quiet_path;  // take the device's quiet-wave reduction wherever a unit qualifies (default on)
+    int quiet_group_path;  // ... and its group form (quiet_group_apply / lr_quiet_run: 16 frames decided at once) where a launch allows
+    uint64_t quiet_groups, quiet_group_fires, quiet_group_slow;  // groups applied in closed form / of those with a firing / stepped by the unit
     int use_cb;          // Collapse with delta_t_max > time: the bounded step (cb_step) instead of the generic one
     int frac_time_seen;  // a non-integer time_spanned has been integrated since the last reset (cb needs exact sums)
     // feature-driven rate control (the kernel-side flow of adder_feature_kernel, serially)
@@ -143,6 +145,8 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->continuous = 0;
     s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = s->cb_quiet_steps = s->lean_quiet_steps = 0;
     s->cb_quiet_path = 1;
+    s->quiet_group_path = 1;
+    s->quiet_groups = s->quiet_group_fires = s->quiet_group_slow = 0;
     s->use_cb = 1;
     s->frac_time_seen = 0;
     s->feat_detect = s->feat_adjust = s->roi_on = s->perpx = 0;
@@ -199,6 +203,10 @@ uint64_t sim_cb_steps(const Sim *s) { return s->cb_steps; }
 uint64_t sim_cb_quiet_steps(const Sim *s) { return s->cb_quiet_steps; }
 uint64_t sim_lean_quiet_steps(const Sim *s) { return s->lean_quiet_steps; }
 void sim_set_cb_quiet_path(Sim *s, int on) { s->cb_quiet_path = on; }
+void sim_set_quiet_group_path(Sim *s, int on) { s->quiet_group_path = on; }
+uint64_t sim_quiet_groups(const Sim *s) { return s->quiet_groups; }
+uint64_t sim_quiet_group_fires(const Sim *s) { return s->quiet_group_fires; }
+uint64_t sim_quiet_group_slow(const Sim *s) { return s->quiet_group_slow; }
 void sim_set_use_cb(Sim *s, int on) { s->use_cb = on; }
 
 // integrate_for_px(px, &mut 0, frame_val, intensity, time) per step, in order (the flow of adder_sparse_run_kernel,
@@ -336,6 +344,30 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                     } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
                     CbPlan plan;
                     const uint32_t vq = frames[(size_t)i * s->N + u];
+                    if (s->cb_quiet_path && s->quiet_group_path && (i % kQuietGroup) == 0u && p.m == 1u && (p.popped || p.thr0 == 0.0f)) {
+                        // the device's group form (adder_cb_kernel at the start of an input group): the whole group at once
+                        const uint32_t n = nb - i < kQuietGroup ? nb - i : kQuietGroup;
+                        uint32_t cth_min = 255u;
+                        for (uint32_t k = 0; k < n; ++k) cth_min = cths[i + k] < cth_min ? cths[i + k] : cth_min;
+                        const QuietGroupStats g = quiet_group_stats(frames + (size_t)i * s->N + u, s->N, n, quiet_group_need(p.S, p.thr0));
+                        CbPx t = p;
+                        const float thr_was = p.thr0;
+                        const uint32_t r = cb_group_apply(t, g, n, cth_min, T);
+                        if (r != kQuietNo) {
+                            if (r == kQuietDone) {
+                                p = t;
+                                s->quiet_groups++;
+                                if (p.thr0 != thr_was) s->quiet_group_fires++;
+                            } else {
+                                for (uint32_t k = 0; k < n; ++k) cb_step_quiet<ScalarLanes, true>(p, frames[(size_t)(i + k) * s->N + u], T);
+                                s->quiet_group_slow++;
+                            }
+                            s->cb_quiet_steps += n;
+                            s->cb_steps += n;
+                            i += n - 1u;
+                            continue;
+                        }
+                    }
                     if (s->cb_quiet_path && cb_quiet(p, vq, sc.cth)) {
                         // the device's fast path (a wave all of whose units are quiet): must equal the step, no events
                         if (cb_quiet_fires(p, vq) || (s->cb_steps & 1u)) cb_step_quiet<ScalarLanes, true>(p, vq, T);
@@ -575,6 +607,19 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 for (uint32_t i = 0; i < nb; ++i) {
                     uint32_t w0, w8, w1 = 0u;
                     const uint32_t vin = frames[(size_t)i * s->N + u];
+                    if (s->quiet_group_path && (i % kQuietGroup) == 0u) {
+                        // the device's group form (adder_lr_kernel at the start of an input group): every byte of the group
+                        // equals base_val -- no flush, no event, the run grows by the group
+                        const uint32_t n = nb - i < kQuietGroup ? nb - i : kQuietGroup;
+                        bool same = true;
+                        for (uint32_t k = 0; k < n; ++k) same = same && frames[(size_t)(i + k) * s->N + u] == p.base;
+                        if (same) {
+                            lr_quiet_run(p, n);
+                            s->quiet_groups++;
+                            i += n - 1u;
+                            continue;
+                        }
+                    }
                     const LeanFlagsT<ScalarLanes> fl = lr_step<ScalarLanes>(p, vin, (p.base << kLrBaseShift) | (vin << kLrInShift), (uint32_t)(u & 127u), nz_old, w0, w8);
                     if (s->abs_t) lr_step_lq<ScalarLanes>(lq, fl, frame0 + i, w1);
                     if (fl.b && !fl.a) rc = -9;

@@ -60,6 +60,10 @@ def lib():
     L.sim_cb_quiet_steps.restype = C.c_uint64
     L.sim_cb_quiet_steps.argtypes = [vp]
     L.sim_set_cb_quiet_path.argtypes = [vp, C.c_int]
+    L.sim_set_quiet_group_path.argtypes = [vp, C.c_int]
+    for f in (L.sim_quiet_groups, L.sim_quiet_group_fires, L.sim_quiet_group_slow):
+        f.restype = C.c_uint64
+        f.argtypes = [vp]
     L.sim_lean_quiet_steps.restype = C.c_uint64
     L.sim_lean_quiet_steps.argtypes = [vp]
     L.sim_set_use_cb.argtypes = [vp, i32]
@@ -199,6 +203,14 @@ class Sim:
 
     def set_cb_quiet_path(self, on):
         self.L.sim_set_cb_quiet_path(self.h, int(on))
+
+    def set_quiet_group_path(self, on):
+        self.L.sim_set_quiet_group_path(self.h, int(on))
+
+    @property
+    def quiet_groups(self):
+        """(groups applied in closed form, of those with a firing inside, groups a unit stepped itself)"""
+        return (self.L.sim_quiet_groups(self.h), self.L.sim_quiet_group_fires(self.h), self.L.sim_quiet_group_slow(self.h))
 
     def integrate_cb_block(self, frames, time_spanned):
         """nb frames as ONE temporally blocked launch of the bounded Collapse step; (rc, events frame-major)."""

@@ -753,3 +753,90 @@ def test_lr_every_intensity_and_run_length_rgb_and_tick_rates():
     assert sv.integrate_lr_block(clip[:2], 20.0)[0] == -7
     sv = Sim(6, 5, 3, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255)
     assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
+
+
+# ---- quiet GROUPS: 16 frames of a quiet unit decided at once (quiet_group_apply / lr_quiet_run) ----
+_quiet_group_clip = clips.quiet_group_clip
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_cb_quiet_groups_break_at_every_position_with_ramp_and_firings(time_mode):
+    """The group form of the bounded Collapse kernel's quiet path: quiet broken at every position of a 16-frame group, the
+    c_thresh ramp stepping inside groups (crf 3: 2 -> 7 over the first 35 frames after each reset of the thresholds),
+    roots firing inside groups (every power of two), dark pixels that fire twice in a group and black roots that wake up
+    (both stepped by the unit), launches of every length -- bit-exact against the oracle with the group form on and off."""
+    frames, H, W = 1088, 10, 8
+    rng = np.random.default_rng(23 + time_mode)
+    clip, breaks = _quiet_group_clip(frames, H, W, rng, jitter=1)
+    assert sorted({b % 16 for b in breaks}) == list(range(16))
+    for crf, groups_on, lens in ((3, True, [64]), (3, True, [1, 5, 16, 30, 47, 64]), (3, False, [64]), (6, True, [64, 33]), (9, True, [64])):
+        ov, sv = _cb_pair(W, H, 1, time_mode, 7650, crf=CRFS[crf])
+        sv.set_quiet_group_path(groups_on)
+        k = 0
+        while k < frames:
+            nb = min(int(rng.choice(lens)), frames - k)
+            if k and k % 320 == 0:   # update_crf mid-stream: every pixel's c_thresh back to the baseline, the ramp starts again
+                for v in (ov, sv):
+                    v.reset_c_thresh(CRFS[crf][0])
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (crf, groups_on, k, nb)
+            k += nb
+        assert sv.plan_mismatches == 0
+        done, fires, slow = sv.quiet_groups
+        if groups_on:
+            assert done > 0.4 * frames * H * W / 16 and fires > 50 and slow > 0, (crf, done, fires, slow)
+        else:
+            assert done == fires == slow == 0
+
+
+def test_quiet_group_statistics_and_closed_form_against_the_stepped_root():
+    """quiet_group_apply against cb_step_quiet frame by frame on random roots and random groups (through the sim's cb block
+    on a popped plane this is implied; here the corner cases are forced: thresholds about to be reached in the first and the
+    last frame of a group, sums one short of the threshold, groups of fewer than 16 frames)."""
+    rng = np.random.default_rng(77)
+    H, W = 4, 64
+    for trial in range(6):
+        frames = 30 + 16 * 6 + int(rng.integers(0, 16))
+        base = rng.integers(1, 256, (1, H, W, 1))
+        clip = np.repeat(base, frames, axis=0).astype(np.int64)
+        clip[31:] += rng.integers(-2, 3, (frames - 31, H, W, 1))
+        clip = np.clip(clip, 1, 255).astype(np.uint8)
+        ov, sv = _cb_pair(W, H, 1, O.DELTA_T, 7650, crf=CRFS[3])
+        want = np.concatenate([ov.integrate_matrix(f) for f in clip[:32]])
+        rc, got = sv.integrate_cb_block(clip[:32], 255.0)   # frame 30 pops every root; frame 31 is quiet
+        assert rc == 0 and np.array_equal(want, got)
+        k = 32
+        while k < frames:
+            nb = min(16 * int(rng.integers(1, 4)) - int(rng.integers(0, 2)) * int(rng.integers(0, 15)), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_cb_block(clip[k:k + nb], 255.0)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (trial, k, nb)
+            k += nb
+        # what the quiet frames left behind shows in the next flush: every root's best event
+        flush = ((clip[-1].astype(np.int64) + 128) % 256).astype(np.uint8)   # 128 away from every base_val
+        want = ov.integrate_matrix(flush)
+        rc, got = sv.integrate_cb_block(flush[None], 255.0)
+        assert rc == 0 and len(want) == 2 * H * W and np.array_equal(want, got), trial
+        assert sv.quiet_groups[0] > 0 and sv.quiet_groups[1] > 0
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_lr_quiet_groups_break_at_every_position(time_mode):
+    """The lean-runs kernel's group form (every byte of a 16-frame group equals base_val: rho += 16, or the black root stays
+    one frame old): static content with a change at every position of a group, launches of every length, both time modes."""
+    frames, H, W = 1088, 10, 8
+    rng = np.random.default_rng(41 + time_mode)
+    clip, breaks = _quiet_group_clip(frames, H, W, rng, jitter=0)
+    assert sorted({b % 16 for b in breaks}) == list(range(16))
+    for groups_on, lens in ((True, [64]), (True, [1, 2, 16, 31, 60, 64]), (False, [64])):
+        ov, sv = _lean_pair(W, H, 1, time_mode=time_mode)
+        sv.set_quiet_group_path(groups_on)
+        k = 0
+        while k < frames:
+            nb = min(int(rng.choice(lens)), frames - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+            rc, got = sv.integrate_lr_block(clip[k:k + nb], 255.0)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (groups_on, k, nb)
+            k += nb
+        assert (sv.quiet_groups[0] > 0.8 * frames * H * W / 16) == groups_on
