@@ -220,6 +220,8 @@ class HipVideo:
     def frame_collect(self, want_chunks=False, copy=True):
         ev, n, ch = C.c_void_p(), C.c_size_t(0), C.c_void_p()
         rc = self.L.adder_hip_frame_collect(self.h, C.byref(ev), C.byref(n), C.byref(ch))
+        if rc == N.E_BAD_PARAMS:  # nothing in flight, or the slot holds the other format: nothing was consumed
+            N.check(self.h, rc)
         if getattr(self, "_inflight", None):
             self._inflight.pop(0)
         self.last_required = n.value
@@ -239,6 +241,8 @@ class HipVideo:
         """-> (wire bytes of the oldest frame in flight, its number of events[, chunk offsets in events])."""
         by, nb, n, ch = C.c_void_p(), C.c_size_t(0), C.c_size_t(0), C.c_void_p()
         rc = self.L.adder_hip_frame_collect_wire(self.h, C.byref(by), C.byref(nb), C.byref(n), C.byref(ch))
+        if rc == N.E_BAD_PARAMS:
+            N.check(self.h, rc)
         if getattr(self, "_inflight", None):
             self._inflight.pop(0)
         self.last_required = n.value

@@ -233,6 +233,7 @@ struct AdderHipCtx {
         uint32_t *d_counters = nullptr; // feature path: this frame's counters (the shared ones are reset per enqueue)
         AdderEvent *out = nullptr;      // where the events were sent (h_events, or the caller's pinned buffer)
         size_t out_cap = 0;
+        bool wire = false;              // the slot holds 9 / 11-byte wire records (the ring's format when it was submitted)
     } fslot[4];
     uint32_t f_slots = 3;
     bool f_wire = false;             // the ring hands out 9 / 11-byte wire records instead of AdderEvents (adder_hip_frames_set_format)
@@ -964,8 +965,9 @@ static int status_to_code(AdderHipCtx *c, uint32_t st) {
 // segment can emit over the chunk (log_capacity: 2 or 3 events per unit and frame + one arena), instead of a slot per
 // frame that would have to hold a whole arena per unit -- 18 instead of 144 bytes per unit and frame at 64 frames.
 // Chunk = frames per scan launch: as many as the budget allows (ring_chunks chunks are in flight), at most kMaxChunk.
-// The budget is a quarter of what the device has free, at most 64 GiB (a 1080p plane takes 3 - 5 GiB at 64-frame
-// chunks, a 4K RGB one -- 12 times the units -- would fall to 5-frame chunks under 16 GiB).
+// The budget is a third of what the device has free, at most 96 GiB (a 1080p plane takes 3 - 5 GiB at 64-frame
+// chunks; a 4K RGB one -- 12 times the units -- needs 88 GiB for 64-frame chunks of per-event logs and fell to 48-frame
+// chunks under round 4's 64 GiB: a 64-frame batch then paid the state's round trip twice).
 static size_t scratch_bytes_per_chunk(const AdderHipCtx *c, AdderHipCtx::ScratchKind kind, uint32_t chunk) {
     switch (kind) {
         case AdderHipCtx::kScratchLean: return (size_t)c->num_waves * chunk * kLeanParkBytes;
@@ -996,7 +998,7 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
         if (p) HIPCHK(c, hipFree(p));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::min<size_t>((size_t)64 << 30, free_b / 4);
+    const size_t budget = std::min<size_t>((size_t)96 << 30, free_b / 3);
     c->ring_chunks = 3;  // a chunk being stepped, one being scanned / expanded, one of slack between the two streams
     if (const char *e = getenv("ADDER_HIP_RING_CHUNKS")) c->ring_chunks = std::max(2, std::min(atoi(e), 4));
     // default: groups of 16 segments -- the 16 segments an expansion wave reads of one frame are contiguous; contexts
@@ -1017,7 +1019,8 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
     HIPCHK(c, dalloc(&c->park_ring, (size_t)c->ring_chunks * scratch_bytes_per_chunk(c, kind, c->chunk)));
     HIPCHK(c, dalloc(&c->wtot_ring, (size_t)c->slots * c->num_waves));
     HIPCHK(c, dalloc(&c->wpref_ring, (size_t)c->slots * c->num_waves));
-    HIPCHK(c, dalloc(&c->ftot_ring, 2 * (size_t)c->slots));  // events, then parked records per frame
+    // events, then parked records per frame, then the scan's tile sums [slot][tile][2] (planes scanned in tiles)
+    HIPCHK(c, dalloc(&c->ftot_ring, 2 * (size_t)c->slots + (size_t)c->slots * ((c->num_waves + kScanTileWaves - 1) / kScanTileWaves) * 2));
     if (kind != AdderHipCtx::kScratchCont) {  // (the lean records of blocked batches go to logs too: lean_log_cap)
         HIPCHK(c, dalloc(&c->wofs_ring, (size_t)c->slots * c->num_waves));
         HIPCHK(c, dalloc(&c->wcur, (size_t)c->ring_chunks * c->num_waves));
@@ -1097,7 +1100,7 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
     const bool band = band_features(c);  // the feature step waits for the halo exchange: adder_hip_feature_detect
     for (uint32_t f = 0; f < num_frames; ++f) {
         HIPCHK(c, adder_launch_frame(c->d_batch, f, 1u, variant, c->num_waves, 0u, s, &wide));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, s));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f, 1u, c->num_waves, s));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f, 1u, s));
         HIPCHK(c, adder_launch_expand(c->d_batch, f, 1u, c->num_waves, variant, 0u, s));
         if (!band) HIPCHK(c, adder_launch_features(c->d_batch, f, &fa, s));
@@ -1166,7 +1169,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             t = s2;
         }
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, t, num_frames == 1u ? 1u : 0u));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u));
         if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
         if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
         if (timing) {
@@ -1204,7 +1207,7 @@ static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t
         HIPCHK(c, hipEventRecord(c->split_el[k % 5u], ls));
         if (ps != ls) HIPCHK(c, hipStreamWaitEvent(ps, c->split_el[k % 5u], 0));
         if (k && ps != prev_p) HIPCHK(c, hipStreamWaitEvent(ps, c->cap_e2[(k - 1u) % 5u], 0));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, ps));
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, ps));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, ps));
         HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps));
         HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], ps));
@@ -2437,10 +2440,12 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
     const bool wire = c->f_wire && !direct_out;
+    fs.wire = wire;
     if (wire && !wire_direct)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
         HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
                                             c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
-                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), c->out_s));
+                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), c->out_s,
+                                            (uint64_t)need));  // (a frame that overflowed its slot: only what the expansion kept is read)
     HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(wire_direct ? fs.out : fs.d_events), fs.d_offsets, fs.out_cap,
                                      wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
                                      reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
@@ -2488,6 +2493,9 @@ extern "C" int adder_hip_frame_submit(AdderHipCtx *c, const uint8_t *frame, size
 extern "C" int adder_hip_frame_collect(AdderHipCtx *c, const AdderEvent **events, size_t *n_events,
                                        const uint32_t **chunk_offsets) {
     if (!c) return ADDER_E_BAD_PARAMS;
+    // (the slot's own format, as it was submitted: reading packed 9 / 11-byte records as 12-byte events would run past them)
+    if (c->f_collected != c->f_submitted && c->fslot[c->f_collected % c->f_slots].wire)
+        return fail(c, ADDER_E_BAD_PARAMS, "the oldest frame in flight holds wire records: adder_hip_frame_collect_wire");
     return frame_collect_impl(c, events, n_events, chunk_offsets);
 }
 
@@ -2501,6 +2509,8 @@ extern "C" int adder_hip_frame_collect_wire(AdderHipCtx *c, const uint8_t **byte
                                             const uint32_t **chunk_offsets) {
     if (!c) return ADDER_E_BAD_PARAMS;
     if (!c->f_wire) return fail(c, ADDER_E_BAD_PARAMS, "the ring hands out AdderEvents (adder_hip_frames_set_format)");
+    if (c->f_collected != c->f_submitted && !c->fslot[c->f_collected % c->f_slots].wire)
+        return fail(c, ADDER_E_BAD_PARAMS, "the oldest frame in flight holds AdderEvents: adder_hip_frame_collect");
     const AdderEvent *ev = nullptr;
     size_t n = 0;
     int rc = frame_collect_impl(c, &ev, &n, chunk_offsets);

@@ -22,6 +22,9 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef ADDER_SCAN_THREADS
 #define ADDER_SCAN_THREADS 512
 #endif
+#ifndef ADDER_SCAN_TILE_WAVES
+#define ADDER_SCAN_TILE_WAVES 16384  // segments one scan workgroup takes (8 uint4 groups per thread: from registers)
+#endif
 #ifndef ADDER_LEAN_WAVES_PER_SIMD
 #define ADDER_LEAN_WAVES_PER_SIMD 8
 #endif
@@ -123,6 +126,7 @@ struct ParkLayout {
     uint32_t rot_shift, rot_mask;
 };
 
+constexpr uint32_t kScanTileWaves = ADDER_SCAN_TILE_WAVES;  // (a multiple of 4)
 // What adder_lean1w_kernel takes as kernel arguments (by value): the level-0 planes and the band's size.
 struct Lean1wArgs {
     uint32_t *hdr;
@@ -285,7 +289,7 @@ hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
-hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream, uint32_t whole_batch = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame offsets too
+hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame offsets too
 size_t adder_sparse_temp_bytes(uint32_t n);
 hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseStep *d_steps, uint32_t n, uint32_t *keys0,
                             uint32_t *keys1, uint32_t *idx0, uint32_t *idx1, void *d_temp, size_t temp_bytes, uint2 *stage,
@@ -306,7 +310,7 @@ hipError_t adder_launch_sink_layout(const uint64_t *all_offs, uint32_t world, ui
                                     uint64_t *dest, uint64_t *merged_offs, hipStream_t stream);
 hipError_t adder_launch_wire_scatter(const adder::AdderEventPod *ev, const uint64_t *offs, uint32_t nf, const uint64_t *dest,
                                      uint32_t rec, uint8_t *out, uint64_t out_cap, uint64_t header, uint32_t *status,
-                                     uint32_t grid, hipStream_t stream);
+                                     uint32_t grid, hipStream_t stream, uint64_t src_cap_events = ~0ull);  // src_cap_events: what `ev` holds
 hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
                                     uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

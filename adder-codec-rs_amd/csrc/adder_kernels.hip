@@ -2373,21 +2373,76 @@ __device__ __forceinline__ uint4 scan_prefix4(const uint4 &v, uint32_t &run) {
     run = o.w + (v.w & 0xffffu);
     return o;
 }
+// Planes of more than kScanTileWaves segments (4K and up) are scanned in TILES of that many, a workgroup each: one block
+// per frame walked 95 uncoalesced groups per thread on a 4K RGB plane (194 400 segments) and took 134 us per 48-frame chunk
+// with 48 workgroups on the chip.  adder_scan_tiles_kernel first leaves every tile's {events, records}; the scan proper
+// then adds up the tiles in front of its own (<= a few dozen words) and scans its tile from registers.  The tile sums live
+// behind the two halves of ftot_ring: [slot][tile][2].
+__device__ __forceinline__ uint32_t scan_tiles_of(uint32_t num_waves) { return (num_waves + kScanTileWaves - 1u) / kScanTileWaves; }
+__global__ __launch_bounds__(kScanThreads) void adder_scan_tiles_kernel(const BatchArgs *__restrict__ b, uint32_t f0) {
+    const uint32_t ntiles = scan_tiles_of(b->base.num_waves);
+    const uint32_t fr = blockIdx.x / ntiles, tile = blockIdx.x - fr * ntiles;
+    const FrameArgs a = frame_args(b, f0 + fr);
+    __shared__ uint32_t s_ev[kScanThreads / kWave], s_rc[kScanThreads / kWave];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    const uint32_t groups = a.num_waves / 4u, tg = kScanTileWaves / 4u;
+    const uint32_t t0 = tile * tg, t1 = min(t0 + tg, groups);
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.wtot);
+    uint32_t ev = 0u, rc = 0u;
+    for (uint32_t g = t0 + tid; g < t1; g += kScanThreads) {  // (only sums: coalesced)
+        const uint4 w = src[g];
+        ev += scan_lo4(w);
+        rc += scan_hi4(w);
+    }
+#pragma unroll
+    for (uint32_t o = kWave / 2; o > 0; o >>= 1) {
+        ev += __shfl_down(ev, o, kWave);
+        rc += __shfl_down(rc, o, kWave);
+    }
+    if (lane == 0) {
+        s_ev[wid] = ev;
+        s_rc[wid] = rc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t e = 0u, r = 0u;
+        for (uint32_t w = 0; w < kScanThreads / kWave; ++w) {
+            e += s_ev[w];
+            r += s_rc[w];
+        }
+        uint32_t *const ts = b->ftot_ring + 2u * b->slots + (((f0 + fr) % b->slots) * ntiles + tile) * 2u;
+        ts[0] = e;
+        ts[1] = r;
+    }
+}
 __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t whole_batch) {
-    const FrameArgs a = frame_args(b, f0 + blockIdx.x);
+    const uint32_t ntiles = scan_tiles_of(b->base.num_waves);  // (1 for every plane up to 2 M units: the whole frame in one block)
+    const uint32_t fr = ntiles == 1u ? blockIdx.x : blockIdx.x / ntiles, tile = blockIdx.x - fr * ntiles;
+    const FrameArgs a = frame_args(b, f0 + fr);
     timeline_mark(b, 1u, f0, false);
     __shared__ uint32_t s_part[kScanThreads / kWave];
     __shared__ uint32_t s_recs[kScanThreads / kWave];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wid = tid / kWave;
-    // num_waves is a multiple of 4: each thread owns `per` consecutive uint4 groups
+    // num_waves is a multiple of 4: each thread owns `per` consecutive uint4 groups of the block's tile
     const uint32_t groups = a.num_waves / 4u;
-    const uint32_t per = (groups + kScanThreads - 1) / kScanThreads;
-    const uint32_t g0 = tid * per;
-    const uint32_t g1 = min(g0 + per, groups);
+    const uint32_t t0 = tile * (kScanTileWaves / 4u), t1 = min(t0 + kScanTileWaves / 4u, groups);
+    const uint32_t per = (t1 - t0 + kScanThreads - 1) / kScanThreads;
+    const uint32_t g0 = t0 + tid * per;
+    const uint32_t g1 = min(g0 + per, t1);
     const uint4 *src = reinterpret_cast<const uint4 *>(a.wtot);
     uint4 *dst = reinterpret_cast<uint4 *>(a.wpref);
+    // the tiles in front of this one (their sums are there: adder_scan_tiles_kernel ran first) and, for the block of the
+    // last tile, the frame's records
+    uint32_t tile_base = 0u, tile_recs = 0u;
+    if (ntiles > 1u) {
+        const uint32_t *const ts = b->ftot_ring + 2u * b->slots + ((f0 + fr) % b->slots) * ntiles * 2u;
+        for (uint32_t t = 0; t < ntiles; ++t) {  // (uniform: scalar loads)
+            if (t < tile) tile_base += ts[2u * t];
+            if (t != tile) tile_recs += ts[2u * t + 1u];
+        }
+    }
     const bool in_regs = per <= kScanRegGroups;  // uniform
     uint4 v[kScanRegGroups];
     uint32_t sum = 0, recs = 0;
@@ -2413,7 +2468,7 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     const uint32_t incl = wave_inclusive_scan(sum, lane);
     if (lane == kWave - 1) s_part[wid] = incl;
     __syncthreads();
-    uint32_t base = 0, total = 0, rec_total = 0;
+    uint32_t base = tile_base, total = tile_base, rec_total = tile_recs;
 #pragma unroll
     for (uint32_t w = 0; w < kScanThreads / kWave; ++w) {
         const uint32_t t = s_part[w];
@@ -2431,7 +2486,7 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     } else {
         for (uint32_t g = g0; g < g1; ++g) dst[g] = scan_prefix4(src[g], run);
     }
-    if (tid == 0) {
+    if (tid == 0 && tile + 1u == ntiles) {  // (the last tile's block knows the frame's totals)
         *a.ftot = total;
         a.ftot[b->slots] = rec_total;  // second half of the ring: records per frame
         if (whole_batch) {  // a batch of ONE frame (the per-frame calls and the ring): the offsets kernel's work, a launch less
@@ -3252,7 +3307,7 @@ __global__ void adder_sink_layout_kernel(const uint64_t *__restrict__ all_offs, 
 __global__ __launch_bounds__(256) void adder_wire_scatter_kernel(const uint32_t *__restrict__ ev, const uint64_t *__restrict__ offs,
                                                                  uint32_t nf, const uint64_t *__restrict__ dest, uint32_t rec,
                                                                  uint8_t *__restrict__ out, uint64_t out_cap, uint64_t header,
-                                                                 uint32_t *status) {
+                                                                 uint32_t *status, uint64_t src_cap) {
     __shared__ uint32_t s_w[kWireEvents * 3];
     const uint32_t tid = threadIdx.x;
     const uint32_t magic = rec == 9u ? 0x38e38e39u : 0xba2e8ba3u;  // floor(B / rec) = mulhi(B, magic) >> (1 | 3)
@@ -3260,7 +3315,14 @@ __global__ __launch_bounds__(256) void adder_wire_scatter_kernel(const uint32_t 
     bool bad = false, over = false;
     for (uint32_t f = 0; f < nf; ++f) {
         const uint64_t fb = offs[f];
-        const uint64_t fcnt = offs[f + 1] - fb;
+        uint64_t fcnt = offs[f + 1] - fb;
+        // (the offsets count what the frames PRODUCED; the buffer holds what fitted -- src_cap events: the rest was dropped
+        // by the expansion and must not be read)
+        const uint64_t held = fb < src_cap ? src_cap - fb : 0ull;
+        if (fcnt > held) {
+            fcnt = held;
+            over = true;
+        }
         const uint64_t nblocks = (fcnt + kWireEvents - 1) / kWireEvents;
         for (uint64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {  // uniform per workgroup
             const uint64_t e0 = blk * kWireEvents;
@@ -3739,15 +3801,17 @@ extern "C" hipError_t adder_launch_sink_layout(const uint64_t *all_offs, uint32_
 }
 extern "C" hipError_t adder_launch_wire_scatter(const AdderEventPod *ev, const uint64_t *offs, uint32_t nf, const uint64_t *dest,
                                                 uint32_t rec, uint8_t *out, uint64_t out_cap, uint64_t header, uint32_t *status,
-                                                uint32_t grid, hipStream_t stream) {
+                                                uint32_t grid, hipStream_t stream, uint64_t src_cap_events) {
     if (nf == 0) return hipSuccess;
     hipLaunchKernelGGL(adder_wire_scatter_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream,
-                       reinterpret_cast<const uint32_t *>(ev), offs, nf, dest, rec, out, out_cap, header, status);
+                       reinterpret_cast<const uint32_t *>(ev), offs, nf, dest, rec, out, out_cap, header, status, src_cap_events);
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream, uint32_t whole_batch) {
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u);
+extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch) {
+    const uint32_t ntiles = (num_waves + kScanTileWaves - 1u) / kScanTileWaves;  // (as the kernels work it out from the batch)
+    if (ntiles > 1u) hipLaunchKernelGGL(adder_scan_tiles_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0);
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -1245,6 +1245,39 @@ def test_frame_ring_rules_and_overflow():
     assert ei.value.code == A.E_POISONED
 
 
+def test_frame_ring_wire_format_overflow_and_format_guards():
+    """The ring in its wire format (9 / 11-byte records in the slots): a frame that overflows a small slot is reported at
+    collect with the size it needed -- the hand-over reads only what the expansion kept of it (round 4's kernel walked the
+    uncapped count past the slot's event buffer) -- and a slot is collected in the format it was submitted in."""
+    A = _hip()
+    for Cn in (1, 3):
+        clip = clips.make_clip("noise", 6, 40, 66, Cn, seed=2 + Cn)
+        ov = O.Video(66, 40, Cn, delta_t_max=255)
+        hv = A.HipVideo(66, 40, Cn, delta_t_max=255)
+        hv.frames_set_format(True)
+        hv.frames_configure(2, 0)
+        hv.frame_submit(clip[0])
+        hv.frame_submit(clip[1])
+        with pytest.raises(A.AdderHipError, match="wire records"):   # the slot's own format decides, nothing is consumed
+            hv.frame_collect()
+        assert hv.frames_in_flight() == 2
+        for k in range(2):
+            data, n = hv.frame_collect_wire()
+            want = ov.integrate_matrix(clip[k])
+            assert n == len(want) and data.tobytes() == O.raw_events(want, Cn)
+        hv.frames_configure(2, 64)   # 64 events per slot: every noise frame past the first overflows it
+        hv.frame_submit(clip[2])
+        need = len(ov.integrate_matrix(clip[2]))
+        assert need > 1000
+        with pytest.raises(A.AdderHipError) as ei:
+            hv.frame_collect_wire()
+        assert ei.value.code == A.E_OUT_CAPACITY and hv.last_required == need
+        with pytest.raises(A.AdderHipError) as ei:
+            hv.frame_submit(clip[3])
+        assert ei.value.code == A.E_POISONED
+        hv.close()
+
+
 @pytest.mark.gpu
 def test_graph_instances_are_interchangeable_and_the_plan_settles():
     """A batch length of several chunks tries up to six instances of its captured graph on the first batches and keeps

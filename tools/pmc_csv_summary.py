@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 --pmc passes written as csv (one *counter_collection.csv per pass).
 
-usage: pmc_csv_summary.py <dir holding pmc_*/ sub-directories> [--traffic out.json]
+usage: pmc_csv_summary.py <dir holding pmc_*/ sub-directories> [--traffic out.json] [--frames-per-launch N]
+
+--frames-per-launch: the frames every frame-kernel launch of the profiled command covered (run it with a frame count
+that is a multiple of the chunk, so that all launches are alike); written into the traffic JSON, bench.py scales by it.
 
 --traffic writes the HBM bytes per launch of the frame kernel (FETCH_SIZE and WRITE_SIZE are KiB on
 gfx950; FETCH_SIZE counts wide coalesced reads at 1/2 and is doubled, MI355X_MICROARCH.md HBM section)."""
@@ -40,6 +43,8 @@ def main():
                "correction": "FETCH_SIZE doubled (gfx950 counts wide coalesced reads at 1/2, MI355X_MICROARCH.md HBM "
                              "section); WRITE_SIZE as reported; both are KiB",
                "kernels": {}}
+        if "--frames-per-launch" in sys.argv:
+            res["frames_per_launch"] = float(sys.argv[sys.argv.index("--frames-per-launch") + 1])
         for (k, c) in sorted(acc):
             if c != "FETCH_SIZE":
                 continue
