@@ -170,6 +170,9 @@ SYMBOLS = {
     "adder_hip_band_segments": (_u32, [_vp]),
     "adder_hip_integrate_records_device": (C.c_int, [_vp, _vp, _u32, C.c_float, _vp, _vp, _vp]),
     "adder_hip_expand_records_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _u64, _vp, _vp]),
+    "adder_hip_expand_records_wire_device": (C.c_int, [_vp, _vp, _u32, _vp, C.c_size_t, _u64, _vp, _vp]),
+    "adder_hip_segment_units": (_u32, []),
+    "adder_hip_wire_record_bytes": (_u32, [_vp]),
     "adder_hip_expand_status": (C.c_int, [_vp, _vp]),
     "adder_hip_records_wire_bytes": (_sz, [_u32, _u32, _u32, _u64]),
     "adder_hip_records_wire_sections": (None, [_u32, _u32, _u32, _vp]),

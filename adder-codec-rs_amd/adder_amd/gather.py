@@ -31,6 +31,7 @@ SYMBOLS = {
     "adder_gather_local_group_destroy": (None, [_vp]),
     "adder_gather_create_local": (_i32, [_vp, _vp, _i32, C.POINTER(_vp)]),
     "adder_gather_records_begin": (_i32, [_vp, _i32, _vp, _sz, C.c_uint64, _vp, _vp]),
+    "adder_gather_records_begin_wire": (_i32, [_vp, _i32, _vp, _sz, C.c_uint64, _vp, _vp]),
     "adder_gather_records_push": (_i32, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "adder_gather_records_end": (_i32, [_vp, C.POINTER(_sz), C.POINTER(C.c_uint64)]),
     "adder_gather_records_host_us": (C.c_double, [_vp]),
@@ -192,6 +193,13 @@ class HipGather:
         cap = 0 if d_merged is None else d_merged.numel() * d_merged.element_size() // 12
         self._check(self.L.adder_gather_records_begin(
             self.h, root, None if d_merged is None else d_merged.data_ptr(), cap, int(merged_base),
+            None if d_merged_offsets is None else d_merged_offsets.data_ptr(), C.c_void_p(stream) if stream else None))
+
+    def records_begin_wire(self, root, d_wire, merged_base, d_merged_offsets, stream=None):
+        """As records_begin with the raw sink's 9 / 11-byte records as root's output (d_wire: uint8 CUDA tensor on root)."""
+        cap = 0 if d_wire is None else d_wire.numel() * d_wire.element_size()
+        self._check(self.L.adder_gather_records_begin_wire(
+            self.h, root, None if d_wire is None else d_wire.data_ptr(), cap, int(merged_base),
             None if d_merged_offsets is None else d_merged_offsets.data_ptr(), C.c_void_p(stream) if stream else None))
 
     def records_push(self, rec, n_records, n_events):

@@ -367,6 +367,14 @@ class HipVideo:
             self.h, C.byref(arr), len(bands), d_merged.data_ptr(), cap, int(merged_base), d_merged_offsets.data_ptr(),
             C.c_void_p(stream) if stream else None))
 
+    def expand_records_wire_device(self, bands, d_wire, merged_base, d_merged_offsets, stream=None):
+        """As expand_records_device with the raw sink's 9 / 11-byte records as the output (d_wire: uint8 CUDA tensor; event
+        k of the merged stream at byte k * record size; merged_base and the offsets count events)."""
+        arr = (N.AdderBandRecords * len(bands))(*bands)
+        N.check(self.h, self.L.adder_hip_expand_records_wire_device(
+            self.h, C.byref(arr), len(bands), d_wire.data_ptr(), d_wire.numel() * d_wire.element_size(), int(merged_base),
+            d_merged_offsets.data_ptr(), C.c_void_p(stream) if stream else None))
+
     def records_to_wire(self, rec, n_records, d_dst, stream=None):
         """One contiguous image of the batch `rec` describes (adder_hip_records_to_wire) into the uint8 CUDA tensor d_dst."""
         N.check(self.h, self.L.adder_hip_records_to_wire(self.h, C.byref(rec), int(n_records), d_dst.data_ptr(),

@@ -241,8 +241,10 @@ struct AdderGather {
     uint32_t rec_calls = 0;
     // streamed records gather (adder_gather_records_begin / _push / _end)
     struct RecordStream {
-        bool open = false, agreed = false, overflow = false;
+        bool open = false, agreed = false, overflow = false, wire = false, failed = false;
         int root = 0;
+        int agreed_root = -1;        // the root the receive buffers were agreed for (another root: the agreement runs again)
+        std::vector<size_t> worst;   // [world] every band's worst case of one chunk, as agreed (every rank holds the same)
         AdderEvent *d_merged = nullptr;
         size_t merged_cap = 0;
         uint64_t merged_base = 0, merged_pos = 0;
@@ -599,7 +601,7 @@ static int image_to_slot(AdderGather *g, const AdderBandRecords *rec, uint64_t n
 // the payload of the chunk in `slot` (sizes in `all`, [world][kMetaWords]): every peer -> root, one point-to-point transfer
 // each (its own xGMI link); on root the bands' descriptions over the images and the expansion behind merged_base
 static int transfer_and_expand(AdderGather *g, int slot, const uint64_t *all, int root, AdderEvent *d_merged, size_t merged_cap,
-                               uint64_t merged_base, uint64_t *d_merged_offsets, hipStream_t s) {
+                               uint64_t merged_base, uint64_t *d_merged_offsets, hipStream_t s, bool wire = false) {
     GTR(g, g->tr.group_start(g->tr.self));
     if (g->rank == root) {
         for (int r = 0; r < g->world; ++r)
@@ -634,8 +636,12 @@ static int transfer_and_expand(AdderGather *g, int slot, const uint64_t *all, in
         b.d_runs = reinterpret_cast<const uint32_t *>(img + sec[4]);
         b.d_records = img + sec[5];
     }
-    int rc = adder_hip_expand_records_device(g->ctx, bands.data(), (uint32_t)g->world, d_merged, merged_cap, merged_base,
-                                             d_merged_offsets, s);
+    // (wire: merged_cap counts events of the byte buffer behind d_merged)
+    const size_t wrec = wire ? adder_hip_wire_record_bytes(g->ctx) : 0;
+    int rc = wire ? adder_hip_expand_records_wire_device(g->ctx, bands.data(), (uint32_t)g->world, reinterpret_cast<uint8_t *>(d_merged),
+                                                         merged_cap * wrec, merged_base, d_merged_offsets, s)
+                  : adder_hip_expand_records_device(g->ctx, bands.data(), (uint32_t)g->world, d_merged, merged_cap, merged_base,
+                                                    d_merged_offsets, s);
     if (rc != ADDER_OK) return gfail(g, rc, "expansion: %s", adder_hip_last_error(g->ctx));
     GHIP(g, hipEventRecord(g->rec_ev[slot], s));
     return ADDER_OK;
@@ -719,9 +725,14 @@ extern "C" int adder_gather_records_begin(AdderGather *g, int root, AdderEvent *
         return gfail(g, ADDER_E_BAD_PARAMS, "root needs the merged buffers");
     { int rc_ = ensure_meta(g); if (rc_ != ADDER_OK) return rc_; }
     AdderGather::RecordStream &rs = g->rs;
-    const bool agreed = rs.agreed;
+    // the receive buffers were sized and agreed on for ONE root: a clip with another root agrees again (every rank sees
+    // the same root argument, so every rank re-runs the blocking round in its first push)
+    const bool agreed = rs.agreed && rs.agreed_root == root;
+    std::vector<size_t> worst = std::move(rs.worst);
     rs = AdderGather::RecordStream{};
     rs.agreed = agreed;
+    rs.agreed_root = agreed ? root : -1;
+    if (agreed) rs.worst = std::move(worst);
     rs.open = true;
     rs.root = root;
     rs.d_merged = d_merged;
@@ -730,6 +741,14 @@ extern "C" int adder_gather_records_begin(AdderGather *g, int root, AdderEvent *
     rs.d_merged_offsets = d_merged_offsets;
     rs.s = (hipStream_t)stream;
     return ADDER_OK;
+}
+extern "C" int adder_gather_records_begin_wire(AdderGather *g, int root, uint8_t *d_wire, size_t wire_cap_bytes, uint64_t merged_base,
+                                               uint64_t *d_merged_offsets, void *stream) {
+    if (!g) return ADDER_E_BAD_PARAMS;
+    const size_t wrec = adder_hip_wire_record_bytes(g->ctx);
+    int rc = adder_gather_records_begin(g, root, reinterpret_cast<AdderEvent *>(d_wire), wire_cap_bytes / wrec, merged_base, d_merged_offsets, stream);
+    if (rc == ADDER_OK) g->rs.wire = true;
+    return rc;
 }
 
 // the chunk in `slot`: its sizes have been gathered -- check them, post its payload, expand (root)
@@ -746,16 +765,18 @@ static int records_complete(AdderGather *g, int slot) {
         total += row[6];
     }
     const uint32_t nf = (uint32_t)all[0];
+    // (every rank holds the agreed worst cases and reads the same rows: a chunk that outgrows them is refused by ALL of
+    // them before anything is posted -- a check on root alone would leave the peers in their sends)
+    for (int r = 0; r < g->world; ++r)
+        if (r != rs.root && (size_t)r < rs.worst.size() && row_wire_bytes(all + (size_t)r * kMetaWords) > rs.worst[r])
+            return gfail(g, ADDER_E_BAD_PARAMS, "rank %d's chunk exceeds the worst case its first chunk announced", r);
     if (g->rank == rs.root) {
-        for (int r = 0; r < g->world; ++r)
-            if (r != g->rank && row_wire_bytes(all + (size_t)r * kMetaWords) > g->peer_img_cap[slot][r])
-                return gfail(g, ADDER_E_BAD_PARAMS, "rank %d's chunk exceeds the worst case its first chunk announced", r);
         if (rs.merged_pos > rs.merged_cap || total > rs.merged_cap - rs.merged_pos) rs.overflow = true;  // (the kernels clamp)
     } else {
         rs.sent_bytes += row_wire_bytes(all + (size_t)g->rank * kMetaWords);
     }
     int rc = transfer_and_expand(g, slot, all, rs.root, rs.d_merged, rs.merged_cap, rs.merged_pos,
-                                 rs.d_merged_offsets ? rs.d_merged_offsets + rs.frame_pos : nullptr, rs.s);
+                                 rs.d_merged_offsets ? rs.d_merged_offsets + rs.frame_pos : nullptr, rs.s, rs.wire);
     if (rc != ADDER_OK) return rc;
     rs.merged_pos += total;
     rs.frame_pos += nf;
@@ -766,15 +787,30 @@ extern "C" int adder_gather_records_push(AdderGather *g, const AdderBandRecords 
     if (!g || !rec) return gfail(g, ADDER_E_BAD_PARAMS, "null argument");
     AdderGather::RecordStream &rs = g->rs;
     if (!rs.open) return gfail(g, ADDER_E_BAD_PARAMS, "no streamed records gather is open (adder_gather_records_begin)");
+    // a clip that failed posts nothing more: every rank saw the same rows, so every rank stops at the same chunk
+    if (rs.failed) return gfail(g, ADDER_E_BAD_PARAMS, "the streamed gather failed at an earlier chunk (adder_gather_records_end, then begin again)");
     const auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = rs.s;
     const int slot = (int)(g->rec_calls++ % AdderGather::kRecSlots);
     const uint32_t nf = rec->num_frames, nseg = rec->num_segments, rb = rec->record_bytes;
     // the worst case of one chunk of this band: a record per unit and frame (adder_hip_chunk_frames() frames)
     const uint32_t nf_max = std::max<uint32_t>(adder_hip_chunk_frames(g->ctx), nf);
-    const size_t worst = adder_hip_records_wire_bytes(nf_max, nseg, rb, (uint64_t)nseg * 128u * nf_max);
+    const uint64_t seg_units = adder_hip_segment_units();
+    const size_t worst = adder_hip_records_wire_bytes(nf_max, nseg, rb, (uint64_t)nseg * seg_units * nf_max);
+    // (the image first: the caller's context is free for its next batch whatever happens below)
     int local_rc = image_to_slot(g, rec, n_records, slot, worst, s);
-    // ---- the chunk's sizes: gathered, copied to pinned memory, an event behind them; nobody waits here ----
+    // ---- the payload of the chunk before this one, BEFORE anything new is queued: its rows are checked by every rank
+    // alike, and a rank that meets a failed row (or a peer's failure flag) returns without having posted a collective the
+    // others would wait for -- the failing rank itself returned from the push that queued its last all-gather ----
+    if (rs.pending >= 0) {
+        int rc = records_complete(g, rs.pending);
+        rs.pending = -1;
+        if (rc != ADDER_OK) {
+            rs.failed = true;
+            return rc;
+        }
+    }
+    // ---- this chunk's sizes: gathered, copied to pinned memory, an event behind them; nobody waits here ----
     uint64_t *d_rows = meta_rows(g, g->d_meta, slot), *h_rows = meta_rows(g, g->h_meta, slot);
     uint64_t *mine = h_rows + (size_t)g->world * kMetaWords;
     const uint64_t vals[kMetaWords] = {nf, nseg, rb, n_records, rec->row_begin, rec->rows, n_events, local_rc != ADDER_OK ? 1ull : 0ull};
@@ -784,33 +820,34 @@ extern "C" int adder_gather_records_push(AdderGather *g, const AdderBandRecords 
     GHIP(g, hipMemcpyAsync(h_rows, d_rows, (size_t)g->world * sizeof vals, hipMemcpyDeviceToHost, s));
     GHIP(g, hipEventRecord(g->meta_ev[slot], s));
     if (!rs.agreed) {
-        // the first chunk this object sees: root sizes its receive buffers (all slots) for every peer's worst case, and
-        // the ranks agree that this worked -- the only blocking agreement of the object's life
+        // the first chunk this object sees (for this root): every rank works the bands' worst cases out of the same rows,
+        // root sizes its receive buffers (all slots) for them, and the ranks agree that this worked -- the only blocking
+        // agreement of the object's life
         GHIP(g, hipEventSynchronize(g->meta_ev[slot]));
-        int rc0 = ADDER_OK;
-        if (g->rank == rs.root) {
-            std::vector<size_t> need(g->world, 0);
-            for (int r = 0; r < g->world; ++r) {
-                const uint64_t *row = h_rows + (size_t)r * kMetaWords;
-                const uint32_t fm = std::max<uint32_t>(nf_max, (uint32_t)row[0]);
-                need[r] = adder_hip_records_wire_bytes(fm, (uint32_t)row[1], (uint32_t)row[2], row[1] * 128u * fm);
-            }
-            for (int k = 0; k < AdderGather::kRecSlots && rc0 == ADDER_OK; ++k) rc0 = ensure_peer_images(g, k, need);
+        rs.worst.assign(g->world, 0);
+        for (int r = 0; r < g->world; ++r) {
+            const uint64_t *row = h_rows + (size_t)r * kMetaWords;
+            const uint32_t fm = std::max<uint32_t>(nf_max, (uint32_t)row[0]);
+            rs.worst[r] = adder_hip_records_wire_bytes(fm, (uint32_t)row[1], (uint32_t)row[2], row[1] * seg_units * fm);
         }
+        int rc0 = ADDER_OK;
+        if (g->rank == rs.root)
+            for (int k = 0; k < AdderGather::kRecSlots && rc0 == ADDER_OK; ++k) rc0 = ensure_peer_images(g, k, rs.worst);
         int rc = agree(g, rc0, s);
-        if (rc != ADDER_OK) return rc;
+        if (rc != ADDER_OK) {
+            rs.failed = true;
+            return rc;
+        }
         rs.agreed = true;
-    }
-    // ---- the payload of the chunk before this one ----
-    if (rs.pending >= 0) {
-        int rc = records_complete(g, rs.pending);
-        rs.pending = -1;
-        if (rc != ADDER_OK) return rc;
+        rs.agreed_root = rs.root;
     }
     rs.pending = slot;
     rs.pushes += 1;
     rs.host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    if (local_rc != ADDER_OK) return local_rc;  // (the others learn of it from this rank's row)
+    if (local_rc != ADDER_OK) {  // (the others learn of it from this rank's row, at their next push or end)
+        rs.failed = true;
+        return local_rc;
+    }
     return ADDER_OK;
 }
 
@@ -822,10 +859,12 @@ extern "C" int adder_gather_records_end(AdderGather *g, size_t *n_merged, uint64
     if (!rs.open) return gfail(g, ADDER_E_BAD_PARAMS, "no streamed records gather is open");
     rs.open = false;
     int rc = ADDER_OK;
-    if (rs.pending >= 0) {
+    if (rs.pending >= 0 && !rs.failed) {
         rc = records_complete(g, rs.pending);
-        rs.pending = -1;
+    } else if (rs.failed) {
+        rc = gfail(g, ADDER_E_HIP, "the streamed gather failed at an earlier chunk");
     }
+    rs.pending = -1;
     GHIP(g, hipStreamSynchronize(rs.s));
     if (rc != ADDER_OK) return rc;
     if (bytes_sent) *bytes_sent = rs.sent_bytes;

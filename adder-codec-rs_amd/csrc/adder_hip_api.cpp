@@ -169,6 +169,7 @@ struct AdderHipCtx {
     float lr_tab_time = 0.0f;
     // records over the wire (adder_hip_integrate_records_device / adder_hip_expand_records_device)
     bool records_only = false;        // the batch being queued stops after its scan
+    uint32_t last_variant = 0;        // kernel choice of the batch queued last (enqueue_frames)
     float last_time_spanned = 0.0f;   // of the last batch (root's expansion uses its consts and frame table)
     // root: n_bands BatchArgs + pointer / destination tables per call, kBandDescSlots calls' worth in turn (a slot's
     // host block is reused once the upload queued from it has gone through: no wait for the stream's other work)
@@ -1169,7 +1170,9 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
             t = s2;
         }
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u));
+        // (a lean-runs batch that hands its records out: the scan also leaves the segments' record prefix, for the packing)
+        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u,
+                                    (c->records_only && (variant & 256u)) ? 1u : 0u));
         if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
         if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
         if (timing) {
@@ -1420,6 +1423,18 @@ static int band_precheck(AdderHipCtx *c, uint32_t num_frames) {
     return ADDER_OK;
 }
 
+// the lean-runs expansion's tables for this time step (cr_valid: one time step per reset, so once per stream)
+static int ensure_lr_tab(AdderHipCtx *c, float time_spanned, hipStream_t stream) {
+    if (c->d_lr_tab && c->lr_tab_time == time_spanned) return ADDER_OK;
+    std::vector<uint32_t> tab(kLrTabWords);
+    lr_build_tab(tab.data(), time_spanned);
+    if (!c->d_lr_tab) HIPCHK(c, dalloc(&c->d_lr_tab, tab.size()));
+    HIPCHK(c, hipStreamSynchronize(stream));  // (an expansion of the batch before may still read the old one)
+    HIPCHK(c, hipMemcpy(c->d_lr_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->lr_tab_time = time_spanned;
+    return ADDER_OK;
+}
+
 // Queues `num_frames` frames on `stream`.
 static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames, float time_spanned,
                           AdderEvent *d_out, size_t out_cap, uint64_t *d_offsets, hipStream_t stream) {
@@ -1470,21 +1485,20 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // (AbsoluteT: last_fired_t / T rides along as an integer when time_spanned == ref_time >= 255, like the run records')
     const bool lr_time = c->p.time_mode == ADDER_TIME_DELTA_T ||
                          (c->p.time_mode == ADDER_TIME_ABSOLUTE_T && time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u);
+    // (batches that hand their records out -- the multi-GPU gather -- run it too: the {rho, word} records are the smallest
+    // payload and root's expansion works the events out of them like the single-GPU one)
     const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
-                    !c->records_only && !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
+                    !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |
-                             ((lean_log_batch(c, generic, num_frames) || c->records_only) ? 64u : 0u);  // 64: lean records in per-segment logs
-    if (lr && (!c->d_lr_tab || c->lr_tab_time != time_spanned)) {  // (cr_valid: one time step per reset, so once per stream)
-        std::vector<uint32_t> tab(kLrTabWords);
-        lr_build_tab(tab.data(), time_spanned);
-        if (!c->d_lr_tab) HIPCHK(c, dalloc(&c->d_lr_tab, tab.size()));
-        HIPCHK(c, hipStreamSynchronize(stream));  // (an expansion of the batch before may still read the old one)
-        HIPCHK(c, hipMemcpy(c->d_lr_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->lr_tab_time = time_spanned;
+                             ((lean_log_batch(c, generic, num_frames) || (c->records_only && !lr)) ? 64u : 0u);  // 64: lean records in per-segment logs
+    c->last_variant = variant;
+    if (lr) {
+        int rc_ = ensure_lr_tab(c, time_spanned, stream);
+        if (rc_ != ADDER_OK) return rc_;
     }
     if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
         std::vector<uint8_t> tab(256u * kRrTabRows);
@@ -1762,20 +1776,26 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
         c->poisoned = true;
         return rc;
     }
-    // the batch started at slot 0: the first num_frames rows of the rings are its tables, chunk 0 of the ring its logs;
-    // the logs' used prefixes are packed into chunk 1's (idle) region, the runs re-based onto the packed buffer
+    // the batch started at slot 0: the first num_frames rows of the rings are its tables, chunk 0 of the ring its logs (or
+    // its fixed slots: lean-runs records); the used prefixes are packed into chunk 1's (idle) region, the runs re-based
+    // onto the packed buffer
     const uint32_t rb = lean_rec_bytes(c->p.time_mode == ADDER_TIME_ABSOLUTE_T);
     const uint32_t cap = kWaveUnits * c->chunk;
     const size_t chunk_bytes = (size_t)c->num_waves * cap * rb;
     uint8_t *const packed = c->park_ring + chunk_bytes;
-    uint32_t *const pbase = c->wcur + c->num_waves;
-    uint64_t *const d_total = c->d_side_words;  // (its own word: wcur holds ring_chunks >= 2 rows and two are in use)
-    HIPCHK(c, adder_launch_log_pack(c->park_ring, cap, rb, c->wcur, pbase, c->num_waves, num_frames, c->wofs_ring, packed,
-                                    chunk_bytes, d_total, c->status, s));
+    const bool runs = (c->last_variant & 256u) != 0u;  // adder_lr_kernel ran: {rho, word} records, frame-major packing
+    if (runs) {
+        HIPCHK(c, adder_launch_slot_pack(c->d_batch, num_frames, c->num_waves, rb, packed, chunk_bytes, c->status, s));
+    } else {
+        uint32_t *const pbase = c->wcur + c->num_waves;
+        uint64_t *const d_total = c->d_side_words;  // (its own word: wcur holds ring_chunks >= 2 rows and two are in use)
+        HIPCHK(c, adder_launch_log_pack(c->park_ring, cap, rb, c->wcur, pbase, c->num_waves, num_frames, c->wofs_ring, packed,
+                                        chunk_bytes, d_total, c->status, s));
+    }
     HIPCHK(c, hipEventRecord(c->ev_stop, s));
     out->num_frames = num_frames;
     out->num_segments = c->num_waves;
-    out->record_bytes = rb;
+    out->record_bytes = rb | (runs ? (uint32_t)ADDER_RECORDS_RUNS : 0u);
     out->row_begin = c->p.row_begin;
     out->rows = c->rows;
     out->d_counts = c->wtot_ring;
@@ -1792,21 +1812,27 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
     return ADDER_OK;
 }
 
-extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRecords *bands, uint32_t n_bands,
-                                               AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
-                                               uint64_t *d_merged_offsets, void *stream) {
+static int ensure_lr_tab(AdderHipCtx *c, float time_spanned, hipStream_t stream);
+// wire: d_merged receives the raw sink's 9 / 11-byte records (merged_cap / merged_base still count events)
+static int expand_records_impl(AdderHipCtx *c, const AdderBandRecords *bands, uint32_t n_bands, AdderEvent *d_merged,
+                               size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets, void *stream, bool wire) {
     if (!c || !bands || n_bands == 0 || !d_merged_offsets || (!d_merged && merged_cap)) return ADDER_E_BAD_PARAMS;
     if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
     const uint32_t nf = bands[0].num_frames;
     const bool abs_t = c->p.time_mode == ADDER_TIME_ABSOLUTE_T;
     if (nf == 0 || nf > kMaxChunk || nf > c->ftab_cap) return fail(c, ADDER_E_BAD_PARAMS, "bad num_frames (root integrates the same frames first)");
+    const bool runs = (bands[0].record_bytes & (uint32_t)ADDER_RECORDS_RUNS) != 0u;  // lean-runs records (expansion format 6)
     for (uint32_t r = 0; r < n_bands; ++r)
-        if (bands[r].num_frames != nf || bands[r].record_bytes != lean_rec_bytes(abs_t) || !bands[r].d_counts ||
+        if (bands[r].num_frames != nf || bands[r].record_bytes != (lean_rec_bytes(abs_t) | (runs ? (uint32_t)ADDER_RECORDS_RUNS : 0u)) || !bands[r].d_counts ||
             !bands[r].d_prefix || !bands[r].d_runs || !bands[r].d_records || !bands[r].d_frame_offsets ||
             bands[r].num_segments % (uint32_t)ADDER_EXPAND_SEGS != 0u || bands[r].rows == 0)
             return fail(c, ADDER_E_BAD_PARAMS, "band %u: bad description", r);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (runs) {  // event C's table (root's own lean-runs batches build it too; a root that only expands needs it all the same)
+        int rc_ = ensure_lr_tab(c, c->last_time_spanned, s);
+        if (rc_ != ADDER_OK) return rc_;
+    }
     // device block: n_bands BatchArgs, then the bands' offsets pointers, then the destination table [n_bands][nf]
     const size_t ptrs_at = (size_t)n_bands * kBatchDescBytes;
     const size_t dest_at = ptrs_at + (((size_t)n_bands * sizeof(uint64_t *) + 255) & ~(size_t)255);
@@ -1845,8 +1871,10 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
         b.base.out = reinterpret_cast<AdderEventPod *>(d_merged);
         b.base.out_cap = merged_cap;
         b.base.frame_offsets = d_dest + (size_t)r * nf;  // (the expansion reads [f] only: where the band's frame starts)
-        b.base.lean = 1u;
+        b.base.lean = runs ? 2u : 1u;
         b.base.abs_t = abs_t ? 1u : 0u;
+        b.base.wire_rec = wire ? (c->p.channels == 1 ? 9u : 11u) : 0u;
+        b.lr_tab = c->d_lr_tab;
         b.base.sc = make_consts(c, c->last_time_spanned);
         // the frames' running_t (D_EMPTY fillers): root's own batch of the same frames, or the copy the caller kept of it
         b.ftab = bands[r].d_frame_table ? const_cast<FrameTab *>(reinterpret_cast<const FrameTab *>(bands[r].d_frame_table)) : c->d_ftab;
@@ -1867,15 +1895,28 @@ extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRe
     if (n_bands <= kMaxBands) {  // every band in ONE launch, frame-major across the bands
         uint32_t nw[kMaxBands];
         for (uint32_t r = 0; r < n_bands; ++r) nw[r] = bands[r].num_segments;
-        HIPCHK(c, adder_launch_expand_bands(d_blk, (uint32_t)kBatchDescBytes, n_bands, nw, nf, abs_t ? 1u : 0u, s));
+        HIPCHK(c, adder_launch_expand_bands(d_blk, (uint32_t)kBatchDescBytes, n_bands, nw, nf, abs_t ? 1u : 0u, s, runs ? 1u : 0u,
+                                            wire ? 1u : 0u));
     } else {
-        const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u;
+        const uint32_t variant = 1u | (abs_t ? 2u : 0u) | 64u | (runs ? 256u : 0u) | (wire ? 1024u : 0u);
         for (uint32_t r = 0; r < n_bands; ++r)
             HIPCHK(c, adder_launch_expand(reinterpret_cast<const BatchArgs *>(d_blk + (size_t)r * kBatchDescBytes), 0u, nf,
                                           bands[r].num_segments, variant, 0u, s));
     }
     HIPCHK(c, hipEventRecord(c->band_desc_e[slot], s));  // (the device block is read by the kernels: free after them)
     return ADDER_OK;
+}
+extern "C" int adder_hip_expand_records_device(AdderHipCtx *c, const AdderBandRecords *bands, uint32_t n_bands,
+                                               AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
+                                               uint64_t *d_merged_offsets, void *stream) {
+    return expand_records_impl(c, bands, n_bands, d_merged, merged_cap, merged_base, d_merged_offsets, stream, false);
+}
+extern "C" int adder_hip_expand_records_wire_device(AdderHipCtx *c, const AdderBandRecords *bands, uint32_t n_bands,
+                                                    uint8_t *d_wire, size_t wire_cap_bytes, uint64_t merged_base,
+                                                    uint64_t *d_merged_offsets, void *stream) {
+    if (!c) return ADDER_E_BAD_PARAMS;
+    return expand_records_impl(c, bands, n_bands, reinterpret_cast<AdderEvent *>(d_wire), wire_cap_bytes / (c->p.channels == 1 ? 9u : 11u),
+                               merged_base, d_merged_offsets, stream, true);
 }
 
 static size_t wire_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1892,7 +1933,7 @@ extern "C" void adder_hip_records_wire_sections(uint32_t nf, uint32_t nseg, uint
 extern "C" size_t adder_hip_records_wire_bytes(uint32_t nf, uint32_t nseg, uint32_t rb, uint64_t n_records) {
     size_t sec[6];
     adder_hip_records_wire_sections(nf, nseg, rb, sec);
-    return sec[5] + wire_align((size_t)n_records * rb);
+    return sec[5] + wire_align((size_t)n_records * (rb & 0xffu));  // (record_bytes may carry ADDER_RECORDS_RUNS)
 }
 extern "C" int adder_hip_records_to_wire(AdderHipCtx *c, const AdderBandRecords *rec, uint64_t n_records, void *d_dst,
                                          size_t dst_bytes, void *stream) {
@@ -1913,7 +1954,7 @@ extern "C" int adder_hip_records_to_wire(AdderHipCtx *c, const AdderBandRecords 
     HIPCHK(c, hipMemcpyAsync(dst + sec[2], rec->d_counts, tab, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(dst + sec[3], rec->d_prefix, tab, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(dst + sec[4], rec->d_runs, tab, hipMemcpyDeviceToDevice, s));
-    if (n_records) HIPCHK(c, hipMemcpyAsync(dst + sec[5], rec->d_records, (size_t)n_records * rb, hipMemcpyDeviceToDevice, s));
+    if (n_records) HIPCHK(c, hipMemcpyAsync(dst + sec[5], rec->d_records, (size_t)n_records * (rb & 0xffu), hipMemcpyDeviceToDevice, s));
     return ADDER_OK;
 }
 
@@ -2047,6 +2088,8 @@ extern "C" float adder_hip_last_post_avg_us(AdderHipCtx *c) { return c ? c->last
 extern "C" uint32_t adder_hip_last_post_chunks(AdderHipCtx *c) { return c ? c->timed_posts : 0u; }
 extern "C" uint64_t adder_hip_last_batch_records(AdderHipCtx *c) { return c ? c->last_records : 0ull; }
 extern "C" uint32_t adder_hip_chunk_frames(const AdderHipCtx *c) { return c ? c->chunk : 0u; }
+extern "C" uint32_t adder_hip_segment_units(void) { return kWaveUnits; }
+extern "C" uint32_t adder_hip_wire_record_bytes(const AdderHipCtx *c) { return c ? (c->p.channels == 1 ? 9u : 11u) : 0u; }
 
 extern "C" float adder_hip_last_launch_frames(AdderHipCtx *c) {
     return (c && c->timed_launches) ? (float)c->timed_frames / (float)c->timed_launches : 0.0f;

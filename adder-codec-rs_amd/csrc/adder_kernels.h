@@ -289,7 +289,8 @@ hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
-hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame offsets too
+hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch = 0u,
+                             uint32_t rec_prefix = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame offsets too
 size_t adder_sparse_temp_bytes(uint32_t n);
 hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseStep *d_steps, uint32_t n, uint32_t *keys0,
                             uint32_t *keys1, uint32_t *idx0, uint32_t *idx1, void *d_temp, size_t temp_bytes, uint2 *stage,
@@ -305,12 +306,14 @@ hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t
                                  uint32_t *pbase, uint32_t num_waves, uint32_t nf, uint32_t *wofs_rows, uint8_t *packed,
                                  uint64_t packed_cap_bytes, uint64_t *d_total, uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t stride, uint32_t n_bands, const uint32_t *num_waves,
-                                     uint32_t nf, uint32_t abs_t, hipStream_t stream);
+                                     uint32_t nf, uint32_t abs_t, hipStream_t stream, uint32_t runs = 0u, uint32_t wire = 0u);
 hipError_t adder_launch_sink_layout(const uint64_t *all_offs, uint32_t world, uint32_t rank, uint32_t nf, uint64_t *file_pos,
                                     uint64_t *dest, uint64_t *merged_offs, hipStream_t stream);
 hipError_t adder_launch_wire_scatter(const adder::AdderEventPod *ev, const uint64_t *offs, uint32_t nf, const uint64_t *dest,
                                      uint32_t rec, uint8_t *out, uint64_t out_cap, uint64_t header, uint32_t *status,
                                      uint32_t grid, hipStream_t stream, uint64_t src_cap_events = ~0ull);  // src_cap_events: what `ev` holds
+hipError_t adder_launch_slot_pack(const adder::BatchArgs *b, uint32_t nf, uint32_t num_waves, uint32_t rec_bytes, uint8_t *packed,
+                                  uint64_t packed_cap_bytes, uint32_t *status, hipStream_t stream);
 hipError_t adder_launch_band_layout(const uint64_t *const *offs, uint32_t n_bands, uint32_t nf, uint64_t merged_base,
                                     uint64_t *merged_offsets, uint64_t *dest, hipStream_t stream);
 hipError_t adder_launch_chunk_offsets(const adder::AdderEventPod *ev, uint32_t n, uint32_t row_begin,

@@ -2415,7 +2415,10 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_tiles_kernel(const Ba
         ts[1] = r;
     }
 }
-__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t whole_batch) {
+// rec_prefix: also the exclusive prefix of the segments' RECORD counts, into the frame's wofs row (batches that hand their
+// records out, adder_hip_integrate_records_device: where a segment's run goes in the packed buffer).
+__global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t whole_batch,
+                                                                  uint32_t rec_prefix) {
     const uint32_t ntiles = scan_tiles_of(b->base.num_waves);  // (1 for every plane up to 2 M units: the whole frame in one block)
     const uint32_t fr = ntiles == 1u ? blockIdx.x : blockIdx.x / ntiles, tile = blockIdx.x - fr * ntiles;
     const FrameArgs a = frame_args(b, f0 + fr);
@@ -2435,11 +2438,12 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     uint4 *dst = reinterpret_cast<uint4 *>(a.wpref);
     // the tiles in front of this one (their sums are there: adder_scan_tiles_kernel ran first) and, for the block of the
     // last tile, the frame's records
-    uint32_t tile_base = 0u, tile_recs = 0u;
+    uint32_t tile_base = 0u, tile_recs = 0u, tile_rbase = 0u;
     if (ntiles > 1u) {
         const uint32_t *const ts = b->ftot_ring + 2u * b->slots + ((f0 + fr) % b->slots) * ntiles * 2u;
         for (uint32_t t = 0; t < ntiles; ++t) {  // (uniform: scalar loads)
             if (t < tile) tile_base += ts[2u * t];
+            if (t < tile) tile_rbase += ts[2u * t + 1u];
             if (t != tile) tile_recs += ts[2u * t + 1u];
         }
     }
@@ -2461,20 +2465,34 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
             recs += scan_hi4(w);
         }
     }
-    // parked records of the frame (diagnostics: bench.py's byte accounting); the offsets kernel adds the frames up
-#pragma unroll
-    for (uint32_t o = kWave / 2; o > 0; o >>= 1) recs += __shfl_down(recs, o, kWave);
-    if (lane == 0) s_recs[wid] = recs;
+    // parked records of the frame (bench.py's byte accounting; the records gather); the offsets kernel adds the frames up
+    const uint32_t incl_r = wave_inclusive_scan(recs, lane);
+    if (lane == kWave - 1) s_recs[wid] = incl_r;
     const uint32_t incl = wave_inclusive_scan(sum, lane);
     if (lane == kWave - 1) s_part[wid] = incl;
     __syncthreads();
-    uint32_t base = tile_base, total = tile_base, rec_total = tile_recs;
+    uint32_t base = tile_base, total = tile_base, rec_total = tile_recs, rbase = tile_rbase;
 #pragma unroll
     for (uint32_t w = 0; w < kScanThreads / kWave; ++w) {
-        const uint32_t t = s_part[w];
+        const uint32_t t = s_part[w], r = s_recs[w];
         if (w < wid) base += t;
+        if (w < wid) rbase += r;
         total += t;
-        rec_total += s_recs[w];
+        rec_total += r;
+    }
+    if (rec_prefix) {  // (uniform) the segments' record prefix of this frame -> its wofs row
+        uint4 *const dst_r = reinterpret_cast<uint4 *>(b->wofs_ring + (size_t)((f0 + fr) % b->slots) * a.num_waves);
+        uint32_t run_r = rbase + incl_r - recs;
+        for (uint32_t g = g0; g < g1; ++g) {
+            const uint4 w = src[g];  // (read again: indexing the register copy by a loop counter would put it in scratch)
+            uint4 o;
+            o.x = run_r;
+            o.y = o.x + (w.x >> 16);
+            o.z = o.y + (w.y >> 16);
+            o.w = o.z + (w.z >> 16);
+            run_r = o.w + (w.w >> 16);
+            dst_r[g] = o;
+        }
     }
     uint32_t run = base + incl - sum;
     if (in_regs) {
@@ -2782,9 +2800,10 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
 
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
     constexpr bool RR = FORMAT == 4;
-    constexpr bool LR = FORMAT == 5;  // lean-runs records in fixed slots (adder_lr_kernel; DeltaT only): a format of its own, so that
+    constexpr bool LR = FORMAT == 5 || FORMAT == 6;  // lean-runs records (adder_lr_kernel) in fixed slots (5) or found through a run table (6:
+                                      // the bands' packed records on root); formats of their own, so that
                                       // the decoders do not meet in one instantiation (their results would merge through registers)
     // staging capacity of one wave, in events: run-record rounds hold up to 64 x (depth + 1) events and like room
     constexpr uint32_t XE = RR ? 640u : kXbufEvents;
@@ -2821,7 +2840,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
     const ParkLayout lay = park_layout_u(b);
     // lean records of blocked batches lie in per-segment logs like the per-event ones (log_cap records per segment and
     // chunk, a frame's run at wofs); batches launched one frame at a time keep a fixed slot per frame
-    constexpr bool lean_log = FORMAT == 3;
+    constexpr bool lean_log = FORMAT == 3 || FORMAT == 6;
     const uint32_t lean_log_cap = lean_log ? __builtin_amdgcn_readfirstlane(b->log_cap) : 0u;
     const uint32_t seg_stride = FORMAT == 0 ? 0u : lean_log ? lean_log_cap * lean_rec_bytes(ABS_T) : __builtin_amdgcn_readfirstlane(
         (uint32_t)(park_offset(slot, seg0 + 1u, chunk_frames, num_waves, park_bytes, lay) -
@@ -3184,7 +3203,7 @@ struct BandBlocks {
     uint32_t n_bands;
     uint32_t cum[kMaxBands + 1];  // blocks of the bands before band r (cum[n_bands] = all of them)
 };
-template <bool ABS_T>
+template <int FORMAT, bool ABS_T, bool WIRE>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_bands_kernel(const uint8_t *__restrict__ descs, uint32_t stride,
                                                                           BandBlocks bb, uint32_t nf) {
     const uint32_t per_frame = bb.cum[bb.n_bands];
@@ -3193,10 +3212,13 @@ __global__ __launch_bounds__(kBlockThreads) void adder_expand_bands_kernel(const
     const uint32_t f = w / per_frame, rem = w - f * per_frame;
     uint32_t r = 0;
     while (r + 1u < bb.n_bands && rem >= bb.cum[r + 1u]) ++r;  // uniform
-    expand_block<3, ABS_T>(reinterpret_cast<const BatchArgs *>(descs + (size_t)r * stride), f, rem - bb.cum[r]);
+    expand_block<FORMAT, ABS_T, WIRE>(reinterpret_cast<const BatchArgs *>(descs + (size_t)r * stride), f, rem - bb.cum[r]);
 }
+// runs: the bands shipped lean-RUNS records (format 6) instead of lean records (format 3); wire: the merged output is the raw
+// sink's 9 / 11-byte records (BatchArgs::base.wire_rec of the descriptions) instead of AdderEvents
 extern "C" hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t stride, uint32_t n_bands,
-                                                const uint32_t *num_waves, uint32_t nf, uint32_t abs_t, hipStream_t stream) {
+                                                const uint32_t *num_waves, uint32_t nf, uint32_t abs_t, hipStream_t stream,
+                                                uint32_t runs, uint32_t wire) {
     if (n_bands == 0 || n_bands > kMaxBands) return hipErrorInvalidValue;
     BandBlocks bb;
     bb.n_bands = n_bands;
@@ -3205,8 +3227,15 @@ extern "C" hipError_t adder_launch_expand_bands(const uint8_t *descs, uint32_t s
     for (uint32_t r = 0; r < n_bands; ++r) bb.cum[r + 1] = bb.cum[r] + (num_waves[r] + per_block - 1) / per_block;
     for (uint32_t r = n_bands + 1; r <= kMaxBands; ++r) bb.cum[r] = bb.cum[n_bands];
     const dim3 grid(bb.cum[n_bands] * nf);
-    if (abs_t) hipLaunchKernelGGL((adder_expand_bands_kernel<true>), grid, dim3(kBlockThreads), 0, stream, descs, stride, bb, nf);
-    else hipLaunchKernelGGL((adder_expand_bands_kernel<false>), grid, dim3(kBlockThreads), 0, stream, descs, stride, bb, nf);
+#define ADDER_XB(F, A, W) hipLaunchKernelGGL((adder_expand_bands_kernel<F, A, W>), grid, dim3(kBlockThreads), 0, stream, descs, stride, bb, nf)
+    if (runs) {
+        if (abs_t) { if (wire) ADDER_XB(6, true, true); else ADDER_XB(6, true, false); }
+        else { if (wire) ADDER_XB(6, false, true); else ADDER_XB(6, false, false); }
+    } else {
+        if (abs_t) { if (wire) ADDER_XB(3, true, true); else ADDER_XB(3, true, false); }
+        else { if (wire) ADDER_XB(3, false, true); else ADDER_XB(3, false, false); }
+    }
+#undef ADDER_XB
     return hipGetLastError();
 }
 
@@ -3808,10 +3837,12 @@ extern "C" hipError_t adder_launch_wire_scatter(const AdderEventPod *ev, const u
     return hipGetLastError();
 }
 
-extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch) {
+extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch,
+                                        uint32_t rec_prefix) {
     const uint32_t ntiles = (num_waves + kScanTileWaves - 1u) / kScanTileWaves;  // (as the kernels work it out from the batch)
     if (ntiles > 1u) hipLaunchKernelGGL(adder_scan_tiles_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0);
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u);
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u,
+                       rec_prefix);
     return hipGetLastError();
 }
 
@@ -3841,7 +3872,10 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
         else ADDER_XW(4, false);
     } else if (generic && (variant & 32u)) ADDER_XW(0, true);
     else if (generic) ADDER_XW(0, false);
-    else if (variant & 64u) {
+    else if ((variant & 64u) && (variant & 256u)) {  // lean-runs records found through a run table (a band's packed records on root)
+        if (abs_t) ADDER_XW(6, true);
+        else ADDER_XW(6, false);
+    } else if (variant & 64u) {
         if (abs_t) ADDER_XW(3, true);
         else ADDER_XW(3, false);
     } else if (variant & 256u) {
@@ -3903,6 +3937,52 @@ __global__ __launch_bounds__(kBlockThreads) void adder_log_pack_kernel(const uin
         for (uint32_t k = lane; k < dwords; k += kWave) dst[k] = src[k];
     }
     for (uint32_t f = lane; f < nf; f += kWave) wofs_rows[(size_t)f * num_waves + sgm] += base;
+}
+// Records in FIXED SLOTS (the lean-runs kernel's, park_offset) -> one packed buffer, frame-major: a wave takes the sixteen
+// segments one expansion wave will read of a frame; a segment's run goes to the frame's base (the records of the frames
+// before it) + the scan's record prefix of the segment (its wofs row, rec_prefix), and the row then holds the run's
+// ABSOLUTE start -- the run table root's expansion indexes the packed buffer with (AdderBandRecords::d_runs).
+__global__ __launch_bounds__(kBlockThreads) void adder_slot_pack_kernel(const BatchArgs *__restrict__ b, uint32_t nf, uint32_t rec_bytes,
+                                                                       uint8_t *__restrict__ packed, uint64_t packed_cap_bytes,
+                                                                       uint32_t *status) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t num_waves = b->base.num_waves;
+    const uint32_t groups = (num_waves + 15u) / 16u;
+    const uint32_t item = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+    if (item >= groups * nf) return;
+    const uint32_t f = item / groups, seg0 = (item - f * groups) * 16u;
+    const uint32_t slots = b->slots;
+    // records of the batch's frames before f (the batch started at slot 0: frame f is slot f)
+    uint32_t before = lane < f ? b->ftot_ring[slots + lane] : 0u;
+#pragma unroll
+    for (uint32_t o = kWave / 2; o > 0; o >>= 1) before += __shfl_xor(before, o, kWave);
+    const ParkLayout lay = b->park_layout;
+    const uint32_t *const wtot = b->wtot_ring + (size_t)f * num_waves;
+    uint32_t *const wofs = b->wofs_ring + (size_t)f * num_waves;
+    bool over = false;
+    for (uint32_t q = 0; q < 16u && seg0 + q < num_waves; ++q) {  // uniform
+        const uint32_t sgm = seg0 + q;
+        const uint32_t n = wtot[sgm] >> 16;
+        const uint32_t start = before + wofs[sgm];
+        const uint32_t ndw = n * (rec_bytes / 4u);
+        if ((uint64_t)(start + n) * rec_bytes > packed_cap_bytes) {
+            over = true;
+        } else {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(b->park_ring + park_offset(f, sgm, b->chunk, num_waves, b->park_bytes, lay));
+            uint32_t *dst = reinterpret_cast<uint32_t *>(packed + (size_t)start * rec_bytes);
+            for (uint32_t k = lane; k < ndw; k += kWave) dst[k] = src[k];
+        }
+        __builtin_amdgcn_wave_barrier();  // (every lane has read the prefix before lane 0 replaces it)
+        if (lane == 0u) wofs[sgm] = start;
+    }
+    if (over && lane == 0u) raise(status, kStatusScratch);
+}
+extern "C" hipError_t adder_launch_slot_pack(const BatchArgs *b, uint32_t nf, uint32_t num_waves, uint32_t rec_bytes, uint8_t *packed,
+                                             uint64_t packed_cap_bytes, uint32_t *status, hipStream_t stream) {
+    const uint32_t items = ((num_waves + 15u) / 16u) * nf;
+    hipLaunchKernelGGL(adder_slot_pack_kernel, dim3((items + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads), 0, stream, b, nf,
+                       rec_bytes, packed, packed_cap_bytes, status);
+    return hipGetLastError();
 }
 // One block.  offs[r] = band r's local frame offsets (nf + 1 entries, starting anywhere); merged_offsets[0 .. nf] (the
 // caller's, [0] = merged_base on entry... written here) and dest[r * nf + f] = where band r's events of frame f start.

@@ -229,7 +229,11 @@ def main():
         if mode == "records":
             # adder_gather_records_begin / _push / _end: per chunk the host only waits for its OWN batch (finish); the
             # sizes of chunk k are gathered while chunk k-1's payload moves and root expands on the side stream
-            hg.records_begin(0, d_merged, 0, d_merged_offs, stream=side.cuda_stream)
+            if gather_wire:  # root writes the raw sink's records, like the single-GPU step (adder_gather_records_begin_wire)
+                hg.records_begin_wire(0, None if d_merged is None else d_merged.view(torch.uint8).reshape(-1), 0, d_merged_offs,
+                                      stream=side.cuda_stream)
+            else:
+                hg.records_begin(0, d_merged, 0, d_merged_offs, stream=side.cuda_stream)
             pos, nrec = 0, 0
             gc = wire.get("chunk", gchunk)
             for k, f0 in enumerate(range(0, T, gc)):
@@ -308,6 +312,9 @@ def main():
         return n, merged_total
 
     wire_out = world == 1 and args.output == "wire"
+    # N > 1 with records on the wire: the bands run the lean-runs kernel, root expands every band straight into the raw
+    # sink's records -- the same kernels and the same output as the N = 1 step
+    gather_wire = gather_mode == "records" and args.output == "wire"
 
     def barrier():
         if world > 1:
@@ -524,15 +531,15 @@ def main():
             "workload": f"{Wd}x{Ht}{'x3 RGB' if Cn == 3 else ' gray'} 8-bit, {T} frames, "
                         f"delta_t_max={args.delta_t_max}, ref_time={REF_TIME}, content={args.content}, crf0 "
                         f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, " +
-                        ("the raw sink's 9 / 11-byte records to HBM (serialised by the expansion)" if wire_out else "raw events to HBM"),
-            "output": "raw-sink records" if wire_out else "AdderEvents (12 B)",
+                        ("the raw sink's 9 / 11-byte records to HBM (serialised by the expansion)" if (wire_out or gather_wire) else "raw events to HBM"),
+            "output": "raw-sink records" if (wire_out or gather_wire) else "AdderEvents (12 B)",
             "plane": [Wd, Ht, Cn],
             "rows_per_gpu": rows,
             "row_bands": [list(b) for b in bands],
             "frames_per_step": T,
             "sharding": ("single GPU" if world == 1 else
                          f"{world} row bands of the one plane; per step the bands' " +
-                         ("parked RECORDS are shipped to rank 0, which expands every band into the one ordered stream"
+                         ("lean-runs RECORDS are shipped to rank 0, which expands every band into the one ordered stream"
                           if gather_mode in ("records", "records-torch") else
                           "wire bytes are stored by every rank itself into the one .adder image in shared memory (a sink per rank)"
                           if gather_mode == "host" else "event streams are gathered to rank 0") +

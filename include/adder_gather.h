@@ -118,6 +118,17 @@ int adder_gather_records_at(AdderGather *g, const AdderBandRecords *rec, uint64_
  * is left in a send.  One clip at a time per object; adder_gather_records_at must not be mixed into an open stream. */
 int adder_gather_records_begin(AdderGather *g, int root, AdderEvent *d_merged, size_t merged_cap, uint64_t merged_base,
                                uint64_t *d_merged_offsets, void *stream);
+/* The same clip with the raw sink's records as root's output: d_wire receives the merged stream as 9 / 11-byte records back
+ * to back (what adder_hip_integrate_wire_device leaves on one GPU -- the bytes of the .adder file between header and EOF,
+ * raw/stream.rs:101-120); merged_base, the offsets and end()'s count are in events as before. */
+int adder_gather_records_begin_wire(AdderGather *g, int root, uint8_t *d_wire, size_t wire_cap_bytes, uint64_t merged_base,
+                                    uint64_t *d_merged_offsets, void *stream);
+/* Failure rules of a streamed clip: push(k + 1) completes chunk k -- checks its gathered rows, which every rank reads alike --
+ * BEFORE it queues anything of chunk k + 1, so a rank that finds a failed row (a peer's failure flag, chunks of different
+ * lengths or record kinds, a chunk beyond the agreed worst case) returns the error without having posted a collective
+ * the others would wait for, and every rank returns it at the same chunk.  A rank whose own push fails locally has
+ * queued that chunk's all-gather (its row carries the flag) and must post nothing more: further pushes of the clip return
+ * ADDER_E_BAD_PARAMS at once, end() returns the failure and leaves the object ready for the next begin. */
 int adder_gather_records_push(AdderGather *g, const AdderBandRecords *rec, uint64_t n_records, uint64_t n_events);
 int adder_gather_records_end(AdderGather *g, size_t *n_merged, uint64_t *bytes_sent);
 /* Host time spent inside adder_gather_records_push since the last begin, microseconds (diagnostics). */

@@ -305,6 +305,11 @@ float adder_hip_last_launch_avg_us(AdderHipCtx *ctx);
 float adder_hip_last_post_avg_us(AdderHipCtx *ctx);
 uint32_t adder_hip_last_post_chunks(AdderHipCtx *ctx);
 uint32_t adder_hip_chunk_frames(const AdderHipCtx *ctx);
+/* Units (pixel-channels) of one segment -- the granularity of the records' tables; a band's worst case of one chunk is one
+ * record per unit and frame: adder_hip_band_segments() * adder_hip_segment_units() * frames records. */
+uint32_t adder_hip_segment_units(void);
+/* Bytes of one raw-sink record of this plane: 9 (one channel: EventSingle) or 11 (raw/stream.rs:101-120). */
+uint32_t adder_hip_wire_record_bytes(const AdderHipCtx *ctx);
 /* Parked records of the last device batch (diagnostics: the bytes the frame kernel really moved). */
 uint64_t adder_hip_last_batch_records(AdderHipCtx *ctx);
 /* ---- records over the wire (multi-GPU gather of SURVEY 8(e); protocol in include/adder_gather.h / INTEGRATION.md) ----
@@ -317,10 +322,14 @@ uint64_t adder_hip_last_batch_records(AdderHipCtx *ctx);
  * regime only (Collapse, delta_t_max <= time_spanned, no feature mode): others fail with ADDER_E_BAD_PARAMS and the
  * caller gathers events (adder_gather_events).  The tables and the records live in the band context's scratch until its
  * next batch; a peer's copies of them (received over RCCL) are described by the same struct with root's pointers. */
+#define ADDER_RECORDS_RUNS 0x100u
 typedef struct AdderBandRecords {
     uint32_t num_frames;        /* rows of the three tables */
     uint32_t num_segments;      /* columns: the band's 128-unit segments, padded (adder_hip_band_segments) */
-    uint32_t record_bytes;      /* 8 (DeltaT) or 12 (AbsoluteT) */
+    uint32_t record_bytes;      /* 8 (DeltaT) or 12 (AbsoluteT), | ADDER_RECORDS_RUNS when the batch ran the lean-runs kernel:
+                                 * {rho, [last_fired_t / T,] unit | base_val << 8 | input << 16} records, from which root works the
+                                 * events out (constant runs: crf 0, one integer time step since the reset); every band of a
+                                 * gathered chunk carries the same value */
     uint32_t row_begin, rows;   /* the band */
     const uint32_t *d_counts;   /* [num_frames][num_segments] events | records << 16 of the segment in the frame */
     const uint32_t *d_prefix;   /* [num_frames][num_segments] events of the frame before the segment, inside the band */
@@ -343,6 +352,11 @@ int adder_hip_integrate_records_device(AdderHipCtx *ctx, const uint8_t *d_frames
  * adder_hip_expand_status (events past merged_cap are dropped). */
 int adder_hip_expand_records_device(AdderHipCtx *root, const AdderBandRecords *bands, uint32_t n_bands, AdderEvent *d_merged,
                                     size_t merged_cap, uint64_t merged_base, uint64_t *d_merged_offsets, void *stream);
+/* The same with the raw sink's records as root's output (what adder_hip_integrate_wire_device leaves on one GPU; replaces
+ * video.rs:736-740 -> raw/stream.rs:101-120 for the merged stream): d_wire receives 9 / 11-byte records back to back, event
+ * k of the merged stream at byte k * record size; merged_base and the offsets still count events. */
+int adder_hip_expand_records_wire_device(AdderHipCtx *root, const AdderBandRecords *bands, uint32_t n_bands, uint8_t *d_wire,
+                                         size_t wire_cap_bytes, uint64_t merged_base, uint64_t *d_merged_offsets, void *stream);
 /* One contiguous image of a band's batch, for the transport: sections at 256-byte multiples,
  *   frame offsets (num_frames + 1) x 8 | frame table num_frames x 8 | counts | prefix | runs (num_frames x num_segments x 4
  *   each) | n_records x record_bytes.

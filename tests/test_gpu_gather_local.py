@@ -75,6 +75,83 @@ def _whole_plane(A, clip, W, H, Cn, kw):
 
 @pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
 @pytest.mark.parametrize("W,H,Cn,world,T,chunk", [(333, 41, 1, 3, 150, 37), (50, 24, 3, 4, 150, 64), (3840, 2160, 1, 8, 70, 64)])
+def test_streamed_records_gather_writes_the_raw_sinks_records_on_root(time_mode, W, H, Cn, world, T, chunk, monkeypatch):
+    """adder_gather_records_begin_wire / _push / _end: the bands run the lean-runs kernel and ship {rho, word} records, root
+    expands every band straight into 9 / 11-byte raw-sink records (expansion format 6, WIRE) -- the multi-GPU path does what
+    the single-GPU headline does.  Root's bytes == adder_hip_integrate_wire_device's of the whole plane, and one band's
+    records picked out of them == O.raw_events over the oracle's events of that band (raw/stream.rs:101-120); 3 / 4 ranks on
+    ragged and RGB planes and BASELINE config 4's 3840x2160 in 8 bands of 270 rows."""
+    import torch
+    A = _hip()
+    from adder_amd import sharding
+    from adder_amd.gather import HipGather, LocalGroup
+    runs = Cn == 1   # (the RGB case keeps the lean kernel's records in logs -- expansion format 3 -- with the same output)
+    if not runs:
+        monkeypatch.setenv("ADDER_HIP_NO_LR", "1")
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, Cn, T)
+    if W < 1000:  # quiet stretches (the bands' quiet groups), a cut, black rows
+        clip[40:90] = clip[40]
+        clip[:, : H // 6] = 0
+        clip[120:] = 255 - clip[120:]
+    kw = dict(time_mode=time_mode, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
+    rec = 9 if Cn == 1 else 11
+    st0 = torch.cuda.current_stream().cuda_stream
+    whole = A.HipVideo(W, H, Cn, **kw)
+    whole.set_crf_parameters(0, 10)
+    d_all = torch.from_numpy(clip.reshape(T, -1)).cuda()
+    d_want = torch.zeros(int(d_all.numel() * 1.3) * rec + 64, dtype=torch.uint8, device="cuda")
+    want_off = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    whole.integrate_wire_device(d_all, d_want, want_off, stream=st0)
+    n_want = whole.finish()
+    whole.close()
+    del d_all
+    bands = sharding.row_bands(H, world)
+    grp = LocalGroup(world)
+    d_wire = torch.full((n_want * rec + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    d_moff = torch.full((T + 1,), -7, dtype=torch.int64, device="cuda")
+    kinds = [None] * world
+
+    def rank_fn(r):
+        y0, y1 = bands[r]
+        hv = A.HipVideo(W, H, Cn, row_begin=y0, row_end=y1, **kw)
+        hv.set_crf_parameters(0, 10)
+        g = HipGather(hv, None, r, world, local=grp)
+        st, side = torch.cuda.Stream(), torch.cuda.Stream()
+        d_fr = torch.from_numpy(np.ascontiguousarray(clip[:, y0:y1]).reshape(T, -1)).cuda()
+        d_boff = torch.zeros(chunk + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        g.records_begin_wire(0, d_wire if r == 0 else None, 0, d_moff if r == 0 else None, stream=side.cuda_stream)
+        for f0 in range(0, T, chunk):
+            nf = min(chunk, T - f0)
+            rc = hv.integrate_records_device(d_fr[f0:f0 + nf], d_boff, stream=st.cuda_stream)
+            n_k = hv.finish()
+            kinds[r] = int(rc.record_bytes)
+            g.records_push(rc, hv.last_batch_records(), n_k)
+        n_merged, sent = g.records_end()
+        assert n_merged == (n_want if r == 0 else 0)
+        g.close()
+        hv.close()
+
+    _run_ranks(world, rank_fn)
+    grp.close()
+    assert all(k == ((8 if time_mode == O.DELTA_T else 12) | (0x100 if runs else 0)) for k in kinds), kinds   # lean-runs records on the wire
+    assert torch.equal(d_moff, want_off)
+    assert torch.equal(d_wire[:n_want * rec], d_want[:n_want * rec]) and int((d_wire[n_want * rec:] != 0xAB).sum()) == 0
+    # one band against the oracle's raw sink: its records picked out of the merged bytes by their y (bytes 2-3, big-endian)
+    r = world // 2
+    y0, y1 = bands[r]
+    ov = O.Video(W, y1 - y0, Cn, row_begin=y0, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+    ov.ensure_capacity(8)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    ora = O.raw_events(np.concatenate([ov.integrate_matrix(f[y0:y1]) for f in clip]), Cn)
+    recs = d_wire[:n_want * rec].cpu().numpy().reshape(n_want, rec)
+    ys = recs[:, 2].astype(np.int64) * 256 + recs[:, 3]
+    assert recs[(ys >= y0) & (ys < y1)].tobytes() == ora
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("W,H,Cn,world,T,chunk", [(333, 41, 1, 3, 150, 37), (50, 24, 3, 4, 150, 64), (3840, 2160, 1, 8, 70, 64)])
 def test_streamed_records_gather_equals_the_whole_plane_stream(time_mode, W, H, Cn, world, T, chunk):
     """adder_gather_records_begin / _push / _end over 3, 4 and 8 ranks -- the last case is BASELINE config 4's geometry,
     3840x2160 in 8 bands of 270 rows -- : root's merged stream and offsets equal the whole-plane context's byte for

@@ -675,6 +675,24 @@ def test_gather_cabi_single_rank_world():
         rec = hv.integrate_records_device(d_frames[:8], d_boff, stream=st)
         n_k = hv.finish()
         g.gather_records_at(rec, hv.last_batch_records(), n_k, 0, d_m3[: n_k - 1], 0, d_mo3, stream=st)
+    # the streamed form with the raw sink's records as root's output (adder_gather_records_begin_wire / _push / _end: what
+    # bench.py --gpus N runs): lean-runs records through the real communicator, root's wire bytes == the oracle's raw sink
+    ov = O.Video(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    want = O.raw_events(np.concatenate([ov.integrate_matrix(f) for f in clip]), 1)
+    hv.reset()
+    d_w = torch.full((n * 9 + 32,), 0xAB, dtype=torch.uint8, device="cuda")
+    d_mo4 = torch.full((T + 1,), -7, dtype=torch.int64, device="cuda")
+    g.records_begin_wire(0, d_w, 0, d_mo4, stream=side.cuda_stream)
+    for f0, nf in ((0, 8), (8, 8), (16, 4)):
+        rec = hv.integrate_records_device(d_frames[f0:f0 + nf], d_boff, stream=st)
+        n_k = hv.finish()
+        assert rec.record_bytes == (8 | 0x100)
+        g.records_push(rec, hv.last_batch_records(), n_k)
+    n_m, _ = g.records_end()
+    got = d_w.cpu().numpy()
+    assert n_m == n and got[:n * 9].tobytes() == want and (got[n * 9:] == 0xAB).all() and torch.equal(d_mo4, d_off)
     g.close()
 
 
@@ -1811,3 +1829,73 @@ def test_band_in_feature_mode_survives_a_too_small_event_buffer():
     assert retried == 2
     for v in vids + [whole]:
         v.close()
+
+
+def _wire_pair(W, H, Cn, tm, dtm=255):
+    A = _hip()
+    ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+    hv = A.HipVideo(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+    for v in (ov, hv):
+        v.set_crf_parameters(0, 10)
+        v.reset_c_thresh(0)
+    return ov, hv
+
+
+@pytest.mark.parametrize("channels,frames", [(1, 70), (3, 20)])
+def test_full_size_1080p_wire_records_of_the_headline_entry_point(channels, frames):
+    """adder_hip_integrate_wire_device at BASELINE config 2 / 3's size (1920x1080 gray x 70 frames across the chunk boundary,
+    1920x1080 RGB x 20 frames), scene content: the expansion's 9 / 11-byte records == the oracle's raw sink over the oracle's
+    events (raw/stream.rs:79-120), the offsets == the oracle's counts.  Frames start at every stream index mod 4 (the
+    flush's heads and tails at the waves' edges, the kilobyte-per-instruction body, both record sizes); a second pass cuts
+    the clip into batches whose sizes leave every residue at their ends."""
+    import torch
+    W, H = 1920, 1080
+    rec = 9 if channels == 1 else 11
+    st = torch.cuda.current_stream().cuda_stream
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, channels, frames)
+    for tm, cuts in ((O.DELTA_T, [frames]), (O.ABSOLUTE_T, [1, 2, 3, frames - 6])):
+        ov, hv = _wire_pair(W, H, channels, tm)
+        k, residues = 0, set()
+        for nb in cuts:
+            want = [ov.integrate_matrix(f) for f in clip[k:k + nb]]
+            counts = [len(w) for w in want]
+            n = sum(counts)
+            starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+            residues |= {int(s) % 4 for s, c in zip(starts, counts) if c}
+            d_frames = torch.from_numpy(np.ascontiguousarray(clip[k:k + nb]).reshape(nb, -1)).cuda()
+            d_wire = torch.full((n * rec + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+            d_offs = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+            hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+            assert hv.finish() == n
+            offs = d_offs.cpu().numpy()
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == counts, (tm, k)
+            got = d_wire.cpu().numpy()
+            assert got[:n * rec].tobytes() == O.raw_events(np.concatenate(want), channels), (tm, k, nb)
+            assert (got[n * rec:] == 0xAB).all()
+            k += nb
+        if len(cuts) == 1:
+            assert residues == {0, 1, 2, 3}, residues   # frames of the one batch start at every residue
+        hv.close()
+
+
+def test_config_1_adder_file_through_the_wire_path():
+    """BASELINE config 1 (640x480 gray, 30 frames, raw .adder out) as a whole FILE: header + the expansion's wire records +
+    EOF == the oracle's header, raw sink and EOF over the oracle's events (encoder.rs:170-229, raw/stream.rs:79-120)."""
+    import torch
+    A = _hip()
+    W, H, T = 640, 480, 30
+    st = torch.cuda.current_stream().cuda_stream
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, 1, T)
+    for tm in (O.DELTA_T, O.ABSOLUTE_T):
+        ov, hv = _wire_pair(W, H, 1, tm)
+        want = np.concatenate([ov.integrate_matrix(f) for f in clip])
+        oracle_file = O.raw_header(3, W, H, 1, 255 * 30, 255, 255, 0, tm, 0) + O.raw_events(want, 1) + O.raw_eof()
+        d_frames = torch.from_numpy(clip.reshape(T, -1)).cuda()
+        d_wire = torch.zeros(len(want) * 9 + 16, dtype=torch.uint8, device="cuda")
+        d_offs = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+        hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+        n = hv.finish()
+        ours = A.raw_header(3, W, H, 1, 255 * 30, 255, 255, 0, tm, 0) + d_wire[:n * 9].cpu().numpy().tobytes() + A.raw_eof()
+        assert n == len(want) and ours == oracle_file
+        assert len(ours) == 37 + 9 * n + 11 and ours[:5] == b"adder"
+        hv.close()
