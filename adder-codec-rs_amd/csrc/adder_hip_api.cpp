@@ -235,7 +235,13 @@ struct AdderHipCtx {
         AdderEvent *out = nullptr;      // where the events were sent (h_events, or the caller's pinned buffer)
         size_t out_cap = 0;
         bool wire = false;              // the slot holds 9 / 11-byte wire records (the ring's format when it was submitted)
+        hipGraphExec_t out_graph = nullptr;  // the slot's hand-over (wire scatter + frame_out) as ONE launch
+        uint64_t out_key[6] = {0, 0, 0, 0, 0, 0};  // what that graph baked in
     } fslot[4];
+    uint32_t graph_slot = 0;         // 1 + the frame slot whose description the batch being queued uses (0: the context's own)
+    bool frame_only = false;         // the one-frame batch being queued stops after its frame kernel: the caller queues scan and
+                                     // expansion itself, on another stream (the per-frame ring)
+    bool frame_only_done = false;    // ... and enqueue_frames did so (false: the whole pipeline was queued -- feature mode, timing)
     uint32_t f_slots = 3;
     bool f_wire = false;             // the ring hands out 9 / 11-byte wire records instead of AdderEvents (adder_hip_frames_set_format)
     size_t f_events_per_slot = 0;    // 0: the mode's worst case, at most 2 GiB of events
@@ -315,10 +321,11 @@ static void free_ctx(AdderHipCtx *c) {
         if (sl.wired) (void)hipEventDestroy(sl.wired);
     }
     for (auto &fs : c->fslot) {
-        for (void *p : {(void *)fs.d_frame, (void *)fs.d_events, (void *)fs.d_offsets, (void *)fs.d_batch, (void *)fs.d_ftab,
+        if (fs.out_graph) (void)hipGraphExecDestroy(fs.out_graph);
+        for (void *p : {(void *)fs.d_frame, (void *)fs.d_events, (void *)fs.d_offsets, (void *)fs.d_batch,
                         (void *)fs.d_counters})
             if (p) (void)hipFree(p);
-        for (void *p : {(void *)fs.h_events, (void *)fs.h_hdr, (void *)fs.h_batch, (void *)fs.h_ftab})
+        for (void *p : {(void *)fs.h_events, (void *)fs.h_hdr, (void *)fs.h_batch})
             if (p) (void)hipHostFree(p);
         if (fs.done) (void)hipEventDestroy(fs.done);
     }
@@ -1249,10 +1256,13 @@ constexpr int kTuneRecheckRuns = 2;
 
 static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipGraphExec_t *out) {
     // everything the captured launch sequence depends on
-    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 44);
+    // (running_enabled and the lazy-state switch decide the launches' lazy bits, lazy_state_bit)
+    // (graph_slot: a frame slot of the per-frame ring has its own description, so its own graphs)
+    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 44) |
+                         ((uint64_t)(c->running_enabled ? 1u : 0u) << 52) | ((uint64_t)c->graph_slot << 53);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
-        if (c->graphs.size() >= 8) {  // keep the cache small
+        if (c->graphs.size() >= 24) {  // keep the cache small (a ring of four slots holds a graph per slot and kernel choice)
             for (hipGraphExec_t e : c->graphs.begin()->second.cand)
                 if (e) c->retired_execs.push_back(e);
             c->graphs.erase(c->graphs.begin());
@@ -1616,6 +1626,19 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.wtot_ring = c->wtot_ring;
     b.wpref_ring = c->wpref_ring;
     b.ftot_ring = c->ftot_ring;
+    if (c->frame_only && c->graph_slot != 0u) {
+        // the per-frame ring: a one-frame batch always sits in scratch slot 0 -- each frame slot of the ring gets a ring
+        // CHUNK of its own as "its" scratch (views of the rings shifted by whole chunks), so that the scan and expansion of
+        // frame k may run beside the frame kernel of frame k + 1
+        const uint32_t rk = (c->graph_slot - 1u) % c->ring_chunks;
+        b.park_ring += (size_t)rk * scratch_bytes_per_chunk(c, c->scratch_kind, c->chunk);
+        const size_t rows = (size_t)rk * c->chunk * c->num_waves;
+        b.wtot_ring += rows;
+        b.wpref_ring += rows;
+        if (b.wofs_ring) b.wofs_ring += rows;
+        if (b.wcur) b.wcur += (size_t)rk * c->num_waves;
+        b.ftot_ring += (size_t)rk * c->chunk;  // (its second half and the tile sums move along: still inside the allocation)
+    }
     b.slots = c->slots;
     b.chunk = c->chunk;
     b.rec_total = c->d_rec_total;
@@ -1657,7 +1680,14 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->h_result->valid = 0u;
     HIPCHK(c, hipEventRecord(c->ev_start, stream));
     int rc = ADDER_OK;
-    if (c->records_only) {
+    c->frame_only_done = false;
+    if (c->frame_only && num_frames == 1u && !fpath && !timing && !c->records_only) {
+        // the per-frame ring: only the frame kernel goes on this stream -- the NEXT frame's kernel needs nothing else of
+        // this frame, so the ring puts scan, expansion and hand-over on its second stream, beside that kernel
+        const Lean1wArgs wide = lean1w_args(c);
+        HIPCHK(c, adder_launch_frame(c->d_batch, 0u, 1u, variant, c->num_waves, 0u, stream, &wide));
+        c->frame_only_done = true;
+    } else if (c->records_only) {
         rc = launch_frame_loop(c, num_frames, variant, stream, nullptr, false);  // (stops after scan + offsets)
     } else if (fpath) {
         rc = launch_feature_loop(c, num_frames, variant, stream);
@@ -2369,11 +2399,15 @@ static int frame_slot_prepare(AdderHipCtx *c, AdderHipCtx::FrameSlot &fs, size_t
     if (!fs.d_frame) {
         HIPCHK(c, dalloc(&fs.d_frame, c->n_units + 16));
         HIPCHK(c, dalloc(&fs.d_offsets, 2));
-        HIPCHK(c, dalloc(&fs.d_batch, 1));
-        HIPCHK(c, dalloc(&fs.d_ftab, 64));
+        // (description and frame table in one block each, like the context's own: one upload per frame)
+        uint8_t *dd = nullptr, *hd = nullptr;
+        HIPCHK(c, dalloc(&dd, kBatchDescBytes + 64 * sizeof(FrameTab)));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&hd), kBatchDescBytes + 64 * sizeof(FrameTab), hipHostMallocDefault));
+        fs.d_batch = reinterpret_cast<BatchArgs *>(dd);
+        fs.h_batch = reinterpret_cast<BatchArgs *>(hd);
+        fs.d_ftab = reinterpret_cast<FrameTab *>(dd + kBatchDescBytes);
+        fs.h_ftab = reinterpret_cast<FrameTab *>(hd + kBatchDescBytes);
         HIPCHK(c, dalloc(&fs.d_counters, 4));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_batch), sizeof(BatchArgs), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_ftab), 64 * sizeof(FrameTab), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&fs.h_hdr),
                                 sizeof(FrameResult) + ((size_t)c->num_chunks + 1) * sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(c, hipEventCreateWithFlags(&fs.done, hipEventDisableTiming));
@@ -2469,7 +2503,21 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     c->d_ftab = fs.d_ftab;
     c->h_ftab = fs.h_ftab;
     c->ftab_cap = 64;
-    c->use_graph = false;   // the captured graphs point at the shared description
+    // Only the frame kernel runs on the context's stream; scan, expansion and hand-over of this frame go to the ring's
+    // second stream as ONE captured launch per slot and kernel choice (the graph holds the slot's own description), beside
+    // the next frame's kernel -- which needs this frame's pixel state and nothing else of it.  The per-frame path is bound
+    // by the frames' GPU time in a row at the reference's default quality (kernel 29 us + scan / expansion / hand-over
+    // 40 us per 1080p frame: 82 us sustained); side by side the period is the longer of the two.
+    // (ADDER_HIP_RING_NO_SPLIT=1: everything on one stream, eager, as before.)
+    static const bool ring_split_off = env_flag("ADDER_HIP_RING_NO_SPLIT");
+    const bool ring_graph = swap.graph && !ring_split_off;
+    c->use_graph = false;   // (the context's captured graphs point at the shared description)
+    struct SlotTag {
+        AdderHipCtx *c;
+        ~SlotTag() { c->graph_slot = 0u; c->frame_only = false; }
+    } slot_tag{c};
+    c->graph_slot = 1u + (uint32_t)(c->f_submitted % c->f_slots);
+    c->frame_only = !ring_split_off && c->f_slots <= c->ring_chunks && c->chunk >= 2u;  // (a ring chunk of scratch per frame slot)
     c->no_snapshot = true;  // frames behind this one are submitted before its outcome is known: no rollback
     fs.out = direct_out ? direct_out : fs.h_events;
     fs.out_cap = need;
@@ -2484,16 +2532,59 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
     const bool wire = c->f_wire && !direct_out;
     fs.wire = wire;
-    if (wire && !wire_direct)  // 9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw sink writes
-        HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
-                                            c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
-                                            (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), c->out_s,
-                                            (uint64_t)need));  // (a frame that overflowed its slot: only what the expansion kept is read)
-    HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(wire_direct ? fs.out : fs.d_events), fs.d_offsets, fs.out_cap,
-                                     wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
-                                     reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
-                                     feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, c->out_s,
-                                     wire_direct ? wire_record_bytes(c) : 0u));
+    // the hand-over: wire scatter (9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw
+    // sink writes) + frame_out (result header, chunk offsets, the AdderEvents copy)
+    const bool split = c->frame_only_done;  // (feature mode and timed launches queued the whole pipeline themselves)
+    const uint32_t post_variant = c->last_variant;
+    auto hand_over = [&](hipStream_t hs) -> int {
+        if (split) {  // the frame's scan (a batch of one frame: it writes the offsets too) and expansion
+            HIPCHK(c, adder_launch_scan(fs.d_batch, 0u, 1u, c->num_waves, hs, 1u));
+            HIPCHK(c, adder_launch_expand(fs.d_batch, 0u, 1u, c->num_waves, post_variant, 0u, hs));
+        }
+        if (wire && !wire_direct)
+            HIPCHK(c, adder_launch_wire_scatter(reinterpret_cast<const AdderEventPod *>(fs.d_events), fs.d_offsets, 1u,
+                                                c->d_side_words + 2, wire_record_bytes(c), reinterpret_cast<uint8_t *>(fs.out),
+                                                (uint64_t)fs.out_cap * sizeof(AdderEvent), 0ull, c->status, wire_scatter_blocks(c), hs,
+                                                (uint64_t)need));  // (a frame that overflowed its slot: only what the expansion kept is read)
+        HIPCHK(c, adder_launch_frame_out(reinterpret_cast<const AdderEventPod *>(wire_direct ? fs.out : fs.d_events), fs.d_offsets, fs.out_cap,
+                                         wire ? nullptr : reinterpret_cast<AdderEventPod *>(fs.out), reinterpret_cast<FrameResult *>(fs.h_hdr),
+                                         reinterpret_cast<uint32_t *>(fs.h_hdr + sizeof(FrameResult)), c->status,
+                                         feature_path(c) ? fs.d_counters : nullptr, c->p.row_begin, c->p.chunk_rows, c->num_chunks, hs,
+                                         wire_direct ? wire_record_bytes(c) : 0u));
+        return ADDER_OK;
+    };
+    if (ring_graph && !direct_out) {  // ... as one launch too: captured per slot, again whenever something it baked in has changed
+                                      // (the blocking call's destination is the caller's: not worth a capture per buffer)
+        const uint64_t key[6] = {(uint64_t)(uintptr_t)fs.out, (uint64_t)fs.out_cap, (uint64_t)need,
+                                 (uint64_t)(wire ? 1u : 0u) | (wire_direct ? 2u : 0u) | (feature_path(c) ? 4u : 0u) | (split ? 8u : 0u) |
+                                     ((uint64_t)c->p.chunk_rows << 8) | ((uint64_t)post_variant << 32),
+                                 (uint64_t)(uintptr_t)fs.d_events, (uint64_t)wire_scatter_blocks(c)};
+        if (!fs.out_graph || memcmp(key, fs.out_key, sizeof key) != 0) {
+            if (fs.out_graph) c->retired_execs.push_back(fs.out_graph);
+            fs.out_graph = nullptr;
+            hipGraph_t graph = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(c->cap_s, hipStreamCaptureModeThreadLocal));
+            const int rc_h = hand_over(c->cap_s);
+            hipError_t e = hipStreamEndCapture(c->cap_s, &graph);
+            if (rc_h != ADDER_OK) {
+                if (graph) (void)hipGraphDestroy(graph);
+                c->poisoned = true;
+                return rc_h;
+            }
+            HIPCHK(c, e);
+            e = hipGraphInstantiate(&fs.out_graph, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIPCHK(c, e);
+            memcpy(fs.out_key, key, sizeof key);
+        }
+        HIPCHK(c, hipGraphLaunch(fs.out_graph, c->out_s));
+    } else {
+        rc = hand_over(c->out_s);
+        if (rc != ADDER_OK) {
+            c->poisoned = true;
+            return rc;
+        }
+    }
     HIPCHK(c, hipEventRecord(fs.done, c->out_s));
     c->f_submitted += 1;
     return ADDER_OK;

@@ -302,6 +302,42 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
     return x;
 }
 
+// packed 16-bit operations of the quiet groups' statistics (two units of a lane per instruction)
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // max(a - b, 0) per half
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c per half
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// min over each row of 16 lanes, left in the row's last lane (DPP row shifts; lanes without a source keep their own value)
+__device__ __forceinline__ uint32_t row16_min_to_last(uint32_t x) {
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false); x = y < x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false); x = y < x ? y : x;
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1, lean variants (Collapse with delta_t_max <= time_spanned: BASELINE configs 2-4).
 // One segment (64 lanes x kUnitsPerLane units) through `nb` consecutive frames starting at
@@ -350,6 +386,9 @@ __device__ __forceinline__ void lean_store_rec(void *seg, uint32_t byte_off, con
 // per-unit bounds handling inside the frame loop.
 #ifndef ADDER_LEAN_QUIET_PATH
 #define ADDER_LEAN_QUIET_PATH 1
+#endif
+#ifndef ADDER_LEAN_QUIET_GROUPS
+#define ADDER_LEAN_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet loop)
 #endif
 // LOG: the records are appended to the segment's log of the chunk (BatchArgs::log_cap != 0: dense, frame after frame,
 // a frame's run found through wofs) instead of one fixed slot per frame (park_layout).
@@ -469,7 +508,75 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) ok &= px[j].has0 & (px[j].popped | L::from(px[j].integ == 0.0f));
         if (ok == ~0ull) {  // uniform
-            for (; i < nb; ++i) {
+#if ADDER_LEAN_QUIET_GROUPS
+            // the smallest c_thresh of every group of kQuietGroup frames (lane 16 g + 15: group g; frames past the launch do not count)
+            const uint32_t tab_cmin = row16_min_to_last(lane < nb ? tab_cth : 0xffu);
+#endif
+            for (; i < nb;) {
+#if ADDER_LEAN_QUIET_GROUPS
+                // ---------------- a whole group of frames at once (quiet_group_apply, adder_pixel.hpp; adder_cb_kernel's form) ----------------
+                if ((i % kQuietGroup) == 0u) {
+                    static_assert(N == 2u, "two units per lane in one packed register");
+                    const uint32_t gn = nb - i < kQuietGroup ? nb - i : kQuietGroup;  // (uniform)
+                    const uint32_t cth_min = __builtin_amdgcn_readlane(tab_cmin, i + kQuietGroup - 1u);
+                    const uint32_t need2 = quiet_group_need(px[0].integ, px[0].thr) | (quiet_group_need(px[1].integ, px[1].thr) << 16);
+                    uint32_t mn = 0x00ff00ffu, mx = 0u, P = 0u, cnt = 0u, pm = 0u;
+                    for (uint32_t k = 0; k < gn; ++k) {
+                        const uint32_t pk = __builtin_amdgcn_perm(0u, (uint32_t)in_lds[(i + k) * kWave], 0x0c010c00u);  // {v0, v1} as halves
+                        mn = pk_min_u16(mn, pk);
+                        mx = pk_max_u16(mx, pk);
+                        P = pk_add_u16(P, pk);
+                        const uint32_t below = pk_min_u16(pk_sub_sat_u16(need2, P), 0x00010001u);  // prefix sum < need
+                        cnt = pk_add_u16(cnt, below);
+                        pm = pk_mad_u16(pk, below, pm);
+                    }
+                    LeanPxT<L> t[N];
+                    uint32_t verdict[N];
+                    bool any_no = false, any_slow = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < N; ++j) {
+                        QuietGroupStats g;
+                        g.mn = (mn >> (16u * j)) & 0xffffu;
+                        g.mx = (mx >> (16u * j)) & 0xffffu;
+                        g.sum = (P >> (16u * j)) & 0xffffu;
+                        g.cnt = (cnt >> (16u * j)) & 0xffffu;
+                        g.pm = (pm >> (16u * j)) & 0xffffu;
+                        const uint32_t row = g.cnt < gn ? g.cnt : gn - 1u;
+                        g.vc = ((uint32_t)in_lds[(i + row) * kWave] >> (8u * j)) & 0xffu;
+                        t[j] = px[j];
+                        verdict[j] = lean_group_apply<L>(t[j], g, gn, cth_min, T);
+                        any_no = any_no || verdict[j] == kQuietNo;
+                        any_slow = any_slow || verdict[j] == kQuietSlow;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any_no) == 0ull) {  // uniform: every unit of the wave is quiet in every frame
+#pragma unroll
+                        for (uint32_t j = 0; j < N; ++j) {  // (only the root's four floats move; the masks are the wave's)
+                            const bool done = verdict[j] == kQuietDone;
+                            px[j].integ = done ? t[j].integ : px[j].integ;
+                            px[j].dt = done ? t[j].dt : px[j].dt;
+                            px[j].bdt = done ? t[j].bdt : px[j].bdt;
+                            px[j].thr = done ? t[j].thr : px[j].thr;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(any_slow) != 0ull) {  // (rare: second firings, black roots that wake up)
+                            for (uint32_t k = 0; k < gn; ++k) {
+                                const uint32_t vin_s = (uint32_t)in_lds[(i + k) * kWave];
+#pragma unroll
+                                for (uint32_t j = 0; j < N; ++j) {
+                                    LeanPxT<L> u = px[j];
+                                    lean_step_quiet<L, true>(u, (vin_s >> (8 * j)) & 0xffu, T);
+                                    const bool slow = verdict[j] == kQuietSlow;
+                                    px[j].integ = slow ? u.integ : px[j].integ;
+                                    px[j].dt = slow ? u.dt : px[j].dt;
+                                    px[j].bdt = slow ? u.bdt : px[j].bdt;
+                                    px[j].thr = slow ? u.thr : px[j].thr;
+                                }
+                            }
+                        }
+                        i += gn;  // (wt of these frames stays 0: no events, no records)
+                        continue;
+                    }
+                }
+#endif
                 const uint32_t vin_q = (uint32_t)in_lds[i * kWave];
                 const uint32_t cth_q = __builtin_amdgcn_readlane(tab_cth, i);
                 uint64_t quiet = ~0ull, keeps = ~0ull;
@@ -488,6 +595,7 @@ __device__ __forceinline__ void lean_frames(const BatchArgs *__restrict__ b, con
                     for (uint32_t j = 0; j < N; ++j) lean_step_quiet<L, true>(px[j], (vin_q >> (8 * j)) & 0xffu, T);
                 }
                 // (wt of this frame stays 0: no events, no records; the slot walk below starts at frame i)
+                ++i;
             }
             vin_w = i < nb ? (uint32_t)in_lds[i * kWave] : 0u;
             if (!LOG) {
@@ -1469,42 +1577,6 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
                                                uint32_t lane, uint32_t k0, uint32_t nb, uint8_t *lds_in, bool direct) {
     cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, k0, nb, lds_in, direct);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed (and so have the records stored so far)
-}
-
-// packed 16-bit operations of the quiet groups' statistics (two units of a lane per instruction)
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // max(a - b, 0) per half
-    uint32_t r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {  // a * b + c per half
-    uint32_t r;
-    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// min over each row of 16 lanes, left in the row's last lane (DPP row shifts; lanes without a source keep their own value)
-__device__ __forceinline__ uint32_t row16_min_to_last(uint32_t x) {
-    uint32_t y;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false); x = y < x ? y : x;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false); x = y < x ? y : x;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false); x = y < x ? y : x;
-    y = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false); x = y < x ? y : x;
-    return x;
 }
 
 #ifndef ADDER_CB_QUIET_PATH
@@ -3188,10 +3260,18 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
 
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __global__ __launch_bounds__(kBlockThreads) void adder_expand_kernel(const BatchArgs *__restrict__ b, uint32_t f0,
-                                                                     uint32_t xblocks, uint32_t nf) {
-    // (frame, group of segments) pairs, frame-major; a grid smaller than their number walks them (see the lean kernel)
+                                                                     uint32_t xblocks, uint32_t nf, uint32_t items) {
+    // (frame, group of segments) pairs, frame-major; a workgroup takes `items` consecutive ones (a frame without events costs
+    // its workgroups' dispatch and nothing else: fewer, longer workgroups), a grid smaller than their number walks them
     timeline_mark(b, 3u, f0, false);
-    for (uint32_t w = blockIdx.x; w < xblocks * nf; w += gridDim.x) expand_block<FORMAT, ABS_T, WIRE>(b, f0 + w / xblocks, w % xblocks);
+    const uint32_t total = xblocks * nf;
+    for (uint32_t w0 = blockIdx.x * items; w0 < total; w0 += gridDim.x * items) {
+        const uint32_t w1 = w0 + items < total ? w0 + items : total;
+        for (uint32_t w = w0; w < w1; ++w) {
+            expand_block<FORMAT, ABS_T, WIRE>(b, f0 + w / xblocks, w % xblocks);
+            __syncthreads();  // (the next item refills the workgroup's table)
+        }
+    }
     timeline_mark(b, 3u, f0, true);
 }
 
@@ -3860,11 +3940,12 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
                                           uint32_t variant, uint32_t grid_cap, hipStream_t stream) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t xblocks = (num_waves + per_block - 1) / per_block;
-    uint32_t total = xblocks * nf;
+    static const uint32_t items = [] { const char *e = getenv("ADDER_HIP_EXPAND_ITEMS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u; }();
+    uint32_t total = (xblocks * nf + items - 1u) / items;
     if (grid_cap && grid_cap < total) total = grid_cap;
     const dim3 grid(total);
     const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u, wire = variant & 1024u;
-#define ADDER_X(F, A, W) hipLaunchKernelGGL((adder_expand_kernel<F, A, W>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf)
+#define ADDER_X(F, A, W) hipLaunchKernelGGL((adder_expand_kernel<F, A, W>), grid, dim3(kBlockThreads), 0, stream, b, f0, xblocks, nf, items)
 #define ADDER_XW(F, A) do { if (wire) ADDER_X(F, A, true); else ADDER_X(F, A, false); } while (0)
     if (continuous) ADDER_X(2, false, false);  // (its events are stored as they are decoded: no wire form)
     else if (variant & 512u) {  // run records in per-segment logs

@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--multi-mode", default="collapse", choices=["collapse", "normal"])
     ap.add_argument("--time-mode", default="delta_t", choices=["delta_t", "absolute_t"])
     ap.add_argument("--delta-t-max", type=int, default=DTM)
+    ap.add_argument("--crf-numbers", default="0,0,10",
+                    help="c_thresh baseline,max,velocity the pixels start with (rate_controller.rs:5-18: crf 0 = 0,0,10 -- the "
+                         "headline; crf 3 = 2,7,7 -- the reference's default quality; used by the profiling scripts for the quiet legs)")
     ap.add_argument("--channels", type=int, default=C)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
@@ -163,12 +166,13 @@ def main():
     d_offsets = torch.zeros(T + 1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
+    crf = [int(x) for x in args.crf_numbers.split(",")]
     hv = A.HipVideo(Wd, Ht, Cn, row_begin=y0, row_end=y1, time_mode=tmode, multi_mode=multi,
                     ref_time=REF_TIME, delta_t_max=args.delta_t_max, device_id=local_rank,
-                    c_thresh_start=0, c_counter_start=0)
+                    c_thresh_start=crf[0], c_counter_start=0)
     # CRF[0] = (0, 0, 10) (rate_controller.rs:9); pixels start at c_thresh 0 / counter 0, the
     # state `.crf(0)` leaves them in (video.rs:1247-1250), so reset() restores exactly that
-    hv.set_crf_parameters(0, 10)
+    hv.set_crf_parameters(crf[1], crf[2])
 
     if share and gather_mode == "cabi":
         gather_mode = "torch"  # RCCL cannot put two ranks on one device
@@ -490,7 +494,7 @@ def main():
     traffic, traffic_ratio, traffic_note = None, None, "no committed PMC collection for this workload (tools/profile_round.sh)"
     try:
         default_workload = (Wd, Ht, Cn, T, args.delta_t_max, args.content, args.multi_mode, args.time_mode) == \
-            (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t")
+            (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t") and crf == [0, 0, 10]
         cands = [("r05_traffic_default.json" if wire_out else "r05_traffic_events_output.json"),
                  ("r04_traffic_default.json" if wire_out else "r04_traffic_events_output.json")]
         tname = next((n for n in cands if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
@@ -529,8 +533,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{Wd}x{Ht}{'x3 RGB' if Cn == 3 else ' gray'} 8-bit, {T} frames, "
-                        f"delta_t_max={args.delta_t_max}, ref_time={REF_TIME}, content={args.content}, crf0 "
-                        f"numbers (0,0,10), FramePerfect, {args.multi_mode}, {args.time_mode}, " +
+                        f"delta_t_max={args.delta_t_max}, ref_time={REF_TIME}, content={args.content}, crf "
+                        f"numbers ({args.crf_numbers}), FramePerfect, {args.multi_mode}, {args.time_mode}, " +
                         ("the raw sink's 9 / 11-byte records to HBM (serialised by the expansion)" if (wire_out or gather_wire) else "raw events to HBM"),
             "output": "raw-sink records" if (wire_out or gather_wire) else "AdderEvents (12 B)",
             "plane": [Wd, Ht, Cn],

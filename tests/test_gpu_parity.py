@@ -1899,3 +1899,40 @@ def test_config_1_adder_file_through_the_wire_path():
         assert n == len(want) and ours == oracle_file
         assert len(ours) == 37 + 9 * n + 11 and ours[:5] == b"adder"
         hv.close()
+
+
+def test_integer_state_kernels_hand_over_past_65k_frames_since_the_reset():
+    """The lean-runs / run-records kernels keep rho * 255 and rho * time_spanned exact in binary32: the host stops choosing
+    them once (frames since the reset) * 255 would reach 2^24 -- 65 793 frames, 36 minutes of 30 fps video -- and the float
+    kernels (adder_lean_kernel / adder_cr_kernel) take over ON THE SAME PLANES for the rest of the stream (slower, not
+    different: DESIGN section 4).  A stream that crosses the limit, with runs tens of thousands of frames long across it,
+    against the oracle -- the switch-over and the steady state behind it."""
+    A = _hip()
+    W, H, T = 128, 2, 66400
+    rng = np.random.default_rng(8)
+    clip = np.zeros((T, H, W, 1), np.uint8)
+    cur = rng.integers(0, 256, (H, W, 1)).astype(np.uint8)
+    cur[0, :8] = 0
+    change_at = set(rng.integers(1, T, 400).tolist()) | {65000, 65790, 65793, 65794, 65800, 66000}
+    for k in range(T):
+        if k in change_at:
+            m = rng.random((H, W, 1)) < 0.3
+            cur = np.where(m, rng.integers(0, 256, (H, W, 1)).astype(np.uint8), cur)
+        clip[k] = cur
+    for tm, dtm in ((O.DELTA_T, 255), (O.ABSOLUTE_T, 7650)):
+        ov = O.Video(W, H, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm, max_depth=24)
+        ov.ensure_capacity(26)
+        for v in (ov, hv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        k, total = 0, 0
+        while k < T:
+            nb = min(3700, T - k)
+            want = np.concatenate([ov.integrate_matrix(f) for f in clip[k:k + nb]])
+            got, offs = hv.integrate_batch(clip[k:k + nb])
+            assert len(got) == len(want) and np.array_equal(got, want), (tm, k)
+            total += len(got)
+            k += nb
+        assert total > 10000
+        hv.close()

@@ -77,6 +77,25 @@ def test_bounded_collapse_quiet_groups_break_at_every_position_with_ramp_and_fir
     hv.close()
 
 
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+@pytest.mark.parametrize("crf", [3, 9])
+def test_lean_kernel_quiet_groups_break_at_every_position_with_ramp_and_firings(time_mode, crf):
+    """adder_lean_kernel (Collapse with delta_t_max = ref_time at crf > 0: the lean step, not the lean-runs one): the same
+    group form in front of its quiet loop -- static rows with jitter inside the band, the ramp, firings, dark and black
+    rows, a flush at every position of a group."""
+    frames, H, W = 1088, 12, 128
+    rng = np.random.default_rng(29 + time_mode + crf)
+    clip, breaks = clips.quiet_group_clip(frames, H, W, rng, jitter=1)
+    for lens in ([frames], [64, 60, 37, 16, 100, 1, 5]):
+        ov, hv = _pair(W, H, 1, time_mode, 255, CRFS[crf])
+        assert _run_batches(ov, hv, clip, lens, rng, reset_every=320, crf=CRFS[crf]) > 0
+        hv.close()
+    clip3, _ = clips.quiet_group_clip(260, 7, 51, rng, jitter=2, C=3)
+    ov, hv = _pair(51, 7, 3, time_mode, 255, CRFS[crf])
+    _run_batches(ov, hv, clip3, [260], rng)
+    hv.close()
+
+
 def test_quiet_groups_full_size_static_and_default_quality_1080p():
     """1080p: static content through the lean-runs kernel and the reference's default mode at its default quality through the
     bounded Collapse kernel, 150 frames across chunk boundaries (the pop at frame 30, then quiet groups), against the oracle."""

@@ -7,7 +7,7 @@
 #    temporal depth, and of a 96-frame run with ONE frame per launch (the adder_lean1_kernel rows),
 # then writes summaries under gpurun_out/profiles_<round>/ (copy them into profiles/).
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p "$OUT"
@@ -41,11 +41,13 @@ pmc_passes() {  # $1 = tag, $2 = extra env, $3.. = bench args
         env $envs ADDER_HIP_NO_GRAPH=1 ADDER_BENCH_PLAN_STEPS=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/$tag/pmc_$st" -o pmc -- \
             $cmd > "$OUT/$tag/pmc_$st.log" 2>&1
     done
-    python "$REPO/tools/pmc_csv_summary.py" "$OUT/$tag" --traffic "$OUT/${ROUND}_traffic_$tag.json" > "$OUT/${ROUND}_pmc_$tag.csv"
+    # (FPL: frames every frame-kernel launch of the command covered -- bench.py scales the traffic by it; the frame counts
+    #  below are multiples of the 64-frame chunk, so that all launches are alike)
+    python "$REPO/tools/pmc_csv_summary.py" "$OUT/$tag" --traffic "$OUT/${ROUND}_traffic_$tag.json" --frames-per-launch ${FPL:-64} > "$OUT/${ROUND}_pmc_$tag.csv"
     rm -rf "$OUT/$tag"/pmc_*/
 }
-pmc_passes default "A=1" --frames 160
-pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96 --output events
+pmc_passes default "A=1" --frames 128
+FPL=1 pmc_passes one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 96 --output events
 pmc_passes default_mode_dtm7650_abs "A=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
 # 4. the reference default mode (Collapse, AbsoluteT, delta_t_max 7650: adder_cb_kernel) eager on one stream: kernel stats
 ADDER_HIP_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o bench -- \
@@ -70,8 +72,8 @@ pmc_passes cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 
 pmc_passes cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
 pmc_passes cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --output events
 pmc_passes cb_dtm7650_abs "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --output events
-pmc_passes lean_step_no_runs "ADDER_HIP_NO_LR=1" --frames 160 --output events
-pmc_passes events_output "A=1" --frames 160 --output events
+pmc_passes lean_step_no_runs "ADDER_HIP_NO_LR=1" --frames 128 --output events
+pmc_passes events_output "A=1" --frames 128 --output events
 kstats cr_dtm7650_delta "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --output events
 kstats cr_dtm7650_abs "ADDER_HIP_NO_RR=1" --delta-t-max 7650 --time-mode absolute_t --output events
 kstats cb_dtm7650_delta "ADDER_HIP_NO_RR=1 ADDER_HIP_NO_CR=1" --delta-t-max 7650 --output events
@@ -81,5 +83,12 @@ kstats default_mode_delta "A=1" --delta-t-max 7650 --output events
 kstats normal_dtm255_delta "A=1" --multi-mode normal --output events
 kstats normal_dtm7650_abs "A=1" --multi-mode normal --delta-t-max 7650 --time-mode absolute_t --output events
 kstats one_frame_per_launch "ADDER_HIP_FRAMES_PER_LAUNCH=1" --frames 128 --output events
+# 6. (round 5) the QUIET legs -- static content through the lean-runs kernel's quiet groups, the reference's default mode at
+#    its default quality (crf-3 numbers) through the bounded Collapse kernel's, config 5's shape (4K RGB): counters + kernel stats
+pmc_passes quiet_static "A=1" --frames 128 --content static --output events
+pmc_passes quiet_default_quality "A=1" --frames 128 --delta-t-max 7650 --time-mode absolute_t --crf-numbers 2,7,7 --output events
+kstats quiet_static "A=1" --content static --output events
+kstats quiet_default_quality "A=1" --delta-t-max 7650 --time-mode absolute_t --crf-numbers 2,7,7 --output events
+kstats quiet_config5_shape "A=1" --width 3840 --height 2160 --channels 3 --frames 64 --delta-t-max 7650 --time-mode absolute_t --crf-numbers 2,7,7 --output events
 rm -rf "$OUT"/stats "$OUT"/stats2 "$OUT"/stats3 "$OUT"/stats4
 ls -la "$OUT"
