@@ -761,6 +761,9 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 #ifndef ADDER_LR_QUIET_GROUPS
 #define ADDER_LR_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
 #endif
+#ifndef ADDER_LR_NARROW_EXPERIMENT
+#define ADDER_LR_NARROW_EXPERIMENT 0
+#endif
 #ifndef ADDER_LR_QUIET_REENTER
 #define ADDER_LR_QUIET_REENTER 1  // (0: the group test only in front of a launch's first stepped frame)
 #endif
@@ -920,7 +923,11 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
                     struct R12 { uint32_t a, b, c; };
                     gstore(seg, pos * REC, R12{w0[j], w1[j], w8[j]});
                 } else {
+#if ADDER_LR_NARROW_EXPERIMENT  // (measurement only: 4-byte records {unit | base_val << 8 | input << 16 | rho << 23}, no escape for rho >= 511)
+                    gstore(seg, pos * 4u, w8[j] | ((w0[j] < 511u ? w0[j] : 511u) << 23));
+#else
                     gstore(seg, pos * REC, make_uint2(w0[j], w8[j]));
+#endif
                 }
             }
 #else
@@ -2870,6 +2877,20 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
     return make_uint4(r.x, r.y, 0u, 0u);
 }
 
+#ifndef ADDER_LR_NARROW_EXPERIMENT
+#define ADDER_LR_NARROW_EXPERIMENT 0
+#endif
+// record `idx` of a segment's run at `base` (+ byte offset `off`)
+template <int FORMAT, bool ABS_T>
+__device__ __forceinline__ uint4 load_rec_at(const void *base, uint32_t off, uint32_t idx) {
+#if ADDER_LR_NARROW_EXPERIMENT
+    if constexpr (FORMAT == 5 && !ABS_T) {
+        const uint32_t w = gload_rec<uint32_t>(base, off + idx * 4u);
+        return make_uint4(w >> 23, w & 0x7fffffu, 0u, 0u);
+    }
+#endif
+    return lean_load_rec<ABS_T>(base, off + idx * lean_rec_bytes(ABS_T));
+}
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
     constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
@@ -2964,8 +2985,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (hl < (half ? pb : pa)) {
-                v = lean_load_rec<ABS_T>(park + (size_t)(2 * p) * seg_stride,
-                                         (half ? seg_stride + ob : oa) + hl * lean_rec_bytes(ABS_T));
+                v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa), hl);
             }
             return v;
         };
@@ -3173,7 +3193,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                     for (uint32_t i0 = 0; i0 < cnt[h]; i0 += kWave) {  // uniform trip count
                         uint4 rw = make_uint4(0u, 0u, 0u, 0u);
                         if (i0 + lane < cnt[h]) {
-                            rw = lean_load_rec<ABS_T>(seg_park, (i0 + lane) * lean_rec_bytes(ABS_T));
+                            rw = load_rec_at<FORMAT, ABS_T>(seg_park, 0u, i0 + lane);
                         }
                         record_round(rw, 0u);
                     }
