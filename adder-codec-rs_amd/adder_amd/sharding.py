@@ -28,17 +28,19 @@ def row_bands(height, world, chunk_rows=1):
     return bands
 
 
-def gather_peer_share(world, *, link_GBs=120.0, wire_bytes_per_unit_frame=1.45, root_chunk_us_per_plane=(160.0, 170.0),
+def gather_peer_share(world, *, link_GBs=120.0, wire_bytes_per_unit_frame=1.45, root_chunk_us_per_plane=(98.0, 150.0),
                       units=1920 * 1080, chunk=64):
     """Fraction of the rows every PEER should own when the bands' records are gathered to rank 0 over one xGMI link per
     peer (adder_amd.records): the peers' transfers (share * wire bytes / link) and root's own work (its band's frame kernel
     + the expansion of the whole plane) take equally long.  Defaults: what was measured on one MI355X for the 1080p headline
-    (0.159 records * 8 B + 3 tables * 4 B / 128 units per unit-frame; 160 us of frame kernel and 170 us of expansion per
-    64-frame chunk of the whole plane) and a conservative link rate.  Never more than an even split."""
+    (0.159 records * 8 B + 3 tables * 4 B / 128 units per unit-frame; round 5: 98 us of the lean-runs frame kernel and 150 us
+    of expansion per 64-frame chunk of the whole plane -- round 3 priced 160 + 170) and a conservative link rate.  The times scale
+    with the plane (they are given for `units` = 1080p).  Never more than an even split."""
     if world <= 1:
         return 1.0
     wire_us = units * chunk * wire_bytes_per_unit_frame / (link_GBs * 1e3)  # a whole plane's chunk over one link
-    lean_us, expand_us = root_chunk_us_per_plane
+    scale = units / (1920.0 * 1080.0)  # (the kernels' times grow with the plane like the wire bytes do)
+    lean_us, expand_us = root_chunk_us_per_plane[0] * scale, root_chunk_us_per_plane[1] * scale
     # share * wire_us == (1 - (world - 1) * share) * lean_us + expand_us
     share = (lean_us + expand_us) / (wire_us + (world - 1) * lean_us)
     return min(share, 1.0 / world)

@@ -266,7 +266,7 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
     consume() through the ring with wire records out (PCIe is no longer the bound: e ~ 0.006)."""
     import ctypes as Ct
     dev = torch.device("cuda", torch.cuda.current_device())
-    T = 160
+    T, WARM = 320, 160
     hv = None
     try:
         d_frames = torch.empty((T, Wd * Ht), dtype=torch.uint8, device=dev)
@@ -299,12 +299,15 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
                 assert L.adder_hip_frame_submit(hv.h, pin[k].ctypes.data, Wd, float(REF_TIME)) == 0
             while L.adder_hip_frames_in_flight(hv.h):
                 collect()
-        run(0, 32)  # warm: slots, pools; frames 0..31 also pass the start-up transient (everything pops at frame 30)
+        # warm: slots, pools -- one submit some 90 calls into a context's life takes 8-15 ms (the HIP runtime grows its own pools,
+        # once: tools/ring_probe.py; with 32 warm frames it fell into the timed region and read as 118 instead of 62 us per
+        # frame); frames 0..31 also pass the start-up transient (everything pops at frame 30)
+        run(0, WARM)
         total_b = total_e = 0
         t0 = time.perf_counter()
-        run(32, T)
+        run(WARM, T)
         el = time.perf_counter() - t0
-        n = T - 32
+        n = T - WARM
         return {"value": round(Wd * Ht * n / el / 1e6, 1), "unit": "Mpixels/s", "us_per_frame_sustained": round(el / n * 1e6, 1),
                 "frames": n, "events_per_pixel_frame": round(total_e / float(Wd * Ht * n), 5), "wire_bytes": total_b,
                 "note": "1080p scene, the reference's default quality (crf 3) and mode (Collapse, AbsoluteT, delta_t_max 7650), "

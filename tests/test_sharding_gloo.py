@@ -245,4 +245,4 @@ def test_root_heavy_bands_tile_the_plane_and_balance_the_gather():
     for world in (2, 4):
         p = S.gather_peer_share(world, link_GBs=120.0)
         wire_us = 1920 * 1080 * 64 * 1.45 / 120e3
-        assert abs(p * wire_us - ((1 - (world - 1) * p) * 160.0 + 170.0)) < 1e-6
+        assert abs(p * wire_us - ((1 - (world - 1) * p) * 98.0 + 150.0)) < 1e-6   # (round 5's kernel times: lean runs 98 us, expansion 150 us per chunk)
