@@ -238,6 +238,22 @@ struct AdderHipCtx {
         hipGraphExec_t out_graph = nullptr;  // the slot's hand-over (wire scatter + frame_out) as ONE launch
         uint64_t out_key[6] = {0, 0, 0, 0, 0, 0};  // what that graph baked in
     } fslot[4];
+    std::vector<hipStream_t> dummy_streams;  // ADDER_HIP_RING_SKIP_STREAMS (diagnostic)
+    // The per-frame ring's stream arrangement is MEASURED, like the graph instances: where the HIP runtime puts a stream among
+    // its hardware queues decides whether a dependency between two streams is cheap or costs tens of microseconds, and nothing
+    // in the API tells (one process ran the default-quality ring at 60 us per frame, the next at 115; profiles/r05_ring_queues.txt).
+    // Candidates: {second stream A, upload stream A}, {post-processing on the context's own stream, upload A}, and three more
+    // pairs of streams; each gets a window of 24 frames, the fastest stays for the context's life.
+    struct RingCand {
+        hipStream_t out_s = nullptr, in_s = nullptr;  // (borrowed from ring_streams)
+        bool post_on_main = false;
+        double us = 1e30;  // measured period per frame
+    };
+    std::vector<RingCand> ring_cands;
+    std::vector<hipStream_t> ring_streams;  // owned
+    int ring_cur = 0, ring_chosen = -1;
+    uint32_t ring_win_frames = 0, ring_win_waits = 0, ring_win_skip = 0;
+    std::chrono::steady_clock::time_point ring_win_t0;
     uint32_t graph_slot = 0;         // 1 + the frame slot whose description the batch being queued uses (0: the context's own)
     bool frame_only = false;         // the one-frame batch being queued stops after its frame kernel: the caller queues scan and
                                      // expansion itself, on another stream (the per-frame ring)
@@ -331,7 +347,9 @@ static void free_ctx(AdderHipCtx *c) {
     }
     if (c->frame_e) (void)hipEventDestroy(c->frame_e);
     if (c->out_s) (void)hipStreamDestroy(c->out_s);
-    if (c->in_s) (void)hipStreamDestroy(c->in_s);
+    if (c->in_s && c->in_s != c->out_s) (void)hipStreamDestroy(c->in_s);
+    for (hipStream_t d : c->dummy_streams) (void)hipStreamDestroy(d);
+    for (hipStream_t d : c->ring_streams) (void)hipStreamDestroy(d);
     if (c->in_e) (void)hipEventDestroy(c->in_e);
     for (void *p : {(void *)c->snap.slab, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
                     (void *)c->snap.dv_bd})
@@ -2456,7 +2474,25 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
                                    : frame_slot_events(c, time_spanned);
     int rc = frame_slot_prepare(c, fs, need, direct_out == nullptr);
     if (rc != ADDER_OK) return rc;
-    if (!c->out_s) HIPCHK(c, hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
+    if (!c->out_s) {
+        if (const char *e = getenv("ADDER_HIP_RING_SKIP_STREAMS")) {  // (diagnostic: shifts where the ring's streams land among the runtime's hardware queues)
+            for (int k = 0; k < atoi(e); ++k) {
+                hipStream_t dummy = nullptr;
+                HIPCHK(c, hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking));
+                c->dummy_streams.push_back(dummy);
+            }
+        }
+        if (const char *e = getenv("ADDER_HIP_RING_PRIO")) {  // (diagnostic: 1 = out_s, 2 = in_s, 3 = both as high-priority streams)
+            int lo_prio = 0, hi_prio = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            const int m = atoi(e);
+            if (m & 1) HIPCHK(c, hipStreamCreateWithPriority(&c->out_s, hipStreamNonBlocking, hi_prio));
+            if ((m & 2) && !c->in_s) HIPCHK(c, hipStreamCreateWithPriority(&c->in_s, hipStreamNonBlocking, hi_prio));
+            if (m & 4) HIPCHK(c, hipStreamCreateWithPriority(&c->out_s, hipStreamNonBlocking, lo_prio));
+            if ((m & 8) && !c->in_s) HIPCHK(c, hipStreamCreateWithPriority(&c->in_s, hipStreamNonBlocking, lo_prio));
+        }
+        if (!c->out_s) HIPCHK(c, hipStreamCreateWithFlags(&c->out_s, hipStreamNonBlocking));
+    }
     if (!c->frame_e) HIPCHK(c, hipEventCreateWithFlags(&c->frame_e, hipEventDisableTiming));
     // The ring's uploads go on a stream of their own, so that the next frame's 2 MB cross the link beside this frame's
     // kernels instead of behind them: 220 -> 84 us per 1080p frame at the default quality (sparse frames: real video).
@@ -2472,16 +2508,48 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
     const bool own_upload = !direct_out && !own_upload_off;
     hipStream_t up = c->stream;
     if (own_upload) {
+        static const bool upload_on_out = env_flag("ADDER_HIP_RING_UPLOAD_ON_OUT");  // (diagnostic: uploads share the hand-over's stream)
+        if (!c->in_s && upload_on_out) c->in_s = c->out_s;
         if (!c->in_s) HIPCHK(c, hipStreamCreateWithFlags(&c->in_s, hipStreamNonBlocking));
         if (!c->in_e) HIPCHK(c, hipEventCreateWithFlags(&c->in_e, hipEventDisableTiming));
         up = c->in_s;
+    }
+    // the ring's stream arrangement for this frame (AdderHipCtx::RingCand): the chosen one, or the candidate being measured
+    static const bool ring_tune_off = env_flag("ADDER_HIP_RING_NO_TUNE");
+    static const bool post_on_main_env = env_flag("ADDER_HIP_RING_POST_ON_MAIN");
+    hipStream_t ring_out = c->out_s;
+    bool post_on_main = post_on_main_env;
+    if (own_upload && !ring_tune_off && !post_on_main_env) {
+        if (c->ring_cands.empty()) {
+            // the context's own pair, post-processing on the context's stream, and three more pairs -- a spare stream between
+            // two pairs, so that the pairs sit at every offset of the runtime's round robin over its (four) hardware queues
+            c->ring_cands.resize(5);
+            c->ring_cands[0].out_s = c->out_s; c->ring_cands[0].in_s = c->in_s;
+            c->ring_cands[1].out_s = c->out_s; c->ring_cands[1].in_s = c->in_s; c->ring_cands[1].post_on_main = true;
+            for (int k = 2; k < 5; ++k) {
+                hipStream_t t[3] = {nullptr, nullptr, nullptr};
+                for (hipStream_t &x : t) {
+                    HIPCHK(c, hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+                    c->ring_streams.push_back(x);
+                }
+                c->ring_cands[k].out_s = t[1];  // (t[0]: the spare)
+                c->ring_cands[k].in_s = t[2];
+            }
+            c->ring_cur = 0;
+            c->ring_win_frames = c->ring_win_waits = 0;
+            c->ring_win_skip = 6;
+        }
+        const AdderHipCtx::RingCand &rc_ = c->ring_cands[c->ring_chosen >= 0 ? c->ring_chosen : c->ring_cur];
+        up = rc_.in_s;
+        ring_out = rc_.out_s;
+        post_on_main = rc_.post_on_main;
     }
     if (row_stride == rowlen)
         HIPCHK(c, hipMemcpyAsync(fs.d_frame, frame, c->n_units, hipMemcpyHostToDevice, up));
     else
         HIPCHK(c, hipMemcpy2DAsync(fs.d_frame, rowlen, frame, row_stride, rowlen, c->rows, hipMemcpyHostToDevice, up));
     if (own_upload) {
-        HIPCHK(c, hipEventRecord(c->in_e, c->in_s));
+        HIPCHK(c, hipEventRecord(c->in_e, up));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->in_e, 0));
     }
     // the slot's own batch description: the shared one may still be read by the copy engine for the frame before
@@ -2528,8 +2596,13 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         c->poisoned = true;
         return rc;
     }
-    HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->out_s, c->frame_e, 0));
+    // where the frame's scan / expansion / hand-over go: the ring's second stream (behind an event), or -- post_on_main -- the
+    // context's own stream behind the frame kernel (no cross-stream dependency at all)
+    hipStream_t post_s = post_on_main ? c->stream : ring_out;
+    if (!post_on_main) {
+        HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(ring_out, c->frame_e, 0));
+    }
     const bool wire = c->f_wire && !direct_out;
     fs.wire = wire;
     // the hand-over: wire scatter (9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw
@@ -2577,15 +2650,15 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
             HIPCHK(c, e);
             memcpy(fs.out_key, key, sizeof key);
         }
-        HIPCHK(c, hipGraphLaunch(fs.out_graph, c->out_s));
+        HIPCHK(c, hipGraphLaunch(fs.out_graph, post_s));
     } else {
-        rc = hand_over(c->out_s);
+        rc = hand_over(post_s);
         if (rc != ADDER_OK) {
             c->poisoned = true;
             return rc;
         }
     }
-    HIPCHK(c, hipEventRecord(fs.done, c->out_s));
+    HIPCHK(c, hipEventRecord(fs.done, post_s));
     c->f_submitted += 1;
     return ADDER_OK;
 }
@@ -2594,7 +2667,42 @@ static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t 
     if (c->f_collected == c->f_submitted) return fail(c, ADDER_E_BAD_PARAMS, "no frame in flight");
     HIPCHK(c, hipSetDevice(c->device));
     AdderHipCtx::FrameSlot &fs = c->fslot[c->f_collected % c->f_slots];
-    HIPCHK(c, hipEventSynchronize(fs.done));
+    if (c->ring_chosen < 0 && !c->ring_cands.empty()) {
+        // the candidate's window: frames per wall-clock second while the caller keeps the ring full (a collect that has to
+        // wait means the GPU side is the bound; a caller paced by its source never measures, and needs no choice)
+        constexpr uint32_t kWindow = 24;
+        const auto t0 = std::chrono::steady_clock::now();
+        HIPCHK(c, hipEventSynchronize(fs.done));
+        const auto t1 = std::chrono::steady_clock::now();
+        if (c->ring_win_skip) {  // (frames queued under the candidate before are still draining)
+            if (--c->ring_win_skip == 0u) {
+                c->ring_win_t0 = t1;
+                c->ring_win_frames = c->ring_win_waits = 0;
+            }
+        } else {
+            c->ring_win_frames += 1;
+            if (std::chrono::duration<double, std::micro>(t1 - t0).count() > 3.0) c->ring_win_waits += 1;
+            if (c->ring_win_frames == kWindow) {
+                if (c->ring_win_waits * 2u >= kWindow) {
+                    c->ring_cands[c->ring_cur].us = std::chrono::duration<double, std::micro>(t1 - c->ring_win_t0).count() / kWindow;
+                    if (++c->ring_cur == (int)c->ring_cands.size()) {
+                        int best = 0;
+                        for (int k = 1; k < (int)c->ring_cands.size(); ++k)
+                            if (c->ring_cands[k].us < c->ring_cands[best].us) best = k;
+                        c->ring_chosen = best;
+                        if (getenv("ADDER_HIP_DEBUG_TUNE")) {
+                            fprintf(stderr, "[adder_hip] ring stream arrangements (us per frame):");
+                            for (const auto &rc_ : c->ring_cands) fprintf(stderr, " %.1f", rc_.us);
+                            fprintf(stderr, " -> %d\n", best);
+                        }
+                    }
+                }
+                c->ring_win_skip = 6;  // (next candidate, or the same one again when the caller was the bound)
+            }
+        }
+    } else {
+        HIPCHK(c, hipEventSynchronize(fs.done));
+    }
     c->f_collected += 1;
     const FrameResult *res = reinterpret_cast<const FrameResult *>(fs.h_hdr);
     c->last_new_features = res->new_features;

@@ -1589,6 +1589,9 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
 #ifndef ADDER_CB_QUIET_PATH
 #define ADDER_CB_QUIET_PATH 1
 #endif
+#ifndef ADDER_CB_GENERAL_PRIO
+#define ADDER_CB_GENERAL_PRIO 0  // s_setprio level of a wave inside the general loop (0: off)
+#endif
 #ifndef ADDER_CB_QUIET_GROUPS
 #define ADDER_CB_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
 #endif
@@ -1684,6 +1687,9 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     i = nb;
 #endif
     while (i < nb) {  // quiet frames, then general frames up to the next input group, then the same again
+#if ADDER_CB_GENERAL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if ADDER_CB_QUIET_PATH
     // ---------------- quiet frames (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
     // A wave ALL of whose units start the launch popped down to their root (or black: a d = 128 root) stays in this loop
@@ -1814,6 +1820,12 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     // (general frames up to the end of the input group -- the quiet test above then gets another look; the bound is the
     // loop's own, the frames carry no test)
     const uint32_t i_end = ADDER_CB_QUIET_PATH ? ((i / kCbInFrames + 1u) * kCbInFrames < nb ? (i / kCbInFrames + 1u) * kCbInFrames : nb) : nb;
+#if ADDER_CB_GENERAL_PRIO
+    // A wave in the general loop is the launch's critical path on mostly quiet content (it steps 128 units through ~470
+    // instructions per frame while its quiet neighbours are done after a few hundred per GROUP): it asks the SIMD's
+    // arbiter for priority, and gives it back when it returns to the quiet loop
+    __builtin_amdgcn_s_setprio(ADDER_CB_GENERAL_PRIO);
+#endif
     for (; i < i_end; ++i) {
         // (a frame handed over by the quiet loop mid-group finds its group staged)
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);

@@ -187,8 +187,9 @@ def end_to_end(hv, d_frames, T, units, Wd, Ht, Cn):
         for _ in range(3):
             collect()
         # ... and the HIP runtime grows its own pools once, about 90 submits into a process (one call of 8 - 15 ms,
-        # tools/ring_probe.py): a warm ring is what a source that decodes thousands of frames sees
-        for k in range(120):
+        # tools/ring_probe.py), and the ring measures its five stream arrangements over its first 150 frames
+        # (AdderHipCtx::RingCand): a warm ring is what a source that decodes thousands of frames sees
+        for k in range(200):
             if L.adder_hip_frames_in_flight(hv.h) == 3:
                 collect()
             assert L.adder_hip_frame_submit(hv.h, pin[k % (n_calls + 1)].ctypes.data, Wd * Cn, float(REF_TIME)) == 0
@@ -266,7 +267,7 @@ def end_to_end_default_quality(torch, A, Wd, Ht):
     consume() through the ring with wire records out (PCIe is no longer the bound: e ~ 0.006)."""
     import ctypes as Ct
     dev = torch.device("cuda", torch.cuda.current_device())
-    T, WARM = 320, 160
+    T, WARM = 400, 240
     hv = None
     try:
         d_frames = torch.empty((T, Wd * Ht), dtype=torch.uint8, device=dev)

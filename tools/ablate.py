@@ -1,6 +1,6 @@
 """Timing helper (not a test): frame-loop time per frame for a mode, best of 4 batches.
 env: CONTENT (0 static,1 noise,2 scene), MULTI (0 normal,1 collapse), TMODE (0 delta,1 abs), DTM, W, H, C, T,
-CRF ("baseline,max,velocity", default 0,0,10)"""
+CRF ("baseline,max,velocity", default 0,0,10), ITERS (batches, default 4: graph contexts need ~16 to settle their launch plan)"""
 import json
 import os
 import sys
@@ -24,7 +24,7 @@ crf = [int(x) for x in E.get("CRF", "0,0,10").split(",")]
 hv = A.HipVideo(W, H, Cn, time_mode=tmode, multi_mode=multi, delta_t_max=dtm, c_thresh_start=crf[0], c_counter_start=0, max_depth=20)
 hv.set_crf_parameters(crf[1], crf[2])
 best, n = 1e9, -1
-for it in range(4):
+for it in range(int(E.get("ITERS", 4))):
     hv.reset()
     hv.integrate_device(d_frames, d_ev, d_off, stream=st)
     n = hv.finish()

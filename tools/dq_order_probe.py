@@ -23,3 +23,6 @@ for _ in range(16):
 print("with a live headline context + 8 GB of buffers", B.end_to_end_default_quality(torch, A, W, H)["us_per_frame_sustained"])
 r = B.end_to_end(hv, d_frames, 300, W * H, W, H, 1)
 print("after end_to_end legs", B.end_to_end_default_quality(torch, A, W, H)["us_per_frame_sustained"])
+hv.close()
+print("... and with that context closed", B.end_to_end_default_quality(torch, A, W, H)["us_per_frame_sustained"])
+print("again", B.end_to_end_default_quality(torch, A, W, H)["us_per_frame_sustained"])
