@@ -19,6 +19,10 @@ MULTI_NORMAL, MULTI_COLLAPSE = 0, 1
 CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE = 0, 1, 2
 D_MAX, D_ZERO_INTEGRATION, D_EMPTY, C_NONE = 127, 128, 255, 0xFF
 
+# adder_hip_last_batch_kernel (include/adder_hip.h)
+(KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS, KERNEL_LEAN_RUNS,
+ KERNEL_LAZY_LEVELS) = range(8)
+
 OK = 0
 E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED = -1, -2, -3, -4, -5, -6, -7
 
@@ -158,6 +162,7 @@ SYMBOLS = {
     "adder_hip_enable_running_intensities": (_i32, [_vp, _i32]),
     "adder_hip_last_batch_ms": (_f32, [_vp]),
     "adder_hip_launch_plan_settled": (_i32, [_vp]),
+    "adder_hip_last_batch_kernel": (_u32, [_vp]),
     "adder_hip_integrate_sparse": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "adder_hip_integrate_sparse_device": (_i32, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp]),
     "adder_hip_debug_timeline": (_i32, [_vp, _vp]),

@@ -400,6 +400,10 @@ class HipVideo:
     def set_launch_timing(self, on=True):
         N.check(self.h, self.L.adder_hip_set_launch_timing(self.h, int(on)))
 
+    def last_batch_kernel(self):
+        """ADDER_KERNEL_* of the batch queued last (include/adder_hip.h)."""
+        return int(self.L.adder_hip_last_batch_kernel(self.h))
+
     def launch_plan_settled(self):
         return bool(self.L.adder_hip_launch_plan_settled(self.h))
 

@@ -1069,7 +1069,8 @@ ADDER_HD uint32_t quiet_group_apply(float &S, float &dt, float &bdt, float &thr,
     if (fired) *fired = n;
     if ((dmx > dmn ? dmx : dmn) > cth_min) return kQuietNo;  // the extremes bound |v - base_val| of every frame
     if (!popped && g.mx != 0u && !(dtm_f > 0.0f)) return kQuietNo;  // an unpopped unit is in here as a black one: quiet on zeros only
-    if (!popped && dtm_f > 0.0f && thr != 0.0f && !(fadd(dt, fmul((float)n, T)) < dtm_f)) return kQuietNo;  // it pops inside the group
+    // ... it may pop inside the group (a black root accumulates no delta_t while it sees zeros, :449)
+    if (!popped && dtm_f > 0.0f && (thr != 0.0f || g.sum != 0u) && !(fadd(dt, fmul((float)n, T)) < dtm_f)) return kQuietNo;
     if (thr == 0.0f) {
         // a black root (integration 0, d = 128) fires on every zero without accumulating (:449): idempotent
         if (g.sum != 0u) return kQuietSlow;
@@ -1207,10 +1208,71 @@ ADDER_HD void cz_node_step(CzNode &n, uint32_t v, float T, uint32_t t) {
 }
 // the root of the arena that started right after frame t0, after frames t0 + 1 .. t1 (get(f) = the unit's byte of frame f)
 template <class Get>
+ADDER_HD CzNode cz_replay_scan(uint32_t t0, uint32_t t1, float T, const Get &get);
+template <class Get>
 ADDER_HD CzNode cz_replay(uint32_t t0, uint32_t t1, float T, const Get &get) {
     CzNode n{0.0f, 0.0f, 0.0f, 0.0f, t0, false};
     for (uint32_t f = t0 + 1u; f <= t1; ++f) cz_node_step(n, get(f), T, f);
+#ifdef ADDER_CZ_SCAN_CHECK  // (the CPU harness: every replay it makes is also made in integers, cz_replay_scan below)
+    if (t0 + 1u <= t1) {
+        const CzNode m = cz_replay_scan(t0, t1, T, get);
+        if (!(f32_to_bits(m.S) == f32_to_bits(n.S) && f32_to_bits(m.dt) == f32_to_bits(n.dt) && f32_to_bits(m.bdt) == f32_to_bits(n.bdt) &&
+              f32_to_bits(m.thr) == f32_to_bits(n.thr) && m.last == n.last && m.has == n.has))
+            ADDER_CZ_SCAN_CHECK();
+    }
+#endif
     return n;
+}
+
+// The same replay in integers (what the kernel runs): a fresh arena's root fires at its first frame and then whenever its
+// running sum reaches 2^(floor(log2(sum at the previous firing)) + 1) (:427, :452-461) -- whenever the sum's exponent
+// grows; a root still at sum 0 fires on every frame without accumulating delta_t (:449) and with a full time step as its
+// event's delta_t (d = 128, :432-437).  So one pass of integer adds finds the LAST firing -- its frame, the sum before it,
+// its intensity, the delta_t-counted frames before it -- and the firing arm's float arithmetic (:427-447) runs once, on
+// those: all sums and frame counts are exact in binary32 (the bounded regime's conditions), so the result is cz_replay's
+// bit for bit (tests/test_device_logic_cpu.py compares the two on every window of its clips).
+struct CzScan {
+    uint32_t P, thr;      // running sum; the threshold as an integer (0 while the sum is 0)
+    uint32_t nz;          // frames that counted for delta_t so far
+    uint32_t last, Sb, I, nzb;  // the last firing: frame, sum before it, intensity, delta_t-counted frames before it
+    bool unit_prop;       // ... fired at d = 128 or on a zero sum: the event's delta_t takes a whole time step
+    bool has;
+};
+ADDER_HD CzScan cz_scan_start(uint32_t t0) { return CzScan{0u, 0u, 0u, t0, 0u, 0u, 0u, false, false}; }
+ADDER_HD void cz_scan_step(CzScan &c, uint32_t v, uint32_t f) {
+    const uint32_t Pn = c.P + v;
+    const bool fires = !c.has || Pn >= c.thr;
+    const bool zero = Pn == 0u;
+    if (fires) {
+        c.unit_prop = zero || (c.has ? c.thr == 0u : v == 0u);
+        c.last = f;
+        c.Sb = c.P;
+        c.I = v;
+        c.nzb = c.nz;
+        c.thr = zero ? 0u : 2u << (31u - (uint32_t)__builtin_clz(Pn | 1u));
+    }
+    c.nz += (fires && zero) ? 0u : 1u;
+    c.P = Pn;
+    c.has = true;
+}
+ADDER_HD CzNode cz_scan_finish(const CzScan &c, float T) {
+    CzNode n;
+    const float sum = (float)(c.Sb + c.I), integ_old = (float)c.Sb, I = (float)c.I;
+    const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);
+    const float prop = c.unit_prop ? 1.0f : fdiv_small(fsub(p2, integ_old), I);
+    n.bdt = fadd(fmul((float)c.nzb, T), fmul(T, prop));
+    n.thr = fadd(p2, p2);
+    n.S = (float)c.P;
+    n.dt = fmul((float)c.nz, T);
+    n.last = c.last;
+    n.has = c.has;
+    return n;
+}
+template <class Get>
+ADDER_HD CzNode cz_replay_scan(uint32_t t0, uint32_t t1, float T, const Get &get) {
+    CzScan c = cz_scan_start(t0);
+    for (uint32_t f = t0 + 1u; f <= t1; ++f) cz_scan_step(c, get(f), f);
+    return cz_scan_finish(c, T);
 }
 
 constexpr uint32_t kCzLevels = 6;    // levels 1 .. 6 of a flushed arena are kept between the count and the emission
@@ -1241,6 +1303,7 @@ ADDER_HD void cz_step(CzPx &s, uint32_t v, uint32_t cth, float T, float dtm_f, u
     p.old_thr0 = s.thr0;
     p.old_bdt0 = s.bdt0;
     p.n_lv = 0u;
+    for (uint32_t k = 0; k < kCzLevels; ++k) p.lv_bdt[k] = p.lv_thr[k] = 0.0f;
     p.depth_error = false;
     p.promoted.has = false;
     p.count = 0u;
@@ -1250,12 +1313,12 @@ ADDER_HD void cz_step(CzPx &s, uint32_t v, uint32_t cth, float T, float dtm_f, u
             uint32_t t0 = s.tfire;
             while (t0 + 1u < t) {
                 const CzNode n = cz_replay(t0, t - 1u, T, get);
-                if (p.n_lv < kCzLevels) {
-                    p.lv_bdt[p.n_lv] = n.bdt;
-                    p.lv_thr[p.n_lv] = n.thr;
-                } else {
-                    p.depth_error = true;
+                // (stores with constant indices: the arrays stay in registers on the device)
+                for (uint32_t k = 0; k < kCzLevels; ++k) {
+                    p.lv_bdt[k] = p.n_lv == k ? n.bdt : p.lv_bdt[k];
+                    p.lv_thr[k] = p.n_lv == k ? n.thr : p.lv_thr[k];
                 }
+                p.depth_error = p.depth_error || p.n_lv >= kCzLevels;
                 p.n_lv += 1u;
                 t0 = n.last;
             }
@@ -1287,8 +1350,8 @@ ADDER_HD void cz_emit(CzPx &s, const CzPlan &p, const StepConsts &sc, Emit &emit
             emit.filler(sc.running_t_u32);
         } else {
             emit.ev(f32_to_bits(p.old_thr0), event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
-            const uint32_t n = p.n_lv < kCzLevels ? p.n_lv : kCzLevels;
-            for (uint32_t k = 0; k < n; ++k) emit.ev(f32_to_bits(p.lv_thr[k]), event_time<ABS_T>(p.lv_bdt[k], s.lastf, sc));
+            for (uint32_t k = 0; k < kCzLevels; ++k)
+                if (k < p.n_lv) emit.ev(f32_to_bits(p.lv_thr[k]), event_time<ABS_T>(p.lv_bdt[k], s.lastf, sc));
         }
     }
     if (p.need_pop) {

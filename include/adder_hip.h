@@ -288,6 +288,16 @@ float adder_hip_last_batch_ms(AdderHipCtx *ctx);
  * a few instances (2 batches each, 6 instances -- the first on one stream, measured twice more at the end) and keep the fastest; this returns 1 once the last batch's length
  * has settled (always 1 for single-chunk batches and with ADDER_HIP_NO_GRAPH). */
 int adder_hip_launch_plan_settled(const AdderHipCtx *ctx);
+/* Which frame kernel the batch queued last ran (diagnostics; the parity tests assert the kernel they mean to test). */
+#define ADDER_KERNEL_LEAN 0u          /* adder_lean_kernel / adder_lean1*_kernel */
+#define ADDER_KERNEL_GENERIC 1u       /* adder_frame_kernel */
+#define ADDER_KERNEL_CONTINUOUS 2u    /* adder_cont_kernel */
+#define ADDER_KERNEL_BOUNDED 3u       /* adder_cb_kernel: the bounded Collapse step with stepped levels */
+#define ADDER_KERNEL_CONSTANT_RUNS 4u /* adder_cr_kernel */
+#define ADDER_KERNEL_RUN_RECORDS 5u   /* adder_rr_kernel */
+#define ADDER_KERNEL_LEAN_RUNS 6u     /* adder_lr_kernel */
+#define ADDER_KERNEL_LAZY_LEVELS 7u   /* adder_cz_kernel: the bounded Collapse regime, roots only, levels replayed from the input */
+unsigned adder_hip_last_batch_kernel(const AdderHipCtx *ctx);
 /* Diagnostics (environment ADDER_HIP_TIMELINE=1): first start / last end of the kernels of the last batch, in 10 ns
  * ticks of the device's constant clock: dst[4 kinds: frame, scan, offsets, expansion][64 chunks][2]. */
 int adder_hip_debug_timeline(AdderHipCtx *ctx, unsigned long long *dst);

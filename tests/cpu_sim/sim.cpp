@@ -11,6 +11,8 @@
 
 #include <vector>
 
+static unsigned long long g_cz_scan_mismatches = 0;  // integer replays (cz_replay_scan) that differ from the stepped ones
+#define ADDER_CZ_SCAN_CHECK() (++g_cz_scan_mismatches)
 #include "adder_pixel.hpp"
 
 using namespace adder;
@@ -551,6 +553,7 @@ int sim_integrate_cz_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     if (pos > cap && rc == 0) rc = -4;
     return rc;
 }
+uint64_t sim_cz_scan_mismatches() { return g_cz_scan_mismatches; }
 uint64_t sim_cz_steps(const Sim *s) { return s->cz_steps; }
 uint64_t sim_cz_replays(const Sim *s) { return s->cz_replays; }
 

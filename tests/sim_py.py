@@ -78,6 +78,8 @@ def lib():
     for f in (L.sim_cz_steps, L.sim_cz_replays):
         f.restype = C.c_uint64
         f.argtypes = [vp]
+    L.sim_cz_scan_mismatches.restype = C.c_uint64
+    L.sim_cz_scan_mismatches.argtypes = []
     L.sim_integrate_cr_block.restype = i32
     L.sim_integrate_cr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate.restype = i32
@@ -254,6 +256,11 @@ class Sim:
     def cz_counts(self):
         """(unit-frames stepped, input bytes fetched by replays)"""
         return self.L.sim_cz_steps(self.h), self.L.sim_cz_replays(self.h)
+
+    @property
+    def cz_scan_mismatches(self):
+        """integer replays (cz_replay_scan, what the kernel runs) that differed from the stepped replay, process-wide"""
+        return self.L.sim_cz_scan_mismatches()
 
     def integrate_cr_block(self, frames, time_spanned):
         """nb frames as ONE launch of the constant-run step (c_thresh 0 throughout); (rc, events frame-major)."""

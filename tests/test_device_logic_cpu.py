@@ -867,6 +867,7 @@ def test_cz_lazy_levels_match_the_oracle(time_mode, crf):
             total += len(got)
             k += nb
         assert sv.plan_mismatches == 0 and sv.cz_counts[0] == 200 * 63
+        assert sv.cz_scan_mismatches == 0   # every replay made above was also made in integers (cz_replay_scan: the kernel's form)
         # the planes it left: the other steps take over (and the lazy step then refuses: its history is no longer its own)
         for j in range(200, frames):
             want = ov.integrate_matrix(clip[j])
@@ -898,5 +899,6 @@ def test_cz_other_windows_rgb_and_deep_chains():
                 rc, got = sv.integrate_cz_block(clip[k:k + nb], float(ref_time))
                 assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (ref_time, dtm_frames, Cn, tm, k)
                 k += nb
+            assert sv.cz_scan_mismatches == 0
     ov, sv = _cb_pair(6, 5, 1, O.DELTA_T, 255 * 33, crf=CRFS[3])
     assert sv.integrate_cz_block(clips.make_clip("runs", 2, 5, 6, 1, seed=1), 255.0)[0] == -7
