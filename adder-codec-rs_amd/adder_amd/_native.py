@@ -20,8 +20,8 @@ CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE = 0, 1, 2
 D_MAX, D_ZERO_INTEGRATION, D_EMPTY, C_NONE = 127, 128, 255, 0xFF
 
 # adder_hip_last_batch_kernel (include/adder_hip.h)
-(KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS, KERNEL_LEAN_RUNS,
- KERNEL_LAZY_LEVELS) = range(8)
+(KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS,
+ KERNEL_LEAN_RUNS) = range(7)
 
 OK = 0
 E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED = -1, -2, -3, -4, -5, -6, -7

@@ -69,8 +69,6 @@ struct AdderHipCtx {
         bool generic_sticky = false;
         uint8_t *cth_px = nullptr, *cctr_px = nullptr, *fset = nullptr, *running = nullptr;
         bool perpx = false, has_running = false;
-        uint8_t *cz_hist = nullptr;
-        bool has_cz = false;
     } snap;
     // feature-driven rate control + ROI (video.rs:825-837, 865-1112, 1291-1293)
     bool feat_detect = false, feat_adjust = false;
@@ -112,12 +110,6 @@ struct AdderHipCtx {
     // time_spanned, so every arena is a function of (its run's intensity, the run's length) -- adder_pixel.hpp
     bool cr_valid = true;
     float cr_time = 0.0f;
-    // lazy levels (adder_cz_kernel): every dense batch since the reset ran it, with this time step; the stream's last
-    // kCzHistory input frames, row (frame since the reset) % kCzHistory, cz_stride bytes each
-    bool cz_valid = true;
-    float cz_time = 0.0f;
-    uint8_t *cz_hist = nullptr;
-    size_t cz_stride = 0;
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
@@ -360,7 +352,7 @@ static void free_ctx(AdderHipCtx *c) {
     for (hipStream_t d : c->ring_streams) (void)hipStreamDestroy(d);
     if (c->in_e) (void)hipEventDestroy(c->in_e);
     for (void *p : {(void *)c->snap.slab, (void *)c->snap.dv_integ, (void *)c->snap.dv_dt, (void *)c->snap.dv_bdt,
-                    (void *)c->snap.dv_bd, (void *)c->snap.cz_hist, (void *)c->cz_hist})
+                    (void *)c->snap.dv_bd})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->launch_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->post_events) (void)hipEventDestroy(e);
@@ -506,8 +498,6 @@ static int init_state(AdderHipCtx *c) {
     c->frac_time_seen = false;
     c->cr_valid = true;
     c->cr_time = 0.0f;
-    c->cz_valid = true;
-    c->cz_time = 0.0f;
     c->dtm_max_seen = p.delta_t_max;
     c->perpx = false;
     c->sparse_mode = false;
@@ -1152,7 +1142,7 @@ static int launch_feature_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t var
 // 30 us of a 160 us launch were this epilogue.)
 static uint32_t lazy_state_bit(const AdderHipCtx *c, uint32_t variant, bool more_launches) {
     static const bool off = env_flag("ADDER_HIP_NO_LAZY_STATE");
-    return (more_launches && (variant & (256u | 512u | 4096u)) && !c->running_enabled && !off) ? 2048u : 0u;
+    return (more_launches && (variant & (256u | 512u)) && !c->running_enabled && !off) ? 2048u : 0u;
 }
 
 static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t s, hipStream_t s2,
@@ -1405,8 +1395,6 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
         HIPCHK(c, snap_copy(&n.cctr_px, c->cctr_px, c->n_pad, s));
     }
     if (c->fset) HIPCHK(c, snap_copy(&n.fset, c->fset, (size_t)c->rows * c->p.width, s));
-    n.has_cz = c->cz_valid && c->cz_hist;  // (the lazy-levels kernel's input history belongs to the state)
-    if (n.has_cz) HIPCHK(c, snap_copy(&n.cz_hist, c->cz_hist, (size_t)kCzHistory * c->cz_stride, s));
     n.has_running = c->running != nullptr;
     if (c->running) HIPCHK(c, snap_copy(&n.running, c->running, c->n_pad, s));
     n.running_t = c->running_t;
@@ -1439,7 +1427,6 @@ static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
         HIPCHK(c, hipMemcpyAsync(c->cctr_px, n.cctr_px, c->n_pad, hipMemcpyDeviceToDevice, s));
     }
     if (c->fset && n.fset) HIPCHK(c, hipMemcpyAsync(c->fset, n.fset, (size_t)c->rows * c->p.width, hipMemcpyDeviceToDevice, s));
-    if (n.has_cz) HIPCHK(c, hipMemcpyAsync(c->cz_hist, n.cz_hist, (size_t)kCzHistory * c->cz_stride, hipMemcpyDeviceToDevice, s));
     c->perpx = n.perpx;
     if (c->running && n.has_running) HIPCHK(c, hipMemcpyAsync(c->running, n.running, c->n_pad, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(uint32_t), s));
@@ -1531,16 +1518,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
                     !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
-    // lazy levels (adder_cz_kernel) for the rest of the bounded Collapse regime: only the roots are stepped, the levels are
-    // replayed from the last kCzHistory frames' bytes -- every dense batch since the reset must have run it with this time
-    // step (the header's age field and the history ring are its own), and an unpopped root must fit the history
-    const bool cz_off = env_flag("ADDER_HIP_NO_CZ");
-    const bool cz = cb && !cr && !rr && !cz_off && c->cz_valid && !fpath && (c->cz_time == 0.0f || c->cz_time == time_spanned) &&
-                    (double)std::max(c->p.delta_t_max, c->dtm_max_seen) <= (double)kCzHistory * (double)time_spanned &&
-                    c->max_depth > kCzLevels;
-    if (!cz) c->cz_valid = false;  // (sticky until adder_hip_reset, a rolled-back batch included -- like cr_valid)
-    c->cz_time = time_spanned;
-    const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) | (cz ? 4096u : 0u) |
+    const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |
@@ -1549,10 +1527,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     if (lr) {
         int rc_ = ensure_lr_tab(c, time_spanned, stream);
         if (rc_ != ADDER_OK) return rc_;
-    }
-    if (cz && !c->cz_hist) {
-        c->cz_stride = (size_t)c->num_waves * kWaveUnits;
-        HIPCHK(c, dalloc(&c->cz_hist, (size_t)kCzHistory * c->cz_stride));
     }
     if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
         std::vector<uint8_t> tab(256u * kRrTabRows);
@@ -1647,10 +1621,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         b.snap_dv_bdt = sd ? c->snap.dv_bdt : nullptr;
         b.snap_dv_bd = sd ? c->snap.dv_bd : nullptr;
     }
-    b.cz_hist = c->cz_hist;
-    b.cz_stride = (uint32_t)c->cz_stride;
-    b.cz_frames_before = (uint32_t)c->frames_done;
-    b.cz_keep_from = num_frames > kCzHistory ? num_frames - kCzHistory : 0u;
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
@@ -2154,7 +2124,6 @@ extern "C" unsigned adder_hip_last_batch_kernel(const AdderHipCtx *c) {
     if (v & 8u) return ADDER_KERNEL_CONTINUOUS;
     if (v & 512u) return ADDER_KERNEL_RUN_RECORDS;
     if (v & 128u) return ADDER_KERNEL_CONSTANT_RUNS;
-    if (v & 4096u) return ADDER_KERNEL_LAZY_LEVELS;
     if (v & 32u) return ADDER_KERNEL_BOUNDED;
     if (v & 4u) return ADDER_KERNEL_GENERIC;
     if (v & 256u) return ADDER_KERNEL_LEAN_RUNS;

@@ -170,13 +170,6 @@ struct BatchArgs {
     // diagnostics (null in normal operation): first start / last end of every kernel of the batch on the 100 MHz
     // constant clock, [kernel kind 0 frame, 1 scan, 2 offsets, 3 expansion][chunk][2]  (tools/timeline_probe.py)
     unsigned long long *timeline;
-    // Lazy levels (adder_cz_kernel): the last kCzHistory input frames of the stream, row (frame index since the reset) %
-    // kCzHistory, cz_stride bytes per row (whole segments).  A launch whose replays reach behind the batch's first frame
-    // reads them here; the launches that hold the batch's last kCzHistory frames (frame >= cz_keep_from) write theirs back.
-    uint8_t *cz_hist;
-    uint32_t cz_stride;
-    uint32_t cz_frames_before;  // frames since the reset before this batch
-    uint32_t cz_keep_from;
 };
 constexpr uint32_t kTimelineChunks = 64;
 constexpr uint32_t kMaxBands = 16;  // bands one adder_expand_bands_kernel launch takes (more: one launch per band)

@@ -1951,527 +1951,11 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_
     const uint32_t lane = tid & (kWave - 1);
     timeline_mark(b, 0u, f, false);
     // (a capped grid walks the segments, like the lean kernel; the wave's LDS slice is its own, no barrier needed)
-    for (uint32_t gw0 = blockIdx.x * kWavesPerBlock + tid / kWave; gw0 < a.num_waves; gw0 += gridDim.x * kWavesPerBlock) {
-#ifdef ADDER_DBG_SEG_ROT  // (experiment: which segments a launch starts with)
-        const uint32_t gw = (gw0 + ADDER_DBG_SEG_ROT) % a.num_waves;
-#else
-        const uint32_t gw = gw0;
-#endif
+    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
         if (full) cb_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_w[tid / kWave]);
         else cb_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_w[tid / kWave]);
-    }
-    timeline_mark(b, 0u, f, true);
-}
-
-// ------------------------------------------------------------------------------------------
-// K1, lazy levels -- `adder_cz_kernel<ABS_T>`: the bounded Collapse regime (crf > 0 included) with ONLY THE ROOTS stepped
-// (adder_pixel.hpp, LAZY LEVELS): level k + 1 of an arena is the root of the arena that started right after level k's last
-// firing, so the levels are REPLAYED from the unit's last input bytes when a flush emits them, pop_top promotes one or
-// the batch ends -- the last kCzHistory frames' bytes are all a replay can want (delta_t_max <= kCzHistory * time_spanned;
-// the host checks).  The wave's LDS slice is a ring of 64 input rows: the group of 16 frames being stepped, the next one
-// on its way, and the 32 frames behind; frames from before the launch come from the batch's own frames or, before the
-// batch, from the context's history ring (BatchArgs::cz_hist), and only for a wave that starts the launch with an
-// unpopped root that has not just fired.  No level storage, no walk: a frame in which no unit of the wave flushes, fires
-// or reaches delta_t_max is two adds per unit; a group of 16 frames in which no unit flushes or pops is decided at once
-// (quiet_group_apply, unpopped roots included).  The root's last firing travels between launches as its age in the
-// header word (kHdrAgeShift).  Records, logs and expansion are the bounded Collapse kernel's (EmitCb / SegLog / format 0).
-// ------------------------------------------------------------------------------------------
-#ifndef ADDER_CZ_WAVES_PER_SIMD
-#define ADDER_CZ_WAVES_PER_SIMD 4
-#endif
-#ifndef ADDER_CZ_GROUPS
-#define ADDER_CZ_GROUPS 1  // (0: A/B build without the group form)
-#endif
-constexpr uint32_t kCzRows = 2u * kCzHistory;  // rows of the input ring
-constexpr uint32_t kCzT0 = 2048u;              // the launch's first frame in the step's frame numbering (earlier frames: below)
-static_assert(kCzT0 % kCzRows == 0u && kMaxFramesPerLaunch <= kCzRows && kCzHistory % kCbInFrames == 0u && kCbInFrames == kQuietGroup,
-              "the ring holds a launch's frames 32 rows behind the history");
-__device__ __forceinline__ uint32_t cz_row(uint32_t t) { return (t + kCzHistory) & (kCzRows - 1u); }
-
-// the 32 frames in front of the launch -> rows 0 .. 31 (issue only; the caller waits)
-template <bool FULL>
-__device__ __forceinline__ void cz_stage_history(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t n_units_u, uint32_t sgw,
-                                                 uint32_t u0, uint32_t lane, uint8_t *ring, bool direct) {
-    constexpr uint32_t N = kUnitsPerLane;
-    using InT = typename VecOf<uint8_t, N>::type;
-    const uint8_t *const frames = uniform_ptr(b->frames);
-    const uint8_t *const hist = uniform_ptr(b->cz_hist);
-    const uint32_t stride_u = __builtin_amdgcn_readfirstlane(b->cz_stride);
-    const uint32_t before_u = __builtin_amdgcn_readfirstlane(b->cz_frames_before);
-    if (direct) {
-#pragma unroll
-        for (uint32_t g = 0; g < kCzHistory / 8u; ++g) {
-            const uint32_t r = g * 8u + (lane >> 3);       // row r = the batch's frame f0 - 32 + r
-            const uint32_t h = f0 + r - kCzHistory;        // (wraps below the batch's first frame)
-            const uint8_t *const src = f0 + r >= kCzHistory ? frames + (size_t)h * n_units_u
-                                                            : hist + (size_t)((before_u + h) & (kCzHistory - 1u)) * stride_u;
-            __builtin_amdgcn_global_load_lds((const ADDER_GLOBAL void *)(src + (size_t)sgw * kWaveUnits + (lane & 7u) * 16u),
-                                             (__attribute__((address_space(3))) void *)(ring + g * 1024u), 16, 0, 0);
-        }
-    } else {
-        InT *const in_lds = reinterpret_cast<InT *>(ring) + lane;
-#pragma unroll 1
-        for (uint32_t r = 0; r < kCzHistory; ++r) {
-            const uint32_t h = f0 + r - kCzHistory;
-            uint32_t w;
-            if (f0 + r >= kCzHistory) w = load_input(frames + (size_t)h * n_units_u, u0, FULL ? 0xffffffffu : n_units_u);
-            else w = load_input(hist + (size_t)((before_u + h) & (kCzHistory - 1u)) * stride_u, u0, 0xffffffffu);
-            in_lds[r * kWave] = (InT)w;
-        }
-    }
-}
-
-// The replays of one frame, both units of a lane through ONE loop (a lane's trip count is the sum of its two jobs, the
-// wave's the largest of those): unit j (want[j] != 0, from[j] + 1 <= t_end) replays frames from[j] + 1 .. t_end as the root
-// of a fresh arena (cz_replay); MULTI: then the arena behind THAT node's last firing, and so on (a flushed arena's levels
-// 1, 2, ..); rec(j, k, node) takes the k-th node of unit j.  `my`: the lane's byte of row 0 of the input ring.
-template <bool MULTI, class Rec>
-__device__ __forceinline__ void cz_replay_jobs(const uint8_t *my, const uint32_t (&want)[kUnitsPerLane], const uint32_t (&from)[kUnitsPerLane],
-                                               uint32_t t_end, float T, const Rec &rec) {
-    static_assert(kUnitsPerLane == 2u, "two jobs per lane");
-    uint32_t j = want[0] ? 0u : 1u, k = 0u;
-    bool active = (want[0] | want[1]) != 0u;
-    uint32_t f = (want[0] ? from[0] : from[1]) + 1u;
-    CzScan c = cz_scan_start(f - 1u);  // (the replay in integers: adder_pixel.hpp cz_replay_scan)
-    while (active) {
-        cz_scan_step(c, (uint32_t)my[j + cz_row(f) * kWaveUnits], f);
-        if (f == t_end) {
-            const CzNode n = cz_scan_finish(c, T);
-            rec(j, k, n);
-            ++k;
-            uint32_t t0 = n.last;
-            const bool more = MULTI && t0 + 1u <= t_end;
-            const bool next_unit = !more && j == 0u && want[1] != 0u;
-            if (next_unit) {
-                j = 1u;
-                k = 0u;
-                t0 = from[1];
-            }
-            active = more || next_unit;
-            c = cz_scan_start(t0);
-            f = t0;
-        }
-        ++f;
-    }
-}
-// the bounded Collapse kernel's records (EmitCb) with a switch: a unit whose events have nowhere to go computes them all the same
-struct EmitCz {
-    uint2 *seg;
-    uint32_t tagoff, boff;
-    bool live;
-    __device__ __forceinline__ void put(uint32_t w1, uint32_t t) {
-        if (live) gstore<uint2>(seg, boff, make_uint2(t, w1));
-        tagoff += 1u << 7;
-        boff += kGenRecBytes;
-    }
-    __device__ __forceinline__ void ev(uint32_t thr_bits, uint32_t t) { put(__builtin_amdgcn_alignbit(tagoff, thr_bits, 23), t); }
-    __device__ __forceinline__ void code(uint32_t c, uint32_t t) { put((tagoff << 9) | c, t); }
-    __device__ __forceinline__ void filler(uint32_t t) { put((tagoff << 9) | kCbCodeEmpty, t); }
-};
-
-#ifdef ADDER_CZ_PROFILE  // (diagnostic build: cycles per section, summed over waves into the timeline buffer's spare slots; tools/probes/cz_profile.py)
-#define CZ_PROF_T() const unsigned long long czp_t0 = __builtin_readcyclecounter()
-#define CZ_PROF_ADD(n, m) do { czp_acc[n] += __builtin_readcyclecounter() - czp_t0; czp_acc[m] += 1ull; } while (0)
-#else
-#define CZ_PROF_T() do {} while (0)
-#define CZ_PROF_ADD(n, m) do {} while (0)
-#endif
-template <bool ABS_T, bool FULL>
-__device__ __forceinline__ void cz_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
-                                               uint32_t u0, uint32_t gw, uint32_t lane, uint8_t *ring, uint32_t lazy) {
-    constexpr uint32_t N = kUnitsPerLane;
-#ifdef ADDER_CZ_PROFILE
-    const unsigned long long czp_wave0 = __builtin_readcyclecounter();
-    unsigned long long czp_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-#endif
-    CzPx px[N];
-    uint32_t snap_m[N];
-    {
-        uint32_t hdrv[N];
-        float iv[N], dv[N], bv[N], lfv[N];
-        load_vec<ADDER_NT_STATE != 0>(a.hdr, u0, hdrv);
-        load_vec<ADDER_NT_STATE != 0>(a.integ0, u0, iv);
-        load_vec<ADDER_NT_STATE != 0>(a.dt0, u0, dv);
-        load_vec<ADDER_NT_STATE != 0>(a.bdt0, u0, bv);
-        if (ABS_T) load_vec<ADDER_NT_STATE != 0>(a.lastf, u0, lfv);
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            px[j].S = iv[j];
-            px[j].dt0 = dv[j];
-            px[j].bdt0 = bv[j];
-            px[j].thr0 = lean_thr_from_bd((hdrv[j] >> kHdrBdShift) & 0xffu);
-            px[j].base = hdrv[j] & 0xffu;
-            px[j].has = hdr_m(hdrv[j]) != 0u;
-            px[j].popped = (hdrv[j] & kHdrPopped) != 0u;
-            px[j].lastf = ABS_T ? lfv[j] : 0.0f;
-            px[j].tfire = kCzT0 - 1u - (hdrv[j] >> kHdrAgeShift);
-            snap_m[j] = hdr_m(hdrv[j]);
-        }
-    }
-    if (snap_deep_wanted(b, a)) {  // the undo copy takes the levels as the planes have them
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) snap_deep_levels(b, a, (size_t)u0 + j, snap_m[j]);
-    }
-    StepConsts sc = a.sc;
-    const float T = sc.time_spanned;
-    const uint32_t sgw = __builtin_amdgcn_readfirstlane(gw);
-    const uint32_t slots_u = __builtin_amdgcn_readfirstlane(b->slots);
-    const uint32_t num_waves_u = __builtin_amdgcn_readfirstlane(a.num_waves);
-    const uint32_t n_units_u = __builtin_amdgcn_readfirstlane(a.n_units);
-    const uint32_t f0 = __builtin_amdgcn_readfirstlane(a.frame_idx);
-    const uint32_t slot0 = __builtin_amdgcn_readfirstlane(f0 % slots_u);
-    uint32_t tab_cth = 0u, tab_rt = 0u;
-    if (lane < nb) {
-        const uint2 e = gload<uint2>(uniform_ptr(b->ftab), (f0 + lane) * (uint32_t)sizeof(FrameTab));
-        tab_rt = e.x;
-        tab_cth = e.y;
-    }
-    SegLog log;
-    log.open(b, f0, sgw, num_waves_u);
-    const uint8_t *const fr0 = uniform_ptr(b->frames) + (size_t)f0 * n_units_u;
-    const bool direct = ADDER_LDS_DIRECT_INPUT != 0 && FULL &&
-                        __builtin_amdgcn_readfirstlane(((n_units_u | (uint32_t)(uintptr_t)uniform_ptr(b->frames)) & 15u) == 0u);
-    using InT = typename VecOf<uint8_t, N>::type;
-    const uint8_t *const my = ring + lane * N;  // the lane's two bytes of row 0
-    const uint32_t tab_cmin = row16_min_to_last(lane < nb ? tab_cth : 0xffu);
-    uint32_t wt = 0u, wo = 0u;  // lane i: {events | records << 16} and the run's start of the launch's i-th frame
-    bool depth_error = false;
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // (cb_run_segment has the reason)
-
-    // an unpopped root that did not fire in the frame before the launch has levels whose bytes lie before the launch
-    {
-        bool wants = false;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) wants = wants || (px[j].has && !px[j].popped && px[j].tfire + 1u < kCzT0);
-        if (__builtin_amdgcn_ballot_w64(wants) != 0ull) cz_stage_history<FULL>(b, f0, n_units_u, sgw, u0, lane, ring, direct);
-    }
-    bool pref = false;  // the next group's bytes are on their way (uniform)
-    uint32_t i = 0u;
-    while (i < nb) {
-        const uint32_t t = kCzT0 + i;
-        CZ_PROF_T();
-        if ((i % kCbInFrames) == 0u) {
-            if (!pref) cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, ring + cz_row(t) * kWaveUnits, direct);
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed (and the history, and the records stored so far)
-            pref = i + kCbInFrames < nb;
-            if (pref) cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i + kCbInFrames, nb, ring + cz_row(t + kCbInFrames) * kWaveUnits, direct);
-#if ADDER_CZ_GROUPS
-            // ---------------- the whole group at once (quiet_group_apply with delta_t_max: unpopped roots too) ----------------
-            static_assert(N == 2u, "two units per lane in one packed register");
-            if (__builtin_amdgcn_ballot_w64(!(px[0].has && px[1].has)) == 0ull) {
-                const InT *const cur_in = reinterpret_cast<const InT *>(ring + cz_row(t) * kWaveUnits) + lane;
-                const uint32_t gn = nb - i < kCbInFrames ? nb - i : kCbInFrames;
-                const uint32_t cth_min = __builtin_amdgcn_readlane(tab_cmin, i + kCbInFrames - 1u);
-                const uint32_t need2 = quiet_group_need(px[0].S, px[0].thr0) | (quiet_group_need(px[1].S, px[1].thr0) << 16);
-                uint32_t mn = 0x00ff00ffu, mx = 0u, P = 0u, cnt = 0u, pm = 0u;
-                for (uint32_t k = 0; k < gn; ++k) {
-                    const uint32_t pk = __builtin_amdgcn_perm(0u, (uint32_t)cur_in[k * kWave], 0x0c010c00u);  // {v0, v1} as halves
-                    mn = pk_min_u16(mn, pk);
-                    mx = pk_max_u16(mx, pk);
-                    P = pk_add_u16(P, pk);
-                    const uint32_t below = pk_min_u16(pk_sub_sat_u16(need2, P), 0x00010001u);  // prefix sum < need
-                    cnt = pk_add_u16(cnt, below);
-                    pm = pk_mad_u16(pk, below, pm);
-                }
-                CzPx tpx[N];
-                uint32_t verdict[N], fired[N];
-                bool any_no = false, any_slow = false;
-#pragma unroll
-                for (uint32_t j = 0; j < N; ++j) {
-                    QuietGroupStats g;
-                    g.mn = (mn >> (16u * j)) & 0xffffu;
-                    g.mx = (mx >> (16u * j)) & 0xffffu;
-                    g.sum = (P >> (16u * j)) & 0xffffu;
-                    g.cnt = (cnt >> (16u * j)) & 0xffffu;
-                    g.pm = (pm >> (16u * j)) & 0xffffu;
-                    const uint32_t row = g.cnt < gn ? g.cnt : gn - 1u;
-                    g.vc = ((uint32_t)cur_in[row * kWave] >> (8u * j)) & 0xffu;
-                    tpx[j] = px[j];
-                    verdict[j] = quiet_group_apply(tpx[j].S, tpx[j].dt0, tpx[j].bdt0, tpx[j].thr0, tpx[j].base, tpx[j].popped, g, gn,
-                                                   cth_min, T, sc.dtm_f, &fired[j]);
-                    any_no = any_no || verdict[j] == kQuietNo;
-                    any_slow = any_slow || verdict[j] == kQuietSlow;
-                }
-                if (__builtin_amdgcn_ballot_w64(any_no) == 0ull) {  // uniform: no unit of the wave flushes or pops in these frames
-#pragma unroll
-                    for (uint32_t j = 0; j < N; ++j)
-                        if (verdict[j] == kQuietDone) {
-                            px[j].S = tpx[j].S; px[j].dt0 = tpx[j].dt0; px[j].bdt0 = tpx[j].bdt0; px[j].thr0 = tpx[j].thr0;
-                            px[j].tfire = fired[j] < gn ? t + fired[j] : px[j].tfire;
-                        }
-                    if (__builtin_amdgcn_ballot_w64(any_slow) != 0ull) {  // (rare: second firings, black roots that wake up)
-                        for (uint32_t k = 0; k < gn; ++k) {
-                            const uint32_t vin_s = (uint32_t)cur_in[k * kWave];
-#pragma unroll
-                            for (uint32_t j = 0; j < N; ++j)
-                                if (verdict[j] == kQuietSlow) {
-                                    CzNode nd{px[j].S, px[j].dt0, px[j].bdt0, px[j].thr0, px[j].tfire, true};
-                                    cz_node_step(nd, (vin_s >> (8 * j)) & 0xffu, T, t + k);
-                                    px[j].S = nd.S; px[j].dt0 = nd.dt; px[j].bdt0 = nd.bdt; px[j].thr0 = nd.thr; px[j].tfire = nd.last;
-                                }
-                        }
-                    }
-                    // (wt of these frames stays 0: no events, no records; wo is not read then)
-                    i += gn;
-                    CZ_PROF_ADD(0u, 1u);
-                    continue;
-                }
-            }
-#endif
-        }
-        const uint32_t vin_w = (uint32_t)reinterpret_cast<const InT *>(ring + cz_row(t) * kWaveUnits)[lane];
-        const uint32_t cth_i = __builtin_amdgcn_readlane(tab_cth, i);
-        // ---------------- what kind of frame is it for the wave?  (uniform) ----------------
-        //   nothing: no unit flushes, fires or reaches delta_t_max          -> two adds per unit
-        //   firings: some root fires (no flush, no pop_top in the wave)     -> the root-only step, no events
-        //   events:  some unit flushes or pops                             -> counts, log, records, replays
-        uint32_t vj[N];
-        bool flush[N], black0[N];
-        bool lane_ev = false, lane_fire = false;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            vj[j] = (vin_w >> (8 * j)) & 0xffu;
-            flush[j] = contrast_exceeded(vj[j], px[j].base, cth_i);
-            black0[j] = px[j].thr0 == 0.0f && vj[j] == 0u;  // a black root on a zero fires without changing (:449)
-            lane_ev = lane_ev || flush[j] || (!px[j].popped && !(fadd(px[j].dt0, T) < sc.dtm_f));
-            lane_fire = lane_fire || !px[j].has || !(fadd(px[j].S, (float)vj[j]) < px[j].thr0 || black0[j]);
-        }
-        if (__builtin_amdgcn_ballot_w64(lane_ev) == 0ull) {
-            if (__builtin_amdgcn_ballot_w64(lane_fire) == 0ull) {
-#pragma unroll
-                for (uint32_t j = 0; j < N; ++j) {
-                    px[j].S = fadd(px[j].S, (float)vj[j]);
-                    px[j].dt0 = black0[j] ? px[j].dt0 : fadd(px[j].dt0, T);
-                    px[j].tfire = black0[j] ? t : px[j].tfire;
-                }
-            } else {
-#pragma unroll
-                for (uint32_t j = 0; j < N; ++j) {
-                    CzNode r{px[j].S, px[j].dt0, px[j].bdt0, px[j].thr0, px[j].tfire, px[j].has};
-                    cz_node_step(r, vj[j], T, t);
-                    px[j].S = r.S; px[j].dt0 = r.dt; px[j].bdt0 = r.bdt; px[j].thr0 = r.thr; px[j].tfire = r.last; px[j].has = true;
-                }
-            }
-            ++i;  // (wt of this frame stays 0: no events, no records)
-            CZ_PROF_ADD(2u, 3u);
-            continue;
-        }
-        sc.running_t = __uint_as_float(__builtin_amdgcn_readlane(tab_rt, i));
-        sc.running_t_u32 = f32_as_u32(sc.running_t);
-        // ---------------- events: the flushed roots' best events aside, then every root's step ----------------
-        bool flushed[N], collapsed[N], need_pop[N];
-        uint32_t want_chain[N], chain_from[N], cnt[N];
-        float old_thr[N], old_bdt[N];
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            flushed[j] = flush[j] && px[j].has;
-            collapsed[j] = flushed[j] && px[j].popped;
-            // the levels behind a flushed unpopped root: replayed below, unless the root fired in the frame before (no level yet)
-            want_chain[j] = (flushed[j] && !px[j].popped && px[j].tfire + 1u < t) ? 1u : 0u;
-            chain_from[j] = px[j].tfire;
-            old_thr[j] = px[j].thr0;
-            old_bdt[j] = px[j].bdt0;
-            if (flush[j]) {
-                px[j].base = vj[j];
-                px[j].has = false;
-                px[j].popped = false;
-            }
-            CzNode r{px[j].S, px[j].dt0, px[j].bdt0, px[j].thr0, px[j].tfire, px[j].has};
-            cz_node_step(r, vj[j], T, t);
-            px[j].S = r.S; px[j].dt0 = r.dt; px[j].bdt0 = r.bdt; px[j].thr0 = r.thr; px[j].tfire = r.last; px[j].has = true;
-            need_pop[j] = !px[j].popped && px[j].dt0 >= sc.dtm_f;  // :394-396
-            cnt[j] = (flushed[j] ? (collapsed[j] ? 2u : 1u) : 0u) + (need_pop[j] ? 1u : 0u);
-        }
-        // ---------------- the flushed arenas' levels: each the root of the arena that started after its parent's last firing ----------------
-        uint32_t nlv[N] = {0u, 0u}, lvc[N][2] = {{0u, 0u}, {0u, 0u}};  // levels found; their 9-bit threshold codes, three to a word
-        float lvb[N][kCzLevels];                                       // their best delta_t
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j)
-#pragma unroll
-            for (uint32_t k = 0; k < kCzLevels; ++k) lvb[j][k] = 0.0f;
-        if (__builtin_amdgcn_ballot_w64((want_chain[0] | want_chain[1]) != 0u) != 0ull) {
-            const auto rec = [&](uint32_t j, uint32_t k, const CzNode &n) {
-                const uint32_t code = f32_to_bits(n.thr) >> 23;
-#pragma unroll
-                for (uint32_t jj = 0; jj < N; ++jj) {
-#pragma unroll
-                    for (uint32_t kk = 0; kk < kCzLevels; ++kk) lvb[jj][kk] = (j == jj && k == kk) ? n.bdt : lvb[jj][kk];
-#pragma unroll
-                    for (uint32_t w = 0; w < 2u; ++w)
-                        lvc[jj][w] |= (j == jj && k / 3u == w) ? code << (9u * (k % 3u)) : 0u;
-                    nlv[jj] += j == jj ? 1u : 0u;
-                }
-            };
-            cz_replay_jobs<true>(my, want_chain, chain_from, t - 1u, T, rec);
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                depth_error = depth_error || nlv[j] > kCzLevels;
-                cnt[j] += nlv[j] < kCzLevels ? nlv[j] : kCzLevels;
-            }
-        }
-        // ---------------- wave-level ordered compaction into the segment's log ----------------
-        if (!FULL) {
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) cnt[j] = u0 + j < n_units_u ? cnt[j] : 0u;  // padding units: stepped freely, no events
-        }
-        const uint32_t lane_cnt = cnt[0] + cnt[1];
-        const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
-        const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
-        uint32_t run_start = log.cur;
-        uint2 *seg = nullptr;
-        if (total != 0u) seg = log.append(total, run_start, a.status);  // uniform
-        wt = lane == i ? (total | (total << 16)) : wt;
-        wo = lane == i ? run_start : wo;
-        uint32_t off = incl - lane_cnt;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            // (a unit whose events have nowhere to go -- a padding unit, a log beyond its bound -- still makes its state changes)
-            EmitCz em{seg, (lane * N + j) | (off << 7), off * kGenRecBytes, cnt[j] != 0u && seg != nullptr};
-            if (flushed[j]) {
-                if (collapsed[j]) {
-                    em.ev(f32_to_bits(old_thr[j]), f32_as_u32(ABS_T ? fadd(old_bdt[j], px[j].lastf) : old_bdt[j]));
-                    px[j].lastf = sc.running_t;  // :257
-                    em.filler(sc.running_t_u32);
-                } else {
-                    em.ev(f32_to_bits(old_thr[j]), event_time<ABS_T>(old_bdt[j], px[j].lastf, sc));
-#pragma unroll
-                    for (uint32_t k = 0; k < kCzLevels; ++k)
-                        if (k < nlv[j]) em.code((lvc[j][k / 3u] >> (9u * (k % 3u))) & 0x1ffu, event_time<ABS_T>(lvb[j][k], px[j].lastf, sc));
-                }
-            }
-            if (need_pop[j]) em.ev(f32_to_bits(px[j].thr0), event_time<ABS_T>(px[j].bdt0, px[j].lastf, sc));
-            off += cnt[j];
-        }
-        // ---------------- pop_top (:199-207): level 1 becomes the root -- the arena that started after the root's last firing ----------------
-        if (__builtin_amdgcn_ballot_w64(need_pop[0] || need_pop[1]) != 0ull) {
-            uint32_t want_pop[N], pop_from[N];
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) {
-                want_pop[j] = (need_pop[j] && px[j].tfire < t) ? 1u : 0u;
-                pop_from[j] = px[j].tfire;
-                if (need_pop[j]) {
-                    px[j].popped = true;
-                    px[j].has = px[j].tfire < t;  // (the root fired in this very frame: no level 1, the arena is pristine again)
-                }
-            }
-            const auto rec = [&](uint32_t j, uint32_t, const CzNode &n) {
-#pragma unroll
-                for (uint32_t jj = 0; jj < N; ++jj)
-                    if (j == jj) { px[jj].S = n.S; px[jj].dt0 = n.dt; px[jj].bdt0 = n.bdt; px[jj].thr0 = n.thr; px[jj].tfire = n.last; }
-            };
-            cz_replay_jobs<false>(my, want_pop, pop_from, t, T, rec);
-        }
-        ++i;
-        CZ_PROF_ADD(4u, 5u);
-    }
-#ifdef ADDER_CZ_PROFILE
-    const unsigned long long czp_loop_end = __builtin_readcyclecounter();
-#endif
-    if (depth_error) raise(a.status, kStatusDepth);
-    log.close(lane);
-    if (lane < nb) {
-        uint32_t s = slot0 + lane;
-        s = s >= slots_u ? s - slots_u : s;
-        gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
-        gstore<uint32_t>(uniform_ptr(b->wofs_ring), (s * num_waves_u + sgw) * 4u, wo);
-    }
-
-    // ---------------- state back to HBM ----------------
-    {
-        const uint32_t t_last = kCzT0 + nb - 1u;
-        uint32_t hdrv[N];
-        float iv[N], dv[N], bv[N], lfv[N];
-        bool too_deep = false;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            uint32_t m = px[j].has ? 1u : 0u;
-            if (!lazy) {  // the batch's last launch: the levels in their resident form, for whoever steps next (or rolls back)
-                struct Store {
-                    DeepGlobal g;
-                    uint32_t max_depth;
-                    bool over;
-                    __device__ __forceinline__ void operator()(uint32_t k, const Node &n) {
-                        if (k < max_depth) g.store(k, n);
-                        else over = true;
-                    }
-                } st{DeepGlobal{a.dv_integ, a.dv_dt, a.dv_bdt, a.dv_bd, a.plane_stride, (size_t)u0 + j}, sc.max_depth, false};
-                const uint8_t *const mine = my + j;
-                const auto get = [mine](uint32_t f) -> uint32_t { return (uint32_t)mine[cz_row(f) * kWaveUnits]; };
-                m = cz_materialize(px[j], t_last, T, get, st);
-                too_deep = too_deep || (st.over && (FULL || u0 + j < n_units_u));
-            }
-            const uint32_t age = t_last - px[j].tfire;
-            hdrv[j] = hdr_make(px[j].base, px[j].has ? lean_bd_from_thr(f32_to_bits(px[j].thr0)) : 0u, m < kHdrMMask ? m : kHdrMMask,
-                               px[j].popped) |
-                      ((px[j].has ? (age < 1023u ? age : 1023u) : 0u) << kHdrAgeShift);
-            iv[j] = px[j].S;
-            dv[j] = px[j].dt0;
-            bv[j] = px[j].bdt0;
-            lfv[j] = px[j].lastf;
-        }
-        if (too_deep) raise(a.status, kStatusDepth);
-        constexpr bool NTS = ADDER_NT_STATE != 0;
-        store_vec<NTS>(a.hdr, u0, hdrv);
-        store_vec<NTS>(a.integ0, u0, iv);
-        store_vec<NTS>(a.dt0, u0, dv);
-        store_vec<NTS>(a.bdt0, u0, bv);
-        if (ABS_T) store_vec<NTS>(a.lastf, u0, lfv);
-        if (a.running) {  // side plane (the host keeps nb == 1 while it is enabled)
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j)
-                if (u0 + j < n_units_u && px[j].has)
-                    a.running[u0 + j] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(px[j].thr0)),
-                                                                f32_as_u32(px[j].bdt0), (double)sc.ref_time);
-        }
-    }
-    // ---------------- the batch's last frames into the history ring (whole rows of the segment: the ring is padded) ----------------
-    {
-        const uint32_t keep_u = __builtin_amdgcn_readfirstlane(b->cz_keep_from);
-        if (f0 + nb > keep_u) {  // uniform
-            uint8_t *const hist = uniform_ptr(b->cz_hist);
-            const uint32_t stride_u = __builtin_amdgcn_readfirstlane(b->cz_stride);
-            const uint32_t before_u = __builtin_amdgcn_readfirstlane(b->cz_frames_before);
-#pragma unroll
-            for (uint32_t g = 0; g < kCzHistory / 8u; ++g) {
-                const uint32_t r = g * 8u + (lane >> 3);
-                const uint32_t fi = nb + r - kCzHistory;  // the launch's frame (wraps when the launch is shorter than the history)
-                if (nb + r >= kCzHistory && f0 + fi >= keep_u) {
-                    uint4 v;
-                    __builtin_memcpy(&v, ring + cz_row(kCzT0 + fi) * kWaveUnits + (lane & 7u) * 16u, 16);
-                    uint8_t *const dst = hist + (size_t)((before_u + f0 + fi) & (kCzHistory - 1u)) * stride_u + (size_t)sgw * kWaveUnits +
-                                         (lane & 7u) * 16u;
-                    *reinterpret_cast<uint4 *>(dst) = v;
-                }
-            }
-        }
-    }
-#ifdef ADDER_CZ_PROFILE
-    if (b->timeline && lane == 0u) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        for (uint32_t q = 0; q < 6u; ++q) atomicAdd(b->timeline + (3u * kTimelineChunks + 32u + q) * 2u + 1u, czp_acc[q]);
-        atomicAdd(b->timeline + (3u * kTimelineChunks + 32u + 6u) * 2u + 1u, now - czp_wave0);     // wave total
-        atomicAdd(b->timeline + (3u * kTimelineChunks + 32u + 7u) * 2u + 1u, 1ull);
-        atomicMax(b->timeline + (3u * kTimelineChunks + 32u + 8u) * 2u + 1u, now - czp_wave0);     // slowest wave
-        atomicAdd(b->timeline + (3u * kTimelineChunks + 32u + 9u) * 2u + 1u, now - czp_loop_end);  // epilogue
-    }
-#endif
-}
-
-template <bool ABS_T>
-__global__ __launch_bounds__(kBlockThreads, ADDER_CZ_WAVES_PER_SIMD) void adder_cz_kernel(const BatchArgs *__restrict__ b,
-                                                                                         uint32_t f, uint32_t nb, uint32_t lazy) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kWavesPerBlock][kCzRows * kWaveUnits];
-    const FrameArgs a = frame_args(b, f);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & (kWave - 1);
-    timeline_mark(b, 0u, f, false);
-    for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
-        const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
-        const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
-        if (full) cz_run_segment<ABS_T, true>(b, a, nb, u0, gw, lane, s_ring[tid / kWave], lazy);
-        else cz_run_segment<ABS_T, false>(b, a, nb, u0, gw, lane, s_ring[tid / kWave], lazy);
     }
     timeline_mark(b, 0u, f, true);
 }
@@ -4387,13 +3871,6 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
         if (abs_t) hipLaunchKernelGGL((adder_cr_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
         else hipLaunchKernelGGL((adder_cr_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb);
-        return hipGetLastError();
-    }
-    if (variant & 4096u) {  // bounded Collapse regime, lazy levels
-        const uint32_t SG = grid_cap && grid_cap < S ? grid_cap : S;
-        const uint32_t lazy = (variant & 2048u) ? 1u : 0u;  // (more launches of this batch follow: adder_hip_api.cpp lazy_state_bit)
-        if (abs_t) hipLaunchKernelGGL((adder_cz_kernel<true>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
-        else hipLaunchKernelGGL((adder_cz_kernel<false>), dim3(SG), dim3(kBlockThreads), 0, stream, b, f, nb, lazy);
         return hipGetLastError();
     }
     if (variant & 32u) {  // bounded Collapse step

@@ -66,7 +66,6 @@ constexpr uint32_t kHdrBdShift = 8;
 constexpr uint32_t kHdrMShift = 16;
 constexpr uint32_t kHdrMMask = 0x1f;
 constexpr uint32_t kHdrPopped = 1u << 21;
-constexpr uint32_t kHdrAgeShift = 22;  // lazy levels (cz_step): frames since the root last fired, 10 bits; other kernels leave 0
 ADDER_HD uint32_t hdr_m(uint32_t hdr) { return (hdr >> kHdrMShift) & kHdrMMask; }
 ADDER_HD uint32_t hdr_make(uint32_t base, uint32_t bd, uint32_t m, bool popped) {
     return base | (bd << kHdrBdShift) | (m << kHdrMShift) | (popped ? kHdrPopped : 0u);
@@ -1059,23 +1058,15 @@ ADDER_HD QuietGroupStats quiet_group_stats(const uint8_t *v, size_t stride, uint
 }
 // (S, dt, bdt, thr) = the root's integration, delta_t, best delta_t and threshold 2^d; precondition: the unit holds its
 // root alone and is popped or black (cb_quiet / lean_quiet without their per-frame part)
-// dtm_f > 0 (the lazy-levels kernel): an UNPOPPED root may take the group as well -- nothing but the root is stepped there --
-// as long as it does not reach delta_t_max inside the group (pop_top, :394-396); *fired = the group's frame in which the
-// root fired (n: none), for the root's last-firing mark.
 ADDER_HD uint32_t quiet_group_apply(float &S, float &dt, float &bdt, float &thr, uint32_t base, bool popped,
-                                    const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T, float dtm_f = 0.0f,
-                                    uint32_t *fired = nullptr) {
+                                    const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T) {
     const uint32_t dmx = g.mx > base ? g.mx - base : base - g.mx, dmn = g.mn > base ? g.mn - base : base - g.mn;
-    if (fired) *fired = n;
     if ((dmx > dmn ? dmx : dmn) > cth_min) return kQuietNo;  // the extremes bound |v - base_val| of every frame
-    if (!popped && g.mx != 0u && !(dtm_f > 0.0f)) return kQuietNo;  // an unpopped unit is in here as a black one: quiet on zeros only
-    // ... it may pop inside the group (a black root accumulates no delta_t while it sees zeros, :449)
-    if (!popped && dtm_f > 0.0f && (thr != 0.0f || g.sum != 0u) && !(fadd(dt, fmul((float)n, T)) < dtm_f)) return kQuietNo;
+    if (!popped && g.mx != 0u) return kQuietNo;              // an unpopped unit is in here as a black one: quiet on zeros only
     if (thr == 0.0f) {
         // a black root (integration 0, d = 128) fires on every zero without accumulating (:449): idempotent
         if (g.sum != 0u) return kQuietSlow;
         bdt = fadd(dt, fmul(T, 1.0f));
-        if (fired) *fired = n - 1u;  // (it fires in every frame: the last one counts)
         return kQuietDone;
     }
     const float S_new = fadd(S, (float)g.sum), dt_new = fadd(dt, fmul((float)n, T));
@@ -1088,7 +1079,6 @@ ADDER_HD uint32_t quiet_group_apply(float &S, float &dt, float &bdt, float &thr,
         if (S_new >= thr2) return kQuietSlow;  // a second firing inside the group
         bdt = fadd(fadd(dt, fmul((float)g.cnt, T)), fmul(T, fdiv_small(fsub(p2, S_old), I)));
         thr = thr2;
-        if (fired) *fired = g.cnt;
     }
     S = S_new;
     dt = dt_new;
@@ -1158,229 +1148,6 @@ ADDER_HD void cb_pop(CbPxT<L> &s, const CbPlanT<L> &p, const Lv &lv) {
         }
     }
     s.popped = L::or_(s.popped, p.need_pop);
-}
-
-// ---------------------------------------------------------------------------------------
-// LAZY LEVELS (round 5): the bounded Collapse regime WITHOUT stepping the levels.  The constant-run step below derives a
-// flushed arena from (intensity, run length); with a contrast band (crf > 0) the inputs of a run differ, but the structure
-// behind that closed form holds all the same (event_pixel_tree.rs:342-362, 418-479):
-//   * a node that fires gets a fresh child and everything deeper is dropped (:342-356), and the child is first visited in the
-//     NEXT frame (the walk stops at the firing node), where -- pristine -- it fires at once with d = floor(log2 I) (:332-335);
-//   * from then on it is visited in every frame in which its parent is visited and does not fire, with the frame's
-//     intensity and time, and nothing it does depends on its parent's values.
-// So level k+1 is exactly THE ROOT OF AN ARENA THAT STARTED RIGHT AFTER LEVEL k's LAST FIRING: its state is a function of
-// the input bytes since then, obtained by running the root-only step (cz_node_step: accumulate, fire when the sum reaches
-// the threshold -- what a popped root does, cb_step_quiet) over those bytes.  Nothing but the root is stepped per frame;
-// the root remembers the frame of its last firing; the levels are REPLAYED from the input bytes when something wants them
-// -- a flush of an unpopped arena (pop_best_events emits every level, :213-287), pop_top (level 1 becomes the root,
-// :199-207), the end of a batch (the planes go back to their resident form).  Every level's span is shorter than its
-// parent's, and an unpopped root has fired within the last delta_t_max / time_spanned frames, so the bytes wanted are the
-// last few dozen frames': the kernel keeps them in LDS.  All sums are the reference's own running sums: the same adds of
-// the same integers in the same order.
-// ---------------------------------------------------------------------------------------
-struct CzNode {
-    float S, dt, bdt, thr;  // integration, delta_t, best_event.delta_t, 2^d (0: d = 128)
-    uint32_t last;          // the frame in which it last fired (meaningful iff has)
-    bool has;               // false: pristine (never visited)
-};
-// frame t (intensity v, time T) into a node that is visited and is the first node of its (sub-)arena to be asked
-ADDER_HD void cz_node_step(CzNode &n, uint32_t v, float T, uint32_t t) {
-    const float I = (float)v;
-    const float integ_old = n.has ? n.S : 0.0f, dt_old = n.has ? n.dt : 0.0f;
-    const float sum = fadd(integ_old, I);
-    const bool fires = !n.has || sum >= n.thr;  // (the pristine tail always fires, :332-335 / :427)
-    if (fires) {  // the firing arm of integrate_main (:427-473)
-        const bool zero = sum == 0.0f;                                   // get_d(sum) == 128: the node keeps (integration, delta_t) (:449)
-        const bool d128 = n.has ? n.thr == 0.0f : I < 1.0f;              // the node's d before it fires is 128 (:432-437)
-        const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);   // 2^get_d(sum)
-        const float q = fdiv_small(fsub(p2, integ_old), I);
-        const float prop = (zero || d128) ? 1.0f : q;
-        n.bdt = fadd(dt_old, fmul(T, prop));
-        n.thr = fadd(p2, p2);
-        n.S = sum;
-        n.dt = zero ? dt_old : fadd(dt_old, T);
-        n.last = t;
-        n.has = true;
-    } else {
-        n.S = sum;
-        n.dt = fadd(dt_old, T);
-    }
-}
-// the root of the arena that started right after frame t0, after frames t0 + 1 .. t1 (get(f) = the unit's byte of frame f)
-template <class Get>
-ADDER_HD CzNode cz_replay_scan(uint32_t t0, uint32_t t1, float T, const Get &get);
-template <class Get>
-ADDER_HD CzNode cz_replay(uint32_t t0, uint32_t t1, float T, const Get &get) {
-    CzNode n{0.0f, 0.0f, 0.0f, 0.0f, t0, false};
-    for (uint32_t f = t0 + 1u; f <= t1; ++f) cz_node_step(n, get(f), T, f);
-#ifdef ADDER_CZ_SCAN_CHECK  // (the CPU harness: every replay it makes is also made in integers, cz_replay_scan below)
-    if (t0 + 1u <= t1) {
-        const CzNode m = cz_replay_scan(t0, t1, T, get);
-        if (!(f32_to_bits(m.S) == f32_to_bits(n.S) && f32_to_bits(m.dt) == f32_to_bits(n.dt) && f32_to_bits(m.bdt) == f32_to_bits(n.bdt) &&
-              f32_to_bits(m.thr) == f32_to_bits(n.thr) && m.last == n.last && m.has == n.has))
-            ADDER_CZ_SCAN_CHECK();
-    }
-#endif
-    return n;
-}
-
-// The same replay in integers (what the kernel runs): a fresh arena's root fires at its first frame and then whenever its
-// running sum reaches 2^(floor(log2(sum at the previous firing)) + 1) (:427, :452-461) -- whenever the sum's exponent
-// grows; a root still at sum 0 fires on every frame without accumulating delta_t (:449) and with a full time step as its
-// event's delta_t (d = 128, :432-437).  So one pass of integer adds finds the LAST firing -- its frame, the sum before it,
-// its intensity, the delta_t-counted frames before it -- and the firing arm's float arithmetic (:427-447) runs once, on
-// those: all sums and frame counts are exact in binary32 (the bounded regime's conditions), so the result is cz_replay's
-// bit for bit (tests/test_device_logic_cpu.py compares the two on every window of its clips).
-struct CzScan {
-    uint32_t P, thr;      // running sum; the threshold as an integer (0 while the sum is 0)
-    uint32_t nz;          // frames that counted for delta_t so far
-    uint32_t last, Sb, I, nzb;  // the last firing: frame, sum before it, intensity, delta_t-counted frames before it
-    bool unit_prop;       // ... fired at d = 128 or on a zero sum: the event's delta_t takes a whole time step
-    bool has;
-};
-ADDER_HD CzScan cz_scan_start(uint32_t t0) { return CzScan{0u, 0u, 0u, t0, 0u, 0u, 0u, false, false}; }
-ADDER_HD void cz_scan_step(CzScan &c, uint32_t v, uint32_t f) {
-    const uint32_t Pn = c.P + v;
-    const bool fires = !c.has || Pn >= c.thr;
-    const bool zero = Pn == 0u;
-    if (fires) {
-        c.unit_prop = zero || (c.has ? c.thr == 0u : v == 0u);
-        c.last = f;
-        c.Sb = c.P;
-        c.I = v;
-        c.nzb = c.nz;
-        c.thr = zero ? 0u : 2u << (31u - (uint32_t)__builtin_clz(Pn | 1u));
-    }
-    c.nz += (fires && zero) ? 0u : 1u;
-    c.P = Pn;
-    c.has = true;
-}
-ADDER_HD CzNode cz_scan_finish(const CzScan &c, float T) {
-    CzNode n;
-    const float sum = (float)(c.Sb + c.I), integ_old = (float)c.Sb, I = (float)c.I;
-    const float p2 = bits_to_f32(f32_to_bits(sum) & 0x7f800000u);
-    const float prop = c.unit_prop ? 1.0f : fdiv_small(fsub(p2, integ_old), I);
-    n.bdt = fadd(fmul((float)c.nzb, T), fmul(T, prop));
-    n.thr = fadd(p2, p2);
-    n.S = (float)c.P;
-    n.dt = fmul((float)c.nz, T);
-    n.last = c.last;
-    n.has = c.has;
-    return n;
-}
-template <class Get>
-ADDER_HD CzNode cz_replay_scan(uint32_t t0, uint32_t t1, float T, const Get &get) {
-    CzScan c = cz_scan_start(t0);
-    for (uint32_t f = t0 + 1u; f <= t1; ++f) cz_scan_step(c, get(f), f);
-    return cz_scan_finish(c, T);
-}
-
-constexpr uint32_t kCzLevels = 6;    // levels 1 .. 6 of a flushed arena are kept between the count and the emission
-constexpr uint32_t kCzHistory = 32;  // frames of input behind the current one that a replay may want (delta_t_max / time_spanned <= 32)
-struct CzPx {
-    float S, dt0, bdt0, thr0;  // the root (meaningful iff has)
-    uint32_t base;
-    uint32_t tfire;            // the frame in which the root last fired
-    bool has, popped;
-    float lastf;
-};
-struct CzPlan {
-    bool flush, flushed, collapsed, need_pop;
-    float old_thr0, old_bdt0;      // the flushed root's best event
-    uint32_t n_lv;                 // levels behind it that leave with it (unpopped flush)
-    float lv_bdt[kCzLevels], lv_thr[kCzLevels];
-    uint32_t count;
-    bool depth_error;              // more levels than kCzLevels (cannot happen while delta_t_max / time_spanned <= 32)
-    CzNode promoted;               // pop_top's new root (has == false: none)
-};
-// One frame of one unit.  t = the frame's index, get(f) the unit's input byte of frame f (f in (t - kCzHistory, t]);
-// n_pop_dtm = delta_t_max as f32.  After it: cz_emit, then nothing (the pop is folded in).
-template <class Get>
-ADDER_HD void cz_step(CzPx &s, uint32_t v, uint32_t cth, float T, float dtm_f, uint32_t t, const Get &get, CzPlan &p) {
-    p.flush = contrast_exceeded(v, s.base, cth);
-    p.flushed = p.flush && s.has;
-    p.collapsed = p.flushed && s.popped;
-    p.old_thr0 = s.thr0;
-    p.old_bdt0 = s.bdt0;
-    p.n_lv = 0u;
-    for (uint32_t k = 0; k < kCzLevels; ++k) p.lv_bdt[k] = p.lv_thr[k] = 0.0f;
-    p.depth_error = false;
-    p.promoted.has = false;
-    p.count = 0u;
-    if (p.flushed) {
-        p.count = p.collapsed ? 2u : 1u;
-        if (!p.collapsed) {  // the levels behind the root: each the root of the arena that started after its parent's last firing
-            uint32_t t0 = s.tfire;
-            while (t0 + 1u < t) {
-                const CzNode n = cz_replay(t0, t - 1u, T, get);
-                // (stores with constant indices: the arrays stay in registers on the device)
-                for (uint32_t k = 0; k < kCzLevels; ++k) {
-                    p.lv_bdt[k] = p.n_lv == k ? n.bdt : p.lv_bdt[k];
-                    p.lv_thr[k] = p.n_lv == k ? n.thr : p.lv_thr[k];
-                }
-                p.depth_error = p.depth_error || p.n_lv >= kCzLevels;
-                p.n_lv += 1u;
-                t0 = n.last;
-            }
-            p.count += p.n_lv;
-        }
-    }
-    if (p.flush) {
-        s.base = v;
-        s.has = false;
-        s.popped = false;
-    }
-    // integrate: the root, or the pristine tail at index 0 (which fires)
-    CzNode r{s.S, s.dt0, s.bdt0, s.thr0, s.tfire, s.has};
-    cz_node_step(r, v, T, t);
-    s.S = r.S; s.dt0 = r.dt; s.bdt0 = r.bdt; s.thr0 = r.thr; s.tfire = r.last; s.has = true;
-    p.need_pop = !s.popped && s.dt0 >= dtm_f;  // :394-396 (d == D_MAX cannot happen with 8-bit input)
-    if (p.need_pop) {
-        p.count += 1u;
-        if (s.tfire < t) p.promoted = cz_replay(s.tfire, t, T, get);  // level 1, if there is one
-    }
-}
-// the unit's events of this frame in emission order, then the pop (cb_emit + cb_pop)
-template <bool ABS_T, class Emit>
-ADDER_HD void cz_emit(CzPx &s, const CzPlan &p, const StepConsts &sc, Emit &emit) {
-    if (p.flushed) {
-        if (p.collapsed) {
-            emit.ev(f32_to_bits(p.old_thr0), f32_as_u32(ABS_T ? fadd(p.old_bdt0, s.lastf) : p.old_bdt0));
-            s.lastf = sc.running_t;  // :257
-            emit.filler(sc.running_t_u32);
-        } else {
-            emit.ev(f32_to_bits(p.old_thr0), event_time<ABS_T>(p.old_bdt0, s.lastf, sc));
-            for (uint32_t k = 0; k < kCzLevels; ++k)
-                if (k < p.n_lv) emit.ev(f32_to_bits(p.lv_thr[k]), event_time<ABS_T>(p.lv_bdt[k], s.lastf, sc));
-        }
-    }
-    if (p.need_pop) {
-        emit.ev(f32_to_bits(s.thr0), event_time<ABS_T>(s.bdt0, s.lastf, sc));
-        if (p.promoted.has) {
-            s.S = p.promoted.S; s.dt0 = p.promoted.dt; s.bdt0 = p.promoted.bdt; s.thr0 = p.promoted.thr; s.tfire = p.promoted.last;
-        } else {
-            s.has = false;
-        }
-        s.popped = true;
-    }
-}
-// the levels behind an unpopped root after frame t, in their resident form (store(k, Node) for k = 1 ..): returns m
-template <class Get, class Store>
-ADDER_HD uint32_t cz_materialize(const CzPx &s, uint32_t t, float T, const Get &get, Store &store) {
-    if (!s.has) return 0u;
-    uint32_t m = 1u;
-    if (!s.popped) {
-        uint32_t t0 = s.tfire;
-        while (t0 < t) {
-            const CzNode n = cz_replay(t0, t, T, get);
-            Node node;
-            node.integ = n.S; node.dt = n.dt; node.bdt = n.bdt; node.bd = lean_bd_from_thr(f32_to_bits(n.thr));
-            store(m, node);
-            m += 1u;
-            t0 = n.last;
-        }
-    }
-    return m;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -11,8 +11,6 @@
 
 #include <vector>
 
-static unsigned long long g_cz_scan_mismatches = 0;  // integer replays (cz_replay_scan) that differ from the stepped ones
-#define ADDER_CZ_SCAN_CHECK() (++g_cz_scan_mismatches)
 #include "adder_pixel.hpp"
 
 using namespace adder;
@@ -48,11 +46,6 @@ struct Sim {
     std::vector<float> c_integ, c_dt, c_bdt;       // [node][unit]
     uint64_t fast_steps, generic_steps, lean_steps, cb_steps, cb_quiet_steps, lean_quiet_steps;
     int cb_quiet_path;  // take the device's quiet-wave reduction wherever a unit qualifies (default on)
-    // lazy levels (cz_step): absolute frame counter, the last kCzHistory frames of input, "every frame since the reset went through it"
-    uint32_t cz_frames;
-    int cz_ok;
-    std::vector<uint8_t> cz_hist;  // [kCzHistory][N], frame f at row f % kCzHistory
-    uint64_t cz_steps, cz_replays;
     int quiet_group_path;  // ... and its group form (quiet_group_apply / lr_quiet_run: 16 frames decided at once) where a launch allows
     uint64_t quiet_groups, quiet_group_fires, quiet_group_slow;  // groups applied in closed form / of those with a firing / stepped by the unit
     int use_cb;          // Collapse with delta_t_max > time: the bounded step (cb_step) instead of the generic one
@@ -152,10 +145,6 @@ Sim *sim_new(uint32_t W, uint32_t H, uint32_t C, uint32_t row_begin, int time_mo
     s->continuous = 0;
     s->fast_steps = s->generic_steps = s->lean_steps = s->cb_steps = s->cb_quiet_steps = s->lean_quiet_steps = 0;
     s->cb_quiet_path = 1;
-    s->cz_frames = 0;
-    s->cz_ok = 1;
-    s->cz_hist.assign((size_t)kCzHistory * s->N, 0);
-    s->cz_steps = s->cz_replays = 0;
     s->quiet_group_path = 1;
     s->quiet_groups = s->quiet_group_fires = s->quiet_group_slow = 0;
     s->use_cb = 1;
@@ -290,7 +279,6 @@ static bool sim_cb_possible(const Sim *s, float T) {
 int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
     if (!sim_cb_possible(s, T)) return -7;
     s->generic_sticky = 1;
-    s->cz_ok = 0;
     StepConsts sc;
     sc.time_spanned = T;
     sc.dtm_f = (float)s->dtm;
@@ -414,149 +402,6 @@ int sim_integrate_cb_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
-// One launch of the LAZY-LEVELS step (cz_step / cz_emit / cz_materialize), as adder_cz_kernel runs it: only the roots are
-// loaded and stepped, a flush or a pop replays the levels it needs from the unit's last input bytes (this launch's frames,
-// the context's history of the kCzHistory frames before it), the launch's end writes the levels back in their resident
-// form.  -7 outside its regime: the bounded Collapse step's, delta_t_max / T <= kCzHistory, and every frame since the reset
-// through this function (the history and the roots' ages are its own).
-int sim_integrate_cz_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
-    if (!sim_cb_possible(s, T) || !s->cz_ok) return -7;
-    if (!((float)s->dtm <= T * (float)kCzHistory)) return -7;
-    s->generic_sticky = 1;
-    StepConsts sc;
-    sc.time_spanned = T;
-    sc.dtm_f = (float)s->dtm;
-    sc.ref_time = s->ref_time;
-    sc.collapse = 1;
-    sc.abs_t = s->abs_t;
-    sc.max_depth = s->max_depth;
-    sc.ref_magic = s->ref_time >= 2 ? (uint32_t)(0x100000000ull / s->ref_time) : 0u;
-    std::vector<float> rts(nb);
-    std::vector<uint8_t> cths(nb);
-    {
-        float rt = s->running_t;
-        uint8_t cth = s->c_thresh, cctr = s->c_counter;
-        for (uint32_t i = 0; i < nb; ++i) {
-            rts[i] = rt;
-            cths[i] = cth;
-            rt += T;
-            c_thresh_advance(cth, cctr, (uint8_t)s->c_max, (uint8_t)s->velocity, T, s->ref_time);
-        }
-        s->running_t = rt;
-        s->c_thresh = cth;
-        s->c_counter = cctr;
-    }
-    const uint32_t first = s->cz_frames + 1u;  // index of the launch's first frame (frames are counted from 1)
-    std::vector<std::vector<SimEvent>> per_frame(nb);
-    int rc = 0;
-    size_t u = 0;
-    for (uint32_t y = 0; y < s->H; y++)
-        for (uint32_t x = 0; x < s->W; x++)
-            for (uint32_t c = 0; c < s->C; c++, u++) {
-                const uint32_t hdr = s->hdr[u];
-                CzPx p;
-                p.base = hdr & 0xffu;
-                p.has = hdr_m(hdr) != 0u;
-                p.popped = (hdr & kHdrPopped) != 0u;
-                p.S = p.has ? s->integ0[u] : -12345.0f;
-                p.dt0 = p.has ? s->dt0[u] : -777.0f;
-                p.bdt0 = p.has ? s->bdt0[u] : -999.0f;
-                p.thr0 = lean_thr_from_bd((hdr >> kHdrBdShift) & 0xffu);
-                p.lastf = s->abs_t ? s->lastf[u] : -1.0f;
-                p.tfire = (first - 1u) - (hdr >> kHdrAgeShift);
-                auto get = [&](uint32_t f) -> uint32_t {
-                    s->cz_replays++;
-                    if (f >= first) return frames[(size_t)(f - first) * s->N + u];
-                    if (f + kCzHistory < first || f == 0u) { rc = -12; return 0u; }  // (older than the history: must never be asked for)
-                    return s->cz_hist[(size_t)(f % kCzHistory) * s->N + u];
-                };
-                for (uint32_t i = 0; i < nb; ++i) {
-                    sc.running_t = rts[i];
-                    sc.running_t_u32 = f32_as_u32(rts[i]);
-                    struct VecEmit {
-                        std::vector<SimEvent> *v;
-                        uint16_t x, y;
-                        uint8_t c;
-                        uint32_t n;
-                        void put(uint32_t d, uint32_t t) {
-                            SimEvent e;
-                            e.x = x; e.y = y; e.c = c; e.d = (uint8_t)d; e.pad = 0; e.t = t;
-                            v->push_back(e);
-                            ++n;
-                        }
-                        void ev(uint32_t thr_bits, uint32_t t) { put(cb_d_from_code(thr_bits >> 23), t); }
-                        void filler(uint32_t t) { put(cb_d_from_code(kCbCodeEmpty), t); }
-                    } em{&per_frame[i], (uint16_t)x, (uint16_t)(y + s->row_begin), s->C == 1 ? (uint8_t)0xFF : (uint8_t)c, 0u};
-                    if (s->quiet_group_path && (i % kQuietGroup) == 0u && p.has) {
-                        // the kernel's group form, for popped and unpopped roots alike (no flush, no pop inside the group)
-                        const uint32_t n = nb - i < kQuietGroup ? nb - i : kQuietGroup;
-                        uint32_t cth_min = 255u;
-                        for (uint32_t k = 0; k < n; ++k) cth_min = cths[i + k] < cth_min ? cths[i + k] : cth_min;
-                        const QuietGroupStats g = quiet_group_stats(frames + (size_t)i * s->N + u, s->N, n, quiet_group_need(p.S, p.thr0));
-                        CzPx t = p;
-                        uint32_t fired = n;
-                        const uint32_t r = quiet_group_apply(t.S, t.dt0, t.bdt0, t.thr0, t.base, t.popped, g, n, cth_min, T, sc.dtm_f, &fired);
-                        if (r != kQuietNo) {
-                            if (r == kQuietDone) {
-                                p = t;
-                                if (fired < n) p.tfire = first + i + fired;
-                                s->quiet_groups++;
-                            } else {
-                                CzNode nd{p.S, p.dt0, p.bdt0, p.thr0, p.tfire, true};
-                                for (uint32_t k = 0; k < n; ++k) cz_node_step(nd, frames[(size_t)(i + k) * s->N + u], T, first + i + k);
-                                p.S = nd.S; p.dt0 = nd.dt; p.bdt0 = nd.bdt; p.thr0 = nd.thr; p.tfire = nd.last;
-                                s->quiet_group_slow++;
-                            }
-                            s->cz_steps += n;
-                            i += n - 1u;
-                            continue;
-                        }
-                    }
-                    CzPlan plan;
-                    cz_step(p, frames[(size_t)i * s->N + u], cths[i], T, sc.dtm_f, first + i, get, plan);
-                    if (plan.depth_error) rc = -5;
-                    if (s->abs_t) cz_emit<true>(p, plan, sc, em); else cz_emit<false>(p, plan, sc, em);
-                    if (em.n != plan.count) s->plan_mismatch++;
-                    s->cz_steps++;
-                }
-                DeepAcc deep{s, u};
-                struct Store {
-                    DeepAcc *d;
-                    uint32_t max_depth;
-                    int *rc;
-                    void operator()(uint32_t k, const Node &n) {
-                        if (k < max_depth) d->store(k, n);
-                        else *rc = -5;
-                    }
-                } st{&deep, s->max_depth, &rc};
-                const uint32_t last = first + nb - 1u;
-                const uint32_t m = cz_materialize(p, last, T, get, st);
-                if (m > s->max_m) s->max_m = m;
-                const uint32_t age = p.has ? last - p.tfire : 0u;
-                s->hdr[u] = hdr_make(p.base, p.has ? lean_bd_from_thr(f32_to_bits(p.thr0)) : 0u, m, p.popped) | ((age < 1023u ? age : 1023u) << kHdrAgeShift);
-                if (p.has) { s->integ0[u] = p.S; s->dt0[u] = p.dt0; s->bdt0[u] = p.bdt0; }
-                if (s->abs_t) s->lastf[u] = p.lastf;
-                if (p.has)
-                    s->running[u] = (uint8_t)frame_value_u8(lean_bd_from_thr(f32_to_bits(p.thr0)), f32_as_u32(p.bdt0), (double)s->ref_time);
-            }
-    // the launch's last frames into the history
-    for (uint32_t i = nb > kCzHistory ? nb - kCzHistory : 0u; i < nb; ++i)
-        memcpy(&s->cz_hist[(size_t)((first + i) % kCzHistory) * s->N], frames + (size_t)i * s->N, s->N);
-    s->cz_frames += nb;
-    size_t pos = 0;
-    for (uint32_t i = 0; i < nb; ++i)
-        for (const SimEvent &e : per_frame[i]) {
-            if (pos < cap) out[pos] = e;
-            ++pos;
-        }
-    *n_out = pos;
-    if (pos > cap && rc == 0) rc = -4;
-    return rc;
-}
-uint64_t sim_cz_scan_mismatches() { return g_cz_scan_mismatches; }
-uint64_t sim_cz_steps(const Sim *s) { return s->cz_steps; }
-uint64_t sim_cz_replays(const Sim *s) { return s->cz_replays; }
-
 // One temporally blocked launch of the CONSTANT-RUN step (cr_step / cr_emit / cr_pop / cr_materialize), as
 // adder_cr_kernel runs it: only the roots are loaded and stepped, the levels are written back in their resident form at
 // the end.  The caller vouches for the regime (c_thresh 0 in every frame since the reset, one integer time_spanned):
@@ -564,7 +409,6 @@ uint64_t sim_cz_replays(const Sim *s) { return s->cz_replays; }
 int sim_integrate_cr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
     if (!sim_cb_possible(s, T) || s->c_thresh != 0 || s->c_max != 0) return -7;
     s->generic_sticky = 1;
-    s->cz_ok = 0;
     StepConsts sc;
     sc.time_spanned = T;
     sc.dtm_f = (float)s->dtm;
@@ -662,7 +506,6 @@ int sim_integrate_rr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     }
     if (s->abs_t && (T != (float)s->ref_time || s->ref_time < 255u)) return -7;
     s->generic_sticky = 1;
-    s->cz_ok = 0;
     const uint32_t Tu = (uint32_t)T;
     const uint32_t n_pop = (s->dtm + Tu - 1u) / Tu;
     std::vector<uint8_t> tab(256 * kRrTabRows);
@@ -844,7 +687,6 @@ int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *ou
         return sim_integrate_cb_block(s, frame, 1u, time_spanned, out, cap, n_out);
     if (!(time_spanned >= 1.0f) || time_spanned != (float)(uint32_t)time_spanned) s->frac_time_seen = 1;
     if (!lean) s->generic_sticky = 1;
-    s->cz_ok = 0;
     int rc = 0;
     Emitter em;
     em.out = out; em.cap = cap; em.pos = 0;

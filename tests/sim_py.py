@@ -73,13 +73,6 @@ def lib():
     L.sim_integrate_lr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_rr_block.restype = i32
     L.sim_integrate_rr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
-    L.sim_integrate_cz_block.restype = i32
-    L.sim_integrate_cz_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
-    for f in (L.sim_cz_steps, L.sim_cz_replays):
-        f.restype = C.c_uint64
-        f.argtypes = [vp]
-    L.sim_cz_scan_mismatches.restype = C.c_uint64
-    L.sim_cz_scan_mismatches.argtypes = []
     L.sim_integrate_cr_block.restype = i32
     L.sim_integrate_cr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate.restype = i32
@@ -240,27 +233,6 @@ class Sim:
         rc = self.L.sim_integrate_lr_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
                                            C.byref(n))
         return rc, out[: n.value].copy()
-
-    def integrate_cz_block(self, frames, time_spanned):
-        """nb frames as ONE launch of the lazy-levels step (only roots are stepped; levels replayed from the input bytes)."""
-        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), -1)
-        assert frames.shape[1] == self.n
-        cap = self._cap * len(frames)
-        out = np.zeros(cap, EVENT_DTYPE)
-        n = C.c_size_t(0)
-        rc = self.L.sim_integrate_cz_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
-                                           C.byref(n))
-        return rc, out[: n.value].copy()
-
-    @property
-    def cz_counts(self):
-        """(unit-frames stepped, input bytes fetched by replays)"""
-        return self.L.sim_cz_steps(self.h), self.L.sim_cz_replays(self.h)
-
-    @property
-    def cz_scan_mismatches(self):
-        """integer replays (cz_replay_scan, what the kernel runs) that differed from the stepped replay, process-wide"""
-        return self.L.sim_cz_scan_mismatches()
 
     def integrate_cr_block(self, frames, time_spanned):
         """nb frames as ONE launch of the constant-run step (c_thresh 0 throughout); (rc, events frame-major)."""

@@ -840,65 +840,3 @@ def test_lr_quiet_groups_break_at_every_position(time_mode):
             assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (groups_on, k, nb)
             k += nb
         assert (sv.quiet_groups[0] > 0.8 * frames * H * W / 16) == groups_on
-
-
-# ---- lazy levels: the bounded Collapse regime with only the roots stepped (cz_step / cz_emit / cz_materialize) ----
-@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
-@pytest.mark.parametrize("crf", [0, 3, 6, 9])
-def test_cz_lazy_levels_match_the_oracle(time_mode, crf):
-    """The reference's default mode (Collapse, delta_t_max = 30 frames) with the levels REPLAYED from the input bytes when a
-    flush or pop_top wants them: every content kind (jitter inside and across the contrast band, runs, steps, dark pixels
-    and zeros inside runs, noise, static), launches of every length (the history of the 32 frames before a launch), the
-    c_thresh ramp -- every event equals the oracle's, and the planes a launch leaves are the oracle's arena (a launch of the
-    bounded or the generic step continues from them)."""
-    rng = np.random.default_rng(101 + crf + 7 * time_mode)
-    for kind in ("jitter", "runs", "steps", "dark", "noise", "static", "scene"):
-        frames = 230
-        clip = (O.synth_clip(O.CONTENT_SCENE, 9, 7, 1, frames) if kind == "scene"
-                else clips.make_clip(kind, frames, 7, 9, 1, seed=31 + len(kind) + crf))
-        ov, sv = _cb_pair(9, 7, 1, time_mode, 7650, crf=CRFS[crf])
-        k, total = 0, 0
-        while k < 200:
-            nb = min(int(rng.choice([1, 2, 5, 16, 29, 30, 31, 64])), 200 - k)
-            want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
-            rc, got = sv.integrate_cz_block(clip[k:k + nb], 255.0)
-            assert rc == 0, (kind, k, rc)
-            assert len(want) == len(got) and np.array_equal(want, got), (kind, k, nb)
-            total += len(got)
-            k += nb
-        assert sv.plan_mismatches == 0 and sv.cz_counts[0] == 200 * 63
-        assert sv.cz_scan_mismatches == 0   # every replay made above was also made in integers (cz_replay_scan: the kernel's form)
-        # the planes it left: the other steps take over (and the lazy step then refuses: its history is no longer its own)
-        for j in range(200, frames):
-            want = ov.integrate_matrix(clip[j])
-            if j % 2:
-                rc, got = sv.integrate_cb_block(clip[j:j + 1], 255.0)
-            else:
-                sv.set_use_cb(False)
-                rc, got = sv.integrate(clip[j], 255.0)
-                sv.set_use_cb(True)
-            assert rc == 0 and np.array_equal(want, got), (kind, j)
-        assert sv.integrate_cz_block(clip[:1], 255.0)[0] == -7
-        if kind != "static":
-            assert total > 0
-
-
-def test_cz_other_windows_rgb_and_deep_chains():
-    """delta_t_max of 2, 3, 8 and 32 frames (the longest window the history holds), three channels, other tick rates; a
-    window beyond the history is refused."""
-    rng = np.random.default_rng(55)
-    for ref_time, dtm_frames, Cn in ((255, 2, 1), (255, 3, 3), (255, 8, 1), (255, 32, 1), (1000, 20, 1), (20, 30, 3)):
-        clip = clips.make_clip("jitter", 150, 5, 6, Cn, seed=dtm_frames)
-        clip[60:] = clips.make_clip("runs", 90, 5, 6, Cn, seed=dtm_frames + 1)
-        for tm in (O.DELTA_T, O.ABSOLUTE_T):
-            ov, sv = _cb_pair(6, 5, Cn, tm, ref_time * dtm_frames, ref_time=ref_time, crf=CRFS[3])
-            k = 0
-            while k < 150:
-                nb = min(int(rng.choice([1, 7, 33, 64])), 150 - k)
-                want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=float(ref_time)) for i in range(nb)])
-                rc, got = sv.integrate_cz_block(clip[k:k + nb], float(ref_time))
-                assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (ref_time, dtm_frames, Cn, tm, k)
-                k += nb
-            assert sv.cz_scan_mismatches == 0
-    ov, sv = _cb_pair(6, 5, 1, O.DELTA_T, 255 * 33, crf=CRFS[3])
-    assert sv.integrate_cz_block(clips.make_clip("runs", 2, 5, 6, 1, seed=1), 255.0)[0] == -7

@@ -12,6 +12,11 @@ import clips
 CRFS = {0: (0, 0, 10), 3: (2, 7, 7), 6: (7, 13, 4), 9: (15, 25, 1)}
 
 
+def _hipmod():
+    import adder_amd as A
+    return A
+
+
 def _pair(W, H, Cn, tm, dtm, crf, **kw):
     import adder_amd as A
     ov = O.Video(W, H, Cn, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
@@ -23,7 +28,7 @@ def _pair(W, H, Cn, tm, dtm, crf, **kw):
     return ov, hv
 
 
-def _run_batches(ov, hv, clip, lens, rng, reset_every=0, crf=None):
+def _run_batches(ov, hv, clip, lens, rng, reset_every=0, crf=None, kernel=None):
     k, total = 0, 0
     while k < len(clip):
         nb = min(int(rng.choice(lens)), len(clip) - k)
@@ -32,6 +37,8 @@ def _run_batches(ov, hv, clip, lens, rng, reset_every=0, crf=None):
                 v.reset_c_thresh(crf[0])
         want = [ov.integrate_matrix(clip[k + i]) for i in range(nb)]
         got, offs = hv.integrate_batch(clip[k:k + nb])
+        if kernel is not None and nb > 1:   # (the test means THIS kernel: adder_hip_last_batch_kernel; one-frame batches run the one-frame kernels)
+            assert hv.last_batch_kernel() == kernel, (k, nb, hv.last_batch_kernel())
         assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (k, nb)
         assert np.array_equal(got, np.concatenate(want)), (k, nb)
         total += len(got)
@@ -49,7 +56,7 @@ def test_lean_runs_quiet_groups_break_at_every_position(time_mode):
     assert sorted({b % 16 for b in breaks}) == list(range(16))
     for lens in ([frames], [64, 60, 37, 16, 100, 1, 2]):
         ov, hv = _pair(W, H, 1, time_mode, 255, CRFS[0])
-        assert _run_batches(ov, hv, clip, lens, rng) > 0
+        assert _run_batches(ov, hv, clip, lens, rng, kernel=_hipmod().KERNEL_LEAN_RUNS) > 0
         hv.close()
     # ragged plane (the register staging path, padding units), three channels
     clip3, _ = clips.quiet_group_clip(200, 7, 51, rng, jitter=0, C=3)
@@ -69,7 +76,7 @@ def test_bounded_collapse_quiet_groups_break_at_every_position_with_ramp_and_fir
     clip, breaks = clips.quiet_group_clip(frames, H, W, rng, jitter=1)
     for lens in ([frames], [64, 60, 37, 16, 100, 1, 5]):
         ov, hv = _pair(W, H, 1, time_mode, 7650, CRFS[crf], max_depth=20)
-        assert _run_batches(ov, hv, clip, lens, rng, reset_every=320, crf=CRFS[crf]) > 0
+        assert _run_batches(ov, hv, clip, lens, rng, reset_every=320, crf=CRFS[crf], kernel=_hipmod().KERNEL_BOUNDED) > 0
         hv.close()
     clip3, _ = clips.quiet_group_clip(260, 7, 51, rng, jitter=2, C=3)
     ov, hv = _pair(51, 7, 3, time_mode, 7650, CRFS[crf], max_depth=20)
@@ -88,7 +95,7 @@ def test_lean_kernel_quiet_groups_break_at_every_position_with_ramp_and_firings(
     clip, breaks = clips.quiet_group_clip(frames, H, W, rng, jitter=1)
     for lens in ([frames], [64, 60, 37, 16, 100, 1, 5]):
         ov, hv = _pair(W, H, 1, time_mode, 255, CRFS[crf])
-        assert _run_batches(ov, hv, clip, lens, rng, reset_every=320, crf=CRFS[crf]) > 0
+        assert _run_batches(ov, hv, clip, lens, rng, reset_every=320, crf=CRFS[crf], kernel=_hipmod().KERNEL_LEAN) > 0
         hv.close()
     clip3, _ = clips.quiet_group_clip(260, 7, 51, rng, jitter=2, C=3)
     ov, hv = _pair(51, 7, 3, time_mode, 255, CRFS[crf])
