@@ -1,3 +1,4 @@
+"""Does the default-quality per-frame ring leg depend on what the process ran before it?  The leg after N other contexts (the HW-queue mapping of DESIGN 5b)."""
 import json, os, sys
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "adder-codec-rs_amd"))
