@@ -94,6 +94,7 @@ def secondary_legs(args, torch, A):
                 "events_per_unit_frame": round(e, 5), "frames_per_chunk": hv.chunk_frames(),
                 "bytes_per_unit_frame": round(alg_b, 3), "achieved_GBs": round(achieved, 1),
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frame_kernel": A.KERNEL_NAMES[hv.last_batch_kernel()],  # (which K1 the leg's batches ran: adder_hip_last_batch_kernel)
                 "frame_kernel_us_per_frame": round(k1_pf, 3), "scan_offsets_expand_us_per_frame": round(post_pf, 3),
                 # the same algorithmic bytes over the kernels' own time, and each big kernel against ITS part of them:
                 # the frame kernel reads the input and moves the state, the expansion writes the events

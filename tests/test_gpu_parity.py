@@ -1936,3 +1936,90 @@ def test_integer_state_kernels_hand_over_past_65k_frames_since_the_reset():
             k += nb
         assert total > 10000
         hv.close()
+
+
+@pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
+def test_kernel_switch_points_random_walk_with_the_kernel_asserted(monkeypatch, time_mode):
+    """The step kernels are chosen per batch by host-side properties of the stream ("constant runs since the reset", the
+    window, the ramp): every switch point is a correctness surface.  A random walk over all the kernels a stream can meet,
+    batch by batch, with the kernel that ran ASSERTED (adder_hip_last_batch_kernel) -- the lean regime (lean runs, the lean
+    step, the one-frame kernels), the default mode (run records, constant runs, bounded Collapse; then a mid-stream
+    update_crf, after which only the bounded step may run), and a window that grows and shrinks mid-stream (lean -> bounded
+    Collapse -> the generic step, for good) -- against the oracle, with a rollback at some of the switch points."""
+    A = _hip()
+    rng = np.random.default_rng(401 + time_mode)
+    W, H = 131, 21
+
+    def pair(dtm, crf):
+        ov = O.Video(W, H, 1, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, 1, time_mode=time_mode, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm, max_depth=24)
+        ov.ensure_capacity(26)
+        for v in (ov, hv):
+            v.set_crf_parameters(crf[1], crf[2])
+            v.reset_c_thresh(crf[0])
+        return ov, hv
+
+    def batch(ov, hv, clip, k, nb, expect):
+        want = [ov.integrate_matrix(clip[k + i]) for i in range(nb)]
+        need = sum(len(w) for w in want)
+        if need > 4 and rng.random() < 0.25:   # a buffer that is too small first: the rollback lands on the switch point
+            with pytest.raises(A.AdderHipError) as ei:
+                hv.integrate_batch(clip[k:k + nb], out_cap=need - 1)
+            assert ei.value.code == A.E_OUT_CAPACITY and hv.last_required == need
+        got, offs = hv.integrate_batch(clip[k:k + nb], out_cap=max(need, 1))
+        assert hv.last_batch_kernel() in expect, (k, nb, hv.last_batch_kernel(), expect)
+        assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (k, nb)
+        assert np.array_equal(got, np.concatenate(want)), (k, nb)
+
+    # ---- the lean regime at crf 0: lean runs <-> the lean step <-> the one-frame kernels ----
+    clip = clips.make_clip("runs", 360, H, W, 1, seed=23)
+    clip[200:260] = clips.make_clip("dark", 60, H, W, 1, seed=24)
+    ov, hv = pair(255, CRFS[0])
+    k, seen = 0, set()
+    while k < len(clip):
+        choice = ("lr", "lean", "one")[int(rng.integers(0, 3))]
+        nb = 1 if choice == "one" else min(int(rng.choice([2, 5, 16, 60, 64, 70])), len(clip) - k)
+        monkeypatch.setenv("ADDER_HIP_NO_LR", "1" if choice == "lean" else "0")
+        expect = {A.KERNEL_LEAN_RUNS} if (choice == "lr" and nb > 1) else {A.KERNEL_LEAN}
+        batch(ov, hv, clip, k, nb, expect)
+        seen.add((choice, nb > 1))
+        k += nb
+    assert {("lr", True), ("lean", True), ("one", False)} <= seen
+    monkeypatch.delenv("ADDER_HIP_NO_LR")
+    hv.close()
+
+    # ---- the default mode at crf 0: run records <-> constant runs <-> bounded Collapse; then update_crf mid-stream ----
+    ov, hv = pair(7650, CRFS[0])
+    names = {"rr": A.KERNEL_RUN_RECORDS, "cr": A.KERNEL_CONSTANT_RUNS, "cb": A.KERNEL_BOUNDED}
+    k, seen = 0, set()
+    while k < 240:
+        step = ("rr", "cr", "cb")[int(rng.integers(0, 3))]
+        _use_step(monkeypatch, step)
+        nb = min(int(rng.choice([1, 3, 17, 64, 100])), 240 - k)
+        batch(ov, hv, clip, k, nb, {names[step]})
+        seen.add(step)
+        k += nb
+    assert seen == {"rr", "cr", "cb"}
+    for v in (ov, hv):   # update_crf: the ramp is alive from here on, the constant-run property is gone for good
+        v.set_crf_parameters(CRFS[3][1], CRFS[3][2])
+        v.reset_c_thresh(CRFS[3][0])
+    while k < len(clip):
+        _use_step(monkeypatch, ("rr", "cr", "cb")[int(rng.integers(0, 3))])
+        nb = min(int(rng.choice([1, 9, 64])), len(clip) - k)
+        batch(ov, hv, clip, k, nb, {A.KERNEL_BOUNDED})
+        k += nb
+    _use_step(monkeypatch, "rr")
+    hv.close()
+
+    # ---- the window grows and shrinks mid-stream (update_quality_manual): lean runs -> bounded Collapse -> generic ----
+    ov, hv = pair(255, CRFS[0])
+    k = 0
+    for dtm, expect, until in ((255, {A.KERNEL_LEAN_RUNS, A.KERNEL_LEAN}, 90), (7650, {A.KERNEL_BOUNDED, A.KERNEL_CONSTANT_RUNS, A.KERNEL_RUN_RECORDS}, 230),
+                               (255, {A.KERNEL_GENERIC}, len(clip))):
+        for v in (ov, hv):
+            v.set_delta_t_max(dtm)
+        while k < until:
+            nb = min(int(rng.choice([1, 4, 33, 64])), until - k)
+            batch(ov, hv, clip, k, nb, expect)
+            k += nb
+    hv.close()

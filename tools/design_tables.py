@@ -8,13 +8,13 @@ print(f"roofline: chunk {r['chunk_us']} us = frame kernel {r['frame_kernel_launc
       f"{r['traffic_over_record_bytes']}x at record bytes); one frame per launch: {d['roofline_one_frame_per_launch']['launch_avg_us']} us, frac {d['roofline_one_frame_per_launch']['frac']}")
 print("output_check:", d.get("output_check"))
 print()
-print("| leg | µs per frame | Mpixels/s | e | frac (wall) | frame kernel µs / frame | scan + offsets + expansion µs / frame | kernels frac | frame kernel frac | expansion frac |")
-print("|---|---|---|---|---|---|---|---|---|---|")
+print("| leg | K1 | µs per frame | Mpixels/s | e | frac (wall) | frame kernel µs / frame | scan + offsets + expansion µs / frame | kernels frac | frame kernel frac | expansion frac |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 for l in d.get("secondary", []):
     if "error" in l:
         print(f"| {l['workload']} | error: {l['error'][:60]} |")
         continue
-    print(f"| {l['workload']} | {l['us_per_frame']} | {l['value']:,.0f} | {l['events_per_unit_frame']} | {l['frac']} | {l.get('frame_kernel_us_per_frame')} | "
+    print(f"| {l['workload']} | {l.get('frame_kernel', '').replace('adder_', '').replace('_kernel', '')} | {l['us_per_frame']} | {l['value']:,.0f} | {l['events_per_unit_frame']} | {l['frac']} | {l.get('frame_kernel_us_per_frame')} | "
           f"{l.get('scan_offsets_expand_us_per_frame')} | {l.get('kernels_frac')} | {l.get('frame_kernel_frac')} | {l.get('expansion_frac')} |")
 print()
 for k, v in d.get("end_to_end", {}).items():
