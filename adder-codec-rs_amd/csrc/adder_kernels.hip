@@ -1612,6 +1612,10 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 #else
     using L = ScalarLanes;
 #endif
+#ifdef ADDER_CB_PROFILE  // (diagnostic build: cycles per section of the wave, into the timeline buffer's spare slots; tools/probes/cb_profile.py)
+    const unsigned long long cbp_wave0 = __builtin_readcyclecounter();
+    unsigned long long cbp_acc[4] = {0ull, 0ull, 0ull, 0ull};  // general-frame cycles, general frames, quiet-section cycles, quiet sections
+#endif
     CbPxT<L> px[N];
     uint32_t snap_m[N];  // fired levels as the header has them (the undo copy takes all of them)
     {
@@ -1687,6 +1691,10 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     i = nb;
 #endif
     while (i < nb) {  // quiet frames, then general frames up to the next input group, then the same again
+#ifdef ADDER_CB_PROFILE
+        const unsigned long long cbp_q0 = __builtin_readcyclecounter();
+        const uint32_t cbp_i0 = i;
+#endif
 #if ADDER_CB_GENERAL_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1820,6 +1828,12 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     // (general frames up to the end of the input group -- the quiet test above then gets another look; the bound is the
     // loop's own, the frames carry no test)
     const uint32_t i_end = ADDER_CB_QUIET_PATH ? ((i / kCbInFrames + 1u) * kCbInFrames < nb ? (i / kCbInFrames + 1u) * kCbInFrames : nb) : nb;
+#ifdef ADDER_CB_PROFILE
+    const unsigned long long cbp_g0 = __builtin_readcyclecounter();
+    cbp_acc[2] += cbp_g0 - cbp_q0;
+    cbp_acc[3] += i - cbp_i0;
+    const uint32_t cbp_i1 = i;
+#endif
 #if ADDER_CB_GENERAL_PRIO
     // A wave in the general loop is the launch's critical path on mostly quiet content (it steps 128 units through ~470
     // instructions per frame while its quiet neighbours are done after a few hundred per GROUP): it asks the SIMD's
@@ -1902,7 +1916,14 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             cb_pop<L>(px[j], plan[j], lv[j]);
         }
     }
+#ifdef ADDER_CB_PROFILE
+    cbp_acc[0] += __builtin_readcyclecounter() - cbp_g0;
+    cbp_acc[1] += i - cbp_i1;
+#endif
     }
+#ifdef ADDER_CB_PROFILE
+    const unsigned long long cbp_loop_end = __builtin_readcyclecounter();
+#endif
     if (L::lane(depth_error)) raise(a.status, kStatusDepth);
     log.close(lane);
     if (lane < nb) {
@@ -1940,12 +1961,31 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
                                                                 f32_as_u32(px[j].bdt0), (double)sc.ref_time);
         }
     }
+#ifdef ADDER_CB_PROFILE
+    if (b->timeline && lane == 0u) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        unsigned long long *const t = b->timeline + (3u * kTimelineChunks + 32u) * 2u + 1u;
+        for (uint32_t q = 0; q < 4u; ++q) atomicAdd(t + q * 2u, cbp_acc[q]);
+        atomicAdd(t + 4u * 2u, now - cbp_wave0);
+        atomicAdd(t + 5u * 2u, 1ull);
+        atomicMax(t + 6u * 2u, now - cbp_wave0);
+        atomicMax(t + 7u * 2u, cbp_acc[0]);       // the wave with the most general-path cycles
+        atomicMax(t + 8u * 2u, cbp_acc[1]);       // ... and the most general frames
+        atomicAdd(t + 9u * 2u, cbp_loop_end - cbp_wave0 - cbp_acc[0] - cbp_acc[2]);  // prologue
+        atomicAdd(t + 10u * 2u, now - cbp_loop_end);  // epilogue
+        if (cbp_acc[1] >= 48ull) { atomicAdd(t + 11u * 2u, now - cbp_wave0); atomicAdd(t + 12u * 2u, 1ull); atomicAdd(t + 13u * 2u, cbp_acc[0]); }  // busy waves
+    }
+#endif
 }
 
 template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_cb_kernel(const BatchArgs *__restrict__ b,
                                                                                          uint32_t f, uint32_t nb) {
     __shared__ CbWaveLds s_w[kWavesPerBlock];
+#ifdef ADDER_CB_LDS_PAD  // (experiment: fewer workgroups per CU)
+    __shared__ uint8_t s_pad[ADDER_CB_LDS_PAD];
+    if (nb == 0xffffffffu) s_pad[threadIdx.x] = (uint8_t)f;
+#endif
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
