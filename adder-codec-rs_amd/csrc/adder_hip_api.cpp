@@ -714,7 +714,9 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
     return ADDER_OK;
 }
 
-extern "C" void adder_hip_destroy(AdderHipCtx *ctx) { free_ctx(ctx); }
+static void ring_timeline_report();  // (diagnostics: ADDER_HIP_RING_TIMING=2, below)
+extern "C" void adder_hip_destroy(AdderHipCtx *ctx) {
+    ring_timeline_report(); free_ctx(ctx); }
 
 extern "C" const char *adder_hip_last_error(const AdderHipCtx *ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
@@ -2464,6 +2466,46 @@ static uint32_t wire_scatter_blocks(const AdderHipCtx *c) {
     return env ? env : c->num_cus * 2u;  // (sweep, 1080p e = 0.3: 64-128: 203, 256: 197, 512: 185, 1024: 189 us per frame)
 }
 
+struct RingTiming {  // ADDER_HIP_RING_TIMING=1: where adder_hip_frame_submit's host time goes (printed when the process ends)
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    ~RingTiming() {
+        if (n) fprintf(stderr, "[adder_hip] frame_submit host us per call over %llu calls: upload %.1f | in-event pair %.1f | enqueue (description copy + frame kernel) %.1f | frame-event pair %.1f | hand-over launch %.1f | done event %.1f\n",
+                       (unsigned long long)n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n);
+    }
+};
+static RingTiming g_ring_timing;
+// ADDER_HIP_RING_TIMING=2: the GPU side of the last frames on one clock -- timing events before / behind the upload, around the
+// frame kernel and behind the hand-over; adder_hip_destroy prints them relative to the first (us)
+struct RingGpuTimeline {
+    static constexpr int kFrames = 96, kPer = 5;
+    hipEvent_t ev[kFrames][kPer] = {};
+    uint64_t n = 0;
+    bool made = false;
+    void make() {
+        if (made) return;
+        for (auto &row : ev)
+            for (hipEvent_t &e : row) (void)hipEventCreate(&e);
+        made = true;
+    }
+    void report() {
+        if (!made || n < 24) return;
+        (void)hipDeviceSynchronize();
+        const uint64_t first = n > (uint64_t)kFrames ? n - kFrames : 0, from = n - 16;
+        hipEvent_t base = ev[from % kFrames][0];
+        fprintf(stderr, "[adder_hip] ring timeline, us from frame %llu's upload start: upload start, upload end, kernel start, kernel end, hand-over end\n", (unsigned long long)from);
+        (void)first;
+        for (uint64_t f = from; f < n; ++f) {
+            float t[kPer];
+            for (int k = 0; k < kPer; ++k) (void)hipEventElapsedTime(&t[k], base, ev[f % kFrames][k]);
+            fprintf(stderr, "  frame %llu: %8.1f %8.1f %8.1f %8.1f %8.1f\n", (unsigned long long)f, t[0] * 1e3f, t[1] * 1e3f, t[2] * 1e3f, t[3] * 1e3f, t[4] * 1e3f);
+        }
+        n = 0;
+    }
+};
+static RingGpuTimeline g_ring_tl;
+static void ring_timeline_report() { g_ring_tl.report(); }
+#define RING_T(k) do { if (ring_timing) { const auto t_ = std::chrono::steady_clock::now(); g_ring_timing.acc[k] += std::chrono::duration<double, std::micro>(t_ - rt_).count(); rt_ = t_; } } while (0)
 static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_stride, float time_spanned,
                              AdderEvent *direct_out, size_t direct_cap) {
     if (c->poisoned) return fail(c, ADDER_E_POISONED, "context is poisoned by an earlier failure: %s", c->err.c_str());
@@ -2534,10 +2576,11 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         if (c->ring_cands.empty()) {
             // the context's own pair, post-processing on the context's stream, and three more pairs -- a spare stream between
             // two pairs, so that the pairs sit at every offset of the runtime's round robin over its (four) hardware queues
-            c->ring_cands.resize(5);
+            const int n_cands = 5;
+            c->ring_cands.resize(n_cands);
             c->ring_cands[0].out_s = c->out_s; c->ring_cands[0].in_s = c->in_s;
             c->ring_cands[1].out_s = c->out_s; c->ring_cands[1].in_s = c->in_s; c->ring_cands[1].post_on_main = true;
-            for (int k = 2; k < 5; ++k) {
+            for (int k = 2; k < n_cands; ++k) {
                 hipStream_t t[3] = {nullptr, nullptr, nullptr};
                 for (hipStream_t &x : t) {
                     HIPCHK(c, hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
@@ -2555,14 +2598,27 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         ring_out = rc_.out_s;
         post_on_main = rc_.post_on_main;
     }
+    static const bool ring_timing = env_flag("ADDER_HIP_RING_TIMING");
+    static const bool ring_tl = [] { const char *e = getenv("ADDER_HIP_RING_TIMING"); return e && atoi(e) == 2; }();
+    hipEvent_t *tl = nullptr;
+    if (ring_tl) {
+        g_ring_tl.make();
+        tl = g_ring_tl.ev[g_ring_tl.n % RingGpuTimeline::kFrames];
+        HIPCHK(c, hipEventRecord(tl[0], up));
+    }
+    auto rt_ = std::chrono::steady_clock::now();
     if (row_stride == rowlen)
         HIPCHK(c, hipMemcpyAsync(fs.d_frame, frame, c->n_units, hipMemcpyHostToDevice, up));
     else
         HIPCHK(c, hipMemcpy2DAsync(fs.d_frame, rowlen, frame, row_stride, rowlen, c->rows, hipMemcpyHostToDevice, up));
+    RING_T(0);
+    if (tl) HIPCHK(c, hipEventRecord(tl[1], up));
     if (own_upload) {
         HIPCHK(c, hipEventRecord(c->in_e, up));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->in_e, 0));
     }
+    RING_T(1);
+    if (tl) HIPCHK(c, hipEventRecord(tl[2], c->stream));
     // the slot's own batch description: the shared one may still be read by the copy engine for the frame before
     struct Swap {
         AdderHipCtx *c;
@@ -2607,6 +2663,8 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         c->poisoned = true;
         return rc;
     }
+    RING_T(2);
+    if (tl) HIPCHK(c, hipEventRecord(tl[3], c->stream));
     // where the frame's scan / expansion / hand-over go: the ring's second stream (behind an event), or -- post_on_main -- the
     // context's own stream behind the frame kernel (no cross-stream dependency at all)
     hipStream_t post_s = post_on_main ? c->stream : ring_out;
@@ -2614,6 +2672,7 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         HIPCHK(c, hipEventRecord(c->frame_e, c->stream));
         HIPCHK(c, hipStreamWaitEvent(ring_out, c->frame_e, 0));
     }
+    RING_T(3);
     const bool wire = c->f_wire && !direct_out;
     fs.wire = wire;
     // the hand-over: wire scatter (9 / 11-byte records straight into the slot: 25 % fewer bytes over PCIe, and what the raw
@@ -2669,9 +2728,34 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
             return rc;
         }
     }
+    RING_T(4);
     HIPCHK(c, hipEventRecord(fs.done, post_s));
+    RING_T(5);
+    if (tl) {
+        HIPCHK(c, hipEventRecord(tl[4], post_s));
+        g_ring_tl.n += 1;
+    }
+    if (ring_timing) g_ring_timing.n += 1;
     c->f_submitted += 1;
     return ADDER_OK;
+}
+
+// Waiting for a frame slot's `done` event: polled for a while before the thread is parked -- an event wait that parks wakes
+// up tens of microseconds late (adder_hip_finish spins on its result flag for the same reason), and at one frame per 60 us
+// that is a third of the period.  ADDER_HIP_RING_NO_SPIN=1: park at once.
+static hipError_t wait_done_event(hipEvent_t e) {
+    static const bool no_spin = env_flag("ADDER_HIP_RING_NO_SPIN");
+    if (!no_spin) {
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        uint32_t polls = 0;
+        for (;;) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if ((++polls & 15u) == 0u && std::chrono::steady_clock::now() >= t_end) break;
+        }
+    }
+    return hipEventSynchronize(e);
 }
 
 static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t *n_events, const uint32_t **chunk_offsets) {
@@ -2683,7 +2767,7 @@ static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t 
         // wait means the GPU side is the bound; a caller paced by its source never measures, and needs no choice)
         constexpr uint32_t kWindow = 24;
         const auto t0 = std::chrono::steady_clock::now();
-        HIPCHK(c, hipEventSynchronize(fs.done));
+        HIPCHK(c, wait_done_event(fs.done));
         const auto t1 = std::chrono::steady_clock::now();
         if (c->ring_win_skip) {  // (frames queued under the candidate before are still draining)
             if (--c->ring_win_skip == 0u) {
@@ -2712,7 +2796,7 @@ static int frame_collect_impl(AdderHipCtx *c, const AdderEvent **events, size_t 
             }
         }
     } else {
-        HIPCHK(c, hipEventSynchronize(fs.done));
+        HIPCHK(c, wait_done_event(fs.done));
     }
     c->f_collected += 1;
     const FrameResult *res = reinterpret_cast<const FrameResult *>(fs.h_hdr);
