@@ -65,7 +65,7 @@ struct AdderHipCtx {
         bool valid = false, deep = false;
         float running_t = 0.0f;
         uint8_t c_thresh = 0, c_counter = 0;
-        uint64_t frames_done = 0;
+        uint64_t frames_done = 0, run_bound = 0;
         bool generic_sticky = false;
         uint8_t *cth_px = nullptr, *cctr_px = nullptr, *fset = nullptr, *running = nullptr;
         bool perpx = false, has_running = false;
@@ -110,6 +110,13 @@ struct AdderHipCtx {
     // time_spanned, so every arena is a function of (its run's intensity, the run's length) -- adder_pixel.hpp
     bool cr_valid = true;
     float cr_time = 0.0f;
+    // The integer-state kernels need rho * max(255, time_spanned) < 2^24 for every run length rho.  run_bound = an upper bound
+    // of any unit's run: it grows by every frame queued and comes down to what the kernels REPORT at the end of a batch
+    // (BatchResult::max_run) -- so a stream whose pixels keep changing stays on the integer kernels for good, where "frames
+    // since the reset" sent every stream to the float kernels after 65 793 frames (18 minutes of video)
+    uint64_t run_bound = 0, pending_end_frames = 0;
+    bool pending_reports = false;
+    uint32_t *d_run_max = nullptr;
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
     uint32_t *ftot_ring = nullptr;   // [slots]
@@ -359,6 +366,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->d_rec_total) (void)hipFree(c->d_rec_total);
     if (c->d_side_words) (void)hipFree(c->d_side_words);
     if (c->d_rr_tab) (void)hipFree(c->d_rr_tab);
+    if (c->d_run_max) (void)hipFree(c->d_run_max);
     if (c->d_lr_tab) (void)hipFree(c->d_lr_tab);
     if (c->d_band_desc) (void)hipFree(c->d_band_desc);
     if (c->h_band_desc) (void)hipHostFree(c->h_band_desc);
@@ -498,6 +506,8 @@ static int init_state(AdderHipCtx *c) {
     c->frac_time_seen = false;
     c->cr_valid = true;
     c->cr_time = 0.0f;
+    c->run_bound = 0;
+    c->pending_reports = false;
     c->dtm_max_seen = p.delta_t_max;
     c->perpx = false;
     c->sparse_mode = false;
@@ -1403,6 +1413,7 @@ static int take_snapshot(AdderHipCtx *c, bool deep, hipStream_t s) {
     n.c_thresh = c->c_thresh;
     n.c_counter = c->c_counter;
     n.frames_done = c->frames_done;
+    n.run_bound = c->run_bound;
     n.generic_sticky = c->generic_sticky;
     n.valid = true;
     return ADDER_OK;
@@ -1437,6 +1448,8 @@ static int restore_snapshot(AdderHipCtx *c, hipStream_t s) {
     c->c_thresh = n.c_thresh;
     c->c_counter = n.c_counter;
     c->frames_done = n.frames_done;
+    c->run_bound = n.run_bound;
+    c->pending_reports = false;
     c->generic_sticky = n.generic_sticky;
     n.valid = false;
     return ADDER_OK;
@@ -1501,6 +1514,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->cr_time = time_spanned;
     const bool cr_off = env_flag("ADDER_HIP_NO_CR");  // (read per batch: the tests switch kernels inside one process)
     const bool cr = cb && c->cr_valid && !cr_off;  // ... then only the roots are stepped (adder_cr_kernel)
+    // how long a run can be by now: frames since the reset in AbsoluteT (last_fired_t / T is an integer of that size), in DeltaT
+    // the bound the kernels' own reports keep down (AdderHipCtx::run_bound)
+    const uint64_t run_frames = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? c->frames_done : std::min<uint64_t>(c->run_bound, c->frames_done);
     // run records (adder_rr_kernel): the same regime with integer state while n * 255 and n * time_spanned stay exact in
     // binary32; AbsoluteT also wants last_fired_t on multiples of time_spanned (time_spanned == ref_time >= 255)
     const bool rr_off = env_flag("ADDER_HIP_NO_RR");
@@ -1508,7 +1524,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const bool rr_regime = cr || (generic && !collapse && c->cr_valid && rr_possible(c, time_spanned, true));
     const bool rr = rr_regime && !rr_off &&
                     (c->p.time_mode != ADDER_TIME_ABSOLUTE_T || (time_spanned == (float)c->p.ref_time && c->p.ref_time >= 255u)) &&
-                    (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
+                    (double)(run_frames + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     // lean runs (adder_lr_kernel): the lean regime in DeltaT under the same property, in blocked batches of events, while
     // rho * 255 and rho * time_spanned stay exact in binary32 (rho <= frames since the reset)
     const bool lr_off = env_flag("ADDER_HIP_NO_LR");
@@ -1519,7 +1535,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // payload and root's expansion works the events out of them like the single-GPU one)
     const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
                     !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
-                    (double)(c->frames_done + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
+                    (double)(run_frames + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
@@ -1530,6 +1546,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         int rc_ = ensure_lr_tab(c, time_spanned, stream);
         if (rc_ != ADDER_OK) return rc_;
     }
+    if ((lr || rr) && !c->d_run_max) HIPCHK(c, dalloc(&c->d_run_max, 1));
     if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
         std::vector<uint8_t> tab(256u * kRrTabRows);
         rr_build_tab(tab.data(), 255.0f);
@@ -1623,6 +1640,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         b.snap_dv_bdt = sd ? c->snap.dv_bdt : nullptr;
         b.snap_dv_bd = sd ? c->snap.dv_bd : nullptr;
     }
+    b.run_max = (lr || rr) ? c->d_run_max : nullptr;
+    if (b.run_max) HIPCHK(c, hipMemsetAsync(c->d_run_max, 0, sizeof(uint32_t), stream));
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
@@ -1742,6 +1761,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     c->c_counter = cctr;
     c->last_time_spanned = time_spanned;
     c->frames_done += num_frames;
+    c->run_bound += num_frames;  // (every unit may have gone on accumulating; adder_hip_finish takes the kernels' report)
+    c->pending_end_frames = c->frames_done;
+    c->pending_reports = b.run_max != nullptr;
     c->band_frame_pending = band_features(c);
     return ADDER_OK;
 }
@@ -2057,6 +2079,9 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
         st = c->h_result->status;
         total = c->h_result->total_events;
         c->last_records = c->h_result->records;
+        if (c->pending_reports)  // the longest run at the batch's end + whatever was queued behind it
+            c->run_bound = std::min<uint64_t>(c->run_bound, (uint64_t)c->h_result->max_run + (c->frames_done - c->pending_end_frames));
+        c->pending_reports = false;
     } else {
         HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));
         HIPCHK(c, hipMemcpyAsync(&total, c->pending_offsets + c->pending_frames, sizeof total, hipMemcpyDeviceToHost,

@@ -170,6 +170,9 @@ struct BatchArgs {
     // diagnostics (null in normal operation): first start / last end of every kernel of the batch on the 100 MHz
     // constant clock, [kernel kind 0 frame, 1 scan, 2 offsets, 3 expansion][chunk][2]  (tools/timeline_probe.py)
     unsigned long long *timeline;
+    // the integer-state kernels (lean runs, run records) report the longest run -- frames a root has accumulated -- their units
+    // hold at the end of a launch: the host's bound on "rho * 255 and rho * time_spanned stay exact in binary32" (may be null)
+    uint32_t *run_max;
 };
 constexpr uint32_t kTimelineChunks = 64;
 constexpr uint32_t kMaxBands = 16;  // bands one adder_expand_bands_kernel launch takes (more: one launch per band)
@@ -209,6 +212,8 @@ struct BatchResult {
     uint64_t records;       // parked records (diagnostics)
     uint32_t status;
     uint32_t valid;         // set last
+    uint32_t max_run;       // the longest run any unit held at the end of a launch of the batch (BatchArgs::run_max), 0 = not reported
+    uint32_t pad;
 };
 
 // result header of one frame handed to the host (adder_frame_out_kernel), in page-locked host memory

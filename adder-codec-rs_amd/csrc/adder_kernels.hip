@@ -48,6 +48,20 @@ __device__ __forceinline__ void timeline_mark(const BatchArgs *b, uint32_t kind,
     else atomicMin(slot, t);
 }
 
+// the segment's longest run into BatchArgs::run_max -- only when it beats what the batch's other waves have reported (static
+// content grows every unit's run alike: a handful of atomics per launch, not one per wave)
+__device__ __forceinline__ void report_run_max(const BatchArgs *__restrict__ b, uint32_t lane_max, uint32_t lane) {
+    uint32_t *const rm = b->run_max;
+    if (rm == nullptr) return;
+    uint32_t m = lane_max;
+#pragma unroll
+    for (uint32_t d = 32u; d != 0u; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)d);
+        m = o > m ? o : m;
+    }
+    if (lane == 0u && m > __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(rm, m);
+}
+
 __device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
     __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1015,6 +1029,7 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
     }
+    report_run_max(b, px[0].rho > px[1].rho ? px[0].rho : px[1].rho, lane);
     constexpr bool NTS_ = ADDER_NT_STATE != 0;
     if (lazy) {  // another launch of this batch follows: only what lr_unpack reads (header, delta_t, last_fired_t)
         uint32_t hdrv[N];
@@ -2326,6 +2341,7 @@ __device__ __forceinline__ void rr_run_segment(const BatchArgs *__restrict__ b, 
         s = s >= slots_u ? s - slots_u : s;
         gstore<uint32_t>(uniform_ptr(b->wtot_ring), (s * num_waves_u + sgw) * 4u, wt);
     }
+    report_run_max(b, px[0].n > px[1].n ? px[0].n : px[1].n, lane);
     if (lazy) {  // another launch of this batch follows: only what rr_unpack reads (header, delta_t, last_fired_t)
         uint32_t hdrv[N];
         float dv[N], lfv[N];
@@ -2692,6 +2708,7 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
     h->total_events = b->base.frame_offsets[num_frames];
     h->records = b->rec_total ? *b->rec_total : 0ull;
     h->status = *b->base.status;
+    h->max_run = b->run_max ? *b->run_max : 0u;
     __threadfence_system();
     h->valid = 1u;
 }

@@ -1376,8 +1376,9 @@ ADDER_HD void cr_pop(CrPxT<L> &s, const CrPlanT<L> &p, float T) {
 // popped_dtm}, the step is compares and a counter, and the one event that needs arithmetic (A, the flushed root's best
 // event) is worked out by the EXPANSION from (base_val, rho), densely, like it already works event C out from the
 // input byte.  The parked 8-byte record is {rho of the flushed root, unit | popped_dtm << 7 | flushed base_val << 8 |
-// input byte << 16}.  rho I and rho T stay below 2^24 (the host switches to lean_step before they would
-// not: 65 000 frames after a reset), so the closed form's operations are the stepped ones bit for bit.
+// input byte << 16}.  rho I and rho T stay below 2^24 (the host switches to lean_step before they would not: it bounds
+// the longest run by what the kernel reports, BatchArgs::run_max -- 65 793 frames), so the closed form's operations are the
+// stepped ones bit for bit.
 // ---------------------------------------------------------------------------------------
 // popped_dtm is no state of its own here: in this regime a root of non-zero intensity is popped in the very frame it
 // starts (it has accumulated time_spanned >= delta_t_max), a black one never is, a flush clears the flag and the same

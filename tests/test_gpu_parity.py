@@ -1938,6 +1938,51 @@ def test_integer_state_kernels_hand_over_past_65k_frames_since_the_reset():
         hv.close()
 
 
+def test_integer_state_kernels_stay_past_65k_frames_while_the_runs_are_short():
+    """The bound of the integer-state kernels is the longest RUN, not the stream's length: the kernels report the longest run
+    their units hold (BatchResult::max_run) and the host's bound follows it -- a DeltaT stream whose pixels keep changing
+    (every unit at least every 4 000 frames here) is still on adder_lr_kernel / adder_rr_kernel 72 000 frames after the
+    reset; one static pixel in the plane sends it to the float kernels at 65 793 frames as before, and so does AbsoluteT
+    (last_fired_t / T is an integer of the stream's length there).  All of it against the oracle."""
+    A = _hip()
+    W, H, T = 128, 2, 72000
+    rng = np.random.default_rng(18)
+    period = rng.integers(1500, 4000, (H, W, 1))
+    phase = rng.integers(0, 4000, (H, W, 1))
+    vals = rng.integers(0, 256, (64, H, W, 1)).astype(np.uint8)
+    clip = np.empty((T, H, W, 1), np.uint8)
+    idx = np.arange(H * W).reshape(H, W, 1)
+    for k in range(T):
+        step = (k + phase) // period            # every unit takes a new value every `period` frames of its own
+        clip[k] = np.take_along_axis(vals, (step % 64)[None], axis=0)[0]
+    cases = ((O.DELTA_T, 255, False, A.KERNEL_LEAN_RUNS), (O.DELTA_T, 7650, False, A.KERNEL_RUN_RECORDS),
+             (O.DELTA_T, 255, True, A.KERNEL_LEAN), (O.ABSOLUTE_T, 255, False, A.KERNEL_LEAN))
+    for tm, dtm, one_static, last_kernel in cases:
+        c = clip
+        if one_static:
+            c = clip.copy()
+            c[:, 1, 77] = 131                    # one pixel that never changes: its run is the stream
+        ov = O.Video(W, H, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, 1, time_mode=tm, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm, max_depth=24)
+        ov.ensure_capacity(26)
+        for v in (ov, hv):
+            v.set_crf_parameters(0, 10)
+            v.reset_c_thresh(0)
+        k, kernels = 0, []
+        while k < T:
+            nb = min(4096, T - k)
+            want = np.concatenate([ov.integrate_matrix(f) for f in c[k:k + nb]])
+            got, offs = hv.integrate_batch(c[k:k + nb])
+            assert len(got) == len(want) and np.array_equal(got, want), (tm, dtm, one_static, k)
+            kernels.append(hv.last_batch_kernel())
+            k += nb
+        integer = A.KERNEL_LEAN_RUNS if dtm == 255 else A.KERNEL_RUN_RECORDS
+        assert kernels[0] == integer and kernels[-1] == last_kernel, (tm, dtm, one_static, kernels)
+        if last_kernel != integer:               # the switch happens where frames * 255 reaches 2^24, not before
+            assert kernels[65793 // 4096 - 1] == integer, kernels
+        hv.close()
+
+
 @pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
 def test_kernel_switch_points_random_walk_with_the_kernel_asserted(monkeypatch, time_mode):
     """The step kernels are chosen per batch by host-side properties of the stream ("constant runs since the reset", the
