@@ -508,6 +508,9 @@ static int init_state(AdderHipCtx *c) {
     c->cr_time = 0.0f;
     c->run_bound = 0;
     c->pending_reports = false;
+#ifndef ADDER_DBG_NO_RUNMAX_RESET
+    if (c->d_run_max) HIPCHK(c, hipMemsetAsync(c->d_run_max, 0, sizeof(uint32_t), c->stream));
+#endif
     c->dtm_max_seen = p.delta_t_max;
     c->perpx = false;
     c->sparse_mode = false;
@@ -1546,7 +1549,10 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         int rc_ = ensure_lr_tab(c, time_spanned, stream);
         if (rc_ != ADDER_OK) return rc_;
     }
-    if ((lr || rr) && !c->d_run_max) HIPCHK(c, dalloc(&c->d_run_max, 1));
+    if ((lr || rr) && !c->d_run_max) {
+        HIPCHK(c, dalloc(&c->d_run_max, 1));
+        HIPCHK(c, hipMemset(c->d_run_max, 0, sizeof(uint32_t)));  // (once: adder_publish_kernel clears it behind every batch)
+    }
     if (rr && !c->d_rr_tab) {  // (does not depend on the time step: a node's last firing is ceil(2^e / I))
         std::vector<uint8_t> tab(256u * kRrTabRows);
         rr_build_tab(tab.data(), 255.0f);
@@ -1641,7 +1647,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         b.snap_dv_bd = sd ? c->snap.dv_bd : nullptr;
     }
     b.run_max = (lr || rr) ? c->d_run_max : nullptr;
-    if (b.run_max) HIPCHK(c, hipMemsetAsync(c->d_run_max, 0, sizeof(uint32_t), stream));
     b.wofs_ring = c->wofs_ring;
     b.wcur = c->wcur;
     // ring layout (park_offset): batches launched one frame at a time park frame-major, the others in groups of
@@ -2079,8 +2084,9 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
         st = c->h_result->status;
         total = c->h_result->total_events;
         c->last_records = c->h_result->records;
-        if (c->pending_reports)  // the longest run at the batch's end + whatever was queued behind it
-            c->run_bound = std::min<uint64_t>(c->run_bound, (uint64_t)c->h_result->max_run + (c->frames_done - c->pending_end_frames));
+        if (c->pending_reports)  // the longest run at the batch's end (0: below kRunReportMin) + whatever was queued behind it
+            c->run_bound = std::min<uint64_t>(c->run_bound, (uint64_t)std::max(c->h_result->max_run, kRunReportMin) +
+                                                                (c->frames_done - c->pending_end_frames));
         c->pending_reports = false;
     } else {
         HIPCHK(c, hipMemcpyAsync(&st, c->status, sizeof st, hipMemcpyDeviceToHost, c->pending_stream));

@@ -174,6 +174,7 @@ struct BatchArgs {
     // hold at the end of a launch: the host's bound on "rho * 255 and rho * time_spanned stay exact in binary32" (may be null)
     uint32_t *run_max;
 };
+constexpr uint32_t kRunReportMin = 16384;  // runs shorter than this are not reported (BatchResult::max_run 0 = "below it")
 constexpr uint32_t kTimelineChunks = 64;
 constexpr uint32_t kMaxBands = 16;  // bands one adder_expand_bands_kernel launch takes (more: one launch per band)
 

@@ -48,9 +48,11 @@ __device__ __forceinline__ void timeline_mark(const BatchArgs *b, uint32_t kind,
     else atomicMin(slot, t);
 }
 
-// the segment's longest run into BatchArgs::run_max -- only when it beats what the batch's other waves have reported (static
-// content grows every unit's run alike: a handful of atomics per launch, not one per wave)
+// the segment's longest run into BatchArgs::run_max, once it is long enough to matter (kRunReportMin frames: below that the
+// wave touches no memory) and only when it beats what the batch's other waves have reported (static content grows every
+// unit's run alike: a handful of atomics per launch, not one per wave)
 __device__ __forceinline__ void report_run_max(const BatchArgs *__restrict__ b, uint32_t lane_max, uint32_t lane) {
+    if (__builtin_amdgcn_ballot_w64(lane_max >= kRunReportMin) == 0ull) return;  // uniform
     uint32_t *const rm = b->run_max;
     if (rm == nullptr) return;
     uint32_t m = lane_max;
@@ -2708,7 +2710,11 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
     h->total_events = b->base.frame_offsets[num_frames];
     h->records = b->rec_total ? *b->rec_total : 0ull;
     h->status = *b->base.status;
-    h->max_run = b->run_max ? *b->run_max : 0u;
+    h->max_run = 0u;
+    if (b->run_max) {  // (read and cleared here: the next batch starts from zero without a host-side memset in front of it)
+        h->max_run = *b->run_max;
+        *b->run_max = 0u;
+    }
     __threadfence_system();
     h->valid = 1u;
 }
