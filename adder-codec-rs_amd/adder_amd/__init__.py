@@ -9,7 +9,7 @@ from ._native import (  # noqa: F401
     AdderHipError, AdderHipParams, AdderFramerParams, AdderCompressedParams, EVENT_DTYPE, SPARSE_STEP_DTYPE, LIB_PATH, load,
     TIME_DELTA_T, TIME_ABSOLUTE_T, TIME_MIXED, MULTI_NORMAL, MULTI_COLLAPSE,
     CONTENT_STATIC, CONTENT_NOISE, CONTENT_SCENE, D_EMPTY, D_ZERO_INTEGRATION, D_MAX, C_NONE,
-    KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS, KERNEL_LEAN_RUNS,
+    KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS, KERNEL_LEAN_RUNS, KERNEL_LEAN_RUNS_PACKED,
     KERNEL_NAMES,
     OK, E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED,
 )

@@ -21,9 +21,9 @@ D_MAX, D_ZERO_INTEGRATION, D_EMPTY, C_NONE = 127, 128, 255, 0xFF
 
 # adder_hip_last_batch_kernel (include/adder_hip.h)
 (KERNEL_LEAN, KERNEL_GENERIC, KERNEL_CONTINUOUS, KERNEL_BOUNDED, KERNEL_CONSTANT_RUNS, KERNEL_RUN_RECORDS,
- KERNEL_LEAN_RUNS) = range(7)
+ KERNEL_LEAN_RUNS, KERNEL_LEAN_RUNS_PACKED) = range(8)
 KERNEL_NAMES = ("adder_lean_kernel", "adder_frame_kernel", "adder_cont_kernel", "adder_cb_kernel", "adder_cr_kernel", "adder_rr_kernel",
-                "adder_lr_kernel")
+                "adder_lr_kernel", "adder_lp_kernel")
 
 OK = 0
 E_BAD_PARAMS, E_HIP, E_NO_DEVICE, E_OUT_CAPACITY, E_ARENA_DEPTH, E_TIMEOUT, E_POISONED = -1, -2, -3, -4, -5, -6, -7

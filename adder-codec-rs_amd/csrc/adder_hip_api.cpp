@@ -1539,7 +1539,12 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
                     !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(run_frames + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
-    const uint32_t variant = (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
+    // ... in packed bytes (adder_lp_kernel, four units per lane): DeltaT batches whose records the expansion reads itself
+    // (the pair's records lie in one run: the ring layout must keep a pair of segments adjacent)
+    const bool lp_off = env_flag("ADDER_HIP_NO_LP");
+    const bool lp = lr && !lp_off && c->p.time_mode == ADDER_TIME_DELTA_T && !c->records_only && c->park_group_shift >= 1u &&
+                    !park_frame_major();
+    const uint32_t variant = (lp ? 4096u : 0u) | (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |
@@ -2159,6 +2164,7 @@ extern "C" unsigned adder_hip_last_batch_kernel(const AdderHipCtx *c) {
     if (v & 128u) return ADDER_KERNEL_CONSTANT_RUNS;
     if (v & 32u) return ADDER_KERNEL_BOUNDED;
     if (v & 4u) return ADDER_KERNEL_GENERIC;
+    if (v & 4096u) return ADDER_KERNEL_LEAN_RUNS_PACKED;
     if (v & 256u) return ADDER_KERNEL_LEAN_RUNS;
     return ADDER_KERNEL_LEAN;
 }

@@ -291,6 +291,9 @@ extern "C" {
 hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t variant,
                               uint32_t num_waves, uint32_t grid_cap, hipStream_t stream,
                               const adder::Lean1wArgs *wide);  // (host copy of the level-0 planes, or null)
+// the lean-runs step in packed bytes (adder_lp_kernels.hip; variant bit 4096): a wave per PAIR of segments
+hipError_t adder_launch_lp(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t lazy, uint32_t num_waves,
+                           uint32_t grid_cap, hipStream_t stream);
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);

@@ -31,63 +31,9 @@
 
 #include "adder_kernels.h"
 #include "adder_pixel.hpp"
+#include "adder_kernel_util.hpp"
 
 namespace adder {
-
-constexpr uint32_t kWave = 64;
-constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
-
-// diagnostics: a workgroup's start / end into the batch's timeline (no-ops when the batch has none)
-__device__ __forceinline__ void timeline_mark(const BatchArgs *b, uint32_t kind, uint32_t f, bool end) {
-    if (!b->timeline || threadIdx.x != 0) return;
-    const uint32_t chunk = f / b->chunk;
-    if (chunk >= kTimelineChunks) return;
-    unsigned long long *slot = b->timeline + ((size_t)kind * kTimelineChunks + chunk) * 2u + (end ? 1u : 0u);
-    const unsigned long long t = wall_clock64();
-    if (end) atomicMax(slot, t);
-    else atomicMin(slot, t);
-}
-
-// the segment's longest run into BatchArgs::run_max, once it is long enough to matter (kRunReportMin frames: below that the
-// wave touches no memory) and only when it beats what the batch's other waves have reported (static content grows every
-// unit's run alike: a handful of atomics per launch, not one per wave)
-__device__ __forceinline__ void report_run_max(const BatchArgs *__restrict__ b, uint32_t lane_max, uint32_t lane) {
-    if (__builtin_amdgcn_ballot_w64(lane_max >= kRunReportMin) == 0ull) return;  // uniform
-    uint32_t *const rm = b->run_max;
-    if (rm == nullptr) return;
-    uint32_t m = lane_max;
-#pragma unroll
-    for (uint32_t d = 32u; d != 0u; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)m, (int)d);
-        m = o > m ? o : m;
-    }
-    if (lane == 0u && m > __hip_atomic_load(rm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(rm, m);
-}
-
-__device__ __forceinline__ void raise(uint32_t *status, uint32_t bit) {
-    __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, uint32_t lane) {
-#pragma unroll
-    for (uint32_t o = 1; o < kWave; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o, kWave);
-        if (lane >= o) x += y;
-    }
-    return x;
-}
-
-// the batch's ring layout in SGPRs
-__device__ __forceinline__ ParkLayout park_layout_u(const BatchArgs *__restrict__ b) {
-    ParkLayout l;
-    l.group_shift = __builtin_amdgcn_readfirstlane(b->park_layout.group_shift);
-    l.group_stride = __builtin_amdgcn_readfirstlane(b->park_layout.group_stride);
-    l.frame_stride = __builtin_amdgcn_readfirstlane(b->park_layout.frame_stride);
-    l.seg_stride = __builtin_amdgcn_readfirstlane(b->park_layout.seg_stride);
-    l.rot_shift = __builtin_amdgcn_readfirstlane(b->park_layout.rot_shift);
-    l.rot_mask = __builtin_amdgcn_readfirstlane(b->park_layout.rot_mask);
-    return l;
-}
 
 // levels k >= 1 of one unit, straight from / to the deep planes (index k - 1)
 struct DeepGlobal {
@@ -147,69 +93,6 @@ template <> struct VecOf<float, 2> { using type = float2; };
 template <> struct VecOf<uint8_t, 4> { using type = uint32_t; };
 template <> struct VecOf<uint8_t, 2> { using type = uint16_t; };
 
-// Global-address-space accesses as (wave-uniform base, 32-bit byte offset of the lane): the
-// pointers of the argument block are generic in the IR, which would make every access a FLAT
-// instruction with a 64-bit VALU address; with these the base stays in SGPRs and the lane
-// supplies one 32-bit offset (global_load/store ... saddr).  Offsets stay below 4 GiB: one state
-// plane holds n_pad * 4 bytes (adder_hip_create bounds n_pad), a parked segment a few KiB.
-#define ADDER_GLOBAL __attribute__((address_space(1)))
-template <int BYTES> struct RawOf;
-template <> struct RawOf<1> { using type = uint8_t; };
-template <> struct RawOf<2> { using type = uint16_t; };
-template <> struct RawOf<4> { using type = uint32_t; };
-template <> struct RawOf<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct RawOf<12> { typedef uint32_t type __attribute__((ext_vector_type(3))); };
-template <> struct RawOf<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <class V>
-__device__ __forceinline__ V gload(const void *base, uint32_t byte_off) {
-    using R = typename RawOf<sizeof(V)>::type;
-    const R r = *reinterpret_cast<const ADDER_GLOBAL R *>((const ADDER_GLOBAL char *)base + byte_off);
-    V v;
-    __builtin_memcpy(&v, &r, sizeof(V));
-    return v;
-}
-template <class V>
-__device__ __forceinline__ void gstore(void *base, uint32_t byte_off, V v) {
-    using R = typename RawOf<sizeof(V)>::type;
-    R r;
-    __builtin_memcpy(&r, &v, sizeof(V));
-    *reinterpret_cast<ADDER_GLOBAL R *>((ADDER_GLOBAL char *)base + byte_off) = r;
-}
-// The same with the non-temporal hint (`nt`: the line is marked for early eviction): for bytes that are
-// touched once -- the event stream on its way out, parked records on their way back in.
-template <class V>
-__device__ __forceinline__ V gload_nt(const void *base, uint32_t byte_off) {
-    using R = typename RawOf<sizeof(V)>::type;
-    const R r = __builtin_nontemporal_load(reinterpret_cast<const ADDER_GLOBAL R *>((const ADDER_GLOBAL char *)base + byte_off));
-    V v;
-    __builtin_memcpy(&v, &r, sizeof(V));
-    return v;
-}
-template <class V>
-__device__ __forceinline__ void gstore_nt(void *base, uint32_t byte_off, V v) {
-    using R = typename RawOf<sizeof(V)>::type;
-    R r;
-    __builtin_memcpy(&r, &v, sizeof(V));
-    __builtin_nontemporal_store(r, reinterpret_cast<ADDER_GLOBAL R *>((ADDER_GLOBAL char *)base + byte_off));
-}
-#ifndef ADDER_NT_EVENTS
-#define ADDER_NT_EVENTS 1
-#endif
-#ifndef ADDER_NT_RECLOAD
-#define ADDER_NT_RECLOAD 1
-#endif
-#ifndef ADDER_NT_INPUT
-#define ADDER_NT_INPUT 1
-#endif
-#ifndef ADDER_LDS_DIRECT_INPUT
-#define ADDER_LDS_DIRECT_INPUT 1
-#endif
-#ifndef ADDER_NT_STATE
-#define ADDER_NT_STATE 1
-#endif
-#ifndef ADDER_NT_RECSTORE
-#define ADDER_NT_RECSTORE 0
-#endif
 __device__ __forceinline__ void EmitPark::operator()(uint32_t d, uint32_t t) {
     gstore<uint2>(seg, off * 8u, make_uint2(t, d | tag | (off << 16)));  // (uniform base + the lane's 32-bit offset)
     ++off;
@@ -235,48 +118,6 @@ struct EmitCb {
     __device__ __forceinline__ void ev(uint32_t thr_bits, uint32_t t) { put(__builtin_amdgcn_alignbit(tagoff, thr_bits, 23), t); }
     __device__ __forceinline__ void filler(uint32_t t) { put((tagoff << 9) | kCbCodeEmpty, t); }
 };
-template <class V>
-__device__ __forceinline__ void gstore_ev(void *base, uint32_t byte_off, V v) {
-#if defined(ADDER_EV_POLICY_ID) && defined(__HIP_DEVICE_COMPILE__)  // A/B builds: the cache-policy bits of the event stream's 16-byte stores
-#if ADDER_EV_POLICY_ID == 1
-#define ADDER_EV_POLICY "sc1"
-#elif ADDER_EV_POLICY_ID == 2
-#define ADDER_EV_POLICY "sc0 sc1"
-#elif ADDER_EV_POLICY_ID == 3
-#define ADDER_EV_POLICY "nt sc1"
-#elif ADDER_EV_POLICY_ID == 4
-#define ADDER_EV_POLICY "sc0 sc1 nt"
-#elif ADDER_EV_POLICY_ID == 5
-#define ADDER_EV_POLICY "sc0"
-#else
-#define ADDER_EV_POLICY "sc0 nt"
-#endif
-    if constexpr (sizeof(V) == 16) {
-        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-        u4v r;
-        __builtin_memcpy(&r, &v, 16);
-        ADDER_GLOBAL char *const a64 = (ADDER_GLOBAL char *)base + byte_off;
-        asm volatile("global_store_dwordx4 %0, %1, off " ADDER_EV_POLICY : : "v"(a64), "v"(r) : "memory");
-        return;
-    }
-#endif
-    if (ADDER_NT_EVENTS) gstore_nt<V>(base, byte_off, v);
-    else gstore<V>(base, byte_off, v);
-}
-template <class V>
-__device__ __forceinline__ V gload_rec(const void *base, uint32_t byte_off) {
-    if (ADDER_NT_RECLOAD) return gload_nt<V>(base, byte_off);
-    return gload<V>(base, byte_off);
-}
-// a pointer that is the same in every lane, forced into SGPRs
-template <class T>
-__device__ __forceinline__ T *uniform_ptr(T *p) {
-    const uint64_t x = (uint64_t)p;
-    // (the builtin returns int: without the casts the low half would be sign-extended)
-    return (T *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) |
-                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x));
-}
-
 template <bool NT = false, class T>
 __device__ __forceinline__ void load_vec(const T *plane, uint32_t u0, T (&v)[kUnitsPerLane]) {
     using V = typename VecOf<T, kUnitsPerLane>::type;
@@ -304,18 +145,6 @@ __device__ __forceinline__ uint32_t load_input(const uint8_t *frame, uint32_t u0
             if (u0 + j < n_units) w |= (uint32_t)gload<uint8_t>(frame, u0 + j) << (8 * j);
     }
     return w;
-}
-
-// inclusive prefix sum across the wave with DPP row shifts / broadcasts (no LDS traffic)
-__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
-    // row_shr:1,2,4,8 within rows of 16, then row_bcast:15 and row_bcast:31
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, true);
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, true);
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, true);
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, true);
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
-    return x;
 }
 
 // packed 16-bit operations of the quiet groups' statistics (two units of a lane per instruction)
@@ -2968,11 +2797,14 @@ __device__ __forceinline__ uint4 load_rec_at(const void *base, uint32_t off, uin
 }
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6 || FORMAT == 7;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
     constexpr bool RR = FORMAT == 4;
-    constexpr bool LR = FORMAT == 5 || FORMAT == 6;  // lean-runs records (adder_lr_kernel) in fixed slots (5) or found through a run table (6:
+    constexpr bool LR = FORMAT == 5 || FORMAT == 6 || FORMAT == 7;  // lean-runs records (adder_lr_kernel) in fixed slots (5) or found through a run table (6:
                                       // the bands' packed records on root); formats of their own, so that
                                       // the decoders do not meet in one instantiation (their results would merge through registers)
+    // 7: adder_lp_kernel's records -- a PAIR of segments' records in one contiguous run at the pair's first slot, the unit
+    // counted from the pair's first unit (8 bits), rho as rho' (adder_pixel.hpp lp_rho)
+    constexpr bool LP = FORMAT == 7;
     // staging capacity of one wave, in events: run-record rounds hold up to 64 x (depth + 1) events and like room
     constexpr uint32_t XE = RR ? 640u : kXbufEvents;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][XE * 3u + 4u];
@@ -3059,7 +2891,9 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t oa = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p) : 0u;
             const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (hl < (half ? pb : pa)) {
+            if constexpr (LP) {
+                if (lane < pa + pb) v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, 0u, lane);
+            } else if (hl < (half ? pb : pa)) {
                 v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa), hl);
             }
             return v;
@@ -3130,6 +2964,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
         LeanEvents e;
         if constexpr (LR && ABS_T) e = lr_decode12(rw.x, rw.y, rw.z, time_spanned_u, rt_u32, frame_idx_u);
+        else if constexpr (LP) e = lr_decode8_tab(lp_rho(rw.x, rw.y), rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
         else if constexpr (LR) e = lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
         else if constexpr (ABS_T) e = lean_decode(r, true, rt_u32);
         else e = lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
@@ -3139,7 +2974,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t w = phase + ev0 + (ev0 << 1);  // the record's first dword in the buffer (x3 without a 64-bit multiply-add)
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t unit = lean_runs ? (ABS_T ? rw.z : rw.y) & 0x7fu : ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
+        const uint32_t unit = LP ? rw.y & 0xffu : lean_runs ? (ABS_T ? rw.z : rw.y) & 0x7fu : ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
@@ -3250,13 +3085,22 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
-            if (pa <= 32u && pb <= 32u) {
+            if (LP ? pa + pb <= kWave : (pa <= 32u && pb <= 32u)) {
 #if defined(ADDER_DBG_X_NODECODE)  // diagnostic A/B build: no record loads, no decode, no staging -- only the stream's stores
                 if (fill + 3u * kWave > XE) flush();
                 fill += (__builtin_amdgcn_readlane(my_tot, 2 * p) & 0xffffu) + (__builtin_amdgcn_readlane(my_tot, 2 * p + 1) & 0xffffu);
 #else
-                if (pa + pb != 0u) record_round(first[p], half * kWaveUnits);
+                if (pa + pb != 0u) record_round(first[p], LP ? 0u : half * kWaveUnits);
 #endif
+                next_segment();
+                next_segment();
+            } else if constexpr (LP) {  // (more than 64 records in the pair's run: 64 at a time)
+                const uint8_t *const pair_park = park + (size_t)(2 * p) * seg_stride;
+                for (uint32_t i0 = 0; i0 < pa + pb; i0 += kWave) {  // uniform trip count
+                    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+                    if (i0 + lane < pa + pb) rw = load_rec_at<FORMAT, ABS_T>(pair_park, 0u, i0 + lane);
+                    record_round(rw, 0u);
+                }
                 next_segment();
                 next_segment();
             } else {
@@ -3954,6 +3798,8 @@ extern "C" hipError_t adder_launch_frame(const BatchArgs *b, uint32_t f, uint32_
         return hipGetLastError();
     }
     if (!collapse) return hipErrorInvalidValue;  // the lean step is Collapse-only
+    if (variant & 4096u)  // lean runs, packed bytes (adder_lp_kernels.hip): DeltaT batches of events or wire records
+        return adder_launch_lp(b, f, nb, (variant & 2048u) ? 1u : 0u, num_waves, grid_cap, stream);
     if (variant & 256u) {  // lean runs (DeltaT, constant runs): every launch of the batch, whatever its length
         const uint32_t SR = grid_cap && grid_cap < S ? grid_cap : S;
         const uint32_t lazy = (variant & 2048u) ? 1u : 0u;  // (more launches of this batch follow: adder_hip_api.cpp lazy_state_bit)
@@ -4054,6 +3900,8 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     } else if (variant & 64u) {
         if (abs_t) ADDER_XW(3, true);
         else ADDER_XW(3, false);
+    } else if (variant & 4096u) {  // adder_lp_kernel's records (DeltaT)
+        ADDER_XW(7, false);
     } else if (variant & 256u) {
         if (abs_t) ADDER_XW(5, true);
         else ADDER_XW(5, false);

@@ -1545,6 +1545,71 @@ ADDER_HD uint32_t lr_pack(const LrPxT<L> &p, float T, float &integ, float &dt, f
 }
 
 // ---------------------------------------------------------------------------------------
+// LEAN RUNS, PACKED (adder_lp_kernel): lr_step on FOUR units per 32-bit word -- the lane's four input bytes of a frame
+// are never taken apart.  Booleans are bit 7 of the unit's byte (kLpK8), so one vector instruction decides four units:
+//   flush  h = nzb(vin ^ prev)                 (video.rs:1338-1340 with c_thresh 0: any change of value)
+//   A      = h & ~hnp      hnp: the unit holds NO root (rho == 0) -- exactly the units that flushed to a non-zero value in
+//                          the frame before (the new root was popped at once, lr_step) and the pristine ones of a fresh stream
+//   B      = A & nzp       nzp: base_val != 0 (== popped_dtm, LrPxT)
+//   C      = h & nz(vin)   and that is the next frame's hnp
+// The events of a frame are the set bits of A, B and C (v_bcnt), a unit that does not change costs nothing of its own.
+// rho is not counted: every unit remembers the launch-relative frame `start` of its last flush, a record carries
+// rho' = i - start, which is rho + 1 for a root of non-zero intensity (start = -rho - 1 when the launch begins) and >= 1
+// for a black root (start = -rho; it never accumulates, event_pixel_tree.rs:449) -- lp_rho() undoes it for lr_decode8.
+// Record: w0 = rho', w8 = unit (8 bits: a wave steps a PAIR of segments) | flushed base_val << 8 | input << 16.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kLpK7 = 0x7f7f7f7fu, kLpK8 = 0x80808080u;
+ADDER_HD uint32_t lp_nzb(uint32_t w) { return (((w & kLpK7) + kLpK7) | w) & kLpK8; }  // bit 7 of every non-zero byte
+struct LpWord {
+    uint32_t prev;      // the four base_vals (= the previous frame's input bytes)
+    uint32_t nzp, hnp;  // bit 7 per byte: base_val != 0; no root
+    uint32_t start[4];  // (two's complement) frame of the last flush, relative to the launch's first frame
+};
+struct LpMasks {
+    uint32_t h, a, b, c;  // bit 7 per byte: flush, events A, B, C
+};
+// the word's state from the resident planes' (base_val, rho) of its four units (lr_unpack)
+ADDER_HD void lp_init(LpWord &s, const LrPx (&p)[4]) {
+    s.prev = s.nzp = s.hnp = 0u;
+    for (uint32_t j = 0; j < 4u; ++j) {
+        s.prev |= p[j].base << (8u * j);
+        s.nzp |= (p[j].base != 0u ? 0x80u : 0u) << (8u * j);
+        s.hnp |= (p[j].rho == 0u ? 0x80u : 0u) << (8u * j);
+        s.start[j] = 0u - p[j].rho - (p[j].base != 0u ? 1u : 0u);
+    }
+}
+ADDER_HD LpMasks lp_step(LpWord &s, uint32_t vin) {
+    LpMasks m;
+    m.h = lp_nzb(vin ^ s.prev);
+    const uint32_t nzv = lp_nzb(vin);
+    m.c = m.h & nzv;
+    m.a = m.h & ~s.hnp;
+    m.b = m.a & s.nzp;
+    s.prev = vin;
+    s.nzp = nzv;
+    s.hnp = m.c;
+    return m;
+}
+// frames whose four bytes equal the base_vals: nothing leaves, every root goes on accumulating (or comes into being)
+ADDER_HD void lp_quiet(LpWord &s) { s.hnp = 0u; }
+// unit j's record of frame i: base_w = the word's base_vals BEFORE the frame's lp_step, start_j = its start then (the
+// caller sets start[j] = i afterwards)
+ADDER_HD void lp_record(uint32_t base_w, uint32_t vin, uint32_t start_j, uint32_t j, uint32_t i, uint32_t unit8, uint32_t &w0,
+                        uint32_t &w8) {
+    w0 = i - start_j;
+    w8 = unit8 | (((base_w >> (8u * j)) & 0xffu) << kLrBaseShift) | (((vin >> (8u * j)) & 0xffu) << kLrInShift);
+}
+ADDER_HD uint32_t lp_rho(uint32_t w0, uint32_t w8) { return w0 - (((w8 >> kLrBaseShift) & 0xffu) != 0u ? 1u : 0u); }
+// (base_val, rho) of unit j after nb frames of the launch
+ADDER_HD LrPx lp_final(const LpWord &s, uint32_t j, uint32_t nb) {
+    LrPx p;
+    p.base = (s.prev >> (8u * j)) & 0xffu;
+    const uint32_t d = nb - s.start[j];
+    p.rho = p.base != 0u ? d - 1u : (d != 0u ? 1u : 0u);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------
 // RUN RECORDS: the bounded Collapse regime (delta_t_max > time_spanned) under the constant-run conditions, with the
 // whole step in integers -- what LEAN RUNS does for the lean regime.  A unit is {base_val, n, popped_dtm} (n = the frames
 // the root has accumulated) and, in AbsoluteT, lq = last_fired_t / T: nothing else is state -- an unpopped root of n frames

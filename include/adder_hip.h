@@ -296,6 +296,7 @@ int adder_hip_launch_plan_settled(const AdderHipCtx *ctx);
 #define ADDER_KERNEL_CONSTANT_RUNS 4u /* adder_cr_kernel */
 #define ADDER_KERNEL_RUN_RECORDS 5u   /* adder_rr_kernel */
 #define ADDER_KERNEL_LEAN_RUNS 6u     /* adder_lr_kernel */
+#define ADDER_KERNEL_LEAN_RUNS_PACKED 7u /* adder_lp_kernel: the same step on four units per lane (DeltaT) */
 unsigned adder_hip_last_batch_kernel(const AdderHipCtx *ctx);
 /* Diagnostics (environment ADDER_HIP_TIMELINE=1): first start / last end of the kernels of the last batch, in 10 ns
  * ticks of the device's constant clock: dst[4 kinds: frame, scan, offsets, expansion][64 chunks][2]. */

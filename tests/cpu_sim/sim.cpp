@@ -659,6 +659,111 @@ int sim_integrate_lr_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
+// One temporally blocked launch of the PACKED lean-runs step (lp_init / lp_step / lp_record / lp_final, decoded through
+// lp_rho + lr_decode8), as adder_lp_kernel and the expansion's format 7 run it: four units per word, booleans in bit 7 of the
+// unit's byte, rho as the distance to the launch-relative frame of the last flush.  DeltaT only; -7 outside the regime.
+// Every frame's masks are also checked against lr_step on the same units (rc -12), the event counts against the masks' bits.
+int sim_integrate_lp_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, SimEvent *out, size_t cap, size_t *n_out) {
+    if (!s->collapse || !((float)s->dtm <= T) || s->generic_sticky || s->perpx || s->continuous || s->abs_t ||
+        s->c_thresh != 0 || s->c_max != 0 || !(T >= 1.0f) || T != (float)(uint32_t)T || s->frac_time_seen)
+        return -7;
+    std::vector<float> rts(nb);
+    {
+        float rt = s->running_t;
+        for (uint32_t i = 0; i < nb; ++i) {
+            rts[i] = rt;
+            rt += T;
+        }
+        s->running_t = rt;
+    }
+    std::vector<std::vector<SimEvent>> per_frame(nb);
+    std::vector<uint32_t> lr_tab(kLrTabWords);
+    lr_build_tab(lr_tab.data(), T);
+    int rc = 0;
+    const size_t N = s->N;
+    const uint32_t rowlen = s->W * s->C;
+    for (size_t u0 = 0; u0 < N; u0 += 4) {
+        LrPx p[4], ref[4];
+        bool nz_old[4];
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const size_t u = u0 + j;
+            p[j].base = 0u;
+            p[j].rho = 0u;  // (padding units: pristine, fed zeros)
+            if (u < N) {
+                bool consistent;
+                p[j] = lr_unpack<ScalarLanes>(s->hdr[u], hdr_m(s->hdr[u]) ? s->dt0[u] : -777.0f, T, consistent);
+                if (!consistent) rc = -10;
+            }
+            ref[j] = p[j];
+            nz_old[j] = p[j].base != 0u;
+        }
+        LpWord w;
+        lp_init(w, p);
+        for (uint32_t i = 0; i < nb; ++i) {
+            uint32_t vin = 0u;
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (u0 + j < N) vin |= (uint32_t)frames[(size_t)i * N + u0 + j] << (8u * j);
+            const uint32_t base_w = w.prev;
+            if (vin == base_w && (i & 1u)) {  // (the kernel's quiet frames and groups; odd frames here, so that both forms run)
+                lp_quiet(w);
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    uint32_t w0, w8;
+                    const LeanFlagsT<ScalarLanes> fl = lr_step<ScalarLanes>(ref[j], (vin >> (8u * j)) & 0xffu, 0u, 0u, nz_old[j], w0, w8);
+                    if (fl.a || fl.b || fl.c) rc = -12;
+                }
+                continue;
+            }
+            const LpMasks m = lp_step(w, vin);
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t bit = 0x80u << (8u * j);
+                uint32_t r0, r8;
+                const LeanFlagsT<ScalarLanes> fl = lr_step<ScalarLanes>(ref[j], (vin >> (8u * j)) & 0xffu, 0u, 0u, nz_old[j], r0, r8);
+                if (fl.a != ((m.a & bit) != 0u) || fl.b != ((m.b & bit) != 0u) || fl.c != ((m.c & bit) != 0u)) rc = -12;
+                if (((m.h & bit) != 0u) != (fl.a || fl.c || ((vin ^ base_w) >> (8u * j) & 0xffu) != 0u)) rc = -12;
+                if (!(m.h & bit)) continue;
+                const size_t u = u0 + j;
+                uint32_t w0, w8;
+                lp_record(base_w, vin, w.start[j], j, i, (uint32_t)(u & 255u), w0, w8);
+                w.start[j] = i;
+                if (u >= N) { rc = -12; continue; }  // (a padding unit never flushes)
+                const uint32_t rho = lp_rho(w0, w8);
+                const LeanEvents e = lr_decode8_tab(rho, w8, T, f32_as_u32(rts[i]), (u & 1u) ? lr_tab.data() : nullptr, lr_tab.data() + 256u * kLrTabRuns);
+                if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
+                if (fl.a && r0 != rho && ((w8 >> kLrBaseShift) & 0xffu) != 0u) rc = -13;  // (the run lr_step counted)
+                SimEvent ev;
+                ev.x = (uint16_t)((u % rowlen) / s->C); ev.y = (uint16_t)(u / rowlen + s->row_begin);
+                ev.c = s->C == 1 ? (uint8_t)0xFF : (uint8_t)(u % s->C); ev.pad = 0;
+                if (e.a) { ev.d = (uint8_t)e.da; ev.t = e.ta; per_frame[i].push_back(ev); }
+                if (e.b) { ev.d = (uint8_t)kDEmpty; ev.t = e.tb; per_frame[i].push_back(ev); }
+                if (e.c) { ev.d = (uint8_t)e.dc; ev.t = e.tc; per_frame[i].push_back(ev); }
+            }
+        }
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const size_t u = u0 + j;
+            if (u >= N) continue;
+            const LrPx q = lp_final(w, j, nb);
+            if (q.base != ref[j].base || q.rho != ref[j].rho) rc = -13;
+            float integ, dt, bdt;
+            s->hdr[u] = lr_pack(q, T, integ, dt, bdt);
+            if (q.rho != 0u) {
+                s->integ0[u] = integ; s->dt0[u] = dt; s->bdt0[u] = bdt;
+                if (s->max_m < 1) s->max_m = 1;
+                s->running[u] = (uint8_t)frame_value_u8((s->hdr[u] >> kHdrBdShift) & 0xffu, f32_as_u32(bdt), (double)s->ref_time);
+            }
+            s->lean_steps += nb;
+        }
+    }
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i)
+        for (const SimEvent &e : per_frame[i]) {
+            if (pos < cap) out[pos] = e;
+            ++pos;
+        }
+    *n_out = pos;
+    if (pos > cap && rc == 0) rc = -4;
+    return rc;
+}
+
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
     StepConsts sc;

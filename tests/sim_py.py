@@ -71,6 +71,8 @@ def lib():
     L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_lr_block.restype = i32
     L.sim_integrate_lr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
+    L.sim_integrate_lp_block.restype = i32
+    L.sim_integrate_lp_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_rr_block.restype = i32
     L.sim_integrate_rr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_cr_block.restype = i32
@@ -231,6 +233,17 @@ class Sim:
         out = np.zeros(cap, EVENT_DTYPE)
         n = C.c_size_t(0)
         rc = self.L.sim_integrate_lr_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
+                                           C.byref(n))
+        return rc, out[: n.value].copy()
+
+    def integrate_lp_block(self, frames, time_spanned):
+        """nb frames as ONE launch of the PACKED lean-runs step (four units per word; DeltaT, c_thresh 0 throughout)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(len(frames), -1)
+        assert frames.shape[1] == self.n
+        cap = self._cap * len(frames)
+        out = np.zeros(cap, EVENT_DTYPE)
+        n = C.c_size_t(0)
+        rc = self.L.sim_integrate_lp_block(self.h, frames.ctypes.data, len(frames), time_spanned, out.ctypes.data, cap,
                                            C.byref(n))
         return rc, out[: n.value].copy()
 

@@ -755,6 +755,66 @@ def test_lr_every_intensity_and_run_length_rgb_and_tick_rates():
     assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
 
 
+# ---- lean runs, packed (lp_step: four units per word, adder_lp_kernel + the expansion's format 7) ----
+def test_lp_packed_step_matches_the_oracle_and_interleaves_with_the_other_lean_steps():
+    """The headline regime through the packed step: launches of every length on every content (planes whose unit count is
+    no multiple of four included), mixed at random with lr launches and frames of the ordinary lean step -- all three keep
+    the same resident planes; every event equals the oracle's, every frame's masks equal lr_step's (rc -12 / -13)."""
+    rng = np.random.default_rng(77)
+    used = set()
+    for kind in ("scene", "runs", "jitter", "static", "dark", "noise", "steps"):
+        for (W, H, Cn) in ((12, 7, 1), (5, 3, 3), (9, 2, 1)):
+            frames = 200
+            clip = (O.synth_clip(O.CONTENT_SCENE, W, H, Cn, frames) if kind == "scene"
+                    else clips.make_clip(kind, frames, H, W, Cn, seed=5 + len(kind)))
+            ov, sv = _lean_pair(W, H, Cn)
+            k = 0
+            while k < frames:
+                nb = min(int(rng.choice([1, 2, 3, 7, 16, 31, 64])), frames - k)
+                want = np.concatenate([ov.integrate_matrix(clip[k + i]) for i in range(nb)])
+                pick = int(rng.integers(0, 4))
+                if pick >= 2:
+                    rc, got = sv.integrate_lp_block(clip[k:k + nb], 255.0)
+                    used.add("lp")
+                elif pick == 1:
+                    rc, got = sv.integrate_lr_block(clip[k:k + nb], 255.0)
+                    used.add("lr")
+                else:
+                    parts = [sv.integrate(clip[k + i], 255.0) for i in range(nb)]
+                    rc, got = max(p[0] for p in parts), np.concatenate([p[1] for p in parts])
+                    used.add("lean")
+                assert rc == 0, (kind, W, k, rc)
+                assert len(want) == len(got) and np.array_equal(want, got), (kind, W, k, nb)
+                k += nb
+    assert used == {"lp", "lr", "lean"}
+
+
+def test_lp_every_intensity_and_run_length_and_tick_rates():
+    """Every intensity 0..255 against runs of 1..70 frames (and one of 700) through the packed step's start-frame form
+    of rho, at other tick rates and with time_spanned > delta_t_max; refused outside its regime."""
+    for ref_time, dtm, T in ((255, 255, 255.0), (255, 255, 510.0), (1000, 1000, 1000.0), (20, 20, 20.0)):
+        ov, sv = _lean_pair(256, 1, 1, dtm=dtm, ref_time=ref_time)
+        frames = []
+        for run in list(range(1, 71, 3)) + [700]:
+            frames += [np.arange(256, dtype=np.uint8).reshape(1, 256, 1)] * run
+            frames += [((np.arange(256) + 1 + run) % 256).astype(np.uint8).reshape(1, 256, 1)]
+        clip = np.stack(frames)
+        k = 0
+        while k < len(clip):
+            nb = min(64, len(clip) - k)
+            want = np.concatenate([ov.integrate_matrix(clip[k + i], time_spanned=T) for i in range(nb)])
+            rc, got = sv.integrate_lp_block(clip[k:k + nb], T)
+            assert rc == 0 and len(want) == len(got) and np.array_equal(want, got), (ref_time, T, k)
+            k += nb
+    clip = clips.make_clip("runs", 120, 5, 6, 3, seed=9)
+    sv = Sim(6, 5, 3, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+    sv.set_crf_parameters(0, 10)
+    sv.reset_c_thresh(0)
+    assert sv.integrate_lp_block(clip[:2], 255.0)[0] == -7  # AbsoluteT: the lr kernel's
+    sv = Sim(6, 5, 3, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, delta_t_max=255)
+    assert sv.integrate_lp_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
+
+
 # ---- quiet GROUPS: 16 frames of a quiet unit decided at once (quiet_group_apply / lr_quiet_run) ----
 _quiet_group_clip = clips.quiet_group_clip
 

@@ -1955,7 +1955,7 @@ def test_integer_state_kernels_stay_past_65k_frames_while_the_runs_are_short():
     for k in range(T):
         step = (k + phase) // period            # every unit takes a new value every `period` frames of its own
         clip[k] = np.take_along_axis(vals, (step % 64)[None], axis=0)[0]
-    cases = ((O.DELTA_T, 255, False, A.KERNEL_LEAN_RUNS), (O.DELTA_T, 7650, False, A.KERNEL_RUN_RECORDS),
+    cases = ((O.DELTA_T, 255, False, A.KERNEL_LEAN_RUNS_PACKED), (O.DELTA_T, 7650, False, A.KERNEL_RUN_RECORDS),
              (O.DELTA_T, 255, True, A.KERNEL_LEAN), (O.ABSOLUTE_T, 255, False, A.KERNEL_LEAN))
     for tm, dtm, one_static, last_kernel in cases:
         c = clip
@@ -1976,7 +1976,7 @@ def test_integer_state_kernels_stay_past_65k_frames_while_the_runs_are_short():
             assert len(got) == len(want) and np.array_equal(got, want), (tm, dtm, one_static, k)
             kernels.append(hv.last_batch_kernel())
             k += nb
-        integer = A.KERNEL_LEAN_RUNS if dtm == 255 else A.KERNEL_RUN_RECORDS
+        integer = (A.KERNEL_LEAN_RUNS_PACKED if tm == O.DELTA_T else A.KERNEL_LEAN_RUNS) if dtm == 255 else A.KERNEL_RUN_RECORDS
         assert kernels[0] == integer and kernels[-1] == last_kernel, (tm, dtm, one_static, kernels)
         if last_kernel != integer:               # the switch happens where frames * 255 reaches 2^24, not before
             assert kernels[65793 // 4096 - 1] == integer, kernels
@@ -2022,15 +2022,18 @@ def test_kernel_switch_points_random_walk_with_the_kernel_asserted(monkeypatch, 
     ov, hv = pair(255, CRFS[0])
     k, seen = 0, set()
     while k < len(clip):
-        choice = ("lr", "lean", "one")[int(rng.integers(0, 3))]
+        choice = ("lp", "lr", "lean", "one")[int(rng.integers(0, 4))]   # (lp: lean runs in packed bytes -- DeltaT only)
         nb = 1 if choice == "one" else min(int(rng.choice([2, 5, 16, 60, 64, 70])), len(clip) - k)
         monkeypatch.setenv("ADDER_HIP_NO_LR", "1" if choice == "lean" else "0")
-        expect = {A.KERNEL_LEAN_RUNS} if (choice == "lr" and nb > 1) else {A.KERNEL_LEAN}
+        monkeypatch.setenv("ADDER_HIP_NO_LP", "1" if choice == "lr" else "0")
+        packed = choice == "lp" and time_mode == O.DELTA_T
+        expect = {A.KERNEL_LEAN_RUNS_PACKED if packed else A.KERNEL_LEAN_RUNS} if (choice in ("lp", "lr") and nb > 1) else {A.KERNEL_LEAN}
         batch(ov, hv, clip, k, nb, expect)
         seen.add((choice, nb > 1))
         k += nb
-    assert {("lr", True), ("lean", True), ("one", False)} <= seen
+    assert {("lp", True), ("lr", True), ("lean", True), ("one", False)} <= seen
     monkeypatch.delenv("ADDER_HIP_NO_LR")
+    monkeypatch.delenv("ADDER_HIP_NO_LP")
     hv.close()
 
     # ---- the default mode at crf 0: run records <-> constant runs <-> bounded Collapse; then update_crf mid-stream ----
@@ -2059,7 +2062,7 @@ def test_kernel_switch_points_random_walk_with_the_kernel_asserted(monkeypatch, 
     # ---- the window grows and shrinks mid-stream (update_quality_manual): lean runs -> bounded Collapse -> generic ----
     ov, hv = pair(255, CRFS[0])
     k = 0
-    for dtm, expect, until in ((255, {A.KERNEL_LEAN_RUNS, A.KERNEL_LEAN}, 90), (7650, {A.KERNEL_BOUNDED, A.KERNEL_CONSTANT_RUNS, A.KERNEL_RUN_RECORDS}, 230),
+    for dtm, expect, until in ((255, {A.KERNEL_LEAN_RUNS_PACKED, A.KERNEL_LEAN_RUNS, A.KERNEL_LEAN}, 90), (7650, {A.KERNEL_BOUNDED, A.KERNEL_CONSTANT_RUNS, A.KERNEL_RUN_RECORDS}, 230),
                                (255, {A.KERNEL_GENERIC}, len(clip))):
         for v in (ov, hv):
             v.set_delta_t_max(dtm)

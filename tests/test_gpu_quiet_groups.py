@@ -47,17 +47,21 @@ def _run_batches(ov, hv, clip, lens, rng, reset_every=0, crf=None, kernel=None):
 
 
 @pytest.mark.parametrize("time_mode", [O.DELTA_T, O.ABSOLUTE_T])
-def test_lean_runs_quiet_groups_break_at_every_position(time_mode):
+def test_lean_runs_quiet_groups_break_at_every_position(monkeypatch, time_mode):
     """adder_lr_kernel: one 128-unit wave per row; static rows (black, dark, mid, bright) whose groups are skipped, a change at
     every position of a 16-frame group, batches of every length (launches that end inside a group, short last groups)."""
     frames, H, W = 1088, 12, 128
     rng = np.random.default_rng(3 + time_mode)
     clip, breaks = clips.quiet_group_clip(frames, H, W, rng, jitter=0)
     assert sorted({b % 16 for b in breaks}) == list(range(16))
-    for lens in ([frames], [64, 60, 37, 16, 100, 1, 2]):
-        ov, hv = _pair(W, H, 1, time_mode, 255, CRFS[0])
-        assert _run_batches(ov, hv, clip, lens, rng, kernel=_hipmod().KERNEL_LEAN_RUNS) > 0
-        hv.close()
+    A = _hipmod()
+    for packed in ((True, False) if time_mode == O.DELTA_T else (False,)):   # DeltaT: adder_lp_kernel (packed bytes), then adder_lr_kernel
+        for lens in ([frames], [64, 60, 37, 16, 100, 1, 2]):
+            ov, hv = _pair(W, H, 1, time_mode, 255, CRFS[0])
+            monkeypatch.setenv("ADDER_HIP_NO_LP", "0" if packed else "1")
+            assert _run_batches(ov, hv, clip, lens, rng, kernel=A.KERNEL_LEAN_RUNS_PACKED if packed else A.KERNEL_LEAN_RUNS) > 0
+            hv.close()
+    monkeypatch.delenv("ADDER_HIP_NO_LP")
     # ragged plane (the register staging path, padding units), three channels
     clip3, _ = clips.quiet_group_clip(200, 7, 51, rng, jitter=0, C=3)
     ov, hv = _pair(51, 7, 3, time_mode, 255, CRFS[0])
