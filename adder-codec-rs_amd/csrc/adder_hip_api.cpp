@@ -1020,6 +1020,14 @@ static size_t scratch_bytes_per_chunk(const AdderHipCtx *c, AdderHipCtx::Scratch
         default: return 0;
     }
 }
+static uint32_t park_group_shift_wanted() {
+    if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
+        const int sh = atoi(e);
+        static_assert(16 % ADDER_EXPAND_SEGS == 0, "a group (and a rotation group of 16 segments) must hold whole expansion waves");
+        return sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
+    }
+    return 4u;
+}
 static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
     // (a Collapse context that has the general log can run the bounded step on it: no thrash between the two)
     if (c->park_ring && (c->scratch_kind == kind || (c->scratch_kind == AdderHipCtx::kScratchLog3 && kind == AdderHipCtx::kScratchLog2)))
@@ -1046,12 +1054,7 @@ static int alloc_scratch(AdderHipCtx *c, AdderHipCtx::ScratchKind kind) {
     // measured 1.515 - 1.525 ms per step (a few 1.57 - 1.58) against 1.55 / 1.62 (two modes) for the rotated
     // segment-major layout (profiles/r03_ctx_spread.txt).  (A group must divide the segment count, which is padded to a
     // multiple of 16: larger requests fall back to 16.)
-    c->park_group_shift = 4u;
-    if (const char *e = getenv("ADDER_HIP_PARK_GROUP_SHIFT")) {  // 0, or >= log2(segments per expansion wave)
-        const int sh = atoi(e);
-        c->park_group_shift = sh <= 0 ? 0u : (uint32_t)std::max(sh, 4);
-        static_assert(16 % ADDER_EXPAND_SEGS == 0, "a group (and a rotation group of 16 segments) must hold whole expansion waves");
-    }
+    c->park_group_shift = park_group_shift_wanted();
     uint32_t ch = kMaxChunk;
     while (ch > 1u && c->ring_chunks * (scratch_bytes_per_chunk(c, kind, ch) + (size_t)c->num_waves * ch * 12u) > budget) --ch;
     c->chunk = ch;
@@ -1214,7 +1217,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u,
                                     (c->records_only && (variant & 256u)) ? 1u : 0u));
         if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
-        if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t));
+        if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t, c->slots, c->chunk));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));
             c->timed_posts += 1;
@@ -1252,7 +1255,7 @@ static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t
         if (k && ps != prev_p) HIPCHK(c, hipStreamWaitEvent(ps, c->cap_e2[(k - 1u) % 5u], 0));
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, ps));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, ps));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps, c->slots, c->chunk));
         HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], ps));
         prev_l = ls;
         prev_p = ps;
@@ -1542,9 +1545,9 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // ... in packed bytes (adder_lp_kernel, four units per lane): DeltaT batches whose records the expansion reads itself
     // (the pair's records lie in one run: the ring layout must keep a pair of segments adjacent)
     const bool lp_off = env_flag("ADDER_HIP_NO_LP");
-    const bool lp = lr && !lp_off && c->p.time_mode == ADDER_TIME_DELTA_T && !c->records_only && c->park_group_shift >= 1u &&
+    const bool lp = lr && !lp_off && c->p.time_mode == ADDER_TIME_DELTA_T && !c->records_only && park_group_shift_wanted() >= 1u &&
                     !park_frame_major();
-    const uint32_t variant = (lp ? 4096u : 0u) | (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
+    const uint32_t variant = (lp ? 4096u : 0u) | ((lp && c->p.channels == 3) ? 8192u : 0u) | (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |

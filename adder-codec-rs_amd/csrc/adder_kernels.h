@@ -28,6 +28,7 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef ADDER_LEAN_WAVES_PER_SIMD
 #define ADDER_LEAN_WAVES_PER_SIMD 8
 #endif
+constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;                // segments one expansion wave takes of a frame
 constexpr uint32_t kUnitsPerLane = ADDER_UNITS_PER_LANE;           // pixel-channels per lane (2 or 4)
 constexpr uint32_t kWaveUnits = 64 * kUnitsPerLane;                // units per wave segment
 constexpr uint32_t kTileUnits = kBlockThreads * kUnitsPerLane;     // units per K1 block
@@ -294,6 +295,10 @@ hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb
 // the lean-runs step in packed bytes (adder_lp_kernels.hip; variant bit 4096): a wave per PAIR of segments
 hipError_t adder_launch_lp(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t lazy, uint32_t num_waves,
                            uint32_t grid_cap, hipStream_t stream);
+// ... and its expansion (adder_lpx_kernel): rec = 9 / 11 (the raw sink's records) or 12 (AdderEvents)
+// (slot0 / cir: frame f0's slot of the scratch ring and that slot's chunk in the ring; the launch's frames share the chunk)
+hipError_t adder_launch_lpx(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, uint32_t rec,
+                            uint32_t slot0, uint32_t cir, hipStream_t stream);
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
@@ -307,8 +312,9 @@ hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseSt
                             unsigned long long *d_total, hipStream_t stream);
 hipError_t adder_launch_publish(const adder::BatchArgs *b, uint32_t num_frames, adder::BatchResult *h, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
+// (slots / chunk: the ring's geometry as BatchArgs holds it -- the packed lean-runs expansion takes its slot from the host)
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                               uint32_t variant, uint32_t grid_cap, hipStream_t stream);
+                               uint32_t variant, uint32_t grid_cap, hipStream_t stream, uint32_t slots = 0u, uint32_t chunk = 0u);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 // records over the wire (adder_kernels.hip: adder_log_pack_kernel, adder_band_layout_kernel)
 hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t rec_bytes, const uint32_t *wcur,

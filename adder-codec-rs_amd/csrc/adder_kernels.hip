@@ -2560,7 +2560,6 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
 // (lean_decode: <= 3 events each) and a DPP scan of the per-record event counts gives each
 // event its place; generic batches park one 8-byte record per event with its final offset.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kExpandSegs = ADDER_EXPAND_SEGS;
 #ifndef ADDER_XBUF_EVENTS
 #define ADDER_XBUF_EVENTS 448
 #endif
@@ -2795,6 +2794,25 @@ __device__ __forceinline__ uint4 load_rec_at(const void *base, uint32_t off, uin
 #endif
     return lean_load_rec<ABS_T>(base, off + idx * lean_rec_bytes(ABS_T));
 }
+// record `idx` of a pair's run of adder_lp_kernel's 4-byte records (adder_pixel.hpp lp_park4) as {rho', word, -, -}: an escaping
+// record's full rho' lies 4 (k + 1) bytes below the end of the pair's `region` bytes, k = its rank among the run's escaping
+// records (esc_before of them in the rounds before this one)
+__device__ __forceinline__ uint4 lp_load_rec(const uint8_t *pair_park, uint32_t region, uint32_t idx, uint32_t n, uint32_t esc_before,
+                                             uint32_t *n_esc = nullptr) {
+    uint32_t w4 = 0u;
+    if (idx < n) w4 = gload_rec<uint32_t>(pair_park, idx * 4u);
+    const bool e = idx < n && lp_escapes(w4);
+    const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+    uint32_t esc = 0u;
+    if (em != 0ull) {  // (uniform; rare)
+        const uint32_t rank = esc_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+        if (e) esc = gload_rec<uint32_t>(pair_park, region - 4u * (rank + 1u));
+    }
+    if (n_esc) *n_esc = (uint32_t)__popcll(em);
+    uint32_t w0, w8;
+    lp_unpark4(w4, esc, w0, w8);
+    return make_uint4(w0, w8, 0u, 0u);
+}
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
     constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6 || FORMAT == 7;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
@@ -2892,7 +2910,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if constexpr (LP) {
-                if (lane < pa + pb) v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, 0u, lane);
+                v = lp_load_rec(park + (size_t)(2 * p) * seg_stride, 2u * seg_stride, lane, pa + pb, 0u);
             } else if (hl < (half ? pb : pa)) {
                 v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa), hl);
             }
@@ -3096,9 +3114,11 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
                 next_segment();
             } else if constexpr (LP) {  // (more than 64 records in the pair's run: 64 at a time)
                 const uint8_t *const pair_park = park + (size_t)(2 * p) * seg_stride;
+                uint32_t esc_before = 0u;  // escaping records of the rounds before (uniform)
                 for (uint32_t i0 = 0; i0 < pa + pb; i0 += kWave) {  // uniform trip count
-                    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
-                    if (i0 + lane < pa + pb) rw = load_rec_at<FORMAT, ABS_T>(pair_park, 0u, i0 + lane);
+                    uint32_t n_esc;
+                    const uint4 rw = lp_load_rec(pair_park, 2u * seg_stride, i0 + lane, pa + pb, esc_before, &n_esc);
+                    esc_before += n_esc;
                     record_round(rw, 0u);
                 }
                 next_segment();
@@ -3878,7 +3898,7 @@ extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint
 }
 
 extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                                          uint32_t variant, uint32_t grid_cap, hipStream_t stream) {
+                                          uint32_t variant, uint32_t grid_cap, hipStream_t stream, uint32_t slots, uint32_t chunk) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t xblocks = (num_waves + per_block - 1) / per_block;
     static const uint32_t items = [] { const char *e = getenv("ADDER_HIP_EXPAND_ITEMS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u; }();
@@ -3900,7 +3920,10 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
     } else if (variant & 64u) {
         if (abs_t) ADDER_XW(3, true);
         else ADDER_XW(3, false);
-    } else if (variant & 4096u) {  // adder_lp_kernel's records (DeltaT)
+    } else if (variant & 4096u) {  // adder_lp_kernel's records (DeltaT): the expansion of adder_lp_kernels.hip
+        static const bool old_x = [] { const char *e = getenv("ADDER_HIP_LP_OLD_EXPAND"); return e && atoi(e) != 0; }();  // (A/B: format 7 of this file)
+        if (!old_x && slots != 0u && chunk != 0u && f0 % chunk == 0u && nf <= chunk)
+            return adder_launch_lpx(b, f0, nf, num_waves, wire ? ((variant & 8192u) ? 11u : 9u) : 12u, f0 % slots, (f0 % slots) / chunk, stream);
         ADDER_XW(7, false);
     } else if (variant & 256u) {
         if (abs_t) ADDER_XW(5, true);

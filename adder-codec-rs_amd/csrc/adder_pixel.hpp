@@ -1600,6 +1600,17 @@ ADDER_HD void lp_record(uint32_t base_w, uint32_t vin, uint32_t start_j, uint32_
     w8 = unit8 | (((base_w >> (8u * j)) & 0xffu) << kLrBaseShift) | (((vin >> (8u * j)) & 0xffu) << kLrInShift);
 }
 ADDER_HD uint32_t lp_rho(uint32_t w0, uint32_t w8) { return w0 - (((w8 >> kLrBaseShift) & 0xffu) != 0u ? 1u : 0u); }
+// The PARKED form is four bytes: unit | base_val << 8 | input << 16 | min(rho', 255) << 24.  A unit that flushed in this
+// launch has rho' <= the launch's length; only a run carried in from earlier launches can reach 255 -- then the record says
+// 255 and the full rho' is an ESCAPE word: the pair's k-th escaping record of the frame keeps it 4 (k + 1) bytes below the
+// end of the pair's two slots (a pair parks at most 256 records of 4 bytes and 256 escapes: its 2 KB).
+constexpr uint32_t kLpRhoEsc = 255u, kLpRhoShift = 24u;
+ADDER_HD uint32_t lp_park4(uint32_t w0, uint32_t w8) { return (w8 & 0xffffffu) | ((w0 < kLpRhoEsc ? w0 : kLpRhoEsc) << kLpRhoShift); }
+ADDER_HD bool lp_escapes(uint32_t w4) { return (w4 >> kLpRhoShift) == kLpRhoEsc; }
+ADDER_HD void lp_unpark4(uint32_t w4, uint32_t esc, uint32_t &w0, uint32_t &w8) {
+    w0 = lp_escapes(w4) ? esc : w4 >> kLpRhoShift;
+    w8 = w4 & 0xffffffu;
+}
 // (base_val, rho) of unit j after nb frames of the launch
 ADDER_HD LrPx lp_final(const LpWord &s, uint32_t j, uint32_t nb) {
     LrPx p;

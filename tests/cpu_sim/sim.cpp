@@ -726,6 +726,12 @@ int sim_integrate_lp_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
                 lp_record(base_w, vin, w.start[j], j, i, (uint32_t)(u & 255u), w0, w8);
                 w.start[j] = i;
                 if (u >= N) { rc = -12; continue; }  // (a padding unit never flushes)
+                {   // through the parked 4-byte form and its escape word
+                    const uint32_t w4 = lp_park4(w0, w8);
+                    uint32_t b0, b8;
+                    lp_unpark4(w4, w0, b0, b8);
+                    if (b0 != w0 || b8 != w8 || lp_escapes(w4) != (w0 >= kLpRhoEsc)) rc = -14;
+                }
                 const uint32_t rho = lp_rho(w0, w8);
                 const LeanEvents e = lr_decode8_tab(rho, w8, T, f32_as_u32(rts[i]), (u & 1u) ? lr_tab.data() : nullptr, lr_tab.data() + 256u * kLrTabRuns);
                 if (e.a != fl.a || e.b != fl.b || e.c != fl.c) rc = -9;
