@@ -1217,7 +1217,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u,
                                     (c->records_only && (variant & 256u)) ? 1u : 0u));
         if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
-        if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t, c->slots, c->chunk));
+        if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t, c->h_batch));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));
             c->timed_posts += 1;
@@ -1255,7 +1255,7 @@ static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t
         if (k && ps != prev_p) HIPCHK(c, hipStreamWaitEvent(ps, c->cap_e2[(k - 1u) % 5u], 0));
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, ps));
         HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, ps));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps, c->slots, c->chunk));
+        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps, c->h_batch));
         HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], ps));
         prev_l = ls;
         prev_p = ps;

@@ -296,9 +296,9 @@ hipError_t adder_launch_frame(const adder::BatchArgs *b, uint32_t f, uint32_t nb
 hipError_t adder_launch_lp(const adder::BatchArgs *b, uint32_t f, uint32_t nb, uint32_t lazy, uint32_t num_waves,
                            uint32_t grid_cap, hipStream_t stream);
 // ... and its expansion (adder_lpx_kernel): rec = 9 / 11 (the raw sink's records) or 12 (AdderEvents)
-// (slot0 / cir: frame f0's slot of the scratch ring and that slot's chunk in the ring; the launch's frames share the chunk)
-hipError_t adder_launch_lpx(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, uint32_t rec,
-                            uint32_t slot0, uint32_t cir, hipStream_t stream);
+// (host_b: the host's copy of *b; frames [f0, f0 + nf) lie in ONE chunk of the scratch ring)
+hipError_t adder_launch_lpx(const adder::BatchArgs *b, const adder::BatchArgs *host_b, uint32_t f0, uint32_t nf, uint32_t rec,
+                            hipStream_t stream);
 hipError_t adder_launch_divtest(unsigned long long *d_bad, hipStream_t stream);
 hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_t rec, uint8_t *out, uint32_t *status,
                              hipStream_t stream);
@@ -312,9 +312,9 @@ hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseSt
                             unsigned long long *d_total, hipStream_t stream);
 hipError_t adder_launch_publish(const adder::BatchArgs *b, uint32_t num_frames, adder::BatchResult *h, hipStream_t stream);
 hipError_t adder_launch_offsets(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, hipStream_t stream);
-// (slots / chunk: the ring's geometry as BatchArgs holds it -- the packed lean-runs expansion takes its slot from the host)
+// (host_b: the host's copy of *b -- the packed lean-runs expansion takes its context-constant part as kernel arguments)
 hipError_t adder_launch_expand(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                               uint32_t variant, uint32_t grid_cap, hipStream_t stream, uint32_t slots = 0u, uint32_t chunk = 0u);
+                               uint32_t variant, uint32_t grid_cap, hipStream_t stream, const adder::BatchArgs *host_b = nullptr);
 hipError_t adder_launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
 // records over the wire (adder_kernels.hip: adder_log_pack_kernel, adder_band_layout_kernel)
 hipError_t adder_launch_log_pack(const uint8_t *logs, uint32_t log_cap, uint32_t rec_bytes, const uint32_t *wcur,

@@ -3898,7 +3898,7 @@ extern "C" hipError_t adder_launch_offsets(const BatchArgs *b, uint32_t f0, uint
 }
 
 extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves,
-                                          uint32_t variant, uint32_t grid_cap, hipStream_t stream, uint32_t slots, uint32_t chunk) {
+                                          uint32_t variant, uint32_t grid_cap, hipStream_t stream, const BatchArgs *host_b) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t xblocks = (num_waves + per_block - 1) / per_block;
     static const uint32_t items = [] { const char *e = getenv("ADDER_HIP_EXPAND_ITEMS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u; }();
@@ -3922,8 +3922,8 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
         else ADDER_XW(3, false);
     } else if (variant & 4096u) {  // adder_lp_kernel's records (DeltaT): the expansion of adder_lp_kernels.hip
         static const bool old_x = [] { const char *e = getenv("ADDER_HIP_LP_OLD_EXPAND"); return e && atoi(e) != 0; }();  // (A/B: format 7 of this file)
-        if (!old_x && slots != 0u && chunk != 0u && f0 % chunk == 0u && nf <= chunk)
-            return adder_launch_lpx(b, f0, nf, num_waves, wire ? ((variant & 8192u) ? 11u : 9u) : 12u, f0 % slots, (f0 % slots) / chunk, stream);
+        if (!old_x && host_b != nullptr && f0 % host_b->chunk == 0u && nf <= host_b->chunk)
+            return adder_launch_lpx(b, host_b, f0, nf, wire ? ((variant & 8192u) ? 11u : 9u) : 12u, stream);
         ADDER_XW(7, false);
     } else if (variant & 256u) {
         if (abs_t) ADDER_XW(5, true);

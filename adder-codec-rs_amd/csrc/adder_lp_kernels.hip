@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "adder_kernel_util.hpp"
@@ -286,10 +287,13 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 //   2. a round decodes 64 records (lr_decode8_tab: event A worked out from (base_val, rho), C from the 256-word table), a
 //      DPP scan of the records' event counts places the events, and every event is written into the staging buffer in its
 //      FINAL bytes -- REC = 9 / 11: the raw sink's record (RawOutput::ingest_event, raw/stream.rs:101-120: bincode fixint
-//      big-endian {x u16, y u16, [0x01, c,] d u8, t u32}), byte-aligned LDS stores (gfx950 takes them); REC = 12: the AdderEvent;
+//      big-endian {x u16, y u16, [0x01, c,] d u8, t u32}) at whatever byte it falls on; REC = 12: the AdderEvent.  (An LDS
+//      store that is not naturally aligned costs fifteen aligned ones -- tools/ubench/lds_writes.hip -- and is still the
+//      cheaper form here: the kernel is bound by the instructions it issues, and three aligned dwords per event + a packing
+//      pass of byte permutes measured 154-159 us per launch against 138-147.)
 //   3. the staging buffer sits at the 16-byte phase of its destination, so a flush is 16-byte LDS reads -> 16-byte global
 //      stores, a kilobyte per instruction, and single bytes for the <= 15 + 15 bytes the wave shares with its neighbours' blocks.
-// No conversion pass, no per-pair rounds, one copy of every loop: a tenth of adder_expand_kernel<5>'s code.
+// One copy of every loop: a sixth of adder_expand_kernel<5>'s code.
 // ------------------------------------------------------------------------------------------
 #ifndef ADDER_LPX_REC_CAP
 #define ADDER_LPX_REC_CAP 384  // records unparked per batch of pairs (>= 256: one pair's worst case)
@@ -302,48 +306,73 @@ constexpr uint32_t kLpxRecCap = ADDER_LPX_REC_CAP;
 constexpr uint32_t kLpxStageEvents = ADDER_LPX_STAGE_EVENTS;
 static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxStageEvents >= 4u * kWave, "sizes the loops below assume");
 
+// What adder_lpx_kernel takes by value: what stays the same for every batch of a context's current scratch ring.
+struct LpxArgs {
+    const uint8_t *park_chunk;             // the launch's chunk of the scratch ring
+    const uint32_t *wtot, *wpref, *ftot;   // the rows of the launch's first frame slot
+    const uint32_t *tab_c;                 // event C by input byte (lr_build_tab's last 256 words)
+    const FrameTab *ftab;
+    uint32_t *status;
+    uint32_t num_waves, fi0;               // fi0: the first frame's slot inside its chunk
+    uint32_t group_shift, group_stride, frame_stride, seg_stride, rot_shift, rot_mask;  // ParkLayout
+    uint32_t rowlen, channels, row_begin, wraps;
+    float inv_row;
+};
+#define ADDER_LDS __attribute__((address_space(3)))
+typedef uint32_t lpx_u32x2 __attribute__((ext_vector_type(2)));  // (plain vectors: HIP's uint2 / uint4 classes do not live in LDS address space)
+typedef uint32_t lpx_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t __attribute__((aligned(1))) lpx_u64_any;  // (an 8-byte LDS store at any byte address: gfx950 takes it)
+typedef uint16_t __attribute__((aligned(1))) lpx_u16_any;
+
+// One event into the staging buffer at byte offset `off` (32-bit LDS addressing).  REC = 12: the AdderEvent {x | y << 16,
+// c | d << 8, t}; REC = 9 / 11: the raw sink's record in its FINAL bytes {x_hi x_lo y_hi y_lo, [01 c] d, t3 t2 t1 t0}.
 template <uint32_t REC>
-__device__ __forceinline__ void lpx_put(uint8_t *p, uint32_t xy, uint32_t xyw, uint32_t c, uint32_t d, uint32_t t) {
+__device__ __forceinline__ void lpx_put(ADDER_LDS uint8_t *stage, uint32_t off, uint32_t xy, uint32_t xyw, uint32_t c, uint32_t d, uint32_t t) {
     if constexpr (REC == 12u) {
-        const uint32_t w[3] = {xy, c | (d << 8), t};
-        __builtin_memcpy(p, w, 12);
+        ADDER_LDS uint32_t *const w = reinterpret_cast<ADDER_LDS uint32_t *>(stage + off);
+        w[0] = xy;
+        w[1] = c | (d << 8);
+        w[2] = t;
     } else {
         const uint32_t tb = __builtin_amdgcn_perm(0u, t, 0x00010203u);  // t3 t2 t1 t0
         if constexpr (REC == 9u) {
-            const uint32_t w[2] = {xyw, d | (tb << 8)};
-            __builtin_memcpy(p, w, 8);
-            p[8] = (uint8_t)(tb >> 24);
+            *reinterpret_cast<ADDER_LDS lpx_u64_any *>(stage + off) = (uint64_t)xyw | ((uint64_t)(d | (tb << 8)) << 32);
+            stage[off + 8u] = (uint8_t)(tb >> 24);
         } else {
-            const uint32_t w[2] = {xyw, 1u | (c << 8) | (d << 16) | (tb << 24)};
-            __builtin_memcpy(p, w, 8);
-            const uint16_t m = (uint16_t)(tb >> 8);
-            __builtin_memcpy(p + 8, &m, 2);
-            p[10] = (uint8_t)(tb >> 24);
+            *reinterpret_cast<ADDER_LDS lpx_u64_any *>(stage + off) = (uint64_t)xyw | ((uint64_t)(1u | (c << 8) | (d << 16) | (tb << 24)) << 32);
+            *reinterpret_cast<ADDER_LDS lpx_u16_any *>(stage + off + 8u) = (uint16_t)(tb >> 8);
+            stage[off + 10u] = (uint8_t)(tb >> 24);
         }
     }
 }
 
+// One wave's item: kLpxPairs pairs (16 segments) of frame f, the launch's frame `fy`.
 template <uint32_t REC>
-__device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32_t f, uint32_t slot, uint32_t cir, uint32_t seg0,
-                                         uint32_t lane, uint8_t *stage, uint2 *rec_lds, const uint32_t *tab_c) {
-    const uint32_t num_waves = __builtin_amdgcn_readfirstlane(b->base.num_waves);
-    const uint32_t park_bytes = __builtin_amdgcn_readfirstlane(b->park_bytes);
-    const uint32_t chunk_frames = __builtin_amdgcn_readfirstlane(b->chunk);
-    const ParkLayout lay = park_layout_u(b);
-    const uint32_t pair_stride = 2u * lay.seg_stride;  // (the wave's 16 segments lie in one group: a constant stride apart)
-    // park_offset() with the launch's chunk-in-ring and frame slot given (the host knows both: no division here)
-    const uint32_t fi = (slot - cir * chunk_frames + (seg0 >> lay.rot_shift)) & lay.rot_mask;
-    const uint32_t group = seg0 >> lay.group_shift;
-    const uint8_t *const park = uniform_ptr(b->park_ring) + (size_t)cir * num_waves * chunk_frames * park_bytes +
-                                (size_t)group * lay.group_stride + (size_t)fi * lay.frame_stride +
-                                (size_t)(seg0 - (group << lay.group_shift)) * lay.seg_stride;
-    const uint32_t *const wtot = uniform_ptr(b->wtot_ring) + (size_t)slot * num_waves + seg0;
-    const uint32_t *const wpref = uniform_ptr(b->wpref_ring) + (size_t)slot * num_waves + seg0;
-    // one round trip: the segments' totals, the events in front of them, the frame's place in the stream
+__device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const LpxArgs &x, uint32_t f, uint32_t fy, uint32_t seg0,
+                                         uint32_t lane, ADDER_LDS uint8_t *stage, ADDER_LDS lpx_u32x2 *rec_lds, const uint32_t *tab_c) {
+    const uint32_t pair_stride = 2u * x.seg_stride;  // (16 segments of one group: a constant stride apart)
+    // park_offset() inside the launch's chunk of the ring
+    const uint32_t fi = (x.fi0 + fy + (seg0 >> x.rot_shift)) & x.rot_mask;
+    const uint32_t group = seg0 >> x.group_shift;
+    const uint8_t *const park = x.park_chunk + (size_t)group * x.group_stride + (size_t)fi * x.frame_stride +
+                                (size_t)(seg0 - (group << x.group_shift)) * x.seg_stride;
+    // one round trip: the segments' totals, the events in front of them, the frame's place in the stream -- and (below) the
+    // records themselves, which do not wait for the totals
+    const size_t row = (size_t)fy * x.num_waves + seg0;
     uint32_t my_tot = 0u;
-    if (lane < kExpandSegs) my_tot = gload<uint32_t>(wtot, lane * 4u);
-    const uint32_t pref0 = gload<uint32_t>(wpref, 0u);
+    if (lane < kExpandSegs) my_tot = gload<uint32_t>(x.wtot + row, lane * 4u);
+    const uint32_t pref0 = gload<uint32_t>(x.wpref + row, 0u);
     const uint64_t fo = b->base.frame_offsets[f];
+    // every pair's first 64 record words, asked for at once -- by EVERY lane, whatever the pair holds (the slots are there):
+    // a load under `lane < np[p]` is a branch, and the compiler waits for each of the eight before it issues the next
+    // (eight round trips in a row: 175 against 140 us per launch)
+    uint32_t first[kLpxPairs];
+#pragma unroll
+    for (uint32_t p = 0; p < kLpxPairs; ++p) first[p] = gload_rec<uint32_t>(park + (size_t)p * pair_stride, lane * 4u);
+    const float T = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
+    const uint64_t out_cap = b->base.out_cap;
+    uint8_t *const out = reinterpret_cast<uint8_t *>(uniform_ptr(b->base.out));
+    const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(x.ftab[f].running_t));  // t of D_EMPTY
     if (__builtin_amdgcn_ballot_w64((my_tot & 0xffffu) != 0u) == 0ull) return;  // quiet content: sixteen empty segments
     // records of pair p = of segments 2p and 2p + 1 (lanes 2p, 2p + 1 hold them: a quad permute adds the neighbour's)
     const uint32_t recs = my_tot >> 16;
@@ -351,18 +380,10 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
     uint32_t np[kLpxPairs];
 #pragma unroll
     for (uint32_t p = 0; p < kLpxPairs; ++p) np[p] = (uint32_t)__builtin_amdgcn_readlane((int)pair_recs, 2 * p);
-    // every pair's first 64 records, asked for at once
-    uint32_t first[kLpxPairs];
-#pragma unroll
-    for (uint32_t p = 0; p < kLpxPairs; ++p) {
-        first[p] = 0u;
-        if (lane < np[p]) first[p] = gload_rec<uint32_t>(park + (size_t)p * pair_stride, lane * 4u);
-    }
     // geometry: (row, offset in row) of the wave's first unit; a unit of the wave lies at most 2047 behind it
-    const uint32_t rowlen = __builtin_amdgcn_readfirstlane(b->base.rowlen);
-    const uint32_t channels = __builtin_amdgcn_readfirstlane(b->base.channels);
-    const uint32_t row_begin = __builtin_amdgcn_readfirstlane(b->base.row_begin);
-    const float inv_row = 1.0f / (float)rowlen;
+    const uint32_t rowlen = x.rowlen;
+    const bool rgb = x.channels == 3u;
+    const float inv_row = x.inv_row;
     uint32_t y0;
     {   // seg0 * 128 / rowlen: a float estimate (units stay below 2^26), fixed either way
         const uint32_t u = seg0 * kWaveUnits;
@@ -374,15 +395,13 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
         y0 = __builtin_amdgcn_readfirstlane(q);
     }
     const uint32_t rem0 = seg0 * kWaveUnits - y0 * rowlen;
-    const uint32_t wraps = rowlen >= kLpxPairs * kLpPairUnits ? 1u : rowlen >= kLpxPairs * kLpPairUnits / 2u ? 2u : 0u;  // (0: divide)
-    const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(b->ftab[f].running_t));  // t of D_EMPTY
-    const float T = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
-    const uint64_t out_cap = b->base.out_cap;
-    uint8_t *const out = reinterpret_cast<uint8_t *>(uniform_ptr(b->base.out));
+    const uint32_t yb = y0 + x.row_begin;
+    const uint32_t wraps = x.wraps;
     uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32)) << 32) |
                      __builtin_amdgcn_readfirstlane((uint32_t)fo)) + __builtin_amdgcn_readfirstlane(pref0);
     uint32_t fill = 0u;  // events staged (uniform)
-    uint32_t phase = (uint32_t)((uintptr_t)out + gpos * REC) & 15u;  // the staging buffer's first byte within its 16-byte block
+    // the staging buffer's first byte sits at the 16-byte phase of its destination: LDS blocks are destination blocks
+    uint32_t phase = (uint32_t)((uintptr_t)out + gpos * REC) & 15u;
     bool dropped = false;
     constexpr uint32_t CAPE = kLpxStageEvents;
 
@@ -393,25 +412,27 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (n) {
-            uint8_t *const dst = out + gpos * REC - phase;  // 16-byte aligned: LDS byte L of the buffer goes to dst + L
+            uint8_t *const dst = uniform_ptr(out + gpos * REC - phase);  // 16-byte aligned: LDS byte L of the buffer goes to dst + L
             const uint32_t end = phase + n * REC;
             const uint32_t kb = phase ? 1u : 0u, ke = end >> 4;
-            for (uint32_t k = kb + lane; k < ke; k += kWave) {
-                uint4 v;
-                __builtin_memcpy(&v, (const uint8_t *)__builtin_assume_aligned(stage + 16u * k, 16), 16);
+            for (uint32_t k = kb + lane; k < ke; k += kWave) {  // 16-byte LDS reads -> 16-byte stores, a kilobyte per instruction
+                const lpx_u32x4 lv = *reinterpret_cast<ADDER_LDS const lpx_u32x4 *>(stage + 16u * k);
+                const uint4 v = make_uint4(lv.x, lv.y, lv.z, lv.w);
+#if !defined(ADDER_DBG_LPX) || ADDER_DBG_LPX < 1  // (diagnostic A/B builds: 1 no event stores, 2 no staging either, 3 no rounds at all)
                 gstore_ev<uint4>(dst, 16u * k, v);
+#else
+                if (v.x == 0x12345u && v.w == 0x54321u) gstore_ev<uint4>(dst, 16u * k, v);
+#endif
             }
             // the bytes in front of the first whole block and behind the last one: shared with the neighbouring waves' blocks
             const uint32_t head_n = phase ? (end < 16u ? end : 16u) - phase : 0u;
             const uint32_t tail_lo = (end > 16u || phase == 0u) ? (ke << 4) : end;
             const uint32_t tail_n = end - tail_lo;
-            if (lane < 32u) {
-                const uint32_t t = lane & 15u;
-                const bool is_tail = lane >= 16u;
-                if (t < (is_tail ? tail_n : head_n)) {
-                    const uint32_t L = (is_tail ? tail_lo : phase) + t;
-                    gstore<uint8_t>(dst, L, stage[L]);
-                }
+            const uint32_t t = lane & 15u;
+            const bool is_tail = lane >= 16u;
+            if (lane < 32u && t < (is_tail ? tail_n : head_n)) {
+                const uint32_t L = (is_tail ? tail_lo : phase) + t;
+                gstore<uint8_t>(dst, L, stage[L]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -438,14 +459,14 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
         for (uint32_t p = 0; p < kLpxPairs; ++p) {
             if (p >= pstart && p < pe && np[p] != 0u) {  // uniform
                 const uint32_t w4 = first[p];
-                if (lane < np[p]) rec_lds[rb + lane] = make_uint2((w4 >> kLpRhoShift) | (p << 28), w4);
-                esc_any |= __builtin_amdgcn_ballot_w64(lp_escapes(w4));
+                if (lane < np[p]) rec_lds[rb + lane] = lpx_u32x2{(w4 >> kLpRhoShift) | (p << 28), w4};
+                esc_any |= __builtin_amdgcn_ballot_w64(lane < np[p] && lp_escapes(w4));
                 if (__builtin_expect(np[p] > kWave, 0)) {  // (more than a quarter of the pair's units flushed)
                     const uint8_t *const pp = park + (size_t)p * pair_stride;
                     for (uint32_t l0 = kWave; l0 < np[p]; l0 += kWave) {
                         const uint32_t idx = l0 + lane;
                         const uint32_t w = idx < np[p] ? gload_rec<uint32_t>(pp, idx * 4u) : 0u;
-                        if (idx < np[p]) rec_lds[rb + idx] = make_uint2((w >> kLpRhoShift) | (p << 28), w);
+                        if (idx < np[p]) rec_lds[rb + idx] = lpx_u32x2{(w >> kLpRhoShift) | (p << 28), w};
                         esc_any |= __builtin_amdgcn_ballot_w64(lp_escapes(w));
                     }
                 }
@@ -465,13 +486,13 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
                 uint32_t esc_before = 0u;
                 for (uint32_t l0 = 0; l0 < n_p; l0 += kWave) {
                     const uint32_t idx = l0 + lane;
-                    uint2 r = make_uint2(0u, 0u);
+                    lpx_u32x2 r = {0u, 0u};
                     if (idx < n_p) r = rec_lds[qb + idx];
                     const bool e = idx < n_p && lp_escapes(r.y);
                     const uint64_t em = __builtin_amdgcn_ballot_w64(e);
                     if (em != 0ull) {
                         const uint32_t rank = esc_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-                        if (e) rec_lds[qb + idx] = make_uint2(gload_rec<uint32_t>(pp, pair_stride - 4u * (rank + 1u)) | (p << 28), r.y);
+                        if (e) rec_lds[qb + idx] = lpx_u32x2{gload_rec<uint32_t>(pp, pair_stride - 4u * (rank + 1u)) | (p << 28), r.y};
                         esc_before += (uint32_t)__popcll(em);
                     }
                 }
@@ -482,11 +503,15 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // 2. dense rounds
+#if defined(ADDER_DBG_LPX) && ADDER_DBG_LPX >= 3
+        for (uint32_t r0 = 0; r0 < (R == 0x7777u ? 64u : 0u); r0 += kWave) {
+#else
 #pragma clang loop unroll(disable)
         for (uint32_t r0 = 0; r0 < R; r0 += kWave) {
+#endif
             if (fill + 3u * kWave > CAPE) flush();
             const bool valid = r0 + lane < R;
-            uint2 rec = make_uint2(0u, 0u);
+            lpx_u32x2 rec = {0u, 0u};
             if (valid) rec = rec_lds[r0 + lane];
             const uint32_t w8 = rec.y;
             const LeanEvents e = lr_decode8_tab(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32, nullptr, tab_c);  // (a zero record: no events)
@@ -494,7 +519,7 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
             const uint32_t incl = wave_inclusive_scan_dpp(n);
             // coordinates: the unit counted from the wave's first
             uint32_t rem = rem0 + ((rec.x >> 28) << 8) + (w8 & 0xffu);
-            uint32_t y = y0 + row_begin;
+            uint32_t y = yb;
             if (wraps != 0u) {
                 const bool w1 = rem >= rowlen;
                 rem -= w1 ? rowlen : 0u;
@@ -512,57 +537,61 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, uint32
                 y += q;
             }
             uint32_t x = rem, c = 0xffu;
-            if (channels == 3u) {
+            if (rgb) {
                 x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
                 c = rem - 3u * x;
             }
             const uint32_t xy = x | (y << 16);
             const uint32_t xyw = __builtin_amdgcn_perm(0u, xy, 0x02030001u);  // x_hi x_lo y_hi y_lo
-            uint8_t *p = stage + phase + (fill + incl - n) * REC;
+            uint32_t off = phase + (fill + incl - n) * REC;
             fill += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+#if defined(ADDER_DBG_LPX) && ADDER_DBG_LPX >= 2
+            if (e.a && e.ta == 0x7654321u && e.tc == 0x1234567u && xyw == 0x33u) lpx_put<REC>(stage, off, xy, xyw, c, e.da, e.ta + e.tc);
+#else
             if (e.a) {
-                lpx_put<REC>(p, xy, xyw, c, e.da, e.ta);
-                p += REC;
+                lpx_put<REC>(stage, off, xy, xyw, c, e.da, e.ta);
+                off += REC;
             }
             if (e.b) {
-                lpx_put<REC>(p, xy, xyw, c, kDEmpty, e.tb);
-                p += REC;
+                lpx_put<REC>(stage, off, xy, xyw, c, kDEmpty, e.tb);
+                off += REC;
             }
-            if (e.c) lpx_put<REC>(p, xy, xyw, c, e.dc, e.tc);
+            if (e.c) lpx_put<REC>(stage, off, xy, xyw, c, e.dc, e.tc);
+#endif
         }
         pstart = pe;
     }
     flush();
-    if (dropped) raise(b->base.status, kStatusCapacity);
+    if (dropped) raise(x.status, kStatusCapacity);
 }
 
-// grid: (blocks of 64 segments, frames of the launch); slot0 / cir: the first frame's slot of the scratch ring and its chunk
-// in the ring (a launch covers frames of ONE chunk, consecutive slots)
+// grid: (blocks of 64 segments, frames of the launch).  What does not change from batch to batch of a context -- the scratch
+// ring, the plane's geometry -- arrives as kernel arguments (LpxArgs: scalar registers when the wave starts); the batch's own
+// (output buffer, capacity, frame offsets, time step) come from the device-resident description like everywhere else, so a
+// captured graph still serves any batch.  (With everything read from the description a wave spent 54 % of its life in
+// s_waitcnt: 18 dependent scalar loads.)  (Workgroups that walk several items with the next
+// items' loads in flight were tried: 147-172 us per launch against this form's 138-144 -- the uniform state of three items
+// in flight spilled the scalar registers.)
 template <uint32_t REC>
-__global__ __launch_bounds__(kBlockThreads) void adder_lpx_kernel(const BatchArgs *__restrict__ b, uint32_t f0, uint32_t slot0,
-                                                                  uint32_t cir) {
+__global__ __launch_bounds__(kBlockThreads) void adder_lpx_kernel(const BatchArgs *__restrict__ b, const LpxArgs x, uint32_t f0) {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kLpxStageEvents * REC + 16u];
     __shared__ __attribute__((aligned(8))) uint2 s_rec[kWavesPerBlock][kLpxRecCap];
     __shared__ uint32_t s_tab_c[256];  // event C by input byte (lr_build_tab)
-    timeline_mark(b, 3u, f0, false);
-    const uint32_t f = f0 + blockIdx.y, slot = slot0 + blockIdx.y, xblock = blockIdx.x;
+    const uint32_t fy = blockIdx.y, xblock = blockIdx.x;
     // (the table's words are asked for first and parked after the test: the two loads share one round trip)
-    const uint32_t tab_word = gload<uint32_t>(uniform_ptr(b->lr_tab), (256u * kLrTabRuns + threadIdx.x) * 4u);
-    const uint32_t *const ft = b->ftot_ring;  // a frame without a single event has nothing to expand
-    if (ft != nullptr && __builtin_amdgcn_readfirstlane(ft[slot]) == 0u) return;
+    const uint32_t tab_word = gload<uint32_t>(x.tab_c, threadIdx.x * 4u);
+    if (x.ftot[fy] == 0u) return;  // a frame without a single event has nothing to expand
     s_tab_c[threadIdx.x] = tab_word;
     __syncthreads();
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + wid) * kExpandSegs);
-    if (seg0 < __builtin_amdgcn_readfirstlane(b->base.num_waves))
-        lpx_wave<REC>(b, f, slot, cir, seg0, threadIdx.x & (kWave - 1u), s_stage[wid], s_rec[wid], s_tab_c);
-    timeline_mark(b, 3u, f0, true);
+    if (seg0 < x.num_waves)
+        lpx_wave<REC>(b, x, f0 + fy, fy, seg0, threadIdx.x & (kWave - 1u), (ADDER_LDS uint8_t *)s_stage[wid], (ADDER_LDS lpx_u32x2 *)s_rec[wid], s_tab_c);
 }
 
 }  // namespace adder
 
 using namespace adder;
-
 extern "C" hipError_t adder_launch_lp(const BatchArgs *b, uint32_t f, uint32_t nb, uint32_t lazy, uint32_t num_waves,
                                       uint32_t grid_cap, hipStream_t stream) {
     const uint32_t pairs = num_waves / 2u;
@@ -572,13 +601,34 @@ extern "C" hipError_t adder_launch_lp(const BatchArgs *b, uint32_t f, uint32_t n
     return hipGetLastError();
 }
 
-
-extern "C" hipError_t adder_launch_lpx(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, uint32_t rec,
-                                       uint32_t slot0, uint32_t cir, hipStream_t stream) {
+extern "C" hipError_t adder_launch_lpx(const BatchArgs *b, const BatchArgs *hb, uint32_t f0, uint32_t nf, uint32_t rec, hipStream_t stream) {
+    // hb: the host's copy of the description *b -- the kernel arguments are worked out from its context-constant part
+    const uint32_t num_waves = hb->base.num_waves, slot0 = f0 % hb->slots, cir = slot0 / hb->chunk;
+    LpxArgs x;
+    x.park_chunk = hb->park_ring + (size_t)cir * num_waves * hb->chunk * hb->park_bytes;
+    x.wtot = hb->wtot_ring + (size_t)slot0 * num_waves;
+    x.wpref = hb->wpref_ring + (size_t)slot0 * num_waves;
+    x.ftot = hb->ftot_ring + slot0;
+    x.tab_c = hb->lr_tab + 256u * kLrTabRuns;
+    x.ftab = hb->ftab;
+    x.status = hb->base.status;
+    x.num_waves = num_waves;
+    x.fi0 = slot0 - cir * hb->chunk;
+    x.group_shift = hb->park_layout.group_shift;
+    x.group_stride = hb->park_layout.group_stride;
+    x.frame_stride = hb->park_layout.frame_stride;
+    x.seg_stride = hb->park_layout.seg_stride;
+    x.rot_shift = hb->park_layout.rot_shift;
+    x.rot_mask = hb->park_layout.rot_mask;
+    x.rowlen = hb->base.rowlen;
+    x.channels = hb->base.channels;
+    x.row_begin = hb->base.row_begin;
+    x.wraps = x.rowlen >= kLpxPairs * kLpPairUnits ? 1u : x.rowlen >= kLpxPairs * kLpPairUnits / 2u ? 2u : 0u;  // (0: divide)
+    x.inv_row = 1.0f / (float)x.rowlen;
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const dim3 grid((num_waves + per_block - 1u) / per_block, nf);
-    if (rec == 9u) hipLaunchKernelGGL((adder_lpx_kernel<9u>), grid, dim3(kBlockThreads), 0, stream, b, f0, slot0, cir);
-    else if (rec == 11u) hipLaunchKernelGGL((adder_lpx_kernel<11u>), grid, dim3(kBlockThreads), 0, stream, b, f0, slot0, cir);
-    else hipLaunchKernelGGL((adder_lpx_kernel<12u>), grid, dim3(kBlockThreads), 0, stream, b, f0, slot0, cir);
+    if (rec == 9u) hipLaunchKernelGGL((adder_lpx_kernel<9u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
+    else if (rec == 11u) hipLaunchKernelGGL((adder_lpx_kernel<11u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
+    else hipLaunchKernelGGL((adder_lpx_kernel<12u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
     return hipGetLastError();
 }
