@@ -310,7 +310,6 @@ static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxStageEvents >
 struct LpxArgs {
     const uint8_t *park_chunk;             // the launch's chunk of the scratch ring
     const uint32_t *wtot, *wpref, *ftot;   // the rows of the launch's first frame slot
-    const uint32_t *tab_c;                 // event C by input byte (lr_build_tab's last 256 words)
     const FrameTab *ftab;
     uint32_t *status;
     uint32_t num_waves, fi0;               // fi0: the first frame's slot inside its chunk
@@ -349,7 +348,7 @@ __device__ __forceinline__ void lpx_put(ADDER_LDS uint8_t *stage, uint32_t off, 
 // One wave's item: kLpxPairs pairs (16 segments) of frame f, the launch's frame `fy`.
 template <uint32_t REC>
 __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const LpxArgs &x, uint32_t f, uint32_t fy, uint32_t seg0,
-                                         uint32_t lane, ADDER_LDS uint8_t *stage, ADDER_LDS lpx_u32x2 *rec_lds, const uint32_t *tab_c) {
+                                         uint32_t lane, ADDER_LDS uint8_t *stage, ADDER_LDS lpx_u32x2 *rec_lds) {
     const uint32_t pair_stride = 2u * x.seg_stride;  // (16 segments of one group: a constant stride apart)
     // park_offset() inside the launch's chunk of the ring
     const uint32_t fi = (x.fi0 + fy + (seg0 >> x.rot_shift)) & x.rot_mask;
@@ -358,21 +357,37 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
                                 (size_t)(seg0 - (group << x.group_shift)) * x.seg_stride;
     // one round trip: the segments' totals, the events in front of them, the frame's place in the stream -- and (below) the
     // records themselves, which do not wait for the totals
+    // Every vector load of the item is ISSUED HERE, before anything is waited for, by every lane (a load under a lane mask is
+    // a branch the compiler waits at) and as volatile asm: written as ordinary loads the compiler sinks them below the
+    // early exits, behind the scalar loads those wait for -- a chain of six round trips where one will do.  lpx_loads_done()
+    // is their s_waitcnt.
     const size_t row = (size_t)fy * x.num_waves + seg0;
-    uint32_t my_tot = 0u;
-    if (lane < kExpandSegs) my_tot = gload<uint32_t>(x.wtot + row, lane * 4u);
-    const uint32_t pref0 = gload<uint32_t>(x.wpref + row, 0u);
-    const uint64_t fo = b->base.frame_offsets[f];
-    // every pair's first 64 record words, asked for at once -- by EVERY lane, whatever the pair holds (the slots are there):
-    // a load under `lane < np[p]` is a branch, and the compiler waits for each of the eight before it issues the next
-    // (eight round trips in a row: 175 against 140 us per launch)
-    uint32_t first[kLpxPairs];
+    uint32_t my_tot, pref0, first[kLpxPairs];
+    const uint32_t tot_off = (lane < kExpandSegs ? lane : kExpandSegs - 1u) * 4u, zero_off = 0u, rec_off = lane * 4u;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(my_tot) : "v"(tot_off), "s"(x.wtot + row) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(pref0) : "v"(zero_off), "s"(x.wpref + row) : "memory");
 #pragma unroll
-    for (uint32_t p = 0; p < kLpxPairs; ++p) first[p] = gload_rec<uint32_t>(park + (size_t)p * pair_stride, lane * 4u);
+    for (uint32_t p = 0; p < kLpxPairs; ++p)  // every pair's first 64 record words (whatever the pair holds: the slots are there)
+        asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(first[p]) : "v"(rec_off), "s"(park + (size_t)p * pair_stride) : "memory");
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 fo2;  // the frame's place in the stream (the batch's own table: its address comes out of the description first)
+    const uint32_t fo_off = f * 8u;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fo2) : "v"(fo_off), "s"(b->base.frame_offsets) : "memory");
+    const uint32_t frame_events = x.ftot[fy];
     const float T = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
     const uint64_t out_cap = b->base.out_cap;
     uint8_t *const out = reinterpret_cast<uint8_t *>(uniform_ptr(b->base.out));
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(x.ftab[f].running_t));  // t of D_EMPTY
+    if (frame_events == 0u) {  // a frame without a single event has nothing to expand
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads still name this wave's registers)
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(fo2), "+v"(my_tot), "+v"(pref0), "+v"(first[0]), "+v"(first[1]), "+v"(first[2]), "+v"(first[3]), "+v"(first[4]), "+v"(first[5]),
+                   "+v"(first[6]), "+v"(first[7])
+                 :
+                 : "memory");
+    my_tot = lane < kExpandSegs ? my_tot : 0u;
     if (__builtin_amdgcn_ballot_w64((my_tot & 0xffffu) != 0u) == 0ull) return;  // quiet content: sixteen empty segments
     // records of pair p = of segments 2p and 2p + 1 (lanes 2p, 2p + 1 hold them: a quad permute adds the neighbour's)
     const uint32_t recs = my_tot >> 16;
@@ -397,8 +412,8 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
     const uint32_t rem0 = seg0 * kWaveUnits - y0 * rowlen;
     const uint32_t yb = y0 + x.row_begin;
     const uint32_t wraps = x.wraps;
-    uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fo >> 32)) << 32) |
-                     __builtin_amdgcn_readfirstlane((uint32_t)fo)) + __builtin_amdgcn_readfirstlane(pref0);
+    uint64_t gpos = (((uint64_t)__builtin_amdgcn_readfirstlane(fo2.y) << 32) | __builtin_amdgcn_readfirstlane(fo2.x)) +
+                    __builtin_amdgcn_readfirstlane(pref0);
     uint32_t fill = 0u;  // events staged (uniform)
     // the staging buffer's first byte sits at the 16-byte phase of its destination: LDS blocks are destination blocks
     uint32_t phase = (uint32_t)((uintptr_t)out + gpos * REC) & 15u;
@@ -514,7 +529,7 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
             lpx_u32x2 rec = {0u, 0u};
             if (valid) rec = rec_lds[r0 + lane];
             const uint32_t w8 = rec.y;
-            const LeanEvents e = lr_decode8_tab(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32, nullptr, tab_c);  // (a zero record: no events)
+            const LeanEvents e = lr_decode8(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32);  // (a zero record: no events)
             const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
             const uint32_t incl = wave_inclusive_scan_dpp(n);
             // coordinates: the unit counted from the wave's first
@@ -576,17 +591,12 @@ template <uint32_t REC>
 __global__ __launch_bounds__(kBlockThreads) void adder_lpx_kernel(const BatchArgs *__restrict__ b, const LpxArgs x, uint32_t f0) {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kLpxStageEvents * REC + 16u];
     __shared__ __attribute__((aligned(8))) uint2 s_rec[kWavesPerBlock][kLpxRecCap];
-    __shared__ uint32_t s_tab_c[256];  // event C by input byte (lr_build_tab)
+    // (the waves of a workgroup share nothing: no table in LDS -- event C's one division is worked out like event A's --, no barrier)
     const uint32_t fy = blockIdx.y, xblock = blockIdx.x;
-    // (the table's words are asked for first and parked after the test: the two loads share one round trip)
-    const uint32_t tab_word = gload<uint32_t>(x.tab_c, threadIdx.x * 4u);
-    if (x.ftot[fy] == 0u) return;  // a frame without a single event has nothing to expand
-    s_tab_c[threadIdx.x] = tab_word;
-    __syncthreads();
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + wid) * kExpandSegs);
     if (seg0 < x.num_waves)
-        lpx_wave<REC>(b, x, f0 + fy, fy, seg0, threadIdx.x & (kWave - 1u), (ADDER_LDS uint8_t *)s_stage[wid], (ADDER_LDS lpx_u32x2 *)s_rec[wid], s_tab_c);
+        lpx_wave<REC>(b, x, f0 + fy, fy, seg0, threadIdx.x & (kWave - 1u), (ADDER_LDS uint8_t *)s_stage[wid], (ADDER_LDS lpx_u32x2 *)s_rec[wid]);
 }
 
 }  // namespace adder
@@ -609,7 +619,6 @@ extern "C" hipError_t adder_launch_lpx(const BatchArgs *b, const BatchArgs *hb, 
     x.wtot = hb->wtot_ring + (size_t)slot0 * num_waves;
     x.wpref = hb->wpref_ring + (size_t)slot0 * num_waves;
     x.ftot = hb->ftot_ring + slot0;
-    x.tab_c = hb->lr_tab + 256u * kLrTabRuns;
     x.ftab = hb->ftab;
     x.status = hb->base.status;
     x.num_waves = num_waves;
