@@ -93,9 +93,24 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
             }
         }
     };
+    // Vector memory instructions complete in the order they were issued, so the wait for a group's input is COUNTED: `since`
+    // record stores have certainly been issued behind the group's loads and may stay in flight (vmcnt(0) here made every wave
+    // sit out its last frames' store acknowledgements once per group).  (An instruction not counted only makes the wait longer.)
+    uint32_t since = 0u;
     auto stage = [&](uint32_t i) {  // group i starts: its bytes have landed, the next group leaves
-        __builtin_amdgcn_s_waitcnt(0x0f70);
+        switch (i == 0u ? 0u : (since < 8u ? since : 8u)) {
+            case 0u: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1u: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2u: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3u: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4u: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5u: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6u: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7u: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
         if (i != 0u && i + kLpGroup < nb) stage_issue(i + kLpGroup);
+        since = 0u;
     };
     stage_issue(0u);
     if (kLpGroup < nb) stage_issue(kLpGroup);
@@ -127,13 +142,31 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
 
     // ESC: some unit of the pair carries a run in that can reach rho' = 255 within this launch (uniform; never on content that
     // keeps changing) -- its frames also look for escaping records and park their full rho' (adder_pixel.hpp lp_park4)
+    // The frame's records leave ONE FRAME LATER (pend_n of them, to pend_seg): the LDS run is read back at the top of the next
+    // frame and stored behind its packed step, so no frame waits for its own LDS round trip.
+    uint32_t pend_n = 0u;
+    uint8_t *pend_seg = seg;
     auto frame = [&](uint32_t i, auto esc_tag) {
         constexpr bool ESC = decltype(esc_tag)::value;
         const uint32_t vin = in_lds[(i % kLpInFrames) * kWave];
+        uint32_t pend_w = 0u;
+        if (pend_n != 0u) pend_w = rec_lds[lane < pend_n ? lane : 0u];  // (uniform branch; every lane reads: no lane mask around the LDS read)
         const uint32_t x = vin ^ s.prev;
-        if (__builtin_amdgcn_ballot_w64(x != 0u) != 0ull) {
-            const uint32_t base_w = s.prev;
-            const LpMasks m = lp_step(s, vin);
+        const bool busy = __builtin_amdgcn_ballot_w64(x != 0u) != 0ull;
+        LpMasks m{0u, 0u, 0u, 0u};
+        const uint32_t base_w = s.prev;
+        if (busy) m = lp_step(s, vin);
+        else lp_quiet(s);
+#if !defined(ADDER_DBG_LP_NOSTORE)
+        if (pend_n != 0u) {
+            if (lane < pend_n) gstore(pend_seg, lane * 4u, pend_w);
+            since += 1u;
+            pend_n = 0u;
+        }
+#else
+        pend_n = 0u;
+#endif
+        if (busy) {
             const uint32_t nrec = lp_bcnt(m.h, 0u);
             const uint32_t nev = lp_bcnt(m.c, lp_bcnt(m.b, lp_bcnt(m.a, 0u)));
             const uint32_t sw = nrec | (nev << 16);
@@ -173,20 +206,25 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
                 }
             }
             const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) & 0xffffu;
+            if (!ESC && n_rec <= kWave) {  // (uniform) the usual case: the store waits for the next frame
+                pend_n = n_rec;
+                pend_seg = seg;
+            } else {
 #if !defined(ADDER_DBG_LP_NOSTORE)  // (diagnostic A/B build: everything but the record stores)
-            for (uint32_t k0 = 0; k0 < n_rec; k0 += kWave) {  // uniform trip count: one trip unless a quarter of the units flush
-                const uint32_t k = k0 + lane;
-                if (k < n_rec) gstore(seg, k * 4u, rec_lds[k]);
-            }
-            if (ESC) {
-                for (uint32_t k0 = 0; k0 < n_esc; k0 += kWave) {  // (escape k: 4 (k + 1) bytes below the end of the pair's two slots)
+                for (uint32_t k0 = 0; k0 < n_rec; k0 += kWave) {  // more than a quarter of the units flushed, or escapes: at once
                     const uint32_t k = k0 + lane;
-                    if (k < n_esc) gstore(seg, 2u * park_bytes_u - 4u * (k + 1u), rec_lds[kLpPairUnits + k]);
+                    if (k < n_rec) gstore(seg, k * 4u, rec_lds[k]);
+                    since += 1u;
                 }
-            }
+                if (ESC) {
+                    for (uint32_t k0 = 0; k0 < n_esc; k0 += kWave) {  // (escape k: 4 (k + 1) bytes below the end of the pair's two slots)
+                        const uint32_t k = k0 + lane;
+                        if (k < n_esc) gstore(seg, 2u * park_bytes_u - 4u * (k + 1u), rec_lds[kLpPairUnits + k]);
+                        since += 1u;
+                    }
+                }
 #endif
-        } else {
-            lp_quiet(s);
+            }
         }
         seg += frame_stride_u;
         if (__builtin_expect(i == wrap_at, 0)) seg -= wrap_bytes;
@@ -210,6 +248,9 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
         }
     }
 
+#if !defined(ADDER_DBG_LP_NOSTORE)
+    if (pend_n != 0u && lane < pend_n) gstore(pend_seg, lane * 4u, rec_lds[lane]);  // the last frame's records
+#endif
     // the frames' totals: lane f holds frame f's {records | events << 16} up to lane 31 and up to lane 63
     if (lane < nb) {
         const uint2 t = reinterpret_cast<const uint2 *>(lds_tot)[lane];
