@@ -35,9 +35,27 @@ constexpr uint32_t kLpInFrames = 2u * kLpGroup;
 constexpr uint32_t kLpUnits = 4u;                    // units per lane
 constexpr uint32_t kLpPairUnits = kWave * kLpUnits;  // 256: a pair of segments
 static_assert(kWaveUnits == 128u && kLpPairUnits == 2u * kWaveUnits, "a wave steps two 128-unit segments");
-static_assert(kLpGroup % 4u == 0u && kMaxFramesPerLaunch % kLpInFrames == 0u, "four frames of a pair per load instruction");
+static_assert(kLpGroup % 4u == 0u && kMaxFramesPerLaunch % kLpInFrames == 0u && kLpGroup >= 4u, "four frames of a pair per load instruction");
 
 __device__ __forceinline__ uint32_t lp_bcnt(uint32_t x, uint32_t acc) { return (uint32_t)__builtin_popcount(x) + acc; }
+
+// One byte position of a frame (units 4 lane + J): the lanes whose unit flushed (bit 7 of byte J of h) put their record word
+// {unit | base_val << 8 | input << 16 | (i - start) << 24} at LDS address `addr`, step the address and restart the unit's run.
+// By hand: half of the kernel's vector instructions are these four blocks, and the compiler's form of one is eleven
+// instructions (two copies of the new start, a temporary for the address) where seven do.  rho' = i - start < 255 here (lp_frames).
+#define ADDER_LP_SLOT(J)                                                                                                      \
+    asm volatile("v_cmp_ne_u32_sdwa vcc, %[h], %[z] src0_sel:BYTE_" #J " src1_sel:DWORD\n\t"                                   \
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"                                                                          \
+                 "v_sub_u32_sdwa %[t], %[i], %[st] dst_sel:BYTE_3 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"    \
+                 "v_perm_b32 %[p], %[vin], %[bw], %[sel]\n\t"                                                                 \
+                 "v_or3_b32 %[t], %[t], %[p], %[un]\n\t"                                                                      \
+                 "ds_write_b32 %[a], %[t]\n\t"                                                                                \
+                 "v_add_u32 %[a], 4, %[a]\n\t"                                                                                \
+                 "v_mov_b32 %[st], %[i]\n\t"                                                                                  \
+                 "s_mov_b64 exec, %[sv]"                                                                                       \
+                 : [a] "+v"(addr), [st] "+v"(s.start[J]), [t] "=&v"(slot_t), [p] "=&v"(slot_p), [sv] "=&s"(slot_sv)             \
+                 : [h] "v"(m.h), [z] "v"(zero_v), [i] "s"(i), [vin] "v"(vin), [bw] "v"(base_w), [sel] "v"(sel[J]), [un] "v"(unitj[J]) \
+                 : "vcc", "memory")
 
 template <bool FULL>
 __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t pw,
@@ -137,6 +155,12 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
 #pragma unroll
     for (uint32_t j = 0; j < kLpUnits; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(sel[j]) : "s"(0x0c00000cu | (j << 8) | ((4u + j) << 16)));
     const uint32_t unit0 = lane * kLpUnits;
+    uint32_t unitj[kLpUnits];
+#pragma unroll
+    for (uint32_t j = 0; j < kLpUnits; ++j) asm volatile("v_or_b32 %0, %1, %2" : "=v"(unitj[j]) : "v"(unit0), "s"(j));  // (kept in registers)
+    uint32_t zero_v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const uint32_t rec_lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)rec_lds;
     uint32_t *const tot_lds = lds_tot + (lane >> 5);
     const bool tot_lane = (lane & 31u) == 31u;
 
@@ -146,11 +170,11 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
     // frame and stored behind its packed step, so no frame waits for its own LDS round trip.
     uint32_t pend_n = 0u;
     uint8_t *pend_seg = seg;
+    const uint32_t lane4 = lane * 4u;
     auto frame = [&](uint32_t i, auto esc_tag) {
         constexpr bool ESC = decltype(esc_tag)::value;
         const uint32_t vin = in_lds[(i % kLpInFrames) * kWave];
-        uint32_t pend_w = 0u;
-        if (pend_n != 0u) pend_w = rec_lds[lane < pend_n ? lane : 0u];  // (uniform branch; every lane reads: no lane mask around the LDS read)
+        const uint32_t pend_w = rec_lds[lane];  // (every lane, every frame: no branch around the LDS read; lanes >= pend_n read what is not stored)
         const uint32_t x = vin ^ s.prev;
         const bool busy = __builtin_amdgcn_ballot_w64(x != 0u) != 0ull;
         LpMasks m{0u, 0u, 0u, 0u};
@@ -159,7 +183,7 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
         else lp_quiet(s);
 #if !defined(ADDER_DBG_LP_NOSTORE)
         if (pend_n != 0u) {
-            if (lane < pend_n) gstore(pend_seg, lane * 4u, pend_w);
+            if (lane < pend_n) asm volatile("global_store_dword %0, %1, %2" : : "v"(lane4), "v"(pend_w), "s"(pend_seg) : "memory");
             since += 1u;
             pend_n = 0u;
         }
@@ -176,11 +200,19 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
             // 8-byte stores per frame (one per byte position) cost the kernel 40 of its 100 us -- the memory pipeline takes
             // a store instruction at a time, whatever its lanes hold
             uint32_t pos = (incl - sw) & 0xffffu;
-            uint32_t rho[kLpUnits];
             uint32_t n_esc = 0u, epos = 0u;
-#pragma unroll
-            for (uint32_t j = 0; j < kLpUnits; ++j) rho[j] = i - s.start[j];
+            if constexpr (!ESC) {
+                uint32_t addr = rec_lds_addr + pos * 4u, slot_t, slot_p;
+                uint64_t slot_sv;
+                ADDER_LP_SLOT(0);
+                ADDER_LP_SLOT(1);
+                ADDER_LP_SLOT(2);
+                ADDER_LP_SLOT(3);
+            }
+            uint32_t rho[kLpUnits];
             if (ESC) {
+#pragma unroll
+                for (uint32_t j = 0; j < kLpUnits; ++j) rho[j] = i - s.start[j];
                 uint32_t ne = 0u;
 #pragma unroll
                 for (uint32_t j = 0; j < kLpUnits; ++j) ne += ((m.h & (0x80u << (8u * j))) && rho[j] >= kLpRhoEsc) ? 1u : 0u;
@@ -188,21 +220,21 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
                 epos = ei - ne;
                 n_esc = (uint32_t)__builtin_amdgcn_readlane((int)ei, kWave - 1);
             }
+            if (ESC) {
 #pragma unroll
-            for (uint32_t j = 0; j < kLpUnits; ++j) {
-                if (m.h & (0x80u << (8u * j))) {
-                    const uint32_t w8 = __builtin_amdgcn_perm(vin, base_w, sel[j]) | unit0 | j;
-                    uint32_t r8 = rho[j];
-                    if (ESC) {
+                for (uint32_t j = 0; j < kLpUnits; ++j) {
+                    if (m.h & (0x80u << (8u * j))) {
+                        const uint32_t w8 = __builtin_amdgcn_perm(vin, base_w, sel[j]) | unit0 | j;
+                        uint32_t r8 = rho[j];
                         if (r8 >= kLpRhoEsc) {
                             rec_lds[kLpPairUnits + epos] = r8;
                             epos += 1u;
                             r8 = kLpRhoEsc;
                         }
+                        rec_lds[pos] = w8 | (r8 << kLpRhoShift);
+                        pos += 1u;
+                        s.start[j] = i;
                     }
-                    rec_lds[pos] = w8 | (r8 << kLpRhoShift);
-                    pos += 1u;
-                    s.start[j] = i;
                 }
             }
             const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) & 0xffffu;
