@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t lp_bcnt(uint32_t x, uint32_t acc) { return (
                  "s_mov_b64 exec, %[sv]"                                                                                       \
                  : [a] "+v"(addr), [st] "+v"(s.start[J]), [t] "=&v"(slot_t), [p] "=&v"(slot_p), [sv] "=&s"(slot_sv)             \
                  : [h] "v"(m.h), [z] "v"(zero_v), [i] "s"(i), [vin] "v"(vin), [bw] "v"(base_w), [sel] "v"(sel[J]), [un] "v"(unitj[J]) \
-                 : "vcc", "memory")
+                 : "vcc", "scc", "memory")  /* (s_and_saveexec writes SCC) */
 
 template <bool FULL>
 __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb, uint32_t pw,
@@ -193,16 +193,17 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
         if (busy) {
             const uint32_t nrec = lp_bcnt(m.h, 0u);
             const uint32_t nev = lp_bcnt(m.c, lp_bcnt(m.b, lp_bcnt(m.a, 0u)));
-            const uint32_t sw = nrec | (nev << 16);
+            // {events | 4 x records << 16}: the scan's upper half is the byte offset of the lane's first record in the LDS run
+            const uint32_t sw = nev | (nrec << 18);
             const uint32_t incl = wave_inclusive_scan_dpp(sw);
             if (tot_lane) tot_lds[i * 2u] = incl;
             // the records go through the wave's LDS run and leave as ONE contiguous store per 64 of them: four sparse
             // 8-byte stores per frame (one per byte position) cost the kernel 40 of its 100 us -- the memory pipeline takes
             // a store instruction at a time, whatever its lanes hold
-            uint32_t pos = (incl - sw) & 0xffffu;
+            uint32_t pos = (incl - sw) >> 18;
             uint32_t n_esc = 0u, epos = 0u;
             if constexpr (!ESC) {
-                uint32_t addr = rec_lds_addr + pos * 4u, slot_t, slot_p;
+                uint32_t addr = rec_lds_addr + ((incl - sw) >> 16), slot_t, slot_p;
                 uint64_t slot_sv;
                 ADDER_LP_SLOT(0);
                 ADDER_LP_SLOT(1);
@@ -237,7 +238,7 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
                     }
                 }
             }
-            const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) & 0xffffu;
+            const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) >> 18;
             if (!ESC && n_rec <= kWave) {  // (uniform) the usual case: the store waits for the next frame
                 pend_n = n_rec;
                 pend_seg = seg;
@@ -275,7 +276,11 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
 #pragma clang loop unroll(disable)
             for (; i < i_end; ++i) frame(i, std::true_type{});
         } else {
+#if defined(ADDER_LP_NO_UNROLL2)
 #pragma clang loop unroll(disable)
+#else
+#pragma clang loop unroll_count(2)
+#endif
             for (; i < i_end; ++i) frame(i, std::false_type{});
         }
     }
@@ -286,12 +291,12 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
     // the frames' totals: lane f holds frame f's {records | events << 16} up to lane 31 and up to lane 63
     if (lane < nb) {
         const uint2 t = reinterpret_cast<const uint2 *>(lds_tot)[lane];
-        const uint32_t ta = t.x, tb = t.y - t.x;
+        const uint32_t ta = t.x, tb = t.y - t.x;  // {events | 4 x records << 16} of segment 2p and of segment 2p + 1
         uint32_t sl = slot0 + lane;
         sl = sl >= slots_u ? sl - slots_u : sl;
         // wtot = events | records << 16 of each segment
         gstore<uint2>(uniform_ptr(b->wtot_ring), (sl * num_waves_u + sgw) * 4u,
-                      make_uint2((ta >> 16) | (ta << 16), (tb >> 16) | (tb << 16)));
+                      make_uint2((ta & 0xffffu) | ((ta >> 18) << 16), (tb & 0xffffu) | ((tb >> 18) << 16)));
     }
     LrPx q[kLpUnits];
     uint32_t rmax = 0u;
