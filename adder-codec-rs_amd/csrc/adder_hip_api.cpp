@@ -1294,8 +1294,9 @@ static int get_graph(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipG
     // everything the captured launch sequence depends on
     // (running_enabled and the lazy-state switch decide the launches' lazy bits, lazy_state_bit)
     // (graph_slot: a frame slot of the per-frame ring has its own description, so its own graphs)
-    const uint64_t key = (uint64_t)num_frames | ((uint64_t)variant << 32) | ((uint64_t)launch_depth(c) << 44) |
-                         ((uint64_t)(c->running_enabled ? 1u : 0u) << 52) | ((uint64_t)c->graph_slot << 53);
+    // (bits: frames 0-23, variant 24-39, launch depth 40-47, running 48, frame slot 49-)
+    const uint64_t key = (uint64_t)(num_frames & 0xffffffu) | ((uint64_t)(variant & 0xffffu) << 24) | ((uint64_t)(launch_depth(c) & 0xffu) << 40) |
+                         ((uint64_t)(c->running_enabled ? 1u : 0u) << 48) | ((uint64_t)c->graph_slot << 49);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         if (c->graphs.size() >= 24) {  // keep the cache small (a ring of four slots holds a graph per slot and kernel choice)
@@ -1522,7 +1523,11 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     const bool cr = cb && c->cr_valid && !cr_off;  // ... then only the roots are stepped (adder_cr_kernel)
     // how long a run can be by now: frames since the reset in AbsoluteT (last_fired_t / T is an integer of that size), in DeltaT
     // the bound the kernels' own reports keep down (AdderHipCtx::run_bound)
-    const uint64_t run_frames = c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? c->frames_done : std::min<uint64_t>(c->run_bound, c->frames_done);
+    // (a batch that hands its records to the multi-GPU gather takes the bound every rank shares -- the frames since the reset:
+    // the kernels' reports follow each band's own content, a static band would leave the integer-state kernel where a busy one
+    // stays, and root expands ONE record kind per chunk)
+    const uint64_t run_frames = (c->p.time_mode == ADDER_TIME_ABSOLUTE_T || c->records_only)
+                                    ? c->frames_done : std::min<uint64_t>(c->run_bound, c->frames_done);
     // run records (adder_rr_kernel): the same regime with integer state while n * 255 and n * time_spanned stay exact in
     // binary32; AbsoluteT also wants last_fired_t on multiples of time_spanned (time_spanned == ref_time >= 255)
     const bool rr_off = env_flag("ADDER_HIP_NO_RR");
@@ -1703,6 +1708,8 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         b.timeline = c->d_timeline;
     }
     // (frame_offsets[0] and the record count are started by the first chunk's offsets kernel: nothing to clear here)
+    static const bool dbg_memset = env_flag("ADDER_HIP_DBG_DESC_MEMSET");  // (tests/test_gpu_stress.py: round 5's arrangement, on purpose)
+    if (dbg_memset && c->d_rec_total) HIPCHK(c, hipMemsetAsync(c->d_rec_total, 0, 4, stream));
     if (reinterpret_cast<uint8_t *>(c->d_ftab) == reinterpret_cast<uint8_t *>(c->d_batch) + kBatchDescBytes &&
         reinterpret_cast<uint8_t *>(c->h_ftab) == reinterpret_cast<uint8_t *>(c->h_batch) + kBatchDescBytes) {
         HIPCHK(c, hipMemcpyAsync(c->d_batch, c->h_batch, kBatchDescBytes + num_frames * sizeof(FrameTab),
@@ -2692,7 +2699,10 @@ static int frame_submit_impl(AdderHipCtx *c, const uint8_t *frame, size_t row_st
         ~SlotTag() { c->graph_slot = 0u; c->frame_only = false; }
     } slot_tag{c};
     c->graph_slot = 1u + (uint32_t)(c->f_submitted % c->f_slots);
-    c->frame_only = !ring_split_off && c->f_slots <= c->ring_chunks && c->chunk >= 2u;  // (a ring chunk of scratch per frame slot)
+    // (a ring chunk of scratch per frame slot -- its share of the frame totals must also hold the scan's tile sums, 2 words per
+    // tile: planes beyond 16 384 segments with a chunk shortened by the memory budget keep the one-stream form)
+    const uint32_t scan_tiles = (c->num_waves + kScanTileWaves - 1u) / kScanTileWaves;
+    c->frame_only = !ring_split_off && c->f_slots <= c->ring_chunks && c->chunk >= 2u && c->chunk >= 2u * scan_tiles;
     c->no_snapshot = true;  // frames behind this one are submitted before its outcome is known: no rollback
     fs.out = direct_out ? direct_out : fs.h_events;
     fs.out_cap = need;

@@ -168,6 +168,9 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
     // keeps changing) -- its frames also look for escaping records and park their full rho' (adder_pixel.hpp lp_park4)
     // The frame's records leave ONE FRAME LATER (pend_n of them, to pend_seg): the LDS run is read back at the top of the next
     // frame and stored behind its packed step, so no frame waits for its own LDS round trip.
+    uint32_t act_w = 0u;  // bit 7 of byte j: unit 4 lane + j lies inside the plane
+#pragma unroll
+    for (uint32_t j = 0; j < kLpUnits; ++j) act_w |= (FULL || u0 + j < n_units_u) ? (0x80u << (8u * j)) : 0u;
     uint32_t pend_n = 0u;
     uint8_t *pend_seg = seg;
     const uint32_t lane4 = lane * 4u;
@@ -181,6 +184,12 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
         const uint32_t base_w = s.prev;
         if (busy) m = lp_step(s, vin);
         else lp_quiet(s);
+        if (!FULL) {  // padding units (beyond the plane) are stepped freely, like every frame kernel steps them -- and leave nothing
+            m.h &= act_w;
+            m.a &= act_w;
+            m.b &= act_w;
+            m.c &= act_w;
+        }
 #if !defined(ADDER_DBG_LP_NOSTORE)
         if (pend_n != 0u) {
             if (lane < pend_n) asm volatile("global_store_dword %0, %1, %2" : : "v"(lane4), "v"(pend_w), "s"(pend_seg) : "memory");

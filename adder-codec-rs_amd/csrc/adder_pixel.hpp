@@ -1089,8 +1089,18 @@ ADDER_HD uint32_t cb_group_apply(CbPxT<L> &s, const QuietGroupStats &g, uint32_t
     return quiet_group_apply(s.S, s.dt0, s.bdt0, s.thr0, s.base, L::lane(s.popped), g, n, cth_min, T);
 }
 // (the lean step's quiet root is the same root: lean_step_quiet == cb_step_quiet on {integ, dt, bdt, thr})
+// The lean step also runs at fractional time steps (the bounded Collapse step does not: cb_possible).  The closed form
+// advances delta_t by n T in ONE rounding where the reference adds T n times (event_pixel_tree.rs:449-451): the same number
+// only while every partial sum is exact -- T and delta_t integers (the group's sums stay below 2^24, checked inside).
+// Otherwise the unit steps its frames (kQuietSlow).
 template <class L>
 ADDER_HD uint32_t lean_group_apply(LeanPxT<L> &p, const QuietGroupStats &g, uint32_t n, uint32_t cth_min, float T) {
+    if (!(T == (float)f32_as_u32(T) && p.dt == (float)f32_as_u32(p.dt))) {
+        const uint32_t dmx = g.mx > p.base ? g.mx - p.base : p.base - g.mx, dmn = g.mn > p.base ? g.mn - p.base : p.base - g.mn;
+        if ((dmx > dmn ? dmx : dmn) > cth_min) return kQuietNo;
+        if (!L::lane(p.popped) && g.mx != 0u) return kQuietNo;
+        return kQuietSlow;
+    }
     return quiet_group_apply(p.integ, p.dt, p.bdt, p.thr, p.base, L::lane(p.popped), g, n, cth_min, T);
 }
 

@@ -770,6 +770,45 @@ int sim_integrate_lp_block(Sim *s, const uint8_t *frames, uint32_t nb, float T, 
     return rc;
 }
 
+// The lean kernel's quiet-GROUP form against its own stepped form (lean_group_apply vs n x lean_step_quiet) on random quiet
+// roots at the time step T: returns the number of groups whose (integration, delta_t, best delta_t, threshold) differ in a
+// bit, *applied = groups the closed form took.  (adder_lean_kernel applies the group form at whatever T the batch has.)
+uint64_t sim_lean_group_check(float T, uint32_t groups, uint32_t seed, uint64_t *applied) {
+    uint64_t bad = 0, done = 0;
+    uint32_t x = seed * 2654435761u + 12345u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    for (uint32_t gi = 0; gi < groups; ++gi) {
+        const uint32_t base = rnd() % 256u, n = 1u + rnd() % kQuietGroup, cth = rnd() % 4u;
+        uint8_t v[kQuietGroup];
+        for (uint32_t i = 0; i < n; ++i) {
+            int d = (int)(rnd() % (2u * cth + 1u)) - (int)cth, q = (int)base + d;
+            v[i] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+        }
+        LeanPx p{};
+        p.base = base;
+        p.has0 = true;
+        p.popped = true;
+        const uint32_t frames = 1u + rnd() % 300u;  // a root that has accumulated `frames` frames of about base
+        p.integ = (float)(base * frames);
+        p.dt = 0.0f;
+        for (uint32_t i = 0; i < frames; ++i) p.dt = fadd(p.dt, T);
+        p.bdt = p.dt;
+        p.thr = bits_to_f32((f32_to_bits(p.integ > 1.0f ? p.integ : 1.0f) & 0x7f800000u) + 0x00800000u);
+        if (p.integ == 0.0f) p.thr = 0.0f;  // a black root
+        LeanPx a = p, b = p;
+        const QuietGroupStats g = quiet_group_stats(v, 1, n, quiet_group_need(p.integ, p.thr));
+        const uint32_t r = lean_group_apply<ScalarLanes>(a, g, n, cth, T);
+        if (r != kQuietDone) continue;
+        ++done;
+        for (uint32_t i = 0; i < n; ++i) lean_step_quiet<ScalarLanes>(b, v[i], T);
+        if (f32_to_bits(a.integ) != f32_to_bits(b.integ) || f32_to_bits(a.dt) != f32_to_bits(b.dt) ||
+            f32_to_bits(a.bdt) != f32_to_bits(b.bdt) || f32_to_bits(a.thr) != f32_to_bits(b.thr))
+            ++bad;
+    }
+    if (applied) *applied = done;
+    return bad;
+}
+
 // returns 0 ok, -4 capacity, -5 depth
 int sim_integrate(Sim *s, const uint8_t *frame, float time_spanned, SimEvent *out, size_t cap, size_t *n_out) {
     StepConsts sc;

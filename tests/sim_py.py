@@ -71,6 +71,8 @@ def lib():
     L.sim_integrate_cb_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_lr_block.restype = i32
     L.sim_integrate_lr_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
+    L.sim_lean_group_check.restype = C.c_uint64
+    L.sim_lean_group_check.argtypes = [f32, u32, u32, C.POINTER(C.c_uint64)]
     L.sim_integrate_lp_block.restype = i32
     L.sim_integrate_lp_block.argtypes = [vp, vp, u32, f32, vp, sz, C.POINTER(sz)]
     L.sim_integrate_rr_block.restype = i32
@@ -83,6 +85,13 @@ def lib():
     L.sim_framer_run.argtypes = [vp, sz, u32, u32, u32, u32, u32, u32, u32, vp, sz]
     _lib = L
     return L
+
+
+def lean_group_check(T, groups=20000, seed=1):
+    """(groups whose closed form differs from the stepped form, groups the closed form took) at time step T."""
+    applied = C.c_uint64(0)
+    bad = lib().sim_lean_group_check(T, groups, seed, C.byref(applied))
+    return int(bad), int(applied.value)
 
 
 def fast9_plane(img):

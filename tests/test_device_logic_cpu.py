@@ -755,6 +755,20 @@ def test_lr_every_intensity_and_run_length_rgb_and_tick_rates():
     assert sv.integrate_lr_block(clip[:2], 255.0)[0] == -7  # construction-default pixels: c_thresh 10
 
 
+def test_lean_quiet_groups_only_take_the_closed_form_at_integer_time_steps():
+    """adder_lean_kernel also runs at fractional time_spanned, where the closed form's ONE rounding of delta_t + n T is not the
+    reference's n rounded additions (event_pixel_tree.rs:449-451): the group form must step there (and still apply, bit for bit,
+    at integer steps)."""
+    from sim_py import lean_group_check
+    for T in (255.0, 1000.0, 20.0):
+        bad, applied = lean_group_check(T, 20000, seed=int(T))
+        assert bad == 0 and applied > 5000, (T, bad, applied)
+    for T in (300.7, 1000.3, 33333.332, 0.5):
+        bad, applied = lean_group_check(T, 20000, seed=7)
+        assert bad == 0, (T, bad, applied)   # whatever it applies is exact ...
+        assert applied == 0, (T, applied)     # ... and at a fractional step it applies nothing: the units step their frames
+
+
 # ---- lean runs, packed (lp_step: four units per word, adder_lp_kernel + the expansion's format 7) ----
 def test_lp_packed_step_matches_the_oracle_and_interleaves_with_the_other_lean_steps():
     """The headline regime through the packed step: launches of every length on every content (planes whose unit count is

@@ -224,6 +224,66 @@ def test_streamed_records_gather_equals_the_whole_plane_stream(time_mode, W, H, 
     assert len(ora) == band_counts[r] and np.array_equal(got, ora)
 
 
+def test_streamed_records_gather_past_the_run_bound_with_a_static_band():
+    """The integer-state kernel is left where a run could reach 2^24 / time_spanned frames.  In the records gather every rank
+    must leave it in the SAME chunk (root expands one record kind per chunk) -- whatever its band shows: here band 0 is static
+    (its runs are the stream), band 1 keeps changing, the tick is 60 000 per frame so that the bound is 279 frames, and the
+    clip runs 400: the merged stream equals the whole-plane context's and the oracle's across the switch."""
+    import torch
+    A = _hip()
+    from adder_amd import sharding
+    from adder_amd.gather import HipGather, LocalGroup
+    W, H, T, chunk, world, tick = 96, 16, 400, 64, 2, 60000
+    clip = O.synth_clip(O.CONTENT_NOISE, W, H, 1, T)
+    clip[:, : H // 2] = clip[0, : H // 2]          # band 0: static
+    kw = dict(time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, ref_time=tick, delta_t_max=tick, c_thresh_start=0, c_counter_start=0)
+    ov = O.Video(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=tick, delta_t_max=tick)
+    ov.ensure_capacity(8)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    want = [ov.integrate_matrix(f, time_spanned=float(tick)) for f in clip]
+    want_ev = np.concatenate(want)
+    n_want = len(want_ev)
+    bands = sharding.row_bands(H, world)
+    grp = LocalGroup(world)
+    d_merged = torch.full((n_want + 16, 3), -1, dtype=torch.int32, device="cuda")
+    d_moff = torch.full((T + 1,), -7, dtype=torch.int64, device="cuda")
+    kernels = [None] * world
+
+    def rank_fn(r):
+        y0, y1 = bands[r]
+        hv = A.HipVideo(W, H, 1, row_begin=y0, row_end=y1, **kw)
+        hv.set_crf_parameters(0, 10)
+        g = HipGather(hv, None, r, world, local=grp)
+        st, side = torch.cuda.Stream(), torch.cuda.Stream()
+        d_fr = torch.from_numpy(np.ascontiguousarray(clip[:, y0:y1]).reshape(T, -1)).cuda()
+        d_boff = torch.zeros(chunk + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        g.records_begin(0, d_merged if r == 0 else None, 0, d_moff if r == 0 else None, stream=side.cuda_stream)
+        ks = []
+        for f0 in range(0, T, chunk):
+            nf = min(chunk, T - f0)
+            rec = hv.integrate_records_device(d_fr[f0:f0 + nf], d_boff, time_spanned=float(tick), stream=st.cuda_stream)
+            n_k = hv.finish()
+            ks.append(hv.last_batch_kernel())
+            g.records_push(rec, hv.last_batch_records(), n_k)
+        n_merged, _ = g.records_end()
+        if r == 0:
+            assert n_merged == n_want, (n_merged, n_want)
+        kernels[r] = ks
+        g.close()
+        hv.close()
+
+    _run_ranks(world, rank_fn)
+    grp.close()
+    assert kernels[0] == kernels[1], kernels                       # the ranks change kernels together ...
+    assert kernels[0][0] == A.KERNEL_LEAN_RUNS and kernels[0][-1] == A.KERNEL_LEAN, kernels   # ... and they do change
+    got = np.frombuffer(d_merged[:n_want].cpu().numpy().tobytes(), dtype=O.EVENT_DTYPE)
+    assert np.array_equal(got, want_ev)
+    offs = d_moff.cpu().numpy()
+    assert [int(offs[i + 1] - offs[i]) for i in range(T)] == [len(w) for w in want]
+
+
 def test_streamed_records_gather_reports_a_merged_buffer_that_is_too_small_on_root_only():
     """The expansion drops what does not fit, end() says so on root; the peers are not left in a send, and the objects
     stay usable for the next clip."""

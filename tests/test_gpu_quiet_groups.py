@@ -107,6 +107,35 @@ def test_lean_kernel_quiet_groups_break_at_every_position_with_ramp_and_firings(
     hv.close()
 
 
+@pytest.mark.parametrize("T", [300.7, 1000.3, 255.0])
+def test_lean_kernel_quiet_groups_at_fractional_time_steps(T):
+    """adder_lean_kernel accepts a fractional time_spanned (only the integer-state kernels refuse it).  The group form's closed
+    form rounds delta_t + n T once where the reference adds T n times (event_pixel_tree.rs:449-451): at a fractional step the
+    groups must be stepped (lean_group_apply) -- static rows with jitter inside the band, the ramp, firings, DeltaT: every
+    best delta_t and truncated t against the oracle."""
+    frames, H, W = 400, 12, 128
+    rng = np.random.default_rng(131)
+    clip, _ = clips.quiet_group_clip(frames, H, W, rng, jitter=1)
+    A = _hipmod()
+    for crf in (3, 9):
+        dtm = 255
+        ov = O.Video(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+        hv = A.HipVideo(W, H, 1, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=dtm)
+        ov.ensure_capacity(24)
+        for v in (ov, hv):
+            v.set_crf_parameters(CRFS[crf][1], CRFS[crf][2])
+            v.reset_c_thresh(CRFS[crf][0])
+        k = 0
+        for nb in (64, 60, 37, 16, 100, 64, 59):
+            want = [ov.integrate_matrix(clip[k + i], time_spanned=T) for i in range(nb)]
+            got, offs = hv.integrate_batch(clip[k:k + nb], time_spanned=T)
+            assert hv.last_batch_kernel() == A.KERNEL_LEAN
+            assert [int(offs[i + 1] - offs[i]) for i in range(nb)] == [len(w) for w in want], (T, crf, k)
+            assert np.array_equal(got, np.concatenate(want)), (T, crf, k)
+            k += nb
+        hv.close()
+
+
 def test_quiet_groups_full_size_static_and_default_quality_1080p():
     """1080p: static content through the lean-runs kernel and the reference's default mode at its default quality through the
     bounded Collapse kernel, 150 frames across chunk boundaries (the pop at frame 30, then quiet groups), against the oracle."""
