@@ -116,6 +116,7 @@ struct AdderHipCtx {
     // since the reset" sent every stream to the float kernels after 65 793 frames (18 minutes of video)
     uint64_t run_bound = 0, pending_end_frames = 0;
     bool pending_reports = false;
+    hipEvent_t null_join = nullptr;  // stream == NULL: the batch is ordered behind the legacy default stream (join_null_stream)
     uint32_t *d_run_max = nullptr;
     uint32_t *wtot_ring = nullptr;   // [slots][num_waves]
     uint32_t *wpref_ring = nullptr;  // [slots][num_waves]
@@ -393,6 +394,7 @@ static void free_ctx(AdderHipCtx *c) {
     if (c->split_b) (void)hipStreamDestroy(c->split_b);
     for (hipEvent_t e : c->split_el)
         if (e) (void)hipEventDestroy(e);
+    if (c->null_join) (void)hipEventDestroy(c->null_join);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1800,6 +1802,20 @@ extern "C" int adder_hip_integrate_wire_device(AdderHipCtx *c, const uint8_t *d_
     return rc;
 }
 
+// stream == NULL means "the default stream" to a caller, and the context's own stream is a non-blocking one: whatever the
+// caller queued on the legacy default stream -- a torch.zeros() of the offsets, the clip's generator -- is NOT ordered against
+// it.  (Round 5's "a 3-frame batch left its offsets untouched" was this: the test's zero-fill of the offsets tensor, on the
+// null stream, landing AFTER the short batch had written them; tests/test_gpu_stress.py holds the arrangement.)  So a batch
+// submitted with stream == NULL first waits for the default stream's work queued so far.
+static int join_null_stream(AdderHipCtx *c) {
+    static const bool off = env_flag("ADDER_HIP_DBG_NO_NULL_JOIN");  // (tests/test_gpu_stress.py shows the race with it)
+    if (off) return ADDER_OK;
+    if (!c->null_join) HIPCHK(c, hipEventCreateWithFlags(&c->null_join, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->null_join, nullptr));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->null_join, 0));
+    return ADDER_OK;
+}
+
 extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_frames,
                                           float time_spanned, AdderEvent *d_out, size_t out_cap,
                                           uint64_t *d_frame_offsets, void *stream) {
@@ -1813,6 +1829,7 @@ extern "C" int adder_hip_integrate_device(AdderHipCtx *c, const uint8_t *d_frame
     { int rc_ = band_precheck(c, num_frames); if (rc_ != ADDER_OK) return rc_; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!stream) { int rc_ = join_null_stream(c); if (rc_ != ADDER_OK) return rc_; }
     if (num_frames == 0) {
         HIPCHK(c, hipMemsetAsync(d_frame_offsets, 0, sizeof(uint64_t), s));
     } else {
@@ -1851,6 +1868,7 @@ extern "C" int adder_hip_integrate_records_device(AdderHipCtx *c, const uint8_t 
                     "time_spanned, no feature mode, no generic batch before): gather events instead");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!stream) { int rc_ = join_null_stream(c); if (rc_ != ADDER_OK) return rc_; }
     // the scratch must exist before the chunk size is known
     {
         int rc_ = alloc_scratch(c, c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? AdderHipCtx::kScratchLean : AdderHipCtx::kScratchLean8);

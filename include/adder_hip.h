@@ -250,8 +250,10 @@ int adder_hip_integrate_batch(AdderHipCtx *ctx, const uint8_t *frames_hwc, uint3
 /* --- T frames resident in HBM (clip and event buffer are DEVICE pointers) -----------
  * d_frames: packed [T][rows][width][channels] u8.  d_out: device AdderEvent[out_cap].
  * d_frame_offsets: device uint64[T+1] (prefix offsets into d_out; [0] = 0).
- * stream: hipStream_t (NULL = the context's own stream).  Asynchronous: call
- * adder_hip_finish() (or synchronise the stream and call it) to collect status. */
+ * stream: hipStream_t.  NULL = the context's own (non-blocking) stream, ordered BEHIND whatever the caller has queued on the
+ * legacy default stream so far (a NULL stream means "the default stream" to the caller: buffers it prepared there -- zeroed,
+ * generated, copied -- are seen as prepared).  Asynchronous: call adder_hip_finish() (or synchronise the stream and call
+ * it) to collect status; work queued on another stream AFTER the call is not ordered against the batch. */
 int adder_hip_integrate_device(AdderHipCtx *ctx, const uint8_t *d_frames, uint32_t num_frames,
                                float time_spanned, AdderEvent *d_out, size_t out_cap,
                                uint64_t *d_frame_offsets, void *stream);

@@ -1878,6 +1878,78 @@ def test_full_size_1080p_wire_records_of_the_headline_entry_point(channels, fram
         hv.close()
 
 
+def test_config_2_exactly_as_benchmarked_300_frames_wire_sha256():
+    """BASELINE config 2 at its STATED length, through the entry point bench.py times: 1920x1080 gray, 300 frames of the scene
+    clip in ONE adder_hip_integrate_wire_device batch from a fresh transcoder (Collapse, DeltaT, delta_t_max 255, crf-0
+    numbers).  Every frame's count and the sha256 of the whole stream's 9-byte records == the oracle's raw sink over the
+    oracle's 300 frames (video.rs:651-778, raw/stream.rs:101-120) -- frames 65-300 included, which bench.py's own check only
+    compares GPU against GPU."""
+    import torch
+    A = _hip()
+    W, H, T = 1920, 1080, 300
+    st = torch.cuda.current_stream().cuda_stream
+    ov, hv = _wire_pair(W, H, 1, O.DELTA_T)
+    d_frames = torch.empty((T, W * H), dtype=torch.uint8, device="cuda")
+    A.synth_clip_device(d_frames, A.CONTENT_SCENE, W, H, 1, num_frames=T, stream=st)   # (the clip bench.py times)
+    torch.cuda.synchronize()   # (the generator runs on the stream given, the batch on the context's own when that is the null stream)
+    d_wire = torch.empty(int(W * H * T * 0.4) * 9, dtype=torch.uint8, device="cuda")
+    d_offs = torch.zeros(T + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+    n = hv.finish()
+    assert hv.last_batch_kernel() == A.KERNEL_LEAN_RUNS_PACKED
+    offs = d_offs.cpu().numpy()
+    h_want, h_got, total = hashlib.sha256(), hashlib.sha256(), 0
+    for k in range(0, T, 20):                    # (20 frames of events at a time: the whole stream is 1.7 GB)
+        clip = O.synth_clip(O.CONTENT_SCENE, W, H, 1, 20, k0=k)
+        assert k != 0 or np.array_equal(clip[0].reshape(-1), d_frames[0].cpu().numpy())
+        want = [ov.integrate_matrix(f) for f in clip]
+        assert [int(offs[k + i + 1] - offs[k + i]) for i in range(20)] == [len(w) for w in want], k
+        h_want.update(O.raw_events(np.concatenate(want), 1))
+        h_got.update(d_wire[int(offs[k]) * 9:int(offs[k + 20]) * 9].cpu().numpy().tobytes())
+        total += sum(len(w) for w in want)
+    assert n == total and int(offs[T]) == total
+    assert h_got.hexdigest() == h_want.hexdigest()
+    hv.close()
+
+
+def test_config_4_one_band_at_its_stated_1200_frames():
+    """One of BASELINE config 4's eight row bands -- rows 270..539 of the 3840x2160 plane -- over the config's 1 200 frames
+    (Collapse, DeltaT, delta_t_max 255, crf 0), in the four 300-frame batches a rank of the bench integrates, wire records:
+    counts and bytes == the oracle's band (row_begin = 270: the events carry plane coordinates)."""
+    import torch
+    A = _hip()
+    W, H, T, y0, y1 = 3840, 2160, 1200, 270, 540
+    st = torch.cuda.current_stream().cuda_stream
+    ov = O.Video(W, y1 - y0, 1, row_begin=y0, time_mode=O.DELTA_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+    ov.ensure_capacity(8)
+    ov.set_crf_parameters(0, 10)
+    ov.reset_c_thresh(0)
+    hv = A.HipVideo(W, H, 1, row_begin=y0, row_end=y1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, ref_time=255,
+                    delta_t_max=255, c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    units = W * (y1 - y0)
+    nb = 300
+    d_frames = torch.empty((nb, units), dtype=torch.uint8, device="cuda")
+    d_wire = torch.empty(int(units * nb * 0.45) * 9, dtype=torch.uint8, device="cuda")
+    d_offs = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+    for k0 in range(0, T, nb):
+        A.synth_clip_device(d_frames, A.CONTENT_SCENE, W, H, 1, row_begin=y0, rows=y1 - y0, frame_begin=k0, num_frames=nb, stream=st)
+        torch.cuda.synchronize()
+        hv.integrate_wire_device(d_frames, d_wire, d_offs, stream=st)
+        n = hv.finish()
+        offs = d_offs.cpu().numpy()
+        h_want, h_got, total = hashlib.sha256(), hashlib.sha256(), 0
+        for k in range(0, nb, 30):
+            clip = O.synth_clip(O.CONTENT_SCENE, W, H, 1, 30, y0=y0, rows=y1 - y0, k0=k0 + k)
+            want = [ov.integrate_matrix(f) for f in clip]
+            assert [int(offs[k + i + 1] - offs[k + i]) for i in range(30)] == [len(w) for w in want], (k0, k)
+            h_want.update(O.raw_events(np.concatenate(want), 1))
+            h_got.update(d_wire[int(offs[k]) * 9:int(offs[k + 30]) * 9].cpu().numpy().tobytes())
+            total += sum(len(w) for w in want)
+        assert n == total and h_got.hexdigest() == h_want.hexdigest(), k0
+    hv.close()
+
+
 def test_config_1_adder_file_through_the_wire_path():
     """BASELINE config 1 (640x480 gray, 30 frames, raw .adder out) as a whole FILE: header + the expansion's wire records +
     EOF == the oracle's header, raw sink and EOF over the oracle's events (encoder.rs:170-229, raw/stream.rs:79-120)."""

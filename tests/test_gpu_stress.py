@@ -89,3 +89,65 @@ def test_twenty_thousand_short_batches_two_contexts_two_output_forms(batches):
     assert full_checks > batches // 200
     for c in ctx:
         c["hv"].close()
+
+
+def test_a_null_stream_batch_is_ordered_behind_the_default_stream():
+    """Round 5's flake, on purpose: the offsets tensor is zero-filled on the legacy default stream BEHIND a long kernel, then a
+    3-frame batch is submitted with stream = NULL.  The context's own stream is non-blocking -- without the join of
+    adder_hip_integrate_device the short batch would write its offsets first and the zero-fill would land on top of them
+    ("a 3-frame batch left its offsets untouched").  Now the batch waits for the default stream's work queued so far."""
+    import torch
+    import adder_amd as A
+    W, H, nb = 96, 24, 3
+    clip = clips.make_clip("runs", nb, H, W, 1, seed=8)
+    cnt, _ = _oracle_counts_and_events(clip, O.DELTA_T, 255)
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=255,
+                    c_thresh_start=0, c_counter_start=0)
+    hv.set_crf_parameters(0, 10)
+    d_frames = torch.from_numpy(clip.reshape(nb, -1)).cuda()
+    d_ev = torch.zeros((4 * W * H * nb, 3), dtype=torch.int32, device="cuda")
+    big = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(20):
+        hv.reset()
+        for _ in range(6):
+            big = (big @ big).clamp_(-1.0, 1.0)          # tens of milliseconds of work on the default stream ...
+        d_off = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")   # ... and the zero-fill queued behind it
+        hv.integrate_device(d_frames, d_ev, d_off, stream=None)
+        n = hv.finish()
+        offs = d_off.cpu().numpy()
+        assert n == int(cnt.sum()) and np.array_equal(np.diff(offs), cnt), (rep, n, offs, cnt)
+    hv.close()
+
+
+def test_the_round_5_flake_is_that_race():
+    """The same arrangement with the join switched off (ADDER_HIP_DBG_NO_NULL_JOIN=1, a child process): the zero-fill lands on top
+    of the batch's offsets -- the symptom round 5 recorded.  (Shown, not relied upon: a race may also not happen.)"""
+    import subprocess
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import adder_amd as A
+W, H, nb = 96, 24, 3
+rng = np.random.default_rng(1)
+clip = rng.integers(1, 255, (nb, H * W), dtype=np.uint8)
+hv = A.HipVideo(W, H, 1, time_mode=A.TIME_DELTA_T, multi_mode=A.MULTI_COLLAPSE, ref_time=255, delta_t_max=255, c_thresh_start=0, c_counter_start=0)
+hv.set_crf_parameters(0, 10)
+d_frames = torch.from_numpy(clip).cuda(); d_ev = torch.zeros((4 * W * H * nb, 3), dtype=torch.int32, device="cuda")
+big = torch.randn(4096, 4096, device="cuda"); torch.cuda.synchronize()
+lost = 0
+for rep in range(10):
+    hv.reset()
+    for _ in range(6): big = (big @ big).clamp_(-1.0, 1.0)
+    d_off = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+    hv.integrate_device(d_frames, d_ev, d_off, stream=None)
+    n = hv.finish()
+    if n and int(d_off.cpu()[-1]) == 0: lost += 1
+print("LOST", lost)
+""" % (ROOT, os.path.join(ROOT, "adder-codec-rs_amd"))
+    env = dict(os.environ, ADDER_HIP_DBG_NO_NULL_JOIN="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lost = int(out.stdout.strip().split("LOST")[-1])
+    print("batches whose offsets the late zero-fill overwrote, without the join:", lost, "of 10")
+    assert lost >= 1, "the race did not show in 10 tries (it is a race) -- the join is the fix either way"
