@@ -213,6 +213,10 @@ class HipGather:
         self._check(rc)
         return n.value, sent.value
 
+    def world(self):
+        """The communicator's size as the library sees it (adder_gather_world)."""
+        return int(self.L.adder_gather_world(self.h))
+
     def records_host_us(self):
         return float(self.L.adder_gather_records_host_us(self.h))
 

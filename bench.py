@@ -157,7 +157,10 @@ def main():
     multi = A.MULTI_COLLAPSE if args.multi_mode == "collapse" else A.MULTI_NORMAL
     tmode = A.TIME_DELTA_T if args.time_mode == "delta_t" else A.TIME_ABSOLUTE_T
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # the step's batches run on a stream of their own (a NULL stream would mean "behind the default stream": the library then
+    # joins the legacy default stream per batch, include/adder_hip.h)
+    bench_stream = torch.cuda.Stream(device=dev)
+    stream = bench_stream.cuda_stream
     d_frames = torch.empty((T, units), dtype=torch.uint8, device=dev)
     A.synth_clip_device(d_frames, content, Wd, Ht, Cn, row_begin=y0, rows=rows, frame_begin=0,
                         num_frames=T, stream=stream)
@@ -189,19 +192,40 @@ def main():
         if rank == 0 and gather_mode != "host":
             d_merged = torch.empty((cap * world, 3), dtype=torch.int32, device=dev)
             d_merged_offs = torch.zeros(T + 1, dtype=torch.int64, device=dev)
-        if gather_mode == "host":
-            # the .adder image every rank stores into: /dev/shm/<name>, made by rank 0, mapped + registered by all
-            header = A.raw_header(3, Wd, Ht, Cn, REF_TIME * 30, REF_TIME, args.delta_t_max, 0, tmode, 0)
+
+        def open_host_image():
+            # the .adder image every rank stores into: /dev/shm/<name>, made by rank 0, mapped + registered by all.  Every rank
+            # takes every collective below whatever happens to it, and the ranks AGREE on the outcome before anyone uses the image
+            hdr = A.raw_header(3, Wd, Ht, Cn, REF_TIME * 30, REF_TIME, args.delta_t_max, 0, tmode, 0)
             rec_b = 9 if Cn == 1 else 11
-            img_bytes = len(header) + int(Wd * Ht * Cn * T * (1.25 if args.content == "noise" else 0.45)) * rec_b + 4096
-            name = [f"/adder_bench_{os.getpid()}" if rank == 0 else None]
+            img_bytes = len(hdr) + int(Wd * Ht * Cn * T * (1.25 if args.content == "noise" else 0.45)) * rec_b + 4096
+            name = [f"/adder_bench_{os.getpid()}_{len(opened_images)}" if rank == 0 else None]
             dist.broadcast_object_list(name, src=0)
-            if rank == 0:
-                image = HostImage(name[0], img_bytes, create=True)
-                image.host_array()[:len(header)] = __import__("numpy").frombuffer(header, dtype="uint8")
+            img, err = None, None
+            try:
+                if rank == 0:
+                    img = HostImage(name[0], img_bytes, create=True)
+                    img.host_array()[:len(hdr)] = __import__("numpy").frombuffer(hdr, dtype="uint8")
+            except Exception as exc:
+                err = exc
             dist.barrier()
-            if rank != 0:
-                image = HostImage(name[0], img_bytes, create=False)
+            try:
+                if rank != 0 and err is None:
+                    img = HostImage(name[0], img_bytes, create=False)
+            except Exception as exc:
+                err = exc
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int64, device=torch.device("cpu") if share else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if img is not None:
+                    img.close(unlink=(rank == 0))
+                raise RuntimeError(f"the shared .adder image could not be opened on every rank: {err!r}")
+            opened_images.append(name[0])
+            return img, hdr
+
+        opened_images = []
+        if gather_mode == "host":
+            image, header = open_host_image()
 
     # N > 1: the band is integrated one chunk of frames at a time, and every finished chunk is exchanged and merged on a
     # SIDE stream while the next chunk integrates (sharding.ChunkPipelinedGather / adder_gather_events_at): the gather
@@ -260,7 +284,7 @@ def main():
                 offs_k = d_chunk_offs[k, :nf + 1]
                 hv.integrate_device(d_frames[f0:f0 + nf], d_events[pos:], offs_k, stream=stream)
                 n_k = hv.finish()
-                side.wait_stream(torch.cuda.current_stream(dev))
+                side.wait_stream(bench_stream)
                 hg.host_sink_chunk(d_events[pos:], offs_k, nf, stream=side.cuda_stream)  # PCIe stores beside the next chunk
                 pos += n_k
             return pos, hg.host_sink_close(stream=side.cuda_stream)
@@ -291,7 +315,7 @@ def main():
                 if mode == "torch":
                     pg.push(d_events[pos:pos + n_k], offs_k)  # side stream: overlaps the next chunk's integration
                 else:
-                    side.wait_stream(torch.cuda.current_stream(dev))
+                    side.wait_stream(bench_stream)
                     d_offsets[f0:f0 + nf + 1] = offs_k + pos  # (the rank's own whole-clip offsets, for the record)
                     merged_pos += hg.gather_events_at(d_events[pos:], offs_k, 0, nf, 0, d_merged, merged_pos,
                                                       None if d_merged_offs is None else d_merged_offs[f0:],
@@ -409,8 +433,36 @@ def main():
         if gather_mode != "layout":  # the cheaper exchange, as an extra key
             layout_elapsed, _ = timed("layout", layout_steps, 1)
 
+    # ---- N > 1: the other two forms of the exchange as first-class legs of their own (each timed like the headline) ----
+    # `value` times ONE form (config.sharding says which); the first scaling curve should show all three side by side:
+    # the sink per rank and the layout-only exchange are the forms whose cost does not funnel through rank 0.
+    scale_legs = {}
+    if world > 1 and layout_elapsed is not None:
+        scale_legs["layout_only"] = {"ms_per_step": round(layout_elapsed / layout_steps * 1e3, 3),
+                                     "value": round(Wd * Ht * T / (layout_elapsed / layout_steps) / 1e6, 1), "unit": "Mpixels/s",
+                                     "bytes_sent_per_rank_per_step": 8 * (T + 1),
+                                     "what": "every rank keeps its band's stream in its own HBM; only the per-frame counts are all-gathered"}
+    if world > 1 and hg is not None and gather_mode in ("records", "cabi") and not share and os.environ.get("ADDER_BENCH_SCALE_LEGS", "1") == "1":
+        try:
+            leg_steps = max(2, args.steps // 2)
+            image, header = open_host_image()
+            if side is None:
+                side = torch.cuda.Stream(device=dev)
+            if d_chunk_offs is None or d_chunk_offs.shape[0] < (T + gchunk - 1) // gchunk:
+                d_chunk_offs = torch.zeros((T + gchunk - 1) // gchunk, gchunk + 1, dtype=torch.int64, device=dev)
+            sink_elapsed, (sink_n, sink_total) = timed("host", leg_steps, 1)
+            rec_b = 9 if Cn == 1 else 11
+            scale_legs["sink_per_rank"] = {"ms_per_step": round(sink_elapsed / leg_steps * 1e3, 3),
+                                           "value": round(Wd * Ht * T / (sink_elapsed / leg_steps) / 1e6, 1), "unit": "Mpixels/s",
+                                           "bytes_stored_by_this_rank_per_step": int(sink_n) * rec_b,
+                                           "what": "every rank serialises its band and stores the bytes at their final place of the one "
+                                                   ".adder image in shared memory over its own PCIe link (adder_gather_host_sink_*)"}
+        except Exception as exc:  # (never at the price of the headline line)
+            scale_legs["sink_per_rank"] = {"error": repr(exc)[:300]}
+
     # ---- roofline: one extra step with HIP event pairs around the launches ----
-    k1_us = post_us = k1_one_us = k1_one_pair_us = 0.0
+    k1_us = post_us = k1_one_us = k1_one_pair_us = post_one_us = 0.0
+    post_one_chunks = 1
     k1_frames = 1.0
     post_chunks = 1
     chunk_frames = hv.chunk_frames()
@@ -432,6 +484,8 @@ def main():
         hv.set_launch_timing(2)
         step("none")
         k1_one_us = hv.last_launch_avg_us()
+        post_one_us = hv.last_post_avg_us()          # scan + offsets + expansion of the same step, per chunk of its launches
+        post_one_chunks = hv.last_post_chunks()
         records1 = hv.last_batch_records()
         hv.set_frames_per_launch(int(os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH", "0")) or default_depth)
         hv.set_launch_timing(False)
@@ -474,15 +528,23 @@ def main():
     alg_b = 1 + 2 * S / max(k1_frames, 1.0) + 12 * e0
     achieved = alg_b * units * chunk_frames / (chunk_us * 1e-6) / 1e9 if chunk_us > 0 else 0.0
     # the frame kernel's own traffic (what it really moves): input + state + parked records
-    rec_bytes = REC_BYTES if abs_t or not lean else 8
+    rec_bytes_one = REC_BYTES if abs_t or not lean else 8      # the one-frame kernels' records
+    # blocked launches at crf 0 in DeltaT run adder_lp_kernel: 4-byte records (adder_pixel.hpp lp_park4)
+    rec_bytes = 4 if (lean and not abs_t and crf == [0, 0, 10]) else rec_bytes_one
     k1_b = 1 + 2 * S / max(k1_frames, 1.0) + rec_bytes * r0
     k1_gbs = k1_b * units * k1_frames / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
     # the rest of the chunk: parked records in, 12-byte events out
     post_b = rec_bytes * r0 + 12 * e0
     post_gbs = post_b * units * chunk_frames / (post_us_full * 1e-6) / 1e9 if post_us > 0 else 0.0
     r1 = records1 / float(units * T)
-    one_b = 1 + 2 * S + rec_bytes * r1
+    one_b = 1 + 2 * S + rec_bytes_one * r1
     one_gbs = one_b * units / (k1_one_us * 1e-6) / 1e9 if k1_one_us > 0 else 0.0
+    # ... and the WHOLE one-frame-per-launch pipeline (the literal `consume` contract of north_star): a chunk = chunk_frames
+    # launches of the frame kernel + scan + offsets + expansion, priced with SURVEY's bytes at T = 1 (1 + 2 S + 12 e)
+    one_post_full = post_one_us * (chunk_frames / max(T / max(post_one_chunks, 1), 1.0))
+    one_chunk_us = k1_one_us * chunk_frames + one_post_full
+    one_alg_b = 1 + 2 * S + 12 * e0
+    one_pipe_gbs = one_alg_b * units * chunk_frames / (one_chunk_us * 1e-6) / 1e9 if one_chunk_us > 0 else 0.0
 
     # HBM bytes really moved by the chunk's kernels: PMC counters cannot be read inside this process (rocprofv3 collects
     # them in separate passes), so the figure comes from the committed collection of the SAME command
@@ -495,16 +557,15 @@ def main():
     try:
         default_workload = (Wd, Ht, Cn, T, args.delta_t_max, args.content, args.multi_mode, args.time_mode) == \
             (W, H, C, FRAMES, DTM, "scene", "collapse", "delta_t") and crf == [0, 0, 10]
-        cands = [("r05_traffic_default.json" if wire_out else "r05_traffic_events_output.json"),
-                 ("r04_traffic_default.json" if wire_out else "r04_traffic_events_output.json")]
+        cands = [("r06_traffic_default.json" if wire_out else "r06_traffic_events_output.json")]
         tname = next((n for n in cands if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         if default_workload and world == 1 and tname:
             tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
             tk = tj["kernels"]
             fpl = float(tj.get("frames_per_launch", 160.0 / 3.0))  # (round 4's collection carries no such key)
             per_launch = {k: v["hbm_bytes_per_launch"] for k, v in tk.items()}
-            lean_b = sum(v for k, v in per_launch.items() if "lean_kernel" in k or "lr_kernel" in k)
-            exp_b = sum(v for k, v in per_launch.items() if "expand_kernel" in k)
+            lean_b = sum(v for k, v in per_launch.items() if "lean_kernel" in k or "lr_kernel" in k or "lp_kernel" in k)
+            exp_b = sum(v for k, v in per_launch.items() if "expand_kernel" in k or "lpx_kernel" in k)
             scan_b = sum(v for k, v in per_launch.items() if "scan_kernel" in k or "offsets_kernel" in k)
             measured = lean_b + exp_b + scan_b  # bytes of one measured launch set (fpl frames)
             traffic = int(measured * chunk_frames / fpl)
@@ -550,6 +611,8 @@ def main():
                          f" ({gather_mode}) inside the timed region, chunk by chunk ({gchunk} frames) on side "
                          f"streams while the next chunk integrates"),
             "world_size_seen": world,
+            "world_size_seen_by_rccl": (hg.world() if (hg is not None and hasattr(hg, "world")) else None),
+            "value_times": ("one GPU, no exchange" if world == 1 else gather_mode),
             "backend": "none" if world == 1 else ("gloo (shared-device debug)" if share else "nccl (RCCL)"),
         },
         "output_check": output_check,
@@ -563,8 +626,9 @@ def main():
                                 "queues at instantiation; measured 1.86 vs 2.08 ms per step between instances)"},
         "roofline": {
             "bound": "hbm",
-            "kernel": ("one chunk of frames: adder_lr_kernel (the lean step over constant runs: crf 0, DeltaT; adder_lean_kernel "
-                       "otherwise) + adder_scan_kernel + adder_offsets_kernel + adder_expand_kernel") if lean else
+            "kernel": ("one chunk of frames: adder_lp_kernel (the lean-runs step in packed bytes: crf 0, DeltaT; adder_lr_kernel in "
+                       "AbsoluteT, adder_lean_kernel otherwise) + adder_scan_kernel + adder_offsets_kernel + adder_lpx_kernel "
+                       "(adder_expand_kernel for the other record formats)") if lean else
                       "one chunk of frames: adder_frame_kernel + adder_scan_kernel + adder_offsets_kernel + "
                       "adder_expand_kernel",
             "achieved": round(achieved, 1),
@@ -599,10 +663,16 @@ def main():
         "roofline_one_frame_per_launch": {
             "bound": "hbm",
             "kernel": "adder_lean1w_kernel" if lean else "adder_frame_kernel",
+            "pipeline": {"what": "the whole one-frame-per-launch chunk: %d frame-kernel launches + scan + offsets + expansion, "
+                                 "SURVEY 8(d)'s bytes at T = 1 (1 + 2 x state + 12 e per unit-frame)" % chunk_frames,
+                         "chunk_us": round(one_chunk_us, 3), "frame_kernels_us": round(k1_one_us * chunk_frames, 3),
+                         "scan_offsets_expand_us": round(one_post_full, 3), "bytes_per_unit_frame": round(one_alg_b, 3),
+                         "achieved": round(one_pipe_gbs, 1), "frac": round(one_pipe_gbs / HBM_PEAK_GBS, 4)},
             "achieved": round(one_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(one_gbs / HBM_PEAK_GBS, 4),
+            "frac_is": "the FRAME KERNEL alone on the bytes it moves; `pipeline.frac` is the regime's figure",
             "bytes_per_unit_frame": round(one_b, 3),
             "units_per_launch": units,
             "launch_avg_us": round(k1_one_us, 3),
@@ -631,6 +701,17 @@ def main():
             "note": "every rank serialises its band's events to wire records on the device and stores them at their final "
                     "bytes of /dev/shm/<image> over its own PCIe link (adder_gather_host_sink_*); no xGMI funnel, no "
                     "host wait per chunk"}
+    if world > 1:
+        wire_b = wire.get("bytes", 0)
+        out["scale"] = {
+            "value_form": gather_mode,
+            "value_ms_per_step": round(ms_per_step, 3),
+            "bytes_sent_per_step_all_peers": int(wire_b), "bytes_sent_per_step_per_peer": int(wire_b // max(world - 1, 1)),
+            "legs": scale_legs,
+            "predicted_ms_per_step": {"records (root expands every band)": {"2": 1.4, "4": 1.3, "8": 1.1},
+                                      "note": "DESIGN section 6's prediction made from the N = 1 kernels of round 5 (1.25 ms at N = 1): the default "
+                                              "form is flat by construction -- root writes every output byte; sink_per_rank and layout_only are "
+                                              "the forms that can scale (their legs above)"}}
     if layout_elapsed is not None:
         out["layout_only_exchange"] = {
             "value": round(pixels_per_step / (layout_elapsed / layout_steps) / 1e6, 1),
