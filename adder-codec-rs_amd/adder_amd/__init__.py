@@ -16,3 +16,4 @@ from ._native import (  # noqa: F401
 from .video import CRF, crf_feature_radius, HipVideo, raw_header, raw_events, raw_eof, synth_clip_device  # noqa: F401
 from .framer import HipFramer, contiguous_run_segments, FRAMED_U8, DVS, FRAME_U8, FRAME_U16, FRAME_U32  # noqa: F401
 from .compressed import CompressedEncoder, compressed_decode  # noqa: F401
+from .quality import calculate_quality_metrics, calculate_mse, calculate_psnr  # noqa: F401

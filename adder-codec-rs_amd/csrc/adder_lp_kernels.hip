@@ -450,15 +450,10 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
     u32x2 fo2;  // the frame's place in the stream (the batch's own table: its address comes out of the description first)
     const uint32_t fo_off = f * 8u;
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(fo2) : "v"(fo_off), "s"(b->base.frame_offsets) : "memory");
-    const uint32_t frame_events = x.ftot[fy];
     const float T = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b->base.sc.time_spanned)));
     const uint64_t out_cap = b->base.out_cap;
     uint8_t *const out = reinterpret_cast<uint8_t *>(uniform_ptr(b->base.out));
     const uint32_t rt_u32 = __builtin_amdgcn_readfirstlane(f32_as_u32(x.ftab[f].running_t));  // t of D_EMPTY
-    if (frame_events == 0u) {  // a frame without a single event has nothing to expand
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the loads still name this wave's registers)
-        return;
-    }
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(fo2), "+v"(my_tot), "+v"(pref0), "+v"(first[0]), "+v"(first[1]), "+v"(first[2]), "+v"(first[3]), "+v"(first[4]), "+v"(first[5]),
                    "+v"(first[6]), "+v"(first[7])
@@ -670,6 +665,9 @@ __global__ __launch_bounds__(kBlockThreads) void adder_lpx_kernel(const BatchArg
     __shared__ __attribute__((aligned(8))) uint2 s_rec[kWavesPerBlock][kLpxRecCap];
     // (the waves of a workgroup share nothing: no table in LDS -- event C's one division is worked out like event A's --, no barrier)
     const uint32_t fy = blockIdx.y, xblock = blockIdx.x;
+    // a frame without a single event has nothing to expand: static content is mostly such frames, and their workgroups are gone
+    // before a vector load is issued (one scalar round trip; busy frames pay it once more -- 1 % of a wave's life)
+    if (x.ftot[fy] == 0u) return;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + wid) * kExpandSegs);
     if (seg0 < x.num_waves)

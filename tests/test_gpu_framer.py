@@ -149,6 +149,73 @@ def test_transcode_then_frame_on_device(time_mode, multi_mode, dtm, channels, ba
         assert ofr.frames_written == fr.frames_written
 
 
+def test_lossy_round_trip_psnr_1080p_default_quality():
+    """What SURVEY 8(f)1 names as the harness's purpose: the QUALITY of a lossy transcode.  1080p scene clip through the
+    reference's default mode at its default quality -- crf-3 numbers (2, 7, 7), Collapse, AbsoluteT, delta_t_max 7650,
+    config 5's mode (bin/adder_simulproc.rs:75-90) -- on the device, the events reframed on the device
+    (framer/driver.rs:984-1133), MSE / PSNR of every reconstructed frame against its source frame as
+    utils/cv.rs:306-360 computes them.  The reconstruction equals the oracle pair's (transcoder oracle -> framer oracle) byte for
+    byte, so the metrics are the reference path's; the mean PSNR is printed (it is the number a user of the harness asks for)."""
+    import torch
+    A = _hip()
+    W, H, T, dtm = 1920, 1080, 60, 7650
+    base, cmax, vel = 2, 7, 7
+    clip = O.synth_clip(O.CONTENT_SCENE, W, H, 1, T)
+    ov = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, delta_t_max=dtm)
+    ov.set_crf_parameters(cmax, vel)
+    ov.reset_c_thresh(base)
+    ov.ensure_capacity(24)
+    kwf = dict(tps=255 * 30, ref_interval=255, delta_t_max=dtm, output_fps=30.0, codec_version=3, time_mode=O.ABSOLUTE_T)
+    ofr = O.Framer(W, H, 1, chunk_rows=64, source_camera=O.FRAMED_U8, **kwf)
+    want = b""
+    for k in range(T):
+        want += ofr.ingest_events(ov.integrate_matrix(clip[k]))
+
+    hv = A.HipVideo(W, H, 1, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=dtm,
+                    c_thresh_start=base, c_counter_start=0, max_depth=20)
+    hv.set_crf_parameters(cmax, vel)
+    fr = A.HipFramer(W, H, 1, source_camera=A.FRAMED_U8, ring_frames=256, **kwf)
+    st = torch.cuda.current_stream().cuda_stream
+    n_units = W * H
+    got = b""
+    for k0 in range(0, T, 20):
+        d_frames = torch.from_numpy(clip[k0:k0 + 20].reshape(20, n_units)).cuda()
+        d_ev = torch.empty((n_units * 20, 3), dtype=torch.int32, device="cuda")
+        d_off = torch.zeros(21, dtype=torch.int64, device="cuda")
+        hv.integrate_device(d_frames, d_ev, d_off, stream=st)
+        hv.finish()
+        fr.ingest_frames_device(d_ev, d_off.cpu().numpy().astype(np.uint64), stream=st)
+        n = fr.frames_ready()
+        if n:
+            d_out = torch.empty((n, n_units), dtype=torch.uint8, device="cuda")
+            m = fr.pop_device(d_out, n, stream=st)
+            torch.cuda.synchronize()
+            got += d_out[:m].cpu().numpy().tobytes()
+    assert got == want
+    # Collapse holds a frame back until its last pixel has spoken (a black pixel never does): the player's end-of-stream
+    # arrangement -- flush_frame_buffer + write_frame_bytes, driver.rs:632-677 -- hands the frames out, 40 of them here
+    for _ in range(40):
+        assert ofr.flush_frame_buffer() == fr.flush_frame_buffer()
+        wa, wb = ofr.write_frame_bytes(), fr.write_frame_bytes()
+        assert wa == wb and len(wa) == n_units
+        want += wa
+        got += wb
+    n_got, n_want = len(got) // n_units, len(want) // n_units
+    assert n_got == n_want and n_got >= 40
+    psnrs = []
+    for i in range(min(n_got, n_want)):
+        rec_g = np.frombuffer(got, np.uint8, n_units, i * n_units).reshape(H, W, 1)
+        rec_o = np.frombuffer(want, np.uint8, n_units, i * n_units).reshape(H, W, 1)
+        mg, mo = A.calculate_quality_metrics(clip[i], rec_g), A.calculate_quality_metrics(clip[i], rec_o)
+        assert mg == mo
+        psnrs.append(mg["psnr"])
+    # the reference's own arithmetic on a case with a known answer: MSE 0 -> 1e-7 -> 20 log10(255) + 70 dB
+    assert abs(A.calculate_quality_metrics(clip[0], clip[0])["psnr"] - (20.0 * np.log10(255.0) + 70.0)) < 1e-9
+    mean = float(np.mean(psnrs[1:]))  # (frame 0 is reconstructed before any pixel has fired twice)
+    print(f"lossy round trip at the default quality: {len(psnrs)} frames, mean PSNR {mean:.2f} dB, min {min(psnrs[1:]):.2f} dB")
+    assert mean > 30.0   # +-2 flicker inside the contrast band, a moving box: tens of dB, not a broken reconstruction
+
+
 def test_ring_overflow_is_reported():
     A = _hip()
     fr = A.HipFramer(4, 4, 1, tps=7650, ref_interval=255, delta_t_max=7650, output_fps=30.0, ring_frames=8)
