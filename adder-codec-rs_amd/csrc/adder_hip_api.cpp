@@ -161,9 +161,6 @@ struct AdderHipCtx {
     // ADDER_HIP_CU_SPLIT=n (0 < n < CUs): spatial partitioning instead of time sharing -- the frame kernel of chunk k+1
     // on a stream masked to n CUs (the same share of every XCD), scan / offsets / expansion of chunk k on a stream masked
     // to the others; a batch's first frame-kernel run and last expansion have no partner and take the unmasked stream.
-    hipStream_t split_a = nullptr, split_b = nullptr;
-    hipEvent_t split_el[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t cu_split = 0;
     uint32_t *status = nullptr;   // device status word
     uint64_t *d_rec_total = nullptr;  // parked records of the last batch (diagnostics)
     // [0]: adder_log_pack_kernel's total (written, never read back); [1] (as u32): the status word of
@@ -390,10 +387,6 @@ static void free_ctx(AdderHipCtx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->cap_s) (void)hipStreamDestroy(c->cap_s);
     if (c->cap_s2) (void)hipStreamDestroy(c->cap_s2);
-    if (c->split_a) (void)hipStreamDestroy(c->split_a);
-    if (c->split_b) (void)hipStreamDestroy(c->split_b);
-    for (hipEvent_t e : c->split_el)
-        if (e) (void)hipEventDestroy(e);
     if (c->null_join) (void)hipEventDestroy(c->null_join);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -683,21 +676,6 @@ extern "C" int adder_hip_create(const AdderHipParams *params, AdderHipCtx **out)
             c->use_graph = atoi(ng) == 0;
             c->eager_two_streams = atoi(ng) == 2;
         }
-        if (const char *cs = getenv("ADDER_HIP_CU_SPLIT")) {
-            // CU-mask bit i is CU i / XCDs of XCD i % XCDs (the driver deals the bits round-robin over the XCDs, then over
-            // the shader engines), so bits [0, n) take n / 8 CUs of EVERY XCD: both partitions keep all eight L2s
-            const int n = atoi(cs);
-            if (n > 0 && (uint32_t)n < c->num_cus) {
-                uint32_t ma[16] = {0}, mb[16] = {0};
-                const uint32_t words = (c->num_cus + 31u) / 32u;
-                for (uint32_t i = 0; i < c->num_cus && i < 512u; ++i) ((int)i < n ? ma : mb)[i >> 5] |= 1u << (i & 31u);
-                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->split_a, words, ma));
-                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->split_b, words, mb));
-                for (hipEvent_t &e : c->split_el) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                c->cu_split = (uint32_t)n;
-                c->use_graph = false;  // (a captured kernel node does not carry its stream's CU mask)
-            }
-        }
         {
             // workgroups per CU of the lean frame kernel and of the expansion when they share the chip (0: full grids)
             const char *lb = getenv("ADDER_HIP_LEAN_BLOCKS_PER_CU"), *eb = getenv("ADDER_HIP_EXPAND_BLOCKS_PER_CU");
@@ -956,11 +934,6 @@ static bool lean_possible(const AdderHipCtx *c, float time_spanned) {
 // The bounded Collapse step (adder_pixel.hpp cb_step): Collapse with delta_t_max > time_spanned, a uniform c_thresh, and
 // every sum its prefix coordinates form an exact integer below 2^24 -- integer time_spanned, at most delta_t_max /
 // time + 1 frames of 8-bit intensities before the pop.  Anything else takes the generic step.
-// ADDER_HIP_LEAN_LOG=1 (measured alternative, off by default): lean batches stepped several frames per launch append
-// their records to a log per segment and chunk (dense, the expansion reads a frame's run at wofs) instead of a slot per
-// frame.  Measured: frame kernel 164.6 -> 158.9 us per 64 frames, step time unchanged, and the expansion FETCHES more
-// (127 instead of 104 MiB per launch: a run of ~160 bytes at 8-byte alignment touches 2.25 128-byte lines, a slot 2).
-static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames);
 static bool rr_possible(const AdderHipCtx *c, float T, bool pop_at_once_ok = false);
 static bool cb_possible(const AdderHipCtx *c, float T) {
     if (c->p.multi_mode != ADDER_MULTI_COLLAPSE) return false;
@@ -1103,18 +1076,7 @@ static int alloc_deep_planes(AdderHipCtx *c) {
 // K1, and the K1s of chunk k+2 wait for them (the scratch ring holds two chunks).  Running the
 // expansion inside K1's grid (round 1) no longer pays: with the lean step both kernels are bound by the
 // memory system, and a resident K1 grid leaves no wave slots for a concurrent kernel anyway.
-// ADDER_HIP_PARK_FRAME_MAJOR=1: blocked batches park frame-major too (A/B: the expansion then reads a frame's slots
-// linearly, the frame kernel's waves write 64 slots num_waves * park_bytes apart)
-static bool park_frame_major() {
-    static const bool on = [] { const char *e = getenv("ADDER_HIP_PARK_FRAME_MAJOR"); return e && atoi(e) != 0; }();
-    return on;
-}
 static uint32_t launch_depth(const AdderHipCtx *c) { return c->running_enabled ? 1u : c->frames_per_launch; }
-static bool lean_log_batch(const AdderHipCtx *c, bool generic, uint32_t num_frames) {
-    static const bool on = [] { const char *e = getenv("ADDER_HIP_LEAN_LOG"); return e && atoi(e) != 0; }();
-    return on && !generic && !c->continuous && launch_depth(c) > 1u && num_frames > 1u;  // (one frame: the one-frame kernels)
-}
-
 static Lean1wArgs lean1w_args(const AdderHipCtx *c) {
     return Lean1wArgs{c->hdr, c->integ0, c->dt0, c->bdt0, c->lastf, c->n_units, c->num_waves};
 }
@@ -1228,43 +1190,6 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
     }
     if (s2 && k) HIPCHK(c, hipStreamWaitEvent(s, c->cap_e2[(k - 1) % 5u], 0));  // join (s2 is in-order)
     HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, s));
-    return ADDER_OK;
-}
-
-// ADDER_HIP_CU_SPLIT: the same launch sequence on CU-masked streams.  `full` (unmasked) takes what has no partner: the
-// first chunk's frame kernels and the last chunk's scan / offsets / expansion; in between chunk k+1's frame kernels run
-// on split_a's CUs while chunk k's expansion runs on split_b's.  Every dependency is an event (the streams differ from
-// chunk to chunk): frame kernels after the previous chunk's (the pixel state) and after the expansion that last used
-// their scratch; scan after its chunk's frame kernels and after the previous chunk's offsets (the offsets chain).
-static int launch_frame_loop_split(AdderHipCtx *c, uint32_t num_frames, uint32_t variant, hipStream_t full) {
-    const uint32_t depth = launch_depth(c);
-    const Lean1wArgs wide = lean1w_args(c);
-    const uint32_t n_chunks = (num_frames + c->chunk - 1u) / c->chunk;
-    hipStream_t prev_l = nullptr, prev_p = nullptr;
-    uint32_t k = 0;
-    for (uint32_t f0 = 0; f0 < num_frames; f0 += c->chunk, ++k) {
-        const uint32_t nf = std::min(c->chunk, num_frames - f0);
-        hipStream_t ls = (k == 0u || n_chunks == 1u) ? full : c->split_a;
-        hipStream_t ps = (k + 1u == n_chunks) ? full : c->split_b;
-        if (k && ls != prev_l) HIPCHK(c, hipStreamWaitEvent(ls, c->split_el[(k - 1u) % 5u], 0));
-        if (k >= c->ring_chunks) HIPCHK(c, hipStreamWaitEvent(ls, c->cap_e2[(k - c->ring_chunks) % 5u], 0));
-        for (uint32_t f = f0; f < f0 + nf; f += depth) {
-            const uint32_t nb = std::min(depth, f0 + nf - f);
-            HIPCHK(c, adder_launch_frame(c->d_batch, f, nb, variant | lazy_state_bit(c, variant, f + nb < num_frames), c->num_waves, 0u, ls, &wide));
-        }
-        HIPCHK(c, hipEventRecord(c->split_el[k % 5u], ls));
-        if (ps != ls) HIPCHK(c, hipStreamWaitEvent(ps, c->split_el[k % 5u], 0));
-        if (k && ps != prev_p) HIPCHK(c, hipStreamWaitEvent(ps, c->cap_e2[(k - 1u) % 5u], 0));
-        HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, ps));
-        HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, ps));
-        HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, 0u, ps, c->h_batch));
-        HIPCHK(c, hipEventRecord(c->cap_e2[k % 5u], ps));
-        prev_l = ls;
-        prev_p = ps;
-    }
-    // (the last chunk's expansion is on `full`, in order behind everything `full` was given; its frame kernels and the
-    // earlier expansions are ordered before it by the events above)
-    HIPCHK(c, adder_launch_publish(c->d_batch, num_frames, c->h_result, full));
     return ADDER_OK;
 }
 
@@ -1547,18 +1472,17 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // (batches that hand their records out -- the multi-GPU gather -- run it too: the {rho, word} records are the smallest
     // payload and root's expansion works the events out of them like the single-GPU one)
     const bool lr = !generic && !c->continuous && collapse && lr_time && c->cr_valid && !lr_off &&
-                    !lean_log_batch(c, generic, num_frames) && launch_depth(c) > 1u && num_frames > 1u &&
+                    launch_depth(c) > 1u && num_frames > 1u &&
                     (double)(run_frames + num_frames) * std::max(255.0, (double)time_spanned) < 16777216.0;
     // ... in packed bytes (adder_lp_kernel, four units per lane): DeltaT batches whose records the expansion reads itself
     // (the pair's records lie in one run: the ring layout must keep a pair of segments adjacent)
     const bool lp_off = env_flag("ADDER_HIP_NO_LP");
-    const bool lp = lr && !lp_off && c->p.time_mode == ADDER_TIME_DELTA_T && !c->records_only && park_group_shift_wanted() >= 1u &&
-                    !park_frame_major();
+    const bool lp = lr && !lp_off && c->p.time_mode == ADDER_TIME_DELTA_T && !c->records_only && park_group_shift_wanted() >= 1u;
     const uint32_t variant = (lp ? 4096u : 0u) | ((lp && c->p.channels == 3) ? 8192u : 0u) | (collapse ? 1u : 0u) | (c->p.time_mode == ADDER_TIME_ABSOLUTE_T ? 2u : 0u) |
                              (generic ? 4u : 0u) | (c->continuous ? 8u : 0u) |
                              (c->n_units >= 4u ? 16u : 0u) |  // 16: the 4-units-per-lane one-frame kernel may run
                              (cb ? 32u : 0u) | (cr ? 128u : 0u) | (lr ? 256u : 0u) | (rr ? 512u : 0u) | (c->wire_batch ? 1024u : 0u) |
-                             ((lean_log_batch(c, generic, num_frames) || (c->records_only && !lr)) ? 64u : 0u);  // 64: lean records in per-segment logs
+                             ((c->records_only && !lr) ? 64u : 0u);  // 64: lean records in per-segment logs (batches that hand them out)
     c->last_variant = variant;
     if (lr) {
         int rc_ = ensure_lr_tab(c, time_spanned, stream);
@@ -1668,7 +1592,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     // segments (ADDER_HIP_PARK_GROUP_SHIFT: 0 = segment-major)
     if (b.log_cap) {
         b.park_layout = ParkLayout{0u, 0u, 0u, 0u, 31u, 0xffffffffu};  // (unused: the records are appended to logs)
-    } else if ((launch_depth(c) == 1u || park_frame_major()) && (uint64_t)c->num_waves * pb <= 0xffffffffull) {
+    } else if (launch_depth(c) == 1u && (uint64_t)c->num_waves * pb <= 0xffffffffull) {
         b.park_layout = ParkLayout{31u, 0u, c->num_waves * pb, pb, 31u, 0xffffffffu};
     } else {
         uint32_t sh = c->park_group_shift;
@@ -1756,14 +1680,6 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
         hipGraphExec_t exec = nullptr;
         rc = get_graph(c, num_frames, variant, &exec);
         if (rc == ADDER_OK) HIPCHK(c, hipGraphLaunch(exec, stream));
-    } else if (c->cu_split && !timing && !(variant & 4u) && !c->continuous && num_frames > c->chunk) {
-        HIPCHK(c, hipEventRecord(c->cap_e1, stream));
-        HIPCHK(c, hipStreamWaitEvent(c->cap_s, c->cap_e1, 0));
-        rc = launch_frame_loop_split(c, num_frames, variant, c->cap_s);
-        if (rc == ADDER_OK) {
-            HIPCHK(c, hipEventRecord(c->cap_e1, c->cap_s));
-            HIPCHK(c, hipStreamWaitEvent(stream, c->cap_e1, 0));
-        }
     } else if (c->eager_two_streams && !timing) {
         // the graph's two-stream structure, submitted eagerly (diagnostics)
         HIPCHK(c, hipEventRecord(c->cap_e1, stream));

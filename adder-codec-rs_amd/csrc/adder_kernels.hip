@@ -103,15 +103,8 @@ struct EmitCb {
     uint2 *seg;       // the segment's run of this frame (wave-uniform)
     uint32_t tagoff;  // unit_in_wave | offset << 7
     uint32_t boff;    // offset * 8: where the next record goes
-#ifdef ADDER_DBG_CB_NOSTORE
-    uint32_t dbg_acc = 0u;
-#endif
     __device__ __forceinline__ void put(uint32_t w1, uint32_t t) {
-#ifdef ADDER_DBG_CB_NOSTORE
-        dbg_acc ^= t ^ w1;
-#else
         gstore<uint2>(seg, boff, make_uint2(t, w1));
-#endif
         tagoff += 1u << 7;
         boff += kGenRecBytes;
     }
@@ -562,12 +555,6 @@ __device__ __forceinline__ void lean_run_segment(const BatchArgs *__restrict__ b
 }
 
 template <bool ABS_T, bool LOG>
-#ifdef ADDER_LEAN_MAX_WAVES
-__attribute__((amdgpu_waves_per_eu(1, ADDER_LEAN_MAX_WAVES)))
-#endif
-#ifdef ADDER_LEAN_NUM_VGPR
-__attribute__((amdgpu_num_vgpr(ADDER_LEAN_NUM_VGPR)))
-#endif
 __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_kernel(
     const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
     const FrameArgs a = frame_args(b, f);
@@ -605,12 +592,6 @@ __global__ __launch_bounds__(kBlockThreads, kLeanWavesPerSimd) void adder_lean_k
 #endif
 #ifndef ADDER_LR_QUIET_GROUPS
 #define ADDER_LR_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
-#endif
-#ifndef ADDER_LR_NARROW_EXPERIMENT
-#define ADDER_LR_NARROW_EXPERIMENT 0
-#endif
-#ifndef ADDER_LR_QUIET_REENTER
-#define ADDER_LR_QUIET_REENTER 1  // (0: the group test only in front of a launch's first stepped frame)
 #endif
 // input frames in the wave's LDS slice (two groups of half as many, one being stepped, one on its way): the step needs ~46
 // registers, so the slice decides the occupancy -- 32 frames (4 KB per wave, 16 KB per workgroup) leave room for 8 waves
@@ -722,9 +703,6 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         // bytes {0, prev_w[j], vin_w[j], 0}: selectors 0-3 = bytes of the second operand, 4-7 of the first, 12 = 0
         asm volatile("v_mov_b32 %0, %1" : "=v"(sel[j]) : "s"(0x0c00000cu | (j << 8) | ((4u + j) << 16)));
     }
-#ifndef ADDER_LR_COUNT_VALU
-#define ADDER_LR_COUNT_VALU 1  // events counted per lane (an add-with-carry per mask), summed over the wave once per pair of frames
-#endif
     auto frame = [&](uint32_t i, uint32_t &k_lane) -> uint32_t {  // -> events | records << 16 of the segment's frame i (uniform)
         const uint32_t vin_w = (uint32_t)in_lds[(i % kLrInFrames) * kWave];
         uint32_t w0[N], w1[N], w8[N];
@@ -742,17 +720,12 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
                 fl.c &= active[j];
             }
             mrec[j] = fl.a | fl.c;
-#if ADDER_LR_COUNT_VALU
             {   // k_lane += a + b + c (the carry-in of v_addc_co_u32 is a lane mask)
                 uint64_t co;
                 asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.a));
                 asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.b));
                 asm volatile("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(k_lane), "=s"(co) : "s"(fl.c));
             }
-#else
-            nrec += (uint32_t)__popcll(mrec[j]);
-            nev += (uint32_t)__popcll(fl.a) + (uint32_t)__popcll(fl.b) + (uint32_t)__popcll(fl.c);
-#endif
         }
         prev_w = vin_w;
         uint32_t pos = 0u;
@@ -762,31 +735,19 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             const bool has = L::lane(mrec[j]);
-#if !defined(ADDER_DBG_LR_NOSTORE)  // (diagnostic A/B build: everything but the record stores)
             if (has) {
                 if (ABS_T) {
                     struct R12 { uint32_t a, b, c; };
                     gstore(seg, pos * REC, R12{w0[j], w1[j], w8[j]});
                 } else {
-#if ADDER_LR_NARROW_EXPERIMENT  // (measurement only: 4-byte records {unit | base_val << 8 | input << 16 | rho << 23}, no escape for rho >= 511)
-                    gstore(seg, pos * 4u, w8[j] | ((w0[j] < 511u ? w0[j] : 511u) << 23));
-#else
                     gstore(seg, pos * REC, make_uint2(w0[j], w8[j]));
-#endif
                 }
             }
-#else
-            if (has && w0[j] == 0xfffffff1u) gstore(seg, pos * 8u, make_uint2(w0[j], w8[j]));
-#endif
             pos += has ? 1u : 0u;
         }
         seg += frame_stride_u;
         if (__builtin_expect(i == wrap_at, 0)) seg -= wrap_bytes;  // (a branch, not selects: taken once per chunk at most)
-#if ADDER_LR_COUNT_VALU
         return (uint32_t)__builtin_amdgcn_readlane((int)pos, kWave - 1) << 16;  // (the records parked: the last lane's offset)
-#else
-        return nev | (nrec << 16);
-#endif
     };
     static_assert(kLrGroup % 2u == 0u && N <= 4u, "pairs of frames never straddle a staging group; an input word holds the units' bytes");
     // QUIET GROUPS (lr_quiet_run): a staged group ALL of whose bytes equal the units' base_vals -- static content -- is decided
@@ -829,28 +790,24 @@ __device__ __forceinline__ void lr_frames(const BatchArgs *__restrict__ b, const
         }
         // (REENTER: one staged group per trip; otherwise the rest of the launch, staging as it goes)
         const uint32_t i_first = i;
-        const uint32_t i_end = ADDER_LR_QUIET_REENTER ? (i + kLrGroup < nb ? i + kLrGroup : nb) : nb;
+        const uint32_t i_end = 1 ? (i + kLrGroup < nb ? i + kLrGroup : nb) : nb;
 #pragma clang loop unroll(disable)
         for (; i + 2u <= i_end; i += 2u) {
-            if (!ADDER_LR_QUIET_REENTER && (i % kLrGroup) == 0u && i != i_first) stage(i);
+            if (!1 && (i % kLrGroup) == 0u && i != i_first) stage(i);
             uint32_t k0 = 0u, k1 = 0u;
             uint32_t t0 = frame(i, k0);
             uint32_t t1 = frame(i + 1u, k1);
-            if (ADDER_LR_QUIET_REENTER) last_recs = t1 >> 16;
-#if ADDER_LR_COUNT_VALU
+            if (1) last_recs = t1 >> 16;
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0 | (k1 << 16)), kWave - 1);
             t0 |= tot & 0xffffu;
             t1 |= tot >> 16;
-#endif
             wt = lane == i ? t0 : lane == i + 1u ? t1 : wt;
         }
         if (i < i_end) {  // (the launch's last frame, odd launches only)
-            if (!ADDER_LR_QUIET_REENTER && (i % kLrGroup) == 0u && i != i_first) stage(i);
+            if (!1 && (i % kLrGroup) == 0u && i != i_first) stage(i);
             uint32_t k0 = 0u;
             uint32_t t0 = frame(i, k0);
-#if ADDER_LR_COUNT_VALU
             t0 |= (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_dpp(k0), kWave - 1);
-#endif
             wt = lane == i ? t0 : wt;
             i += 1u;
         }
@@ -1009,14 +966,7 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
         active[j] = FULL ? ~0ull : L::from(u0 + j < n_units_u);
         const uint32_t v = (raw.vin >> (8 * j)) & 0xffu;
         const uint32_t tag = ((lane & 31u) * N + j) << kLeanUnitShift;
-#ifdef ADDER_DBG_NOSTEP
-        LeanFlagsT<L> fl;
-        px[j].integ += (float)v; px[j].dt += T; px[j].bdt += 1.0f;
-        fl.a = L::from(px[j].integ > 1e9f); fl.b = 0; fl.c = L::from((v & 7u) == 0u);
-        rec[j].ta = tag; rec[j].tc = v; rec[j].w = cth;
-#else
         LeanFlagsT<L> fl = lean_step<ABS_T, L>(px[j], v, cth, T, sc, tag, rec[j]);
-#endif
         if (!FULL) {
             fl.a &= active[j];
             fl.b &= active[j];
@@ -1049,9 +999,7 @@ __device__ __forceinline__ void wide_step_pair(const BatchArgs *__restrict__ b, 
 #pragma unroll
     for (uint32_t j = 0; j < N; ++j) {
         const bool has = L::lane(mrec[j]);
-#ifndef ADDER_DBG_NOREC
         if (has) lean_store_rec<ABS_T, false>(seg, off, rec[j]);
-#endif
         off += has ? lean_rec_bytes(ABS_T) : 0u;
     }
     if (lane == 0u)
@@ -1435,17 +1383,8 @@ __device__ __forceinline__ void cb_stage_input(const uint8_t *fr0, uint32_t n_un
 #ifndef ADDER_CB_QUIET_PATH
 #define ADDER_CB_QUIET_PATH 1
 #endif
-#ifndef ADDER_CB_GENERAL_PRIO
-#define ADDER_CB_GENERAL_PRIO 0  // s_setprio level of a wave inside the general loop (0: off)
-#endif
 #ifndef ADDER_CB_QUIET_GROUPS
 #define ADDER_CB_QUIET_GROUPS 1  // (0: A/B build without the group form of the quiet path)
-#endif
-#ifndef ADDER_CB_QUIET_PREFETCH
-#define ADDER_CB_QUIET_PREFETCH 1  // (0: the quiet loop stages a group when it gets there, as the general loop does)
-#endif
-#ifndef ADDER_CB_SEQUENTIAL
-#define ADDER_CB_SEQUENTIAL 1
 #endif
 template <bool ABS_T, bool FULL>
 __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, const FrameArgs &a, uint32_t nb,
@@ -1529,20 +1468,12 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     // everything loaded so far (state, frame table, log cursor) has landed BEFORE the loop: otherwise the compiler must
     // assume at the loop header that one of those registers is still in flight and waits vmcnt(0) in EVERY frame --
     // i.e. for the acknowledgement of the previous frame's record stores
-#ifndef ADDER_DBG_CB_NO_PRELOOP_WAIT
     __builtin_amdgcn_s_waitcnt(0x0f70);
-#endif
     uint32_t i = 0u;
-#ifdef ADDER_DBG_CB_SKIP_LOOP  // diagnostic A/B build: prologue + epilogue only (what a launch costs before its first frame)
-    i = nb;
-#endif
     while (i < nb) {  // quiet frames, then general frames up to the next input group, then the same again
 #ifdef ADDER_CB_PROFILE
         const unsigned long long cbp_q0 = __builtin_readcyclecounter();
         const uint32_t cbp_i0 = i;
-#endif
-#if ADDER_CB_GENERAL_PRIO
-        __builtin_amdgcn_s_setprio(0);
 #endif
 #if ADDER_CB_QUIET_PATH
     // ---------------- quiet frames (cb_quiet / cb_step_quiet, adder_pixel.hpp) ----------------
@@ -1581,7 +1512,7 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
                         cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
                     }
                     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the group has landed
-                    pref = ADDER_CB_QUIET_PREFETCH != 0 && i + kCbInFrames < nb;
+                    pref = 1 != 0 && i + kCbInFrames < nb;
                     if (pref) cb_stage_issue<FULL>(fr0, n_units_u, sgw, u0, lane, i + kCbInFrames, nb, cur ? w.in : buf_b, direct);
                     cur_in = reinterpret_cast<const InT *>(cur ? buf_b : w.in) + lane;
 #if ADDER_CB_QUIET_GROUPS
@@ -1680,12 +1611,6 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
     cbp_acc[3] += i - cbp_i0;
     const uint32_t cbp_i1 = i;
 #endif
-#if ADDER_CB_GENERAL_PRIO
-    // A wave in the general loop is the launch's critical path on mostly quiet content (it steps 128 units through ~470
-    // instructions per frame while its quiet neighbours are done after a few hundred per GROUP): it asks the SIMD's
-    // arbiter for priority, and gives it back when it returns to the quiet loop
-    __builtin_amdgcn_s_setprio(ADDER_CB_GENERAL_PRIO);
-#endif
     for (; i < i_end; ++i) {
         // (a frame handed over by the quiet loop mid-group finds its group staged)
         if ((i % kCbInFrames) == 0u) cb_stage_input<FULL>(fr0, n_units_u, sgw, u0, lane, i, nb, w.in, direct);
@@ -1698,7 +1623,6 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
         // ---------------- the step of every unit + the event counts ----------------
         CbPlanT<L> plan[N];
         uint32_t lane_cnt = 0u;
-#if ADDER_CB_SEQUENTIAL
         // one unit after the other, each through its whole step: the step's booleans of one unit are dead before the next
         // unit's are made (with the booleans as wave masks that halves the scalar registers the step holds at once)
 #pragma unroll
@@ -1715,29 +1639,6 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
             if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;
             lane_cnt += plan[j].count;
         }
-#else
-        CbMidT<L> mid[N];
-        bool lane_walks = false;
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            cb_step_a<L>(px[j], lv[j], (vin_w >> (8 * j)) & 0xffu, sc, plan[j], mid[j]);
-            lane_walks = lane_walks || L::lane(mid[j].walk);
-        }
-        // a wave whose arenas are all popped (static content; lossy content between its rare flushes) only steps roots
-        const bool wave_walks = __builtin_amdgcn_ballot_w64(lane_walks) != 0ull;  // uniform
-        if (wave_walks) {
-#pragma unroll
-            for (uint32_t j = 0; j < N; ++j) cb_step_reads<L>(lv[j], mid[j]);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < N; ++j) {
-            if (wave_walks) cb_step_b<L, CbLevelsDev, true>(px[j], lv[j], T, sc, plan[j], mid[j]);
-            else cb_step_b<L, CbLevelsDev, false>(px[j], lv[j], T, sc, plan[j], mid[j]);
-            depth_error = L::or_(depth_error, plan[j].depth_error);
-            if (!FULL) plan[j].count = u0 + j < n_units_u ? plan[j].count : 0u;  // padding units: stepped freely, no events
-            lane_cnt += plan[j].count;
-        }
-#endif
         // ---------------- wave-level ordered compaction into the segment's log ----------------
         const uint32_t incl = wave_inclusive_scan_dpp(lane_cnt);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
@@ -1750,13 +1651,8 @@ __device__ __forceinline__ void cb_run_segment(const BatchArgs *__restrict__ b, 
 #pragma unroll
         for (uint32_t j = 0; j < N; ++j) {
             if (plan[j].count != 0u && seg) {
-#ifndef ADDER_DBG_CB_NOEMIT
                 EmitCb em{seg, (lane * N + j) | (off << 7), off * kGenRecBytes};
                 cb_emit<ABS_T, L>(px[j], plan[j], sc, lv[j], em);
-#ifdef ADDER_DBG_CB_NOSTORE
-                wo ^= em.dbg_acc;
-#endif
-#endif
             }
             off += plan[j].count;
             cb_pop<L>(px[j], plan[j], lv[j]);
@@ -1828,10 +1724,6 @@ template <bool ABS_T>
 __global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_cb_kernel(const BatchArgs *__restrict__ b,
                                                                                          uint32_t f, uint32_t nb) {
     __shared__ CbWaveLds s_w[kWavesPerBlock];
-#ifdef ADDER_CB_LDS_PAD  // (experiment: fewer workgroups per CU)
-    __shared__ uint8_t s_pad[ADDER_CB_LDS_PAD];
-    if (nb == 0xffffffffu) s_pad[threadIdx.x] = (uint8_t)f;
-#endif
     const FrameArgs a = frame_args(b, f);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
@@ -2563,9 +2455,6 @@ __global__ void adder_publish_kernel(const BatchArgs *__restrict__ b, uint32_t n
 #ifndef ADDER_XBUF_EVENTS
 #define ADDER_XBUF_EVENTS 448
 #endif
-#ifndef ADDER_XFLUSH_UNROLL
-#define ADDER_XFLUSH_UNROLL 1
-#endif
 constexpr uint32_t kXbufEvents = ADDER_XBUF_EVENTS;   // staging capacity of one wave, in events (>= 192)
 constexpr uint32_t kXbufDwords = kXbufEvents * 3 + 4; // + the 16-byte phase of the destination
 
@@ -2606,36 +2495,16 @@ __device__ __forceinline__ void xbuf_flush(const uint32_t *xb, uint32_t phase, u
 // xb[phase .. phase + nd) -> dwords [gd0, gd0 + nd) of the output, phase == gd0 & 3
 __device__ __forceinline__ void xbuf_flush_dwords(const uint32_t *xb, uint32_t phase, uint32_t nd, uint32_t *out_dw,
                                                   uint64_t gd0, uint32_t lane) {
-#if defined(ADDER_DBG_X_NOSTORE)  // diagnostic A/B build: the expansion without its event stores
-    return;
-#endif
     uint32_t head = (4u - phase) & 3u;
     head = head < nd ? head : nd;
     uint32_t *const dst = out_dw + gd0;  // uniform 64-bit base; the lanes add 32-bit offsets
     if (lane < head) gstore_ev<uint32_t>(dst, lane * 4u, xb[phase + lane]);
     const uint32_t body = (nd - head) >> 2;  // whole 16-byte blocks
     const uint32_t b0 = phase + head;        // a multiple of 4
-#if ADDER_XFLUSH_UNROLL > 1
-    // (several LDS reads in flight before the first store: a flush is a chain of read -> wait -> store otherwise)
-    for (uint32_t k0 = 0; k0 < body; k0 += kWave * ADDER_XFLUSH_UNROLL) {  // uniform trip count
-        uint4 v[ADDER_XFLUSH_UNROLL];
-#pragma unroll
-        for (uint32_t q = 0; q < ADDER_XFLUSH_UNROLL; ++q) {
-            const uint32_t k = k0 + q * kWave + lane;
-            if (k < body) v[q] = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < ADDER_XFLUSH_UNROLL; ++q) {
-            const uint32_t k = k0 + q * kWave + lane;
-            if (k < body) gstore_ev<uint4>(dst, (head + 4u * k) * 4u, v[q]);
-        }
-    }
-#else
     for (uint32_t k = lane; k < body; k += kWave) {
         const uint4 v = *reinterpret_cast<const uint4 *>(xb + b0 + 4u * k);
         gstore_ev<uint4>(dst, (head + 4u * k) * 4u, v);
     }
-#endif
     const uint32_t tail = (nd - head) & 3u;
     if (lane < tail) gstore_ev<uint32_t>(dst, (head + 4u * body + lane) * 4u, xb[b0 + 4u * body + lane]);
 }
@@ -2780,49 +2649,19 @@ __device__ __forceinline__ uint4 lean_load_rec(const void *base, uint32_t byte_o
     return make_uint4(r.x, r.y, 0u, 0u);
 }
 
-#ifndef ADDER_LR_NARROW_EXPERIMENT
-#define ADDER_LR_NARROW_EXPERIMENT 0
-#endif
 // record `idx` of a segment's run at `base` (+ byte offset `off`)
 template <int FORMAT, bool ABS_T>
 __device__ __forceinline__ uint4 load_rec_at(const void *base, uint32_t off, uint32_t idx) {
-#if ADDER_LR_NARROW_EXPERIMENT
-    if constexpr (FORMAT == 5 && !ABS_T) {
-        const uint32_t w = gload_rec<uint32_t>(base, off + idx * 4u);
-        return make_uint4(w >> 23, w & 0x7fffffu, 0u, 0u);
-    }
-#endif
     return lean_load_rec<ABS_T>(base, off + idx * lean_rec_bytes(ABS_T));
-}
-// record `idx` of a pair's run of adder_lp_kernel's 4-byte records (adder_pixel.hpp lp_park4) as {rho', word, -, -}: an escaping
-// record's full rho' lies 4 (k + 1) bytes below the end of the pair's `region` bytes, k = its rank among the run's escaping
-// records (esc_before of them in the rounds before this one)
-__device__ __forceinline__ uint4 lp_load_rec(const uint8_t *pair_park, uint32_t region, uint32_t idx, uint32_t n, uint32_t esc_before,
-                                             uint32_t *n_esc = nullptr) {
-    uint32_t w4 = 0u;
-    if (idx < n) w4 = gload_rec<uint32_t>(pair_park, idx * 4u);
-    const bool e = idx < n && lp_escapes(w4);
-    const uint64_t em = __builtin_amdgcn_ballot_w64(e);
-    uint32_t esc = 0u;
-    if (em != 0ull) {  // (uniform; rare)
-        const uint32_t rank = esc_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-        if (e) esc = gload_rec<uint32_t>(pair_park, region - 4u * (rank + 1u));
-    }
-    if (n_esc) *n_esc = (uint32_t)__popcll(em);
-    uint32_t w0, w8;
-    lp_unpark4(w4, esc, w0, w8);
-    return make_uint4(w0, w8, 0u, 0u);
 }
 template <int FORMAT, bool ABS_T, bool WIRE = false>
 __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, uint32_t f, uint32_t xblock) {
-    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6 || FORMAT == 7;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
+    constexpr bool LEAN = FORMAT == 1 || FORMAT == 3 || FORMAT == 4 || FORMAT == 5 || FORMAT == 6;  // (3: lean records in per-segment logs, variant bit 64; 4: run records there)
     constexpr bool RR = FORMAT == 4;
-    constexpr bool LR = FORMAT == 5 || FORMAT == 6 || FORMAT == 7;  // lean-runs records (adder_lr_kernel) in fixed slots (5) or found through a run table (6:
+    constexpr bool LR = FORMAT == 5 || FORMAT == 6;  // lean-runs records (adder_lr_kernel) in fixed slots (5) or found through a run table (6:
                                       // the bands' packed records on root); formats of their own, so that
                                       // the decoders do not meet in one instantiation (their results would merge through registers)
-    // 7: adder_lp_kernel's records -- a PAIR of segments' records in one contiguous run at the pair's first slot, the unit
-    // counted from the pair's first unit (8 bits), rho as rho' (adder_pixel.hpp lp_rho)
-    constexpr bool LP = FORMAT == 7;
+    // (adder_lp_kernel's 4-byte records have an expansion of their own: adder_lpx_kernel, adder_lp_kernels.hip)
     // staging capacity of one wave, in events: run-record rounds hold up to 64 x (depth + 1) events and like room
     constexpr uint32_t XE = RR ? 640u : kXbufEvents;
     __shared__ __attribute__((aligned(16))) uint32_t s_xbuf[kWavesPerBlock][XE * 3u + 4u];
@@ -2909,9 +2748,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
             const uint32_t oa = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p) : 0u;
             const uint32_t ob = lean_log ? __builtin_amdgcn_readlane(lean_ofs, 2 * p + 1) : 0u;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (LP) {
-                v = lp_load_rec(park + (size_t)(2 * p) * seg_stride, 2u * seg_stride, lane, pa + pb, 0u);
-            } else if (hl < (half ? pb : pa)) {
+            if (hl < (half ? pb : pa)) {
                 v = load_rec_at<FORMAT, ABS_T>(park + (size_t)(2 * p) * seg_stride, (half ? seg_stride + ob : oa), hl);
             }
             return v;
@@ -2982,7 +2819,6 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         // (DeltaT batches of the lean-runs kernel park {rho, ..base_val..}: event A is worked out here -- uniform choice)
         LeanEvents e;
         if constexpr (LR && ABS_T) e = lr_decode12(rw.x, rw.y, rw.z, time_spanned_u, rt_u32, frame_idx_u);
-        else if constexpr (LP) e = lr_decode8_tab(lp_rho(rw.x, rw.y), rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
         else if constexpr (LR) e = lr_decode8_tab(rw.x, rw.y, time_spanned_u, rt_u32, nullptr, s_tab_c);
         else if constexpr (ABS_T) e = lean_decode(r, true, rt_u32);
         else e = lean_decode8(rw.x, rw.y, time_spanned_u, rt_u32);
@@ -2992,7 +2828,7 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         const uint32_t w = phase + ev0 + (ev0 << 1);  // the record's first dword in the buffer (x3 without a 64-bit multiply-add)
         fill += __builtin_amdgcn_readlane(incl, kWave - 1);
         uint32_t c;
-        const uint32_t unit = LP ? rw.y & 0xffu : lean_runs ? (ABS_T ? rw.z : rw.y) & 0x7fu : ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
+        const uint32_t unit = lean_runs ? (ABS_T ? rw.z : rw.y) & 0x7fu : ABS_T ? (r.w >> kLeanUnitShift) & 0x3ffu : (rw.y >> kLean8UnitShift) & 0x7fu;
         const uint32_t xy = coord_xy_c(uc, unit + unit_shift, c);
         stage_lean(xb, w, e, xy, c);
     };
@@ -3103,24 +2939,8 @@ __device__ __forceinline__ void expand_block(const BatchArgs *__restrict__ b, ui
         for (uint32_t p = 0; p < kExpandSegs / 2u; ++p) {
             const uint32_t pa = __builtin_amdgcn_readlane(my_tot, 2 * p) >> 16;
             const uint32_t pb = __builtin_amdgcn_readlane(my_tot, 2 * p + 1) >> 16;
-            if (LP ? pa + pb <= kWave : (pa <= 32u && pb <= 32u)) {
-#if defined(ADDER_DBG_X_NODECODE)  // diagnostic A/B build: no record loads, no decode, no staging -- only the stream's stores
-                if (fill + 3u * kWave > XE) flush();
-                fill += (__builtin_amdgcn_readlane(my_tot, 2 * p) & 0xffffu) + (__builtin_amdgcn_readlane(my_tot, 2 * p + 1) & 0xffffu);
-#else
-                if (pa + pb != 0u) record_round(first[p], LP ? 0u : half * kWaveUnits);
-#endif
-                next_segment();
-                next_segment();
-            } else if constexpr (LP) {  // (more than 64 records in the pair's run: 64 at a time)
-                const uint8_t *const pair_park = park + (size_t)(2 * p) * seg_stride;
-                uint32_t esc_before = 0u;  // escaping records of the rounds before (uniform)
-                for (uint32_t i0 = 0; i0 < pa + pb; i0 += kWave) {  // uniform trip count
-                    uint32_t n_esc;
-                    const uint4 rw = lp_load_rec(pair_park, 2u * seg_stride, i0 + lane, pa + pb, esc_before, &n_esc);
-                    esc_before += n_esc;
-                    record_round(rw, 0u);
-                }
+            if (pa <= 32u && pb <= 32u) {
+                if (pa + pb != 0u) record_round(first[p], half * kWaveUnits);
                 next_segment();
                 next_segment();
             } else {
@@ -3901,8 +3721,8 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
                                           uint32_t variant, uint32_t grid_cap, hipStream_t stream, const BatchArgs *host_b) {
     const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
     const uint32_t xblocks = (num_waves + per_block - 1) / per_block;
-    static const uint32_t items = [] { const char *e = getenv("ADDER_HIP_EXPAND_ITEMS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u; }();
-    uint32_t total = (xblocks * nf + items - 1u) / items;
+    constexpr uint32_t items = 1u;  // (2 / 4 / 8 work items per workgroup measured slower on every content: DESIGN appendix)
+    uint32_t total = xblocks * nf;
     if (grid_cap && grid_cap < total) total = grid_cap;
     const dim3 grid(total);
     const bool abs_t = variant & 2u, generic = variant & 4u, continuous = variant & 8u, wire = variant & 1024u;
@@ -3921,10 +3741,8 @@ extern "C" hipError_t adder_launch_expand(const BatchArgs *b, uint32_t f0, uint3
         if (abs_t) ADDER_XW(3, true);
         else ADDER_XW(3, false);
     } else if (variant & 4096u) {  // adder_lp_kernel's records (DeltaT): the expansion of adder_lp_kernels.hip
-        static const bool old_x = [] { const char *e = getenv("ADDER_HIP_LP_OLD_EXPAND"); return e && atoi(e) != 0; }();  // (A/B: format 7 of this file)
-        if (!old_x && host_b != nullptr && f0 % host_b->chunk == 0u && nf <= host_b->chunk)
-            return adder_launch_lpx(b, host_b, f0, nf, wire ? ((variant & 8192u) ? 11u : 9u) : 12u, stream);
-        ADDER_XW(7, false);
+        if (host_b == nullptr || f0 % host_b->chunk != 0u || nf > host_b->chunk) return hipErrorInvalidValue;  // (a launch covers frames of one chunk)
+        return adder_launch_lpx(b, host_b, f0, nf, wire ? ((variant & 8192u) ? 11u : 9u) : 12u, stream);
     } else if (variant & 256u) {
         if (abs_t) ADDER_XW(5, true);
         else ADDER_XW(5, false);
