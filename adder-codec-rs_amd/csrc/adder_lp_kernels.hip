@@ -8,7 +8,7 @@
 // change costs nothing of its own.  Per frame and wave: one DPP scan of {records | events << 16} places the records and
 // leaves both segments' totals (lanes 31 and 63, parked in LDS until the launch ends), the four byte positions put
 // their records into the wave's LDS run under the flush mask, one coalesced store writes the run out.  The pair's records are CONTIGUOUS in the pair's two slots (segment 2p's then
-// segment 2p + 1's: the expansion's format 7 reads one run per pair), FOUR bytes each: unit (8 bits) | base_val << 8 |
+// segment 2p + 1's: adder_lpx_kernel reads one run per pair), FOUR bytes each: unit (8 bits) | base_val << 8 |
 // input << 16 | min(rho', 255) << 24, a run longer than that in an escape word at the far end of the pair's slots
 // (adder_pixel.hpp lp_park4).  Same resident planes, scan, offsets and ring as every other frame kernel.
 #include <hip/hip_runtime.h>
@@ -356,12 +356,12 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 }
 
 // ------------------------------------------------------------------------------------------
-// K2 for adder_lp_kernel's records (format 7): adder_lpx_kernel<REC>.  A wave takes kLpxPairs consecutive pairs (16
+// K2 for adder_lp_kernel's records: adder_lpx_kernel<REC>.  A wave takes kLpxPairs consecutive pairs (16
 // segments, 2048 units) of ONE frame -- their events are contiguous in the stream.
 //   1. the pairs' runs of 4-byte records (one coalesced load per pair, all in flight at once) are unparked into ONE dense run
 //      of {rho' | pair << 28, word} in LDS: the decode rounds below then run on 64 records each, whatever the pairs held
 //      (a round per pair left 40 of 64 lanes idle);
-//   2. a round decodes 64 records (lr_decode8_tab: event A worked out from (base_val, rho), C from the 256-word table), a
+//   2. a round decodes 64 records (lr_decode8: events A and C worked out from (base_val, rho) and the input byte), a
 //      DPP scan of the records' event counts places the events, and every event is written into the staging buffer in its
 //      FINAL bytes -- REC = 9 / 11: the raw sink's record (RawOutput::ingest_event, raw/stream.rs:101-120: bincode fixint
 //      big-endian {x u16, y u16, [0x01, c,] d u8, t u32}) at whatever byte it falls on; REC = 12: the AdderEvent.  (An LDS

@@ -709,9 +709,10 @@ def main():
             "bytes_sent_per_step_all_peers": int(wire_b), "bytes_sent_per_step_per_peer": int(wire_b // max(world - 1, 1)),
             "legs": scale_legs,
             "predicted_ms_per_step": {"records (root expands every band)": {"2": 1.4, "4": 1.3, "8": 1.1},
-                                      "note": "DESIGN section 6's prediction made from the N = 1 kernels of round 5 (1.25 ms at N = 1): the default "
-                                              "form is flat by construction -- root writes every output byte; sink_per_rank and layout_only are "
-                                              "the forms that can scale (their legs above)"}}
+                                      "note": "DESIGN section 6's prediction: the bands of a gather still run round 5's kernels (adder_lr_kernel, root's "
+                                              "adder_expand_bands_kernel: 1.25 ms at N = 1) while N = 1 runs round 6's packed pair at ~1.0 ms, so the "
+                                              "default form is predicted SLOWER than one GPU at N = 2-4 and level at 8 -- root writes every output "
+                                              "byte, flat by construction; sink_per_rank and layout_only are the forms that can scale (their legs above)"}}
     if layout_elapsed is not None:
         out["layout_only_exchange"] = {
             "value": round(pixels_per_step / (layout_elapsed / layout_steps) / 1e6, 1),
