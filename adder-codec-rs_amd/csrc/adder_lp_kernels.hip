@@ -164,9 +164,9 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
     uint32_t pend_n = 0u;
     uint8_t *pend_seg = seg;
     const uint32_t lane4 = lane * 4u;
-    auto frame = [&](uint32_t i, auto esc_tag) {
+    auto frame = [&](uint32_t i, const uint32_t *in_row, auto esc_tag) {  // in_row: the frame's row of the LDS slice
         constexpr bool ESC = decltype(esc_tag)::value;
-        const uint32_t vin = in_lds[(i % kLpInFrames) * kWave];
+        const uint32_t vin = *in_row;
         const uint32_t pend_w = rec_lds[lane];  // (every lane, every frame: no branch around the LDS read; lanes >= pend_n read what is not stored)
         const uint32_t x = vin ^ s.prev;
         const bool busy = __builtin_amdgcn_ballot_w64(x != 0u) != 0ull;
@@ -273,14 +273,19 @@ __device__ __forceinline__ void lp_frames(const BatchArgs *__restrict__ b, const
         const uint32_t i_end = i + kLpGroup < nb ? i + kLpGroup : nb;
         if (esc) {
 #pragma clang loop unroll(disable)
-            for (; i < i_end; ++i) frame(i, std::true_type{});
-        } else {
-#if defined(ADDER_LP_NO_UNROLL2)
-#pragma clang loop unroll(disable)
-#else
-#pragma clang loop unroll_count(2)
+            for (; i < i_end; ++i) frame(i, in_lds + (i % kLpInFrames) * kWave, std::true_type{});
+#if !defined(ADDER_LP_NO_UNROLL_GROUP)
+        } else if (i + kLpGroup == i_end) {
+            // a whole group, unrolled (a loop of convergent operations is only unrolled at a constant trip count): no registers
+            // rotated between frames, the rows' LDS addresses as instruction offsets
+            const uint32_t *const row0 = in_lds + (i % kLpInFrames) * kWave;
+#pragma unroll
+            for (uint32_t q = 0; q < kLpGroup; ++q) frame(i + q, row0 + q * kWave, std::false_type{});
+            i += kLpGroup;
 #endif
-            for (; i < i_end; ++i) frame(i, std::false_type{});
+        } else {
+#pragma clang loop unroll(disable)
+            for (; i < i_end; ++i) frame(i, in_lds + (i % kLpInFrames) * kWave, std::false_type{});
         }
     }
 
