@@ -1178,9 +1178,12 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         }
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
         // (a lean-runs batch that hands its records out: the scan also leaves the segments' record prefix, for the packing)
+        // (packed lean-runs batches: the scan's blocks chain the frame offsets themselves, adder_scan_kernel CHAIN -- a launch less)
+        static const bool no_chain = env_flag("ADDER_HIP_NO_SCAN_CHAIN");
+        const bool chain = (variant & 4096u) != 0u && num_frames != 1u && !c->records_only && !no_chain;
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u,
-                                    (c->records_only && (variant & 256u)) ? 1u : 0u));
-        if (num_frames != 1u) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
+                                    (c->records_only && (variant & 256u)) ? 1u : 0u, chain ? 1u : 0u));
+        if (num_frames != 1u && !chain) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)
         if (!c->records_only) HIPCHK(c, adder_launch_expand(c->d_batch, f0, nf, c->num_waves, variant, expand_cap, t, c->h_batch));
         if (timing) {
             HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts + 1], t));

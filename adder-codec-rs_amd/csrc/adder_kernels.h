@@ -304,7 +304,8 @@ hipError_t adder_launch_wire(const adder::AdderEventPod *ev, uint64_t n, uint32_
                              hipStream_t stream);
 // frames [f0, f0 + nf): per-frame scan, frame_offsets chain, expansion of the parked records
 hipError_t adder_launch_scan(const adder::BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch = 0u,
-                             uint32_t rec_prefix = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame offsets too
+                             uint32_t rec_prefix = 0u, uint32_t chain = 0u);  // whole_batch: a batch of one frame -- the scan writes the frame
+                                                                              // offsets too; chain: ... of every batch (adder_scan_kernel)
 size_t adder_sparse_temp_bytes(uint32_t n);
 hipError_t adder_sparse_run(const adder::SparseArgs *args, const adder::SparseStep *d_steps, uint32_t n, uint32_t *keys0,
                             uint32_t *keys1, uint32_t *idx0, uint32_t *idx1, void *d_temp, size_t temp_bytes, uint2 *stage,

@@ -2377,11 +2377,26 @@ __global__ __launch_bounds__(kScanThreads) void adder_scan_kernel(const BatchArg
     if (tid == 0 && tile + 1u == ntiles) {  // (the last tile's block knows the frame's totals)
         *a.ftot = total;
         a.ftot[b->slots] = rec_total;  // second half of the ring: records per frame
-        if (whole_batch) {  // a batch of ONE frame (the per-frame calls and the ring): the offsets kernel's work, a launch less
+        if (whole_batch & 1u) {  // a batch of ONE frame (the per-frame calls and the ring): the offsets kernel's work, a launch less
             b->base.frame_offsets[0] = 0ull;
             b->base.frame_offsets[1] = total;
             if (b->rec_total) *b->rec_total = rec_total;
         }
+    }
+    // CHAIN (whole_batch & 2; the packed lean-runs batches): the frame_offsets chain without the offsets kernel's launch.
+    // frame_offsets[f0 + j + 1] = frame_offsets[f0] + the totals of frames f0 .. f0 + j: this frame's block ADDS its total
+    // to every later entry of the chunk (one atomic instruction, a lane per entry; the chunk's first block also adds the
+    // chain's value in front of the chunk -- final since the previous chunk's scan ended).  The entries were zeroed by the
+    // frame kernel that ran these frames (adder_lp_kernel); sums commute, nothing waits, the expansion starts a kernel later.
+    if ((whole_batch & 2u) && wid == 0u && tile + 1u == ntiles) {
+        const uint32_t nf = gridDim.x / ntiles;
+        unsigned long long *const offs = reinterpret_cast<unsigned long long *>(b->base.frame_offsets);
+        unsigned long long add = total;
+        if (fr == 0u && f0 != 0u) add += offs[f0];
+        if (lane >= fr && lane < nf) (void)__hip_atomic_fetch_add(&offs[f0 + lane + 1u], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0u && b->rec_total)
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(b->rec_total), (unsigned long long)rec_total, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
     }
     timeline_mark(b, 1u, f0, true);
 }
@@ -3699,11 +3714,11 @@ extern "C" hipError_t adder_launch_wire_scatter(const AdderEventPod *ev, const u
 }
 
 extern "C" hipError_t adder_launch_scan(const BatchArgs *b, uint32_t f0, uint32_t nf, uint32_t num_waves, hipStream_t stream, uint32_t whole_batch,
-                                        uint32_t rec_prefix) {
+                                        uint32_t rec_prefix, uint32_t chain) {
     const uint32_t ntiles = (num_waves + kScanTileWaves - 1u) / kScanTileWaves;  // (as the kernels work it out from the batch)
     if (ntiles > 1u) hipLaunchKernelGGL(adder_scan_tiles_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0);
-    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0, (whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u,
-                       rec_prefix);
+    hipLaunchKernelGGL(adder_scan_kernel, dim3(nf * ntiles), dim3(kScanThreads), 0, stream, b, f0,
+                       ((whole_batch && f0 == 0u && nf == 1u) ? 1u : 0u) | (chain ? 2u : 0u), rec_prefix);
     return hipGetLastError();
 }
 
