@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 constexpr uint32_t kLpxPairs = kExpandSegs / 2u;
 constexpr uint32_t kLpxRecCap = ADDER_LPX_REC_CAP;
 constexpr uint32_t kLpxStageEvents = ADDER_LPX_STAGE_EVENTS;
-static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxStageEvents >= 4u * kWave, "sizes the loops below assume");
+static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxRecCap % kWave == 0u && kLpxStageEvents >= 4u * kWave, "sizes the loops below assume");
 
 // What adder_lpx_kernel takes by value: what stays the same for every batch of a context's current scratch ring.
 struct LpxArgs {
@@ -576,6 +576,8 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
                 rb += np[p];
             }
         }
+        // (the last round's idle lanes read zero records -- no events -- instead of being masked out of the read)
+        if ((R & (kWave - 1u)) != 0u && lane >= (R & (kWave - 1u))) rec_lds[(R & ~(kWave - 1u)) + lane] = lpx_u32x2{0u, 0u};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -613,9 +615,7 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
         for (uint32_t r0 = 0; r0 < R; r0 += kWave) {
 #endif
             if (fill + 3u * kWave > CAPE) flush();
-            const bool valid = r0 + lane < R;
-            lpx_u32x2 rec = {0u, 0u};
-            if (valid) rec = rec_lds[r0 + lane];
+            const lpx_u32x2 rec = rec_lds[r0 + lane];
             const uint32_t w8 = rec.y;
             const LeanEvents e = lr_decode8(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32);  // (a zero record: no events)
             const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
@@ -623,15 +623,10 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
             // coordinates: the unit counted from the wave's first
             uint32_t rem = rem0 + ((rec.x >> 28) << 8) + (w8 & 0xffu);
             uint32_t y = yb;
-            if (wraps != 0u) {
-                const bool w1 = rem >= rowlen;
-                rem -= w1 ? rowlen : 0u;
-                y += w1 ? 1u : 0u;
-                if (wraps == 2u) {
-                    const bool w2 = rem >= rowlen;
-                    rem -= w2 ? rowlen : 0u;
-                    y += w2 ? 1u : 0u;
-                }
+            if (wraps != 0u) {  // at most two rows further on: min(rem, rem - rowlen) is rem - rowlen exactly when that does not wrap
+                y += (rem >= rowlen ? 1u : 0u) + (rem >= 2u * rowlen ? 1u : 0u);
+                rem = min(rem, rem - rowlen);
+                rem = min(rem, rem - rowlen);
             } else {  // narrow planes: a quotient estimate, one step either way
                 uint32_t q = (uint32_t)((float)rem * inv_row);
                 q -= q * rowlen > rem ? 1u : 0u;

@@ -1488,7 +1488,7 @@ ADDER_HD LeanEvents lr_decode8(uint32_t w0, uint32_t w8, float T, uint32_t runni
     const float I = (float)Iv;
     const float p2 = bits_to_f32(f32_to_bits(I) & 0x7f800000u);  // 2^get_d(I)
     e.dc = get_d(I);
-    e.tc = f32_as_u32(fadd(0.0f, fmul(T, fdiv_small(fsub(p2, 0.0f), I))));  // (C exists only for I >= 1)
+    e.tc = f32_as_u32(fmul(T, fdiv_small(p2, I)));  // 0 + T (2^d - 0) / I: both identities on positive values (C exists only for I >= 1)
     return e;
 }
 // The same through a table: the expansion is bound by vector instructions, and the two events' arithmetic (three
