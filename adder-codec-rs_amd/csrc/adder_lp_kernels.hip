@@ -545,6 +545,10 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
         fill = 0u;
     };
 
+    // (the rare paths below work their pairs' addresses out again from an opaque copy of the base: reusing the eight pointers
+    // of the loads above kept sixteen scalar registers alive through the whole item -- and spilled as many)
+    const uint8_t *park_rare = park;
+    asm volatile("" : "+s"(park_rare));
     uint32_t pstart = 0u;
     while (pstart < kLpxPairs) {  // batches of pairs whose records fit the LDS run (one batch unless the content is dense)
         uint32_t pe = pstart, R = 0u;
@@ -561,19 +565,25 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
 #pragma unroll
         for (uint32_t p = 0; p < kLpxPairs; ++p) {
             if (p >= pstart && p < pe && np[p] != 0u) {  // uniform
+                // (an opaque copy of the count: its lane masks are loop invariants otherwise, all eight pairs' hoisted in
+                // front of this loop -- 48 scalar registers, most of them spilled to lanes and read back here)
+                uint32_t n_p = np[p];
+                asm volatile("" : "+s"(n_p));
                 const uint32_t w4 = first[p];
-                if (lane < np[p]) rec_lds[rb + lane] = lpx_u32x2{(w4 >> kLpRhoShift) | (p << 28), w4};
-                esc_any |= __builtin_amdgcn_ballot_w64(lane < np[p] && lp_escapes(w4));
-                if (__builtin_expect(np[p] > kWave, 0)) {  // (more than a quarter of the pair's units flushed)
-                    const uint8_t *const pp = park + (size_t)p * pair_stride;
-                    for (uint32_t l0 = kWave; l0 < np[p]; l0 += kWave) {
+                if (lane < n_p) rec_lds[rb + lane] = lpx_u32x2{(w4 >> kLpRhoShift) | (p << 28), w4};
+                esc_any |= __builtin_amdgcn_ballot_w64(lane < n_p && lp_escapes(w4));
+                if (__builtin_expect(n_p > kWave, 0)) {  // (more than a quarter of the pair's units flushed)
+                    const uint8_t *pr = park_rare;
+                    asm volatile("" : "+s"(pr));  // (worked out here, not hoisted)
+                    const uint8_t *const pp = pr + (size_t)p * pair_stride;
+                    for (uint32_t l0 = kWave; l0 < n_p; l0 += kWave) {
                         const uint32_t idx = l0 + lane;
-                        const uint32_t w = idx < np[p] ? gload_rec<uint32_t>(pp, idx * 4u) : 0u;
-                        if (idx < np[p]) rec_lds[rb + idx] = lpx_u32x2{(w >> kLpRhoShift) | (p << 28), w};
+                        const uint32_t w = idx < n_p ? gload_rec<uint32_t>(pp, idx * 4u) : 0u;
+                        if (idx < n_p) rec_lds[rb + idx] = lpx_u32x2{(w >> kLpRhoShift) | (p << 28), w};
                         esc_any |= __builtin_amdgcn_ballot_w64(lp_escapes(w));
                     }
                 }
-                rb += np[p];
+                rb += n_p;
             }
         }
         // (the last round's idle lanes read zero records -- no events -- instead of being masked out of the read)
@@ -587,7 +597,7 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
 #pragma unroll 1
             for (uint32_t p = pstart; p < pe; ++p) {
                 const uint32_t n_p = (uint32_t)__builtin_amdgcn_readlane((int)pair_recs, 2 * p);
-                const uint8_t *const pp = park + (size_t)p * pair_stride;
+                const uint8_t *const pp = park_rare + (size_t)p * pair_stride;
                 uint32_t esc_before = 0u;
                 for (uint32_t l0 = 0; l0 < n_p; l0 += kWave) {
                     const uint32_t idx = l0 + lane;
