@@ -392,12 +392,18 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 #define ADDER_LPX_REC_CAP 384  // records unparked per batch of pairs (>= 256: one pair's worst case)
 #endif
 #ifndef ADDER_LPX_STAGE_EVENTS
-#define ADDER_LPX_STAGE_EVENTS 512  // events the staging buffer holds (>= 192 + what a flush should carry)
+#define ADDER_LPX_STAGE_EVENTS 400  // events the staging buffer holds (>= 192 + what a flush should carry; a multiple of 16).
+// 400: a wave's LDS is 6.7 KB for 9-byte records -- six waves per SIMD (512: five; 117.4 / 113.5 against 118.8 / 115.1 us per
+// launch), five for 11- and 12-byte ones (512: four).  Eight waves per workgroup, at four per SIMD: 139 us.
 #endif
 constexpr uint32_t kLpxPairs = kExpandSegs / 2u;
 constexpr uint32_t kLpxRecCap = ADDER_LPX_REC_CAP;
+#ifndef ADDER_LPX_WAVES
+#define ADDER_LPX_WAVES 4
+#endif
+constexpr uint32_t kLpxWaves = ADDER_LPX_WAVES;  // waves (= items) per workgroup: they share nothing
 constexpr uint32_t kLpxStageEvents = ADDER_LPX_STAGE_EVENTS;
-static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxRecCap % kWave == 0u && kLpxStageEvents >= 4u * kWave, "sizes the loops below assume");
+static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxRecCap % kWave == 0u && kLpxStageEvents >= 4u * kWave && kLpxStageEvents % 16u == 0u, "sizes the loops below assume");
 
 // What adder_lpx_kernel takes by value: what stays the same for every batch of a context's current scratch ring.
 struct LpxArgs {
@@ -681,16 +687,16 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
 // items' loads in flight were tried: 147-172 us per launch against this form's 138-144 -- the uniform state of three items
 // in flight spilled the scalar registers.)
 template <uint32_t REC>
-__global__ __launch_bounds__(kBlockThreads) void adder_lpx_kernel(const BatchArgs *__restrict__ b, const LpxArgs x, uint32_t f0) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kLpxStageEvents * REC + 16u];
-    __shared__ __attribute__((aligned(8))) uint2 s_rec[kWavesPerBlock][kLpxRecCap];
+__global__ __launch_bounds__(kLpxWaves * kWave) void adder_lpx_kernel(const BatchArgs *__restrict__ b, const LpxArgs x, uint32_t f0) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kLpxWaves][kLpxStageEvents * REC + 16u];
+    __shared__ __attribute__((aligned(8))) uint2 s_rec[kLpxWaves][kLpxRecCap];
     // (the waves of a workgroup share nothing: no table in LDS -- event C's one division is worked out like event A's --, no barrier)
     const uint32_t fy = blockIdx.y, xblock = blockIdx.x;
     // a frame without a single event has nothing to expand: static content is mostly such frames, and their workgroups are gone
     // before a vector load is issued (one scalar round trip; busy frames pay it once more -- 1 % of a wave's life)
     if (x.ftot[fy] == 0u) return;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kWavesPerBlock + wid) * kExpandSegs);
+    const uint32_t seg0 = __builtin_amdgcn_readfirstlane((xblock * kLpxWaves + wid) * kExpandSegs);
     if (seg0 < x.num_waves)
         lpx_wave<REC>(b, x, f0 + fy, fy, seg0, threadIdx.x & (kWave - 1u), (ADDER_LDS uint8_t *)s_stage[wid], (ADDER_LDS lpx_u32x2 *)s_rec[wid]);
 }
@@ -730,10 +736,10 @@ extern "C" hipError_t adder_launch_lpx(const BatchArgs *b, const BatchArgs *hb, 
     x.row_begin = hb->base.row_begin;
     x.wraps = x.rowlen >= kLpxPairs * kLpPairUnits ? 1u : x.rowlen >= kLpxPairs * kLpPairUnits / 2u ? 2u : 0u;  // (0: divide)
     x.inv_row = 1.0f / (float)x.rowlen;
-    const uint32_t per_block = kWavesPerBlock * kExpandSegs;  // segments per block
-    const dim3 grid((num_waves + per_block - 1u) / per_block, nf);
-    if (rec == 9u) hipLaunchKernelGGL((adder_lpx_kernel<9u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
-    else if (rec == 11u) hipLaunchKernelGGL((adder_lpx_kernel<11u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
-    else hipLaunchKernelGGL((adder_lpx_kernel<12u>), grid, dim3(kBlockThreads), 0, stream, b, x, f0);
+    const uint32_t per_block = kLpxWaves * kExpandSegs;  // segments per block
+    const dim3 grid((num_waves + per_block - 1u) / per_block, nf), block(kLpxWaves * kWave);
+    if (rec == 9u) hipLaunchKernelGGL((adder_lpx_kernel<9u>), grid, block, 0, stream, b, x, f0);
+    else if (rec == 11u) hipLaunchKernelGGL((adder_lpx_kernel<11u>), grid, block, 0, stream, b, x, f0);
+    else hipLaunchKernelGGL((adder_lpx_kernel<12u>), grid, block, 0, stream, b, x, f0);
     return hipGetLastError();
 }
