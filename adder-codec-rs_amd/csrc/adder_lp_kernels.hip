@@ -403,7 +403,7 @@ constexpr uint32_t kLpxRecCap = ADDER_LPX_REC_CAP;
 #endif
 constexpr uint32_t kLpxWaves = ADDER_LPX_WAVES;  // waves (= items) per workgroup: they share nothing
 constexpr uint32_t kLpxStageEvents = ADDER_LPX_STAGE_EVENTS;
-static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxRecCap % kWave == 0u && kLpxStageEvents >= 4u * kWave && kLpxStageEvents % 16u == 0u, "sizes the loops below assume");
+static_assert(kLpxPairs == 8u && kLpxRecCap >= kLpPairUnits && kLpxRecCap % kWave == 0u && kLpxStageEvents >= 6u * kWave && kLpxStageEvents % 16u == 0u, "sizes the loops below assume");
 
 // What adder_lpx_kernel takes by value: what stays the same for every batch of a context's current scratch ring.
 struct LpxArgs {
@@ -434,8 +434,24 @@ __device__ __forceinline__ void lpx_put(ADDER_LDS uint8_t *stage, uint32_t off, 
     } else {
         const uint32_t tb = __builtin_amdgcn_perm(0u, t, 0x00010203u);  // t3 t2 t1 t0
         if constexpr (REC == 9u) {
+#if defined(ADDER_LPX_BYTE_STAGE)  // (A/B build: nine byte stores -- none misaligned -- instead of an 8-byte store at any address + a byte)
+            const uint32_t addr = (uint32_t)(uintptr_t)(stage + off);
+            asm volatile("ds_write_b8 %0, %1\n\t"
+                         "ds_write_b8_d16_hi %0, %1 offset:2\n\t"
+                         "ds_write_b8 %0, %2 offset:1\n\t"
+                         "ds_write_b8_d16_hi %0, %2 offset:3\n\t"
+                         "ds_write_b8 %0, %3 offset:4\n\t"
+                         "ds_write_b8 %0, %4 offset:5\n\t"
+                         "ds_write_b8_d16_hi %0, %4 offset:7\n\t"
+                         "ds_write_b8 %0, %5 offset:6\n\t"
+                         "ds_write_b8_d16_hi %0, %5 offset:8"
+                         :
+                         : "v"(addr), "v"(xyw), "v"(xyw >> 8), "v"(d), "v"(tb), "v"(tb >> 8)
+                         : "memory");
+#else
             *reinterpret_cast<ADDER_LDS lpx_u64_any *>(stage + off) = (uint64_t)xyw | ((uint64_t)(d | (tb << 8)) << 32);
             stage[off + 8u] = (uint8_t)(tb >> 24);
+#endif
         } else {
             *reinterpret_cast<ADDER_LDS lpx_u64_any *>(stage + off) = (uint64_t)xyw | ((uint64_t)(1u | (c << 8) | (d << 16) | (tb << 24)) << 32);
             *reinterpret_cast<ADDER_LDS lpx_u16_any *>(stage + off + 8u) = (uint16_t)(tb >> 8);
@@ -624,18 +640,17 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // 2. dense rounds
-#if defined(ADDER_DBG_LPX) && ADDER_DBG_LPX >= 3
-        for (uint32_t r0 = 0; r0 < (R == 0x7777u ? 64u : 0u); r0 += kWave) {
-#else
-#pragma clang loop unroll(disable)
-        for (uint32_t r0 = 0; r0 < R; r0 += kWave) {
-#endif
-            if (fill + 3u * kWave > CAPE) flush();
-            const lpx_u32x2 rec = rec_lds[r0 + lane];
+        struct Round {
+            LeanEvents e;
+            uint32_t n, incl, xy, xyw, c;
+        };
+        auto decode = [&](uint32_t idx) {  // 64 records -> their events, the events' places among the round's, the coordinates
+            Round r;
+            const lpx_u32x2 rec = rec_lds[idx];
             const uint32_t w8 = rec.y;
-            const LeanEvents e = lr_decode8(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32);  // (a zero record: no events)
-            const uint32_t n = (e.a ? 1u : 0u) + (e.b ? 1u : 0u) + (e.c ? 1u : 0u);
-            const uint32_t incl = wave_inclusive_scan_dpp(n);
+            r.e = lr_decode8(lp_rho(rec.x & 0x0fffffffu, w8), w8, T, rt_u32);  // (a zero record: no events)
+            r.n = (r.e.a ? 1u : 0u) + (r.e.b ? 1u : 0u) + (r.e.c ? 1u : 0u);
+            r.incl = wave_inclusive_scan_dpp(r.n);
             // coordinates: the unit counted from the wave's first
             uint32_t rem = rem0 + ((rec.x >> 28) << 8) + (w8 & 0xffu);
             uint32_t y = yb;
@@ -650,28 +665,59 @@ __device__ __forceinline__ void lpx_wave(const BatchArgs *__restrict__ b, const 
                 rem -= q * rowlen;
                 y += q;
             }
-            uint32_t x = rem, c = 0xffu;
+            uint32_t x = rem;
+            r.c = 0xffu;
             if (rgb) {
                 x = (uint32_t)(((uint64_t)rem * 0xAAAAAAABull) >> 33);  // rem / 3
-                c = rem - 3u * x;
+                r.c = rem - 3u * x;
             }
-            const uint32_t xy = x | (y << 16);
-            const uint32_t xyw = __builtin_amdgcn_perm(0u, xy, 0x02030001u);  // x_hi x_lo y_hi y_lo
-            uint32_t off = phase + (fill + incl - n) * REC;
-            fill += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+            r.xy = x | (y << 16);
+            r.xyw = __builtin_amdgcn_perm(0u, r.xy, 0x02030001u);  // x_hi x_lo y_hi y_lo
+            return r;
+        };
+        auto put = [&](const Round &r, uint32_t off) {
 #if defined(ADDER_DBG_LPX) && ADDER_DBG_LPX >= 2
-            if (e.a && e.ta == 0x7654321u && e.tc == 0x1234567u && xyw == 0x33u) lpx_put<REC>(stage, off, xy, xyw, c, e.da, e.ta + e.tc);
+            if (r.e.a && r.e.ta == 0x7654321u && r.e.tc == 0x1234567u && r.xyw == 0x33u) lpx_put<REC>(stage, off, r.xy, r.xyw, r.c, r.e.da, r.e.ta + r.e.tc);
 #else
-            if (e.a) {
-                lpx_put<REC>(stage, off, xy, xyw, c, e.da, e.ta);
+            if (r.e.a) {
+                lpx_put<REC>(stage, off, r.xy, r.xyw, r.c, r.e.da, r.e.ta);
                 off += REC;
             }
-            if (e.b) {
-                lpx_put<REC>(stage, off, xy, xyw, c, kDEmpty, e.tb);
+            if (r.e.b) {
+                lpx_put<REC>(stage, off, r.xy, r.xyw, r.c, kDEmpty, r.e.tb);
                 off += REC;
             }
-            if (e.c) lpx_put<REC>(stage, off, xy, xyw, c, e.dc, e.tc);
+            if (r.e.c) lpx_put<REC>(stage, off, r.xy, r.xyw, r.c, r.e.dc, r.e.tc);
 #endif
+        };
+        uint32_t r0 = 0u;
+#if defined(ADDER_DBG_LPX) && ADDER_DBG_LPX >= 3
+        const uint32_t R_run = R == 0x7777u ? 64u : 0u;
+#else
+        const uint32_t R_run = R;
+#endif
+#if defined(ADDER_LPX_ROUNDS2)
+        // two rounds at a time while there are two: their chains (an LDS read, three divisions, a DPP scan, the LDS stores) are
+        // independent up to the second's place in the stream -- a wave spent 39 % of its life in s_waitcnt with one at a time
+#pragma clang loop unroll(disable)
+        for (; r0 + kWave < R_run; r0 += 2u * kWave) {
+            if (fill + 6u * kWave > CAPE) flush();
+            const Round ra = decode(r0 + lane), rb2 = decode(r0 + kWave + lane);
+            const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ra.incl, kWave - 1);
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)rb2.incl, kWave - 1);
+            const uint32_t off_a = phase + (fill + ra.incl - ra.n) * REC, off_b = phase + (fill + ta + rb2.incl - rb2.n) * REC;
+            fill += ta + tb;
+            put(ra, off_a);
+            put(rb2, off_b);
+        }
+#endif
+#pragma clang loop unroll(disable)
+        for (; r0 < R_run; r0 += kWave) {
+            if (fill + 3u * kWave > CAPE) flush();
+            const Round r = decode(r0 + lane);
+            const uint32_t off = phase + (fill + r.incl - r.n) * REC;
+            fill += (uint32_t)__builtin_amdgcn_readlane((int)r.incl, kWave - 1);
+            put(r, off);
         }
         pstart = pe;
     }

@@ -627,7 +627,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("one chunk of frames: adder_lp_kernel (the lean-runs step in packed bytes: crf 0, DeltaT; adder_lr_kernel in "
-                       "AbsoluteT, adder_lean_kernel otherwise) + adder_scan_kernel + adder_offsets_kernel + adder_lpx_kernel "
+                       "AbsoluteT, adder_lean_kernel otherwise) + adder_scan_kernel (its blocks chain the frame offsets; adder_offsets_kernel for the other frame kernels) + adder_lpx_kernel "
                        "(adder_expand_kernel for the other record formats)") if lean else
                       "one chunk of frames: adder_frame_kernel + adder_scan_kernel + adder_offsets_kernel + "
                       "adder_expand_kernel",
