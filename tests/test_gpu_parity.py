@@ -842,13 +842,15 @@ def test_lake_golden_bytes_pipelined_stream(golden_dir):
         hv.stream_collect()  # nothing in flight
 
 
-def test_batch_lengths_around_chunk_and_lag_boundaries():
+@pytest.mark.parametrize("tmode", ["ABSOLUTE_T", "DELTA_T"])
+def test_batch_lengths_around_chunk_and_lag_boundaries(tmode):
     """The scratch ring holds three chunks of 64 frames and a launch steps up to 64 frames: batch lengths on
     both sides of every boundary (launch depth, chunk, ring wrap-around at 192), several submission forms, consecutive batches on one context -- always
-    the oracle's stream and frame offsets."""
+    the oracle's stream and frame offsets.  (AbsoluteT: the lean-runs kernel and the offsets kernel; DeltaT: the packed
+    kernels, whose scan chains the frame offsets itself -- several frame-kernel launches per chunk included.)"""
     import subprocess, sys
     code = r'''
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, "%s"); sys.path.insert(0, "%s/adder-codec-rs_amd"); sys.path.insert(0, "%s/tests")
 import torch
 import adder_amd as A
@@ -857,9 +859,9 @@ import clips
 W, H = 70, 23
 lens = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 257, 5]
 clip = clips.make_clip("runs", sum(lens), H, W, 1, seed=4)
-ov = O.Video(W, H, 1, time_mode=O.ABSOLUTE_T, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
+ov = O.Video(W, H, 1, time_mode=O.TMODE, multi_mode=O.COLLAPSE, ref_time=255, delta_t_max=255)
 ov.set_crf_parameters(0, 10); ov.reset_c_thresh(0)
-hv = A.HipVideo(W, H, 1, time_mode=A.TIME_ABSOLUTE_T, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
+hv = A.HipVideo(W, H, 1, time_mode=A.TIME_TMODE, multi_mode=A.MULTI_COLLAPSE, delta_t_max=255,
                 c_thresh_start=0, c_counter_start=0)
 hv.set_crf_parameters(0, 10)
 st = torch.cuda.current_stream().cuda_stream
@@ -877,8 +879,11 @@ for T in lens:
     assert n == len(want) and np.array_equal(got, want), T
     assert d_off.cpu().tolist() == np.concatenate([[0], np.cumsum([len(p) for p in per])]).tolist(), T
     assert int((d_ev[n:] != -1).sum()) == 0, T  # nothing written past the stream
+    if "TMODE" == "DELTA_T" and T > 1 and not os.environ.get("ADDER_HIP_FRAMES_PER_LAUNCH") == "1":
+        assert hv.last_batch_kernel() == A.KERNEL_LEAN_RUNS_PACKED, (T, hv.last_batch_kernel())
 print("ok")
 ''' % (ROOT, ROOT, ROOT)
+    code = code.replace("TMODE", tmode)
     for env in ({}, {"ADDER_HIP_NO_GRAPH": "1"}, {"ADDER_HIP_NO_GRAPH": "2"},
                 {"ADDER_HIP_FRAMES_PER_LAUNCH": "1"}, {"ADDER_HIP_FRAMES_PER_LAUNCH": "5"},
                 {"ADDER_HIP_CHUNK": "4", "ADDER_HIP_FRAMES_PER_LAUNCH": "4"}):
