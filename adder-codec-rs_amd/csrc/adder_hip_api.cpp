@@ -1169,7 +1169,7 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         // (scan + offsets on a third stream of their own -- they depend on the chunk's frame kernels only -- was
         // tried: they then run at once instead of behind the previous expansion, and the expansions, now back to
         // back, take as much longer as was gained: the two big kernels compete for the same thing; in-kernel
-        // timestamps, tools/timeline_probe.py)
+        // timestamps, adder_hip_debug_timeline)
         hipStream_t t = s;
         if (s2) {
             HIPCHK(c, hipEventRecord(c->cap_e1, s));
@@ -1629,7 +1629,7 @@ static int enqueue_frames(AdderHipCtx *c, const uint8_t *d_frames, uint32_t num_
     b.chunk = c->chunk;
     b.rec_total = c->d_rec_total;
     b.timeline = nullptr;
-    if (getenv("ADDER_HIP_TIMELINE")) {  // diagnostics (tools/timeline_probe.py)
+    if (getenv("ADDER_HIP_TIMELINE")) {  // diagnostics (adder_hip_debug_timeline)
         if (!c->d_timeline) HIPCHK(c, dalloc(&c->d_timeline, 4 * kTimelineChunks * 2));
         std::vector<unsigned long long> init(4 * kTimelineChunks * 2);
         for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? 0ull : ~0ull;
