@@ -1178,9 +1178,13 @@ static int launch_frame_loop(AdderHipCtx *c, uint32_t num_frames, uint32_t varia
         }
         if (timing) HIPCHK(c, hipEventRecord(c->post_events[2 * c->timed_posts], t));
         // (a lean-runs batch that hands its records out: the scan also leaves the segments' record prefix, for the packing)
-        // (packed lean-runs batches: the scan's blocks chain the frame offsets themselves, adder_scan_kernel CHAIN -- a launch less)
+        // (the integer-state kernels' and the bounded Collapse kernel's batches: the scan's blocks chain the frame offsets
+        // themselves, adder_scan_kernel CHAIN -- a launch less per chunk; those frame kernels zero the entries, chain_zero)
         static const bool no_chain = env_flag("ADDER_HIP_NO_SCAN_CHAIN");
-        const bool chain = (variant & 4096u) != 0u && num_frames != 1u && !c->records_only && !no_chain;
+        // (adder_launch_frame's order: Continuous, run records, constant runs, bounded Collapse, generic, packed / plain lean runs)
+        const bool chain_kernel = (variant & 8u) == 0u && ((variant & (512u | 128u | 32u)) != 0u ||
+                                                           ((variant & 4u) == 0u && (variant & (4096u | 256u)) != 0u));
+        const bool chain = chain_kernel && num_frames != 1u && !c->records_only && !no_chain;
         HIPCHK(c, adder_launch_scan(c->d_batch, f0, nf, c->num_waves, t, num_frames == 1u ? 1u : 0u,
                                     (c->records_only && (variant & 256u)) ? 1u : 0u, chain ? 1u : 0u));
         if (num_frames != 1u && !chain) HIPCHK(c, adder_launch_offsets(c->d_batch, f0, nf, t));  // (one frame: done by the scan)

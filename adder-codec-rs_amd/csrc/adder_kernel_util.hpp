@@ -184,4 +184,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
 }
 
 
+// CHAIN (adder_scan_kernel): a frame kernel whose batches chain their frame offsets in the scan zeroes the entries of its
+// launch's frames first -- the scan's blocks ADD the chain to them.  Atomics: no line of the table sits dirty in this XCD's L2
+// while another XCD adds to it.  nb <= 64 frames per launch.
+__device__ __forceinline__ void chain_zero(const BatchArgs *__restrict__ b, uint32_t f, uint32_t nb) {
+    if (blockIdx.x != 0u || threadIdx.x >= kWave) return;
+    unsigned long long *const offs = reinterpret_cast<unsigned long long *>(b->base.frame_offsets);
+    if (threadIdx.x < nb) (void)__hip_atomic_exchange(&offs[f + threadIdx.x + 1u], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f == 0u && threadIdx.x == kWave - 1u) {
+        (void)__hip_atomic_exchange(&offs[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b->rec_total)
+            (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(b->rec_total), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace adder

@@ -861,6 +861,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LR_WAVES_PER_SIMD) void adder_
     __shared__ __attribute__((aligned(16))) uint8_t s_in[kWavesPerBlock][kLrInFrames * kWaveUnits];
     __shared__ __attribute__((aligned(16))) uint8_t s_base[kWavesPerBlock][kWaveUnits];  // the units' base_vals as a frame row (quiet groups)
     timeline_mark(b, 0u, f, false);
+    chain_zero(b, f, nb);  // (adder_scan_kernel CHAIN)
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
@@ -1728,6 +1729,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CB_WAVES_PER_SIMD) void adder_
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     timeline_mark(b, 0u, f, false);
+    chain_zero(b, f, nb);  // (adder_scan_kernel CHAIN)
     // (a capped grid walks the segments, like the lean kernel; the wave's LDS slice is its own, no barrier needed)
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
@@ -1918,6 +1920,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_CR_WAVES_PER_SIMD) void adder_
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     timeline_mark(b, 0u, f, false);
+    chain_zero(b, f, nb);  // (adder_scan_kernel CHAIN)
     for (uint32_t gw = blockIdx.x * kWavesPerBlock + tid / kWave; gw < a.num_waves; gw += gridDim.x * kWavesPerBlock) {
         const uint32_t u0 = gw * kWaveUnits + lane * kUnitsPerLane;
         const bool full = __builtin_amdgcn_readfirstlane(gw * kWaveUnits + kWaveUnits <= a.n_units);
@@ -2123,6 +2126,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_RR_WAVES_PER_SIMD) void adder_
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     timeline_mark(b, 0u, f, false);
+    chain_zero(b, f, nb);  // (adder_scan_kernel CHAIN)
     {   // the table of chain lengths (8 KB, the same for every launch: it comes out of L2)
         const uint4 *const src = reinterpret_cast<const uint4 *>(b->rr_tab);
         uint4 *const dst = reinterpret_cast<uint4 *>(s_tab);

@@ -351,17 +351,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
     __shared__ __attribute__((aligned(8))) uint32_t s_tot[kWavesPerBlock][2u * kMaxFramesPerLaunch];
     __shared__ uint32_t s_rec[kWavesPerBlock][2u * kLpPairUnits];  // a frame's records of the pair in order, then its escape words
     timeline_mark(b, 0u, f, false);
-    // the frame_offsets entries of this launch's frames start at zero: the scan's blocks ADD the chain to them
-    // (adder_scan_kernel CHAIN; atomics -- no line of the table sits dirty in this XCD's L2 while they do)
-    if (blockIdx.x == 0u && tid < kWave) {
-        unsigned long long *const offs = reinterpret_cast<unsigned long long *>(b->base.frame_offsets);
-        if (tid < nb) (void)__hip_atomic_exchange(&offs[f + tid + 1u], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f == 0u && tid == kWave - 1u) {
-            (void)__hip_atomic_exchange(&offs[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (b->rec_total)
-                (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(b->rec_total), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    chain_zero(b, f, nb);  // (the scan chains the frame offsets of these batches: adder_scan_kernel CHAIN)
     const uint32_t num_pairs = a.num_waves / 2u;  // (num_waves is a multiple of kExpandSegs)
     for (uint32_t pw = blockIdx.x * kWavesPerBlock + tid / kWave; pw < num_pairs; pw += gridDim.x * kWavesPerBlock) {
         const bool full = __builtin_amdgcn_readfirstlane(pw * kLpPairUnits + kLpPairUnits <= a.n_units);
