@@ -2093,6 +2093,13 @@ extern "C" int adder_hip_finish(AdderHipCtx *c, size_t *n_out) {
                     "retry with a larger buffer)", (unsigned long long)total);
     }
     c->snap.valid = false;
+    // (a total beyond the caller's buffer with no capacity status cannot come out of a sound batch: refuse it here rather
+    // than hand the caller a count it would copy by)
+    if (st == 0u && total > (uint64_t)c->pending_cap) {
+        c->poisoned = true;
+        return fail(c, ADDER_E_HIP, "the batch reports %llu events for a buffer of %llu without a capacity status (frame offsets damaged)",
+                    (unsigned long long)total, (unsigned long long)c->pending_cap);
+    }
     const int rc_st = status_to_code(c, st);
     if (rc_st != ADDER_OK) c->band_frame_pending = false;  // (no feature step follows a failed frame)
     return rc_st;
