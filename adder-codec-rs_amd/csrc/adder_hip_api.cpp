@@ -1291,7 +1291,7 @@ static void graph_tune_report(AdderHipCtx *c, float ms) {
     if (g.last < 0 || g.chosen >= 0) return;
     g.runs[g.last] += 1;
     if (g.runs[g.last] > 1 || kTuneRunsPerCandidate == 1) g.ms[g.last] = std::min(g.ms[g.last], ms);
-    const uint32_t want = (c->pending_frames > c->chunk && !((c->tune_key >> 32) & 4u)) ? std::max(1u, c->graph_candidates) : 1u;
+    const uint32_t want = (c->pending_frames > c->chunk && !((c->tune_key >> 24) & 4u)) ? std::max(1u, c->graph_candidates) : 1u;  // (get_graph's: variant bit 2 = generic)
     const bool all_ran = g.cand.size() >= want && g.runs.back() >= kTuneRunsPerCandidate;
     if (all_ran && g.cand.size() > 1 && g.last == 0 && g.runs[0] > kTuneRunsPerCandidate) g.recheck += 1;
     if (all_ran && (g.cand.size() == 1 || g.recheck >= kTuneRecheckRuns)) {
