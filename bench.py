@@ -647,6 +647,11 @@ def main():
                 "same time with E = the record's bytes" if wire_out else ""),
             "frac_at_record_bytes": (round((alg_b - (12 - (9 if Cn == 1 else 11)) * e0) * units * chunk_frames / (chunk_us * 1e-6) / 1e9
                                            / HBM_PEAK_GBS, 4) if wire_out and chunk_us > 0 else None),
+            # the same algorithmic bytes over the STEP's wall time (the timed region of `value`): the tuned graph may run chunk
+            # k + 1's frame kernel beside chunk k's scan and expansion, so a step can be shorter than its kernels' eager sum
+            "step_wall_frac": round(alg_b * units * T / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if world == 1 else None,
+            "step_wall_frac_at_record_bytes": (round((alg_b - (12 - (9 if Cn == 1 else 11)) * e0) * units * T / (ms_per_step * 1e-3) / 1e9
+                                                     / HBM_PEAK_GBS, 4) if wire_out and world == 1 else None),
             "frames_per_launch": k1_frames,
             "frames_per_chunk": chunk_frames,
             "units_per_chunk": int(units * chunk_frames),
