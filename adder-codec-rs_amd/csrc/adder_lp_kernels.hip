@@ -371,9 +371,9 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 //      DPP scan of the records' event counts places the events, and every event is written into the staging buffer in its
 //      FINAL bytes -- REC = 9 / 11: the raw sink's record (RawOutput::ingest_event, raw/stream.rs:101-120: bincode fixint
 //      big-endian {x u16, y u16, [0x01, c,] d u8, t u32}) at whatever byte it falls on; REC = 12: the AdderEvent.  (An LDS
-//      store that is not naturally aligned costs fifteen aligned ones -- tools/ubench/lds_writes.hip -- and is still the
-//      cheaper form here: the kernel is bound by the instructions it issues, and three aligned dwords per event + a packing
-//      pass of byte permutes measured 154-159 us per launch against 138-147.)
+//      store that is not naturally aligned costs fifteen to twenty-three aligned ones -- tools/ubench/lds_writes.hip --, so a
+//      9-byte record goes in as nine byte stores, an 11-byte one as an 8-byte store at any address + 2 + 1 bytes; three
+//      aligned dwords per event + a packing pass of byte permutes measured 154-159 us per launch against 138-147.)
 //   3. the staging buffer sits at the 16-byte phase of its destination, so a flush is 16-byte LDS reads -> 16-byte global
 //      stores, a kilobyte per instruction, and single bytes for the <= 15 + 15 bytes the wave shares with its neighbours' blocks.
 // One copy of every loop: a sixth of adder_expand_kernel<5>'s code.
@@ -424,7 +424,8 @@ __device__ __forceinline__ void lpx_put(ADDER_LDS uint8_t *stage, uint32_t off, 
     } else {
         const uint32_t tb = __builtin_amdgcn_perm(0u, t, 0x00010203u);  // t3 t2 t1 t0
         if constexpr (REC == 9u) {
-#if defined(ADDER_LPX_BYTE_STAGE)  // (A/B build: nine byte stores -- none misaligned -- instead of an 8-byte store at any address + a byte)
+#if !defined(ADDER_LPX_WIDE_STAGE)  // nine byte stores -- none misaligned: 9 x 26 ns per wave-instruction per CU -- instead of an 8-byte store at
+            // any address + a byte (400-600 + 26 ns, tools/ubench/lds_writes.hip): 1 % of the step, eager or overlapped (-DADDER_LPX_WIDE_STAGE: the old form)
             const uint32_t addr = (uint32_t)(uintptr_t)(stage + off);
             asm volatile("ds_write_b8 %0, %1\n\t"
                          "ds_write_b8_d16_hi %0, %1 offset:2\n\t"
