@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlockThreads, ADDER_LP_WAVES_PER_SIMD) void adder_
 //      FINAL bytes -- REC = 9 / 11: the raw sink's record (RawOutput::ingest_event, raw/stream.rs:101-120: bincode fixint
 //      big-endian {x u16, y u16, [0x01, c,] d u8, t u32}) at whatever byte it falls on; REC = 12: the AdderEvent.  (An LDS
 //      store that is not naturally aligned costs fifteen to twenty-three aligned ones -- tools/ubench/lds_writes.hip --, so a
-//      9-byte record goes in as nine byte stores, an 11-byte one as an 8-byte store at any address + 2 + 1 bytes; three
+//      9-byte record goes in as nine byte stores, an 11-byte one as eleven; three
 //      aligned dwords per event + a packing pass of byte permutes measured 154-159 us per launch against 138-147.)
 //   3. the staging buffer sits at the 16-byte phase of its destination, so a flush is 16-byte LDS reads -> 16-byte global
 //      stores, a kilobyte per instruction, and single bytes for the <= 15 + 15 bytes the wave shares with its neighbours' blocks.
@@ -444,9 +444,27 @@ __device__ __forceinline__ void lpx_put(ADDER_LDS uint8_t *stage, uint32_t off, 
             stage[off + 8u] = (uint8_t)(tb >> 24);
 #endif
         } else {
+#if !defined(ADDER_LPX_WIDE_STAGE)  // (eleven byte stores, like the nine above)
+            const uint32_t addr = (uint32_t)(uintptr_t)(stage + off), w1 = 1u | (c << 8) | (d << 16);
+            asm volatile("ds_write_b8 %0, %1\n\t"
+                         "ds_write_b8_d16_hi %0, %1 offset:2\n\t"
+                         "ds_write_b8 %0, %2 offset:1\n\t"
+                         "ds_write_b8_d16_hi %0, %2 offset:3\n\t"
+                         "ds_write_b8 %0, %3 offset:4\n\t"
+                         "ds_write_b8_d16_hi %0, %3 offset:6\n\t"
+                         "ds_write_b8 %0, %4 offset:5\n\t"
+                         "ds_write_b8 %0, %5 offset:7\n\t"
+                         "ds_write_b8_d16_hi %0, %5 offset:9\n\t"
+                         "ds_write_b8 %0, %6 offset:8\n\t"
+                         "ds_write_b8_d16_hi %0, %6 offset:10"
+                         :
+                         : "v"(addr), "v"(xyw), "v"(xyw >> 8), "v"(w1), "v"(w1 >> 8), "v"(tb), "v"(tb >> 8)
+                         : "memory");
+#else
             *reinterpret_cast<ADDER_LDS lpx_u64_any *>(stage + off) = (uint64_t)xyw | ((uint64_t)(1u | (c << 8) | (d << 16) | (tb << 24)) << 32);
             *reinterpret_cast<ADDER_LDS lpx_u16_any *>(stage + off + 8u) = (uint16_t)(tb >> 8);
             stage[off + 10u] = (uint8_t)(tb >> 24);
+#endif
         }
     }
 }
