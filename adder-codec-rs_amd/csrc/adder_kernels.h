@@ -20,10 +20,10 @@ constexpr uint32_t kBlockThreads = 256;
 #define ADDER_LEAN1_WIDE 1  // one frame per launch: the 4-units-per-lane kernel (16-byte accesses)
 #endif
 #ifndef ADDER_SCAN_THREADS
-#define ADDER_SCAN_THREADS 512
+#define ADDER_SCAN_THREADS 256
 #endif
 #ifndef ADDER_SCAN_TILE_WAVES
-#define ADDER_SCAN_TILE_WAVES 16384  // segments one scan workgroup takes (8 uint4 groups per thread: from registers)
+#define ADDER_SCAN_TILE_WAVES 16384  // segments one scan workgroup takes (16 uint4 groups per thread: from registers)
 #endif
 #ifndef ADDER_LEAN_WAVES_PER_SIMD
 #define ADDER_LEAN_WAVES_PER_SIMD 8

@@ -2225,13 +2225,14 @@ __global__ __launch_bounds__(kBlockThreads) void adder_cont_kernel(const BatchAr
 // Scan: exclusive prefix of the per-segment event counts of one frame per block
 // (blockIdx.x = frame inside the chunk) and the frame's total.
 // ------------------------------------------------------------------------------------------
-// 512 threads: in the pipelined graph this kernel starts beside the resident frame kernel of the next chunk (5
+// 256 threads: in the pipelined graph this kernel starts beside the resident frame kernel of the next chunk (5
 // waves per SIMD), and a 1024-thread block needs 4 free wave slots on EVERY SIMD of one CU: it queued for 32 us
-// where it runs 8.  A thread owns `per` consecutive uint4 groups; up to kScanRegGroups of them are fetched in one
+// where it runs 8 (round 6, with the scan + expansion branch the step's critical path: 1024 / 512 / 256 / 128 threads =
+// 0.915 / 0.908 / 0.900 / 0.92 ms per headline step).  A thread owns `per` consecutive uint4 groups; up to kScanRegGroups of them are fetched in one
 // go and kept in registers for both passes.
 constexpr uint32_t kScanThreads = ADDER_SCAN_THREADS;
 #ifndef ADDER_SCAN_REG_GROUPS
-#define ADDER_SCAN_REG_GROUPS 8
+#define ADDER_SCAN_REG_GROUPS 16
 #endif
 constexpr uint32_t kScanRegGroups = ADDER_SCAN_REG_GROUPS;
 __device__ __forceinline__ uint32_t scan_lo4(const uint4 &v) {
